@@ -1,0 +1,419 @@
+"""numpy restatement of the reference's host-side hot-path functions.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Each function cites the reference
+lines (relative to /root/reference/src/openea/) it follows.  Heavy loops are delegated to
+oracle/c/oracle.c through oracle.cport.
+"""
+import math
+
+import numpy as np
+
+from . import cport
+
+# ----------------------------------------------------------------------------------------
+# modules/utils/util.py
+# ----------------------------------------------------------------------------------------
+
+
+def task_divide(idx, n):
+    """util.py:16-30."""
+    total = len(idx)
+    if n <= 0 or 0 == total:
+        return [idx]
+    if n > total:
+        return [idx]
+    elif n == total:
+        return [[i] for i in idx]
+    j = total // n
+    tasks = [idx[i:i + j] for i in range(0, (n - 1) * j, j)]
+    tasks.append(idx[(n - 1) * j:])
+    return tasks
+
+
+# ----------------------------------------------------------------------------------------
+# modules/train/batch.py -- positive batching
+# ----------------------------------------------------------------------------------------
+
+
+def generate_pos_triples(triples, batch_size, step, is_fixed_size=False):
+    """batch.py:48-57."""
+    start = step * batch_size
+    end = min(start + batch_size, len(triples))
+    pos_batch = triples[start:end]
+    if is_fixed_size and len(pos_batch) < batch_size:
+        pos_batch = pos_batch + triples[:batch_size - len(pos_batch)]
+    return pos_batch
+
+
+def batch_sizes(n1, n2, batch_size):
+    """batch.py:18-19 / 39-40: b1 = int(n1/(n1+n2)*B), b2 = B - b1 (python float arithmetic)."""
+    b1 = int(n1 / (n1 + n2) * batch_size)
+    return b1, batch_size - b1
+
+
+def generate_pos_batch(triple_list1, triple_list2, batch_size, step):
+    """batch.py:17-22."""
+    b1, b2 = batch_sizes(len(triple_list1), len(triple_list2), batch_size)
+    return generate_pos_triples(triple_list1, b1, step) + generate_pos_triples(triple_list2, b2, step)
+
+
+# ----------------------------------------------------------------------------------------
+# modules/train/batch.py -- neighbour search
+# ----------------------------------------------------------------------------------------
+
+
+def find_neighbours(frags, entity_list, sub_embed, embed, k):
+    """batch.py:157-165.  Returns {entity -> sorted list of k neighbour entity ids}.
+
+    The reference returns an UNORDERED k-set per entity (argpartition); ties at the k-th
+    value are arbitrary there.  Restatement: (value desc, column asc) selection, listed in
+    ascending column order."""
+    entity_list = np.asarray(entity_list)
+    idx = cport.topk_inner(sub_embed, embed, k)
+    return {frags[i]: entity_list[idx[i]].tolist() for i in range(len(frags))}
+
+
+def generate_neighbours(entity_embeds, entity_list, neighbors_num, threads_num):
+    """batch.py:122-154 (both variants return the same dict)."""
+    ent_frags = task_divide(np.array(entity_list), threads_num)
+    ent_frag_indexes = task_divide(np.array(range(len(entity_list))), threads_num)
+    dic = dict()
+    for i in range(len(ent_frags)):
+        dic.update(find_neighbours(ent_frags[i], np.array(entity_list),
+                                   entity_embeds[ent_frag_indexes[i], :], entity_embeds,
+                                   neighbors_num))
+    return dic
+
+
+# ----------------------------------------------------------------------------------------
+# modules/finding/similarity.py
+# ----------------------------------------------------------------------------------------
+
+
+def normalize_rows(x):
+    """sklearn.preprocessing.normalize (similarity.py:32-33)."""
+    return cport.l2_normalize_rows(x)
+
+
+def sim(embed1, embed2, metric='inner', normalize=False, csls_k=0):
+    """similarity.py:11-54."""
+    if normalize:
+        embed1, embed2 = normalize_rows(embed1), normalize_rows(embed2)
+    if metric == 'inner' or (metric == 'cosine' and normalize):
+        sim_mat = cport.sim_matrix(embed1, embed2, 'inner')
+    elif metric == 'euclidean':
+        sim_mat = cport.sim_matrix(embed1, embed2, 'euclidean')
+    elif metric == 'cosine':
+        # 1 - cdist(cosine) == cosine similarity of the rows (similarity.py:42-44)
+        sim_mat = cport.sim_matrix(normalize_rows(embed1), normalize_rows(embed2), 'inner')
+    elif metric == 'manhattan':
+        sim_mat = cport.sim_matrix(embed1, embed2, 'manhattan')
+    else:
+        raise ValueError(metric)
+    if csls_k > 0:
+        sim_mat = csls_sim(sim_mat, csls_k)
+    return sim_mat
+
+
+def calculate_nearest_k(sim_mat, k):
+    """similarity.py:80-83 (mean of the k largest per row)."""
+    return cport.topk_mean(sim_mat, k, axis=1)
+
+
+def csls_sim(sim_mat, k):
+    """similarity.py:57-77."""
+    r = cport.topk_mean(sim_mat, k, axis=1)
+    c = cport.topk_mean(sim_mat, k, axis=0)
+    return cport.csls_apply(sim_mat, r, c)
+
+
+# ----------------------------------------------------------------------------------------
+# modules/finding/alignment.py + evaluation.py
+# ----------------------------------------------------------------------------------------
+
+
+def metrics_from_ranks(rank, top_k, total_num):
+    """alignment.py:163-168 + 65-67: hits counts, hits %, MR, MRR from 0-based ranks."""
+    rank = np.asarray(rank, np.int64)
+    hits_cnt = [int((rank < k).sum()) for k in top_k]
+    mr = float((rank + 1).sum()) / total_num
+    mrr = float((1.0 / (rank + 1)).sum()) / total_num
+    hits = np.array(hits_cnt) / total_num * 100
+    hits = np.array([round(h, 3) for h in hits])
+    return hits_cnt, hits, mr, mrr
+
+
+def calculate_rank(idx, sim_mat, top_k, accurate, total_num):
+    """alignment.py:146-168 (accurate semantics; stable tie rule, see oracle.c)."""
+    assert 1 in top_k
+    rank, argmax = _rank_rows(idx, sim_mat)
+    hits_cnt, _, _, _ = metrics_from_ranks(rank, top_k, total_num)
+    mr = float((rank.astype(np.int64) + 1).sum()) / total_num
+    mrr = float((1.0 / (rank.astype(np.int64) + 1)).sum()) / total_num
+    hits1_rest = {(int(idx[i]), int(argmax[i])) for i in range(len(idx))}
+    return mr, mrr, hits_cnt, hits1_rest
+
+
+def _rank_rows(idx, sim_rows):
+    sim_rows = np.ascontiguousarray(sim_rows, np.float32)
+    idx = np.asarray(idx)
+    n, n2 = sim_rows.shape
+    rank = np.empty(n, np.int32)
+    argmax = np.empty(n, np.int32)
+    for i in range(n):
+        row = sim_rows[i]
+        g = row[idx[i]]
+        rank[i] = int((row > g).sum() + (row[:idx[i]] == g).sum())
+        argmax[i] = int(np.argmax(row))  # first maximum
+    return rank, argmax
+
+
+def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
+    """alignment.py:13-84.  Returns (alignment_rest, hits1, mr, mrr) like the reference and
+    keeps the raw integer results in greedy_alignment.last for bit-exact comparisons."""
+    sim_mat = sim(embed1, embed2, metric=metric, normalize=normalize, csls_k=csls_k)
+    num = sim_mat.shape[0]
+    rank, argmax = cport.rank_from_matrix(sim_mat)
+    hits_cnt, hits, mr, mrr = metrics_from_ranks(rank, top_k, num)
+    alignment_rest = {(i, int(argmax[i])) for i in range(num)}
+    assert len(alignment_rest) == num
+    greedy_alignment.last = dict(rank=rank, argmax=argmax, hits_cnt=hits_cnt)
+    return alignment_rest, hits[0], mr, mrr
+
+
+def valid(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False,
+          csls_k=0, accurate=False):
+    """evaluation.py:6-14."""
+    if mapping is not None:
+        embeds1 = np.matmul(embeds1, mapping)
+    _, hits1_12, mr_12, mrr_12 = greedy_alignment(embeds1, embeds2, top_k, threads_num, metric,
+                                                  normalize, csls_k, accurate)
+    return hits1_12, mrr_12
+
+
+def test(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False,
+         csls_k=0, accurate=True):
+    """evaluation.py:17-25."""
+    if mapping is not None:
+        embeds1 = np.matmul(embeds1, mapping)
+    rest, hits1_12, mr_12, mrr_12 = greedy_alignment(embeds1, embeds2, top_k, threads_num, metric,
+                                                     normalize, csls_k, accurate)
+    return rest, hits1_12, mrr_12
+
+
+def early_stop(flag1, flag2, flag):
+    """evaluation.py:28-33."""
+    if flag <= flag2 <= flag1:
+        return flag2, flag, True
+    return flag2, flag, False
+
+
+# ----------------------------------------------------------------------------------------
+# TF1 graph pieces (PARITY UNPINNED -- restatements of TF1 semantics)
+# ----------------------------------------------------------------------------------------
+
+
+def l2_normalize(x, eps=1e-12):
+    """tf.nn.l2_normalize(x, 1): x * rsqrt(max(sum(x^2, 1), eps)) (initializers.py:26)."""
+    x = np.asarray(x)
+    ss = np.maximum((x.astype(np.float64) ** 2).sum(1, keepdims=True), eps)
+    return (x / np.sqrt(ss)).astype(x.dtype)
+
+
+def truncated_normal(rng, shape, stddev):
+    """tf.truncated_normal: N(0, stddev) re-drawn outside 2 sigma."""
+    out = rng.standard_normal(shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * stddev).astype(np.float32)
+
+
+def triple_step(ent, ent_acc, rel, rel_acc, pos, neg, **cfg):
+    """One optimiser step of the translational graph (see oracle.c:oracle_triple_step)."""
+    return cport.triple_step(ent, ent_acc, rel, rel_acc, pos, neg, **cfg)
+
+
+def mapping_step(ent, mapping, acc_ent, acc_map, links, alpha, lr, ent_l2_norm=True):
+    """MTransE mapping step (mapping.py:9-19, losses.py:76-80) with Adagrad on BOTH the
+    entity table and M (generate_optimizer without var_list, optimizers.py:4-7).
+    loss = alpha * (sum ||e2 - e1 M||^2 + sum (M M^T - I)^2).  fp64 internals."""
+    links = np.asarray(links, np.int64).reshape(-1, 2)
+    d = ent.shape[1]
+    v = ent.astype(np.float64)
+    M = mapping.astype(np.float64)
+    ss = np.maximum((v ** 2).sum(1, keepdims=True), 1e-12)
+    inv = 1.0 / np.sqrt(ss) if ent_l2_norm else np.ones_like(ss)
+    y = v * inv
+    e1, e2 = y[links[:, 0]], y[links[:, 1]]
+    diff = e2 - e1 @ M
+    orth = M @ M.T - np.eye(d)
+    loss = alpha * ((diff ** 2).sum() + (orth ** 2).sum())
+    g_e2 = alpha * 2.0 * diff
+    g_e1 = -alpha * 2.0 * diff @ M.T
+    g_M = alpha * (-2.0 * e1.T @ diff + 4.0 * orth @ M)
+    gy = np.zeros_like(v)
+    np.add.at(gy, links[:, 0], g_e1)
+    np.add.at(gy, links[:, 1], g_e2)
+    touched = np.zeros(len(v), bool)
+    touched[links.ravel()] = True
+    if ent_l2_norm:
+        gv = (gy - y * (y * gy).sum(1, keepdims=True)) * inv
+    else:
+        gv = gy
+    a = acc_ent.astype(np.float64)
+    a[touched] += gv[touched] ** 2
+    v[touched] -= lr * gv[touched] / np.sqrt(a[touched])
+    am = acc_map.astype(np.float64) + g_M ** 2
+    M -= lr * g_M / np.sqrt(am)
+    ent[...] = v.astype(np.float32)
+    acc_ent[...] = a.astype(np.float32)
+    mapping[...] = M.astype(np.float32)
+    acc_map[...] = am.astype(np.float32)
+    return float(loss)
+
+
+# ----------------------------------------------------------------------------------------
+# GCN-Align (approaches/gcn_align.py)
+# ----------------------------------------------------------------------------------------
+
+
+def gcn_func(triples):
+    """gcn_align.py:610-624: r2f[r] = #distinct heads / #triples."""
+    head, cnt = {}, {}
+    for h, r, t in triples:
+        cnt[r] = cnt.get(r, 0) + 1
+        head.setdefault(r, set()).add(h)
+    return {r: len(head[r]) / cnt[r] for r in cnt}
+
+
+def gcn_ifunc(triples):
+    """gcn_align.py:626-640: r2if[r] = #distinct tails / #triples."""
+    tail, cnt = {}, {}
+    for h, r, t in triples:
+        cnt[r] = cnt.get(r, 0) + 1
+        tail.setdefault(r, set()).add(t)
+    return {r: len(tail[r]) / cnt[r] for r in cnt}
+
+
+def gcn_weighted_adj(e, triples):
+    """gcn_align.py:642-664 -> scipy COO with row = second key, col = first key."""
+    import scipy.sparse as sp
+    r2f, r2if = gcn_func(triples), gcn_ifunc(triples)
+    M = {}
+    for h, r, t in triples:
+        if h == t:
+            continue
+        M[(h, t)] = M.get((h, t), 0.0) + max(r2if[r], 0.3)
+        M[(t, h)] = M.get((t, h), 0.0) + max(r2f[r], 0.3)
+    row = [key[1] for key in M]
+    col = [key[0] for key in M]
+    data = [M[key] for key in M]
+    return sp.coo_matrix((data, (row, col)), shape=(e, e))
+
+
+def gcn_normalize_adj(adj):
+    """gcn_align.py:566-573 (note: adj.dot(D).transpose().dot(D))."""
+    import scipy.sparse as sp
+    adj = sp.coo_matrix(adj)
+    rowsum = np.array(adj.sum(1))
+    with np.errstate(divide='ignore'):
+        d_inv_sqrt = np.power(rowsum, -0.5).flatten()
+    d_inv_sqrt[np.isinf(d_inv_sqrt)] = 0.
+    d_mat_inv_sqrt = sp.diags(d_inv_sqrt)
+    return adj.dot(d_mat_inv_sqrt).transpose().dot(d_mat_inv_sqrt).tocoo()
+
+
+def gcn_preprocess_adj(adj):
+    """gcn_align.py:575-578 -> (coords[nnz,2], values, shape)."""
+    import scipy.sparse as sp
+    a = gcn_normalize_adj(adj + sp.eye(adj.shape[0]))
+    coords = np.vstack((a.row, a.col)).transpose()
+    return coords, a.data, a.shape
+
+
+def spmm(coords, values, x, n_rows):
+    """tf.sparse_tensor_dense_matmul(A, X), fp32 (gcn_align.py:83)."""
+    return cport.spmm_coo(coords[:, 0], coords[:, 1], values, x, n_rows)
+
+
+def align_loss_and_grad(out, ILL, gamma, k, neg_left, neg_right, neg2_left, neg2_right):
+    """gcn_align.py:298-320: L1 hinge over t seed links x k negatives, both sides,
+    / (2 k t).  Returns (loss, d loss / d out) in fp64."""
+    out = out.astype(np.float64)
+    ILL = np.asarray(ILL, np.int64)
+    t = len(ILL)
+    left, right = ILL[:, 0], ILL[:, 1]
+    dpos = out[left] - out[right]
+    A = np.abs(dpos).sum(1)
+    D = A + gamma
+    g = np.zeros_like(out)
+    loss = 0.0
+    for nl, nr in ((neg_left, neg_right), (neg2_left, neg2_right)):
+        nl = np.asarray(nl, np.int64)
+        nr = np.asarray(nr, np.int64)
+        dneg = out[nl] - out[nr]
+        B = np.abs(dneg).sum(1)
+        L = D[:, None] - B.reshape(t, k)
+        mask = L > 0
+        loss += L[mask].sum()
+        # d/dA: +mask summed over k ; d/dB: -mask
+        ca = mask.sum(1).astype(np.float64)
+        sp_ = np.sign(dpos) * ca[:, None]
+        np.add.at(g, left, sp_)
+        np.add.at(g, right, -sp_)
+        sn = -np.sign(dneg) * mask.reshape(-1)[:, None]
+        np.add.at(g, nl, sn)
+        np.add.at(g, nr, -sn)
+    scale = 1.0 / (2.0 * k * t)
+    return loss * scale, g * scale
+
+
+def gcn_se_epoch(W, coords, values, ILL, gamma, k, negs, lr):
+    """One full-batch SGD epoch of the GCN-Align structure model (gcn_align.py:498-539,
+    204-267, 737-785): T = l2_normalize(W) (trunc_normal returns the normalised tensor,
+    gcn_align.py:52-56); H1 = relu(A T); out = A H1; loss = align_loss; W -= lr * dW.
+    fp64 internals; returns (loss, out_before_update fp32)."""
+    n = W.shape[0]
+    Wd = W.astype(np.float64)
+    ss = np.maximum((Wd ** 2).sum(1, keepdims=True), 1e-12)
+    inv = 1.0 / np.sqrt(ss)
+    T = Wd * inv
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.asarray(values, np.float32).astype(np.float64),
+                       (coords[:, 0], coords[:, 1])), shape=(n, n))
+    pre1 = A @ T
+    H1 = np.maximum(pre1, 0.0)
+    out = A @ H1
+    loss, g_out = align_loss_and_grad(out, ILL, gamma, k, *negs)
+    g_H1 = A.T @ g_out
+    g_pre1 = g_H1 * (pre1 > 0)
+    g_T = A.T @ g_pre1
+    g_W = (g_T - T * (T * g_T).sum(1, keepdims=True)) * inv
+    W[...] = (Wd - lr * g_W).astype(np.float32)
+    return float(loss), out.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+# Sparse attention pieces (alinet.py:656-677, rdgcn.py:202-215) -- PARITY UNPINNED (H3)
+# ----------------------------------------------------------------------------------------
+
+
+def segment_softmax(logits, seg_offsets):
+    """softmax within each segment [seg_offsets[s], seg_offsets[s+1]) (tf.sparse_softmax
+    groups by the leading index; which entries form a group is DATA here, see H3)."""
+    out = np.empty_like(logits, dtype=np.float64)
+    lg = logits.astype(np.float64)
+    for s in range(len(seg_offsets) - 1):
+        a, b = seg_offsets[s], seg_offsets[s + 1]
+        if b > a:
+            m = lg[a:b].max()
+            e = np.exp(lg[a:b] - m)
+            out[a:b] = e / e.sum()
+    return out
+
+
+def leaky_relu(x, alpha=0.2):
+    """tf.nn.leaky_relu default alpha = 0.2."""
+    return np.where(x > 0, x, alpha * x)

@@ -1,0 +1,111 @@
+"""Pin the oracle against the reference's own numpy functions (fixtures made by
+tests/golden/make_golden.py, which imports the reference in place)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cport, np_oracle as orc
+
+TOP_K = [1, 5, 10, 50]
+CASES = [('inner', False), ('inner', True), ('cosine', True), ('cosine', False),
+         ('euclidean', False), ('manhattan', False)]
+
+
+@pytest.fixture(scope="module")
+def ali(golden_dir):
+    return np.load(os.path.join(golden_dir, "alignment.npz"))
+
+
+@pytest.mark.parametrize("metric,normalize", CASES)
+@pytest.mark.parametrize("csls", [0, 10])
+def test_greedy_alignment_matches_reference(ali, metric, normalize, csls):
+    key = '%s_%d_%d' % (metric, int(normalize), csls)
+    e1, e2 = ali['e1'], ali['e2']
+    s = orc.sim(e1, e2, metric=metric, normalize=normalize, csls_k=csls)
+    ref_rows = ali['sim_' + key]
+    if metric == 'manhattan' and csls == 0:
+        # fp64 sequential restatement of scipy cdist: bit-exact
+        assert np.array_equal(s[:len(ref_rows)], ref_rows)
+    else:
+        np.testing.assert_allclose(s[:len(ref_rows)], ref_rows, rtol=0, atol=3e-6)
+    rest, hits1, mr, mrr = orc.greedy_alignment(e1, e2, TOP_K, 1, metric, normalize, csls, True)
+    last = orc.greedy_alignment.last
+    ref_rank = ali['rank_' + key]
+    # integer results: identical except where the reference's own fp32 summation order
+    # produces a near-tie; the fixture was chosen so there are none.
+    assert np.array_equal(last['rank'], ref_rank)
+    assert np.array_equal(last['argmax'], ali['argmax_' + key])
+    ref_hits1, ref_mr, ref_mrr = ali['stats_' + key]
+    assert hits1 == ref_hits1
+    assert abs(mr - ref_mr) < 1e-9 and abs(mrr - ref_mrr) < 1e-9
+    assert ali['hits1_quick_' + key][0] == ref_hits1  # quick mode agrees on hits (reference)
+
+
+def test_valid_with_mapping(ali):
+    hits1, mrr = orc.valid(ali['e1'], ali['e2'], ali['mapping'], TOP_K, 1, metric='inner', normalize=True)
+    assert hits1 == ali['valid_mapping'][0]
+    # quick-mode MRR of the reference is only meaningful for rows ranked < 50
+
+
+def test_csls_blocks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "csls.npz"))
+    s = g['s']
+    np.testing.assert_allclose(orc.calculate_nearest_k(s, 10), g['nearest_rows'], rtol=2e-6)
+    np.testing.assert_allclose(orc.calculate_nearest_k(s.T, 10), g['nearest_cols'], rtol=2e-6)
+    np.testing.assert_allclose(orc.csls_sim(s, 10), g['csls'], rtol=0, atol=2e-6)
+
+
+def test_neighbours(golden_dir):
+    g = np.load(os.path.join(golden_dir, "neighbours.npz"))
+    k = int(g['k'])
+    dic = orc.generate_neighbours(g['emb'], g['entity_list'].tolist(), k, 4)
+    assert sorted(dic.keys()) == g['keys'].tolist()
+    for key, ref in zip(g['keys'], g['nbrs']):
+        got = dic[int(key)]
+        assert len(got) == k and len(set(got)) == k
+        assert int(key) in got                      # lists contain the entity itself
+        assert got == ref.tolist()                  # no boundary ties in the fixture
+
+
+def test_pos_batch_task_divide_early_stop(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pos_batch.npz"))
+    t1 = [tuple(x) for x in g['t1'].tolist()]
+    t2 = [tuple(x) for x in g['t2'].tolist()]
+    for step in (0, 1, 3, 9):
+        got = np.array(orc.generate_pos_batch(t1, t2, 200, step), np.int32).reshape(-1, 3)
+        assert np.array_equal(got, g['step%d' % step])
+    misc = json.load(open(os.path.join(golden_dir, "misc.json")))
+    for key, ref in misc['task_divide'].items():
+        total, n = map(int, key.split('_'))
+        got = [list(map(int, x)) for x in orc.task_divide(list(range(total)), n)]
+        assert got == ref
+    for f1, f2, f, r0, r1, r2 in misc['early_stop']:
+        assert orc.early_stop(f1, f2, f) == (r0, r1, r2)
+
+
+def test_reference_sampler_invariants(golden_dir):
+    """Properties of the REFERENCE sampler's output that the Philox restatement
+    must share; the restatement itself is checked in test_sampler.py."""
+    g = np.load(os.path.join(golden_dir, "neg_sampling.npz"))
+    tri = set(map(tuple, g['triples'].tolist()))
+    pos = g['pos']
+    for name in ('neg_uniform', 'neg_truncated'):
+        neg = g[name].reshape(len(pos), 10, 3)
+        for p in range(len(pos)):
+            h, r, t = pos[p]
+            for nh, nr, nt in neg[p]:
+                assert nr == r and ((nh == h) != (nt == t) or (nh == h and nt == t))
+        frac_true = np.mean([tuple(x) in tri for x in g[name].tolist()])
+        assert frac_true < 0.01
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    out = cport.philox([0, 0, 0, 0], [0, 0])
+    assert [hex(x) for x in out] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    out = cport.philox([0xffffffff] * 4, [0xffffffff] * 2)
+    assert [hex(x) for x in out] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
+    out = cport.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
+    assert [hex(x) for x in out] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
