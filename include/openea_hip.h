@@ -1,0 +1,203 @@
+/*
+ * openea_hip.h -- C ABI of libopenea_hip.so: the MI355X (gfx950) implementation of OpenEA's
+ * training / evaluation hot path.
+ *
+ * The reference (nju-websoft/OpenEA) has NO FFI of its own: the path runs as TensorFlow-1 stock
+ * ops plus numpy/scipy calls.  Each entry point below therefore names the reference call site
+ * (file:line relative to /root/reference/src/openea/) whose arithmetic it replaces; the Python
+ * mirror of the reference's module API (openea_amd/modules/...) is the only caller.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.
+ *   - every `*_dev` / unqualified data pointer is a HIP DEVICE pointer unless the name ends in
+ *     `_host`; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all functions return 0 on success, a negative OEA_E* code otherwise;
+ *     oea_last_error() returns a thread-local message for the last failure.
+ *   - tables are fp32 row-major [rows, ld] with ld >= dim and ld % 4 == 0; columns
+ *     [dim, ld) must be zero and are kept zero.  ids are int32.  Triples are int32 [n,3]
+ *     (head, relation, tail) interleaved.
+ *   - calls are asynchronous on `stream`; the caller synchronises.  Not re-entrant on the
+ *     same buffers.
+ */
+#ifndef OPENEA_HIP_H
+#define OPENEA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OEA_OK 0
+#define OEA_EINVAL (-1)   /* bad argument */
+#define OEA_EHIP (-2)     /* HIP runtime error */
+#define OEA_ENOMEM (-3)
+#define OEA_EUNSUPPORTED (-4)
+
+int oea_version(void);
+const char *oea_last_error(void);
+/* number of visible HIP devices, <0 on error (used by the host side to fail loudly) */
+int oea_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Embedding store -- replaces the tf.Variable tables of BasicModel._define_variables
+ * (models/basic_model.py:73-78) and their .eval() round trips (basic_model.py:106-121,
+ * 184-204).  Payload layout of load/save_host == the C-contiguous fp32 [rows, dim] payload
+ * of ent_embeds.npy (modules/load/read.py:325-349).
+ * ------------------------------------------------------------------------------------- */
+typedef struct oea_store *oea_store_t;
+int oea_store_create(int64_t rows, int32_t dim, oea_store_t *out);
+int oea_store_destroy(oea_store_t s);
+int64_t oea_store_rows(oea_store_t s);
+int32_t oea_store_dim(oea_store_t s);
+int32_t oea_store_ld(oea_store_t s);
+float *oea_store_rows_ptr(oea_store_t s);                       /* device pointer [rows, ld] */
+int oea_store_load_host(oea_store_t s, const float *src_host, void *stream);  /* [rows, dim] */
+int oea_store_save_host(oea_store_t s, float *dst_host, void *stream);        /* [rows, dim] */
+
+/* out[i, 0:dim] = table[ids[i]] (optionally row-L2-normalised: tf.nn.l2_normalize,
+ * modules/base/initializers.py:26) -- tf.nn.embedding_lookup, basic_model.py:89-94,106-121.
+ * out is [n, out_ld]; columns [dim, out_ld) are zero-filled. */
+int oea_gather_rows(const float *table, int32_t dim, int32_t ld, const int32_t *ids, int64_t n,
+                    int32_t normalize, float *out, int32_t out_ld, void *stream);
+/* in place: table[r] = l2_normalize(table[r]) for all rows (sklearn normalize semantics when
+ * sk != 0: zero rows stay zero; TF semantics otherwise: x*rsqrt(max(ss,1e-12))) */
+int oea_normalize_rows(float *table, int64_t rows, int32_t dim, int32_t ld, int32_t sk, void *stream);
+int oea_fill_f32(float *p, int64_t n, float value, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Translational step -- replaces one session.run([triple_loss, triple_optimizer]) of
+ * BasicModel.launch_triple_training_1epo (basic_model.py:222-232): gather
+ * (basic_model.py:89-94) -> l2_normalize (initializers.py:26) -> loss (modules/base/losses.py:
+ * 15-73, approaches/bootea.py:197) -> gradient -> duplicate rows summed -> optimizer
+ * (modules/base/optimizers.py:4-20).
+ * ------------------------------------------------------------------------------------- */
+enum { OEA_LOSS_MARGIN = 0, OEA_LOSS_LIMITED = 1, OEA_LOSS_LOGISTIC = 2, OEA_LOSS_POSITIVE = 3,
+       OEA_LOSS_ALIGN = 4 };
+enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1 };
+
+typedef struct oea_step_cfg {
+    int32_t loss_kind;   /* OEA_LOSS_* */
+    int32_t l1;          /* 1: args.loss_norm == 'L1'; 0: 'L2' (squared, no sqrt) */
+    float margin;        /* margin-based: args.margin */
+    float pos_margin;    /* limited: args.pos_margin */
+    float neg_margin;    /* limited: args.neg_margin */
+    float balance;       /* limited: args.neg_margin_balance */
+    int32_t ent_l2_norm; /* args.ent_l2_norm */
+    int32_t rel_l2_norm; /* args.rel_l2_norm */
+    int32_t opt_kind;    /* OEA_OPT_* (args.optimizer) */
+    float lr;            /* args.learning_rate */
+} oea_step_cfg;
+
+/* Workspace owned by the caller, sized by oea_step_workspace_bytes(); must be zero-initialised
+ * once (hipMemset) before first use; the step leaves it zeroed again. */
+size_t oea_step_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld);
+
+/* One optimiser step.  pos/neg: int32 [n,3].  For OEA_LOSS_MARGIN n_neg must equal n_pos
+ * (pairs aligned, losses.py:26); neg may be NULL when n_neg == 0 (positive / align losses).
+ * ent_acc / rel_acc: Adagrad accumulators (same shape as the tables, initial value 0.1 =
+ * tf.train.AdagradOptimizer default), ignored for SGD.
+ * loss_accum: device double; the batch loss (sum over the batch, as in the reference) is
+ * ADDED to it, so an epoch's loss is read back once (basic_model.py:231-233). */
+int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
+                    int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
+                    const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
+                    double *loss_accum, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Negative sampling -- replaces generate_neg_triples_fast (modules/train/batch.py:89-119).
+ * The membership set replaces the python set `all_triples_set`.
+ * ------------------------------------------------------------------------------------- */
+/* capacity: power of two >= 2*n;  table: uint64[capacity] on the device */
+uint64_t oea_tripleset_capacity(int64_t n);
+int oea_tripleset_build(const int32_t *triples, int64_t n, uint64_t *table, uint64_t capacity,
+                        void *stream);
+/* out[p*k + s] = s-th negative of positive p.  candidates = nbr[ent_pos[e]*nbr_k ...] when
+ * nbr != NULL (truncated sampling, neighbor.get(e), batch.py:96-97) else entity_list.
+ * RNG stream: Philox4x32-10 keyed by seed, counter (p + pos_offset, step, try, draw). */
+int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uint64_t *table,
+                         uint64_t capacity, const int32_t *entity_list, int32_t n_ent_list,
+                         const int32_t *ent_pos, const int32_t *nbr, int32_t nbr_k, uint64_t seed,
+                         uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
+                         int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):
+ * np.matmul(sub_embed, embed.T) + per-row np.argpartition(-row, k)[:k].
+ * out_idx [nq, k]: the k columns with the largest inner product per query, selected by
+ * (value desc, column asc), listed in ascending column order.  If id_map != NULL the
+ * output holds id_map[col] (entity_list[neighbors_index], batch.py:163).
+ * workspace: oea_topk_workspace_bytes(nq, nc) bytes (may be smaller: the call processes
+ * query rows in chunks that fit `ws_bytes`; minimum one 128-row strip).
+ * ------------------------------------------------------------------------------------- */
+size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc);
+int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int64_t nc, int32_t ldc,
+                   int32_t dim, int32_t k, const int32_t *id_map, int32_t *out_idx, void *workspace,
+                   size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Alignment evaluation -- replaces sim() + calculate_rank() of greedy_alignment
+ * (modules/finding/similarity.py:11-83, modules/finding/alignment.py:13-84,146-168).
+ * Gold of row i is column i (n1 <= n2).
+ *   rank[i]   = #{j != i : S_ij > S_ii  or (S_ij == S_ii and j < i)}     (0-based)
+ *   argmax[i] = smallest j maximising S_ij                               (rank[0])
+ * metric: OEA_METRIC_*; csls_r / csls_c: per-row / per-column top-k means (NULL = no CSLS),
+ * S'_ij = (2*S_ij - r_i) - c_j (similarity.py:74-76).
+ * rank / argmax: int32 [n1].  workspace: oea_rank_workspace_bytes(n1) bytes.
+ * ------------------------------------------------------------------------------------- */
+enum { OEA_METRIC_INNER = 0, OEA_METRIC_MANHATTAN = 1, OEA_METRIC_EUCLIDEAN = 2 };
+size_t oea_rank_workspace_bytes(int64_t n1);
+int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
+                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c,
+                  int32_t *rank, int32_t *argmax, void *workspace, void *stream);
+/* integer reductions of rank[]: hits[i] = #{rank < top_k[i]}, rank_sum = sum(rank+1) (int64),
+ * rr_sum = sum 1/(rank+1) (double, fixed summation order).  alignment.py:163-168. */
+int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, int32_t nk,
+                     int64_t *hits_dev, int64_t *rank_sum_dev, double *rr_sum_dev, void *stream);
+
+/* Similarity strip S[i, j] for i in [0,n1), j in [0,n2): out is [n1, ld_out] fp32
+ * (similarity.py:34-48).  Used by the sim() mirror, CSLS and the neighbour search. */
+int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2,
+                   int32_t ld2, int32_t dim, int32_t metric, float *out, int64_t ld_out,
+                   void *stream);
+/* out[i] = mean of the k largest of S[i, 0:n2] (calculate_nearest_k, similarity.py:80-83),
+ * summed in descending order in fp32.  k <= 64. */
+int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_t k, float *out,
+                      void *stream);
+/* in place S'_ij = (2*S_ij - r_i) - c_j (csls_sim, similarity.py:74-76) */
+int oea_csls_apply(float *s, int64_t n1, int64_t n2, int64_t ld, const float *r, const float *c,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Neighbour aggregation -- replaces tf.sparse_tensor_dense_matmul(A, X)
+ * (approaches/gcn_align.py:83,259; alinet.py:581; rdgcn.py:187,196) and its gradient.
+ * CSR: rowptr int32 [n_rows+1], colidx int32 [nnz], vals fp32 [nnz].
+ *   y[i, :] = act( sum_e vals[e] * x[colidx[e], :] )      act: 0 none, 1 relu
+ * The backward pass is the same call on the transposed CSR.  mask_from (may be NULL):
+ * y = y * (mask_from > 0) -- the relu gradient gate fused into the backward aggregate.
+ * ------------------------------------------------------------------------------------- */
+int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
+                 const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from,
+                 float *y, int32_t ldy, void *stream);
+
+/* L1 alignment hinge of GCN-Align / RDGCN (approaches/gcn_align.py:298-320,
+ * rdgcn.py:293-315): forward + gradient w.r.t. the output embedding table.
+ * ILL int32 [t,2]; neg_*: int32 [t*k]; grad [n, ld] must be zero on entry.
+ * loss_accum += (sum L1 + sum L2) / (2 k t). */
+int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, const int32_t *ill,
+                      int64_t t, int32_t k, float gamma, const int32_t *neg_left,
+                      const int32_t *neg_right, const int32_t *neg2_left, const int32_t *neg2_right,
+                      float *grad, double *loss_accum, void *stream);
+
+/* W -= lr * dW where dW is the gradient w.r.t. T = l2_normalize(W) pulled back through the
+ * normalisation (gcn_align.py:52-56 + GradientDescentOptimizer, gcn_align.py:511).
+ * normalize == 0: plain SGD. */
+int oea_sgd_rows(float *w, const float *grad_t, int64_t rows, int32_t dim, int32_t ld,
+                 int32_t normalize, float lr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENEA_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libopenea_hip.so (the C ABI declared in include/openea_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, cannot be loaded, or no
+HIP device is visible, every compute entry point raises ``OpenEAHipError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libopenea_hip.so")
+
+
+class OpenEAHipError(RuntimeError):
+    pass
+
+
+class StepCfg(C.Structure):
+    """mirror of `oea_step_cfg` (include/openea_hip.h)."""
+    _fields_ = [("loss_kind", C.c_int32), ("l1", C.c_int32), ("margin", C.c_float),
+                ("pos_margin", C.c_float), ("neg_margin", C.c_float), ("balance", C.c_float),
+                ("ent_l2_norm", C.c_int32), ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32),
+                ("lr", C.c_float)]
+
+
+LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
+OPT_KIND = {"SGD": 0, "Adagrad": 1}
+METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2}
+
+_vp, _i32, _i64, _u32, _u64, _f32, _sz = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64,
+                                          C.c_float, C.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/openea_hip.h declares
+PROTOTYPES = {
+    "oea_version": (C.c_int, []),
+    "oea_last_error": (C.c_char_p, []),
+    "oea_device_count": (C.c_int, []),
+    "oea_store_create": (C.c_int, [_i64, _i32, C.POINTER(_vp)]),
+    "oea_store_destroy": (C.c_int, [_vp]),
+    "oea_store_rows": (_i64, [_vp]),
+    "oea_store_dim": (_i32, [_vp]),
+    "oea_store_ld": (_i32, [_vp]),
+    "oea_store_rows_ptr": (_vp, [_vp]),
+    "oea_store_load_host": (C.c_int, [_vp, _vp, _vp]),
+    "oea_store_save_host": (C.c_int, [_vp, _vp, _vp]),
+    "oea_gather_rows": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "oea_normalize_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp]),
+    "oea_fill_f32": (C.c_int, [_vp, _i64, _f32, _vp]),
+    "oea_step_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "oea_triple_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
+                                  C.POINTER(StepCfg), _vp, _vp, _vp]),
+    "oea_tripleset_capacity": (_u64, [_i64]),
+    "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
+    "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,
+                                       _u32, _u32, _i32, _vp, _vp, _vp]),
+    "oea_topk_workspace_bytes": (_sz, [_i64, _i64]),
+    "oea_topk_inner": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "oea_rank_workspace_bytes": (_sz, [_i64]),
+    "oea_rank_eval": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "oea_sim_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
+    "oea_sgd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+}
+
+_lib = None
+
+
+def load(require_device=True):
+    """Load libopenea_hip.so and bind every prototype.  Raises OpenEAHipError when the
+    library is absent or (require_device) no HIP device is visible."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OpenEAHipError(
+                "libopenea_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise OpenEAHipError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_device and _lib.oea_device_count() <= 0:
+        raise OpenEAHipError("no HIP device visible: the OpenEA hot path runs on MI355X only "
+                             "(there is no CPU fallback)")
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        msg = _lib.oea_last_error().decode("utf-8", "replace") if _lib is not None else ""
+        raise OpenEAHipError("libopenea_hip error %d: %s" % (code, msg))

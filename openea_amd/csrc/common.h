@@ -1,0 +1,84 @@
+// common.h -- shared helpers for libopenea_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/openea_hip.h"
+
+namespace oea {
+
+void set_error(const char *fmt, ...);
+
+#define OEA_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            oea::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return OEA_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define OEA_REQUIRE(cond, msg)                                              \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            oea::set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, msg); \
+            return OEA_EINVAL;                                              \
+        }                                                                   \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave64 helpers ---------------------------------------------------------------------
+// Sum over the G-lane group (G power of two <= 64) containing this lane; every lane of the
+// group gets the result.  Butterfly with __shfl_xor: fixed order -> deterministic.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double group_sum_d(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) { return group_sum_d<64>(v); }
+
+// hardware fp32 atomic add (global_atomic_add_f32, no CAS loop); device scope.
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ---- Philox4x32-10 (bit-identical with oracle/c/oracle.c) ------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// ---- triple membership set (layout shared with oracle/c/oracle.c) ---------------------------
+#define OEA_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+__host__ __device__ __forceinline__ uint64_t pack_triple(uint32_t h, uint32_t r, uint32_t t) {
+    return ((uint64_t)h << 40) | ((uint64_t)(r & 0xFFFFu) << 24) | (uint64_t)(t & 0xFFFFFFu);
+}
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+}  // namespace oea

@@ -1,0 +1,564 @@
+// sim_rank.hip -- similarity tiles on the fp32 matrix cores + fused alignment-rank epilogue.
+//
+// Replaces sim() / csls_sim() / calculate_rank() of the reference's greedy_alignment
+// (modules/finding/similarity.py:11-83, modules/finding/alignment.py:13-84,146-168):
+//   np.matmul(e1, e2.T)             -> 128x128 tiles of v_mfma_f32_32x32x2_f32 (exact fp32:
+//                                      a k-ordered fmaf chain, k = 0,1,2,... -- identical to
+//                                      oracle/c/oracle.c:dot_chain, hence bit-exact ranks)
+//   argsort(-row) + np.where(==gold) -> rank_i = #{j : S_ij > S_ii} (+ stable tie rule),
+//                                      counted in the epilogue; the N1 x N2 matrix is never
+//                                      written (19.6 GB at 70,000^2 in the reference)
+//   scipy cdist('cityblock')         -> fp64 VALU tiles, sequential k (bit-exact vs scipy)
+//
+// Operand layout: both operands are row-major [n, ld] fp32 (K contiguous).  A K-chunk of 32
+// is staged global -> registers -> LDS with the k index permuted inside groups of 8
+// (positions 0..3 hold k = 0,2,4,6; 4..7 hold k = 1,3,5,7) so that one ds_read_b128 gives a
+// lane its operand for four consecutive MFMA k-steps in natural k order.  Row stride 36
+// floats (144 B) makes the b128 reads bank-conflict free.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = 128;      // block tile edge (both operands)
+constexpr int BK = 32;         // K chunk
+constexpr int LDS_LD = BK + 4; // padded row stride (floats)
+
+__device__ __forceinline__ uint32_t f2ord(float f) {   // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f + 0.0f);   // -0 -> +0 so that key order == float order
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Stage rows [row0, row0+128) x k [k0, k0+32) of `src` into `dst` (LDS, permuted k).
+__device__ __forceinline__ void stage_tile(const float *__restrict__ src, int64_t n, int ld, int dim,
+                                           int64_t row0, int k0, float *__restrict__ dst, int tid) {
+    const int q = tid & 7;            // float4 index inside the 32-wide chunk
+    const int g = q >> 1, half = q & 1;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = (tid >> 3) + pass * 32;
+        const int64_t row = row0 + r;
+        const int c = k0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n && c < ld) {
+            v = oea::ld4(src + row * ld + c);
+            if (c + 0 >= dim) v.x = 0.f;
+            if (c + 1 >= dim) v.y = 0.f;
+            if (c + 2 >= dim) v.z = 0.f;
+            if (c + 3 >= dim) v.w = 0.f;
+        }
+        float *p = dst + r * LDS_LD + g * 8;
+        *reinterpret_cast<float2 *>(p + 2 * half) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2 *>(p + 4 + 2 * half) = make_float2(v.y, v.w);
+    }
+}
+
+// One 128(M) x 128(N) x K product accumulated into acc[2][2] per wave.
+// M operand = `am` rows [m0, m0+128), N operand = `bn` rows [n0, n0+128).
+__device__ __forceinline__ void tile_gemm(const float *__restrict__ am, int64_t m_rows, int lda,
+                                          const float *__restrict__ bn, int64_t n_rows, int ldb, int dim,
+                                          int64_t m0, int64_t n0, float *As, float *Bs, f32x16 (&acc)[2][2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int kend = (dim + 7) / 8 * 8;
+    for (int k0 = 0; k0 < kend; k0 += BK) {
+        __syncthreads();   // previous chunk fully consumed
+        stage_tile(am, m_rows, lda, dim, m0, k0, As, tid);
+        stage_tile(bn, n_rows, ldb, dim, n0, k0, Bs, tid);
+        __syncthreads();
+        const int groups = min(BK, kend - k0) / 8;
+        const float *ap = As + (wm * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+        const float *bp = Bs + (wn * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+        for (int g = 0; g < groups; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(ap + g * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * LDS_LD + g * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(bp + g * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * LDS_LD + g * 8);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[0][s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[1][s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[0][s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[1][s], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ---- gold similarity: S_ii as the same k-ordered fmaf chain (one lane per query) ---------------
+__global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2,
+                                  int ld2, int dim, const float *__restrict__ csls_r,
+                                  const float *__restrict__ csls_c, float *__restrict__ gold) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const float *a = e1 + i * ld1, *b = e2 + i * ld2;
+    float acc = 0.f;
+    for (int k = 0; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+    if (csls_r) acc = (2.0f * acc - csls_r[i]) - csls_c[i];
+    gold[i] = acc;
+}
+
+// ---- fused rank epilogue: M = candidates (e2 rows), N = queries (e1 rows) -----------------------
+// grid.x = query tiles, grid.y = candidate chunks.  Per lane: one query (MFMA column) and 16
+// candidates per MFMA tile, so the per-query reductions stay in registers across the whole
+// candidate sweep; partial results are merged with integer atomics (order independent).
+__global__ __launch_bounds__(256) void rank_inner_kernel(
+    const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2,
+    int dim, const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
+    int tiles_per_chunk, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
+    __shared__ __attribute__((aligned(16))) float As[TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TILE * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t q0 = (int64_t)blockIdx.x * TILE;
+    const int64_t nct = (n2 + TILE - 1) / TILE;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
+
+    int64_t qi[2];
+    float g[2], rq[2];
+    int cnt[2] = {0, 0};
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {0x7fffffff, 0x7fffffff};
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
+        const bool ok = qi[tn] < n1;
+        g[tn] = ok ? gold[qi[tn]] : 0.f;
+        rq[tn] = (ok && csls_r) ? csls_r[qi[tn]] : 0.f;
+    }
+    for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
+        const int64_t c0 = ct * TILE;
+        f32x16 acc[2][2];
+        tile_gemm(e2, n2, ld2, e1, n1, ld1, dim, c0, q0, As, Bs, acc);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t j = c0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (j < n2) {
+                    const float cj = csls_c ? csls_c[j] : 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        float v = acc[tm][tn][r];
+                        if (csls_r) v = (2.0f * v - rq[tn]) - cj;
+                        const int64_t i = qi[tn];
+                        cnt[tn] += (j != i) && (v > g[tn] || (v == g[tn] && j < i));
+                        if (v > best[tn] || (v == best[tn] && (int)j < bidx[tn])) { best[tn] = v; bidx[tn] = (int)j; }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        // merge the two half-waves (same query, disjoint candidates)
+        cnt[tn] += __shfl_xor(cnt[tn], 32, 64);
+        const float ob = __shfl_xor(best[tn], 32, 64);
+        const int oi = __shfl_xor(bidx[tn], 32, 64);
+        if (ob > best[tn] || (ob == best[tn] && oi < bidx[tn])) { best[tn] = ob; bidx[tn] = oi; }
+        if (lane < 32 && qi[tn] < n1 && ct_end > ct_begin) {
+            if (cnt[tn]) atomicAdd(rank + qi[tn], cnt[tn]);
+            const unsigned long long key = ((unsigned long long)f2ord(best[tn]) << 32) | (0xFFFFFFFFu - (uint32_t)bidx[tn]);
+            atomicMax(best_key + qi[tn], key);
+        }
+    }
+}
+
+__global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best_key, int64_t n1,
+                                     int32_t *__restrict__ argmax) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n1) argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(best_key[i] & 0xFFFFFFFFull));
+}
+
+// ---- store epilogue: M = e1 rows (output rows), N = e2 rows (output columns) ----------------------
+__global__ __launch_bounds__(256) void sim_inner_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
+                                                              const float *__restrict__ e2, int64_t n2, int ld2,
+                                                              int dim, float *__restrict__ out, int64_t ld_out) {
+    __shared__ __attribute__((aligned(16))) float As[TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TILE * LDS_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
+    f32x16 acc[2][2];
+    tile_gemm(e1, n1, ld1, e2, n2, ld2, dim, m0, c0, As, Bs, acc);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int64_t j = c0 + wn * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < n1 && j < n2) out[i * ld_out + j] = acc[tm][tn][r];
+            }
+        }
+}
+
+// ---- fp64 VALU tiles: manhattan / euclidean --------------------------------------------------------
+// 64 queries x 64 candidates per block, 4x4 per thread, K chunk 32 staged as doubles.
+// sim = float(1 - sum_k |a_k - b_k|)  (scipy cdist cityblock, similarity.py:46-48), sequential k.
+constexpr int VT = 64, VK = 32;
+
+__device__ __forceinline__ void stage_f64(const float *__restrict__ src, int64_t n, int ld, int dim, int64_t row0,
+                                          int k0, double *__restrict__ dst /* [VK][VT+1] */, int tid) {
+    // thread -> (row = tid / 4, 8 k values starting at (tid % 4) * 8)
+    const int r = tid >> 2, kq = (tid & 3) * 8;
+    const int64_t row = row0 + r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + kq + e;
+        float v = 0.f;
+        if (row < n && k < dim) v = src[row * ld + k];
+        dst[(kq + e) * (VT + 1) + r] = (double)v;
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ void valu_tile(const float *__restrict__ e1, int64_t n1, int ld1,
+                                          const float *__restrict__ e2, int64_t n2, int ld2, int dim, int64_t q0,
+                                          int64_t c0, double *Qs, double *Cs, float (&simv)[4][4]) {
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = 0; k0 < dim; k0 += VK) {
+        __syncthreads();
+        stage_f64(e1, n1, ld1, dim, q0, k0, Qs, tid);
+        stage_f64(e2, n2, ld2, dim, c0, k0, Cs, tid);
+        __syncthreads();
+        const int kk = min(VK, dim - k0);
+        for (int k = 0; k < kk; ++k) {
+            double qv[4], cv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) qv[a] = Qs[k * (VT + 1) + ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cv[b] = Cs[k * (VT + 1) + tx + 16 * b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double t = qv[a] - cv[b];
+                    if (METRIC == OEA_METRIC_MANHATTAN) acc[a][b] += fabs(t);
+                    else acc[a][b] += t * t;
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            simv[a][b] = METRIC == OEA_METRIC_MANHATTAN ? (float)(1.0 - acc[a][b]) : (float)(1.0 - sqrt(acc[a][b]));
+}
+
+template <int METRIC>
+__global__ void gold_valu_kernel(const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2,
+                                 int ld2, int dim, const float *__restrict__ csls_r,
+                                 const float *__restrict__ csls_c, float *__restrict__ gold) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    const float *a = e1 + i * ld1, *b = e2 + i * ld2;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        const double t = (double)a[k] - (double)b[k];
+        if (METRIC == OEA_METRIC_MANHATTAN) s += fabs(t);
+        else s += t * t;
+    }
+    float v = METRIC == OEA_METRIC_MANHATTAN ? (float)(1.0 - s) : (float)(1.0 - sqrt(s));
+    if (csls_r) v = (2.0f * v - csls_r[i]) - csls_c[i];
+    gold[i] = v;
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void rank_valu_kernel(
+    const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2, int dim,
+    const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
+    int tiles_per_chunk, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
+    __shared__ double Qs[VK * (VT + 1)];
+    __shared__ double Cs[VK * (VT + 1)];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t q0 = (int64_t)blockIdx.x * VT;
+    const int64_t nct = (n2 + VT - 1) / VT;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
+    int cnt[4] = {0, 0, 0, 0};
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    float g[4], rq[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t i = q0 + ty * 4 + a;
+        g[a] = i < n1 ? gold[i] : 0.f;
+        rq[a] = (i < n1 && csls_r) ? csls_r[i] : 0.f;
+    }
+    for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
+        const int64_t c0 = ct * VT;
+        float simv[4][4];
+        valu_tile<METRIC>(e1, n1, ld1, e2, n2, ld2, dim, q0, c0, Qs, Cs, simv);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t j = c0 + tx + 16 * b;
+            if (j < n2) {
+                const float cj = csls_c ? csls_c[j] : 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int64_t i = q0 + ty * 4 + a;
+                    float v = simv[a][b];
+                    if (csls_r) v = (2.0f * v - rq[a]) - cj;
+                    cnt[a] += (j != i) && (v > g[a] || (v == g[a] && j < i));
+                    if (v > best[a] || (v == best[a] && (int)j < bidx[a])) { best[a] = v; bidx[a] = (int)j; }
+                }
+            }
+        }
+    }
+    if (ct_end > ct_begin) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int64_t i = q0 + ty * 4 + a;
+            if (i < n1) {
+                if (cnt[a]) atomicAdd(rank + i, cnt[a]);
+                const unsigned long long key = ((unsigned long long)f2ord(best[a]) << 32) | (0xFFFFFFFFu - (uint32_t)bidx[a]);
+                atomicMax(best_key + i, key);
+            }
+        }
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void sim_valu_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
+                                                             const float *__restrict__ e2, int64_t n2, int ld2,
+                                                             int dim, float *__restrict__ out, int64_t ld_out) {
+    __shared__ double Qs[VK * (VT + 1)];
+    __shared__ double Cs[VK * (VT + 1)];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t q0 = (int64_t)blockIdx.y * VT, c0 = (int64_t)blockIdx.x * VT;
+    float simv[4][4];
+    valu_tile<METRIC>(e1, n1, ld1, e2, n2, ld2, dim, q0, c0, Qs, Cs, simv);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t i = q0 + ty * 4 + a, j = c0 + tx + 16 * b;
+            if (i < n1 && j < n2) out[i * ld_out + j] = simv[a][b];
+        }
+}
+
+// ---- integer metric reductions ---------------------------------------------------------------------
+// hits[k] = #{rank < top_k[k]}, rank_sum = sum(rank + 1), rr_sum = sum 1/(rank+1) in a fixed order
+// (one block, strided partials, tree reduce) -> deterministic.
+__global__ __launch_bounds__(1024) void rank_metrics_kernel(const int32_t *__restrict__ rank, int64_t n, int4 tk0,
+                                                            int4 tk1, int nk, long long *__restrict__ hits,
+                                                            long long *__restrict__ rank_sum, double *__restrict__ rr_sum) {
+    __shared__ long long s_i[1024];
+    __shared__ double s_d[1024];
+    const int tks[8] = {tk0.x, tk0.y, tk0.z, tk0.w, tk1.x, tk1.y, tk1.z, tk1.w};
+    long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs = 0;
+    double rr = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = rank[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] += (k < nk && r < tks[k]);
+        rs += r + 1;
+        rr += 1.0 / (double)(r + 1);
+    }
+    for (int k = 0; k <= nk; ++k) {
+        s_i[threadIdx.x] = k < nk ? h[k] : rs;
+        __syncthreads();
+        for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) s_i[threadIdx.x] += s_i[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { if (k < nk) hits[k] = s_i[0]; else *rank_sum = s_i[0]; }
+        __syncthreads();
+    }
+    s_d[threadIdx.x] = rr;
+    __syncthreads();
+    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_d[threadIdx.x] += s_d[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *rr_sum = s_d[0];
+}
+
+// ---- per-row top-k mean (CSLS) -------------------------------------------------------------------
+// One wave per row.  Each lane keeps the KMAX largest values of its strided slice sorted in
+// registers; the 64 sorted lists are then merged by k rounds of wave-wide "largest head",
+// accumulating in DESCENDING order exactly like oracle_topk_mean.
+template <int KMAX>
+__global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restrict__ s, int64_t n1, int64_t n2,
+                                                            int64_t ld, int k, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n1) return;
+    float top[KMAX];
+#pragma unroll
+    for (int p = 0; p < KMAX; ++p) top[p] = -INFINITY;
+    const float *src = s + row * ld;
+    for (int64_t j = lane; j < n2; j += 64) {
+        float v = src[j];
+        if (v > top[KMAX - 1]) {
+#pragma unroll
+            for (int p = 0; p < KMAX; ++p) {
+                const float hi = fmaxf(top[p], v), lo = fminf(top[p], v);
+                top[p] = hi; v = lo;
+            }
+        }
+    }
+    float acc = 0.f;
+    int taken = 0;    // how many of this lane's list were consumed
+    for (int round = 0; round < k; ++round) {
+        float head = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < KMAX; ++p) if (p == taken) head = top[p];
+        float m = head;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        // lowest lane holding the maximum advances
+        const unsigned long long bal = __ballot(head == m);
+        const int winner = __ffsll((long long)bal) - 1;
+        if (lane == winner) ++taken;
+        acc += m;
+    }
+    if (lane == 0) out[row] = acc / (float)k;
+}
+
+__global__ void csls_apply_kernel(float *__restrict__ s, int64_t n1, int64_t n2, int64_t ld,
+                                  const float *__restrict__ r, const float *__restrict__ c) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j < n2) s[i * ld + j] = (2.0f * s[i * ld + j] - r[i]) - c[j];
+}
+
+static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
+    // enough workgroups to fill 256 CUs several times over, without splitting finer than a tile
+    int64_t want = std::max<int64_t>(1, (2048 + q_tiles - 1) / q_tiles);
+    int64_t chunks = std::min<int64_t>(want, c_tiles);
+    *tiles_per_chunk = (int)((c_tiles + chunks - 1) / chunks);
+    return (int)((c_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t oea_rank_workspace_bytes(int64_t n1) {
+    return (size_t)n1 * (sizeof(float) + sizeof(unsigned long long)) + 256;
+}
+
+int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
+                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c, int32_t *rank,
+                  int32_t *argmax, void *workspace, void *stream) {
+    OEA_REQUIRE(e1 && e2 && rank && argmax && workspace, "null pointer");
+    OEA_REQUIRE(n1 >= 0 && n1 <= n2, "gold of row i is column i: n1 <= n2");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
+    OEA_REQUIRE((csls_r == nullptr) == (csls_c == nullptr), "csls_r and csls_c go together");
+    OEA_REQUIRE(n2 < 0x7fffffff, "n2 < 2^31");
+    if (n1 == 0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    unsigned long long *keys = static_cast<unsigned long long *>(workspace);
+    float *gold = reinterpret_cast<float *>(keys + n1);
+    OEA_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)n1, st));
+    OEA_CHECK_HIP(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n1, st));
+    const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
+    int tpc = 1;
+    if (metric == OEA_METRIC_INNER) {
+        gold_inner_kernel<<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+        const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
+        const int chunks = pick_chunks(qt, ctiles, &tpc);
+        rank_inner_kernel<<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
+                                                                              csls_c, tpc, rank, keys);
+    } else if (metric == OEA_METRIC_MANHATTAN || metric == OEA_METRIC_EUCLIDEAN) {
+        const int64_t qt = oea::ceil_div(n1, VT), ctiles = oea::ceil_div(n2, VT);
+        const int chunks = pick_chunks(qt, ctiles, &tpc);
+        if (metric == OEA_METRIC_MANHATTAN) {
+            gold_valu_kernel<OEA_METRIC_MANHATTAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+            rank_valu_kernel<OEA_METRIC_MANHATTAN><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(
+                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, rank, keys);
+        } else {
+            gold_valu_kernel<OEA_METRIC_EUCLIDEAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+            rank_valu_kernel<OEA_METRIC_EUCLIDEAN><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(
+                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, rank, keys);
+        }
+    } else {
+        oea::set_error("unknown metric %d", metric);
+        return OEA_EINVAL;
+    }
+    rank_finalize_kernel<<<gb, 256, 0, st>>>(keys, n1, argmax);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, int32_t nk, int64_t *hits_dev,
+                     int64_t *rank_sum_dev, double *rr_sum_dev, void *stream) {
+    OEA_REQUIRE(rank && top_k_host && hits_dev && rank_sum_dev && rr_sum_dev, "null pointer");
+    OEA_REQUIRE(nk >= 1 && nk <= 8, "1 <= len(top_k) <= 8");
+    int t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nk; ++i) t[i] = top_k_host[i];
+    rank_metrics_kernel<<<1, 1024, 0, oea::as_stream(stream)>>>(rank, n, make_int4(t[0], t[1], t[2], t[3]),
+                                                               make_int4(t[4], t[5], t[6], t[7]), nk,
+                                                               (long long *)hits_dev, (long long *)rank_sum_dev, rr_sum_dev);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
+                   int32_t dim, int32_t metric, float *out, int64_t ld_out, void *stream) {
+    OEA_REQUIRE(e1 && e2 && out, "null pointer");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && ld_out >= n2, "shapes");
+    if (n1 == 0 || n2 == 0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    if (metric == OEA_METRIC_INNER) {
+        sim_inner_store_kernel<<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
+            e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
+    } else if (metric == OEA_METRIC_MANHATTAN) {
+        sim_valu_store_kernel<OEA_METRIC_MANHATTAN><<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(
+            e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
+    } else if (metric == OEA_METRIC_EUCLIDEAN) {
+        sim_valu_store_kernel<OEA_METRIC_EUCLIDEAN><<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(
+            e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
+    } else {
+        oea::set_error("unknown metric %d", metric);
+        return OEA_EINVAL;
+    }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_t k, float *out, void *stream) {
+    OEA_REQUIRE(s && out, "null pointer");
+    OEA_REQUIRE(k >= 1 && k <= 32 && k <= n2, "1 <= k <= min(32, n2)");
+    if (n1 == 0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    const unsigned grid = (unsigned)oea::ceil_div(n1, 4);
+    if (k <= 16) row_topk_mean_kernel<16><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
+    else row_topk_mean_kernel<32><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_csls_apply(float *s, int64_t n1, int64_t n2, int64_t ld, const float *r, const float *c, void *stream) {
+    OEA_REQUIRE(s && r && c, "null pointer");
+    if (n1 == 0 || n2 == 0) return OEA_OK;
+    OEA_REQUIRE(n1 <= 65535 * 1024ll, "n1 too large for one launch");
+    // grid.y is limited to 65535: loop over row blocks
+    for (int64_t i0 = 0; i0 < n1; i0 += 65535) {
+        const int64_t rows = std::min<int64_t>(65535, n1 - i0);
+        csls_apply_kernel<<<dim3((unsigned)oea::ceil_div(n2, 256), (unsigned)rows), 256, 0, oea::as_stream(stream)>>>(
+            s + i0 * ld, rows, n2, ld, r + i0, c);
+    }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// store.hip -- embedding store, gathers, row normalisation, error plumbing.
+// Replaces tf.Variable tables + tf.nn.embedding_lookup + .eval() round trips
+// (reference: models/basic_model.py:73-121,184-204; modules/base/initializers.py:26).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace oea {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace oea
+
+struct oea_store {
+    int64_t rows;
+    int32_t dim, ld;
+    float *dev;
+};
+
+extern "C" {
+
+int oea_version(void) { return 100; }
+const char *oea_last_error(void) { return oea::g_err; }
+int oea_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int oea_store_create(int64_t rows, int32_t dim, oea_store_t *out) {
+    OEA_REQUIRE(rows > 0 && dim > 0 && out, "rows, dim > 0");
+    oea_store *s = new oea_store;
+    s->rows = rows;
+    s->dim = dim;
+    s->ld = (dim + 3) / 4 * 4;
+    s->dev = nullptr;
+    hipError_t e = hipMalloc(&s->dev, sizeof(float) * (size_t)rows * s->ld);
+    if (e != hipSuccess) {
+        oea::set_error("hipMalloc(%zu) failed: %s", sizeof(float) * (size_t)rows * s->ld, hipGetErrorString(e));
+        delete s;
+        return OEA_ENOMEM;
+    }
+    e = hipMemset(s->dev, 0, sizeof(float) * (size_t)rows * s->ld);
+    if (e != hipSuccess) { (void)hipFree(s->dev); delete s; oea::set_error("hipMemset failed"); return OEA_EHIP; }
+    *out = s;
+    return OEA_OK;
+}
+int oea_store_destroy(oea_store_t s) {
+    if (!s) return OEA_OK;
+    (void)hipFree(s->dev);
+    delete s;
+    return OEA_OK;
+}
+int64_t oea_store_rows(oea_store_t s) { return s->rows; }
+int32_t oea_store_dim(oea_store_t s) { return s->dim; }
+int32_t oea_store_ld(oea_store_t s) { return s->ld; }
+float *oea_store_rows_ptr(oea_store_t s) { return s->dev; }
+
+int oea_store_load_host(oea_store_t s, const float *src_host, void *stream) {
+    OEA_REQUIRE(s && src_host, "null");
+    OEA_CHECK_HIP(hipMemcpy2DAsync(s->dev, sizeof(float) * s->ld, src_host, sizeof(float) * s->dim,
+                                   sizeof(float) * s->dim, (size_t)s->rows, hipMemcpyHostToDevice,
+                                   oea::as_stream(stream)));
+    return OEA_OK;
+}
+int oea_store_save_host(oea_store_t s, float *dst_host, void *stream) {
+    OEA_REQUIRE(s && dst_host, "null");
+    OEA_CHECK_HIP(hipMemcpy2DAsync(dst_host, sizeof(float) * s->dim, s->dev, sizeof(float) * s->ld,
+                                   sizeof(float) * s->dim, (size_t)s->rows, hipMemcpyDeviceToHost,
+                                   oea::as_stream(stream)));
+    OEA_CHECK_HIP(hipStreamSynchronize(oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One G-lane group per row, float4 per lane per iteration; rows of ld floats (ld % 4 == 0).
+template <int G>
+__global__ void gather_rows_kernel(const float *__restrict__ table, int dim, int ld,
+                                   const int32_t *__restrict__ ids, int64_t n, int normalize,
+                                   float *__restrict__ out, int out_ld) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t i = grp; i < n; i += ngrp) {
+        const float *src = table + (int64_t)ids[i] * ld;
+        float ss = 0.f;
+        if (normalize) {
+            for (int c = lane * 4; c < ld; c += G * 4) {
+                float4 v = oea::ld4(src + c);
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            ss = oea::group_sum<G>(ss);
+        }
+        const float inv = normalize ? rsqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
+        for (int c = lane * 4; c < out_ld; c += G * 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < ld) v = oea::ld4(src + c);
+            float e[4] = {v.x * inv, v.y * inv, v.z * inv, v.w * inv};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + q >= dim) e[q] = 0.f;
+            oea::st4(out + i * out_ld + c, make_float4(e[0], e[1], e[2], e[3]));
+        }
+    }
+}
+
+template <int G>
+__global__ void normalize_rows_kernel(float *__restrict__ table, int64_t rows, int dim, int ld, int sk) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t i = grp; i < rows; i += ngrp) {
+        float *row = table + i * ld;
+        float ss = 0.f;
+        for (int c = lane * 4; c < ld; c += G * 4) {
+            float4 v = oea::ld4(row + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = oea::group_sum<G>(ss);
+        float inv;
+        if (sk) {  // sklearn.preprocessing.normalize: x / ||x||, zero rows unchanged
+            const float nrm = sqrtf(ss);
+            inv = nrm > 0.f ? 1.0f / nrm : 1.0f;
+        } else {
+            inv = rsqrtf(fmaxf(ss, 1e-12f));
+        }
+        for (int c = lane * 4; c < ld; c += G * 4) {
+            float4 v = oea::ld4(row + c);
+            oea::st4(row + c, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+        }
+    }
+}
+
+__global__ void fill_kernel(float *p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oea_gather_rows(const float *table, int32_t dim, int32_t ld, const int32_t *ids, int64_t n,
+                    int32_t normalize, float *out, int32_t out_ld, void *stream) {
+    OEA_REQUIRE(table && ids && out, "null pointer");
+    OEA_REQUIRE(ld % 4 == 0 && out_ld % 4 == 0 && dim <= ld && dim <= out_ld, "ld % 4 == 0 and dim <= ld");
+    if (n == 0) return OEA_OK;
+    const int block = 256;
+    if (ld <= 64) {
+        const int64_t grid = oea::ceil_div(n, block / 16);
+        gather_rows_kernel<16><<<dim3((unsigned)std::min<int64_t>(grid, 65535)), block, 0, oea::as_stream(stream)>>>(
+            table, dim, ld, ids, n, normalize, out, out_ld);
+    } else if (ld <= 128) {
+        const int64_t grid = oea::ceil_div(n, block / 32);
+        gather_rows_kernel<32><<<dim3((unsigned)std::min<int64_t>(grid, 65535)), block, 0, oea::as_stream(stream)>>>(
+            table, dim, ld, ids, n, normalize, out, out_ld);
+    } else {
+        const int64_t grid = oea::ceil_div(n, block / 64);
+        gather_rows_kernel<64><<<dim3((unsigned)std::min<int64_t>(grid, 65535)), block, 0, oea::as_stream(stream)>>>(
+            table, dim, ld, ids, n, normalize, out, out_ld);
+    }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_normalize_rows(float *table, int64_t rows, int32_t dim, int32_t ld, int32_t sk, void *stream) {
+    OEA_REQUIRE(table && ld % 4 == 0 && dim <= ld, "table, ld % 4 == 0");
+    if (rows == 0) return OEA_OK;
+    const int block = 256;
+    const int64_t grid = std::min<int64_t>(oea::ceil_div(rows, block / 32), 65535);
+    normalize_rows_kernel<32><<<dim3((unsigned)grid), block, 0, oea::as_stream(stream)>>>(table, rows, dim, ld, sk);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_fill_f32(float *p, int64_t n, float value, void *stream) {
+    OEA_REQUIRE(p || n == 0, "null");
+    if (n == 0) return OEA_OK;
+    const int64_t grid = std::min<int64_t>(oea::ceil_div(n, 256), 4096);
+    fill_kernel<<<dim3((unsigned)grid), 256, 0, oea::as_stream(stream)>>>(p, n, value);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+"""Thin typed wrappers over the C ABI (include/openea_hip.h).
+
+PyTorch is plumbing here: device allocations (``torch.empty(..., device='cuda')``), the
+current HIP stream and ``torch.distributed``.  All arithmetic happens inside
+libopenea_hip.so; nothing in this module computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LOSS_KIND, METRIC, OPT_KIND, StepCfg, check
+
+
+def lib():
+    return _lib.load(require_device=True)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pad4(d):
+    return (int(d) + 3) // 4 * 4
+
+
+def device(index=None):
+    lib()
+    return torch.device('cuda', torch.cuda.current_device() if index is None else index)
+
+
+# -------------------------------------------------------------------------------------------
+# tables
+# -------------------------------------------------------------------------------------------
+
+
+def to_table(array, ld=None, dev=None):
+    """host [n, d] (numpy / list) -> device fp32 [n, ld] zero-padded (ld % 4 == 0)."""
+    a = np.ascontiguousarray(np.asarray(array, dtype=np.float32))
+    assert a.ndim == 2
+    n, d = a.shape
+    ld = pad4(d) if ld is None else ld
+    t = torch.zeros((n, ld), dtype=torch.float32, device=dev or device())
+    if n:
+        t[:, :d].copy_(torch.from_numpy(a), non_blocking=False)
+    return t
+
+
+def to_vec(array, dev=None):
+    """host 1-D float array -> device fp32 vector."""
+    a = np.ascontiguousarray(np.asarray(array, dtype=np.float32)).reshape(-1)
+    return torch.from_numpy(a).to(dev or device())
+
+
+def to_ids(array, dev=None):
+    a = np.ascontiguousarray(np.asarray(array, dtype=np.int32))
+    return torch.from_numpy(a).to(dev or device())
+
+
+def gather_rows(table, dim, ids, normalize=False, out_ld=None):
+    """tf.nn.embedding_lookup(l2_normalize?(table), ids) -> device [n, out_ld]."""
+    n = ids.numel()
+    out_ld = pad4(dim) if out_ld is None else out_ld
+    out = torch.empty((n, out_ld), dtype=torch.float32, device=table.device)
+    check(lib().oea_gather_rows(_p(table), dim, table.shape[1], _p(ids), n, int(bool(normalize)),
+                                _p(out), out_ld, _stream()))
+    return out
+
+
+def normalize_rows_(table, dim, sklearn=True):
+    check(lib().oea_normalize_rows(_p(table), table.shape[0], dim, table.shape[1], int(bool(sklearn)), _stream()))
+    return table
+
+
+# -------------------------------------------------------------------------------------------
+# translational step
+# -------------------------------------------------------------------------------------------
+
+
+def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, neg_margin=0.0,
+                  balance=1.0, ent_l2_norm=True, rel_l2_norm=True, optimizer='Adagrad', lr=0.01):
+    return StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
+                   float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
+                   OPT_KIND[optimizer], float(lr))
+
+
+def step_workspace(n_ent, n_rel, ld, dev=None):
+    nbytes = lib().oea_step_workspace_bytes(n_ent, n_rel, ld)
+    return torch.zeros(nbytes, dtype=torch.uint8, device=dev or device())
+
+
+def triple_step(ent, ent_acc, rel, rel_acc, dim, pos, neg, cfg, workspace, loss_accum):
+    """One optimiser step in place; the batch loss is added to `loss_accum` (device f64[1])."""
+    n_neg = 0 if neg is None else neg.shape[0]
+    check(lib().oea_triple_step(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0],
+                                dim, ent.shape[1], _p(pos), pos.shape[0], _p(neg), n_neg,
+                                C.byref(cfg), _p(workspace), _p(loss_accum), _stream()))
+
+
+# -------------------------------------------------------------------------------------------
+# sampler
+# -------------------------------------------------------------------------------------------
+
+
+def tripleset_build(triples):
+    """device int32 [n,3] -> device uint64 table (viewed as int64)."""
+    n = triples.shape[0]
+    cap = lib().oea_tripleset_capacity(n)
+    table = torch.empty(cap, dtype=torch.int64, device=triples.device)
+    check(lib().oea_tripleset_build(_p(triples), n, _p(table), cap, _stream()))
+    return table
+
+
+def sample_negatives(pos, k, table, entity_list, ent_pos=None, nbr=None, seed=0, step=0,
+                     pos_offset=0, max_try=10, out=None, err_flag=None):
+    n_pos = pos.shape[0]
+    if out is None:
+        out = torch.empty((n_pos * k, 3), dtype=torch.int32, device=pos.device)
+    if err_flag is None:
+        err_flag = torch.zeros(1, dtype=torch.int32, device=pos.device)
+    nbr_k = 0 if nbr is None else nbr.shape[1]
+    check(lib().oea_sample_negatives(_p(pos), n_pos, k, _p(table), table.numel(), _p(entity_list),
+                                     entity_list.numel(), _p(ent_pos), _p(nbr), nbr_k, int(seed),
+                                     int(step), int(pos_offset), int(max_try), _p(out), _p(err_flag),
+                                     _stream()))
+    return out, err_flag
+
+
+# -------------------------------------------------------------------------------------------
+# neighbour search / evaluation
+# -------------------------------------------------------------------------------------------
+
+
+def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
+    nq, nc = q.shape[0], c.shape[0]
+    full = lib().oea_topk_workspace_bytes(nq, nc)
+    ws_bytes = full if ws_bytes is None else min(full, ws_bytes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    out = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+    check(lib().oea_topk_inner(_p(q), nq, q.shape[1], _p(c), nc, c.shape[1], dim, k, _p(id_map), _p(out),
+                               _p(ws), ws_bytes, _stream()))
+    return out
+
+
+def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None):
+    n1, n2 = e1.shape[0], e2.shape[0]
+    assert n1 <= n2, "gold of row i is column i: n1 <= n2"
+    ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
+    rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    check(lib().oea_rank_eval(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC[metric],
+                              _p(csls_r), _p(csls_c), _p(rank), _p(argmax), _p(ws), _stream()))
+    return rank, argmax
+
+
+def rank_metrics(rank, top_k):
+    """-> (hits counts list[int], rank_sum int, rr_sum float) with ONE device->host copy."""
+    nk = len(top_k)
+    tk = (C.c_int32 * nk)(*[int(k) for k in top_k])
+    buf = torch.zeros(nk + 2, dtype=torch.int64, device=rank.device)   # hits[nk], rank_sum, rr bits
+    check(lib().oea_rank_metrics(_p(rank), rank.numel(), tk, nk, C.c_void_p(buf.data_ptr()),
+                                 C.c_void_p(buf.data_ptr() + 8 * nk), C.c_void_p(buf.data_ptr() + 8 * (nk + 1)),
+                                 _stream()))
+    host = buf.cpu().numpy()
+    hits = [int(x) for x in host[:nk]]
+    return hits, int(host[nk]), float(host[nk + 1:nk + 2].view(np.float64)[0])
+
+
+def sim_matrix(e1, e2, dim, metric='inner'):
+    n1, n2 = e1.shape[0], e2.shape[0]
+    out = torch.empty((n1, n2), dtype=torch.float32, device=e1.device)
+    check(lib().oea_sim_matrix(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC[metric],
+                               _p(out), n2, _stream()))
+    return out
+
+
+def row_topk_mean(s, k):
+    out = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
+    check(lib().oea_row_topk_mean(_p(s), s.shape[0], s.shape[1], s.stride(0), k, _p(out), _stream()))
+    return out
+
+
+def csls_apply_(s, r, c):
+    check(lib().oea_csls_apply(_p(s), s.shape[0], s.shape[1], s.stride(0), _p(r), _p(c), _stream()))
+    return s
+
+
+# -------------------------------------------------------------------------------------------
+# graph aggregate
+# -------------------------------------------------------------------------------------------
+
+
+def spmm_csr(rowptr, colidx, vals, x, dim, act=0, mask_from=None, out=None):
+    n_rows = rowptr.numel() - 1
+    if out is None:
+        out = torch.empty((n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib().oea_spmm_csr(_p(rowptr), _p(colidx), _p(vals), n_rows, _p(x), dim, x.shape[1], int(act),
+                             _p(mask_from), _p(out), out.shape[1], _stream()))
+    return out
+
+
+def align_loss_l1(out_emb, dim, ill, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum):
+    check(lib().oea_align_loss_l1(_p(out_emb), out_emb.shape[0], dim, out_emb.shape[1], _p(ill), ill.shape[0],
+                                  k, float(gamma), _p(neg_left), _p(neg_right), _p(neg2_left), _p(neg2_right),
+                                  _p(grad), _p(loss_accum), _stream()))
+
+
+def sgd_rows_(w, grad_t, dim, normalize, lr):
+    check(lib().oea_sgd_rows(_p(w), _p(grad_t), w.shape[0], dim, w.shape[1], int(bool(normalize)), float(lr), _stream()))
+    return w
