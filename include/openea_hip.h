@@ -41,6 +41,13 @@ const char *oea_last_error(void);
 /* number of visible HIP devices, <0 on error (used by the host side to fail loudly) */
 int oea_device_count(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figure; no reference counterpart).  Between begin and end, every oea_triple_step
+ * records 3 marks: [fwd_bwd kernel][apply kernel].  oea_profile_end(3, ms, &n) returns
+ * ms[0] = total fwd_bwd time, ms[1] = total apply time (milliseconds) over n calls. */
+int oea_profile_begin(void);
+int oea_profile_end(int32_t group, double *out_ms_host, int32_t *n_calls_host);
+
 /* ---------------------------------------------------------------------------------------
  * Embedding store -- replaces the tf.Variable tables of BasicModel._define_variables
  * (models/basic_model.py:73-78) and their .eval() round trips (basic_model.py:106-121,
@@ -105,6 +112,19 @@ int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float
                     int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
                     const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                     double *loss_accum, void *stream);
+
+/* The same step split at its one exchange point, for entity-table data parallelism
+ * (no reference counterpart: the reference is single-device).  OEA_PHASE_GRAD only fills the
+ * gradient scratch + touched flags (the first oea_step_exchange_floats() floats of the
+ * workspace, one contiguous fp32 region that the host sums across ranks with ONE RCCL
+ * all-reduce); OEA_PHASE_APPLY then runs the optimiser on every rank, so the replicas stay
+ * bit-identical.  n_pos / n_neg must be repeated unchanged in the APPLY call. */
+enum { OEA_PHASE_BOTH = 0, OEA_PHASE_GRAD = 1, OEA_PHASE_APPLY = 2 };
+size_t oea_step_exchange_floats(int64_t n_ent, int64_t n_rel, int32_t ld);
+int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
+                          int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
+                          const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
+                          double *loss_accum, int32_t phase, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Negative sampling -- replaces generate_neg_triples_fast (modules/train/batch.py:89-119).

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "oea_version": (C.c_int, []),
     "oea_last_error": (C.c_char_p, []),
     "oea_device_count": (C.c_int, []),
+    "oea_profile_begin": (C.c_int, []),
+    "oea_profile_end": (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "oea_store_create": (C.c_int, [_i64, _i32, C.POINTER(_vp)]),
     "oea_store_destroy": (C.c_int, [_vp]),
     "oea_store_rows": (_i64, [_vp]),
@@ -48,6 +50,9 @@ PROTOTYPES = {
     "oea_step_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oea_triple_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
                                   C.POINTER(StepCfg), _vp, _vp, _vp]),
+    "oea_step_exchange_floats": (_sz, [_i64, _i64, _i32]),
+    "oea_triple_step_phase": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
+                                        C.POINTER(StepCfg), _vp, _vp, _i32, _vp]),
     "oea_tripleset_capacity": (_u64, [_i64]),
     "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
     "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,

@@ -10,6 +10,10 @@ namespace oea {
 
 void set_error(const char *fmt, ...);
 
+// optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+bool prof_enabled();
+void prof_mark(hipStream_t st);   // records the next event of the current profile session
+
 #define OEA_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

@@ -62,15 +62,19 @@ __global__ __launch_bounds__(64) void sample_negatives_kernel(
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pos) return;
     const int32_t h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
-    const int32_t *hc = nbr ? nbr + (int64_t)ent_pos[h] * nbr_k : entity_list;
-    const int32_t *tc = nbr ? nbr + (int64_t)ent_pos[t] * nbr_k : entity_list;
-    const int nc = nbr ? nbr_k : n_ent_list;
+    // neighbor.get(e, entities_list): entities without a neighbour row (e.g. the other KG's
+    // entities inside seed-swapped triples, kgs.py:45-50) fall back to the whole entity list
+    const bool h_has = nbr && ent_pos[h] >= 0, t_has = nbr && ent_pos[t] >= 0;
+    const int32_t *hc = h_has ? nbr + (int64_t)ent_pos[h] * nbr_k : entity_list;
+    const int32_t *tc = t_has ? nbr + (int64_t)ent_pos[t] * nbr_k : entity_list;
+    const int hn = h_has ? nbr_k : n_ent_list, tn = t_has ? nbr_k : n_ent_list;
     int got = 0;
     const uint32_t c0 = (uint32_t)p + pos_offset;
     for (int tr = 0; tr < max_try && got < k; ++tr) {
         uint4 w = oea::philox4x32_10(c0, step, (uint32_t)tr, 0u, k0, k1);
         const bool corrupt_head = (w.x & 1u) != 0u;
         const int32_t *cand = corrupt_head ? hc : tc;
+        const int nc = corrupt_head ? hn : tn;
         const int need = k - got;
         if (need > nc) { *err_flag = 1; return; }   // random.sample would raise ValueError
         uint32_t draw = 1;
@@ -125,7 +129,7 @@ int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uin
     OEA_REQUIRE(k >= 1 && k <= kMaxK, "1 <= k <= 64");
     OEA_REQUIRE(max_try >= 1, "max_try >= 1");
     OEA_REQUIRE(nbr == nullptr || (ent_pos != nullptr && nbr_k > 0), "nbr needs ent_pos and nbr_k");
-    OEA_REQUIRE((nbr ? nbr_k : n_ent_list) >= k, "Sample larger than population");
+    OEA_REQUIRE((nbr ? nbr_k : n_ent_list) >= k && n_ent_list >= k, "Sample larger than population");
     if (n_pos == 0) return OEA_OK;
     sample_negatives_kernel<<<(unsigned)oea::ceil_div(n_pos, 64), 64, 0, oea::as_stream(stream)>>>(
         pos, n_pos, k, table, capacity, entity_list, n_ent_list, ent_pos, nbr, nbr_k, (uint32_t)seed,

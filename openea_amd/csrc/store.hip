@@ -16,6 +16,20 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+static bool g_prof = false;
+static std::vector<hipEvent_t> g_events;
+static size_t g_nmarks = 0;
+bool prof_enabled() { return g_prof; }
+void prof_mark(hipStream_t st) {
+    if (!g_prof) return;
+    if (g_nmarks == g_events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        g_events.push_back(e);
+    }
+    (void)hipEventRecord(g_events[g_nmarks++], st);
+}
 }  // namespace oea
 
 struct oea_store {
@@ -32,6 +46,30 @@ int oea_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
     return n;
+}
+
+int oea_profile_begin(void) {
+    oea::g_prof = true;
+    oea::g_nmarks = 0;
+    return OEA_OK;
+}
+/* marks come in groups of `group` consecutive events per profiled call; out_ms[j] receives the
+ * SUM over calls of the time between mark j and mark j+1 of each group (j < group-1). */
+int oea_profile_end(int32_t group, double *out_ms_host, int32_t *n_calls_host) {
+    oea::g_prof = false;
+    OEA_REQUIRE(group >= 2 && out_ms_host && n_calls_host, "group >= 2");
+    const size_t n = oea::g_nmarks / (size_t)group;
+    for (int j = 0; j < group - 1; ++j) out_ms_host[j] = 0.0;
+    if (n > 0) OEA_CHECK_HIP(hipEventSynchronize(oea::g_events[n * group - 1]));
+    for (size_t i = 0; i < n; ++i)
+        for (int j = 0; j < group - 1; ++j) {
+            float ms = 0.f;
+            OEA_CHECK_HIP(hipEventElapsedTime(&ms, oea::g_events[i * group + j], oea::g_events[i * group + j + 1]));
+            out_ms_host[j] += (double)ms;
+        }
+    *n_calls_host = (int32_t)n;
+    oea::g_nmarks = 0;
+    return OEA_OK;
 }
 
 int oea_store_create(int64_t rows, int32_t dim, oea_store_t *out) {

@@ -25,7 +25,7 @@ using oea::group_sum;
 
 struct StepWs {
     float *ent_grad, *rel_grad;
-    int32_t *ent_touched, *rel_touched;
+    float *ent_touched, *rel_touched;   // 1.0f = row received gradient (float so one SUM all-reduce covers grads + flags)
     double *partials;   // [kMaxBlocks]
 };
 constexpr int kMaxBlocks = 4096;
@@ -38,8 +38,8 @@ static size_t ws_layout(int64_t n_ent, int64_t n_rel, int32_t ld, void *base, St
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return b ? b + o : nullptr; };
     float *eg = (float *)take(sizeof(float) * (size_t)n_ent * ld);
     float *rg = (float *)take(sizeof(float) * (size_t)n_rel * ld);
-    int32_t *et = (int32_t *)take(sizeof(int32_t) * (size_t)n_ent);
-    int32_t *rt = (int32_t *)take(sizeof(int32_t) * (size_t)n_rel);
+    float *et = (float *)take(sizeof(float) * (size_t)n_ent);
+    float *rt = (float *)take(sizeof(float) * (size_t)n_rel);
     double *pp = (double *)take(sizeof(double) * kMaxBlocks);
     if (ws) { ws->ent_grad = eg; ws->rel_grad = rg; ws->ent_touched = et; ws->rel_touched = rt; ws->partials = pp; }
     return off;
@@ -101,7 +101,7 @@ __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f 
 // scatter coef * ds/d(delta) into the gradient scratch: +h, +r, -t.
 template <int G, int IT>
 __device__ __forceinline__ void scatter_grad(float *__restrict__ eg, float *__restrict__ rg,
-                                             int32_t *__restrict__ et, int32_t *__restrict__ rt, int ld,
+                                             float *__restrict__ et, float *__restrict__ rt, int ld,
                                              int lane, int h, int r, int t, float coef, int l1,
                                              const Row<G, IT> &delta) {
     float *gh = eg + (int64_t)h * ld, *gr = rg + (int64_t)r * ld, *gt = eg + (int64_t)t * ld;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void scatter_grad(float *__restrict__ eg, float *__re
             }
         }
     }
-    if (lane == 0) { et[h] = 1; et[t] = 1; rt[r] = 1; }
+    if (lane == 0) { et[h] = 1.f; et[t] = 1.f; rt[r] = 1.f; }
 }
 
 __device__ __forceinline__ float softplusf_(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
     for (int64_t row_all = grp; row_all < n_ent + n_rel; row_all += ngrp) {
         const bool is_rel = row_all >= n_ent;
         const int64_t row = is_rel ? row_all - n_ent : row_all;
-        int32_t *touched = is_rel ? ws.rel_touched : ws.ent_touched;
-        if (touched[row] == 0) continue;
+        float *touched = is_rel ? ws.rel_touched : ws.ent_touched;
+        if (touched[row] == 0.f) continue;
         float *v = (is_rel ? rel : ent) + row * ld;
         float *acc = (is_rel ? rel_acc : ent_acc) + row * ld;
         float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
                 oea::st4(g + c, make_float4(0.f, 0.f, 0.f, 0.f));
             }
         }
-        if (lane == 0) touched[row] = 0;
+        if (lane == 0) touched[row] = 0.f;
     }
     // fixed-order reduction of the loss partials by one wave of block 0
     if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -266,13 +266,18 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
 template <int G, int IT>
 int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
-                const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, hipStream_t st) {
+                const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
     const int64_t items = cfg.loss_kind == OEA_LOSS_MARGIN ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
-    triple_fwd_bwd<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+    oea::prof_mark(st);
+    if (phase != OEA_PHASE_APPLY)
+        triple_fwd_bwd<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+    oea::prof_mark(st);
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
-    apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum);
+    if (phase != OEA_PHASE_GRAD)
+        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum);
+    oea::prof_mark(st);
     return 0;
 }
 
@@ -284,10 +289,25 @@ size_t oea_step_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld) {
     return ws_layout(n_ent, n_rel, ld, nullptr, nullptr);
 }
 
+size_t oea_step_exchange_floats(int64_t n_ent, int64_t n_rel, int32_t ld) {
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, reinterpret_cast<void *>(256), &ws);   // fake base: only offsets matter
+    return (size_t)(reinterpret_cast<char *>(ws.partials) - reinterpret_cast<char *>(256)) / sizeof(float);
+}
+
 int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
                     int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
                     const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                     double *loss_accum, void *stream) {
+    return oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n_pos, neg, n_neg, cfg,
+                                 workspace, loss_accum, OEA_PHASE_BOTH, stream);
+}
+
+int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
+                          int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
+                          const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
+                          double *loss_accum, int32_t phase, void *stream) {
+    OEA_REQUIRE(phase >= OEA_PHASE_BOTH && phase <= OEA_PHASE_APPLY, "phase");
     OEA_REQUIRE(ent && rel && pos && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(ld % 4 == 0 && dim <= ld && dim > 0, "ld % 4 == 0 and dim <= ld");
     OEA_REQUIRE(n_pos >= 0 && n_neg >= 0 && (neg || n_neg == 0), "neg == NULL needs n_neg == 0");
@@ -301,7 +321,7 @@ int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     hipStream_t st = oea::as_stream(stream);
-#define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, st)
+#define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, phase, st)
     if (ld <= 64) OEA_STEP(16, 1);
     else if (ld <= 128) OEA_STEP(32, 1);
     else if (ld <= 256) OEA_STEP(64, 1);

@@ -1,0 +1,152 @@
+"""Device-resident epoch engine for the translational path.
+
+This is what replaces the reference's producer processes + queue + feed_dict +
+``session.run([triple_loss, triple_optimizer])`` loop
+(``BasicModel.launch_triple_training_1epo``, models/basic_model.py:211-236): positives,
+triple membership set, neighbour lists, tables, optimiser state and the loss accumulator all
+live in HBM; one step = two sampler launches (KG1, KG2 -- batch.py:36-45) + the fused step.
+
+Multi-GPU (torch.distributed, backend nccl = RCCL): tables are replicated, each rank scores
+its own slice of every batch, the gradient scratch is summed with ONE all-reduce per step and
+every rank applies the identical optimiser update (include/openea_hip.h: OEA_PHASE_*), which
+equals the single-GPU step on the concatenated batch.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..modules.train.batch import EpochBatches, TripleSampler, neighbours_device
+
+
+class EmbeddingTable:
+    """A trainable table: raw variable [rows, ld] on the device + the l2_norm flag that the
+    reference bakes into the tensor returned by init_embeddings (initializers.py:26)."""
+
+    def __init__(self, host_init, is_l2_norm, name, dev=None):
+        host_init = np.asarray(host_init, np.float32)
+        self.name = name
+        self.rows, self.dim = host_init.shape
+        self.is_l2_norm = bool(is_l2_norm)
+        self.var = ops.to_table(host_init, dev=dev)          # [rows, ld], pad columns zero
+        self.ld = self.var.shape[1]
+
+    def lookup(self, ids):
+        """tf.nn.embedding_lookup(self, ids) -> device [n, ld] (normalised when l2_norm)."""
+        if not hasattr(ids, "is_cuda"):
+            ids = ops.to_ids(np.asarray(ids, np.int32), self.var.device)
+        return ops.gather_rows(self.var, self.dim, ids, normalize=self.is_l2_norm)
+
+    def eval(self, session=None):
+        """`.eval(session=...)` of the reference: the (normalised) table on the host [rows, dim]."""
+        ids = torch.arange(self.rows, dtype=torch.int32, device=self.var.device)
+        return self.lookup(ids)[:, :self.dim].cpu().numpy()
+
+    def raw(self):
+        return self.var[:, :self.dim].cpu().numpy()
+
+
+class TripleTrainer:
+    def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None):
+        self.ent, self.rel, self.cfg = ent, rel, cfg
+        dev = ent.var.device
+        self.dev = dev
+        if optimizer == 'Adagrad':        # tf.train.AdagradOptimizer: initial_accumulator_value = 0.1
+            self.ent_acc = torch.full_like(ent.var, 0.1)
+            self.rel_acc = torch.full_like(rel.var, 0.1)
+        else:
+            self.ent_acc = self.rel_acc = None
+        self.ws = ops.step_workspace(ent.rows, rel.rows, ent.ld, dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.dist = dist_group
+        self.xchg = ops.step_exchange_view(self.ws, ent.rows, rel.rows, ent.ld) if dist_group is not None else None
+
+    def step(self, pos, neg):
+        """pos / neg: device int32 [n,3] (neg may be None)."""
+        if self.dist is None:
+            ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
+                            self.ws, self.loss)
+        else:
+            import torch.distributed as dist
+            ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
+                            self.ws, self.loss, phase=ops.PHASE_GRAD)
+            dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
+            ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
+                            self.ws, self.loss, phase=ops.PHASE_APPLY)
+
+    def pop_loss(self):
+        """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data
+        parallelism every rank holds the loss of its own slices; they are summed here."""
+        if self.dist is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.loss, op=dist.ReduceOp.SUM, group=self.dist)
+        v = float(self.loss.item())
+        self.loss.zero_()
+        return v
+
+
+class RelationTripleEpochs:
+    """Positives + samplers of both KGs for the (pos, neg) relation-triple batches of
+    generate_relation_triple_batch (batch.py:36-45)."""
+
+    def __init__(self, kgs, batch_size, neg_triple_num, seed=0, dev=None, rank=0, world=1):
+        self.kgs = kgs
+        self.dev = dev or ops.device()
+        self.batch_size, self.k = batch_size, neg_triple_num
+        self.rank, self.world = rank, world
+        self.seed = seed
+        self.rng = np.random.RandomState(seed)
+        self.batches = EpochBatches(kgs.kg1.relation_triples_list, kgs.kg2.relation_triples_list, batch_size, self.dev)
+        n_total = kgs.entities_num
+        self.s1 = TripleSampler(kgs.kg1.relation_triples_set, kgs.kg1.entities_list, n_total, self.dev)
+        self.s2 = TripleSampler(kgs.kg2.relation_triples_set, kgs.kg2.entities_list, n_total, self.dev)
+        triples_num = len(self.batches.t1) + len(self.batches.t2)
+        self.triple_steps = int(np.ceil(triples_num / batch_size))      # basic_model.py:255
+        self.global_step = 0
+        b = self.batches
+        self.neg_buf = torch.empty(((b.b1 + b.b2) * max(self.k, 1), 3), dtype=torch.int32, device=self.dev)
+        self.pos_buf = torch.empty((b.b1 + b.b2, 3), dtype=torch.int32, device=self.dev)
+
+    def set_neighbours(self, nbr1, nbr2):
+        self.s1.set_neighbours(nbr1)
+        self.s2.set_neighbours(nbr2)
+
+    def _shard(self, t):
+        """this rank's contiguous share of a slice of positives (data parallelism)."""
+        if self.world == 1:
+            return t
+        n = t.shape[0]
+        lo = n * self.rank // self.world
+        hi = n * (self.rank + 1) // self.world
+        return t[lo:hi]
+
+    def batch(self, step):
+        """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch."""
+        p1, p2 = self.batches.pos(step)
+        p1, p2 = self._shard(p1), self._shard(p2)
+        n1, n2 = p1.shape[0], p2.shape[0]
+        pos = self.pos_buf[: n1 + n2]
+        pos[:n1].copy_(p1)
+        pos[n1:].copy_(p2)
+        neg = None
+        if self.k > 0:
+            neg = self.neg_buf[: (n1 + n2) * self.k]
+            off = self.rank * (self.batches.b1 + self.batches.b2)    # distinct Philox streams per rank
+            if n1:
+                self.s1.sample(p1, self.k, self.seed, self.global_step, pos_offset=off, out=neg[: n1 * self.k])
+            if n2:
+                self.s2.sample(p2, self.k, self.seed, self.global_step, pos_offset=off + n1, out=neg[n1 * self.k:])
+        self.global_step += 1
+        return pos, neg
+
+    def end_epoch(self):
+        self.batches.shuffle(self.rng)      # basic_model.py:234-235
+        self.s1.check()
+        self.s2.check()
+
+
+def refresh_neighbours(ent, entity_list, k):
+    """Truncated-sampling refresh (basic_model.py:267-289): embeddings of the KG's entities
+    (normalised lookup) -> k nearest entity ids per entity, all on the device."""
+    ids = ops.to_ids(np.asarray(entity_list, np.int32), ent.var.device)
+    emb = ent.lookup(ids)
+    return neighbours_device(emb, ent.dim, ids, k)

@@ -1,0 +1,83 @@
+"""Greedy alignment search + Hits@k / MR / MRR (mirror of openea/modules/finding/alignment.py).
+
+The N1 x N2 similarity matrix is never written: the rank of the gold column and the argmax are
+counted inside the similarity tiles (csrc/sim_rank.hip).  Ranks are exact in BOTH modes -- the
+reference's quick mode (accurate=False) only trusts Hits@k and leaves MR/MRR to
+argpartition's internal order (alignment.py:157-162); Hits@k agree in both.
+"""
+import time
+
+import numpy as np
+
+from ... import ops
+from .similarity import csls_means_device, device_metric
+
+
+def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
+    """device [n1, ld], [n2, ld] (gold of row i = row i of t2) ->
+    (rank int32[n1] device, argmax int32[n1] device, hits counts, rank_sum, rr_sum)."""
+    kmetric, norm = device_metric(metric, normalize)
+    if norm:
+        t1, t2 = t1.clone(), t2.clone()
+        ops.normalize_rows_(t1, dim, sklearn=True)
+        ops.normalize_rows_(t2, dim, sklearn=True)
+    r = c = None
+    if csls_k > 0:
+        r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
+    rank, argmax = ops.rank_eval(t1, t2, dim, kmetric, r, c)
+    hits, rank_sum, rr_sum = ops.rank_metrics(rank, top_k)
+    return rank, argmax, hits, rank_sum, rr_sum
+
+
+def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
+    """alignment.py:13-84: same arguments, same return (alignment_rest, hits1, mr, mrr), same
+    log lines.  `nums_threads` is accepted and ignored (it only forked host workers)."""
+    t = time.time()
+    assert 1 in top_k
+    e1 = embed1 if hasattr(embed1, "is_cuda") else ops.to_table(np.asarray(embed1, np.float32))
+    e2 = embed2 if hasattr(embed2, "is_cuda") else ops.to_table(np.asarray(embed2, np.float32))
+    dim = embed1.shape[1] if not hasattr(embed1, "is_cuda") else getattr(embed1, "oea_dim", embed1.shape[1])
+    num = e1.shape[0]
+    rank, argmax, hits_cnt, rank_sum, rr_sum = greedy_alignment_device(e1, e2, dim, top_k, metric, normalize, csls_k)
+    am = argmax.cpu().numpy()
+    alignment_rest = set(zip(range(num), am.tolist()))
+    assert len(alignment_rest) == num
+    hits = np.array(hits_cnt) / num * 100
+    for i in range(len(hits)):
+        hits[i] = round(hits[i], 3)
+    mr = rank_sum / num
+    mrr = rr_sum / num
+    cost = time.time() - t
+    if accurate:
+        if csls_k > 0:
+            print("accurate results with csls: csls={}, hits@{} = {}%, mr = {:.3f}, mrr = {:.6f}, time = {:.3f} s ".
+                  format(csls_k, top_k, hits, mr, mrr, cost))
+        else:
+            print("accurate results: hits@{} = {}%, mr = {:.3f}, mrr = {:.6f}, time = {:.3f} s ".
+                  format(top_k, hits, mr, mrr, cost))
+    else:
+        if csls_k > 0:
+            print("quick results with csls: csls={}, hits@{} = {}%, time = {:.3f} s ".format(csls_k, top_k, hits, cost))
+        else:
+            print("quick results: hits@{} = {}%, time = {:.3f} s ".format(top_k, hits, cost))
+    greedy_alignment.last = dict(rank=rank, argmax=argmax, hits_cnt=hits_cnt, rank_sum=rank_sum, rr_sum=rr_sum)
+    return alignment_rest, hits[0], mr, mrr
+
+
+def calculate_rank(idx, sim_mat, top_k, accurate, total_num):
+    """alignment.py:146-168 on an explicit row block of a similarity matrix (host arrays):
+    gold of row i is column idx[i]."""
+    import torch
+    assert 1 in top_k
+    s = torch.from_numpy(np.ascontiguousarray(sim_mat, np.float32)).to(ops.device())
+    idx_t = torch.as_tensor(np.asarray(idx, np.int64), device=s.device)
+    gold = s.gather(1, idx_t.view(-1, 1))
+    cols = torch.arange(s.shape[1], device=s.device).view(1, -1)
+    rank = ((s > gold) | ((s == gold) & (cols < idx_t.view(-1, 1)))).sum(1)
+    argmax = s.argmax(1)
+    rank_h = rank.cpu().numpy().astype(np.int64)
+    mr = float((rank_h + 1).sum()) / total_num
+    mrr = float((1.0 / (rank_h + 1)).sum()) / total_num
+    hits = [int((rank_h < k).sum()) for k in top_k]
+    hits1_rest = {(int(idx[i]), int(a)) for i, a in enumerate(argmax.cpu().numpy())}
+    return mr, mrr, hits, hits1_rest

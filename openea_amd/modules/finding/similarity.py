@@ -1,0 +1,93 @@
+"""Pairwise similarity + CSLS (mirror of openea/modules/finding/similarity.py).
+
+``sim`` keeps the reference signature (numpy in, numpy N1 x N2 float32 out) for callers that
+want the matrix; evaluation does NOT go through it (``alignment.greedy_alignment`` never
+materialises the matrix).  The device-resident entry points take / return torch tensors.
+"""
+import numpy as np
+
+from ... import ops
+
+
+def _prepare(embed, normalize):
+    """host [n, d] -> device [n, ld]; optional sklearn row-L2 normalisation (similarity.py:32-33)."""
+    t = embed if hasattr(embed, "is_cuda") else ops.to_table(embed)
+    return t
+
+
+def device_metric(metric, normalize):
+    """Map the reference's (metric, normalize) switch (similarity.py:34-51) onto a kernel metric
+    and an extra row normalisation.  'cosine' without normalize is 1 - cdist(cosine) = the
+    inner product of the L2-normalised rows."""
+    if metric == 'inner':
+        return 'inner', normalize
+    if metric == 'cosine':
+        return 'inner', True
+    if metric == 'euclidean':
+        return 'euclidean', normalize
+    if metric == 'manhattan':
+        return 'manhattan', normalize
+    raise ValueError("unsupported metric %r (inner / cosine / euclidean / manhattan)" % (metric,))
+
+
+def sim_device(t1, t2, dim, metric='inner', normalize=False, csls_k=0, inplace_ok=False):
+    """device [n1, ld], [n2, ld] -> device [n1, n2] similarity (similarity.py:11-54)."""
+    kmetric, norm = device_metric(metric, normalize)
+    if norm:
+        if not inplace_ok:
+            t1, t2 = t1.clone(), t2.clone()
+        ops.normalize_rows_(t1, dim, sklearn=True)
+        ops.normalize_rows_(t2, dim, sklearn=True)
+    s = ops.sim_matrix(t1, t2, dim, kmetric)
+    if csls_k > 0:
+        st = ops.sim_matrix(t2, t1, dim, kmetric)
+        r = ops.row_topk_mean(s, csls_k)
+        c = ops.row_topk_mean(st, csls_k)
+        del st
+        ops.csls_apply_(s, r, c)
+    return s
+
+
+def sim(embed1, embed2, metric='inner', normalize=False, csls_k=0):
+    """similarity.py:11-54: returns the n1 x n2 float32 matrix on the host."""
+    embed1 = np.asarray(embed1, dtype=np.float32)
+    embed2 = np.asarray(embed2, dtype=np.float32)
+    d = embed1.shape[1]
+    s = sim_device(ops.to_table(embed1), ops.to_table(embed2), d, metric, normalize, csls_k, inplace_ok=True)
+    return s.cpu().numpy()
+
+
+def calculate_nearest_k(sim_mat, k):
+    """similarity.py:80-83: mean of the k largest entries of each row."""
+    s = ops.to_table(np.asarray(sim_mat, np.float32), ld=np.asarray(sim_mat).shape[1])
+    return ops.row_topk_mean(s, k).cpu().numpy()
+
+
+def csls_sim(sim_mat, k):
+    """similarity.py:57-77."""
+    sim_mat = np.ascontiguousarray(sim_mat, dtype=np.float32)
+    n2 = sim_mat.shape[1]
+    import torch
+    s = torch.from_numpy(sim_mat).to(ops.device())
+    st = s.t().contiguous()
+    r = ops.row_topk_mean(s, k)
+    c = ops.row_topk_mean(st, k)
+    ops.csls_apply_(s, r, c)
+    return s.cpu().numpy()
+
+
+def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30):
+    """Per-row and per-column top-k means WITHOUT holding the whole matrix: strips of rows of S
+    and of S^T are produced and reduced one after the other (each strip <= max_bytes)."""
+    import torch
+
+    def strip_means(a, b):
+        n, m = a.shape[0], b.shape[0]
+        rows_per = max(128, int(max_bytes // (4 * m)) // 128 * 128)
+        out = torch.empty(n, dtype=torch.float32, device=a.device)
+        for r0 in range(0, n, rows_per):
+            s = ops.sim_matrix(a[r0:r0 + rows_per], b, dim, kmetric)
+            out[r0:r0 + rows_per] = ops.row_topk_mean(s, k)
+            del s
+        return out
+    return strip_means(t1, t2), strip_means(t2, t1)

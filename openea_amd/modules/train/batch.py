@@ -1,0 +1,215 @@
+"""Batching, negative sampling and neighbour search (mirror of openea/modules/train/batch.py).
+
+Two layers:
+
+* the reference's function signatures (python lists / dicts in and out) -- a drop-in for code
+  that calls ``bat.generate_*`` -- which convert at the edge and run the HIP kernels;
+* device-resident objects (``TripleSampler``, ``EpochBatches``) used by ``BasicModel`` so that
+  nothing crosses PCIe inside an epoch.
+
+There is no CPU implementation here: without libopenea_hip.so / a GPU every sampling or search
+call raises ``OpenEAHipError``.
+"""
+import numpy as np
+import torch
+
+from .. import _seed
+from ... import ops
+from ..utils.util import merge_dic, task_divide
+
+# ----------------------------------------------------------------------------------------------
+# positive batching (pure index arithmetic, batch.py:17-22, 48-57)
+# ----------------------------------------------------------------------------------------------
+
+
+def batch_sizes(n1, n2, batch_size):
+    """batch.py:18-19: b1 = int(n1 / (n1 + n2) * B) in python float arithmetic, b2 = B - b1."""
+    b1 = int(n1 / (n1 + n2) * batch_size)
+    return b1, batch_size - b1
+
+
+def generate_pos_triples(triples, batch_size, step, is_fixed_size=False):
+    """batch.py:48-57: the contiguous slice [step*b, step*b + b) of the (shuffled) list."""
+    start = step * batch_size
+    end = min(start + batch_size, len(triples))
+    pos_batch = triples[start:end]
+    if is_fixed_size and len(pos_batch) < batch_size:
+        pos_batch = pos_batch + triples[:batch_size - len(pos_batch)]
+    return pos_batch
+
+
+def generate_pos_batch(triple_list1, triple_list2, batch_size, step):
+    """batch.py:17-22."""
+    b1, b2 = batch_sizes(len(triple_list1), len(triple_list2), batch_size)
+    return generate_pos_triples(triple_list1, b1, step) + generate_pos_triples(triple_list2, b2, step)
+
+
+def generate_pos_batch_queue(triple_list1, triple_list2, batch_size, steps, out_queue):
+    """batch.py:11-14 (kept for callers that still run a producer; the model does not)."""
+    for step in steps:
+        out_queue.put(generate_pos_batch(triple_list1, triple_list2, batch_size, step))
+
+
+# ----------------------------------------------------------------------------------------------
+# device-resident sampler
+# ----------------------------------------------------------------------------------------------
+
+
+class TripleSampler:
+    """Device state replacing (all_triples_set, entities_list, neighbor) of
+    generate_neg_triples_fast (batch.py:89-119) for ONE KG."""
+
+    def __init__(self, triples_set, entities_list, num_entities_total=None, dev=None):
+        dev = dev or ops.device()
+        tri = np.asarray(sorted(triples_set) if not isinstance(triples_set, np.ndarray) else triples_set,
+                         dtype=np.int32).reshape(-1, 3)
+        self.n_triples = len(tri)
+        self.entity_list = ops.to_ids(np.asarray(entities_list, np.int32), dev)
+        n_total = int(num_entities_total if num_entities_total is not None else (max(entities_list) + 1))
+        ent_pos = np.full(n_total, -1, np.int32)
+        ent_pos[np.asarray(entities_list, np.int64)] = np.arange(len(entities_list), dtype=np.int32)
+        self.ent_pos = ops.to_ids(ent_pos, dev)
+        self.table = ops.tripleset_build(ops.to_ids(tri, dev))
+        self.nbr = None                       # int32 [N, k] entity ids; row = position in entity_list
+        self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def set_neighbours(self, nbr):
+        """nbr: device int32 [len(entity_list), k] (rows in entity_list order) or None."""
+        self.nbr = nbr
+
+    def sample(self, pos, k, seed, step, pos_offset=0, out=None, max_try=10):
+        """pos: device int32 [n,3] -> device int32 [n*k, 3]."""
+        out, _ = ops.sample_negatives(pos, k, self.table, self.entity_list, self.ent_pos, self.nbr, seed=seed,
+                                      step=step, pos_offset=pos_offset, max_try=max_try, out=out, err_flag=self.err)
+        return out
+
+    def check(self):
+        if int(self.err.item()) != 0:
+            raise ValueError("Sample larger than population or is negative")   # random.sample's error
+
+
+class EpochBatches:
+    """All positive batches of one epoch, resident in HBM.  batch `step` is the concatenation of
+    KG1's slice [step*b1, ...) and KG2's slice [step*b2, ...) exactly as generate_pos_batch
+    builds it (batch.py:17-22); the arrays are re-uploaded after each epoch's shuffle
+    (basic_model.py:234-235)."""
+
+    def __init__(self, triples1, triples2, batch_size, dev=None):
+        self.dev = dev or ops.device()
+        self.t1 = np.asarray(triples1, np.int32).reshape(-1, 3)
+        self.t2 = np.asarray(triples2, np.int32).reshape(-1, 3)
+        self.b1, self.b2 = batch_sizes(len(self.t1), len(self.t2), batch_size)
+        self.upload()
+
+    def upload(self):
+        self.d1 = ops.to_ids(self.t1, self.dev)
+        self.d2 = ops.to_ids(self.t2, self.dev)
+
+    def shuffle(self, rng):
+        """random.shuffle of both lists (basic_model.py:234-235) with a seeded numpy RNG."""
+        self.t1 = self.t1[rng.permutation(len(self.t1))]
+        self.t2 = self.t2[rng.permutation(len(self.t2))]
+        self.upload()
+
+    def pos(self, step):
+        s1 = self.d1[step * self.b1: step * self.b1 + self.b1]
+        s2 = self.d2[step * self.b2: step * self.b2 + self.b2]
+        return s1, s2
+
+
+# ----------------------------------------------------------------------------------------------
+# reference-signature wrappers
+# ----------------------------------------------------------------------------------------------
+_sampler_cache = {}
+
+
+def _cached_sampler(all_triples_set, entities_list):
+    key = (id(all_triples_set), id(entities_list), len(all_triples_set), len(entities_list))
+    s = _sampler_cache.get(key)
+    if s is None:
+        if len(_sampler_cache) > 8:
+            _sampler_cache.clear()
+        s = TripleSampler(all_triples_set, entities_list)
+        _sampler_cache[key] = s
+    return s
+
+
+def generate_neg_triples_fast(pos_batch, all_triples_set, entities_list, neg_triples_num, neighbor=None, max_try=10):
+    """Drop-in for batch.py:89-119: same arguments, returns a list of (h, r, t) tuples of length
+    neg_triples_num * len(pos_batch) (negatives of positive p at [p*k, (p+1)*k)).
+    The draws come from the device Philox stream (seed: openea_amd.modules.set_seed)."""
+    if len(pos_batch) == 0:
+        return []
+    sampler = _cached_sampler(all_triples_set, entities_list)
+    if neighbor:
+        k_n = len(next(iter(neighbor.values())))
+        nbr = np.empty((len(entities_list), k_n), np.int32)
+        for i, e in enumerate(entities_list):
+            nbr[i] = neighbor.get(e, entities_list[:k_n])
+        sampler.set_neighbours(ops.to_ids(nbr))
+    else:
+        sampler.set_neighbours(None)
+    pos = ops.to_ids(np.asarray(pos_batch, np.int32).reshape(-1, 3))
+    out = sampler.sample(pos, neg_triples_num, _seed.get_seed(), _seed.next_call(), max_try=max_try)
+    sampler.check()
+    neg = out.cpu().numpy()
+    assert len(neg) == neg_triples_num * len(pos_batch)
+    return [tuple(int(x) for x in row) for row in neg]
+
+
+def generate_neg_triples(pos_batch, all_triples_set, entities_list, neg_triples_num, neighbor=None, max_try=10):
+    """batch.py:60-86 draws one candidate per negative; its accepted negatives have the same
+    distribution as one round of the `fast` variant per needed sample, which is what runs."""
+    return generate_neg_triples_fast(pos_batch, all_triples_set, entities_list, neg_triples_num, neighbor, max_try)
+
+
+def generate_relation_triple_batch(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1, entity_list2,
+                                   batch_size, step, neighbor1, neighbor2, neg_triples_num):
+    """batch.py:36-45."""
+    b1, b2 = batch_sizes(len(triple_list1), len(triple_list2), batch_size)
+    pos_batch1 = generate_pos_triples(triple_list1, b1, step)
+    pos_batch2 = generate_pos_triples(triple_list2, b2, step)
+    neg_batch1 = generate_neg_triples_fast(pos_batch1, triple_set1, entity_list1, neg_triples_num, neighbor=neighbor1)
+    neg_batch2 = generate_neg_triples_fast(pos_batch2, triple_set2, entity_list2, neg_triples_num, neighbor=neighbor2)
+    return pos_batch1 + pos_batch2, neg_batch1 + neg_batch2
+
+
+def generate_relation_triple_batch_queue(triple_list1, triple_list2, triple_set1, triple_set2, entity_list1,
+                                         entity_list2, batch_size, steps, out_queue, neighbor1, neighbor2,
+                                         neg_triples_num):
+    """batch.py:25-33."""
+    for step in steps:
+        out_queue.put(generate_relation_triple_batch(triple_list1, triple_list2, triple_set1, triple_set2,
+                                                     entity_list1, entity_list2, batch_size, step, neighbor1,
+                                                     neighbor2, neg_triples_num))
+
+
+# ----------------------------------------------------------------------------------------------
+# neighbour search (batch.py:122-165)
+# ----------------------------------------------------------------------------------------------
+
+
+def neighbours_device(embeds, dim, entity_ids, k):
+    """embeds: device [N, ld] rows in entity_list order; entity_ids: device int32 [N].
+    -> device int32 [N, k] neighbour ENTITY IDS (ascending candidate position per row)."""
+    return ops.topk_inner(embeds, embeds, dim, k, id_map=entity_ids)
+
+
+def find_neighbours(frags, entity_list, sub_embed, embed, k):
+    """batch.py:157-165: {frags[i] -> list of the k nearest entity ids (unordered set in the
+    reference; ascending candidate position here)}."""
+    d = embed.shape[1]
+    idx = ops.topk_inner(ops.to_table(sub_embed), ops.to_table(embed), d, k,
+                         id_map=ops.to_ids(np.asarray(entity_list, np.int32))).cpu().numpy()
+    return {frags[i]: idx[i].tolist() for i in range(len(frags))}
+
+
+def generate_neighbours_single_thread(entity_embeds, entity_list, neighbors_num, threads_num):
+    """batch.py:145-154.  `threads_num` only fragmented the host matmul; one device call here."""
+    ents = np.asarray(entity_list)
+    return find_neighbours(ents.tolist(), ents, entity_embeds, entity_embeds, neighbors_num)
+
+
+def generate_neighbours(entity_embeds, entity_list, neighbors_num, threads_num):
+    """batch.py:122-142."""
+    return generate_neighbours_single_thread(entity_embeds, entity_list, neighbors_num, threads_num)

@@ -97,12 +97,34 @@ def step_workspace(n_ent, n_rel, ld, dev=None):
     return torch.zeros(nbytes, dtype=torch.uint8, device=dev or device())
 
 
-def triple_step(ent, ent_acc, rel, rel_acc, dim, pos, neg, cfg, workspace, loss_accum):
-    """One optimiser step in place; the batch loss is added to `loss_accum` (device f64[1])."""
+PHASE_BOTH, PHASE_GRAD, PHASE_APPLY = 0, 1, 2
+
+
+def triple_step(ent, ent_acc, rel, rel_acc, dim, pos, neg, cfg, workspace, loss_accum, phase=PHASE_BOTH):
+    """One optimiser step in place; the batch loss is added to `loss_accum` (device f64[1]).
+    phase: PHASE_GRAD / PHASE_APPLY split the step at its exchange point (data parallelism)."""
     n_neg = 0 if neg is None else neg.shape[0]
-    check(lib().oea_triple_step(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0],
-                                dim, ent.shape[1], _p(pos), pos.shape[0], _p(neg), n_neg,
-                                C.byref(cfg), _p(workspace), _p(loss_accum), _stream()))
+    check(lib().oea_triple_step_phase(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0],
+                                      dim, ent.shape[1], _p(pos), pos.shape[0], _p(neg), n_neg,
+                                      C.byref(cfg), _p(workspace), _p(loss_accum), int(phase), _stream()))
+
+
+def step_exchange_view(workspace, n_ent, n_rel, ld):
+    """fp32 view of the workspace region (gradient scratch + touched flags) that data-parallel
+    ranks sum with one all-reduce."""
+    n = lib().oea_step_exchange_floats(n_ent, n_rel, ld)
+    return workspace[: 4 * n].view(torch.float32)
+
+
+def profile_begin():
+    check(lib().oea_profile_begin())
+
+
+def profile_end(group=3):
+    ms = (C.c_double * (group - 1))()
+    n = C.c_int32(0)
+    check(lib().oea_profile_end(group, ms, C.byref(n)))
+    return [float(x) for x in ms], int(n.value)
 
 
 # -------------------------------------------------------------------------------------------
