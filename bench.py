@@ -76,7 +76,7 @@ def main():
     ent = EmbeddingTable(truncated_normal_host(rng, (kgs.entities_num, d), 1.0 / np.sqrt(d)), True, "ent_embeds", dev)
     rel = EmbeddingTable(truncated_normal_host(rng, (kgs.relations_num, d), 1.0 / np.sqrt(d)), True, "rel_embeds", dev)
     cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
-                            ent_l2_norm=True, rel_l2_norm=True, optimizer="Adagrad", lr=0.01)
+                            ent_l2_norm=True, rel_l2_norm=True, optimizer="Adagrad", lr=0.01, neg_group_k=args.neg)
     trainer = TripleTrainer(ent, rel, cfg, "Adagrad", dist_group=group)
     epochs = RelationTripleEpochs(kgs, args.batch * world, args.neg, seed=2, dev=dev, rank=rank, world=world)
     k1 = int((1 - args.eps) * kgs.kg1.entities_num)      # basic_model.py:270-271 (1499 at eps=0.9, N=15000)
@@ -88,16 +88,29 @@ def main():
     nbr_first_s = time.time() - t0
     epochs.set_neighbours(nbr1, nbr2)
 
-    state = {"step": 0}
+    steps_per_epoch = len(epochs.batches.splits)
 
-    def one_step():
-        s = state["step"] % epochs.triple_steps
-        pos, neg = epochs.batch(s)
-        trainer.step(pos, neg)
-        state["step"] += 1
-        if state["step"] % epochs.triple_steps == 0:
-            epochs.end_epoch()
-        return pos.shape[0], (0 if neg is None else neg.shape[0])
+    def run_steps(n_steps):
+        """n_steps optimiser steps = whole epochs (one enqueue call each on a single GPU) plus a
+        per-step tail; returns (positives consumed, triples scored) on this rank."""
+        npos = nscored = 0
+        done = 0
+        while n_steps - done >= steps_per_epoch and epochs.global_step % steps_per_epoch == 0:
+            n = epochs.run_epoch(trainer)
+            npos += n
+            nscored += n * (1 + args.neg)
+            done += steps_per_epoch
+        while done < n_steps:
+            s = epochs.global_step % steps_per_epoch
+            pos, neg = epochs.batch(s)
+            if pos.shape[0]:
+                trainer.step(pos, neg)
+            npos += pos.shape[0]
+            nscored += pos.shape[0] * (1 + args.neg)
+            done += 1
+            if epochs.global_step % steps_per_epoch == 0:
+                epochs.end_epoch()
+        return npos, nscored
 
     def barrier():
         if world > 1:
@@ -105,20 +118,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     barrier()
     ops.profile_begin()
-    n_pos_total = n_scored = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        npos, nneg = one_step()
-        n_pos_total += npos
-        n_scored += npos + nneg
+    n_pos_total, n_scored = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     (fwd_ms, apply_ms), n_calls = ops.profile_end(3)
     epoch_loss = trainer.pop_loss()
+    epochs.check()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     cnt = torch.tensor([n_pos_total], dtype=torch.float64, device=dev)
@@ -151,7 +160,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes_per_launch)}
 
     extra = {"neighbour_refresh_first_call_s": round(nbr_first_s, 3), "epoch_loss_sum": epoch_loss,
-             "triple_steps_per_epoch": epochs.triple_steps, "neighbours_k": [k1, k2]}
+             "triple_steps_per_epoch": steps_per_epoch, "neighbours_k": [k1, k2]}
     if not args.no_extra and world == 1:
         extra.update(extra_legs(torch, ops, ent, kgs, d, k1))
     cpu = None

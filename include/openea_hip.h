@@ -96,6 +96,11 @@ typedef struct oea_step_cfg {
     int32_t rel_l2_norm; /* args.rel_l2_norm */
     int32_t opt_kind;    /* OEA_OPT_* (args.optimizer) */
     float lr;            /* args.learning_rate */
+    int32_t neg_group_k; /* 0: neg is an arbitrary list (reference order: python set order, batch.py:118).
+                            k > 0: n_neg == n_pos*k and neg[p*k .. p*k+k) are the corruptions of pos p as
+                            oea_sample_negatives writes them -> one workgroup-lane group scores a positive
+                            with its negatives (fewer row reads / atomics; identical arithmetic per triple,
+                            entries that are not corruptions of pos p are still scored correctly). */
 } oea_step_cfg;
 
 /* Workspace owned by the caller, sized by oea_step_workspace_bytes(); must be zero-initialised
@@ -142,6 +147,39 @@ int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uin
                          const int32_t *ent_pos, const int32_t *nbr, int32_t nbr_k, uint64_t seed,
                          uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                          int32_t *err_flag, void *stream);
+
+/* One launch for a whole (pos_batch1 + pos_batch2) batch of generate_relation_triple_batch
+ * (batch.py:36-45): positives [0, n_split) are sampled against side[0] (KG1's triple set,
+ * entity list and neighbours), positives [n_split, n_pos) against side[1] (KG2).  Identical
+ * draws to two oea_sample_negatives calls with pos_offset and pos_offset + n_split. */
+typedef struct oea_sampler_side {
+    const uint64_t *table;
+    uint64_t capacity;
+    const int32_t *entity_list;
+    const int32_t *ent_pos;
+    const int32_t *nbr;      /* NULL: uniform sampling over entity_list */
+    int32_t n_ent_list;
+    int32_t nbr_k;
+} oea_sampler_side;
+int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
+                              const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                              uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
+                              int32_t *err_flag, void *stream);
+
+/* A whole epoch of BasicModel.launch_triple_training_1epo (basic_model.py:222-232) enqueued by
+ * ONE call: for step in [0, steps): sample the negatives of batch `step`
+ * (oea_sample_negatives_pair with Philox step = step_base + step) and run the fused optimiser
+ * step.  pos_all holds the epoch's positive batches back to back; batch `step` is rows
+ * [offsets_host[step], offsets_host[step+1]) of it and its first splits_host[step] rows belong
+ * to KG1.  k == 0: positive-only losses (MTransE), no sampling.  neg_buf must hold
+ * max_batch*k triples.  Nothing is synchronised: the host returns after enqueueing ~3 kernels
+ * per step, which removes the per-step host round trip of the reference's feed_dict loop. */
+int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                     int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                     const int64_t *splits_host, int32_t steps, int32_t k, const oea_sampler_side *side0,
+                     const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
+                     int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                     void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):

@@ -19,7 +19,13 @@ class StepCfg(C.Structure):
     _fields_ = [("loss_kind", C.c_int32), ("l1", C.c_int32), ("margin", C.c_float),
                 ("pos_margin", C.c_float), ("neg_margin", C.c_float), ("balance", C.c_float),
                 ("ent_l2_norm", C.c_int32), ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32),
-                ("lr", C.c_float)]
+                ("lr", C.c_float), ("neg_group_k", C.c_int32)]
+
+
+class SamplerSide(C.Structure):
+    """mirror of `oea_sampler_side` (include/openea_hip.h)."""
+    _fields_ = [("table", C.c_void_p), ("capacity", C.c_uint64), ("entity_list", C.c_void_p),
+                ("ent_pos", C.c_void_p), ("nbr", C.c_void_p), ("n_ent_list", C.c_int32), ("nbr_k", C.c_int32)]
 
 
 LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
@@ -57,6 +63,11 @@ PROTOTYPES = {
     "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
     "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,
                                        _u32, _u32, _i32, _vp, _vp, _vp]),
+    "oea_sample_negatives_pair": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(SamplerSide), C.POINTER(SamplerSide),
+                                            _u64, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "oea_triple_epoch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32,
+                                   C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
+                                   C.POINTER(StepCfg), _vp, _vp, _vp]),
     "oea_topk_workspace_bytes": (_sz, [_i64, _i64]),
     "oea_topk_inner": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "oea_rank_workspace_bytes": (_sz, [_i64]),

@@ -12,9 +12,9 @@
 // oea_topk_inner and never leaves the device.  RNG = Philox4x32-10, so the CPU oracle
 // reproduces every draw bit-for-bit (oracle/c/oracle.c:oracle_sample_negatives).
 //
-// One lane per positive: the work is a short dependent chain of L2-resident probes, the
-// batch has thousands of positives, so lanes give enough parallelism without any
-// cross-lane traffic.
+// One 16-lane (k <= 16) or 64-lane group per positive, one lane per sampled slot: candidate
+// reads and membership probes of a try go out in parallel (the one-lane-per-positive version
+// was a 34 us dependent chain for 2,500 positives -- profiles/r01a_bench_kernel_stats.txt).
 #include "common.h"
 
 namespace {
@@ -49,18 +49,26 @@ __device__ __forceinline__ bool contains(const uint64_t *__restrict__ table, uin
 
 constexpr int kMaxK = 64;
 
-__global__ __launch_bounds__(64) void sample_negatives_kernel(
-    const int32_t *__restrict__ pos, int64_t n_pos, int k, const uint64_t *__restrict__ table, uint64_t capacity,
-    const int32_t *__restrict__ entity_list, int n_ent_list, const int32_t *__restrict__ ent_pos,
-    const int32_t *__restrict__ nbr, int nbr_k, uint32_t k0, uint32_t k1, uint32_t step, uint32_t pos_offset,
+// G lanes per positive (G = 16 for k <= 16, else 64): slot s of a try lives in lane s, so the
+// k candidate reads and the k membership probes of a try are issued in parallel instead of
+// as one lane's dependent chain.  Distinctness is resolved in synchronous rounds (see
+// oracle_sample_negatives): a slot redraws while an earlier slot holds the same index.
+template <int G>
+__global__ __launch_bounds__(256) void sample_negatives_kernel(
+    const int32_t *__restrict__ pos, int64_t n_pos, int64_t n_split, int k, oea_sampler_side side0,
+    oea_sampler_side side1, uint32_t k0, uint32_t k1, uint32_t step, uint32_t pos_offset,
     int max_try, int32_t *__restrict__ out, int32_t *__restrict__ err_flag) {
-    // chosen[] lives in LDS, transposed ([slot][lane]) so a wave's accesses are conflict-free
-    // and never spill to scratch.
-    __shared__ int32_t s_chosen[kMaxK * 64];
-    int32_t *chosen = s_chosen + threadIdx.x;
-#define CH(q) chosen[(q) * 64]
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pos) return;
+    const int lane = threadIdx.x % G;
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (p >= n_pos) return;                       // whole groups exit together
+    // positives [0, n_split) belong to KG1, the rest to KG2 (pos_batch1 + pos_batch2, batch.py:45)
+    const oea_sampler_side &sd = p < n_split ? side0 : side1;
+    const uint64_t *__restrict__ table = sd.table;
+    const uint64_t capacity = sd.capacity;
+    const int32_t *__restrict__ entity_list = sd.entity_list;
+    const int32_t *__restrict__ ent_pos = sd.ent_pos;
+    const int32_t *__restrict__ nbr = sd.nbr;
+    const int n_ent_list = sd.n_ent_list, nbr_k = sd.nbr_k;
     const int32_t h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
     // neighbor.get(e, entities_list): entities without a neighbour row (e.g. the other KG's
     // entities inside seed-swapped triples, kgs.py:45-50) fall back to the whole entity list
@@ -68,36 +76,55 @@ __global__ __launch_bounds__(64) void sample_negatives_kernel(
     const int32_t *hc = h_has ? nbr + (int64_t)ent_pos[h] * nbr_k : entity_list;
     const int32_t *tc = t_has ? nbr + (int64_t)ent_pos[t] * nbr_k : entity_list;
     const int hn = h_has ? nbr_k : n_ent_list, tn = t_has ? nbr_k : n_ent_list;
-    int got = 0;
     const uint32_t c0 = (uint32_t)p + pos_offset;
+    // mask of this group's lanes inside the 64-lane ballot
+    const int gbase = (threadIdx.x & 63) / G * G;
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    int got = 0;
     for (int tr = 0; tr < max_try && got < k; ++tr) {
         uint4 w = oea::philox4x32_10(c0, step, (uint32_t)tr, 0u, k0, k1);
         const bool corrupt_head = (w.x & 1u) != 0u;
         const int32_t *cand = corrupt_head ? hc : tc;
         const int nc = corrupt_head ? hn : tn;
         const int need = k - got;
-        if (need > nc) { *err_flag = 1; return; }   // random.sample would raise ValueError
-        uint32_t draw = 1;
-        for (int s = 0; s < need; ++s) {
-            for (;;) {
-                w = oea::philox4x32_10(c0, step, (uint32_t)tr, draw++, k0, k1);
-                const int32_t j = (int32_t)__umulhi(w.x, (uint32_t)nc);
-                bool dup = false;
-                for (int q = 0; q < s; ++q) dup |= (CH(q) == j);
-                if (!dup) { CH(s) = j; break; }
+        if (need > nc) { if (lane == 0) *err_flag = 1; return; }   // random.sample would raise ValueError
+        const bool active = lane < need;
+        uint32_t att = 0;
+        int32_t v = -1 - lane;                       // inactive lanes never match anything
+        if (active) {
+            w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane, k0, k1);
+            v = (int32_t)__umulhi(w.x, (uint32_t)nc);
+        }
+        for (;;) {
+            bool conflict = false;
+            for (int q = 0; q < need; ++q) {
+                const int32_t vq = __shfl(v, gbase + q, 64);
+                conflict |= (q < lane) && (vq == v);
+            }
+            conflict &= active;
+            if ((__ballot(conflict) & gmask) == 0ull) break;
+            if (conflict) {
+                ++att;
+                w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane + 64u * att, k0, k1);
+                v = (int32_t)__umulhi(w.x, (uint32_t)nc);
             }
         }
-        for (int s = 0; s < need; ++s) {
-            const int32_t e = cand[CH(s)];
-            const int32_t nh = corrupt_head ? e : h, nt = corrupt_head ? t : e;
-            if (tr == max_try - 1 || !contains(table, capacity, (uint32_t)nh, (uint32_t)r, (uint32_t)nt)) {
-                int32_t *o = out + ((int64_t)p * k + got) * 3;
-                o[0] = nh; o[1] = r; o[2] = nt;
-                ++got;
-            }
+        bool accept = false;
+        int32_t nh = h, nt = t;
+        if (active) {
+            const int32_t e = cand[v];
+            nh = corrupt_head ? e : h;
+            nt = corrupt_head ? t : e;
+            accept = (tr == max_try - 1) || !contains(table, capacity, (uint32_t)nh, (uint32_t)r, (uint32_t)nt);
         }
+        const unsigned long long acc_mask = (__ballot(accept) & gmask) >> gbase;
+        if (accept) {
+            const int slot = got + __popcll(acc_mask & ((1ull << lane) - 1ull));
+            int32_t *o = out + ((int64_t)p * k + slot) * 3;
+            o[0] = nh; o[1] = r; o[2] = nt;
+        }
+        got += __popcll(acc_mask);
     }
-#undef CH
 }
 
 }  // namespace
@@ -125,15 +152,42 @@ int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uin
                          const int32_t *ent_pos, const int32_t *nbr, int32_t nbr_k, uint64_t seed,
                          uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                          int32_t *err_flag, void *stream) {
-    OEA_REQUIRE(pos && table && entity_list && out && err_flag, "null pointer");
+    oea_sampler_side sd;
+    sd.table = table; sd.capacity = capacity; sd.entity_list = entity_list; sd.ent_pos = ent_pos; sd.nbr = nbr;
+    sd.n_ent_list = n_ent_list; sd.nbr_k = nbr_k;
+    return oea_sample_negatives_pair(pos, n_pos, n_pos, k, &sd, &sd, seed, step, pos_offset, max_try, out, err_flag,
+                                     stream);
+}
+
+static int check_side(const oea_sampler_side *s, int k) {
+    OEA_REQUIRE(s && s->table && s->entity_list, "sampler side: null pointer");
+    OEA_REQUIRE(s->nbr == nullptr || (s->ent_pos != nullptr && s->nbr_k > 0), "nbr needs ent_pos and nbr_k");
+    OEA_REQUIRE((s->nbr ? s->nbr_k : s->n_ent_list) >= k && s->n_ent_list >= k, "Sample larger than population");
+    return OEA_OK;
+}
+
+int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
+                              const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                              uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
+                              int32_t *err_flag, void *stream) {
+    OEA_REQUIRE(pos && out && err_flag, "null pointer");
     OEA_REQUIRE(k >= 1 && k <= kMaxK, "1 <= k <= 64");
     OEA_REQUIRE(max_try >= 1, "max_try >= 1");
-    OEA_REQUIRE(nbr == nullptr || (ent_pos != nullptr && nbr_k > 0), "nbr needs ent_pos and nbr_k");
-    OEA_REQUIRE((nbr ? nbr_k : n_ent_list) >= k && n_ent_list >= k, "Sample larger than population");
+    OEA_REQUIRE(n_split >= 0 && n_split <= n_pos, "0 <= n_split <= n_pos");
+    int rc = check_side(side0, k);
+    if (rc != OEA_OK) return rc;
+    rc = check_side(side1, k);
+    if (rc != OEA_OK) return rc;
     if (n_pos == 0) return OEA_OK;
-    sample_negatives_kernel<<<(unsigned)oea::ceil_div(n_pos, 64), 64, 0, oea::as_stream(stream)>>>(
-        pos, n_pos, k, table, capacity, entity_list, n_ent_list, ent_pos, nbr, nbr_k, (uint32_t)seed,
-        (uint32_t)(seed >> 32), step, pos_offset, max_try, out, err_flag);
+    hipStream_t st = oea::as_stream(stream);
+    if (k <= 16)
+        sample_negatives_kernel<16><<<(unsigned)oea::ceil_div(n_pos, 256 / 16), 256, 0, st>>>(
+            pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
+            out, err_flag);
+    else
+        sample_negatives_kernel<64><<<(unsigned)oea::ceil_div(n_pos, 256 / 64), 256, 0, st>>>(
+            pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
+            out, err_flag);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -7,16 +7,26 @@
 // and the normalisation, duplicate-row summation, and Adagrad / SGD
 // (modules/base/optimizers.py:4-20).
 //
-// Kernel 1 (triple_fwd_bwd): one G-lane group per triple (G*4*IT >= ld), each lane owns
-//   float4 slices of the h, r, t rows: coalesced 16-B loads, __shfl_xor butterflies for
-//   the three squared norms and the score, analytic dL/d(delta), hardware fp32 atomics
-//   (global_atomic_add_f32) into a dense gradient scratch w.r.t. the NORMALISED rows.
-//   Triples whose hinge is inactive issue no atomics at all.
+// Layout: a G-lane group (G = 32 for ld <= 128, else 64) owns one work item; lane l holds
+// elements l, l+G, l+2G, ... of a row, so every load AND every atomic instruction of the
+// group covers one contiguous 128-B / 256-B segment of a table row.
+//
+// Kernel 1a (triple_grouped): one group per POSITIVE and its k negatives, used when the
+//   negatives come from oea_sample_negatives (neg[p*k+s] corrupts head or tail of pos p,
+//   batch.py:89-119).  h, r, t are loaded and normalised once; each negative costs one more
+//   row; the gradients of h, r, t are accumulated in registers and leave as ONE row of
+//   atomics each: (3+k) row reads and (3+k) rows of atomics per positive instead of
+//   3(1+k) -- and the hot relation rows (a few hundred rows shared by the whole batch) see
+//   (1+k)x fewer same-address atomics.
+// Kernel 1b (triple_generic): one group per triple for arbitrary (pos, neg) lists, and the
+//   margin loss (pos i paired with neg i).
+//   Both: hardware fp32 atomics (global_atomic_add_f32) into a dense gradient scratch w.r.t.
+//   the NORMALISED rows; triples whose hinge is inactive issue no atomics.
 // Kernel 2 (apply_rows): one group per table row; touched rows pull the summed gradient
 //   back through the normalisation (g - y (y.g)) / |v| and apply Adagrad / SGD, then zero
 //   their scratch row, so the scratch is clean for the next step.
 //
-// HBM / cache traffic per scored triple: 3 rows read (12*ld B) + up to 3 rows of atomics.
+// Algorithmic bytes per scored triple: 3 rows read + 3 rows of gradient = 24*d.
 #include "common.h"
 
 namespace {
@@ -26,7 +36,7 @@ using oea::group_sum;
 struct StepWs {
     float *ent_grad, *rel_grad;
     float *ent_touched, *rel_touched;   // 1.0f = row received gradient (float so one SUM all-reduce covers grads + flags)
-    double *partials;   // [kMaxBlocks]
+    double *partials;                   // [kMaxBlocks]
 };
 constexpr int kMaxBlocks = 4096;
 
@@ -45,92 +55,102 @@ static size_t ws_layout(int64_t n_ent, int64_t n_rel, int32_t ld, void *base, St
     return off;
 }
 
+// ---- lane-strided row fragments ------------------------------------------------------------------
 template <int G, int IT>
 struct Row {
-    float4 v[IT];
+    float v[IT];
 };
 
 template <int G, int IT>
 __device__ __forceinline__ void load_row(const float *__restrict__ base, int ld, int lane, Row<G, IT> &r) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int c = (it * G + lane) * 4;
-        r.v[it] = c < ld ? oea::ld4(base + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = it * G + lane;
+        r.v[it] = c < ld ? base[c] : 0.f;
     }
 }
 template <int G, int IT>
 __device__ __forceinline__ float sumsq(const Row<G, IT> &r) {
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < IT; ++it)
-        s += r.v[it].x * r.v[it].x + r.v[it].y * r.v[it].y + r.v[it].z * r.v[it].z + r.v[it].w * r.v[it].w;
+    for (int it = 0; it < IT; ++it) s += r.v[it] * r.v[it];
     return group_sum<G>(s);
 }
-
-// delta = yh + yr - yt on normalised rows; returns the score (sum |d| or sum d^2).
+// y = l2_normalize(v) when `on` (tf.nn.l2_normalize: v * rsqrt(max(sum v^2, 1e-12)))
 template <int G, int IT>
-__device__ __forceinline__ float score_triple(const float *__restrict__ ent, const float *__restrict__ rel,
-                                              int ld, int lane, int h, int r, int t, int ent_norm,
-                                              int rel_norm, int l1, Row<G, IT> &delta) {
-    Row<G, IT> vh, vr, vt;
-    load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, vh);
-    load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, vr);
-    load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, vt);
-    float ih = 1.f, ir = 1.f, itl = 1.f;
-    if (ent_norm) {
-        ih = rsqrtf(fmaxf(sumsq<G, IT>(vh), 1e-12f));
-        itl = rsqrtf(fmaxf(sumsq<G, IT>(vt), 1e-12f));
-    }
-    if (rel_norm) ir = rsqrtf(fmaxf(sumsq<G, IT>(vr), 1e-12f));
+__device__ __forceinline__ void normalize(Row<G, IT> &r, int on) {
+    if (!on) return;
+    const float inv = rsqrtf(fmaxf(sumsq<G, IT>(r), 1e-12f));
+#pragma unroll
+    for (int it = 0; it < IT; ++it) r.v[it] *= inv;
+}
+template <int G, int IT>
+__device__ __forceinline__ float score(const Row<G, IT> &yh, const Row<G, IT> &yr, const Row<G, IT> &yt, int l1,
+                                       Row<G, IT> &delta) {
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        float4 d;
-        d.x = vh.v[it].x * ih + vr.v[it].x * ir - vt.v[it].x * itl;
-        d.y = vh.v[it].y * ih + vr.v[it].y * ir - vt.v[it].y * itl;
-        d.z = vh.v[it].z * ih + vr.v[it].z * ir - vt.v[it].z * itl;
-        d.w = vh.v[it].w * ih + vr.v[it].w * ir - vt.v[it].w * itl;
+        const float d = yh.v[it] + yr.v[it] - yt.v[it];
         delta.v[it] = d;
-        s += l1 ? (fabsf(d.x) + fabsf(d.y) + fabsf(d.z) + fabsf(d.w)) : (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+        s += l1 ? fabsf(d) : d * d;
     }
     return group_sum<G>(s);
 }
-
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-// scatter coef * ds/d(delta) into the gradient scratch: +h, +r, -t.
+// g = coef * ds/d(delta)
 template <int G, int IT>
-__device__ __forceinline__ void scatter_grad(float *__restrict__ eg, float *__restrict__ rg,
-                                             float *__restrict__ et, float *__restrict__ rt, int ld,
-                                             int lane, int h, int r, int t, float coef, int l1,
-                                             const Row<G, IT> &delta) {
-    float *gh = eg + (int64_t)h * ld, *gr = rg + (int64_t)r * ld, *gt = eg + (int64_t)t * ld;
+__device__ __forceinline__ void dscore(const Row<G, IT> &delta, float coef, int l1, Row<G, IT> &g) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) g.v[it] = l1 ? coef * sgn(delta.v[it]) : 2.f * coef * delta.v[it];
+}
+template <int G, int IT>
+__device__ __forceinline__ void atomic_row(float *__restrict__ dst, int ld, int lane, const Row<G, IT> &g, float sign) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int c = (it * G + lane) * 4;
-        if (c < ld) {
-            const float4 d = delta.v[it];
-            float g[4];
-            if (l1) { g[0] = coef * sgn(d.x); g[1] = coef * sgn(d.y); g[2] = coef * sgn(d.z); g[3] = coef * sgn(d.w); }
-            else { const float c2 = 2.f * coef; g[0] = c2 * d.x; g[1] = c2 * d.y; g[2] = c2 * d.z; g[3] = c2 * d.w; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (g[q] != 0.f) {
-                    oea::atomic_add_f32(gh + c + q, g[q]);
-                    oea::atomic_add_f32(gr + c + q, g[q]);
-                    oea::atomic_add_f32(gt + c + q, -g[q]);
-                }
-            }
-        }
+        const int c = it * G + lane;
+        const float v = sign * g.v[it];
+        if (c < ld && v != 0.f) oea::atomic_add_f32(dst + c, v);
     }
-    if (lane == 0) { et[h] = 1.f; et[t] = 1.f; rt[r] = 1.f; }
 }
 
 __device__ __forceinline__ float softplusf_(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// dL/ds and the loss term of ONE triple for the per-triple losses (not margin).
+__device__ __forceinline__ void triple_coef(const oea_step_cfg &cfg, bool is_pos, float s, float &coef, float &l) {
+    coef = 0.f; l = 0.f;
+    switch (cfg.loss_kind) {
+    case OEA_LOSS_LIMITED:  // losses.py:53-55
+        if (is_pos) { const float x = s - cfg.pos_margin; if (x > 0.f) { l = x; coef = 1.f; } }
+        else { const float x = cfg.neg_margin - s; if (x > 0.f) { l = cfg.balance * x; coef = -cfg.balance; } }
+        break;
+    case OEA_LOSS_LOGISTIC:  // losses.py:70-72
+        if (is_pos) { l = softplusf_(s); coef = sigmoidf_(s); }
+        else { l = softplusf_(-s); coef = -sigmoidf_(-s); }
+        break;
+    case OEA_LOSS_POSITIVE:  // losses.py:38
+        l = s; coef = 1.f;
+        break;
+    case OEA_LOSS_ALIGN:  // bootea.py:197: -log sigmoid(-s) = softplus(s)
+        l = softplusf_(s); coef = sigmoidf_(s);
+        break;
+    default: break;
+    }
+}
+
+__device__ __forceinline__ void block_loss_partial(double loss_local, double *partials) {
+    // fixed reduction tree -> the partial is deterministic
+    __shared__ double sred[4];
+    const double w = oea::wave_sum_d(loss_local);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+// ---- kernel 1b: arbitrary triple lists + margin pairs --------------------------------------------
 template <int G, int IT>
-__global__ __launch_bounds__(256) void triple_fwd_bwd(
+__global__ __launch_bounds__(256) void triple_generic(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
     int64_t n_pos, const int32_t *__restrict__ neg, int64_t n_neg, oea_step_cfg cfg, StepWs ws) {
     const int lane = threadIdx.x % G;
@@ -139,61 +159,147 @@ __global__ __launch_bounds__(256) void triple_fwd_bwd(
     const bool margin = cfg.loss_kind == OEA_LOSS_MARGIN;
     const int64_t items = margin ? n_pos : n_pos + n_neg;
     double loss_local = 0.0;
-
     for (int64_t item = grp; item < items; item += ngrp) {
-        if (margin) {
-            // losses.py:15-27: sum relu(margin + s+ - s-), pos i paired with neg i
-            const int32_t *tp = pos + 3 * item, *tn = neg + 3 * item;
-            const int ph = tp[0], pr = tp[1], pt = tp[2], nh = tn[0], nr = tn[1], nt = tn[2];
-            Row<G, IT> dp, dn;
-            const float sp = score_triple<G, IT>(ent, rel, ld, lane, ph, pr, pt, cfg.ent_l2_norm, cfg.rel_l2_norm, cfg.l1, dp);
-            const float sn = score_triple<G, IT>(ent, rel, ld, lane, nh, nr, nt, cfg.ent_l2_norm, cfg.rel_l2_norm, cfg.l1, dn);
-            const float x = cfg.margin + sp - sn;
-            if (x > 0.f) {
-                if (lane == 0) loss_local += (double)x;
-                scatter_grad<G, IT>(ws.ent_grad, ws.rel_grad, ws.ent_touched, ws.rel_touched, ld, lane, ph, pr, pt, 1.f, cfg.l1, dp);
-                scatter_grad<G, IT>(ws.ent_grad, ws.rel_grad, ws.ent_touched, ws.rel_touched, ld, lane, nh, nr, nt, -1.f, cfg.l1, dn);
-            }
-            continue;
-        }
-        const bool is_pos = item < n_pos;
+        const bool is_pos = margin || item < n_pos;
         const int32_t *tr = is_pos ? pos + 3 * item : neg + 3 * (item - n_pos);
         const int h = tr[0], r = tr[1], t = tr[2];
-        Row<G, IT> delta;
-        const float s = score_triple<G, IT>(ent, rel, ld, lane, h, r, t, cfg.ent_l2_norm, cfg.rel_l2_norm, cfg.l1, delta);
-        float coef = 0.f, l = 0.f;
-        switch (cfg.loss_kind) {
-        case OEA_LOSS_LIMITED:  // losses.py:53-55
-            if (is_pos) { const float x = s - cfg.pos_margin; if (x > 0.f) { l = x; coef = 1.f; } }
-            else { const float x = cfg.neg_margin - s; if (x > 0.f) { l = cfg.balance * x; coef = -cfg.balance; } }
-            break;
-        case OEA_LOSS_LOGISTIC:  // losses.py:70-72
-            if (is_pos) { l = softplusf_(s); coef = sigmoidf_(s); }
-            else { l = softplusf_(-s); coef = -sigmoidf_(-s); }
-            break;
-        case OEA_LOSS_POSITIVE:  // losses.py:38
-            l = s; coef = 1.f;
-            break;
-        case OEA_LOSS_ALIGN:  // bootea.py:197: -log sigmoid(-s) = softplus(s)
-            l = softplusf_(s); coef = sigmoidf_(s);
-            break;
-        default: break;
+        Row<G, IT> yh, yr, yt, delta, g;
+        load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+        load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+        load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+        normalize<G, IT>(yh, cfg.ent_l2_norm);
+        normalize<G, IT>(yr, cfg.rel_l2_norm);
+        normalize<G, IT>(yt, cfg.ent_l2_norm);
+        const float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+        float coef, l;
+        if (margin) {
+            // losses.py:15-27: sum relu(margin + s+ - s-), pos i paired with neg i
+            const int32_t *tn = neg + 3 * item;
+            const int nh = tn[0], nr = tn[1], nt = tn[2];
+            Row<G, IT> zh, zr, zt, dn;
+            load_row<G, IT>(ent + (int64_t)nh * ld, ld, lane, zh);
+            load_row<G, IT>(rel + (int64_t)nr * ld, ld, lane, zr);
+            load_row<G, IT>(ent + (int64_t)nt * ld, ld, lane, zt);
+            normalize<G, IT>(zh, cfg.ent_l2_norm);
+            normalize<G, IT>(zr, cfg.rel_l2_norm);
+            normalize<G, IT>(zt, cfg.ent_l2_norm);
+            const float sn = score<G, IT>(zh, zr, zt, cfg.l1, dn);
+            const float x = cfg.margin + s - sn;
+            if (x <= 0.f) continue;
+            if (lane == 0) loss_local += (double)x;
+            dscore<G, IT>(dn, -1.f, cfg.l1, g);
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)nh * ld, ld, lane, g, 1.f);
+            atomic_row<G, IT>(ws.rel_grad + (int64_t)nr * ld, ld, lane, g, 1.f);
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)nt * ld, ld, lane, g, -1.f);
+            if (lane == 0) { ws.ent_touched[nh] = 1.f; ws.ent_touched[nt] = 1.f; ws.rel_touched[nr] = 1.f; }
+            coef = 1.f;
+        } else {
+            triple_coef(cfg, is_pos, s, coef, l);
+            if (lane == 0) loss_local += (double)l;
+            if (coef == 0.f) continue;
         }
-        if (lane == 0) loss_local += (double)l;
-        if (coef != 0.f)
-            scatter_grad<G, IT>(ws.ent_grad, ws.rel_grad, ws.ent_touched, ws.rel_touched, ld, lane, h, r, t, coef, cfg.l1, delta);
+        dscore<G, IT>(delta, coef, cfg.l1, g);
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.rel_grad + (int64_t)r * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, g, -1.f);
+        if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; }
     }
-
-    // block-level loss partial (fixed reduction tree -> the partial is deterministic)
-    __shared__ double sred[4];
-    double w = oea::wave_sum_d(loss_local);
-    const int wid = threadIdx.x / 64;
-    if ((threadIdx.x & 63) == 0) sred[wid] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) ws.partials[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+    block_loss_partial(loss_local, ws.partials);
 }
 
-// One G-lane group per table row (entity rows first, then relation rows).
+// ---- kernel 1a: one group per positive + its k negatives -------------------------------------------
+template <int G, int IT>
+__global__ __launch_bounds__(256) void triple_grouped(
+    const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
+    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    double loss_local = 0.0;
+    for (int64_t p = grp; p < n_pos; p += ngrp) {
+        const int h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
+        Row<G, IT> yh, yr, yt, delta, g, gh, gr, gt;
+        load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+        load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+        load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+        // first corrupted row is requested before the positive is scored (latency overlap)
+        const int32_t *ng = neg + (int64_t)p * k * 3;
+        int nh = ng[0], nr = ng[1], nt = ng[2];
+        Row<G, IT> yc;
+        load_row<G, IT>(ent + (int64_t)((nh == h) ? nt : nh) * ld, ld, lane, yc);
+        normalize<G, IT>(yh, cfg.ent_l2_norm);
+        normalize<G, IT>(yr, cfg.rel_l2_norm);
+        normalize<G, IT>(yt, cfg.ent_l2_norm);
+        float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+        float coef, l;
+        triple_coef(cfg, true, s, coef, l);
+        double lsum = (double)l;
+        dscore<G, IT>(delta, coef, cfg.l1, g);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
+        bool any = coef != 0.f;
+        for (int sidx = 0; sidx < k; ++sidx) {
+            const bool tail_side = (nh == h);              // tail corrupted (or neg == pos): uses yh, yr
+            const bool head_side = !tail_side && (nt == t);
+            const int cur_h = nh, cur_r = nr, cur_t = nt;
+            Row<G, IT> ycur = yc;
+            if (sidx + 1 < k) {                            // prefetch the next corrupted row
+                nh = ng[3 * (sidx + 1)]; nr = ng[3 * (sidx + 1) + 1]; nt = ng[3 * (sidx + 1) + 2];
+                load_row<G, IT>(ent + (int64_t)((nh == h) ? nt : nh) * ld, ld, lane, yc);
+            }
+            if (cur_r == r && (tail_side || head_side)) {
+                normalize<G, IT>(ycur, cfg.ent_l2_norm);
+                s = tail_side ? score<G, IT>(yh, yr, ycur, cfg.l1, delta) : score<G, IT>(ycur, yr, yt, cfg.l1, delta);
+                triple_coef(cfg, false, s, coef, l);
+                lsum += (double)l;
+                if (coef != 0.f) {
+                    any = true;
+                    dscore<G, IT>(delta, coef, cfg.l1, g);
+                    if (tail_side) {
+#pragma unroll
+                        for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
+                        atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_t * ld, ld, lane, g, -1.f);
+                        if (lane == 0) ws.ent_touched[cur_t] = 1.f;
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < IT; ++it) { gr.v[it] += g.v[it]; gt.v[it] -= g.v[it]; }
+                        atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_h * ld, ld, lane, g, 1.f);
+                        if (lane == 0) ws.ent_touched[cur_h] = 1.f;
+                    }
+                }
+            } else {
+                // not a corruption of this positive: score it as an independent triple
+                Row<G, IT> zh, zr, zt;
+                load_row<G, IT>(ent + (int64_t)cur_h * ld, ld, lane, zh);
+                load_row<G, IT>(rel + (int64_t)cur_r * ld, ld, lane, zr);
+                load_row<G, IT>(ent + (int64_t)cur_t * ld, ld, lane, zt);
+                normalize<G, IT>(zh, cfg.ent_l2_norm);
+                normalize<G, IT>(zr, cfg.rel_l2_norm);
+                normalize<G, IT>(zt, cfg.ent_l2_norm);
+                s = score<G, IT>(zh, zr, zt, cfg.l1, delta);
+                triple_coef(cfg, false, s, coef, l);
+                lsum += (double)l;
+                if (coef != 0.f) {
+                    dscore<G, IT>(delta, coef, cfg.l1, g);
+                    atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_h * ld, ld, lane, g, 1.f);
+                    atomic_row<G, IT>(ws.rel_grad + (int64_t)cur_r * ld, ld, lane, g, 1.f);
+                    atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_t * ld, ld, lane, g, -1.f);
+                    if (lane == 0) { ws.ent_touched[cur_h] = 1.f; ws.ent_touched[cur_t] = 1.f; ws.rel_touched[cur_r] = 1.f; }
+                }
+            }
+        }
+        if (any) {
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, gh, 1.f);
+            atomic_row<G, IT>(ws.rel_grad + (int64_t)r * ld, ld, lane, gr, 1.f);
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, gt, 1.f);
+            if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; }
+        }
+        if (lane == 0) loss_local += lsum;
+    }
+    block_loss_partial(loss_local, ws.partials);
+}
+
+// ---- kernel 2: optimiser on touched rows (entity rows first, then relation rows) -------------------
 template <int G, int IT>
 __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float *__restrict__ ent_acc,
                                                   int64_t n_ent, float *__restrict__ rel,
@@ -221,35 +327,23 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             inv = rsqrtf(fmaxf(ss, 1e-12f));
             float dot = 0.f;
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
-                dot += rv.v[it].x * rg.v[it].x + rv.v[it].y * rg.v[it].y + rv.v[it].z * rg.v[it].z + rv.v[it].w * rg.v[it].w;
+            for (int it = 0; it < IT; ++it) dot += rv.v[it] * rg.v[it];
             dot = group_sum<G>(dot) * inv;           // y . g
             ydg = ss > 1e-12f ? dot : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int c = (it * G + lane) * 4;
+            const int c = it * G + lane;
             if (c < ld) {
-                const float vv[4] = {rv.v[it].x, rv.v[it].y, rv.v[it].z, rv.v[it].w};
-                const float gg[4] = {rg.v[it].x, rg.v[it].y, rg.v[it].z, rg.v[it].w};
-                float nv[4], na[4];
-                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cfg.opt_kind == OEA_OPT_ADAGRAD) a4 = oea::ld4(acc + c);
-                const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float gv = on ? (gg[q] - vv[q] * inv * ydg) * inv : gg[q];
-                    if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
-                        na[q] = aa[q] + gv * gv;
-                        nv[q] = vv[q] - cfg.lr * gv / sqrtf(na[q]);
-                    } else {
-                        na[q] = 0.f;
-                        nv[q] = vv[q] - cfg.lr * gv;
-                    }
+                const float gv = on ? (rg.v[it] - rv.v[it] * inv * ydg) * inv : rg.v[it];
+                if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
+                    const float a = acc[c] + gv * gv;
+                    acc[c] = a;
+                    v[c] = rv.v[it] - cfg.lr * gv / sqrtf(a);
+                } else {
+                    v[c] = rv.v[it] - cfg.lr * gv;
                 }
-                oea::st4(v + c, make_float4(nv[0], nv[1], nv[2], nv[3]));
-                if (cfg.opt_kind == OEA_OPT_ADAGRAD) oea::st4(acc + c, make_float4(na[0], na[1], na[2], na[3]));
-                oea::st4(g + c, make_float4(0.f, 0.f, 0.f, 0.f));
+                g[c] = 0.f;
             }
         }
         if (lane == 0) touched[row] = 0.f;
@@ -268,11 +362,16 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
                 const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
-    const int64_t items = cfg.loss_kind == OEA_LOSS_MARGIN ? n_pos : n_pos + n_neg;
+    const bool grouped = cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN;
+    const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
     oea::prof_mark(st);
-    if (phase != OEA_PHASE_APPLY)
-        triple_fwd_bwd<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+    if (phase != OEA_PHASE_APPLY) {
+        if (grouped)
+            triple_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, cfg.neg_group_k, cfg, ws);
+        else
+            triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+    }
     oea::prof_mark(st);
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD)
@@ -317,19 +416,49 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     if (cfg->loss_kind == OEA_LOSS_MARGIN) OEA_REQUIRE(n_neg == n_pos, "margin loss pairs pos i with neg i");
     if (cfg->loss_kind == OEA_LOSS_POSITIVE || cfg->loss_kind == OEA_LOSS_ALIGN)
         OEA_REQUIRE(n_neg == 0, "positive-only loss takes no negatives");
+    OEA_REQUIRE(cfg->neg_group_k >= 0 && (cfg->neg_group_k == 0 || n_neg == n_pos * (int64_t)cfg->neg_group_k),
+                "neg_group_k > 0 needs n_neg == n_pos * neg_group_k");
     if (n_pos + n_neg == 0) return OEA_OK;
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     hipStream_t st = oea::as_stream(stream);
 #define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, phase, st)
-    if (ld <= 64) OEA_STEP(16, 1);
-    else if (ld <= 128) OEA_STEP(32, 1);
-    else if (ld <= 256) OEA_STEP(64, 1);
-    else if (ld <= 512) OEA_STEP(64, 2);
-    else if (ld <= 1280) OEA_STEP(64, 5);
+    if (ld <= 32) OEA_STEP(32, 1);
+    else if (ld <= 64) OEA_STEP(32, 2);
+    else if (ld <= 96) OEA_STEP(32, 3);
+    else if (ld <= 128) OEA_STEP(32, 4);
+    else if (ld <= 256) OEA_STEP(64, 4);
+    else if (ld <= 512) OEA_STEP(64, 8);
+    else if (ld <= 1280) OEA_STEP(64, 20);
     else { oea::set_error("dim %d > 1280 unsupported", dim); return OEA_EUNSUPPORTED; }
 #undef OEA_STEP
     OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                     int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                     const int64_t *splits_host, int32_t steps, int32_t k, const oea_sampler_side *side0,
+                     const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
+                     int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                     void *stream) {
+    OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
+    OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
+    OEA_REQUIRE(k == 0 || (neg_buf && err_flag && side0 && side1), "sampling needs neg_buf, err_flag and both sides");
+    for (int32_t s = 0; s < steps; ++s) {
+        const int64_t lo = offsets_host[s], n = offsets_host[s + 1] - lo;
+        if (n <= 0) continue;
+        const int32_t *pos = pos_all + 3 * lo;
+        if (k > 0) {
+            const int rc = oea_sample_negatives_pair(pos, n, splits_host[s], k, side0, side1, seed, step_base + (uint32_t)s,
+                                                     0u, 10, neg_buf, err_flag, stream);
+            if (rc != OEA_OK) return rc;
+        }
+        const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
+                                             k > 0 ? neg_buf : nullptr, n * (int64_t)k, cfg, workspace, loss_accum,
+                                             OEA_PHASE_BOTH, stream);
+        if (rc != OEA_OK) return rc;
+    }
     return OEA_OK;
 }
 

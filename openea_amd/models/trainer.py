@@ -94,7 +94,8 @@ class RelationTripleEpochs:
         self.batch_size, self.k = batch_size, neg_triple_num
         self.rank, self.world = rank, world
         self.seed = seed
-        self.rng = np.random.RandomState(seed)
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(int(seed))
         self.batches = EpochBatches(kgs.kg1.relation_triples_list, kgs.kg2.relation_triples_list, batch_size, self.dev)
         n_total = kgs.entities_num
         self.s1 = TripleSampler(kgs.kg1.relation_triples_set, kgs.kg1.entities_list, n_total, self.dev)
@@ -104,44 +105,64 @@ class RelationTripleEpochs:
         self.global_step = 0
         b = self.batches
         self.neg_buf = torch.empty(((b.b1 + b.b2) * max(self.k, 1), 3), dtype=torch.int32, device=self.dev)
-        self.pos_buf = torch.empty((b.b1 + b.b2, 3), dtype=torch.int32, device=self.dev)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._sides = None
 
     def set_neighbours(self, nbr1, nbr2):
         self.s1.set_neighbours(nbr1)
         self.s2.set_neighbours(nbr2)
-
-    def _shard(self, t):
-        """this rank's contiguous share of a slice of positives (data parallelism)."""
-        if self.world == 1:
-            return t
-        n = t.shape[0]
-        lo = n * self.rank // self.world
-        hi = n * (self.rank + 1) // self.world
-        return t[lo:hi]
+        self._sides = None
 
     def batch(self, step):
-        """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch."""
-        p1, p2 = self.batches.pos(step)
-        p1, p2 = self._shard(p1), self._shard(p2)
-        n1, n2 = p1.shape[0], p2.shape[0]
-        pos = self.pos_buf[: n1 + n2]
-        pos[:n1].copy_(p1)
-        pos[n1:].copy_(p2)
+        """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch.
+        Under data parallelism this rank takes a contiguous share of the batch rows."""
+        pos, n_split = self.batches.pos(step)
+        off = 0
+        if self.world > 1:
+            n = pos.shape[0]
+            lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
+            pos, n_split, off = pos[lo:hi], min(max(n_split - lo, 0), hi - lo), lo   # same Philox streams as 1 GPU
         neg = None
-        if self.k > 0:
-            neg = self.neg_buf[: (n1 + n2) * self.k]
-            off = self.rank * (self.batches.b1 + self.batches.b2)    # distinct Philox streams per rank
-            if n1:
-                self.s1.sample(p1, self.k, self.seed, self.global_step, pos_offset=off, out=neg[: n1 * self.k])
-            if n2:
-                self.s2.sample(p2, self.k, self.seed, self.global_step, pos_offset=off + n1, out=neg[n1 * self.k:])
+        if self.k > 0 and pos.shape[0] > 0:
+            if self._sides is None:
+                self._sides = (self.s1.side(), self.s2.side())
+            neg = self.neg_buf[: pos.shape[0] * self.k]
+            ops.sample_negatives_pair(pos, n_split, self.k, self._sides[0], self._sides[1], self.seed,
+                                      self.global_step, off, neg, self.err)
         self.global_step += 1
         return pos, neg
 
+    def run_epoch(self, trainer):
+        """All `triple_steps` steps of one epoch.  Single GPU: one C call enqueues the whole epoch
+        (oea_triple_epoch); data parallel: per-step loop with the all-reduce between the phases."""
+        if self.world == 1:
+            if self._sides is None:
+                self._sides = (self.s1.side(), self.s2.side())
+            b = self.batches
+            ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
+                             b.dall, b.offsets, b.splits, self.k, self._sides[0] if self.k else None,
+                             self._sides[1] if self.k else None, self.seed, self.global_step,
+                             self.neg_buf if self.k else None, self.err if self.k else None, trainer.cfg,
+                             trainer.ws, trainer.loss)
+            self.global_step += len(b.splits)
+            n = int(b.offsets[-1])
+        else:
+            n = 0
+            for step in range(len(self.batches.splits)):
+                pos, neg = self.batch(step)
+                if pos.shape[0]:
+                    trainer.step(pos, neg)
+                n += pos.shape[0]
+        self.end_epoch()
+        return n
+
     def end_epoch(self):
-        self.batches.shuffle(self.rng)      # basic_model.py:234-235
-        self.s1.check()
-        self.s2.check()
+        self.batches.shuffle(self.gen)      # basic_model.py:234-235
+
+    def check(self):
+        """raise random.sample's error if a candidate list was smaller than the sample (one sync)."""
+        if int(self.err.item()) != 0:
+            raise ValueError("Sample larger than population or is negative")
 
 
 def refresh_neighbours(ent, entity_list, k):

@@ -77,6 +77,10 @@ class TripleSampler:
         """nbr: device int32 [len(entity_list), k] (rows in entity_list order) or None."""
         self.nbr = nbr
 
+    def side(self):
+        """this KG's state packed for ops.sample_negatives_pair."""
+        return ops.sampler_side(self.table, self.entity_list, self.ent_pos, self.nbr)
+
     def sample(self, pos, k, seed, step, pos_offset=0, out=None, max_try=10):
         """pos: device int32 [n,3] -> device int32 [n*k, 3]."""
         out, _ = ops.sample_negatives(pos, k, self.table, self.entity_list, self.ent_pos, self.nbr, seed=seed,
@@ -102,19 +106,43 @@ class EpochBatches:
         self.upload()
 
     def upload(self):
-        self.d1 = ops.to_ids(self.t1, self.dev)
-        self.d2 = ops.to_ids(self.t2, self.dev)
+        """Lay the epoch out batch by batch -- [step0: KG1 slice | KG2 slice][step1: ...] -- so that
+        batch `step` is ONE contiguous device slice (no per-step concatenation).  The layout is a
+        fixed gather map over cat(list1, list2); an epoch's shuffle only permutes its input."""
+        n1, n2, b1, b2 = len(self.t1), len(self.t2), self.b1, self.b2
+        steps = 0
+        while steps * b1 < n1 or steps * b2 < n2:
+            steps += 1
+        slot, offsets, splits = [], [0], []
+        for s in range(steps):
+            i1 = np.arange(s * b1, min(s * b1 + b1, n1)) if b1 else np.zeros(0, np.int64)
+            i2 = np.arange(s * b2, min(s * b2 + b2, n2)) + n1 if b2 else np.zeros(0, np.int64)
+            slot += [i1, i2]
+            splits.append(len(i1))
+            offsets.append(offsets[-1] + len(i1) + len(i2))
+        self.offsets = np.asarray(offsets, np.int64)
+        self.splits = np.asarray(splits, np.int64)
+        slot = np.concatenate(slot).astype(np.int64) if slot else np.zeros(0, np.int64)
+        self.slot = torch.from_numpy(slot).to(self.dev)
+        self.tall = ops.to_ids(np.concatenate([self.t1, self.t2]), self.dev)      # [n1+n2, 3]
+        self.dall = self.tall[self.slot].contiguous()
+        self.n1, self.n2 = n1, n2
 
-    def shuffle(self, rng):
-        """random.shuffle of both lists (basic_model.py:234-235) with a seeded numpy RNG."""
-        self.t1 = self.t1[rng.permutation(len(self.t1))]
-        self.t2 = self.t2[rng.permutation(len(self.t2))]
-        self.upload()
+    def shuffle(self, gen=None):
+        """random.shuffle of both lists (basic_model.py:234-235): a device permutation of each KG's
+        triples (torch generator = plumbing RNG), then the fixed batch layout gather.  No host
+        round trip; `dall` keeps its address."""
+        p1 = torch.randperm(self.n1, device=self.dev, generator=gen)
+        p2 = torch.randperm(self.n2, device=self.dev, generator=gen) + self.n1
+        perm = torch.cat([p1, p2])
+        self.tall = self.tall[perm]
+        self.dall.copy_(self.tall[self.slot])
 
     def pos(self, step):
-        s1 = self.d1[step * self.b1: step * self.b1 + self.b1]
-        s2 = self.d2[step * self.b2: step * self.b2 + self.b2]
-        return s1, s2
+        """-> (device [n,3] batch, n_split): rows [0, n_split) come from KG1 (batch.py:45)."""
+        if step + 1 >= len(self.offsets):
+            return self.dall[:0], 0
+        return self.dall[int(self.offsets[step]): int(self.offsets[step + 1])], int(self.splits[step])
 
 
 # ----------------------------------------------------------------------------------------------

@@ -86,10 +86,13 @@ def normalize_rows_(table, dim, sklearn=True):
 
 
 def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, neg_margin=0.0,
-                  balance=1.0, ent_l2_norm=True, rel_l2_norm=True, optimizer='Adagrad', lr=0.01):
+                  balance=1.0, ent_l2_norm=True, rel_l2_norm=True, optimizer='Adagrad', lr=0.01,
+                  neg_group_k=0):
+    """neg_group_k = k when the negatives are laid out as the device sampler writes them
+    (neg[p*k:(p+1)*k] corrupt pos p); 0 for arbitrary lists."""
     return StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
                    float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
-                   OPT_KIND[optimizer], float(lr))
+                   OPT_KIND[optimizer], float(lr), int(neg_group_k))
 
 
 def step_workspace(n_ent, n_rel, ld, dev=None):
@@ -154,6 +157,36 @@ def sample_negatives(pos, k, table, entity_list, ent_pos=None, nbr=None, seed=0,
                                      int(step), int(pos_offset), int(max_try), _p(out), _p(err_flag),
                                      _stream()))
     return out, err_flag
+
+
+def sampler_side(table, entity_list, ent_pos, nbr):
+    """pack one KG's sampler state for sample_negatives_pair (keeps the tensors alive)."""
+    side = _lib.SamplerSide(table.data_ptr(), table.numel(), entity_list.data_ptr(),
+                            ent_pos.data_ptr() if ent_pos is not None else None,
+                            nbr.data_ptr() if nbr is not None else None, entity_list.numel(),
+                            0 if nbr is None else nbr.shape[1])
+    side._keep = (table, entity_list, ent_pos, nbr)
+    return side
+
+
+def sample_negatives_pair(pos, n_split, k, side0, side1, seed, step, pos_offset, out, err_flag, max_try=10):
+    """one launch for pos_batch1 + pos_batch2 (batch.py:36-45): rows [0, n_split) against side0."""
+    check(lib().oea_sample_negatives_pair(_p(pos), pos.shape[0], int(n_split), k, C.byref(side0), C.byref(side1),
+                                          int(seed), int(step), int(pos_offset), int(max_try), _p(out), _p(err_flag),
+                                          _stream()))
+    return out
+
+
+def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
+                 neg_buf, err_flag, cfg, workspace, loss_accum):
+    """Enqueue every step of an epoch with one call (offsets / splits: host int64 numpy arrays)."""
+    steps = len(splits)
+    check(lib().oea_triple_epoch(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+                                 ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
+                                 splits.ctypes.data_as(C.c_void_p), steps, int(k),
+                                 C.byref(side0) if side0 is not None else None,
+                                 C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
+                                 _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum), _stream()))
 
 
 # -------------------------------------------------------------------------------------------

@@ -157,6 +157,32 @@ def test_sampler_bit_exact_vs_oracle(ops, golden_dir):
             assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_sampler_neighbour_fallback_and_k64(ops):
+    """entities without a neighbour row (ent_pos = -1: the other KG's entities inside seed-swapped
+    triples) fall back to the whole entity list; k > 16 uses the 64-lane groups."""
+    from oracle import cport
+    rng = np.random.RandomState(9)
+    n_ent = 300
+    ents = np.arange(0, 2 * n_ent, 2).astype(np.int32)             # this KG: even ids
+    triples = np.unique(np.stack([rng.choice(ents, 2000), rng.randint(0, 7, 2000), rng.choice(ents, 2000)], 1), axis=0).astype(np.int32)
+    pos = triples[:200].copy()
+    pos[::3, 0] = 2 * rng.randint(0, n_ent, len(pos[::3])) + 1     # odd ids: no neighbour row
+    ent_pos = np.full(2 * n_ent, -1, np.int32)
+    ent_pos[ents] = np.arange(n_ent, dtype=np.int32)
+    nbr = np.stack([rng.choice(ents, 70, replace=False) for _ in range(n_ent)]).astype(np.int32)
+    table_ref = cport.tripleset_build(triples)
+    table = ops.tripleset_build(ops.to_ids(triples))
+    for k in (10, 40, 64):
+        out, err = ops.sample_negatives(ops.to_ids(pos), k, table, ops.to_ids(ents), ent_pos=ops.to_ids(ent_pos),
+                                        nbr=ops.to_ids(nbr), seed=77, step=5)
+        ref = cport.sample_negatives(pos, k, table_ref, ents, ent_pos, nbr, seed=77, step=5)
+        assert int(err.item()) == 0
+        assert np.array_equal(out.cpu().numpy(), ref)
+        got = out.cpu().numpy().reshape(len(pos), k, 3)
+        assert np.all(got[:, :, 1] == pos[:, None, 1])             # relation preserved (SURVEY A.3)
+        assert np.all((got[:, :, 0] == pos[:, None, 0]) | (got[:, :, 2] == pos[:, None, 2]))
+
+
 # ---------------------------------------------------------------------------------------------
 # translational step
 # ---------------------------------------------------------------------------------------------
@@ -181,11 +207,14 @@ STEP_CASES = [
 ]
 
 
+@pytest.mark.parametrize("grouped", [False, True])
 @pytest.mark.parametrize("case", STEP_CASES, ids=lambda c: "%s-%s-d%d" % (c["loss"], c["loss_norm"], c["d"]))
-def test_triple_step_vs_oracle(ops, case):
+def test_triple_step_vs_oracle(ops, case, grouped):
     from oracle import cport
     case = dict(case)
     k, d = case.pop("k"), case.pop("d")
+    if grouped and (k == 0 or case["loss"] == "margin-based"):
+        pytest.skip("grouped layout applies to per-triple losses with negatives")
     rng = np.random.RandomState(d + k)
     n_ent, n_rel, n_pos = 700, 23, 900
     ent = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32) * 1.3
@@ -207,7 +236,11 @@ def test_triple_step_vs_oracle(ops, case):
     d_racc[:, d:] = 0.1
     ws = ops.step_workspace(n_ent, n_rel, ld)
     loss_acc = torch.zeros(1, dtype=torch.float64, device=d_ent.device)
-    cfg = ops.make_step_cfg(**cfg_kw)
+    if grouped and neg is not None:
+        # a few entries that are NOT corruptions of their positive: must still be scored correctly
+        neg[5] = (3, 2, 9)
+        neg[40] = neg[41]
+    cfg = ops.make_step_cfg(neg_group_k=k if grouped else 0, **cfg_kw)
     d_pos = ops.to_ids(pos)
     d_neg = ops.to_ids(neg) if neg is not None else None
     losses_ref = []
