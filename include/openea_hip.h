@@ -131,6 +131,15 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                           double *loss_accum, int32_t phase, void *stream);
 
+/* Add externally computed gradients w.r.t. the (normalised) entity rows `ids` into the step's
+ * gradient scratch: grad[ids[i]] += src[i].  Followed by oea_triple_step_phase(...,
+ * n_pos = n_neg = 0, OEA_PHASE_APPLY) this runs the optimiser for losses that are not
+ * translational -- MTransE's mapping loss alpha*(sum|e2 - e1 M|^2 + |M M^T - I|^2)
+ * (modules/base/mapping.py:9-19, modules/base/losses.py:76-80), whose d x d GEMMs are plain
+ * library GEMMs on the host side. */
+int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, const int32_t *ids,
+                              int64_t n, const float *src, int32_t src_ld, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Negative sampling -- replaces generate_neg_triples_fast (modules/train/batch.py:89-119).
  * The membership set replaces the python set `all_triples_set`.

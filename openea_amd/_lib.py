@@ -59,6 +59,7 @@ PROTOTYPES = {
     "oea_step_exchange_floats": (_sz, [_i64, _i64, _i32]),
     "oea_triple_step_phase": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
                                         C.POINTER(StepCfg), _vp, _vp, _i32, _vp]),
+    "oea_step_scatter_ent_rows": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "oea_tripleset_capacity": (_u64, [_i64]),
     "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
     "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,

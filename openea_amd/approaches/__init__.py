@@ -1,0 +1,4 @@
+from .aligne import AlignE  # noqa: F401
+from .bootea import BootEA  # noqa: F401
+from .gcn_align import GCN_Align  # noqa: F401
+from .mtranse import MTransE  # noqa: F401

@@ -357,6 +357,23 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
     }
 }
 
+// grad[ids[i], c] += src[i, c]  (gradients w.r.t. NORMALISED rows produced outside the fused step,
+// e.g. MTransE's mapping loss, approaches/mtranse.py:84-96) + touched flags, so that apply_rows
+// pulls them through the normalisation and the optimiser like any other row gradient.
+__global__ void scatter_rows_kernel(float *__restrict__ grad, float *__restrict__ touched, int ld,
+                                    const int32_t *__restrict__ ids, int64_t n, const float *__restrict__ src,
+                                    int src_ld) {
+    const int64_t total = n * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ld;
+        const int c = (int)(i - row * ld);
+        const float v = src[row * src_ld + c];
+        const int32_t id = ids[row];
+        if (v != 0.f) oea::atomic_add_f32(grad + (int64_t)id * ld + c, v);
+        if (c == 0) touched[id] = 1.f;
+    }
+}
+
 template <int G, int IT>
 int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
@@ -407,7 +424,7 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                           double *loss_accum, int32_t phase, void *stream) {
     OEA_REQUIRE(phase >= OEA_PHASE_BOTH && phase <= OEA_PHASE_APPLY, "phase");
-    OEA_REQUIRE(ent && rel && pos && cfg && workspace && loss_accum, "null pointer");
+    OEA_REQUIRE(ent && rel && (pos || n_pos == 0) && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(ld % 4 == 0 && dim <= ld && dim > 0, "ld % 4 == 0 and dim <= ld");
     OEA_REQUIRE(n_pos >= 0 && n_neg >= 0 && (neg || n_neg == 0), "neg == NULL needs n_neg == 0");
     OEA_REQUIRE(cfg->loss_kind >= OEA_LOSS_MARGIN && cfg->loss_kind <= OEA_LOSS_ALIGN, "loss_kind");
@@ -418,7 +435,7 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
         OEA_REQUIRE(n_neg == 0, "positive-only loss takes no negatives");
     OEA_REQUIRE(cfg->neg_group_k >= 0 && (cfg->neg_group_k == 0 || n_neg == n_pos * (int64_t)cfg->neg_group_k),
                 "neg_group_k > 0 needs n_neg == n_pos * neg_group_k");
-    if (n_pos + n_neg == 0) return OEA_OK;
+    if (n_pos + n_neg == 0 && phase != OEA_PHASE_APPLY) return OEA_OK;   // apply-only: externally scattered gradients
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     hipStream_t st = oea::as_stream(stream);
@@ -432,6 +449,18 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     else if (ld <= 1280) OEA_STEP(64, 20);
     else { oea::set_error("dim %d > 1280 unsupported", dim); return OEA_EUNSUPPORTED; }
 #undef OEA_STEP
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, const int32_t *ids,
+                              int64_t n, const float *src, int32_t src_ld, void *stream) {
+    OEA_REQUIRE(workspace && ids && src && ld % 4 == 0 && src_ld >= ld, "shapes");
+    if (n == 0) return OEA_OK;
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    scatter_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n * ld, 256), 65535), 256, 0, oea::as_stream(stream)>>>(
+        ws.ent_grad, ws.ent_touched, ld, ids, n, src, src_ld);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -57,6 +57,7 @@ class TripleTrainer:
             self.ent_acc = self.rel_acc = None
         self.ws = ops.step_workspace(ent.rows, rel.rows, ent.ld, dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._empty = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         self.dist = dist_group
         self.xchg = ops.step_exchange_view(self.ws, ent.rows, rel.rows, ent.ld) if dist_group is not None else None
 
@@ -72,6 +73,16 @@ class TripleTrainer:
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss, phase=ops.PHASE_APPLY)
+
+    def apply_entity_row_grads(self, ids, grads):
+        """optimiser step for gradients w.r.t. the normalised entity rows `ids` computed outside the
+        fused kernel (device [n, ld] fp32): scatter into the scratch, then the apply phase."""
+        ops.step_scatter_ent_rows(self.ws, self.ent.rows, self.rel.rows, self.ent.ld, ids, grads)
+        if self.dist is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
+        ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
+                        self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
 
     def pop_loss(self):
         """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data

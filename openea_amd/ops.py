@@ -112,6 +112,13 @@ def triple_step(ent, ent_acc, rel, rel_acc, dim, pos, neg, cfg, workspace, loss_
                                       C.byref(cfg), _p(workspace), _p(loss_accum), int(phase), _stream()))
 
 
+def step_scatter_ent_rows(workspace, n_ent, n_rel, ld, ids, src):
+    """grad_scratch[ids[i]] += src[i] (+ touched flags): gradients w.r.t. normalised entity rows
+    computed outside the fused step (MTransE mapping loss)."""
+    check(lib().oea_step_scatter_ent_rows(_p(workspace), n_ent, n_rel, ld, _p(ids), ids.numel(), _p(src),
+                                          src.shape[1], _stream()))
+
+
 def step_exchange_view(workspace, n_ent, n_rel, ld):
     """fp32 view of the workspace region (gradient scratch + touched flags) that data-parallel
     ranks sum with one all-reduce."""

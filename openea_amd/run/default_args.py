@@ -1,0 +1,47 @@
+"""Hyper-parameter sets of the approaches on the hot path, as python dicts.
+
+The values are the ones the reference ships in run/args/{mtranse,bootea,aligne,gcnalign}_args_{15K,100K}.json
+(the `args_*` API: one attribute per key).  ``get_args(name, scale)`` returns an ``ARGs`` object that any
+model accepts through ``set_args``; a reference JSON file loaded with ``load_args`` works the same way.
+"""
+from ..modules.args.args_hander import ARGs
+
+_COMMON = dict(training_data="../../datasets/", output="../../output/results/", dataset_division="721_5fold",
+               search_module="greedy", batch_threads_num=2, test_threads_num=4, ordered=True, start_valid=100,
+               eval_freq=10, stop_metric="hits1", csls=10, top_k=[1, 5, 10, 50], is_save=True, max_epoch=2000)
+
+_ARGS = {
+    "MTransE": dict(embedding_module="MTransE", alignment_module="mapping", dim=100, init="unit", ent_l2_norm=True,
+                    rel_l2_norm=True, loss_norm="L2", learning_rate=0.01, optimizer="Adagrad", batch_size=5000,
+                    alpha=5, eval_metric="inner", eval_norm=True),
+    "AlignE": dict(embedding_module="AlignE", alignment_module="swapping", dim=75, init="normal", ent_l2_norm=True,
+                   rel_l2_norm=True, loss="limited", loss_norm="L2", learning_rate=0.01, optimizer="Adagrad",
+                   batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2, neg_sampling="truncated",
+                   neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10, eval_metric="inner", eval_norm=False),
+    "BootEA": dict(embedding_module="BootEA", alignment_module="swapping", dim=100, init="normal", ent_l2_norm=True,
+                   rel_l2_norm=True, loss="limited", loss_norm="L2", learning_rate=0.01, optimizer="Adagrad",
+                   batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2, neg_sampling="truncated",
+                   neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10, eval_metric="inner", eval_norm=False,
+                   sim_th=0.7, k=10, likelihood_slice=10, sub_epoch=10),
+    "GCN_Align": dict(embedding_module="GCN_Align", alignment_module="mapping", dim=100, neg_sampling="uniform",
+                      neg_triple_num=5, learning_rate=8, batch_size=5000, test_threads_num=3, eval_metric="manhattan",
+                      eval_norm=False, support_number=1, se_dim=100, ae_dim=100, hidden1=100, gamma=3,
+                      early_stop=False, dropout=0, test_method="sa", beta=0.9),
+}
+
+# what changes at the 100K scale (run/args/*_100K.json)
+_SCALE_100K = {
+    "MTransE": dict(batch_size=20000),
+    "AlignE": dict(batch_size=20000, truncated_epsilon=0.98),
+    "BootEA": dict(batch_size=20000, truncated_epsilon=0.98),
+    "GCN_Align": dict(batch_size=20000, learning_rate=25),
+}
+
+
+def get_args(name, scale="15K", **overrides):
+    d = dict(_COMMON)
+    d.update(_ARGS[name])
+    if scale == "100K":
+        d.update(_SCALE_100K.get(name, {}))
+    d.update(overrides)
+    return ARGs(d)

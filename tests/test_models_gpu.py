@@ -1,0 +1,138 @@
+"""End-to-end model tests on the GPU: the reference's class protocol
+(set_args / set_kgs / init / run / test / save) on small synthetic KG pairs, plus step-level
+parity of whole-model epochs against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def kgs_small():
+    from openea_amd.modules.load.synth import make_kgs
+    return {mode: make_kgs("small", mode=mode, seed=0) for mode in ("mapping", "swapping")}
+
+
+def _args(name, tmp_path, **kw):
+    from openea_amd.run.default_args import get_args
+    return get_args(name, output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="fold1/", **kw)
+
+
+def test_aligne_epoch_matches_oracle(kgs_small, tmp_path):
+    """one full AlignE epoch through BasicModel == the oracle replaying the same batches/negatives."""
+    from openea_amd.approaches import AlignE
+    from oracle import cport
+    kgs = kgs_small["swapping"]
+    m = AlignE()
+    m.set_args(_args("AlignE", tmp_path, dim=32, batch_size=2000, neg_triple_num=5, max_epoch=1))
+    m.set_kgs(kgs)
+    m.init()
+    ent0, rel0 = m.ent_embeds.raw().copy(), m.rel_embeds.raw().copy()
+    epochs = m._ensure_epochs(True)
+    b = epochs.batches
+    pos_all = b.dall.cpu().numpy()
+    # oracle replay: uniform sampling (no neighbours yet in epoch 1), same Philox streams
+    ea, ra = np.full_like(ent0, 0.1), np.full_like(rel0, 0.1)
+    sides = []
+    for kg in (kgs.kg1, kgs.kg2):
+        el = np.asarray(kg.entities_list, np.int32)
+        sides.append((cport.tripleset_build(np.asarray(sorted(kg.relation_triples_set), np.int32)), el))
+    loss_ref = 0.0
+    for s in range(len(b.splits)):
+        pos = pos_all[b.offsets[s]:b.offsets[s + 1]]
+        sp = int(b.splits[s])
+        neg = np.concatenate([cport.sample_negatives(pos[:sp], 5, sides[0][0], sides[0][1], seed=0, step=s, pos_offset=0),
+                              cport.sample_negatives(pos[sp:], 5, sides[1][0], sides[1][1], seed=0, step=s, pos_offset=sp)])
+        loss_ref += cport.triple_step(ent0, ea, rel0, ra, pos, neg, loss="limited", loss_norm="L2", pos_margin=0.01,
+                                      neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.01)
+    n = epochs.run_epoch(m._trainer)
+    loss = m._trainer.pop_loss()
+    assert n == len(pos_all)
+    assert abs(loss - loss_ref) <= 1e-4 * abs(loss_ref)
+    assert np.linalg.norm(m.ent_embeds.raw() - ent0) <= 1e-4 * np.linalg.norm(ent0)
+    assert np.linalg.norm(m.rel_embeds.raw() - rel0) <= 1e-4 * np.linalg.norm(rel0)
+
+
+@pytest.mark.parametrize("name,mode,kw", [
+    ("MTransE", "mapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, eval_freq=4)),
+    ("AlignE", "swapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, eval_freq=4, truncated_freq=4)),
+    ("BootEA", "swapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, sub_epoch=4, sim_th=0.3)),
+])
+def test_translational_models_end_to_end(kgs_small, tmp_path, name, mode, kw, capsys):
+    import openea_amd.approaches as approaches
+    kgs = kgs_small[mode]
+    model = getattr(approaches, name)()
+    model.set_args(_args(name, tmp_path, **kw))
+    model.set_kgs(kgs)
+    model.init()
+    before = model.valid("hits1")
+    model.run()
+    after = model.valid("hits1")
+    model.test()
+    model.save()
+    out = capsys.readouterr().out
+    assert "Training ends. Total time" in out and "accurate results: hits@[1, 5, 10, 50]" in out
+    assert "accurate results with csls: csls=10" in out
+    assert after >= before                                   # training does not hurt validation Hits@1
+    ent = np.load(model.out_folder + "ent_embeds.npy")
+    assert ent.shape == (kgs.entities_num, kw["dim"]) and ent.dtype == np.float32
+    np.testing.assert_allclose(np.linalg.norm(ent, axis=1), 1.0, rtol=1e-5)     # saved tensor is l2_normalize(var)
+    for f in ("kg1_ent_ids", "kg2_ent_ids", "kg1_rel_ids", "alignment_results_12", "kg1_ent_embeds_txt"):
+        assert os.path.exists(model.out_folder + f)
+    if name == "MTransE":
+        assert np.load(model.out_folder + "mapping_mat.npy").shape == (32, 32)
+
+
+def test_gcn_align_epoch_matches_oracle(kgs_small, tmp_path):
+    from openea_amd.approaches import GCN_Align
+    from oracle import np_oracle as orc
+    kgs = kgs_small["mapping"]
+    m = GCN_Align()
+    m.set_args(_args("GCN_Align", tmp_path, se_dim=48, ae_dim=48, max_epoch=2))
+    m.set_kgs(kgs)
+    m.init()
+    se = m.model_se
+    W0 = se.W[:, :48].cpu().numpy().copy()
+    # the reference adjacency recipe restated independently in the oracle
+    triples = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+    coords, values, shape = orc.gcn_preprocess_adj(orc.gcn_weighted_adj(kgs.entities_num, triples))
+    import scipy.sparse as sp
+    a_ref = sp.coo_matrix((values, (coords[:, 0], coords[:, 1])), shape=shape).tocsr()
+    a_dev = sp.csr_matrix((se.adj.vals.cpu().numpy(), se.adj.colidx.cpu().numpy(), se.adj.rowptr.cpu().numpy()), shape=shape)
+    assert abs(a_ref - a_dev).max() < 1e-6
+    train = np.asarray(kgs.train_links, np.int32)
+    k, t = m.args.neg_triple_num, len(train)
+    rng = np.random.RandomState(5)
+    negs_h = (np.repeat(train[:, 0], k), rng.choice(kgs.entities_num, t * k), rng.choice(kgs.entities_num, t * k),
+              np.repeat(train[:, 1], k))
+    negs_d = tuple(__import__("openea_amd").ops.to_ids(x.astype(np.int32)) for x in negs_h)
+    W_ref = W0.copy()
+    for _ in range(2):
+        se.train_step(negs_d)
+        loss_ref, out_ref = orc.gcn_se_epoch(W_ref, coords, values.astype(np.float32), train, m.args.gamma, k, negs_h,
+                                             m.args.learning_rate)
+    loss = se.pop_loss()
+    W = se.W[:, :48].cpu().numpy()
+    assert np.linalg.norm(W - W_ref) <= 1e-4 * np.linalg.norm(W_ref)
+    np.testing.assert_allclose(se.outputs[:, :48].cpu().numpy(), out_ref, rtol=0, atol=2e-5)
+
+
+def test_gcn_align_end_to_end(kgs_small, tmp_path, capsys):
+    from openea_amd.approaches import GCN_Align
+    kgs = kgs_small["mapping"]
+    m = GCN_Align()
+    m.set_args(_args("GCN_Align", tmp_path, se_dim=32, ae_dim=32, max_epoch=30, start_valid=10, eval_freq=10))
+    m.set_kgs(kgs)
+    m.init()
+    before = m.valid_("hits1")
+    m.run()
+    after = m.valid_("hits1")
+    m.test()
+    m.save()
+    out = capsys.readouterr().out
+    assert "Training ends. Total time" in out and "accurate results" in out
+    assert after >= before
+    assert np.load(m.out_folder + "ent_embeds.npy").shape == (kgs.entities_num, 32)
