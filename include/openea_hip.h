@@ -207,7 +207,8 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
 /* ---------------------------------------------------------------------------------------
  * Alignment evaluation -- replaces sim() + calculate_rank() of greedy_alignment
  * (modules/finding/similarity.py:11-83, modules/finding/alignment.py:13-84,146-168).
- * Gold of row i is column i (n1 <= n2).
+ * Gold of row i is column gold_offset + i (gold_offset = 0 in the reference; a rank that owns
+ * query rows [lo, hi) of a row-sharded evaluation passes gold_offset = lo and its csls_r slice).
  *   rank[i]   = #{j != i : S_ij > S_ii  or (S_ij == S_ii and j < i)}     (0-based)
  *   argmax[i] = smallest j maximising S_ij                               (rank[0])
  * metric: OEA_METRIC_*; csls_r / csls_c: per-row / per-column top-k means (NULL = no CSLS),
@@ -217,7 +218,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
 enum { OEA_METRIC_INNER = 0, OEA_METRIC_MANHATTAN = 1, OEA_METRIC_EUCLIDEAN = 2 };
 size_t oea_rank_workspace_bytes(int64_t n1);
 int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
-                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c,
+                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c, int64_t gold_offset,
                   int32_t *rank, int32_t *argmax, void *workspace, void *stream);
 /* integer reductions of rank[]: hits[i] = #{rank < top_k[i]}, rank_sum = sum(rank+1) (int64),
  * rr_sum = sum 1/(rank+1) (double, fixed summation order).  alignment.py:163-168. */

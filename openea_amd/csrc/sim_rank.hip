@@ -114,7 +114,7 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
 __global__ __launch_bounds__(256) void rank_inner_kernel(
     const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2,
     int dim, const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
-    int tiles_per_chunk, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
+    int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
     __shared__ __attribute__((aligned(16))) float As[TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void rank_inner_kernel(
                         float v = acc[tm][tn][r];
                         if (csls_r) v = (2.0f * v - rq[tn]) - cj;
                         const int64_t i = qi[tn];
-                        cnt[tn] += (j != i) && (v > g[tn] || (v == g[tn] && j < i));
+                        cnt[tn] += (j != i + gold_off) && (v > g[tn] || (v == g[tn] && j < i + gold_off));
                         if (v > best[tn] || (v == best[tn] && (int)j < bidx[tn])) { best[tn] = v; bidx[tn] = (int)j; }
                     }
                 }
@@ -284,7 +284,7 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void rank_valu_kernel(
     const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2, int dim,
     const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
-    int tiles_per_chunk, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
+    int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
     __shared__ double Qs[VK * (VT + 1)];
     __shared__ double Cs[VK * (VT + 1)];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void rank_valu_kernel(
                     const int64_t i = q0 + ty * 4 + a;
                     float v = simv[a][b];
                     if (csls_r) v = (2.0f * v - rq[a]) - cj;
-                    cnt[a] += (j != i) && (v > g[a] || (v == g[a] && j < i));
+                    cnt[a] += (j != i + gold_off) && (v > g[a] || (v == g[a] && j < i + gold_off));
                     if (v > best[a] || (v == best[a] && (int)j < bidx[a])) { best[a] = v; bidx[a] = (int)j; }
                 }
             }
@@ -457,10 +457,10 @@ size_t oea_rank_workspace_bytes(int64_t n1) {
 }
 
 int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
-                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c, int32_t *rank,
-                  int32_t *argmax, void *workspace, void *stream) {
+                  int32_t dim, int32_t metric, const float *csls_r, const float *csls_c, int64_t gold_offset,
+                  int32_t *rank, int32_t *argmax, void *workspace, void *stream) {
     OEA_REQUIRE(e1 && e2 && rank && argmax && workspace, "null pointer");
-    OEA_REQUIRE(n1 >= 0 && n1 <= n2, "gold of row i is column i: n1 <= n2");
+    OEA_REQUIRE(n1 >= 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
     OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
     OEA_REQUIRE((csls_r == nullptr) == (csls_c == nullptr), "csls_r and csls_c go together");
     OEA_REQUIRE(n2 < 0x7fffffff, "n2 < 2^31");
@@ -473,22 +473,22 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
     const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
     int tpc = 1;
     if (metric == OEA_METRIC_INNER) {
-        gold_inner_kernel<<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+        gold_inner_kernel<<<gb, 256, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r, csls_c ? csls_c + gold_offset : nullptr, gold);
         const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
         rank_inner_kernel<<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
-                                                                              csls_c, tpc, rank, keys);
+                                                                              csls_c, tpc, gold_offset, rank, keys);
     } else if (metric == OEA_METRIC_MANHATTAN || metric == OEA_METRIC_EUCLIDEAN) {
         const int64_t qt = oea::ceil_div(n1, VT), ctiles = oea::ceil_div(n2, VT);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
         if (metric == OEA_METRIC_MANHATTAN) {
-            gold_valu_kernel<OEA_METRIC_MANHATTAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+            gold_valu_kernel<OEA_METRIC_MANHATTAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r, csls_c ? csls_c + gold_offset : nullptr, gold);
             rank_valu_kernel<OEA_METRIC_MANHATTAN><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(
-                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, rank, keys);
+                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset, rank, keys);
         } else {
-            gold_valu_kernel<OEA_METRIC_EUCLIDEAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2, ld2, dim, csls_r, csls_c, gold);
+            gold_valu_kernel<OEA_METRIC_EUCLIDEAN><<<gb, 256, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r, csls_c ? csls_c + gold_offset : nullptr, gold);
             rank_valu_kernel<OEA_METRIC_EUCLIDEAN><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(
-                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, rank, keys);
+                e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset, rank, keys);
         }
     } else {
         oea::set_error("unknown metric %d", metric);

@@ -1,0 +1,100 @@
+"""Multi-GPU layer of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on MI355X; "gloo" in the CPU tests).  The reference has no distributed code at all.
+
+What shards and how:
+
+* alignment evaluation and neighbour search -- independent QUERY rows: rank r owns the contiguous
+  row block [lo_r, hi_r) of the queries, the candidate block is replicated (it is an embedding
+  lookup of a replicated table), no data-path collective; the integer metrics are summed with
+  one small all-reduce, per-row outputs (argmax / neighbour ids) are all-gathered.
+* translational step -- one exchange per step: tables replicated, every rank scores its slice
+  of the batch, the gradient scratch is summed with ONE all-reduce, every rank applies the same
+  update (models/trainer.py).
+
+Everything here is index arithmetic + collectives on whatever device the tensors live on, so it
+is exercised on CPU with gloo (tests/test_dist_cpu.py); the compute callbacks default to the HIP
+kernels.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world(group=None):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_range(n, rank, world_size):
+    """contiguous, balanced block [lo, hi) of n rows owned by `rank` (sizes differ by at most 1)."""
+    return n * rank // world_size, n * (rank + 1) // world_size
+
+
+def shard_batch(n, n_split, rank, world_size):
+    """this rank's share of a (pos_batch1 + pos_batch2) batch of n rows whose first n_split rows are
+    KG1's: -> (lo, hi, local_split).  `lo` doubles as the Philox positive offset, so the union of all
+    ranks' negatives equals the single-GPU draw for the same batch."""
+    lo, hi = shard_range(n, rank, world_size)
+    return lo, hi, min(max(n_split - lo, 0), hi - lo)
+
+
+def shard_sizes(n, world_size):
+    return [shard_range(n, r, world_size)[1] - shard_range(n, r, world_size)[0] for r in range(world_size)]
+
+
+def allgather_rows(local, n_total, group=None):
+    """local: this rank's row block [hi-lo, ...] -> the full [n_total, ...] tensor on every rank.
+    Blocks are padded to the largest block so that one all_gather moves everything."""
+    rank, ws = world(group)
+    if ws == 1:
+        return local
+    sizes = shard_sizes(n_total, ws)
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+
+
+def allreduce_sum_(t, group=None):
+    _, ws = world(group)
+    if ws > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def sharded_rank_metrics(e1, e2, dim, top_k, rank_fn, group=None):
+    """Row-sharded greedy_alignment core.  e1 [n1, ld] / e2 [n2, ld]: full (replicated) query and
+    candidate blocks.  rank_fn(e1_block, e2, dim, gold_offset) -> (rank int32 [m], argmax int32 [m])
+    for the query block whose gold columns start at gold_offset.
+    Returns (hits counts list[int], rank_sum int, rr_sum float, argmax int32 [n1]) -- identical on
+    every rank and identical to the unsharded result (integers exactly; rr_sum to fp64 roundoff)."""
+    rank, ws = world(group)
+    n1 = e1.shape[0]
+    lo, hi = shard_range(n1, rank, ws)
+    rk, am = rank_fn(e1[lo:hi], e2, dim, lo)
+    rk64 = rk.to(torch.int64)
+    nk = len(top_k)
+    ints = torch.zeros(nk + 1, dtype=torch.int64, device=rk.device)
+    for i, k in enumerate(top_k):
+        ints[i] = (rk64 < k).sum()
+    ints[nk] = (rk64 + 1).sum()
+    rr = (1.0 / (rk64 + 1).to(torch.float64)).sum().reshape(1)
+    allreduce_sum_(ints, group)
+    allreduce_sum_(rr, group)
+    argmax = allgather_rows(am, n1, group)
+    host = ints.cpu().numpy()
+    return [int(x) for x in host[:nk]], int(host[nk]), float(rr.item()), argmax
+
+
+def sharded_neighbours(embeds, dim, entity_ids, k, topk_fn, group=None):
+    """Row-sharded truncated-neighbour refresh: rank r searches the neighbours of entity rows
+    [lo, hi) among ALL rows; the [N, k] table is all-gathered so every rank's sampler has it.
+    topk_fn(q_block, candidates, dim, k, id_map) -> int32 [m, k]."""
+    rank, ws = world(group)
+    n = embeds.shape[0]
+    lo, hi = shard_range(n, rank, ws)
+    local = topk_fn(embeds[lo:hi], embeds, dim, k, entity_ids)
+    return allgather_rows(local, n, group)

@@ -130,9 +130,9 @@ class RelationTripleEpochs:
         pos, n_split = self.batches.pos(step)
         off = 0
         if self.world > 1:
-            n = pos.shape[0]
-            lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
-            pos, n_split, off = pos[lo:hi], min(max(n_split - lo, 0), hi - lo), lo   # same Philox streams as 1 GPU
+            from .dist import shard_batch
+            lo, hi, n_split = shard_batch(pos.shape[0], n_split, self.rank, self.world)
+            pos, off = pos[lo:hi], lo                                               # same Philox streams as 1 GPU
         neg = None
         if self.k > 0 and pos.shape[0] > 0:
             if self._sides is None:

@@ -212,14 +212,15 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     return out
 
 
-def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None):
+def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0):
+    """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]
-    assert n1 <= n2, "gold of row i is column i: n1 <= n2"
+    assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
     ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
     check(lib().oea_rank_eval(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC[metric],
-                              _p(csls_r), _p(csls_c), _p(rank), _p(argmax), _p(ws), _stream()))
+                              _p(csls_r), _p(csls_c), int(gold_offset), _p(rank), _p(argmax), _p(ws), _stream()))
     return rank, argmax
 
 

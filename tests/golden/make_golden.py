@@ -149,3 +149,36 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def make_load_golden():
+    """id assignment / swapping triples of the reference's loader on a tiny synthetic dataset written
+    by openea_amd.modules.load.synth.write_dataset (URIs are plain strings)."""
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from openea_amd.modules.load.synth import write_dataset
+    ref_kgs = importlib.import_module('openea.modules.load.kgs')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        folder = write_dataset(tmp + "/tiny/", "tiny", seed=4) 
+        for mode in ("mapping", "sharing", "swapping"):
+            kgs = quiet(ref_kgs.read_kgs_from_folder, folder, "721_5fold/1/", mode, True)
+            out[mode] = {
+                "ent_ids1": kgs.kg1.entities_id_dict, "ent_ids2": kgs.kg2.entities_id_dict,
+                "rel_ids1": kgs.kg1.relations_id_dict, "rel_ids2": kgs.kg2.relations_id_dict,
+                "train_links": [list(map(int, x)) for x in kgs.train_links],
+                "valid_links": [list(map(int, x)) for x in kgs.valid_links],
+                "test_links": [list(map(int, x)) for x in kgs.test_links],
+                "entities_num": kgs.entities_num, "relations_num": kgs.relations_num,
+                "kg1_triples": sorted(map(list, kgs.kg1.relation_triples_set)),
+                "kg2_triples": sorted(map(list, kgs.kg2.relation_triples_set)),
+                "kg1_local_triples": len(kgs.kg1.local_relation_triples_set),
+            }
+    with open(os.path.join(HERE, 'load.json'), 'w') as fh:
+        json.dump(out, fh)
+    print('load golden written')
+
+
+if __name__ == '__main__':
+    import_reference()
+    make_load_golden()

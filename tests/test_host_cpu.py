@@ -1,0 +1,134 @@
+"""CPU tests of the host side: the C ABI library loads and exports every symbol the header declares,
+the loader reproduces the reference's id layout (golden from the reference's own loader), the batch
+index arithmetic, args objects, and the product path failing loudly without a GPU."""
+import json
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from openea_amd import _lib
+    header = open(os.path.join(ROOT, "include", "openea_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(oea_[a-z0-9_]+)\s*\(", header))
+    declared -= {"oea_store", "oea_step_cfg", "oea_sampler_side"}
+    assert len(declared) >= 30
+    lib = _lib.load(require_device=False)          # binds every prototype; AttributeError on a missing symbol
+    for name in sorted(declared):
+        assert hasattr(lib, name), "header declares %s but the library does not export it" % name
+        assert name in _lib.PROTOTYPES, "no ctypes prototype for %s" % name
+    assert set(_lib.PROTOTYPES) <= declared
+    assert lib.oea_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from openea_amd import _lib
+    assert C.sizeof(_lib.StepCfg) == 44            # 11 x 4-byte fields of oea_step_cfg
+    assert C.sizeof(_lib.SamplerSide) == 48        # 5 pointers/u64 + 2 int32
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from openea_amd import OpenEAHipError, ops
+    with pytest.raises(OpenEAHipError, match="no HIP device|no CPU fallback"):
+        ops.lib()
+    from openea_amd.modules.finding.similarity import sim
+    with pytest.raises(OpenEAHipError):
+        sim(np.zeros((4, 8), np.float32), np.zeros((4, 8), np.float32))
+    from openea_amd.modules.train import batch as bat
+    with pytest.raises(OpenEAHipError):
+        bat.generate_neg_triples_fast([(0, 0, 1)], {(0, 0, 1)}, [0, 1, 2], 1)
+
+
+def test_no_oracle_import_in_product():
+    """the product package never imports oracle/ (only tests, smoke() and bench's cpu_baseline may)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "openea_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("mode", ["mapping", "sharing", "swapping"])
+def test_loader_matches_reference(golden_dir, mode):
+    from openea_amd.modules.load.kgs import read_kgs_from_folder
+    from openea_amd.modules.load.synth import write_dataset
+    g = json.load(open(os.path.join(golden_dir, "load.json")))[mode]
+    with tempfile.TemporaryDirectory() as tmp:
+        folder = write_dataset(tmp + "/tiny/", "tiny", seed=4)
+        kgs = read_kgs_from_folder(folder, "721_5fold/1/", mode, True)
+    assert kgs.kg1.entities_id_dict == g["ent_ids1"] and kgs.kg2.entities_id_dict == g["ent_ids2"]
+    assert kgs.kg1.relations_id_dict == g["rel_ids1"] and kgs.kg2.relations_id_dict == g["rel_ids2"]
+    assert [list(x) for x in kgs.train_links] == g["train_links"]
+    assert [list(x) for x in kgs.valid_links] == g["valid_links"]
+    assert [list(x) for x in kgs.test_links] == g["test_links"]
+    assert kgs.entities_num == g["entities_num"] and kgs.relations_num == g["relations_num"]
+    assert sorted(map(list, kgs.kg1.relation_triples_set)) == g["kg1_triples"]
+    assert sorted(map(list, kgs.kg2.relation_triples_set)) == g["kg2_triples"]
+    assert len(kgs.kg1.local_relation_triples_set) == g["kg1_local_triples"]
+    if mode == "mapping":        # KG1 even / KG2 odd ids in descending frequency (read.py:64-92)
+        assert all(v % 2 == 0 for v in kgs.kg1.entities_id_dict.values())
+        assert all(v % 2 == 1 for v in kgs.kg2.entities_id_dict.values())
+
+
+def test_pos_batching_matches_reference(golden_dir):
+    from openea_amd.modules.train import batch as bat
+    g = np.load(os.path.join(golden_dir, "pos_batch.npz"))
+    t1 = [tuple(x) for x in g['t1'].tolist()]
+    t2 = [tuple(x) for x in g['t2'].tolist()]
+    for step in (0, 1, 3, 9):
+        got = np.array(bat.generate_pos_batch(t1, t2, 200, step), np.int32).reshape(-1, 3)
+        assert np.array_equal(got, g['step%d' % step])
+    assert bat.batch_sizes(47334 + 18534, 40864 + 16028, 5000) == (int((47334 + 18534) / 122760 * 5000), 5000 - int((47334 + 18534) / 122760 * 5000))
+
+
+def test_util_and_early_stop_match_reference(golden_dir):
+    from openea_amd.modules.finding.evaluation import early_stop
+    from openea_amd.modules.utils.util import merge_dic, task_divide
+    misc = json.load(open(os.path.join(golden_dir, "misc.json")))
+    for key, ref in misc['task_divide'].items():
+        total, n = map(int, key.split('_'))
+        assert [list(map(int, x)) for x in task_divide(list(range(total)), n)] == ref
+    for f1, f2, f, r0, r1, r2 in misc['early_stop']:
+        assert early_stop(f1, f2, f) == (r0, r1, r2)
+    assert merge_dic({1: 2}, {1: 3, 4: 5}) == {1: 3, 4: 5}
+
+
+def test_args_objects(tmp_path):
+    from openea_amd.modules.args.args_hander import load_args
+    from openea_amd.run.default_args import get_args
+    a = get_args("BootEA")
+    assert (a.dim, a.batch_size, a.neg_triple_num, a.truncated_epsilon, a.loss, a.optimizer) == (100, 5000, 10, 0.9, "limited", "Adagrad")
+    assert int((1 - a.truncated_epsilon) * 15000) == 1499
+    a100 = get_args("BootEA", "100K")
+    assert a100.batch_size == 20000 and int((1 - a100.truncated_epsilon) * 100000) == 2000
+    p = tmp_path / "args.json"
+    p.write_text(json.dumps({"dim": 75, "embedding_module": "AlignE", "top_k": [1, 5]}))
+    b = load_args(str(p))
+    assert b.dim == 75 and b.top_k == [1, 5]
+
+
+def test_save_formats(tmp_path):
+    """ent_embeds.npy payload + id tsv files as the reference's save_embeddings writes them."""
+    from openea_amd.modules.load import read as rd
+    from openea_amd.modules.load.synth import make_kgs
+    kgs = make_kgs("tiny", "mapping")
+    ent = np.arange(kgs.entities_num * 4, dtype=np.float32).reshape(-1, 4)
+    rd.save_embeddings(str(tmp_path) + "/", kgs, ent, ent[:kgs.relations_num], None, mapping_mat=np.eye(4, dtype=np.float32))
+    back = np.load(str(tmp_path) + "/ent_embeds.npy")
+    assert back.dtype == np.float32 and back.flags.c_contiguous and np.array_equal(back, ent)
+    ids = rd.read_dict(str(tmp_path) + "/kg1_ent_ids")
+    assert ids == kgs.kg1.entities_id_dict
+    line = open(str(tmp_path) + "/kg1_ent_embeds_txt").readline().split(' ')
+    assert line[0] in kgs.kg1.entities_id_dict and len(line) == 5
+    rd.save_results(str(tmp_path) + "/", [(1, 2), (3, 4)])
+    assert rd.read_pair_ids(str(tmp_path) + "/alignment_results_12") == [(1, 2), (3, 4)]
