@@ -204,7 +204,9 @@ def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, s
 def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     nq, nc = q.shape[0], c.shape[0]
     full = lib().oea_topk_workspace_bytes(nq, nc)
-    ws_bytes = full if ws_bytes is None else min(full, ws_bytes)
+    # default: strips of <= 192 MB so that a strip written by the similarity kernel is still in
+    # the 256 MB Infinity Cache when the select kernel streams it (4 passes)
+    ws_bytes = min(full, max(192 << 20, 128 * ((nc + 31) // 32 * 32) * 4)) if ws_bytes is None else min(full, ws_bytes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     out = torch.empty((nq, k), dtype=torch.int32, device=q.device)
     check(lib().oea_topk_inner(_p(q), nq, q.shape[1], _p(c), nc, c.shape[1], dim, k, _p(id_map), _p(out),

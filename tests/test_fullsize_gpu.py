@@ -1,0 +1,107 @@
+"""BASELINE.json full sizes (EN-FR-100K: 70,000 test pairs, 100,000 entities per KG, k = 2,000
+neighbours, batch 20,000 x 10 negatives) through size-independent properties + oracle spot checks
+on sampled rows (the oracle cannot finish the full problems in seconds)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from openea_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def _unit_rows(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def test_rank_eval_70k(ops):
+    from oracle import cport
+    rng = np.random.RandomState(0)
+    n, d = 70000, 100
+    e1 = _unit_rows(rng, n, d)
+    e2 = e1 + 0.35 * _unit_rows(rng, n, d)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    rank, argmax = ops.rank_eval(t1, t2, d, "inner")
+    rank_h, am_h = rank.cpu().numpy(), argmax.cpu().numpy()
+    # oracle spot check on 96 sampled query rows (each needs all 70,000 candidates)
+    rows = rng.choice(n, 96, replace=False)
+    s = cport.sim_matrix(e1[rows], e2, "inner")
+    g = s[np.arange(len(rows)), rows]
+    cols = np.arange(n)[None, :]
+    ref = ((s > g[:, None]) | ((s == g[:, None]) & (cols < rows[:, None]))).sum(1)
+    assert np.array_equal(rank_h[rows], ref)
+    assert np.array_equal(am_h[rows], s.argmax(1))
+    # properties: ranks in range; metrics kernel == host reductions; Hits monotone in k
+    assert rank_h.min() >= 0 and rank_h.max() < n
+    hits, rs, rr = ops.rank_metrics(rank, [1, 5, 10, 50])
+    assert hits == [int((rank_h < k).sum()) for k in (1, 5, 10, 50)] and hits == sorted(hits)
+    assert rs == int((rank_h.astype(np.int64) + 1).sum())
+    # idempotence: a set evaluated against itself ranks every gold first
+    r2, a2 = ops.rank_eval(t1, t1, d, "inner")
+    assert int(r2.max().item()) == 0 and bool((a2 == torch.arange(n, device=a2.device, dtype=torch.int32)).all().item())
+    # sharded evaluation (two query blocks with gold offsets) == unsharded
+    lo = 33333
+    ra, _ = ops.rank_eval(t1[:lo], t2, d, "inner", gold_offset=0)
+    rb, _ = ops.rank_eval(t1[lo:], t2, d, "inner", gold_offset=lo)
+    assert np.array_equal(np.concatenate([ra.cpu().numpy(), rb.cpu().numpy()]), rank_h)
+
+
+def test_rank_eval_manhattan_10k5(ops):
+    from oracle import cport
+    rng = np.random.RandomState(1)
+    n, d = 10500, 200             # GCN-Align test size: concat(se, ae) = 200 dims, manhattan
+    e1 = _unit_rows(rng, n, d)
+    e2 = e1 + 0.5 * _unit_rows(rng, n, d)
+    rank, argmax = ops.rank_eval(ops.to_table(e1), ops.to_table(e2), d, "manhattan")
+    rows = rng.choice(n, 64, replace=False)
+    s = cport.sim_matrix(e1[rows], e2, "manhattan")
+    g = s[np.arange(len(rows)), rows]
+    ref = ((s > g[:, None]) | ((s == g[:, None]) & (np.arange(n)[None, :] < rows[:, None]))).sum(1)
+    assert np.array_equal(rank.cpu().numpy()[rows], ref)
+
+
+def test_neighbours_100k(ops):
+    from oracle import cport
+    rng = np.random.RandomState(2)
+    n, d, k = 100000, 100, 2000          # int((1 - 0.98) * 100000) = 2000
+    assert int((1 - 0.98) * 100000) == k
+    emb = _unit_rows(rng, n, d)
+    t = ops.to_table(emb)
+    ids = np.arange(n, dtype=np.int32) * 2
+    out = ops.topk_inner(t, t, d, k, id_map=ops.to_ids(ids))
+    out_h = out.cpu().numpy()
+    assert out_h.shape == (n, k)
+    assert np.all(np.diff(out_h, axis=1) > 0)                       # ascending, unique per row
+    assert np.all((out_h == ids[:, None]).any(1))                   # contains the entity itself
+    rows = rng.choice(n, 16, replace=False)
+    ref = cport.topk_inner(emb[rows], emb, k)
+    assert np.array_equal(out_h[rows], ids[ref])
+
+
+def test_step_100k_shape(ops):
+    """EN-FR-100K batch shape: 20,000 positives x 10 negatives, 200,000 entities, dim 100."""
+    from openea_amd.models.trainer import EmbeddingTable, TripleTrainer
+    rng = np.random.RandomState(3)
+    n_ent, n_rel, d, B, k = 200000, 700, 100, 20000, 10
+    ent = EmbeddingTable(rng.standard_normal((n_ent, d)).astype(np.float32), True, "e")
+    rel = EmbeddingTable(rng.standard_normal((n_rel, d)).astype(np.float32), True, "r")
+    pos = np.stack([rng.randint(0, n_ent, B), rng.randint(0, n_rel, B), rng.randint(0, n_ent, B)], 1).astype(np.int32)
+    neg = np.repeat(pos, k, 0)
+    neg[:, 2] = rng.randint(0, n_ent, len(neg))
+    kw = dict(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.01)
+    tg = TripleTrainer(ent, rel, ops.make_step_cfg(neg_group_k=k, **kw))
+    e0 = ent.var.clone()
+    tg.step(ops.to_ids(pos), ops.to_ids(neg))
+    loss_g = tg.pop_loss()
+    touched = (ent.var != e0).any(1)
+    n_touched = int(touched.sum().item())
+    uniq = len(np.unique(np.concatenate([pos[:, 0], pos[:, 2], neg[:, 2]])))
+    assert 0 < n_touched <= uniq                                     # only referenced rows move
+    assert np.isfinite(loss_g) and loss_g > 0
+    assert not bool((tg.ws[: tg.ws.numel() - 8 * 4096] != 0).any().item())
