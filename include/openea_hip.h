@@ -250,6 +250,31 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
                  const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from,
                  float *y, int32_t ldy, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Sparse graph attention -- replaces tf.nn.leaky_relu(values) -> tf.sparse_softmax ->
+ * tf.sparse_tensor_dense_matmul and their gradients (approaches/alinet.py:661-676,
+ * rdgcn.py:202-215).  Segment s owns edges [seg_ptr[s], seg_ptr[s+1]) (the entries normalised
+ * together -- whole rows, or TF1's consecutive runs) and adds its aggregate to output
+ * row seg_row[s].  z: per-edge pre-activation logits; v: [n_cols, ld] values.
+ *   alpha_e = softmax_seg(leaky_relu(z_e)) ;  out[seg_row[s]] += sum_e alpha_e * v[colidx[e]]
+ * out must be zero on entry unless unique_rows != 0 (every row has exactly one segment: rows
+ * are then written, not accumulated; rows without a segment are left untouched).
+ * Backward: dz[e] and dv [n_cols, ld] from dout; t_ptr/t_row/t_edge = the transposed edge list
+ * (per column j: output row and edge id of each incoming edge).
+ * ------------------------------------------------------------------------------------- */
+int oea_sparse_attn_fwd(const int32_t *seg_ptr, const int32_t *seg_row, int64_t n_seg, const int32_t *colidx,
+                        const float *z, const float *v, int32_t dim, int32_t ld, float lrelu_slope,
+                        int32_t unique_rows, float *out, float *alpha, void *stream);
+int oea_sparse_attn_bwd(const int32_t *seg_ptr, const int32_t *seg_row, int64_t n_seg, const int32_t *colidx,
+                        const float *z, const float *v, const float *alpha, const float *dout, int32_t dim,
+                        int32_t ld, float lrelu_slope, const int32_t *t_ptr, const int32_t *t_row,
+                        const int32_t *t_edge, int64_t n_cols, float *dz, float *dv, void *stream);
+
+/* Dense Adam step with tf.train.AdamOptimizer semantics (alinet.py:871, rdgcn.py:332); t = 1-based
+ * step count. */
+int oea_adam_dense(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t t, void *stream);
+
 /* L1 alignment hinge of GCN-Align / RDGCN (approaches/gcn_align.py:298-320,
  * rdgcn.py:293-315): forward + gradient w.r.t. the output embedding table.
  * ILL int32 [t,2]; neg_*: int32 [t*k]; grad [n, ld] must be zero on entry.

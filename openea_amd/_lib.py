@@ -78,6 +78,10 @@ PROTOTYPES = {
     "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "oea_sparse_attn_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "oea_sparse_attn_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i64,
+                                      _vp, _vp, _vp]),
+    "oea_adam_dense": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _vp]),
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "oea_sgd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),

@@ -1,4 +1,5 @@
 from .aligne import AlignE  # noqa: F401
+from .alinet import AliNet  # noqa: F401
 from .bootea import BootEA  # noqa: F401
 from .gcn_align import GCN_Align  # noqa: F401
 from .mtranse import MTransE  # noqa: F401

@@ -1,0 +1,437 @@
+"""AliNet (mirror of openea/approaches/alinet.py); BASELINE.json config 4.
+
+Gated multi-hop neighbourhood aggregation: per layer a GCN over the 1-hop graph and (all but the
+last layer) a graph-attention aggregate over the pattern-filtered 2-hop graph, merged by a highway
+gate; trained full-graph with Adam on an alignment loss over seed links + a relation-translation
+loss.  Sparse operators (tf.sparse_tensor_dense_matmul, leaky_relu -> tf.sparse_softmax -> matmul
+and their gradients) are HIP kernels (csrc/spmm.hip, csrc/sparse_attn.hip); the dense feature
+transforms are plain library GEMMs; Adam is csrc/optim.hip.
+
+TF1 semantics restated, not executed -- PARITY UNPINNED: BatchNormalization is called
+without `training=` -> inference mode with never-updated moving statistics, i.e. the per-feature
+affine y = gamma * x / sqrt(1 + 1e-3) + beta; tf.sparse_softmax grouping is selectable
+(`attn_grouping`: 'row' = per row, 'runs' = TF1 CPU consecutive-run behaviour).
+"""
+import math
+import random
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .. import ops
+from ..models.basic_model import BasicModel
+from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
+from ..modules.bootstrapping.alignment_finder import find_alignment, PairSim
+from ..modules.finding.evaluation import early_stop
+from ..modules.load import read as rd
+from ..modules.utils.util import generate_out_folder
+
+BN_EPS = 1e-3
+
+
+# ---- host-side graph construction (one-off) ----------------------------------------------------
+def normalize_adj(adj):
+    """alinet.py:44-51: adj.dot(D^-1/2).transpose().dot(D^-1/2) as COO (column-major order)."""
+    adj = sp.coo_matrix(adj)
+    rowsum = np.array(adj.sum(1))
+    with np.errstate(divide='ignore'):
+        d_inv_sqrt = np.power(rowsum, -0.5).flatten()
+    d_inv_sqrt[np.isinf(d_inv_sqrt)] = 0.
+    d_mat_inv_sqrt = sp.diags(d_inv_sqrt)
+    return adj.dot(d_mat_inv_sqrt).transpose().dot(d_mat_inv_sqrt).tocoo()
+
+
+def preprocess_adj(adj):
+    """alinet.py:54-57."""
+    return normalize_adj(adj + sp.eye(adj.shape[0]))
+
+
+def no_weighted_adj(total_ent_num, triple_list):
+    """alinet.py:155-181 (1-hop part): undirected 0/1 adjacency, +I, symmetric normalisation."""
+    edge = {}
+    for h, _, t in triple_list:
+        edge.setdefault(h, set()).add(t)
+        edge.setdefault(t, set()).add(h)
+    row, col = [], []
+    for i in range(total_ent_num):
+        if i in edge:
+            row.extend([i] * len(edge[i]))
+            col.extend(list(edge[i]))
+    data = np.ones(len(row))
+    return preprocess_adj(sp.coo_matrix((data, (row, col)), shape=(total_ent_num, total_ent_num)))
+
+
+def remove_unlinked_triples(triples, linked_ents):
+    """alinet.py:240-247."""
+    return list({(h, r, t) for h, r, t in triples if h in linked_ents and t in linked_ents})
+
+
+def generate_rel_ht(triples):
+    """alinet.py:135-141."""
+    d = {}
+    for h, r, t in triples:
+        d.setdefault(r, []).append((h, t))
+    return d
+
+
+def generate_2hop_triples(kg, linked_ents=None):
+    """alinet.py:250-287: 2-step paths h -r1-> m -r2-> t whose endpoints are not 1-hop neighbours,
+    all but the 5 most frequent (r1, r2) patterns kept, plus self loops (h, 0, h)."""
+    triples = kg.triples
+    if linked_ents is not None:
+        triples = remove_unlinked_triples(triples, linked_ents)
+    by_head = {}
+    for h, r, t in triples:
+        by_head.setdefault(h, []).append((r, t))
+    quads, patterns = set(), {}
+    for h, r1, m in triples:                         # pd.merge(left_on='t', right_on='h')
+        for r2, t in by_head.get(m, ()):
+            if t not in kg.out_related_ents_dict.get(h, set()) and h not in kg.in_related_ents_dict.get(t, set()):
+                patterns[(r1, r2)] = patterns.get((r1, r2), 0) + 1   # counted per merged row, like iterrows
+                quads.add((h, r1, r2, t))
+    ranked = sorted(patterns.items(), key=lambda x: x[1], reverse=True)
+    selected = {p for p, _ in ranked[5:]}
+    out = set()
+    for h, r1, r2, t in quads:
+        if (r1, r2) in selected:
+            out.add((h, 0, h))
+            out.add((h, r1 + r2, t))
+    print("selected 2-hop neighbors:", len(out))
+    return out
+
+
+def enhance_triples(kg1, kg2, ents1, ents2):
+    """alinet.py:399-416: triples implied in the other KG by the seed links."""
+    assert len(ents1) == len(ents2)
+    e1, e2 = set(), set()
+    links1, links2 = dict(zip(ents1, ents2)), dict(zip(ents2, ents1))
+    for h1, r1, t1 in kg1.triples:
+        h2, t2 = links1.get(h1), links1.get(t1)
+        if h2 is not None and t2 is not None and t2 not in kg2.out_related_ents_dict.get(h2, set()):
+            e2.add((h2, r1, t2))
+    for h2, r2, t2 in kg2.triples:
+        h1, t1 = links2.get(h2), links2.get(t2)
+        if h1 is not None and t1 is not None and t1 not in kg1.out_related_ents_dict.get(h1, set()):
+            e1.add((h1, r2, t1))
+    print("after enhanced:", len(e1), len(e2))
+    return e1, e2
+
+
+class AKG:
+    """alinet.py:459-493 (the attributes the path uses)."""
+
+    def __init__(self, triples):
+        self.triples = set(triples)
+        self.triple_list = list(self.triples)
+        self.triples_num = len(self.triples)
+        self.heads = {t[0] for t in self.triple_list}
+        self.tails = {t[2] for t in self.triple_list}
+        self.ents = self.heads | self.tails
+        self.out_related_ents_dict, self.in_related_ents_dict = {}, {}
+        for h, r, t in self.triple_list:
+            self.out_related_ents_dict.setdefault(h, set()).add(t)
+            self.in_related_ents_dict.setdefault(t, set()).add(h)
+
+
+# ---- layers -------------------------------------------------------------------------------------
+def glorot_uniform(rng, shape, dev):
+    limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+    return torch.from_numpy(rng.uniform(-limit, limit, shape).astype(np.float32)).to(dev).requires_grad_(True)
+
+
+class BatchNormAffine:
+    """tf.keras.layers.BatchNormalization in inference mode with initial moving statistics."""
+
+    def __init__(self, dim, dev):
+        self.gamma = torch.ones(dim, device=dev, requires_grad=True)
+        self.beta = torch.zeros(dim, device=dev, requires_grad=True)
+
+    def __call__(self, x):
+        return x * (self.gamma / math.sqrt(1.0 + BN_EPS)) + self.beta
+
+    def params(self):
+        return [self.gamma, self.beta]
+
+
+class GraphConvolution:
+    """alinet.py:539-590: BN -> X.W -> A.(XW) -> +bias -> tanh."""
+
+    def __init__(self, rng, input_dim, output_dim, graph, dev):
+        self.graph = graph
+        self.bn = BatchNormAffine(input_dim, dev)
+        self.kernel = glorot_uniform(rng, (input_dim, output_dim), dev)
+        self.bias = torch.zeros(output_dim, device=dev, requires_grad=True)
+
+    def call(self, inputs):
+        x = self.bn(inputs)
+        return torch.tanh(spmm(self.graph, x @ self.kernel) + self.bias)
+
+    def params(self):
+        return self.bn.params() + [self.kernel, self.bias]
+
+
+class AliNetGraphAttentionLayer:
+    """alinet.py:625-677: e_ij = lrelu(a_ij s1_i + a_ij s2_j), softmax per row, aggregate, tanh."""
+
+    def __init__(self, rng, input_dim, output_dim, graph, dev):
+        self.graph = graph
+        self.bn = BatchNormAffine(input_dim, dev)
+        self.kernel = glorot_uniform(rng, (input_dim, output_dim), dev)
+        self.kernel1 = glorot_uniform(rng, (input_dim, input_dim), dev)
+        self.kernel2 = glorot_uniform(rng, (input_dim, input_dim), dev)
+
+    def call(self, inputs):
+        x = self.bn(inputs)
+        mapped = x @ self.kernel
+        s1 = torch.tanh(((x @ self.kernel1) * x).sum(1))
+        s2 = torch.tanh(((x @ self.kernel2) * x).sum(1))
+        g = self.graph
+        z = g.e_vals * s1[g.e_rows] + g.e_vals * s2[g.e_cols]        # sparse_add of the two products (:667-669)
+        return torch.tanh(sparse_attention(g, z, mapped, slope=0.2))
+
+    def params(self):
+        return self.bn.params() + [self.kernel, self.kernel1, self.kernel2]
+
+
+class HighwayLayer:
+    """alinet.py:597-622: gate = relu(tanh(BN(x1) W)); out = tanh(x2 (1 - gate) + x1 gate)."""
+
+    def __init__(self, rng, input_dim, output_dim, dev):
+        self.weight = glorot_uniform(rng, (input_dim, output_dim), dev)
+        self.bn = BatchNormAffine(input_dim, dev)
+
+    def call(self, input1, input2):
+        input1, input2 = self.bn(input1), self.bn(input2)
+        gate = torch.relu(torch.tanh(input1 @ self.weight))
+        return torch.tanh(input2 * (1 - gate) + input1 * gate)
+
+    def params(self):
+        return self.bn.params() + [self.weight]
+
+
+def l2n(x):
+    """tf.nn.l2_normalize(x, 1)."""
+    return x * torch.rsqrt(torch.clamp((x * x).sum(1, keepdim=True), min=1e-12))
+
+
+# ---- the approach -------------------------------------------------------------------------------
+class AliNet(BasicModel):
+
+    def __init__(self):
+        super().__init__()
+        self.is_two = True
+        self.attn_grouping = 'row'
+        self.new_links = set()
+        self.sup_links_set = set()
+        self.new_sup_links_set = set()
+
+    def set_kgs(self, kgs):
+        self.kgs = kgs
+        self.kg1 = AKG(self.kgs.kg1.relation_triples_set)
+        self.kg2 = AKG(self.kgs.kg2.relation_triples_set)
+
+    def init(self):
+        """alinet.py:692-747."""
+        dev = ops.device()
+        self.dev = dev
+        self.ref_ent1 = self.kgs.test_entities1 + self.kgs.valid_entities1
+        self.ref_ent2 = self.kgs.test_entities2 + self.kgs.valid_entities2
+        self.sup_ent1, self.sup_ent2 = self.kgs.train_entities1, self.kgs.train_entities2
+        self.linked_ents = set(self.kgs.train_entities1 + self.kgs.train_entities2 + self.kgs.valid_entities1 +
+                               self.kgs.test_entities1 + self.kgs.test_entities2 + self.kgs.valid_entities2)
+        e1, e2 = enhance_triples(self.kg1, self.kg2, self.sup_ent1, self.sup_ent2)
+        ori_triples = self.kg1.triple_list + self.kg2.triple_list
+        triples = remove_unlinked_triples(ori_triples + list(e1) + list(e2), self.linked_ents)
+        self.rel_ht_dict = generate_rel_ht(triples)
+        n = self.kgs.entities_num
+        one = no_weighted_adj(n, triples)
+        two = no_weighted_adj(n, generate_2hop_triples(self.kg1, self.linked_ents) |
+                              generate_2hop_triples(self.kg2, self.linked_ents))
+        self.adj = [EdgeGraph(one.row, one.col, one.data, one.shape, dev),
+                    EdgeGraph(two.row, two.col, two.data, two.shape, dev, grouping=self.attn_grouping)]
+        self.rel_win_size = self.args.batch_size // max(len(self.rel_ht_dict), 1)
+        if self.rel_win_size <= 1:
+            self.rel_win_size = self.args.min_rel_win
+        self.sim_th = self.args.sim_th
+        self.sup_links = np.stack([self.sup_ent1, self.sup_ent2], 1).astype(np.int64)
+        self._rng = np.random.RandomState(self._seed)
+        random.seed(self._seed)
+        self._get_variable()
+        self._define_model()
+        self.optimizer = TFAdam(self._params, self.args.learning_rate)
+
+    def _get_variable(self):
+        self.init_embedding = glorot_uniform(self._rng, (self.kgs.entities_num, self.args.layer_dims[0]), self.dev)
+
+    def _define_model(self):
+        """alinet.py:784-826 (layer objects; the forward is `_forward`)."""
+        dims = self.args.layer_dims
+        layer_num = len(dims) - 1
+        self.one_hop_layers, self.two_hop_layers, self.highways = [], [], []
+        for i in range(layer_num):
+            self.one_hop_layers.append(GraphConvolution(self._rng, dims[i], dims[i + 1], self.adj[0], self.dev))
+            if i < layer_num - 1:
+                self.two_hop_layers.append(AliNetGraphAttentionLayer(self._rng, dims[i], dims[i + 1], self.adj[1], self.dev))
+                self.highways.append(HighwayLayer(self._rng, dims[i + 1], dims[i + 1], self.dev))
+        self._params = [self.init_embedding]
+        for layer in self.one_hop_layers + self.two_hop_layers + self.highways:
+            self._params += layer.params()
+
+    def _forward(self):
+        layer_num = len(self.args.layer_dims) - 1
+        output_embeds = self.init_embedding
+        outs = []
+        for i in range(layer_num):
+            one = self.one_hop_layers[i].call(output_embeds)
+            if i < layer_num - 1:
+                two = self.two_hop_layers[i].call(output_embeds)
+                output_embeds = self.highways[i].call(two, one)
+            else:
+                output_embeds = one
+            outs.append(output_embeds)
+        return outs
+
+    def _concat_train(self, outs):
+        """alinet.py:835-840: l2n(concat(l2n(out_0), ..., l2n(init)))."""
+        return l2n(torch.cat([l2n(o) for o in outs + [self.init_embedding]], dim=1))
+
+    def compute_loss(self, emb, pos_links, neg_links):
+        """alinet.py:828-850."""
+        e1, e2 = emb[pos_links[:, 0]], emb[pos_links[:, 1]]
+        pos_loss = ((e1 - e2) ** 2).sum()
+        n1, n2 = emb[neg_links[:, 0]], emb[neg_links[:, 1]]
+        neg_loss = torch.relu(self.args.neg_margin - ((n1 - n2) ** 2).sum(1)).sum()
+        return pos_loss + self.args.neg_margin_balance * neg_loss
+
+    def compute_rel_loss(self, emb, hs, ts):
+        """alinet.py:852-866."""
+        h, t = emb[hs], emb[ts]
+        d = emb.shape[1]
+        r = (h - t).reshape(-1, self.rel_win_size, d).mean(1, keepdim=True).repeat(1, self.rel_win_size, 1).reshape(-1, d)
+        return ((h - t - l2n(r)) ** 2).sum() * self.args.rel_param
+
+    # ---- batches (alinet.py:983-1017) ---------------------------------------------------------------
+    def generate_input_batch(self, batch_size, neighbors1=None, neighbors2=None):
+        batch_size = min(batch_size, len(self.sup_ent1))
+        index = np.random.choice(len(self.sup_ent1), batch_size)
+        pos_links = self.sup_links[index]
+        neg_links = []
+        if neighbors1 is None:
+            neg_ent1, neg_ent2 = [], []
+            for _ in range(self.args.neg_triple_num):
+                neg_ent1.extend(random.sample(self.sup_ent1 + self.ref_ent1, batch_size))
+                neg_ent2.extend(random.sample(self.sup_ent2 + self.ref_ent2, batch_size))
+            neg_links.extend(zip(neg_ent1, neg_ent2))
+        else:
+            for i in range(batch_size):
+                e1, e2 = int(pos_links[i, 0]), int(pos_links[i, 1])
+                neg_links.extend((e1, c) for c in random.sample(neighbors1[e1], self.args.neg_triple_num))
+                neg_links.extend((c, e2) for c in random.sample(neighbors2[e2], self.args.neg_triple_num))
+        neg_links = set(neg_links) - self.sup_links_set - self.new_sup_links_set
+        return pos_links, np.array(list(neg_links), np.int64).reshape(-1, 2)
+
+    def generate_rel_batch(self):
+        hs, rs, ts = [], [], []
+        for r, hts in self.rel_ht_dict.items():
+            for h, t in (random.choice(hts) for _ in range(self.rel_win_size)):
+                hs.append(h)
+                ts.append(t)
+                rs.append(r)
+        return hs, rs, ts
+
+    def find_neighbors(self):
+        """alinet.py:1019-1039: cross-KG truncated neighbours on the last layer's normalised output."""
+        if self.args.truncated_epsilon <= 0.0:
+            return None, None
+        start = time.time()
+        with torch.no_grad():
+            last = self._forward()[-1]
+        ents1, ents2 = self.sup_ent1 + self.ref_ent1, self.sup_ent2 + self.ref_ent2
+        d = last.shape[1]
+        emb1 = ops.gather_rows(last.contiguous(), d, ops.to_ids(np.asarray(ents1, np.int32), self.dev), normalize=True)
+        emb2 = ops.gather_rows(last.contiguous(), d, ops.to_ids(np.asarray(ents2, np.int32), self.dev), normalize=True)
+        num = int((1 - self.args.truncated_epsilon) * len(ents1))
+        print("neighbors num", num)
+        n1 = ops.topk_inner(emb1, emb2, d, num, id_map=ops.to_ids(np.asarray(ents2, np.int32), self.dev)).cpu().numpy()
+        n2 = ops.topk_inner(emb2, emb1, d, num, id_map=ops.to_ids(np.asarray(ents1, np.int32), self.dev)).cpu().numpy()
+        print('finding neighbors for sampling costs time: {:.4f}s'.format(time.time() - start))
+        return {e: n1[i].tolist() for i, e in enumerate(ents1)}, {e: n2[i].tolist() for i, e in enumerate(ents2)}
+
+    # ---- evaluation (alinet.py:922-966) -------------------------------------------------------------
+    def _eval_embeds(self, ent1, ent2):
+        with torch.no_grad():
+            outs = self._forward()
+            full = torch.cat([l2n(o) for o in [self.init_embedding] + outs], dim=1).contiguous()
+        d = full.shape[1]
+        parts, off = [], 0
+        e1 = torch.empty((len(ent1), d), device=self.dev)
+        e2 = torch.empty((len(ent2), d), device=self.dev)
+        i1 = torch.as_tensor(ent1, device=self.dev)
+        i2 = torch.as_tensor(ent2, device=self.dev)
+        for o in [self.init_embedding] + outs:              # lookup then l2_normalize again, per block (:933-937)
+            w = o.shape[1]
+            e1[:, off:off + w] = l2n(full[i1, off:off + w])
+            e2[:, off:off + w] = l2n(full[i2, off:off + w])
+            off += w
+        e1.oea_dim = e2.oea_dim = d
+        return e1, e2, None
+
+    def _eval_valid_embeddings(self):
+        if len(self.kgs.valid_links) > 0:
+            return self._eval_embeds(self.kgs.valid_entities1, self.kgs.valid_entities2 + self.kgs.test_entities2)
+        return self._eval_embeds(self.kgs.test_entities1, self.kgs.test_entities2)
+
+    def _eval_test_embeddings(self):
+        return self._eval_embeds(self.kgs.test_entities1, self.kgs.test_entities2)
+
+    def _apply_mapping(self, embeds1, mapping):
+        return embeds1
+
+    def _with_dim(self, t):
+        return t
+
+    def save(self):
+        with torch.no_grad():
+            outs = self._forward()
+            ent_embeds = torch.cat([l2n(o) for o in [self.init_embedding] + outs], dim=1).cpu().numpy()
+        rd.save_embeddings(self.out_folder, self.kgs, ent_embeds, None, None, mapping_mat=None)
+
+    # ---- training (alinet.py:1041-1079) -------------------------------------------------------------
+    def train_step(self, pos_links, neg_links, hs=None, ts=None):
+        outs = self._forward()
+        emb = self._concat_train(outs)
+        dev = self.dev
+        loss = self.compute_loss(emb, torch.as_tensor(pos_links, device=dev), torch.as_tensor(neg_links, device=dev))
+        if hs is not None:
+            loss = loss + self.compute_rel_loss(emb, torch.as_tensor(hs, device=dev), torch.as_tensor(ts, device=dev))
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def run(self):
+        flag1 = flag2 = 0
+        steps = max(len(self.sup_ent2) // self.args.batch_size, 1)
+        neighbors1, neighbors2 = None, None
+        t0 = time.time()
+        for epoch in range(1, self.args.max_epoch + 1):
+            start = time.time()
+            epoch_loss = 0.0
+            for _ in range(steps):
+                pos, neg = self.generate_input_batch(self.args.batch_size, neighbors1, neighbors2)
+                if self.args.rel_param > 0:
+                    hs, _, ts = self.generate_rel_batch()
+                    loss = self.train_step(pos, neg, hs, ts)
+                else:
+                    loss = self.train_step(pos, neg)
+                epoch_loss += float(loss.item())
+            print('epoch {}, loss: {:.4f}, cost time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
+            if epoch % self.args.eval_freq == 0 and epoch >= self.args.start_valid:
+                flag = self.valid(self.args.stop_metric)
+                flag1, flag2, is_stop = early_stop(flag1, flag2, flag)
+                if is_stop:
+                    print("\n == training stop == \n")
+                    break
+                neighbors1, neighbors2 = self.find_neighbors()
+        print("Training ends. Total time = {:.3f} s.".format(time.time() - t0))

@@ -281,3 +281,33 @@ def align_loss_l1(out_emb, dim, ill, k, gamma, neg_left, neg_right, neg2_left, n
 def sgd_rows_(w, grad_t, dim, normalize, lr):
     check(lib().oea_sgd_rows(_p(w), _p(grad_t), w.shape[0], dim, w.shape[1], int(bool(normalize)), float(lr), _stream()))
     return w
+
+
+# -------------------------------------------------------------------------------------------
+# sparse graph attention + dense Adam
+# -------------------------------------------------------------------------------------------
+
+
+def sparse_attn_fwd(seg_ptr, seg_row, colidx, z, v, dim, slope, unique_rows, n_rows):
+    """-> (out [n_rows, ld], alpha [nnz])."""
+    out = torch.zeros((n_rows, v.shape[1]), dtype=torch.float32, device=v.device)
+    alpha = torch.empty_like(z)
+    check(lib().oea_sparse_attn_fwd(_p(seg_ptr), _p(seg_row), seg_row.numel(), _p(colidx), _p(z), _p(v), dim, v.shape[1],
+                                    float(slope), int(bool(unique_rows)), _p(out), _p(alpha), _stream()))
+    return out, alpha
+
+
+def sparse_attn_bwd(seg_ptr, seg_row, colidx, z, v, alpha, dout, dim, slope, t_ptr, t_row, t_edge):
+    """-> (dz [nnz], dv [n_cols, ld])."""
+    dz = torch.empty_like(z)
+    dv = torch.empty_like(v)
+    check(lib().oea_sparse_attn_bwd(_p(seg_ptr), _p(seg_row), seg_row.numel(), _p(colidx), _p(z), _p(v), _p(alpha),
+                                    _p(dout), dim, v.shape[1], float(slope), _p(t_ptr), _p(t_row), _p(t_edge),
+                                    v.shape[0], _p(dz), _p(dv), _stream()))
+    return dz, dv
+
+
+def adam_dense_(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib().oea_adam_dense(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr), float(beta1), float(beta2),
+                               float(eps), int(t), _stream()))
+    return param

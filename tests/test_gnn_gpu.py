@@ -1,0 +1,112 @@
+"""GPU tests of the sparse graph-attention kernels (vs the fp64 oracle), TF-Adam, and AliNet end to end."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from openea_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def _graph(rng, n, avg_deg, with_dups=True):
+    nnz = n * avg_deg
+    rows = np.minimum(rng.zipf(1.6, nnz) - 1, n - 1)
+    cols = rng.randint(0, n, nnz)
+    if with_dups:
+        rows[:20], cols[:20] = rows[20:40], cols[20:40]          # duplicate (row, col) entries (RDGCN r_mat has them)
+    vals = rng.rand(nnz).astype(np.float32) + 0.1
+    return rows, cols, vals
+
+
+@pytest.mark.parametrize("grouping", ["row", "runs"])
+@pytest.mark.parametrize("d", [32, 100, 400])
+def test_sparse_attention_matches_oracle(ops, grouping, d):
+    from openea_amd.models.graph_ops import EdgeGraph, sparse_attention
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(d)
+    n = 500
+    rows, cols, vals = _graph(rng, n, 6)
+    g = EdgeGraph(rows, cols, vals, (n, n), ops.device(), grouping=grouping)
+    if grouping == "runs":
+        assert not g.unique_rows                                   # several segments add into one row
+    z_h = rng.standard_normal(g.nnz).astype(np.float32) * 2
+    v_h = rng.standard_normal((n, d)).astype(np.float32)
+    w_h = rng.standard_normal((n, d)).astype(np.float32)
+    z = torch.tensor(z_h, device=g.dev, requires_grad=True)
+    v = torch.tensor(v_h, device=g.dev, requires_grad=True)
+    out = sparse_attention(g, z, v, slope=0.2)
+    (out * torch.tensor(w_h, device=g.dev)).sum().backward()
+    seg_ptr, seg_row, col = g.seg_ptr.cpu().numpy(), g.seg_row.cpu().numpy(), g.e_colidx.cpu().numpy()
+    out_ref, alpha = orc.sparse_attn_forward(z_h, v_h, seg_ptr, seg_row, col, n)
+    dz_ref, dv_ref = orc.sparse_attn_backward(z_h, v_h, alpha, w_h, seg_ptr, seg_row, col)
+    # fp32 kernels vs fp64 oracle
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), dz_ref, rtol=0, atol=3e-5 * max(1.0, np.abs(dz_ref).max()))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), dv_ref, rtol=0, atol=2e-5 * max(1.0, np.abs(dv_ref).max()))
+    # rows sum to one per segment
+    a = orc.segment_softmax(np.where(z_h > 0, z_h, 0.2 * z_h), seg_ptr)
+    assert np.allclose(np.add.reduceat(a, seg_ptr[:-1][np.diff(seg_ptr) > 0]), 1.0)
+
+
+def test_spmm_autograd(ops):
+    from openea_amd.models.graph_ops import EdgeGraph, spmm
+    rng = np.random.RandomState(1)
+    n, d = 300, 64
+    rows, cols, vals = _graph(rng, n, 5)
+    g = EdgeGraph(rows, cols, vals, (n, n), ops.device())
+    x = torch.tensor(rng.standard_normal((n, d)).astype(np.float32), device=g.dev, requires_grad=True)
+    w = torch.tensor(rng.standard_normal((n, d)).astype(np.float32), device=g.dev)
+    (spmm(g, x) * w).sum().backward()
+    import scipy.sparse as sp
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(n, n)).astype(np.float64)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), a.T @ w.cpu().numpy().astype(np.float64), rtol=0, atol=1e-4)
+
+
+def test_tf_adam(ops):
+    from openea_amd.models.graph_ops import TFAdam
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(2)
+    p_h = rng.standard_normal(1000)
+    p = torch.tensor(p_h.astype(np.float32), device=ops.device(), requires_grad=True)
+    opt = TFAdam([p], lr=1e-3)
+    m, v = np.zeros(1000), np.zeros(1000)
+    for t in range(1, 6):
+        g = rng.standard_normal(1000).astype(np.float32)
+        p.grad = torch.tensor(g, device=p.device)
+        opt.step()
+        orc.adam_tf(p_h, g.astype(np.float64), m, v, 1e-3, t)
+    np.testing.assert_allclose(p.detach().cpu().numpy(), p_h, rtol=0, atol=2e-6)
+
+
+def test_alinet_end_to_end(ops, tmp_path, capsys):
+    from openea_amd.approaches import AliNet
+    from openea_amd.modules.load.synth import make_kgs
+    from openea_amd.run.default_args import get_args
+    kgs = make_kgs("small", mode="mapping", seed=0)
+    m = AliNet()
+    m.set_args(get_args("AliNet", output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/",
+                        layer_dims=[64, 48, 32], batch_size=600, max_epoch=20, start_valid=10, eval_freq=10,
+                        truncated_epsilon=0.9))
+    m.set_kgs(kgs)
+    m.init()
+    before = m.valid("hits1")
+    m.run()
+    after = m.valid("hits1")
+    m.test()
+    m.save()
+    out = capsys.readouterr().out
+    assert "Training ends. Total time" in out and "accurate results with csls" in out, out[-2000:]
+    assert after >= before
+    n1, n2 = m.find_neighbors()                      # cross-KG truncated neighbours (alinet.py:1019-1039)
+    num = int((1 - 0.9) * len(m.sup_ent1 + m.ref_ent1))
+    assert len(n1) == len(m.sup_ent1 + m.ref_ent1) and all(len(v) == num for v in list(n1.values())[:50])
+    assert set(next(iter(n1.values()))) <= set(m.sup_ent2 + m.ref_ent2)
+    pos, neg = m.generate_input_batch(100, n1, n2)
+    assert pos.shape == (100, 2) and neg.shape[1] == 2 and len(neg) <= 2 * 100 * m.args.neg_triple_num
+    ent = np.load(m.out_folder + "ent_embeds.npy")
+    assert ent.shape == (kgs.entities_num, 64 + 48 + 32)

@@ -109,3 +109,31 @@ def test_philox_known_answer():
     assert [hex(x) for x in out] == ['0x408f276d', '0x41c83b0e', '0xa20bc7c6', '0x6d5451fd']
     out = cport.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])
     assert [hex(x) for x in out] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
+
+
+def test_sparse_attention_oracle_gradient_by_finite_differences():
+    rng = np.random.RandomState(0)
+    n_rows, n_cols, d = 7, 9, 5
+    seg_ptr = np.array([0, 3, 3, 4, 9, 11])          # an empty segment and two segments on one row
+    seg_row = np.array([0, 1, 2, 4, 4])
+    colidx = rng.randint(0, n_cols, 11)
+    z = rng.standard_normal(11)
+    v = rng.standard_normal((n_cols, d))
+    w = rng.standard_normal((n_rows, d))             # loss = sum(out * w)
+    out, alpha = orc.sparse_attn_forward(z, v, seg_ptr, seg_row, colidx, n_rows)
+    dz, dv = orc.sparse_attn_backward(z, v, alpha, w, seg_ptr, seg_row, colidx)
+    eps = 1e-6
+    for e in range(11):
+        zp, zm = z.copy(), z.copy()
+        zp[e] += eps
+        zm[e] -= eps
+        num = ((orc.sparse_attn_forward(zp, v, seg_ptr, seg_row, colidx, n_rows)[0] -
+                orc.sparse_attn_forward(zm, v, seg_ptr, seg_row, colidx, n_rows)[0]) * w).sum() / (2 * eps)
+        assert abs(num - dz[e]) < 1e-6
+    for (j, c) in [(0, 0), (3, 2), (8, 4), (int(colidx[5]), 1)]:
+        vp, vm = v.copy(), v.copy()
+        vp[j, c] += eps
+        vm[j, c] -= eps
+        num = ((orc.sparse_attn_forward(z, vp, seg_ptr, seg_row, colidx, n_rows)[0] -
+                orc.sparse_attn_forward(z, vm, seg_ptr, seg_row, colidx, n_rows)[0]) * w).sum() / (2 * eps)
+        assert abs(num - dv[j, c]) < 1e-6
