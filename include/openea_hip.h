@@ -204,6 +204,13 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
                    int32_t dim, int32_t k, const int32_t *id_map, int32_t *out_idx, void *workspace,
                    size_t ws_bytes, void *stream);
 
+/* The selection half alone, on a similarity strip that already exists: out_idx[i, :] = the k columns
+ * with the largest s[i, :] ((value desc, column asc), ascending column order).  RDGCN's hard-negative
+ * mining (approaches/rdgcn.py:75-87: cdist cityblock + argsort()[0:k]) = oea_sim_matrix(manhattan)
+ * + this call. */
+int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
+                  int32_t *out_idx, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Alignment evaluation -- replaces sim() + calculate_rank() of greedy_alignment
  * (modules/finding/similarity.py:11-83, modules/finding/alignment.py:13-84,146-168).

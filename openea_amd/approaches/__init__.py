@@ -3,3 +3,4 @@ from .alinet import AliNet  # noqa: F401
 from .bootea import BootEA  # noqa: F401
 from .gcn_align import GCN_Align  # noqa: F401
 from .mtranse import MTransE  # noqa: F401
+from .rdgcn import RDGCN  # noqa: F401

@@ -1,0 +1,310 @@
+"""RDGCN (mirror of openea/approaches/rdgcn.py); BASELINE.json config 5.
+
+Relation-aware dual-graph convolution: a dual graph over the relations (dense R x R attention,
+R ~ 700) interacts twice with the primal entity graph through a sparse attention aggregate whose
+per-edge logit is a learned scalar of the edge's relation (rdgcn.py:202-215); two diagonal-weight
+GCN layers with highway gates follow; L1 margin loss over seed links with hard negatives mined by
+L1 nearest-neighbour search every 10 epochs (rdgcn.py:75-87, 466-490); Adam.
+
+Device kernels: the primal sparse attention (csrc/sparse_attn.hip), the GCN aggregate and the
+per-relation head/tail averages (csrc/spmm.hip), the L1 hinge (oea_align_loss_l1), hard-negative
+mining (fp64 L1 similarity strip + radix select: oea_sim_matrix + oea_topk_rows), Adam
+(csrc/optim.hip).  The dual graph is tiny and dense: plain library GEMMs + softmax.
+
+Reproduced quirks: `get_mat` compares head with RELATION id and increments
+degree[relation id] (rdgcn.py:49-51).  The entity input is the summed word vectors of the entity
+names (rdgcn.py:415-464) when `word_embed` exists; the file is not available offline, so the
+default here is the reference's own alternative `get_input_layer` (glorot, rdgcn.py:280-282).
+TF1 semantics restated, not executed: PARITY UNPINNED.
+"""
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..models.basic_model import BasicModel
+from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
+from ..modules.finding.evaluation import early_stop, test, valid
+from ..modules.load import read as rd
+
+
+# ---- host-side structures -----------------------------------------------------------------------
+def rfunc(triple_list, ent_num, rel_num):
+    """rdgcn.py:17-42: head/tail entity sets per relation, and r_mat = one edge (h, t) per triple in
+    triple_list order carrying the relation id (duplicated (h, t) pairs stay separate edges)."""
+    head, tail = {}, {}
+    r_mat_ind, r_mat_val = [], []
+    for h, r, t in triple_list:
+        head.setdefault(r, set()).add(h)
+        tail.setdefault(r, set()).add(t)
+        r_mat_ind.append((h, t))
+        r_mat_val.append(r)
+    return head, tail, np.asarray(r_mat_ind, np.int64).reshape(-1, 2), np.asarray(r_mat_val, np.int64)
+
+
+def get_mat(triple_list, ent_num):
+    """rdgcn.py:45-59 including the head-vs-relation comparison and degree[relation] increment."""
+    degree = [1] * ent_num
+    pos = {}
+    for h, r, t in triple_list:
+        if h != r:
+            degree[h] += 1
+            degree[r] += 1
+        if h == t:
+            continue
+        if (h, t) not in pos:
+            pos[(h, t)] = 1
+            pos[(t, h)] = 1
+    for i in range(ent_num):
+        pos[(i, i)] = 1
+    return pos, degree
+
+
+def get_sparse_tensor(triple_list, ent_num):
+    """rdgcn.py:63-72: M[sec, fir] = 1 / sqrt(deg[fir]) / sqrt(deg[sec])."""
+    pos, degree = get_mat(triple_list, ent_num)
+    rows, cols, vals = [], [], []
+    for fir, sec in pos:
+        rows.append(sec)
+        cols.append(fir)
+        vals.append(pos[(fir, sec)] / math.sqrt(degree[fir]) / math.sqrt(degree[sec]))
+    return np.asarray(rows), np.asarray(cols), np.asarray(vals, np.float32)
+
+
+def dual_adjacency(head, tail, count_r):
+    """rdgcn.py:268-277: Jaccard overlap of head sets + of tail sets, dense [R, R]."""
+    a = np.zeros((count_r, count_r), np.float32)
+    for i in range(count_r):
+        hi, ti = head.get(i, set()), tail.get(i, set())
+        for j in range(count_r):
+            hj, tj = head.get(j, set()), tail.get(j, set())
+            a_h = len(hi & hj) / len(hi | hj) if (hi | hj) else 0.0
+            a_t = len(ti & tj) / len(ti | tj) if (ti | tj) else 0.0
+            a[i, j] = a_h + a_t
+    return a
+
+
+def glorot(rng, shape, dev):
+    r = math.sqrt(6.0 / (shape[0] + shape[1]))
+    return torch.from_numpy(rng.uniform(-r, r, shape).astype(np.float32)).to(dev).requires_grad_(True)
+
+
+class AlignLossL1(torch.autograd.Function):
+    """get_loss (rdgcn.py:293-315) = GCN-Align's align_loss: forward + gradient in one HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, out, ill, k, gamma, negs):
+        out = out.contiguous()
+        grad = torch.zeros_like(out)
+        loss = torch.zeros(1, dtype=torch.float64, device=out.device)
+        ops.align_loss_l1(out, out.shape[1], ill, k, gamma, negs[0], negs[1], negs[2], negs[3], grad, loss)
+        ctx.save_for_backward(grad)
+        return loss.to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None, None, None, None
+
+
+class Layer:
+    """rdgcn.py:162-338."""
+
+    def __init__(self, args, kgs, embedding, dev, seed=0, attn_grouping='row'):
+        self.args, self.dev = args, dev
+        self.dim = args.dim
+        self.gamma, self.k, self.alpha, self.beta = args.gamma, args.neg_triple_num, args.alpha, args.beta
+        self.ILL = np.array(kgs.train_links)
+        self.ill_dev = ops.to_ids(self.ILL.astype(np.int32), dev)
+        self.triple_list = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+        self.rel_num, self.ent_num = kgs.relations_num, kgs.entities_num
+        rng = np.random.RandomState(seed)
+        self.head, self.tail, r_ind, r_val = rfunc(self.triple_list, self.ent_num, self.rel_num)
+        self.count_r = len(self.head)
+        rows, cols, vals = get_sparse_tensor(self.triple_list, self.ent_num)
+        self.M = EdgeGraph(rows, cols, vals, (self.ent_num, self.ent_num), dev)
+        self.r_graph = EdgeGraph(r_ind[:, 0], r_ind[:, 1], np.ones(len(r_ind), np.float32),
+                                 (self.ent_num, self.ent_num), dev, grouping=attn_grouping)
+        # relation id of every attention edge, in the graph's (possibly re-ordered) edge order
+        order = np.lexsort((r_ind[:, 1], r_ind[:, 0])) if attn_grouping == 'row' else np.arange(len(r_ind))
+        self.edge_rel = torch.from_numpy(r_val[order]).to(dev)
+        # compute_r (rdgcn.py:258-266): per-relation mean of its head / tail entity embeddings
+        hr = [(r, h) for r, hs in self.head.items() for h in hs]
+        tr = [(r, t) for r, ts in self.tail.items() for t in ts]
+        hcnt = np.bincount([r for r, _ in hr], minlength=self.count_r).astype(np.float32)
+        tcnt = np.bincount([r for r, _ in tr], minlength=self.count_r).astype(np.float32)
+        self.head_mean = EdgeGraph([r for r, _ in hr], [h for _, h in hr], [1.0 / hcnt[r] for r, _ in hr],
+                                   (self.count_r, self.ent_num), dev)
+        self.tail_mean = EdgeGraph([r for r, _ in tr], [t for _, t in tr], [1.0 / tcnt[r] for r, _ in tr],
+                                   (self.count_r, self.ent_num), dev)
+        self.dual_A = torch.from_numpy(dual_adjacency(self.head, self.tail, self.count_r)).to(dev)
+        self.dual_bias = -1e9 * (1.0 - (self.dual_A > 0).float())
+        d = self.dim
+        # ---- variables (creation order of rdgcn.py:317-338) ---------------------------------------
+        if embedding is not None:
+            self.primal_X_0 = torch.tensor(np.asarray(embedding, np.float32), device=dev, requires_grad=True)
+        else:
+            self.primal_X_0 = glorot(rng, (self.ent_num, d), dev)                 # get_input_layer
+        p = {}
+        p['sa_w'] = glorot(rng, (2 * d, d), dev)                                  # add_self_att_layer: conv1d(dim, 1), no bias
+        p['sa_f1'], p['sa_b1'] = glorot(rng, (d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['sa_f2'], p['sa_b2'] = glorot(rng, (d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['pa1_w'], p['pa1_b'] = glorot(rng, (2 * d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['da_w'], p['da_b'] = glorot(rng, (2 * d, d), dev), torch.zeros(d, device=dev, requires_grad=True)
+        p['da_f1'], p['da_b1'] = glorot(rng, (d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['da_f2'], p['da_b2'] = glorot(rng, (d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['pa2_w'], p['pa2_b'] = glorot(rng, (2 * d, 1), dev), torch.zeros(1, device=dev, requires_grad=True)
+        p['diag1'] = torch.ones((1, d), device=dev, requires_grad=True)           # add_diag_layer init=ones
+        p['hw1_w'], p['hw1_b'] = glorot(rng, (d, d), dev), torch.zeros(d, device=dev, requires_grad=True)
+        p['diag2'] = torch.ones((1, d), device=dev, requires_grad=True)
+        p['hw2_w'], p['hw2_b'] = glorot(rng, (d, d), dev), torch.zeros(d, device=dev, requires_grad=True)
+        self.p = p
+
+    def params(self):
+        return [self.primal_X_0] + list(self.p.values())
+
+    # ---- layers --------------------------------------------------------------------------------------
+    def compute_r(self, inlayer):
+        return torch.cat([spmm(self.head_mean, inlayer), spmm(self.tail_mean, inlayer)], dim=-1)
+
+    def _dense_att(self, in_fts, f1, b1, f2, b2, values):
+        logits = (in_fts @ f1 + b1) + (in_fts @ f2 + b2).t()
+        logits = self.dual_A * logits
+        coefs = torch.softmax(torch.nn.functional.leaky_relu(logits, 0.2) + self.dual_bias, dim=-1)
+        return torch.relu(coefs @ values)
+
+    def add_self_att_layer(self, inlayer):
+        """rdgcn.py:233-248."""
+        p = self.p
+        return self._dense_att(inlayer @ p['sa_w'], p['sa_f1'], p['sa_b1'], p['sa_f2'], p['sa_b2'], inlayer)
+
+    def add_dual_att_layer(self, inlayer, inlayer2):
+        """rdgcn.py:217-231."""
+        p = self.p
+        return self._dense_att(inlayer2 @ p['da_w'] + p['da_b'], p['da_f1'], p['da_b1'], p['da_f2'], p['da_b2'], inlayer)
+
+    def add_sparse_att_layer(self, inlayer, dual_layer, w, b):
+        """rdgcn.py:202-215: logit of an edge = conv1d(dual feature of its relation)."""
+        dual_transform = (dual_layer @ w + b).reshape(-1)
+        z = dual_transform[self.edge_rel]
+        return torch.relu(sparse_attention(self.r_graph, z, inlayer, slope=0.2))
+
+    def add_diag_layer(self, inlayer, w0):
+        """rdgcn.py:184-191."""
+        return torch.relu(spmm(self.M, inlayer * w0))
+
+    @staticmethod
+    def highway(layer1, layer2, kernel_gate, bias_gate):
+        """rdgcn.py:250-256."""
+        gate = torch.sigmoid(layer1 @ kernel_gate + bias_gate)
+        return gate * layer2 + (1.0 - gate) * layer1
+
+    def forward(self):
+        """rdgcn.py:317-337."""
+        p = self.p
+        x0 = self.primal_X_0
+        dual_H_1 = self.add_self_att_layer(self.compute_r(x0))
+        x1 = x0 + self.alpha * self.add_sparse_att_layer(x0, dual_H_1, p['pa1_w'], p['pa1_b'])
+        dual_H_2 = self.add_dual_att_layer(dual_H_1, self.compute_r(x1))
+        x2 = x0 + self.beta * self.add_sparse_att_layer(x1, dual_H_2, p['pa2_w'], p['pa2_b'])
+        g1 = self.highway(x2, self.add_diag_layer(x2, p['diag1']), p['hw1_w'], p['hw1_b'])
+        return self.highway(g1, self.add_diag_layer(g1, p['diag2']), p['hw2_w'], p['hw2_b'])
+
+    def loss(self, out, negs):
+        return AlignLossL1.apply(out, self.ill_dev, self.k, float(self.gamma), negs)
+
+
+def get_neg(ill_ids, output_layer, dim, k):
+    """rdgcn.py:75-87: the k L1-nearest entities of every seed entity among ALL entities (the seed
+    itself included, as in the reference) -> device int32 [t*k]."""
+    q = ops.gather_rows(output_layer, dim, ill_ids)
+    s = ops.sim_matrix(q, output_layer, dim, 'manhattan')        # 1 - cityblock distance, fp64 inside
+    return ops.topk_rows(s, k).reshape(-1)
+
+
+class RDGCN(BasicModel):
+    def __init__(self):
+        super().__init__()
+        self.word_embed = '../../datasets/wiki-news-300d-1M.vec'
+        self.local_name_vectors = None
+        self.attn_grouping = 'row'
+
+    def init(self):
+        self.dev = ops.device()
+        if os.path.exists(self.word_embed):
+            raise NotImplementedError("word-vector name initialisation (rdgcn.py:415-464) needs the fastText file; "
+                                      "pass model.local_name_vectors = <[E, dim] array> instead")
+        self.gcn_model = Layer(self.args, self.kgs, self.local_name_vectors, self.dev, seed=self._seed,
+                               attn_grouping=self.attn_grouping)
+        self.optimizer = TFAdam(self.gcn_model.params(), self.args.learning_rate)
+
+    def _output(self):
+        with torch.no_grad():
+            return self.gcn_model.forward().contiguous()
+
+    def training(self):
+        """rdgcn.py:466-499."""
+        neg_num = self.args.neg_triple_num
+        train_links = np.array(self.kgs.train_links)
+        dev, d = self.dev, self.args.dim
+        neg_left = ops.to_ids(np.repeat(train_links[:, 0], neg_num).astype(np.int32), dev)
+        neg2_right = ops.to_ids(np.repeat(train_links[:, 1], neg_num).astype(np.int32), dev)
+        ill1 = ops.to_ids(train_links[:, 0].astype(np.int32), dev)
+        ill2 = ops.to_ids(train_links[:, 1].astype(np.int32), dev)
+        negs = None
+        for i in range(1, self.args.max_epoch + 1):
+            start = time.time()
+            if i % 10 == 1:
+                output = self._output()
+                neg2_left = get_neg(ill2, output, d, neg_num)
+                neg_right = get_neg(ill1, output, d, neg_num)
+                negs = (neg_left, neg_right, neg2_left, neg2_right)
+            out = self.gcn_model.forward()
+            loss = self.gcn_model.loss(out, negs)
+            loss.backward()
+            self.optimizer.step()
+            if i % 10 == 0 or i == 1:
+                print('epoch {}, avg. relation triple loss: {:.4f}, cost time: {:.4f}s'.format(i, float(loss.item()),
+                                                                                               time.time() - start))
+            if i >= self.args.start_valid and i % self.args.eval_freq == 0:
+                flag = self.valid_(self.args.stop_metric)
+                self.flag1, self.flag2, self.early_stop = early_stop(self.flag1, self.flag2, flag)
+                if self.early_stop or i == self.args.max_epoch:
+                    break
+
+    def _pick(self, emb, ids):
+        out = ops.gather_rows(emb, self.args.dim, ops.to_ids(np.asarray(ids, np.int32), self.dev))
+        out.oea_dim = self.args.dim
+        return out
+
+    def valid_(self, stop_metric):
+        """rdgcn.py:519-527."""
+        emb = self._output()
+        hits1_12, mrr_12 = valid(self._pick(emb, self.kgs.valid_entities1),
+                                 self._pick(emb, self.kgs.valid_entities2 + self.kgs.test_entities2), None,
+                                 self.args.top_k, self.args.test_threads_num, metric=self.args.eval_metric)
+        return hits1_12 if stop_metric == 'hits1' else mrr_12
+
+    def test(self, save=True):
+        """rdgcn.py:501-512."""
+        emb = self._output()
+        e1, e2 = self._pick(emb, self.kgs.test_entities1), self._pick(emb, self.kgs.test_entities2)
+        rest_12, _, _ = test(e1, e2, None, self.args.top_k, self.args.test_threads_num, metric=self.args.eval_metric,
+                             normalize=self.args.eval_norm, csls_k=0, accurate=True)
+        test(e1, e2, None, self.args.top_k, self.args.test_threads_num, metric=self.args.eval_metric,
+             normalize=self.args.eval_norm, csls_k=self.args.csls, accurate=True)
+        if save:
+            rd.save_results(self.out_folder, [(self.kgs.test_entities1[i], self.kgs.test_entities2[j]) for i, j in rest_12])
+
+    def save(self):
+        rd.save_embeddings(self.out_folder, self.kgs, self._output()[:, :self.args.dim].cpu().numpy(), None, None,
+                           mapping_mat=None)
+
+    def run(self):
+        t = time.time()
+        self.training()
+        print("training finish")
+        print("Training ends. Total time = {:.3f} s.".format(time.time() - t))

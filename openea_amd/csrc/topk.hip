@@ -131,6 +131,16 @@ size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
     return (size_t)nq * (size_t)ld * sizeof(float);
 }
 
+int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
+                  int32_t *out_idx, void *stream) {
+    OEA_REQUIRE(s && out_idx, "null pointer");
+    OEA_REQUIRE(k >= 1 && k <= nc && ld >= nc, "1 <= k <= nc <= ld");
+    if (n_rows == 0) return OEA_OK;
+    row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, oea::as_stream(stream)>>>(s, n_rows, nc, ld, k, id_map, out_idx);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
 int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int64_t nc, int32_t ldc,
                    int32_t dim, int32_t k, const int32_t *id_map, int32_t *out_idx, void *workspace,
                    size_t ws_bytes, void *stream) {

@@ -214,6 +214,13 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     return out
 
 
+def topk_rows(s, k, id_map=None):
+    """k largest columns of every row of a device similarity strip [n, nc] -> int32 [n, k]."""
+    out = torch.empty((s.shape[0], k), dtype=torch.int32, device=s.device)
+    check(lib().oea_topk_rows(_p(s), s.shape[0], s.shape[1], s.stride(0), k, _p(id_map), _p(out), _stream()))
+    return out
+
+
 def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0):
     """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]

@@ -27,6 +27,9 @@ _ARGS = {
                       neg_triple_num=5, learning_rate=8, batch_size=5000, test_threads_num=3, eval_metric="manhattan",
                       eval_norm=False, support_number=1, se_dim=100, ae_dim=100, hidden1=100, gamma=3,
                       early_stop=False, dropout=0, test_method="sa", beta=0.9),
+    "RDGCN": dict(embedding_module="RDGCN", alignment_module="mapping", dim=300, neg_sampling="uniform",
+                  neg_triple_num=125, learning_rate=0.002, batch_size=5000, test_threads_num=3, start_valid=30,
+                  eval_metric="manhattan", eval_norm=False, gamma=1.0, dropout=0, beta=0.3, alpha=0.1),
     "AliNet": dict(embedding_module="AliNet", alignment_module="mapping", layer_dims=[500, 400, 300], init="xavier",
                    ent_l2_norm=True, rel_l2_norm=True, learning_rate=0.001, optimizer="Adam", batch_size=3000,
                    neg_margin=1.5, neg_margin_balance=0.1, dropout=0.0, neg_sampling="truncated", neg_triple_num=10,
@@ -42,6 +45,7 @@ _SCALE_100K = {
     "BootEA": dict(batch_size=20000, truncated_epsilon=0.98),
     "GCN_Align": dict(batch_size=20000, learning_rate=25),
     "AliNet": dict(batch_size=20000, truncated_epsilon=0.995, min_rel_win=15),
+    "RDGCN": dict(batch_size=20000, learning_rate=0.001, start_valid=50),
 }
 
 

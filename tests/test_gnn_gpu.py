@@ -110,3 +110,36 @@ def test_alinet_end_to_end(ops, tmp_path, capsys):
     assert pos.shape == (100, 2) and neg.shape[1] == 2 and len(neg) <= 2 * 100 * m.args.neg_triple_num
     ent = np.load(m.out_folder + "ent_embeds.npy")
     assert ent.shape == (kgs.entities_num, 64 + 48 + 32)
+
+
+def test_rdgcn_end_to_end(ops, tmp_path, capsys):
+    from openea_amd.approaches import RDGCN
+    from openea_amd.modules.load.synth import make_kgs
+    from openea_amd.run.default_args import get_args
+    kgs = make_kgs("small", mode="mapping", seed=0)
+    m = RDGCN()
+    m.set_args(get_args("RDGCN", output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/",
+                        dim=32, neg_triple_num=8, max_epoch=30, start_valid=10, eval_freq=10, learning_rate=0.005))
+    m.set_kgs(kgs)
+    m.init()
+    before = m.valid_("hits1")
+    m.run()
+    after = m.valid_("hits1")
+    m.test()
+    m.save()
+    out = capsys.readouterr().out
+    assert "Training ends. Total time" in out and "accurate results with csls" in out, out[-1500:]
+    assert after >= before
+    assert np.load(m.out_folder + "ent_embeds.npy").shape == (kgs.entities_num, 32)
+
+
+def test_rdgcn_hard_negative_mining(ops):
+    """get_neg (rdgcn.py:75-87): k L1-nearest entities of each seed entity, as a set, vs scipy."""
+    from scipy.spatial.distance import cdist
+    from openea_amd.approaches.rdgcn import get_neg
+    rng = np.random.RandomState(4)
+    emb = rng.standard_normal((700, 32)).astype(np.float32)
+    seeds = rng.choice(700, 50, replace=False).astype(np.int32)
+    out = get_neg(ops.to_ids(seeds), ops.to_table(emb), 32, 7).cpu().numpy().reshape(50, 7)
+    ref = cdist(emb[seeds], emb, metric="cityblock").argsort(1)[:, :7]
+    assert all(set(out[i]) == set(ref[i]) for i in range(50))
