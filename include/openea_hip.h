@@ -175,20 +175,32 @@ int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split
                               uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                               int32_t *err_flag, void *stream);
 
+/* Negatives of EVERY batch of an epoch in one launch: pos_all holds the batches back to back, batch s is
+ * rows [offsets[s], offsets[s+1]) with its first splits[s] rows from KG1 (offsets_dev: int64 [steps+1],
+ * splits_dev: int64 [steps], both on the DEVICE).  Draws are identical to `steps` calls of
+ * oea_sample_negatives_pair with step = step_base + s (the sampler does not depend on the tables, so an
+ * epoch's negatives can be drawn ahead of its optimiser steps). */
+int oea_sample_negatives_epoch(const int32_t *pos_all, int64_t n_rows, const int64_t *offsets_dev,
+                               const int64_t *splits_dev, int32_t steps, int32_t k, const oea_sampler_side *side0,
+                               const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t max_try,
+                               int32_t *out_all, int32_t *err_flag, void *stream);
+
 /* A whole epoch of BasicModel.launch_triple_training_1epo (basic_model.py:222-232) enqueued by
  * ONE call: for step in [0, steps): sample the negatives of batch `step`
  * (oea_sample_negatives_pair with Philox step = step_base + step) and run the fused optimiser
  * step.  pos_all holds the epoch's positive batches back to back; batch `step` is rows
  * [offsets_host[step], offsets_host[step+1]) of it and its first splits_host[step] rows belong
- * to KG1.  k == 0: positive-only losses (MTransE), no sampling.  neg_buf must hold
- * max_batch*k triples.  Nothing is synchronised: the host returns after enqueueing ~3 kernels
+ * to KG1.  k == 0: positive-only losses (MTransE), no sampling.  When offsets_dev / splits_dev (device
+ * copies of the two host arrays) are given, neg_buf must hold (total rows)*k triples and the whole
+ * epoch is sampled by ONE launch up front (oea_sample_negatives_epoch); otherwise neg_buf holds
+ * max_batch*k triples and every step samples its own batch.  Nothing is synchronised: the host returns after enqueueing ~3 kernels
  * per step, which removes the per-step host round trip of the reference's feed_dict loop. */
 int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                      int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
                      const int64_t *splits_host, int32_t steps, int32_t k, const oea_sampler_side *side0,
                      const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
                      int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
-                     void *stream);
+                     const int64_t *offsets_dev, const int64_t *splits_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):

@@ -57,12 +57,27 @@ template <int G>
 __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int32_t *__restrict__ pos, int64_t n_pos, int64_t n_split, int k, oea_sampler_side side0,
     oea_sampler_side side1, uint32_t k0, uint32_t k1, uint32_t step, uint32_t pos_offset,
-    int max_try, int32_t *__restrict__ out, int32_t *__restrict__ err_flag) {
+    int max_try, int32_t *__restrict__ out, int32_t *__restrict__ err_flag,
+    const int64_t *__restrict__ seg_off, const int64_t *__restrict__ seg_split, int n_seg) {
     const int lane = threadIdx.x % G;
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (p >= n_pos) return;                       // whole groups exit together
+    // Epoch mode (seg_off != NULL): `pos` holds every batch of the epoch back to back; the batch of
+    // row p is found by bisection and the Philox counter is (row within batch, step + batch), i.e.
+    // exactly the stream of a per-batch call -- one launch samples the whole epoch.
+    int64_t pl = p;                               // row index inside its batch
+    if (seg_off) {
+        int lo = 0, hi = n_seg;                   // invariant: seg_off[lo] <= p < seg_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        pl = p - seg_off[lo];
+        n_split = seg_split[lo];
+        step += (uint32_t)lo;
+    }
     // positives [0, n_split) belong to KG1, the rest to KG2 (pos_batch1 + pos_batch2, batch.py:45)
-    const oea_sampler_side &sd = p < n_split ? side0 : side1;
+    const oea_sampler_side &sd = pl < n_split ? side0 : side1;
     const uint64_t *__restrict__ table = sd.table;
     const uint64_t capacity = sd.capacity;
     const int32_t *__restrict__ entity_list = sd.entity_list;
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int32_t *hc = h_has ? nbr + (int64_t)ent_pos[h] * nbr_k : entity_list;
     const int32_t *tc = t_has ? nbr + (int64_t)ent_pos[t] * nbr_k : entity_list;
     const int hn = h_has ? nbr_k : n_ent_list, tn = t_has ? nbr_k : n_ent_list;
-    const uint32_t c0 = (uint32_t)p + pos_offset;
+    const uint32_t c0 = (uint32_t)pl + pos_offset;
     // mask of this group's lanes inside the 64-lane ballot
     const int gbase = (threadIdx.x & 63) / G * G;
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
@@ -166,10 +181,11 @@ static int check_side(const oea_sampler_side *s, int k) {
     return OEA_OK;
 }
 
-int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
-                              const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
-                              uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
-                              int32_t *err_flag, void *stream) {
+static int sample_impl(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
+                       const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                       uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
+                       int32_t *err_flag, const int64_t *seg_off_dev, const int64_t *seg_split_dev, int n_seg,
+                       void *stream) {
     OEA_REQUIRE(pos && out && err_flag, "null pointer");
     OEA_REQUIRE(k >= 1 && k <= kMaxK, "1 <= k <= 64");
     OEA_REQUIRE(max_try >= 1, "max_try >= 1");
@@ -183,13 +199,30 @@ int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split
     if (k <= 16)
         sample_negatives_kernel<16><<<(unsigned)oea::ceil_div(n_pos, 256 / 16), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
-            out, err_flag);
+            out, err_flag, seg_off_dev, seg_split_dev, n_seg);
     else
         sample_negatives_kernel<64><<<(unsigned)oea::ceil_div(n_pos, 256 / 64), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
-            out, err_flag);
+            out, err_flag, seg_off_dev, seg_split_dev, n_seg);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
+}
+
+int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
+                              const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                              uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
+                              int32_t *err_flag, void *stream) {
+    return sample_impl(pos, n_pos, n_split, k, side0, side1, seed, step, pos_offset, max_try, out, err_flag, nullptr,
+                       nullptr, 0, stream);
+}
+
+int oea_sample_negatives_epoch(const int32_t *pos_all, int64_t n_rows, const int64_t *offsets_dev,
+                               const int64_t *splits_dev, int32_t steps, int32_t k, const oea_sampler_side *side0,
+                               const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t max_try,
+                               int32_t *out_all, int32_t *err_flag, void *stream) {
+    OEA_REQUIRE(offsets_dev && splits_dev && steps >= 1, "offsets / splits / steps");
+    return sample_impl(pos_all, n_rows, 0, k, side0, side1, seed, step_base, 0u, max_try, out_all, err_flag, offsets_dev,
+                       splits_dev, steps, stream);
 }
 
 }  // extern "C"

@@ -505,21 +505,29 @@ int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, floa
                      const int64_t *splits_host, int32_t steps, int32_t k, const oea_sampler_side *side0,
                      const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
                      int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
-                     void *stream) {
+                     const int64_t *offsets_dev, const int64_t *splits_dev, void *stream) {
     OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
     OEA_REQUIRE(k == 0 || (neg_buf && err_flag && side0 && side1), "sampling needs neg_buf, err_flag and both sides");
+    OEA_REQUIRE((offsets_dev == nullptr) == (splits_dev == nullptr), "offsets_dev and splits_dev go together");
+    const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;
+    if (ahead) {   // the sampler does not read the tables: draw the whole epoch's negatives in one launch
+        const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0,
+                                                  side1, seed, step_base, 10, neg_buf, err_flag, stream);
+        if (rc != OEA_OK) return rc;
+    }
     for (int32_t s = 0; s < steps; ++s) {
         const int64_t lo = offsets_host[s], n = offsets_host[s + 1] - lo;
         if (n <= 0) continue;
         const int32_t *pos = pos_all + 3 * lo;
-        if (k > 0) {
+        int32_t *negs = ahead ? neg_buf + 3 * lo * (int64_t)k : neg_buf;
+        if (k > 0 && !ahead) {
             const int rc = oea_sample_negatives_pair(pos, n, splits_host[s], k, side0, side1, seed, step_base + (uint32_t)s,
-                                                     0u, 10, neg_buf, err_flag, stream);
+                                                     0u, 10, negs, err_flag, stream);
             if (rc != OEA_OK) return rc;
         }
         const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
-                                             k > 0 ? neg_buf : nullptr, n * (int64_t)k, cfg, workspace, loss_accum,
+                                             k > 0 ? negs : nullptr, n * (int64_t)k, cfg, workspace, loss_accum,
                                              OEA_PHASE_BOTH, stream);
         if (rc != OEA_OK) return rc;
     }

@@ -153,8 +153,9 @@ class RelationTripleEpochs:
             ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
                              b.dall, b.offsets, b.splits, self.k, self._sides[0] if self.k else None,
                              self._sides[1] if self.k else None, self.seed, self.global_step,
-                             self.neg_buf if self.k else None, self.err if self.k else None, trainer.cfg,
-                             trainer.ws, trainer.loss)
+                             self._epoch_neg_buf() if self.k else None, self.err if self.k else None, trainer.cfg,
+                             trainer.ws, trainer.loss, self._off_dev if self.k else None,
+                             self._spl_dev if self.k else None)
             self.global_step += len(b.splits)
             n = int(b.offsets[-1])
         else:
@@ -166,6 +167,15 @@ class RelationTripleEpochs:
                 n += pos.shape[0]
         self.end_epoch()
         return n
+
+    def _epoch_neg_buf(self):
+        """negatives of a whole epoch (sampled ahead by one launch) + device copies of the batch layout."""
+        b = self.batches
+        if getattr(self, "_neg_all", None) is None:
+            self._neg_all = torch.empty((int(b.offsets[-1]) * self.k, 3), dtype=torch.int32, device=self.dev)
+            self._off_dev = torch.from_numpy(b.offsets).to(self.dev)
+            self._spl_dev = torch.from_numpy(b.splits).to(self.dev)
+        return self._neg_all
 
     def end_epoch(self):
         self.batches.shuffle(self.gen)      # basic_model.py:234-235

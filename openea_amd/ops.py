@@ -185,15 +185,17 @@ def sample_negatives_pair(pos, n_split, k, side0, side1, seed, step, pos_offset,
 
 
 def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
-                 neg_buf, err_flag, cfg, workspace, loss_accum):
-    """Enqueue every step of an epoch with one call (offsets / splits: host int64 numpy arrays)."""
+                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None):
+    """Enqueue every step of an epoch with one call (offsets / splits: host int64 numpy arrays; their
+    device copies enable sampling the whole epoch ahead in one launch -- neg_buf then covers the epoch)."""
     steps = len(splits)
     check(lib().oea_triple_epoch(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
                                  ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
                                  splits.ctypes.data_as(C.c_void_p), steps, int(k),
                                  C.byref(side0) if side0 is not None else None,
                                  C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
-                                 _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum), _stream()))
+                                 _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
+                                 _p(offsets_dev), _p(splits_dev), _stream()))
 
 
 # -------------------------------------------------------------------------------------------
