@@ -276,18 +276,33 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
  * together -- whole rows, or TF1's consecutive runs) and adds its aggregate to output
  * row seg_row[s].  z: per-edge pre-activation logits; v: [n_cols, ld] values.
  *   alpha_e = softmax_seg(leaky_relu(z_e)) ;  out[seg_row[s]] += sum_e alpha_e * v[colidx[e]]
- * out must be zero on entry unless unique_rows != 0 (every row has exactly one segment: rows
- * are then written, not accumulated; rows without a segment are left untouched).
- * Backward: dz[e] and dv [n_cols, ld] from dout; t_ptr/t_row/t_edge = the transposed edge list
- * (per column j: output row and edge id of each incoming edge).
+ * Backward: dz[e] and dv [n_cols, ld] from dout.
  * ------------------------------------------------------------------------------------- */
-int oea_sparse_attn_fwd(const int32_t *seg_ptr, const int32_t *seg_row, int64_t n_seg, const int32_t *colidx,
-                        const float *z, const float *v, int32_t dim, int32_t ld, float lrelu_slope,
-                        int32_t unique_rows, float *out, float *alpha, void *stream);
-int oea_sparse_attn_bwd(const int32_t *seg_ptr, const int32_t *seg_row, int64_t n_seg, const int32_t *colidx,
-                        const float *z, const float *v, const float *alpha, const float *dout, int32_t dim,
-                        int32_t ld, float lrelu_slope, const int32_t *t_ptr, const int32_t *t_row,
-                        const int32_t *t_edge, int64_t n_cols, float *dz, float *dv, void *stream);
+typedef struct oea_attn_graph {
+    /* segments are cut into sub-segments of bounded length on the host (power-law degrees: a hub
+     * row must not become one wave's serial loop); sub-segments of a segment are consecutive */
+    const int32_t *sub_ptr;      /* [n_sub+1] edge range of each sub-segment */
+    const int32_t *sub_seg;      /* [n_sub]   segment a sub-segment belongs to */
+    const int32_t *seg_sub_ptr;  /* [n_seg+1] sub-segment range of each segment */
+    const int32_t *seg_row;      /* [n_seg]   output row of each segment */
+    const int32_t *colidx;       /* [nnz]     value row (column) of each edge */
+    int64_t n_sub, n_seg;
+    /* transposed edge list in column chunks, for dV */
+    const int32_t *t_sub_ptr;    /* [n_tsub+1] incoming-edge range of each column chunk */
+    const int32_t *t_sub_col;    /* [n_tsub]   column of each chunk */
+    const int32_t *t_row;        /* [nnz] output row of the incoming edge */
+    const int32_t *t_edge;       /* [nnz] its edge id (index into z / alpha) */
+    int64_t n_tsub;
+    int32_t unique_rows;         /* every output row has exactly one segment */
+    int32_t t_any_split;         /* some column owns more than one chunk (dV then accumulates atomically) */
+} oea_attn_graph;
+size_t oea_sparse_attn_workspace_floats(int64_t n_sub, int64_t n_seg);
+/* out [n_rows, ld] and (backward) dv [n_cols, ld] must be ZERO on entry. */
+int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v, int32_t dim, int32_t ld,
+                        float lrelu_slope, float *out, float *alpha, float *workspace, void *stream);
+int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v, const float *alpha,
+                        const float *dout, int32_t dim, int32_t ld, float lrelu_slope, float *dz, float *dv,
+                        float *workspace, void *stream);
 
 /* Dense Adam step with tf.train.AdamOptimizer semantics (alinet.py:871, rdgcn.py:332); t = 1-based
  * step count. */

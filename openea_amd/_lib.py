@@ -28,6 +28,14 @@ class SamplerSide(C.Structure):
                 ("ent_pos", C.c_void_p), ("nbr", C.c_void_p), ("n_ent_list", C.c_int32), ("nbr_k", C.c_int32)]
 
 
+class AttnGraph(C.Structure):
+    """mirror of `oea_attn_graph` (include/openea_hip.h)."""
+    _fields_ = [("sub_ptr", C.c_void_p), ("sub_seg", C.c_void_p), ("seg_sub_ptr", C.c_void_p), ("seg_row", C.c_void_p),
+                ("colidx", C.c_void_p), ("n_sub", C.c_int64), ("n_seg", C.c_int64), ("t_sub_ptr", C.c_void_p),
+                ("t_sub_col", C.c_void_p), ("t_row", C.c_void_p), ("t_edge", C.c_void_p), ("n_tsub", C.c_int64),
+                ("unique_rows", C.c_int32), ("t_any_split", C.c_int32)]
+
+
 LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
 OPT_KIND = {"SGD": 0, "Adagrad": 1}
 METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2}
@@ -81,9 +89,9 @@ PROTOTYPES = {
     "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
-    "oea_sparse_attn_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
-    "oea_sparse_attn_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i64,
-                                      _vp, _vp, _vp]),
+    "oea_sparse_attn_workspace_floats": (_sz, [_i64, _i64]),
+    "oea_sparse_attn_fwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "oea_sparse_attn_bwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "oea_adam_dense": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _vp]),
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),

@@ -17,6 +17,77 @@ namespace {
 
 using oea::group_sum;
 
+// accumulate edges e0, e0+stride, ... < e1 of one row into acc (4 independent 16-B gathers in flight)
+template <int G, int IT>
+__device__ __forceinline__ void row_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                               const float *__restrict__ x, int ldx, int lane, int e0, int e1, int stride,
+                                               float4 (&acc)[IT]) {
+    int e = e0;
+    for (; e + 3 * stride < e1; e += 4 * stride) {
+        int c[4];
+        float v[4];
+        float4 xv[4][IT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { c[u] = colidx[e + u * stride]; v[u] = vals[e + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int col = (it * G + lane) * 4;
+                xv[u][it] = col < ldx ? oea::ld4(x + (int64_t)c[u] * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)           // fixed order u = 0..3 -> the serial CSR order when stride == 1
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                acc[it].x = fmaf(v[u], xv[u][it].x, acc[it].x); acc[it].y = fmaf(v[u], xv[u][it].y, acc[it].y);
+                acc[it].z = fmaf(v[u], xv[u][it].z, acc[it].z); acc[it].w = fmaf(v[u], xv[u][it].w, acc[it].w);
+            }
+    }
+    for (; e < e1; e += stride) {
+        const int c0 = colidx[e];
+        const float v0 = vals[e];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int col = (it * G + lane) * 4;
+            const float4 x0 = col < ldx ? oea::ld4(x + (int64_t)c0 * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[it].x = fmaf(v0, x0.x, acc[it].x); acc[it].y = fmaf(v0, x0.y, acc[it].y);
+            acc[it].z = fmaf(v0, x0.z, acc[it].z); acc[it].w = fmaf(v0, x0.w, acc[it].w);
+        }
+    }
+}
+
+template <int G, int IT>
+__device__ __forceinline__ void row_store(float4 (&acc)[IT], int64_t row, int lane, int dim, int act,
+                                          const float *__restrict__ mask_from, float *__restrict__ y, int ldy) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * G + lane) * 4;
+        if (c < ldy) {
+            float4 o = acc[it];
+            if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (mask_from) {
+                const float4 m = oea::ld4(mask_from + row * ldy + c);
+                o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f;
+                o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+            }
+            if (c + 0 >= dim) o.x = 0.f;
+            if (c + 1 >= dim) o.y = 0.f;
+            if (c + 2 >= dim) o.z = 0.f;
+            if (c + 3 >= dim) o.w = 0.f;
+            oea::st4(y + row * ldy + c, o);
+        }
+    }
+}
+
+// Rows are short and skewed (average degree 6-12, hubs with thousands of neighbours at the low ids,
+// read.py:64-79).  A workgroup takes NG = 256/G consecutive rows per iteration: every group sums its
+// own row if it is short (<= kLongRow nonzeros, serial CSR order: deterministic, equals the oracle);
+// long rows of the batch are then summed by ALL groups of the workgroup together (strided edges,
+// partials combined through LDS in group order: still deterministic), so a hub row costs nnz/NG
+// dependent steps instead of nnz (a 2,000-neighbour hub made the first version 1 ms per launch).
+constexpr int kLongRow = 96;
+
 template <int G, int IT>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ colidx,
@@ -24,61 +95,49 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
                                                        const float *__restrict__ x, int dim, int ldx, int act,
                                                        const float *__restrict__ mask_from, float *__restrict__ y,
                                                        int ldy) {
-    const int lane = threadIdx.x % G;
-    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t row = grp; row < n_rows; row += ngrp) {
-        float4 acc[IT];
+    constexpr int NG = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) float s_part[];      // [NG][ldy] partial rows
+    const int lane = threadIdx.x % G, gid = threadIdx.x / G;
+    for (int64_t row0 = (int64_t)blockIdx.x * NG; row0 < n_rows; row0 += (int64_t)gridDim.x * NG) {
+        const int64_t row = row0 + gid;
+        int e0 = 0, e1 = 0;
+        if (row < n_rows) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
+        if (row < n_rows && e1 - e0 <= kLongRow) {
+            float4 acc[IT];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int e0 = rowptr[row], e1 = rowptr[row + 1];
-        int e = e0;
-        // two nonzeros per iteration: two independent 16-B gathers in flight per lane
-        for (; e + 1 < e1; e += 2) {
-            const int c0 = colidx[e], c1 = colidx[e + 1];
-            const float v0 = vals[e], v1 = vals[e + 1];
-            float4 x0[IT], x1[IT];
+            for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            row_accumulate<G, IT>(colidx, vals, x, ldx, lane, e0, e1, 1, acc);
+            row_store<G, IT>(acc, row, lane, dim, act, mask_from, y, ldy);
+        }
+        // long rows of this batch: workgroup-cooperative (block-uniform control flow)
+        for (int r = 0; r < NG; ++r) {
+            const int64_t lrow = row0 + r;
+            if (lrow >= n_rows) break;
+            const int l0 = rowptr[lrow], l1 = rowptr[lrow + 1];
+            if (l1 - l0 <= kLongRow) continue;
+            float4 acc[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            row_accumulate<G, IT>(colidx, vals, x, ldx, lane, l0 + gid, l1, NG, acc);
+            __syncthreads();
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = (it * G + lane) * 4;
-                x0[it] = c < ldx ? oea::ld4(x + (int64_t)c0 * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                x1[it] = c < ldx ? oea::ld4(x + (int64_t)c1 * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < ldy) oea::st4(s_part + gid * ldy + c, acc[it]);
             }
+            __syncthreads();
+            if (gid == 0) {
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                acc[it].x = fmaf(v0, x0[it].x, acc[it].x); acc[it].y = fmaf(v0, x0[it].y, acc[it].y);
-                acc[it].z = fmaf(v0, x0[it].z, acc[it].z); acc[it].w = fmaf(v0, x0[it].w, acc[it].w);
-                acc[it].x = fmaf(v1, x1[it].x, acc[it].x); acc[it].y = fmaf(v1, x1[it].y, acc[it].y);
-                acc[it].z = fmaf(v1, x1[it].z, acc[it].z); acc[it].w = fmaf(v1, x1[it].w, acc[it].w);
-            }
-        }
-        if (e < e1) {
-            const int c0 = colidx[e];
-            const float v0 = vals[e];
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int c = (it * G + lane) * 4;
-                const float4 x0 = c < ldx ? oea::ld4(x + (int64_t)c0 * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc[it].x = fmaf(v0, x0.x, acc[it].x); acc[it].y = fmaf(v0, x0.y, acc[it].y);
-                acc[it].z = fmaf(v0, x0.z, acc[it].z); acc[it].w = fmaf(v0, x0.w, acc[it].w);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = (it * G + lane) * 4;
-            if (c < ldy) {
-                float4 o = acc[it];
-                if (act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                if (mask_from) {
-                    const float4 m = oea::ld4(mask_from + row * ldy + c);
-                    o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f;
-                    o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+                for (int it = 0; it < IT; ++it) {
+                    const int c = (it * G + lane) * 4;
+                    if (c < ldy) {
+                        for (int g2 = 1; g2 < NG; ++g2) {
+                            const float4 p = oea::ld4(s_part + g2 * ldy + c);
+                            acc[it].x += p.x; acc[it].y += p.y; acc[it].z += p.z; acc[it].w += p.w;
+                        }
+                    }
                 }
-                if (c + 0 >= dim) o.x = 0.f;
-                if (c + 1 >= dim) o.y = 0.f;
-                if (c + 2 >= dim) o.z = 0.f;
-                if (c + 3 >= dim) o.w = 0.f;
-                oea::st4(y + row * ldy + c, o);
+                row_store<G, IT>(acc, lrow, lane, dim, act, mask_from, y, ldy);
             }
         }
     }
@@ -238,7 +297,8 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
     if (n_rows == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
 #define CALL(G, IT)                                                                                          \
-    spmm_csr_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20), 256, 0, st>>>( \
+    spmm_csr_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20), 256,           \
+                             sizeof(float) * (256 / G) * (size_t)ldy, st>>>(                                  \
         rowptr, colidx, vals, n_rows, x, dim, ldx, act, mask_from, y, ldy)
     OEA_DISPATCH_LD(ldx, CALL);
 #undef CALL

@@ -10,6 +10,21 @@ import torch
 from .. import ops
 
 
+def split_ranges(ptr, max_len, drop_empty=False):
+    """cut every range [ptr[i], ptr[i+1]) into consecutive pieces of at most max_len edges (empty
+    ranges keep one empty piece unless drop_empty).  The pieces tile [ptr[0], ptr[-1]) in order.
+    -> (piece_ptr [n_pieces+1], piece_owner [n_pieces], owner_piece_ptr [n+1])."""
+    ptr = np.asarray(ptr, np.int64)
+    lens = np.diff(ptr)
+    n_pieces = np.maximum((lens + max_len - 1) // max_len, 0 if drop_empty else 1)
+    owner = np.repeat(np.arange(len(lens)), n_pieces)
+    owner_ptr = np.concatenate([[0], np.cumsum(n_pieces)]).astype(np.int64)
+    within = np.arange(len(owner)) - owner_ptr[owner]
+    start = ptr[owner] + within * max_len
+    piece_ptr = np.concatenate([start, ptr[-1:]]).astype(np.int64)
+    return piece_ptr, owner.astype(np.int64), owner_ptr
+
+
 class EdgeGraph:
     """A sparse [n_rows, n_cols] operator given as an ordered edge list (rows, cols, vals), kept in
     the order the reference would feed it to TF, plus the derived device structures:
@@ -20,6 +35,8 @@ class EdgeGraph:
       edges with equal row (what TF1's CPU kernel does on non-canonical order);
     * the transposed edge list (per column: output row + edge id) for the attention backward.
     """
+
+    SUB = 256          # edges per sub-segment / column chunk
 
     def __init__(self, rows, cols, vals, shape, dev, grouping='row'):
         rows = np.asarray(rows, np.int64)
@@ -45,18 +62,24 @@ class EdgeGraph:
             raise ValueError(grouping)
         change = np.flatnonzero(np.diff(rows_o)) + 1 if self.nnz else np.zeros(0, np.int64)
         seg_start = np.concatenate([[0], change]).astype(np.int64) if self.nnz else np.zeros(0, np.int64)
-        self.seg_ptr = ops.to_ids(np.concatenate([seg_start, [self.nnz]]), dev)
-        self.seg_row = ops.to_ids(rows_o[seg_start] if self.nnz else np.zeros(0), dev)
-        self.unique_rows = len(np.unique(rows_o[seg_start])) == len(seg_start) if self.nnz else True
+        seg_ptr = np.concatenate([seg_start, [self.nnz]]).astype(np.int64)
+        seg_row = rows_o[seg_start] if self.nnz else np.zeros(0, np.int64)
+        self.seg_ptr_host, self.seg_row_host = seg_ptr, seg_row
+        self.unique_rows = len(np.unique(seg_row)) == len(seg_row) if self.nnz else True
         self.e_rows = torch.from_numpy(rows_o).to(dev)             # int64: torch index ops on edge vectors
         self.e_cols = torch.from_numpy(cols_o).to(dev)
         self.e_colidx = ops.to_ids(cols_o, dev)
         self.e_vals = ops.to_vec(vals_o, dev)
+        # sub-segments of at most SUB edges (balanced work on power-law degrees)
+        sub_ptr, sub_seg, seg_sub_ptr = split_ranges(seg_ptr, self.SUB)
         t_order = np.lexsort((rows_o, cols_o))                     # edges grouped by column
         counts = np.bincount(cols_o, minlength=shape[1]) if self.nnz else np.zeros(shape[1], np.int64)
-        self.t_ptr = ops.to_ids(np.concatenate([[0], np.cumsum(counts)]), dev)
-        self.t_row = ops.to_ids(rows_o[t_order], dev)
-        self.t_edge = ops.to_ids(t_order, dev)
+        t_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        t_sub_ptr, t_sub_col, _ = split_ranges(t_ptr, self.SUB, drop_empty=True)
+        self.attn = ops.attn_graph(ops.to_ids(sub_ptr, dev), ops.to_ids(sub_seg, dev), ops.to_ids(seg_sub_ptr, dev),
+                                   ops.to_ids(seg_row, dev), self.e_colidx, ops.to_ids(t_sub_ptr, dev),
+                                   ops.to_ids(t_sub_col, dev), ops.to_ids(rows_o[t_order], dev), ops.to_ids(t_order, dev),
+                                   self.unique_rows, len(t_sub_col) > int((counts > 0).sum()))
 
 
 class SpmmFn(torch.autograd.Function):
@@ -82,8 +105,7 @@ class SparseAttnFn(torch.autograd.Function):
     def forward(ctx, z, v, graph, slope):
         z = z.contiguous()
         v = v.contiguous()
-        out, alpha = ops.sparse_attn_fwd(graph.seg_ptr, graph.seg_row, graph.e_colidx, z, v, v.shape[1], slope,
-                                         graph.unique_rows, graph.shape[0])
+        out, alpha = ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0])
         ctx.graph, ctx.slope = graph, slope
         ctx.save_for_backward(z, v, alpha)
         return out
@@ -92,8 +114,7 @@ class SparseAttnFn(torch.autograd.Function):
     def backward(ctx, dout):
         z, v, alpha = ctx.saved_tensors
         g = ctx.graph
-        dz, dv = ops.sparse_attn_bwd(g.seg_ptr, g.seg_row, g.e_colidx, z, v, alpha, dout.contiguous(), v.shape[1],
-                                     ctx.slope, g.t_ptr, g.t_row, g.t_edge)
+        dz, dv = ops.sparse_attn_bwd(g.attn, z, v, alpha, dout.contiguous(), v.shape[1], ctx.slope)
         return dz, dv, None, None
 
 

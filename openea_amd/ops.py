@@ -297,22 +297,33 @@ def sgd_rows_(w, grad_t, dim, normalize, lr):
 # -------------------------------------------------------------------------------------------
 
 
-def sparse_attn_fwd(seg_ptr, seg_row, colidx, z, v, dim, slope, unique_rows, n_rows):
+def attn_graph(sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, t_sub_ptr, t_sub_col, t_row, t_edge, unique_rows,
+               t_any_split):
+    """pack the device arrays of an attention graph (keeps them alive)."""
+    g = _lib.AttnGraph(sub_ptr.data_ptr(), sub_seg.data_ptr(), seg_sub_ptr.data_ptr(), seg_row.data_ptr(),
+                       colidx.data_ptr(), sub_seg.numel(), seg_row.numel(), t_sub_ptr.data_ptr(), t_sub_col.data_ptr(),
+                       t_row.data_ptr(), t_edge.data_ptr(), t_sub_col.numel(), int(bool(unique_rows)), int(bool(t_any_split)))
+    g._keep = (sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, t_sub_ptr, t_sub_col, t_row, t_edge)
+    return g
+
+
+def sparse_attn_fwd(g, z, v, dim, slope, n_rows):
     """-> (out [n_rows, ld], alpha [nnz])."""
     out = torch.zeros((n_rows, v.shape[1]), dtype=torch.float32, device=v.device)
     alpha = torch.empty_like(z)
-    check(lib().oea_sparse_attn_fwd(_p(seg_ptr), _p(seg_row), seg_row.numel(), _p(colidx), _p(z), _p(v), dim, v.shape[1],
-                                    float(slope), int(bool(unique_rows)), _p(out), _p(alpha), _stream()))
+    ws = torch.empty(lib().oea_sparse_attn_workspace_floats(g.n_sub, g.n_seg), dtype=torch.float32, device=v.device)
+    check(lib().oea_sparse_attn_fwd(C.byref(g), _p(z), _p(v), dim, v.shape[1], float(slope), _p(out), _p(alpha), _p(ws),
+                                    _stream()))
     return out, alpha
 
 
-def sparse_attn_bwd(seg_ptr, seg_row, colidx, z, v, alpha, dout, dim, slope, t_ptr, t_row, t_edge):
+def sparse_attn_bwd(g, z, v, alpha, dout, dim, slope):
     """-> (dz [nnz], dv [n_cols, ld])."""
     dz = torch.empty_like(z)
-    dv = torch.empty_like(v)
-    check(lib().oea_sparse_attn_bwd(_p(seg_ptr), _p(seg_row), seg_row.numel(), _p(colidx), _p(z), _p(v), _p(alpha),
-                                    _p(dout), dim, v.shape[1], float(slope), _p(t_ptr), _p(t_row), _p(t_edge),
-                                    v.shape[0], _p(dz), _p(dv), _stream()))
+    dv = torch.zeros_like(v)
+    ws = torch.empty(lib().oea_sparse_attn_workspace_floats(g.n_sub, g.n_seg), dtype=torch.float32, device=v.device)
+    check(lib().oea_sparse_attn_bwd(C.byref(g), _p(z), _p(v), _p(alpha), _p(dout), dim, v.shape[1], float(slope), _p(dz),
+                                    _p(dv), _p(ws), _stream()))
     return dz, dv
 
 
