@@ -219,7 +219,8 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
 /* The selection half alone, on a similarity strip that already exists: out_idx[i, :] = the k columns
  * with the largest s[i, :] ((value desc, column asc), ascending column order).  RDGCN's hard-negative
  * mining (approaches/rdgcn.py:75-87: cdist cityblock + argsort()[0:k]) = oea_sim_matrix(manhattan)
- * + this call. */
+ * + this call.  s 16-byte aligned, ld % 4 == 0 (rows are read 16 bytes at a time; the pad columns
+ * nc..ld-1 are never selected whatever they hold). */
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
                   int32_t *out_idx, void *stream);
 
@@ -265,9 +266,20 @@ int oea_csls_apply(float *s, int64_t n1, int64_t n2, int64_t ld, const float *r,
  * The backward pass is the same call on the transposed CSR.  mask_from (may be NULL):
  * y = y * (mask_from > 0) -- the relu gradient gate fused into the backward aggregate.
  * ------------------------------------------------------------------------------------- */
+/* Optional work split for hub rows (degrees are power-law; ids are frequency-ordered, read.py:64-79):
+ * rows with more than `threshold` (>= 96) nonzeros are cut on the host into chunks that different
+ * workgroups sum and add atomically; `rows` lists those rows (zeroed before, activation / mask applied
+ * after).  NULL = no splitting (a hub row is then summed by one workgroup). */
+typedef struct oea_csr_split {
+    const int32_t *chunk_row;   /* [n_chunks] row of each chunk */
+    const int32_t *chunk_e0;    /* [n_chunks] first nonzero */
+    const int32_t *chunk_e1;    /* [n_chunks] one past the last nonzero */
+    const int32_t *rows;        /* [n_rows]   the split rows */
+    int32_t n_chunks, n_rows, threshold;
+} oea_csr_split;
 int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                  const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from,
-                 float *y, int32_t ldy, void *stream);
+                 float *y, int32_t ldy, const oea_csr_split *split, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse graph attention -- replaces tf.nn.leaky_relu(values) -> tf.sparse_softmax ->

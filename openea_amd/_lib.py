@@ -28,6 +28,12 @@ class SamplerSide(C.Structure):
                 ("ent_pos", C.c_void_p), ("nbr", C.c_void_p), ("n_ent_list", C.c_int32), ("nbr_k", C.c_int32)]
 
 
+class CsrSplit(C.Structure):
+    """mirror of `oea_csr_split` (include/openea_hip.h)."""
+    _fields_ = [("chunk_row", C.c_void_p), ("chunk_e0", C.c_void_p), ("chunk_e1", C.c_void_p), ("rows", C.c_void_p),
+                ("n_chunks", C.c_int32), ("n_rows", C.c_int32), ("threshold", C.c_int32)]
+
+
 class AttnGraph(C.Structure):
     """mirror of `oea_attn_graph` (include/openea_hip.h)."""
     _fields_ = [("sub_ptr", C.c_void_p), ("sub_seg", C.c_void_p), ("seg_sub_ptr", C.c_void_p), ("seg_row", C.c_void_p),
@@ -88,7 +94,7 @@ PROTOTYPES = {
     "oea_sim_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, C.POINTER(CsrSplit), _vp]),
     "oea_sparse_attn_workspace_floats": (_sz, [_i64, _i64]),
     "oea_sparse_attn_fwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "oea_sparse_attn_bwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),

@@ -126,12 +126,13 @@ class DeviceCSR:
         self.nnz = a.nnz
         self.rowptr, self.colidx, self.vals = ops.to_ids(a.indptr, dev), ops.to_ids(a.indices, dev), ops.to_vec(a.data, dev)
         self.t_rowptr, self.t_colidx, self.t_vals = ops.to_ids(at.indptr, dev), ops.to_ids(at.indices, dev), ops.to_vec(at.data, dev)
+        self.split, self.t_split = ops.csr_split(a.indptr, dev=dev), ops.csr_split(at.indptr, dev=dev)   # hub rows
 
     def mm(self, x, dim, act=0, mask_from=None):
-        return ops.spmm_csr(self.rowptr, self.colidx, self.vals, x, dim, act=act, mask_from=mask_from)
+        return ops.spmm_csr(self.rowptr, self.colidx, self.vals, x, dim, act=act, mask_from=mask_from, split=self.split)
 
     def tmm(self, x, dim, mask_from=None):
-        return ops.spmm_csr(self.t_rowptr, self.t_colidx, self.t_vals, x, dim, mask_from=mask_from)
+        return ops.spmm_csr(self.t_rowptr, self.t_colidx, self.t_vals, x, dim, mask_from=mask_from, split=self.t_split)
 
 
 class GCN_Align_Unit:

@@ -221,8 +221,8 @@ def get_neg(ill_ids, output_layer, dim, k):
     """rdgcn.py:75-87: the k L1-nearest entities of every seed entity among ALL entities (the seed
     itself included, as in the reference) -> device int32 [t*k]."""
     q = ops.gather_rows(output_layer, dim, ill_ids)
-    s = ops.sim_matrix(q, output_layer, dim, 'manhattan')        # 1 - cityblock distance, fp64 inside
-    return ops.topk_rows(s, k).reshape(-1)
+    s = ops.sim_matrix(q, output_layer, dim, 'manhattan', pad=True)        # 1 - cityblock distance, fp64 inside
+    return ops.topk_rows(s, k, nc=output_layer.shape[0]).reshape(-1)
 
 
 class RDGCN(BasicModel):

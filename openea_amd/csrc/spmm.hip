@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
                                                        const float *__restrict__ vals, int64_t n_rows,
                                                        const float *__restrict__ x, int dim, int ldx, int act,
                                                        const float *__restrict__ mask_from, float *__restrict__ y,
-                                                       int ldy) {
+                                                       int ldy, int huge) {
     constexpr int NG = 256 / G;
     extern __shared__ __attribute__((aligned(16))) float s_part[];      // [NG][ldy] partial rows
     const int lane = threadIdx.x % G, gid = threadIdx.x / G;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
             const int64_t lrow = row0 + r;
             if (lrow >= n_rows) break;
             const int l0 = rowptr[lrow], l1 = rowptr[lrow + 1];
-            if (l1 - l0 <= kLongRow) continue;
+            if (l1 - l0 <= kLongRow || l1 - l0 > huge) continue;     // huge rows: split across workgroups below
             float4 acc[IT];
 #pragma unroll
             for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,6 +141,72 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
             }
         }
     }
+}
+
+// ---- hub rows (nnz > split->threshold): chunks of the row go to different workgroups ----------------
+template <int G, int IT>
+__global__ __launch_bounds__(256) void spmm_zero_rows_kernel(const int32_t *__restrict__ rows, int n, float *__restrict__ y, int ldy) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (grp >= n) return;
+    float *o = y + (int64_t)rows[grp] * ldy;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * G + lane) * 4;
+        if (c < ldy) oea::st4(o + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+template <int G, int IT>
+__global__ __launch_bounds__(256) void spmm_chunk_kernel(const int32_t *__restrict__ chunk_row, const int32_t *__restrict__ chunk_e0,
+                                                         const int32_t *__restrict__ chunk_e1,
+                                                         const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                         const float *__restrict__ x, int ldx, float *__restrict__ y, int ldy) {
+    constexpr int NG = 256 / G;
+    extern __shared__ __attribute__((aligned(16))) float s_part[];
+    const int lane = threadIdx.x % G, gid = threadIdx.x / G;
+    const int ch = blockIdx.x;
+    float4 acc[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    row_accumulate<G, IT>(colidx, vals, x, ldx, lane, chunk_e0[ch] + gid, chunk_e1[ch], NG, acc);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * G + lane) * 4;
+        if (c < ldy) oea::st4(s_part + gid * ldy + c, acc[it]);
+    }
+    __syncthreads();
+    if (gid == 0) {
+        float *o = y + (int64_t)chunk_row[ch] * ldy;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * G + lane) * 4;
+            if (c < ldy) {
+                for (int g2 = 1; g2 < NG; ++g2) {
+                    const float4 p = oea::ld4(s_part + g2 * ldy + c);
+                    acc[it].x += p.x; acc[it].y += p.y; acc[it].z += p.z; acc[it].w += p.w;
+                }
+                oea::atomic_add_f32(o + c, acc[it].x); oea::atomic_add_f32(o + c + 1, acc[it].y);
+                oea::atomic_add_f32(o + c + 2, acc[it].z); oea::atomic_add_f32(o + c + 3, acc[it].w);
+            }
+        }
+    }
+}
+
+template <int G, int IT>
+__global__ __launch_bounds__(256) void spmm_rows_epilogue_kernel(const int32_t *__restrict__ rows, int n, int dim, int act,
+                                                                 const float *__restrict__ mask_from, float *__restrict__ y, int ldy) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (grp >= n) return;
+    const int64_t row = rows[grp];
+    float4 acc[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * G + lane) * 4;
+        acc[it] = c < ldy ? oea::ld4(y + row * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    row_store<G, IT>(acc, row, lane, dim, act, mask_from, y, ldy);
 }
 
 __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
@@ -290,16 +356,29 @@ extern "C" {
 
 int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                  const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from, float *y,
-                 int32_t ldy, void *stream) {
+                 int32_t ldy, const oea_csr_split *split, void *stream) {
     OEA_REQUIRE(rowptr && colidx && vals && x && y, "null pointer");
     OEA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && dim > 0 && dim <= ldx && dim <= ldy && ldx == ldy, "ldx == ldy, % 4 == 0");
     OEA_REQUIRE(act == 0 || act == 1, "act: 0 none, 1 relu");
+    OEA_REQUIRE(!split || split->n_chunks == 0 || (split->chunk_row && split->chunk_e0 && split->chunk_e1 && split->rows &&
+                                                   split->threshold >= kLongRow), "csr split: null pointer / threshold");
     if (n_rows == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
-#define CALL(G, IT)                                                                                          \
-    spmm_csr_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20), 256,           \
-                             sizeof(float) * (256 / G) * (size_t)ldy, st>>>(                                  \
-        rowptr, colidx, vals, n_rows, x, dim, ldx, act, mask_from, y, ldy)
+    const bool use_split = split && split->n_chunks > 0;
+    const int huge = use_split ? split->threshold : 0x7fffffff;
+#define CALL(G, IT)                                                                                                    \
+    do {                                                                                                               \
+        const size_t lds = sizeof(float) * (256 / G) * (size_t)ldy;                                                    \
+        spmm_csr_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20), 256, lds, st>>>( \
+            rowptr, colidx, vals, n_rows, x, dim, ldx, act, mask_from, y, ldy, huge);                                  \
+        if (use_split) {                                                                                               \
+            const unsigned gr = (unsigned)oea::ceil_div(split->n_rows, 256 / G);                                       \
+            spmm_zero_rows_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, y, ldy);                      \
+            spmm_chunk_kernel<G, IT><<<(unsigned)split->n_chunks, 256, lds, st>>>(split->chunk_row, split->chunk_e0,   \
+                                                                                  split->chunk_e1, colidx, vals, x, ldx, y, ldy); \
+            spmm_rows_epilogue_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, dim, act, mask_from, y, ldy); \
+        }                                                                                                              \
+    } while (0)
     OEA_DISPATCH_LD(ldx, CALL);
 #undef CALL
     OEA_CHECK_HIP(hipGetLastError());

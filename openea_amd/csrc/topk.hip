@@ -3,14 +3,19 @@
 // Replaces find_neighbours (modules/train/batch.py:157-165):
 //     sim_mat = np.matmul(sub_embed, embed.T); np.argpartition(-sim_mat[i], k)[:k]
 // k is large here (int((1-eps)*N): 1,499 of 15,000; 2,000 of 100,000), so instead of keeping k
-// candidates per row on chip the search is a per-row radix SELECT on the fp32 keys:
+// candidates per row on chip the search is a per-row SELECT on the fp32 keys:
 //   1. a strip of rows of S is produced by the MFMA tile kernel (sim_rank.hip) into an HBM
 //      workspace (the strip is L2 / Infinity-Cache resident when read back),
-//   2. one workgroup per row finds the k-th largest key with three histogram passes
-//      (11 + 11 + 10 bits, histograms in LDS),
-//   3. a fourth pass compacts the selected columns in ascending column order:
-//      key > T, plus the first `need` columns with key == T  -> (value desc, column asc)
-//      selection, bit-identical with oracle_topk_inner.
+//   2. one workgroup per row, three coalesced reads of the row (16 B per lane):
+//        a. histogram over 2048 LINEAR buckets between a sampled [lo, hi] of the row (monotone in
+//           the value, ends clamped) -> the bucket b* holding the k-th largest value,
+//        b. the few entries of bucket b* go to LDS and are ranked exactly by (value desc, column asc);
+//           every wave counts the entries above b* in its quarter of the row,
+//        c. ordered compaction by wave ballots: key > T, or key == T and column <= T's column.
+//      Rows whose threshold bucket holds more than kCandCap entries (constant / heavily tied rows)
+//      take the radix path instead: three 11+11+10-bit histogram passes + scan compaction.
+//   Both give the (value desc, column asc) selection in ascending column order, bit-identical with
+//   oracle_topk_inner.
 #include "common.h"
 
 namespace {
@@ -41,15 +46,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int *s_wave /*[4]*/, int *
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
-                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
-                                                                 int32_t *__restrict__ out /* [n_rows, k] */) {
-    __shared__ int hist[2048];
+// radix path (tie-heavy rows): hist = 2048 ints of LDS
+__device__ void radix_select_row(const float *__restrict__ src, int64_t nc, int k, const int32_t *__restrict__ id_map,
+                                 int32_t *__restrict__ o, int *hist) {
     __shared__ int s_wave[4];
     __shared__ uint32_t s_prefix;
     __shared__ int s_need;
-    const int64_t row = blockIdx.x;
-    const float *src = s + row * ld;
     const int tid = threadIdx.x;
 
     uint32_t prefix = 0;        // key bits decided so far
@@ -104,7 +106,6 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
     const uint32_t T = prefix;
     int taken_gt_eq = 0;   // running output position
     int taken_eq = 0;      // running count of == T entries seen
-    int32_t *o = out + row * (int64_t)k;
     for (int64_t base = 0; base < nc; base += SEL_THREADS) {
         const int64_t j = base + tid;
         uint32_t key = 0;
@@ -122,6 +123,164 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
     }
 }
 
+constexpr int kBins = 2048;
+constexpr int kCandCap = 1024;
+
+__device__ __forceinline__ int lin_bin(float v, float lo, float scale) {
+    // monotone non-decreasing in v; bins 0 and kBins-1 collect what falls outside the sampled range
+    const float b = fminf(fmaxf((v - lo) * scale + 1.0f, 0.0f), (float)(kBins - 1));
+    return (int)b;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                 int32_t *__restrict__ out /* [n_rows, k] */) {
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    __shared__ float s_red[8];
+    __shared__ int s_bstar, s_need, s_ncand, s_gt[4], s_cbefore[4], s_tcol;
+    __shared__ uint32_t s_tkey;
+    const int64_t row = blockIdx.x;
+    const float *src = s + row * ld;
+    int32_t *o = out + row * (int64_t)k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- sampled range ------------------------------------------------------------------------
+    float mn = INFINITY, mx = -INFINITY;
+    {
+        const int64_t ns = nc < 1024 ? nc : 1024;
+        const int64_t stride = nc / ns;
+        for (int64_t i = tid; i < ns; i += SEL_THREADS) {
+            const float v = src[i * stride];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+    }
+    for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+    if (tid < 4) { s_gt[tid] = 0; s_cbefore[tid] = 0; }
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    const float lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    const float hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
+
+    // every wave owns a contiguous, tile-aligned quarter of the row (tiles of 256 columns)
+    const int64_t tiles = (nc + 255) / 256;
+    const int64_t tiles_per_wave = (tiles + 3) / 4;
+    const int64_t seg0 = wave * tiles_per_wave * 256;
+    const int64_t seg1 = seg0 + tiles_per_wave * 256 < nc ? seg0 + tiles_per_wave * 256 : nc;
+
+    // ---- read 1: histogram --------------------------------------------------------------------
+    for (int64_t c0 = seg0 + lane * 4; c0 < seg1; c0 += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + c0);      // ld % 32 == 0: in bounds, 16 B aligned
+        atomicAdd(&hist[lin_bin(v.x, lo, scale)], 1);
+        if (c0 + 1 < nc) atomicAdd(&hist[lin_bin(v.y, lo, scale)], 1);
+        if (c0 + 2 < nc) atomicAdd(&hist[lin_bin(v.z, lo, scale)], 1);
+        if (c0 + 3 < nc) atomicAdd(&hist[lin_bin(v.w, lo, scale)], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {          // the bucket (from the top) where the cumulative count reaches k
+        constexpr int per = kBins / 64;
+        const int top = kBins - 1 - tid * per;
+        int sum = 0;
+        for (int b = 0; b < per; ++b) sum += hist[top - b];
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += t;
+        }
+        const int before = incl - sum;
+        if (before < k && incl >= k) {
+            int acc = before;
+            for (int b = 0; b < per; ++b) {
+                const int c = hist[top - b];
+                if (acc + c >= k) { s_bstar = top - b; s_need = k - acc; break; }
+                acc += c;
+            }
+        }
+    }
+    __syncthreads();
+    const int bstar = s_bstar, need = s_need;
+    if (hist[bstar] > kCandCap) {                       // block-uniform
+        __syncthreads();
+        radix_select_row(src, nc, k, id_map, o, hist);
+        return;
+    }
+
+    // ---- read 2: candidates of bucket b*, per-wave count above it ---------------------------------
+    int gt = 0;
+    for (int64_t c0 = seg0 + lane * 4; c0 < seg1; c0 += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + c0);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c0 + i < nc) {
+                const int b = lin_bin(vv[i], lo, scale);
+                gt += b > bstar;
+                if (b == bstar) {
+                    const int p = atomicAdd(&s_ncand, 1);
+                    c_key[p] = f2ord(vv[i]);
+                    c_col[p] = (int)(c0 + i);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off, 64);
+    if (lane == 0) s_gt[wave] = gt;
+    __syncthreads();
+    // exact rank of every candidate by (value desc, column asc)
+    const int ncand = s_ncand;
+    for (int i = tid; i < ncand; i += SEL_THREADS) {
+        const uint32_t ki = c_key[i];
+        const int ci = c_col[i];
+        int rank = 0;
+        for (int j = 0; j < ncand; ++j) {
+            const uint32_t kj = c_key[j];
+            rank += (kj > ki) || (kj == ki && c_col[j] < ci);
+        }
+        if (rank == need - 1) { s_tkey = ki; s_tcol = ci; }
+        if (rank < need) {
+            for (int w = 1; w < 4; ++w)
+                if (ci < w * tiles_per_wave * 256) atomicAdd(&s_cbefore[w], 1);
+        }
+    }
+    __syncthreads();
+    const uint32_t tkey = s_tkey;
+    const int tcol = s_tcol;
+    int running = s_cbefore[wave];
+    for (int w = 0; w < wave; ++w) running += s_gt[w];
+
+    // ---- read 3: ordered compaction ---------------------------------------------------------------
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int64_t c0 = seg0 + lane * 4; c0 - lane * 4 < seg1; c0 += 256) {       // wave-uniform trip count
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 < seg1) v = *reinterpret_cast<const float4 *>(src + c0);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        bool sel[4];
+        uint64_t bal[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t key = f2ord(vv[i]);
+            sel[i] = (c0 + i < seg1) && (key > tkey || (key == tkey && (int)(c0 + i) <= tcol));
+            bal[i] = __ballot(sel[i]);
+        }
+        int p = running + __popcll(bal[0] & lt) + __popcll(bal[1] & lt) + __popcll(bal[2] & lt) + __popcll(bal[3] & lt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (sel[i]) o[p++] = id_map ? id_map[c0 + i] : (int32_t)(c0 + i);
+        running += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -134,7 +293,7 @@ size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
                   int32_t *out_idx, void *stream) {
     OEA_REQUIRE(s && out_idx, "null pointer");
-    OEA_REQUIRE(k >= 1 && k <= nc && ld >= nc, "1 <= k <= nc <= ld");
+    OEA_REQUIRE(k >= 1 && k <= nc && ld >= nc && ld % 4 == 0, "1 <= k <= nc <= ld, ld % 4 == 0 (rows are read 16 B at a time)");
     if (n_rows == 0) return OEA_OK;
     row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, oea::as_stream(stream)>>>(s, n_rows, nc, ld, k, id_map, out_idx);
     OEA_CHECK_HIP(hipGetLastError());

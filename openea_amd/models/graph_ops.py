@@ -52,6 +52,7 @@ class EdgeGraph:
         at.sort_indices()
         self.rowptr, self.colidx, self.vals = ops.to_ids(a.indptr, dev), ops.to_ids(a.indices, dev), ops.to_vec(a.data, dev)
         self.t_rowptr, self.t_colidx, self.t_vals = ops.to_ids(at.indptr, dev), ops.to_ids(at.indices, dev), ops.to_vec(at.data, dev)
+        self.split, self.t_split = ops.csr_split(a.indptr, dev=dev), ops.csr_split(at.indptr, dev=dev)   # hub rows
         # ---- attention structures over the ordered edge list ------------------------------------
         if grouping == 'row':
             order = np.lexsort((cols, rows))                       # canonical row-major order
@@ -89,13 +90,13 @@ class SpmmFn(torch.autograd.Function):
     def forward(ctx, x, graph):
         ctx.graph = graph
         x = x.contiguous()
-        return ops.spmm_csr(graph.rowptr, graph.colidx, graph.vals, x, x.shape[1])
+        return ops.spmm_csr(graph.rowptr, graph.colidx, graph.vals, x, x.shape[1], split=graph.split)
 
     @staticmethod
     def backward(ctx, dy):
         g = ctx.graph
         dy = dy.contiguous()
-        return ops.spmm_csr(g.t_rowptr, g.t_colidx, g.t_vals, dy, dy.shape[1]), None
+        return ops.spmm_csr(g.t_rowptr, g.t_colidx, g.t_vals, dy, dy.shape[1], split=g.t_split), None
 
 
 class SparseAttnFn(torch.autograd.Function):

@@ -216,10 +216,12 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     return out
 
 
-def topk_rows(s, k, id_map=None):
-    """k largest columns of every row of a device similarity strip [n, nc] -> int32 [n, k]."""
+def topk_rows(s, k, id_map=None, nc=None):
+    """k largest of the first nc (default: all) columns of every row of a device similarity strip
+    [n, ld] -> int32 [n, k]."""
     out = torch.empty((s.shape[0], k), dtype=torch.int32, device=s.device)
-    check(lib().oea_topk_rows(_p(s), s.shape[0], s.shape[1], s.stride(0), k, _p(id_map), _p(out), _stream()))
+    check(lib().oea_topk_rows(_p(s), s.shape[0], s.shape[1] if nc is None else nc, s.stride(0), k, _p(id_map), _p(out),
+                              _stream()))
     return out
 
 
@@ -248,11 +250,14 @@ def rank_metrics(rank, top_k):
     return hits, int(host[nk]), float(host[nk + 1:nk + 2].view(np.float64)[0])
 
 
-def sim_matrix(e1, e2, dim, metric='inner'):
+def sim_matrix(e1, e2, dim, metric='inner', pad=False):
+    """-> device fp32 [n1, n2]; pad=True: [n1, ld] with ld = n2 rounded up to 32 (the row layout that
+    topk_rows reads; columns n2.. are left unwritten)."""
     n1, n2 = e1.shape[0], e2.shape[0]
-    out = torch.empty((n1, n2), dtype=torch.float32, device=e1.device)
+    ld = (n2 + 31) // 32 * 32 if pad else n2
+    out = torch.empty((n1, ld), dtype=torch.float32, device=e1.device)
     check(lib().oea_sim_matrix(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC[metric],
-                               _p(out), n2, _stream()))
+                               _p(out), ld, _stream()))
     return out
 
 
@@ -272,12 +277,33 @@ def csls_apply_(s, r, c):
 # -------------------------------------------------------------------------------------------
 
 
-def spmm_csr(rowptr, colidx, vals, x, dim, act=0, mask_from=None, out=None):
+def csr_split(indptr, threshold=768, chunk=512, dev=None):
+    """host CSR row pointer -> oea_csr_split for rows with more than `threshold` nonzeros (None if there
+    are none): each such row is cut into chunks of `chunk` nonzeros."""
+    indptr = np.asarray(indptr, np.int64)
+    lens = np.diff(indptr)
+    rows = np.flatnonzero(lens > threshold)
+    if len(rows) == 0:
+        return None
+    c_row, c_e0, c_e1 = [], [], []
+    for r in rows:
+        for e0 in range(int(indptr[r]), int(indptr[r + 1]), chunk):
+            c_row.append(r)
+            c_e0.append(e0)
+            c_e1.append(min(e0 + chunk, int(indptr[r + 1])))
+    t = [to_ids(np.asarray(a, np.int32), dev) for a in (c_row, c_e0, c_e1, rows)]
+    sp_ = _lib.CsrSplit(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), len(c_row), len(rows), int(threshold))
+    sp_._keep = t
+    return sp_
+
+
+def spmm_csr(rowptr, colidx, vals, x, dim, act=0, mask_from=None, out=None, split=None):
     n_rows = rowptr.numel() - 1
     if out is None:
         out = torch.empty((n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
     check(lib().oea_spmm_csr(_p(rowptr), _p(colidx), _p(vals), n_rows, _p(x), dim, x.shape[1], int(act),
-                             _p(mask_from), _p(out), out.shape[1], _stream()))
+                             _p(mask_from), _p(out), out.shape[1], C.byref(split) if split is not None else None,
+                             _stream()))
     return out
 
 

@@ -122,6 +122,37 @@ def test_topk_inner_bit_exact(ops, n, d, k):
     assert np.array_equal(idx2, ref)
 
 
+def _select_ref(s, k):
+    """(value desc, column asc) selection, ascending columns -- the rule of oracle_topk_inner."""
+    out = np.empty((s.shape[0], k), np.int32)
+    for i, row in enumerate(s):
+        order = np.lexsort((np.arange(len(row)), -row.astype(np.float64)))
+        out[i] = np.sort(order[:k])
+    return out
+
+
+@pytest.mark.parametrize("nc,k", [(5000, 500), (1027, 37), (257, 257), (3, 2)])
+def test_topk_rows_ties_and_ragged(ops, nc, k):
+    import torch
+    rng = np.random.RandomState(nc)
+    ld = (nc + 31) // 32 * 32
+    rows = []
+    rows.append(np.zeros(nc, np.float32))                                   # constant row: radix path, first k columns
+    rows.append(rng.randint(0, 4, nc).astype(np.float32))                   # 4 distinct values: radix path
+    rows.append(np.round(rng.standard_normal(nc) * 40).astype(np.float32))  # quantised: ties inside the buckets
+    x = rng.standard_normal(nc).astype(np.float32); x[rng.randint(0, nc, max(nc // 8, 1))] = 1e30
+    rows.append(x)                                                          # outliers: clamped end buckets
+    x = rng.standard_normal(nc).astype(np.float32); x[::2] = -0.0; x[1::4] = 0.0
+    rows.append(x)                                                          # signed zeros compare equal
+    rows.append(np.sort(rng.standard_normal(nc).astype(np.float32)))        # sampled range misses nothing / ascending
+    rows.append(-np.sort(rng.standard_normal(nc).astype(np.float32)))
+    s = np.stack(rows)
+    sp_ = np.full((len(rows), ld), np.nan, np.float32)                      # pad columns must never be selected
+    sp_[:, :nc] = s
+    got = ops.topk_rows(torch.from_numpy(sp_).to(ops.device()), k, nc=nc).cpu().numpy()
+    assert np.array_equal(got, _select_ref(s, k))
+
+
 def test_topk_matches_reference_fixture(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, "neighbours.npz"))
     emb, ents, k = g['emb'], g['entity_list'], int(g['k'])
@@ -295,3 +326,11 @@ def test_spmm_bit_exact(ops, d):
     yr = ops.spmm_csr(ops.to_ids(a.indptr), ops.to_ids(a.indices), ops.to_vec(a.data),
                       ops.to_table(x), d, act=1)
     np.testing.assert_allclose(yr.cpu().numpy()[:, :d], np.maximum(ref, 0), rtol=2e-5, atol=5e-4)
+    # hub rows cut into chunks over several workgroups (oea_csr_split), with relu + mask epilogue
+    split = ops.csr_split(a.indptr, threshold=200, chunk=128)
+    assert split is not None and split.n_chunks > split.n_rows
+    mask = rng.standard_normal((n, d)).astype(np.float32)
+    ym = ops.spmm_csr(ops.to_ids(a.indptr), ops.to_ids(a.indices), ops.to_vec(a.data), ops.to_table(x), d,
+                      act=1, mask_from=ops.to_table(mask), split=split)
+    np.testing.assert_allclose(ym.cpu().numpy()[:, :d], np.maximum(ref, 0) * (mask > 0), rtol=2e-5, atol=5e-4)
+    assert np.array_equal(ym.cpu().numpy()[short][:, :d], (np.maximum(ref, 0) * (mask > 0))[short])
