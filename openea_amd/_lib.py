@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libopenea_hip.so")
+# OPENEA_HIP_LIB: load another build of the same library (kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get("OPENEA_HIP_LIB") or os.path.join(_HERE, "csrc", "libopenea_hip.so")
 
 
 class OpenEAHipError(RuntimeError):

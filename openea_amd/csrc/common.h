@@ -38,10 +38,31 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- wave64 helpers ---------------------------------------------------------------------
 // Sum over the G-lane group (G power of two <= 64) containing this lane; every lane of the
 // group gets the result.  Butterfly with __shfl_xor: fixed order -> deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// fp32 butterfly on the VALU cross-lane paths instead of ds_bpermute (each LDS-crossbar hop costs
+// ~100 cycles of dependent latency; the fused step does ~25 reductions per wave): DPP quad_perm /
+// row_half_mirror / row_mirror inside a row of 16, v_permlane16_swap / v_permlane32_swap (gfx950)
+// across rows.  Same pairing as the xor butterfly, so the sums are bit-identical with it.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group width");
+    if (G >= 2) v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (G >= 4) v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (G >= 8) v += dpp_f32<0x141>(v);       // row_half_mirror
+    if (G >= 16) v += dpp_f32<0x140>(v);      // row_mirror
+    if (G >= 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);    // [even rows | odd rows] of the pair
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    if (G >= 64) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
     return v;
 }
 template <int G>

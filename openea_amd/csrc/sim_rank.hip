@@ -30,66 +30,135 @@ __device__ __forceinline__ uint32_t f2ord(float f) {   // order-preserving float
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Stage rows [row0, row0+128) x k [k0, k0+32) of `src` into `dst` (LDS, permuted k).
-__device__ __forceinline__ void stage_tile(const float *__restrict__ src, int64_t n, int ld, int dim,
-                                           int64_t row0, int k0, float *__restrict__ dst, int tid) {
-    const int q = tid & 7;            // float4 index inside the 32-wide chunk
-    const int g = q >> 1, half = q & 1;
+// A K-chunk of one 128-row operand tile in flight between HBM/L2 and LDS: 4 float4 per thread.
+struct Frag { float4 v[4]; };
+
+// rows [row0, row0+128) x k [k0, k0+32) of `src` -> registers.  Rows past the matrix are clamped to
+// its last row (their products are discarded by the epilogues), so that interior chunks are four
+// plain 16-byte loads from a tile base + 32-bit offsets; only the chunk that crosses `dim` masks.
+__device__ __forceinline__ void load_frag(const float *__restrict__ src, int64_t n, int ld, int dim, int64_t row0,
+                                          int k0, int tid, Frag &f) {
+    const float *base = src + row0 * ld;                                  // wave-uniform
+    const int last = (int)(n - 1 - row0 < TILE - 1 ? n - 1 - row0 : TILE - 1);
+    const int c = k0 + (tid & 7) * 4;
+    if (k0 + BK <= dim) {
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int r = (tid >> 3) + pass * 32;
-        const int64_t row = row0 + r;
-        const int c = k0 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n && c < ld) {
-            v = oea::ld4(src + row * ld + c);
-            if (c + 0 >= dim) v.x = 0.f;
-            if (c + 1 >= dim) v.y = 0.f;
-            if (c + 2 >= dim) v.z = 0.f;
-            if (c + 3 >= dim) v.w = 0.f;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = min((tid >> 3) + pass * 32, last);
+            f.v[pass] = oea::ld4(base + r * ld + c);
         }
-        float *p = dst + r * LDS_LD + g * 8;
-        *reinterpret_cast<float2 *>(p + 2 * half) = make_float2(v.x, v.z);
-        *reinterpret_cast<float2 *>(p + 4 + 2 * half) = make_float2(v.y, v.w);
+    } else {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = min((tid >> 3) + pass * 32, last);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < ld) {
+                v = oea::ld4(base + r * ld + c);
+                if (c + 0 >= dim) v.x = 0.f;
+                if (c + 1 >= dim) v.y = 0.f;
+                if (c + 2 >= dim) v.z = 0.f;
+                if (c + 3 >= dim) v.w = 0.f;
+            }
+            f.v[pass] = v;
+        }
     }
 }
 
-// One 128(M) x 128(N) x K product accumulated into acc[2][2] per wave.
-// M operand = `am` rows [m0, m0+128), N operand = `bn` rows [n0, n0+128).
-__device__ __forceinline__ void tile_gemm(const float *__restrict__ am, int64_t m_rows, int lda,
-                                          const float *__restrict__ bn, int64_t n_rows, int ldb, int dim,
-                                          int64_t m0, int64_t n0, float *As, float *Bs, f32x16 (&acc)[2][2]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// registers -> LDS with the k permutation described above
+__device__ __forceinline__ void store_frag(const Frag &f, float *__restrict__ dst, int tid) {
+    const int q = tid & 7, g = q >> 1, half = q & 1;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        float *p = dst + ((tid >> 3) + pass * 32) * LDS_LD + g * 8;
+        *reinterpret_cast<float2 *>(p + 2 * half) = make_float2(f.v[pass].x, f.v[pass].z);
+        *reinterpret_cast<float2 *>(p + 4 + 2 * half) = make_float2(f.v[pass].y, f.v[pass].w);
+    }
+}
+
+// acc += A-chunk (M rows) x B-chunk (N rows) over `groups` groups of 8 k; per wave a 64x64 sub-tile
+__device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const float *__restrict__ Bs, int groups,
+                                          f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const float *ap = As + (wm * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+    const float *bp = Bs + (wn * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+    for (int g = 0; g < groups; ++g) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(ap + g * 8);
+        const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * LDS_LD + g * 8);
+        const float4 b0 = *reinterpret_cast<const float4 *>(bp + g * 8);
+        const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * LDS_LD + g * 8);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[0][s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[1][s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[0][s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[1][s], acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+// Software pipeline over a sequence of `n_tiles` M-tiles against one fixed N-tile: chunk i+1 travels
+// HBM/L2 -> registers while chunk i is on the matrix cores, and lands in the other LDS buffer
+// (one barrier per chunk).  `epilogue(t, acc)` runs after the last chunk of M-tile t with the
+// first chunk of tile t+1 already in flight.  LDS: As/Bs = 2 buffers of TILE*LDS_LD floats each.
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline(const float *__restrict__ am, int64_t m_rows, int lda,
+                                              const float *__restrict__ bn, int64_t n_rows, int ldb, int dim,
+                                              int64_t n0, int64_t n_tiles, MTile m_tile, float *As, float *Bs,
+                                              Epilogue epilogue) {
+    const int tid = threadIdx.x;
     const int kend = (dim + 7) / 8 * 8;
-    for (int k0 = 0; k0 < kend; k0 += BK) {
-        __syncthreads();   // previous chunk fully consumed
-        stage_tile(am, m_rows, lda, dim, m0, k0, As, tid);
-        stage_tile(bn, n_rows, ldb, dim, n0, k0, Bs, tid);
+    const int nchunk = (kend + BK - 1) / BK;
+    const int64_t total = n_tiles * nchunk;
+    if (total == 0) return;
+    constexpr int BUF = TILE * LDS_LD;
+    Frag fa, fb;
+    load_frag(am, m_rows, lda, dim, m_tile(0), 0, tid, fa);
+    load_frag(bn, n_rows, ldb, dim, n0, 0, tid, fb);
+    store_frag(fa, As, tid);
+    store_frag(fb, Bs, tid);
+    __syncthreads();
+    if (total > 1) {
+        const int64_t t1 = 1 / nchunk;
+        const int k1 = (1 % nchunk) * BK;
+        load_frag(am, m_rows, lda, dim, m_tile(t1), k1, tid, fa);
+        load_frag(bn, n_rows, ldb, dim, n0, k1, tid, fb);
+    }
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    int64_t t = 0;
+    int kc = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        const int cur = (int)(it & 1);
+        mma_chunk(As + cur * BUF, Bs + cur * BUF, min(BK, kend - kc * BK) / 8, acc);
+        if (it + 1 < total) {
+            store_frag(fa, As + (cur ^ 1) * BUF, tid);
+            store_frag(fb, Bs + (cur ^ 1) * BUF, tid);
+        }
         __syncthreads();
-        const int groups = min(BK, kend - k0) / 8;
-        const float *ap = As + (wm * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
-        const float *bp = Bs + (wn * 64 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
-        for (int g = 0; g < groups; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(ap + g * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * LDS_LD + g * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(bp + g * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * LDS_LD + g * 8);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[0][s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[1][s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[0][s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[1][s], acc[1][1], 0, 0, 0);
-            }
+        if (it + 2 < total) {
+            int kc2 = kc + 2;
+            int64_t t2 = t;
+            while (kc2 >= nchunk) { kc2 -= nchunk; ++t2; }
+            load_frag(am, m_rows, lda, dim, m_tile(t2), kc2 * BK, tid, fa);
+            load_frag(bn, n_rows, ldb, dim, n0, kc2 * BK, tid, fb);
+        }
+        if (++kc == nchunk) {
+            epilogue(t, acc);
+            zero_acc(acc);
+            kc = 0;
+            ++t;
         }
     }
 }
@@ -111,12 +180,13 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
 // grid.x = query tiles, grid.y = candidate chunks.  Per lane: one query (MFMA column) and 16
 // candidates per MFMA tile, so the per-query reductions stay in registers across the whole
 // candidate sweep; partial results are merged with integer atomics (order independent).
-__global__ __launch_bounds__(256) void rank_inner_kernel(
+template <bool CSLS>
+__global__ __launch_bounds__(256, 2) void rank_inner_kernel(
     const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2,
     int dim, const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
     int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
-    __shared__ __attribute__((aligned(16))) float As[TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t q0 = (int64_t)blockIdx.x * TILE;
@@ -134,31 +204,56 @@ __global__ __launch_bounds__(256) void rank_inner_kernel(
         qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
         const bool ok = qi[tn] < n1;
         g[tn] = ok ? gold[qi[tn]] : 0.f;
-        rq[tn] = (ok && csls_r) ? csls_r[qi[tn]] : 0.f;
+        rq[tn] = (ok && CSLS) ? csls_r[qi[tn]] : 0.f;
     }
-    for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
-        const int64_t c0 = ct * TILE;
-        f32x16 acc[2][2];
-        tile_gemm(e2, n2, ld2, e1, n1, ld1, dim, c0, q0, As, Bs, acc);
+    tile_pipeline(
+        e2, n2, ld2, e1, n1, ld1, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
+        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
+        [&](int64_t t, f32x16 (&acc)[2][2]) {
+            const int64_t c0 = (ct_begin + t) * TILE;
+            const int64_t g_lo = q0 + gold_off;              // the golds of this query tile: columns [g_lo, g_lo + 128)
+            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+            const bool below = c0 + TILE <= g_lo, above = c0 >= g_lo + TILE;
+            if (c0 + TILE <= n2 && (below || above)) {
+                // interior tile away from the golds: every j is on one side of every gold, so the tie
+                // rule is a plain >= (j < gold) or > (j > gold); a lane meets its candidates in
+                // ascending j, so a strict > keeps the smallest argmax
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+                for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t j = c0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (j < n2) {
-                    const float cj = csls_c ? csls_c[j] : 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
+                        const float cj = CSLS ? csls_c[j] : 0.f;
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) {
-                        float v = acc[tm][tn][r];
-                        if (csls_r) v = (2.0f * v - rq[tn]) - cj;
-                        const int64_t i = qi[tn];
-                        cnt[tn] += (j != i + gold_off) && (v > g[tn] || (v == g[tn] && j < i + gold_off));
-                        if (v > best[tn] || (v == best[tn] && (int)j < bidx[tn])) { best[tn] = v; bidx[tn] = (int)j; }
+                        for (int tn = 0; tn < 2; ++tn) {
+                            float v = acc[tm][tn][r];
+                            if (CSLS) v = fmaf(2.0f, v, -rq[tn]) - cj;       // 2v is exact: == (2v - r) - c
+                            cnt[tn] += below ? (v >= g[tn]) : (v > g[tn]);
+                            if (v > best[tn]) { best[tn] = v; bidx[tn] = j; }
+                        }
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    if (j < n2) {
+                        const float cj = CSLS ? csls_c[j] : 0.f;
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) {
+                            float v = acc[tm][tn][r];
+                            if (CSLS) v = fmaf(2.0f, v, -rq[tn]) - cj;
+                            const int64_t i = qi[tn];
+                            cnt[tn] += (j != i + gold_off) && (v > g[tn] || (v == g[tn] && j < i + gold_off));
+                            if (v > best[tn] || (v == best[tn] && (int)j < bidx[tn])) { best[tn] = v; bidx[tn] = (int)j; }
+                        }
                     }
                 }
             }
-        }
-    }
+        });
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         // merge the two half-waves (same query, disjoint candidates)
@@ -181,27 +276,34 @@ __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best
 }
 
 // ---- store epilogue: M = e1 rows (output rows), N = e2 rows (output columns) ----------------------
-__global__ __launch_bounds__(256) void sim_inner_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
+__global__ __launch_bounds__(256, 2) void sim_inner_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
                                                               const float *__restrict__ e2, int64_t n2, int ld2,
                                                               int dim, float *__restrict__ out, int64_t ld_out) {
-    __shared__ __attribute__((aligned(16))) float As[TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
-    f32x16 acc[2][2];
-    tile_gemm(e1, n1, ld1, e2, n2, ld2, dim, m0, c0, As, Bs, acc);
+    tile_pipeline(
+        e1, n1, ld1, e2, n2, ld2, dim, c0, 1, [=](int64_t) { return m0; }, As, Bs,
+        [&](int64_t, f32x16 (&acc)[2][2]) {
+            float *tile = out + m0 * ld_out + c0;                                    // wave-uniform
+            const int rows_left = (int)(n1 - m0 < TILE ? n1 - m0 : TILE), cols_left = (int)(n2 - c0 < TILE ? n2 - c0 : TILE);
+            const int col = wn * 64 + (lane & 31), rbase = wm * 64 + 4 * (lane >> 5);
+            const bool ok0 = col < cols_left, ok1 = col + 32 < cols_left;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int64_t j = c0 + wn * 64 + tn * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i < n1 && j < n2) out[i * ld_out + j] = acc[tm][tn][r];
-            }
-        }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < rows_left) {
+                        float *p = tile + (row * (int)ld_out + col);               // 128 rows * ld_out < 2^31
+                        if (ok0) p[0] = acc[tm][0][r];
+                        if (ok1) p[32] = acc[tm][1][r];
+                    }
+                    asm volatile("" ::: "memory");      // keep the 32 row addresses from all being live at once
+                }
+        });
 }
 
 // ---- fp64 VALU tiles: manhattan / euclidean --------------------------------------------------------
@@ -476,8 +578,12 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
         gold_inner_kernel<<<gb, 256, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r, csls_c ? csls_c + gold_offset : nullptr, gold);
         const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
-        rank_inner_kernel<<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
-                                                                              csls_c, tpc, gold_offset, rank, keys);
+        if (csls_r)
+            rank_inner_kernel<true><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
+                                                                                        csls_c, tpc, gold_offset, rank, keys);
+        else
+            rank_inner_kernel<false><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
+                                                                                         csls_c, tpc, gold_offset, rank, keys);
     } else if (metric == OEA_METRIC_MANHATTAN || metric == OEA_METRIC_EUCLIDEAN) {
         const int64_t qt = oea::ceil_div(n1, VT), ctiles = oea::ceil_div(n2, VT);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
@@ -515,7 +621,7 @@ int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, 
 int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
                    int32_t dim, int32_t metric, float *out, int64_t ld_out, void *stream) {
     OEA_REQUIRE(e1 && e2 && out, "null pointer");
-    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && ld_out >= n2, "shapes");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && ld_out >= n2 && ld_out < (1 << 24), "shapes");
     if (n1 == 0 || n2 == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
     if (metric == OEA_METRIC_INNER) {

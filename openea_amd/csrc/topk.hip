@@ -178,12 +178,22 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
     const int64_t seg1 = seg0 + tiles_per_wave * 256 < nc ? seg0 + tiles_per_wave * 256 : nc;
 
     // ---- read 1: histogram --------------------------------------------------------------------
-    for (int64_t c0 = seg0 + lane * 4; c0 < seg1; c0 += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(src + c0);      // ld % 32 == 0: in bounds, 16 B aligned
-        atomicAdd(&hist[lin_bin(v.x, lo, scale)], 1);
-        if (c0 + 1 < nc) atomicAdd(&hist[lin_bin(v.y, lo, scale)], 1);
-        if (c0 + 2 < nc) atomicAdd(&hist[lin_bin(v.z, lo, scale)], 1);
-        if (c0 + 3 < nc) atomicAdd(&hist[lin_bin(v.w, lo, scale)], 1);
+    constexpr int U = 4;                                   // tiles in flight per wave (latency hiding)
+    for (int64_t t0 = seg0 + lane * 4; t0 - lane * 4 < seg1; t0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                      // ld % 4 == 0: a 16 B load at c0 < nc stays inside the row
+            const int64_t c0 = t0 + u * 256;
+            v[u] = c0 < seg1 ? *reinterpret_cast<const float4 *>(src + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            if (c0 < seg1) atomicAdd(&hist[lin_bin(v[u].x, lo, scale)], 1);
+            if (c0 + 1 < seg1) atomicAdd(&hist[lin_bin(v[u].y, lo, scale)], 1);
+            if (c0 + 2 < seg1) atomicAdd(&hist[lin_bin(v[u].z, lo, scale)], 1);
+            if (c0 + 3 < seg1) atomicAdd(&hist[lin_bin(v[u].w, lo, scale)], 1);
+        }
     }
     __syncthreads();
     if (tid < 64) {          // the bucket (from the top) where the cumulative count reaches k
@@ -217,18 +227,27 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
 
     // ---- read 2: candidates of bucket b*, per-wave count above it ---------------------------------
     int gt = 0;
-    for (int64_t c0 = seg0 + lane * 4; c0 < seg1; c0 += 256) {
-        const float4 v = *reinterpret_cast<const float4 *>(src + c0);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int64_t t0 = seg0 + lane * 4; t0 - lane * 4 < seg1; t0 += 256 * U) {
+        float4 v[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (c0 + i < nc) {
-                const int b = lin_bin(vv[i], lo, scale);
-                gt += b > bstar;
-                if (b == bstar) {
-                    const int p = atomicAdd(&s_ncand, 1);
-                    c_key[p] = f2ord(vv[i]);
-                    c_col[p] = (int)(c0 + i);
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            v[u] = c0 < seg1 ? *reinterpret_cast<const float4 *>(src + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c0 + i < seg1) {
+                    const int b = lin_bin(vv[i], lo, scale);
+                    gt += b > bstar;
+                    if (b == bstar) {
+                        const int p = atomicAdd(&s_ncand, 1);
+                        c_key[p] = f2ord(vv[i]);
+                        c_col[p] = (int)(c0 + i);
+                    }
                 }
             }
         }
@@ -261,23 +280,32 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
 
     // ---- read 3: ordered compaction ---------------------------------------------------------------
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int64_t c0 = seg0 + lane * 4; c0 - lane * 4 < seg1; c0 += 256) {       // wave-uniform trip count
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 < seg1) v = *reinterpret_cast<const float4 *>(src + c0);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        bool sel[4];
-        uint64_t bal[4];
+    for (int64_t t0 = seg0 + lane * 4; t0 - lane * 4 < seg1; t0 += 256 * U) {       // wave-uniform trip count
+        float4 v[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t key = f2ord(vv[i]);
-            sel[i] = (c0 + i < seg1) && (key > tkey || (key == tkey && (int)(c0 + i) <= tcol));
-            bal[i] = __ballot(sel[i]);
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            v[u] = c0 < seg1 ? *reinterpret_cast<const float4 *>(src + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        int p = running + __popcll(bal[0] & lt) + __popcll(bal[1] & lt) + __popcll(bal[2] & lt) + __popcll(bal[3] & lt);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (sel[i]) o[p++] = id_map ? id_map[c0 + i] : (int32_t)(c0 + i);
-        running += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+        for (int u = 0; u < U; ++u) {                       // tiles in column order
+            const int64_t c0 = t0 + u * 256;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            bool sel[4];
+            uint64_t bal[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t key = f2ord(vv[i]);
+                sel[i] = (c0 + i < seg1) && (key > tkey || (key == tkey && (int)(c0 + i) <= tcol));
+                bal[i] = __ballot(sel[i]);
+            }
+            if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;
+            int p = running + __popcll(bal[0] & lt) + __popcll(bal[1] & lt) + __popcll(bal[2] & lt) + __popcll(bal[3] & lt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (sel[i]) o[p++] = id_map ? id_map[c0 + i] : (int32_t)(c0 + i);
+            running += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+        }
     }
 }
 

@@ -217,90 +217,140 @@ __global__ __launch_bounds__(256) void triple_generic(
 // The k corrupted rows are requested KC at a time BEFORE any of them is consumed, so a group pays
 // one memory latency per chunk instead of one per negative (the first version walked the
 // negatives with a prefetch depth of one and was latency-bound: 38 us for 5,000 x 11 triples).
+// score one (h, r, t) as an independent triple (entries of a grouped batch that are not corruptions of
+// their positive): 3 gathers, 3 atomics.
+template <int G, int IT>
+__device__ __attribute__((noinline)) double score_independent(const float *__restrict__ ent, const float *__restrict__ rel, int ld,
+                                                    int lane, int64_t item, int ch, int cr, int ct, bool is_pos,
+                                                    const oea_step_cfg &cfg, const StepWs &ws) {
+    Row<G, IT> zh, zr, zt, delta, g;
+    load_row<G, IT>(ent + (int64_t)ch * ld, ld, lane, zh);
+    load_row<G, IT>(rel + (int64_t)cr * ld, ld, lane, zr);
+    load_row<G, IT>(ent + (int64_t)ct * ld, ld, lane, zt);
+    normalize<G, IT>(zh, cfg.ent_l2_norm);
+    normalize<G, IT>(zr, cfg.rel_l2_norm);
+    normalize<G, IT>(zt, cfg.ent_l2_norm);
+    const float s = score<G, IT>(zh, zr, zt, cfg.l1, delta);
+    float coef, l;
+    triple_coef(cfg, is_pos, s, coef, l);
+    if (coef != 0.f) {
+        dscore<G, IT>(delta, coef, cfg.l1, g);
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)ch * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.rel_grad + (item % kRelCopies) * ws.rel_copy_stride + (int64_t)cr * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)ct * ld, ld, lane, g, -1.f);
+        if (lane == 0) { ws.ent_touched[ch] = 1.f; ws.ent_touched[ct] = 1.f; ws.rel_touched[cr] = 1.f; }
+    }
+    return (double)l;
+}
+
+// The step is latency-bound (a few thousand short waves, ~1,800 instructions each), so the kernel is
+// organised around DEPENDENT ROUND TRIPS, two per positive: (1) the ids -- the positive's three and
+// its negatives' 3k, fetched by the lanes of the group in one coalesced load each and handed round
+// with cross-lane reads; (2) every row the group needs, 3 + k gathers issued back to back.  The
+// arithmetic after that is branch-free per negative so the k reduction chains interleave.
 template <int G, int IT>
 __global__ __launch_bounds__(256) void triple_grouped(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
     int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
-    constexpr int KC = IT <= 4 ? 8 : 2;
+    constexpr int KC = IT <= 4 ? 10 : (IT <= 8 ? 4 : 2);      // negatives in flight: KC * IT row registers
+    static_assert(3 * KC <= G, "ids of a chunk fit one register across the group");
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
     double loss_local = 0.0;
     for (int64_t p = grp; p < n_pos; p += ngrp) {
-        const int h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
         const int32_t *ng = neg + (int64_t)p * k * 3;
+        // ---- round trip 1: ids -------------------------------------------------------------------------
+        const int pid = lane < 3 ? pos[3 * p + lane] : 0;
+        int nid = lane < 3 * min(KC, k) ? ng[lane] : 0;
+        const int h = __shfl(pid, 0, G), r = __shfl(pid, 1, G), t = __shfl(pid, 2, G);
         Row<G, IT> yh, yr, yt, delta, g, gh, gr, gt;
         load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
         load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
         load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
-        normalize<G, IT>(yh, cfg.ent_l2_norm);
-        normalize<G, IT>(yr, cfg.rel_l2_norm);
-        normalize<G, IT>(yt, cfg.ent_l2_norm);
-        float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
-        float coef, l;
-        triple_coef(cfg, true, s, coef, l);
-        double lsum = (double)l;
-        dscore<G, IT>(delta, coef, cfg.l1, g);
-#pragma unroll
-        for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
-        bool any = coef != 0.f;
+        double lsum = 0.0;
+        bool any = false;
         for (int base = 0; base < k; base += KC) {
+            if (base > 0) nid = lane < 3 * min(KC, k - base) ? ng[3 * base + lane] : 0;
             int ch[KC], cr[KC], ct[KC];
+            bool valid[KC], tail[KC], ok[KC];
             Row<G, IT> yc[KC];
+            // ---- round trip 2: the corrupted rows (and, first time round, the positive's) ----------------
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                if (base + j < k) {
-                    ch[j] = ng[3 * (base + j)]; cr[j] = ng[3 * (base + j) + 1]; ct[j] = ng[3 * (base + j) + 2];
-                    load_row<G, IT>(ent + (int64_t)((ch[j] == h) ? ct[j] : ch[j]) * ld, ld, lane, yc[j]);
+                ch[j] = __shfl(nid, 3 * j, G); cr[j] = __shfl(nid, 3 * j + 1, G); ct[j] = __shfl(nid, 3 * j + 2, G);
+                valid[j] = base + j < k;
+                tail[j] = ch[j] == h;                                  // tail corrupted (or neg == pos): uses yh, yr
+                ok[j] = valid[j] && cr[j] == r && (tail[j] || ct[j] == t);
+                const int e = valid[j] ? (tail[j] ? ct[j] : ch[j]) : h;
+                load_row<G, IT>(ent + (int64_t)e * ld, ld, lane, yc[j]);
+            }
+            if (base == 0) {
+                normalize<G, IT>(yh, cfg.ent_l2_norm);
+                normalize<G, IT>(yr, cfg.rel_l2_norm);
+                normalize<G, IT>(yt, cfg.ent_l2_norm);
+                const float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+                float coef, l;
+                triple_coef(cfg, true, s, coef, l);
+                lsum = (double)l;
+                dscore<G, IT>(delta, coef, cfg.l1, g);
+#pragma unroll
+                for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
+                any = coef != 0.f;
+            }
+            float sc[KC];
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {                             // branch-free: k independent chains
+                normalize<G, IT>(yc[j], cfg.ent_l2_norm);
+                float s = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const float a = tail[j] ? yh.v[it] : yc[j].v[it], b = tail[j] ? yc[j].v[it] : yt.v[it];
+                    const float d = a + yr.v[it] - b;
+                    yc[j].v[it] = d;                                    // the row is not needed again: keep delta in place
+                    s += cfg.l1 ? fabsf(d) : d * d;
                 }
+                sc[j] = group_sum<G>(s);
             }
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                if (base + j >= k) continue;
-                const int cur_h = ch[j], cur_r = cr[j], cur_t = ct[j];
-                const bool tail_side = (cur_h == h);              // tail corrupted (or neg == pos): uses yh, yr
-                const bool head_side = !tail_side && (cur_t == t);
-                if (cur_r == r && (tail_side || head_side)) {
-                    normalize<G, IT>(yc[j], cfg.ent_l2_norm);
-                    s = tail_side ? score<G, IT>(yh, yr, yc[j], cfg.l1, delta) : score<G, IT>(yc[j], yr, yt, cfg.l1, delta);
-                    triple_coef(cfg, false, s, coef, l);
-                    lsum += (double)l;
-                    if (coef != 0.f) {
-                        any = true;
-                        dscore<G, IT>(delta, coef, cfg.l1, g);
-                        if (tail_side) {
+                if (!valid[j]) continue;
+                if (!ok[j]) {                                           // not a corruption of this positive
+                    lsum += score_independent<G, IT>(ent, rel, ld, lane, p, ch[j], cr[j], ct[j], false, cfg, ws);
+                    continue;
+                }
+                float coef, l;
+                triple_coef(cfg, false, sc[j], coef, l);
+                lsum += (double)l;
+                if (coef != 0.f) {
+                    any = true;
+                    dscore<G, IT>(yc[j], coef, cfg.l1, g);
+                    if (tail[j]) {
 #pragma unroll
-                            for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
-                            atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_t * ld, ld, lane, g, -1.f);
-                            if (lane == 0) ws.ent_touched[cur_t] = 1.f;
-                        } else {
+                        for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
+                        atomic_row<G, IT>(ws.ent_grad + (int64_t)ct[j] * ld, ld, lane, g, -1.f);
+                        if (lane == 0) ws.ent_touched[ct[j]] = 1.f;
+                    } else {
 #pragma unroll
-                            for (int it = 0; it < IT; ++it) { gr.v[it] += g.v[it]; gt.v[it] -= g.v[it]; }
-                            atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_h * ld, ld, lane, g, 1.f);
-                            if (lane == 0) ws.ent_touched[cur_h] = 1.f;
-                        }
-                    }
-                } else {
-                    // not a corruption of this positive: score it as an independent triple
-                    Row<G, IT> zh, zr, zt;
-                    load_row<G, IT>(ent + (int64_t)cur_h * ld, ld, lane, zh);
-                    load_row<G, IT>(rel + (int64_t)cur_r * ld, ld, lane, zr);
-                    load_row<G, IT>(ent + (int64_t)cur_t * ld, ld, lane, zt);
-                    normalize<G, IT>(zh, cfg.ent_l2_norm);
-                    normalize<G, IT>(zr, cfg.rel_l2_norm);
-                    normalize<G, IT>(zt, cfg.ent_l2_norm);
-                    s = score<G, IT>(zh, zr, zt, cfg.l1, delta);
-                    triple_coef(cfg, false, s, coef, l);
-                    lsum += (double)l;
-                    if (coef != 0.f) {
-                        dscore<G, IT>(delta, coef, cfg.l1, g);
-                        atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_h * ld, ld, lane, g, 1.f);
-                        atomic_row<G, IT>(ws.rel_grad + (p % kRelCopies) * ws.rel_copy_stride + (int64_t)cur_r * ld, ld, lane, g, 1.f);
-                        atomic_row<G, IT>(ws.ent_grad + (int64_t)cur_t * ld, ld, lane, g, -1.f);
-                        if (lane == 0) { ws.ent_touched[cur_h] = 1.f; ws.ent_touched[cur_t] = 1.f; ws.rel_touched[cur_r] = 1.f; }
+                        for (int it = 0; it < IT; ++it) { gr.v[it] += g.v[it]; gt.v[it] -= g.v[it]; }
+                        atomic_row<G, IT>(ws.ent_grad + (int64_t)ch[j] * ld, ld, lane, g, 1.f);
+                        if (lane == 0) ws.ent_touched[ch[j]] = 1.f;
                     }
                 }
             }
+        }
+        if (k <= 0) {       // no negatives: the positive alone
+            normalize<G, IT>(yh, cfg.ent_l2_norm);
+            normalize<G, IT>(yr, cfg.rel_l2_norm);
+            normalize<G, IT>(yt, cfg.ent_l2_norm);
+            const float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+            float coef, l;
+            triple_coef(cfg, true, s, coef, l);
+            lsum = (double)l;
+            dscore<G, IT>(delta, coef, cfg.l1, g);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
+            any = coef != 0.f;
         }
         if (any) {
             atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, gh, 1.f);

@@ -34,6 +34,14 @@ def timed(name, fn, reps=3):
 def main():
     ops.lib()
     rng = np.random.RandomState(0)
+    only = os.environ.get("LEGS", "")          # LEGS=eval70k: just the 70,000^2 inner eval (PMC passes)
+    if only == "eval70k":
+        n, d = 70000, 100
+        e1 = unit(rng, n, d)
+        t1 = ops.to_table(e1)
+        t2 = ops.to_table(e1 + 0.4 * unit(rng, n, d))
+        timed("eval inner   %6d^2 x %d" % (n, d), lambda: greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, 0), reps=1)
+        return
     for n, d in ((10500, 100), (70000, 100), (10500, 300)):
         e1 = unit(rng, n, d)
         t1 = ops.to_table(e1)
