@@ -44,8 +44,10 @@ int oea_device_count(void);
 /* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figure; no reference counterpart).  Between begin and end, every oea_triple_step
  * records 3 marks: [fwd_bwd kernel][apply kernel].  oea_profile_end(3, ms, &n) returns
- * ms[0] = total fwd_bwd time, ms[1] = total apply time (milliseconds) over n calls. */
-int oea_profile_begin(void);
+ * ms[0] = total fwd_bwd time, ms[1] = total apply time (milliseconds) over n calls.
+ * stride: only every stride-th step records its marks (an event record costs a few microseconds of
+ * enqueue time, comparable to the kernels themselves at the 15K shape). */
+int oea_profile_begin(int32_t stride);
 int oea_profile_end(int32_t group, double *out_ms_host, int32_t *n_calls_host);
 
 /* ---------------------------------------------------------------------------------------

@@ -55,7 +55,7 @@ PROTOTYPES = {
     "oea_version": (C.c_int, []),
     "oea_last_error": (C.c_char_p, []),
     "oea_device_count": (C.c_int, []),
-    "oea_profile_begin": (C.c_int, []),
+    "oea_profile_begin": (C.c_int, [_i32]),
     "oea_profile_end": (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "oea_store_create": (C.c_int, [_i64, _i32, C.POINTER(_vp)]),
     "oea_store_destroy": (C.c_int, [_vp]),

@@ -12,7 +12,8 @@ void set_error(const char *fmt, ...);
 
 // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
 bool prof_enabled();
-void prof_mark(hipStream_t st);   // records the next event of the current profile session
+void prof_call();                  // start of a profiled call: is it one of the sampled ones?
+void prof_mark(hipStream_t st);   // records the next event of the current profile session (sampled calls only)
 
 #define OEA_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \

@@ -21,8 +21,13 @@ static bool g_prof = false;
 static std::vector<hipEvent_t> g_events;
 static size_t g_nmarks = 0;
 bool prof_enabled() { return g_prof; }
+static int g_stride = 1;
+static long g_calls = 0;
+static bool g_sampled = false;
+// first thing a profiled entry point does: decides whether THIS call records its marks
+void prof_call() { g_sampled = g_prof && (g_calls++ % g_stride == 0); }
 void prof_mark(hipStream_t st) {
-    if (!g_prof) return;
+    if (!g_sampled) return;
     if (g_nmarks == g_events.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
@@ -48,15 +53,19 @@ int oea_device_count(void) {
     return n;
 }
 
-int oea_profile_begin(void) {
+int oea_profile_begin(int32_t stride) {
+    OEA_REQUIRE(stride >= 1, "stride >= 1");
     oea::g_prof = true;
     oea::g_nmarks = 0;
+    oea::g_stride = stride;
+    oea::g_calls = 0;
     return OEA_OK;
 }
 /* marks come in groups of `group` consecutive events per profiled call; out_ms[j] receives the
  * SUM over calls of the time between mark j and mark j+1 of each group (j < group-1). */
 int oea_profile_end(int32_t group, double *out_ms_host, int32_t *n_calls_host) {
     oea::g_prof = false;
+    oea::g_sampled = false;
     OEA_REQUIRE(group >= 2 && out_ms_host && n_calls_host, "group >= 2");
     const size_t n = oea::g_nmarks / (size_t)group;
     for (int j = 0; j < group - 1; ++j) out_ms_host[j] = 0.0;

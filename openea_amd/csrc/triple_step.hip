@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void triple_generic(
 // score one (h, r, t) as an independent triple (entries of a grouped batch that are not corruptions of
 // their positive): 3 gathers, 3 atomics.
 template <int G, int IT>
-__device__ __attribute__((noinline)) double score_independent(const float *__restrict__ ent, const float *__restrict__ rel, int ld,
+__device__ __forceinline__ double score_independent(const float *__restrict__ ent, const float *__restrict__ rel, int ld,
                                                     int lane, int64_t item, int ch, int cr, int ct, bool is_pos,
                                                     const oea_step_cfg &cfg, const StepWs &ws) {
     Row<G, IT> zh, zr, zt, delta, g;
@@ -298,6 +298,16 @@ __global__ __launch_bounds__(256) void triple_grouped(
                 for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
                 any = coef != 0.f;
             }
+            unsigned slow = 0;                                         // entries that are not corruptions of this positive
+#pragma unroll
+            for (int j = 0; j < KC; ++j) slow |= (valid[j] && !ok[j]) ? 1u << j : 0u;
+            if (slow) {                                                // rare: one copy of the code, ids re-read across lanes
+#pragma unroll 1
+                for (int j = 0; j < KC; ++j)
+                    if ((slow >> j) & 1u)
+                        lsum += score_independent<G, IT>(ent, rel, ld, lane, p, __shfl(nid, 3 * j, G), __shfl(nid, 3 * j + 1, G),
+                                                         __shfl(nid, 3 * j + 2, G), false, cfg, ws);
+            }
             float sc[KC];
 #pragma unroll
             for (int j = 0; j < KC; ++j) {                             // branch-free: k independent chains
@@ -314,11 +324,7 @@ __global__ __launch_bounds__(256) void triple_grouped(
             }
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                if (!valid[j]) continue;
-                if (!ok[j]) {                                           // not a corruption of this positive
-                    lsum += score_independent<G, IT>(ent, rel, ld, lane, p, ch[j], cr[j], ct[j], false, cfg, ws);
-                    continue;
-                }
+                if (!ok[j]) continue;
                 float coef, l;
                 triple_coef(cfg, false, sc[j], coef, l);
                 lsum += (double)l;
@@ -467,6 +473,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     const bool grouped = cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN;
     const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
+    oea::prof_call();
     oea::prof_mark(st);
     if (phase != OEA_PHASE_APPLY) {
         if (grouped)

@@ -126,8 +126,8 @@ def step_exchange_view(workspace, n_ent, n_rel, ld):
     return workspace[: 4 * n].view(torch.float32)
 
 
-def profile_begin():
-    check(lib().oea_profile_begin())
+def profile_begin(stride=1):
+    check(lib().oea_profile_begin(int(stride)))
 
 
 def profile_end(group=3):

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""gpurun_out/<tag> (written by tools/collect_profiles.sh) -> profiles/<name>_*.csv + profiles/traffic_triple_fwd_bwd.json.
+
+HBM traffic per launch follows MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes, both count KB, and on gfx950 FETCH_SIZE reports half of the bytes read: bytes = (2*FETCH + WRITE) * 1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def pmc_avg(d, counter):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]] += float(r["Counter_Value"])
+                n[r["Kernel_Name"]] += 1
+    return {k: acc[k] / n[k] for k in acc}, n
+
+
+def main():
+    src, name = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    for leg, out in (("stats", "bench_kernel_stats"), ("legs", "legs_kernel_stats")):
+        fs = glob.glob(os.path.join(src, leg, "*", "*_kernel_stats.csv"))
+        if fs:
+            shutil.copy(fs[0], os.path.join(prof, "%s_%s.csv" % (name, out)))
+    for log in ("bench_stats.log", "legs.log"):
+        p = os.path.join(src, log)
+        if os.path.exists(p):
+            lines = [l for l in open(p) if not l.startswith("/opt/amdgpu")]
+            open(os.path.join(prof, "%s_%s" % (name, log.replace(".log", "_stdout.txt"))), "w").writelines(lines[-40:])
+    fetch, n = pmc_avg(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    write, _ = pmc_avg(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    rows = []
+    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0)) * n[k]):
+        rows.append((k[:90], n[k], fetch[k], write.get(k, 0.0), int((2 * fetch[k] + write.get(k, 0.0)) * 1024)))
+    with open(os.path.join(prof, "%s_pmc_hbm_traffic.csv" % name), "w") as f:
+        f.write("kernel,calls,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+        for r in rows:
+            f.write('"%s",%d,%.1f,%.1f,%d\n' % r)
+    dom = [r for r in rows if "triple_grouped" in r[0]]
+    if dom:
+        r = dom[0]
+        json.dump({"kernel": r[0].split("(")[0].replace("void (anonymous namespace)::", ""),
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_pmc_hbm_traffic.csv" % name,
+                   "FETCH_SIZE_KB": r[2], "WRITE_SIZE_KB": r[3],
+                   "correction": "gfx950: FETCH_SIZE reads 1/2 of the bytes (MI355X_MICROARCH.md HBM section) -> 2*FETCH + WRITE",
+                   "hbm_bytes_per_launch": r[4]}, open(os.path.join(prof, "traffic_triple_fwd_bwd.json"), "w"), indent=1)
+    print("wrote", sorted(os.listdir(prof)))
+
+
+if __name__ == "__main__":
+    main()
