@@ -247,6 +247,13 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
 int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, int32_t nk,
                      int64_t *hits_dev, int64_t *rank_sum_dev, double *rr_sum_dev, void *stream);
 
+/* calculate_rank (alignment.py:146-168) on an explicit block of a similarity matrix s [n_rows, ld]
+ * (device): gold of row i is column gold_idx[i] (0 <= gold_idx[i] < nc).  rank[i] = position of the
+ * gold in the descending order of row i with the tie rule above, argmax[i] = smallest column of the
+ * row maximum. */
+int oea_rank_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, const int32_t *gold_idx,
+                  int32_t *rank, int32_t *argmax, void *stream);
+
 /* Similarity strip S[i, j] for i in [0,n1), j in [0,n2): out is [n1, ld_out] fp32
  * (similarity.py:34-48).  Used by the sim() mirror, CSLS and the neighbour search. */
 int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2,

@@ -550,6 +550,42 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
     return (int)((c_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk);
 }
 
+// ---- rank of given gold columns on an explicit similarity block (calculate_rank, alignment.py:146-168)
+// one workgroup per row: rank = #{S_ij > S_ig} + #{j < g : S_ij == S_ig}, argmax = smallest j of the max
+__global__ __launch_bounds__(256) void rank_rows_kernel(const float *__restrict__ s, int64_t nc, int64_t ld,
+                                                        const int32_t *__restrict__ gold_idx, int32_t *__restrict__ rank,
+                                                        int32_t *__restrict__ argmax) {
+    __shared__ int s_cnt[4];
+    __shared__ unsigned long long s_key[4];
+    const int64_t row = blockIdx.x;
+    const float *src = s + row * ld;
+    const int g = gold_idx[row];
+    const float gv = src[g];
+    int cnt = 0;
+    unsigned long long best = 0ull;
+    for (int64_t j = threadIdx.x; j < nc; j += 256) {
+        const float v = src[j];
+        cnt += (j != g) && (v > gv || (v == gv && j < g));
+        const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = cnt; s_key[threadIdx.x >> 6] = best; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        unsigned long long b = 0ull;
+        for (int w = 0; w < 4; ++w) { c += s_cnt[w]; b = s_key[w] > b ? s_key[w] : b; }
+        rank[row] = c;
+        argmax[row] = (int32_t)(0xFFFFFFFFu - (uint32_t)(b & 0xFFFFFFFFull));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -649,6 +685,16 @@ int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_
     const unsigned grid = (unsigned)oea::ceil_div(n1, 4);
     if (k <= 16) row_topk_mean_kernel<16><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
     else row_topk_mean_kernel<32><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_rank_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, const int32_t *gold_idx, int32_t *rank,
+                  int32_t *argmax, void *stream) {
+    OEA_REQUIRE(s && gold_idx && rank && argmax, "null pointer");
+    OEA_REQUIRE(nc >= 1 && nc < 0x7fffffff && ld >= nc && n_rows < 0x7fffffff, "1 <= nc <= ld");
+    if (n_rows == 0) return OEA_OK;
+    rank_rows_kernel<<<(unsigned)n_rows, 256, 0, oea::as_stream(stream)>>>(s, nc, ld, gold_idx, rank, argmax);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -81,6 +81,15 @@ class BasicModel:
         self.rel_embeds = init_embeddings([self.kgs.relations_num, self.args.dim], 'rel_embeds',
                                           self.args.init, self.args.rel_l2_norm)
 
+    @staticmethod
+    def _dist_group():
+        """data parallelism is on whenever the process was launched under torch.distributed with more
+        than one rank (one process per GPU; models/dist.py): tables replicated, each rank scores its
+        slice of every batch, evaluation / neighbour search row-sharded."""
+        from . import dist as mdist
+        import torch.distributed as tdist
+        return tdist.group.WORLD if mdist.world()[1] > 1 else None
+
     def _step_cfg(self, loss_cfg, neg_group_k):
         cfg = generate_optimizer(loss_cfg, self.args.learning_rate, opt=self.args.optimizer)
         return ops.make_step_cfg(ent_l2_norm=self.ent_embeds.is_l2_norm, rel_l2_norm=self.rel_embeds.is_l2_norm,
@@ -92,7 +101,7 @@ class BasicModel:
         k = self.args.neg_triple_num if self.args.loss != 'margin-based' else 0
         cfg, opt = self._step_cfg(self.triple_loss, k)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt)
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group())
 
     def _define_mapping_variables(self):
         """mapping.py:22-25: orthogonal d x d matrix + identity."""
@@ -188,8 +197,10 @@ class BasicModel:
     def _ensure_epochs(self, with_negatives=True):
         if self._epochs is None:
             k = self.args.neg_triple_num if with_negatives else 0
+            from . import dist as mdist
+            rank, world = mdist.world()
             self._epochs = RelationTripleEpochs(self.kgs, self.args.batch_size, k, seed=self._seed,
-                                                dev=self.ent_embeds.var.device)
+                                                dev=self.ent_embeds.var.device, rank=rank, world=world)
         return self._epochs
 
     def launch_training_1epo(self, epoch, triple_steps, steps_tasks, training_batch_queue, neighbors1, neighbors2):

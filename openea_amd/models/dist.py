@@ -51,11 +51,13 @@ def allgather_rows(local, n_total, group=None):
         return local
     sizes = shard_sizes(n_total, ws)
     m = max(sizes)
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # gloo (CPU tests, and the 2-processes-on-one-GPU wiring test) has no device all_gather: stage on the host
+    stage = local.is_cuda and dist.get_backend(group) == "gloo"
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device="cpu" if stage else local.device)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).to(local.device)
 
 
 def allreduce_sum_(t, group=None):

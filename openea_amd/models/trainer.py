@@ -191,4 +191,8 @@ def refresh_neighbours(ent, entity_list, k):
     (normalised lookup) -> k nearest entity ids per entity, all on the device."""
     ids = ops.to_ids(np.asarray(entity_list, np.int32), ent.var.device)
     emb = ent.lookup(ids)
+    from . import dist as mdist
+    if mdist.world()[1] > 1:      # query rows sharded over the ranks, table all-gathered
+        return mdist.sharded_neighbours(emb, ent.dim, ids, k,
+                                        lambda q, cand, d, kk, id_map: ops.topk_inner(q.contiguous(), cand, d, kk, id_map=id_map))
     return neighbours_device(emb, ent.dim, ids, k)

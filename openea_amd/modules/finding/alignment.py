@@ -21,12 +21,38 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
         t1, t2 = t1.clone(), t2.clone()
         ops.normalize_rows_(t1, dim, sklearn=True)
         ops.normalize_rows_(t2, dim, sklearn=True)
+    from ...models import dist as mdist
+    rk, ws = mdist.world()
+    if ws > 1:
+        return _greedy_alignment_sharded(t1, t2, dim, top_k, kmetric, csls_k, rk, ws)
     r = c = None
     if csls_k > 0:
         r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
     rank, argmax = ops.rank_eval(t1, t2, dim, kmetric, r, c)
     hits, rank_sum, rr_sum = ops.rank_metrics(rank, top_k)
     return rank, argmax, hits, rank_sum, rr_sum
+
+
+def _greedy_alignment_sharded(t1, t2, dim, top_k, kmetric, csls_k, rk, ws):
+    """torch.distributed is initialised: this rank ranks its block of query rows against the full
+    (replicated) candidate block -- no data-path collective; the integer sums are all-reduced and
+    the per-row outputs all-gathered (models/dist.py).  CSLS: row means of the own block, column
+    means of the own block of CANDIDATE rows (all-gathered)."""
+    from ...models import dist as mdist
+    n1, n2 = t1.shape[0], t2.shape[0]
+    r = c = None
+    if csls_k > 0:
+        lo1, hi1 = mdist.shard_range(n1, rk, ws)
+        lo2, hi2 = mdist.shard_range(n2, rk, ws)
+        r_loc, _ = csls_means_device(t1[lo1:hi1], t2, dim, kmetric, csls_k, cols=False)
+        c_loc, _ = csls_means_device(t2[lo2:hi2], t1, dim, kmetric, csls_k, cols=False)
+        r, c = mdist.allgather_rows(r_loc, n1), mdist.allgather_rows(c_loc, n2)
+
+    def rank_fn(block, cand, d, off):
+        return ops.rank_eval(block, cand, d, kmetric, None if r is None else r[off: off + block.shape[0]].contiguous(),
+                             c, gold_offset=off)
+    hits, rank_sum, rr_sum, argmax = mdist.sharded_rank_metrics(t1, t2, dim, top_k, rank_fn)
+    return None, argmax, hits, rank_sum, rr_sum
 
 
 def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csls_k, accurate):
@@ -70,11 +96,7 @@ def calculate_rank(idx, sim_mat, top_k, accurate, total_num):
     import torch
     assert 1 in top_k
     s = torch.from_numpy(np.ascontiguousarray(sim_mat, np.float32)).to(ops.device())
-    idx_t = torch.as_tensor(np.asarray(idx, np.int64), device=s.device)
-    gold = s.gather(1, idx_t.view(-1, 1))
-    cols = torch.arange(s.shape[1], device=s.device).view(1, -1)
-    rank = ((s > gold) | ((s == gold) & (cols < idx_t.view(-1, 1)))).sum(1)
-    argmax = s.argmax(1)
+    rank, argmax = ops.rank_rows(s, ops.to_ids(np.asarray(idx, np.int32), s.device))
     rank_h = rank.cpu().numpy().astype(np.int64)
     mr = float((rank_h + 1).sum()) / total_num
     mrr = float((1.0 / (rank_h + 1)).sum()) / total_num

@@ -76,9 +76,10 @@ def csls_sim(sim_mat, k):
     return s.cpu().numpy()
 
 
-def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30):
+def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
     """Per-row and per-column top-k means WITHOUT holding the whole matrix: strips of rows of S
-    and of S^T are produced and reduced one after the other (each strip <= max_bytes)."""
+    and of S^T are produced and reduced one after the other (each strip <= max_bytes).
+    cols=False: only the row means (second result None)."""
     import torch
 
     def strip_means(a, b):
@@ -90,4 +91,4 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30):
             out[r0:r0 + rows_per] = ops.row_topk_mean(s, k)
             del s
         return out
-    return strip_means(t1, t2), strip_means(t2, t1)
+    return strip_means(t1, t2), (strip_means(t2, t1) if cols else None)

@@ -1,6 +1,13 @@
 """In-memory KG (mirror of openea/modules/load/kg.py: same attribute names, kg.py:10-141)."""
 
 
+def _ordered(s):
+    """list of a set in SORTED order.  The reference takes `list(set)` (kg.py:58,63,...), i.e. an arbitrary
+    order that changes with PYTHONHASHSEED for URI strings; data-parallel ranks (one process each) must
+    lay out identical batches and candidate lists, so the order is fixed here."""
+    return sorted(s)
+
+
 def parse_triples(triples):
     subjects, predicates, objects = set(), set(), set()
     for s, p, o in triples:
@@ -34,14 +41,14 @@ class KG:
     def set_relations(self, relation_triples):
         """kg.py:56-72."""
         self.relation_triples_set = set(relation_triples)
-        self.relation_triples_list = list(self.relation_triples_set)
+        self.relation_triples_list = _ordered(self.relation_triples_set)
         self.local_relation_triples_set = self.relation_triples_set
         self.local_relation_triples_list = self.relation_triples_list
         heads, relations, tails = parse_triples(self.relation_triples_set)
         self.entities_set = heads | tails
         self.relations_set = relations
-        self.entities_list = list(self.entities_set)
-        self.relations_list = list(self.relations_set)
+        self.entities_list = _ordered(self.entities_set)
+        self.relations_list = _ordered(self.relations_set)
         self.entities_num = len(self.entities_set)
         self.relations_num = len(self.relations_set)
         self.relation_triples_num = len(self.relation_triples_set)
@@ -52,15 +59,15 @@ class KG:
     def set_attributes(self, attribute_triples):
         """kg.py:74-93 (entities that only occur in attribute triples join the entity set)."""
         self.attribute_triples_set = set(attribute_triples)
-        self.attribute_triples_list = list(self.attribute_triples_set)
+        self.attribute_triples_list = _ordered(self.attribute_triples_set)
         self.local_attribute_triples_set = self.attribute_triples_set
         self.local_attribute_triples_list = self.attribute_triples_list
         entities, attributes, _ = parse_triples(self.attribute_triples_set)
         self.attributes_set = attributes
-        self.attributes_list = list(self.attributes_set)
+        self.attributes_list = _ordered(self.attributes_set)
         self.attributes_num = len(self.attributes_set)
         self.entities_set |= entities
-        self.entities_list = list(self.entities_set)
+        self.entities_list = _ordered(self.entities_set)
         self.entities_num = len(self.entities_set)
         self.attribute_triples_num = len(self.attribute_triples_set)
         self.local_attribute_triples_num = len(self.local_attribute_triples_set)
@@ -97,14 +104,14 @@ class KG:
     def add_sup_relation_triples(self, sup_triples):
         """kg.py:136-141 (seed-swapped triples join the training triples, not rt/hr_dict)."""
         self.sup_relation_triples_set = set(sup_triples)
-        self.sup_relation_triples_list = list(self.sup_relation_triples_set)
+        self.sup_relation_triples_list = _ordered(self.sup_relation_triples_set)
         self.relation_triples_set |= sup_triples
-        self.relation_triples_list = list(self.relation_triples_set)
+        self.relation_triples_list = _ordered(self.relation_triples_set)
         self.relation_triples_num = len(self.relation_triples_list)
 
     def add_sup_attribute_triples(self, sup_triples):
         self.sup_attribute_triples_set = set(sup_triples)
-        self.sup_attribute_triples_list = list(self.sup_attribute_triples_set)
+        self.sup_attribute_triples_list = _ordered(self.sup_attribute_triples_set)
         self.attribute_triples_set |= sup_triples
-        self.attribute_triples_list = list(self.attribute_triples_set)
+        self.attribute_triples_list = _ordered(self.attribute_triples_set)
         self.attribute_triples_num = len(self.attribute_triples_list)

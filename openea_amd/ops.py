@@ -237,6 +237,15 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     return rank, argmax
 
 
+def rank_rows(s, gold_idx):
+    """rank of column gold_idx[i] in row i of a device similarity block + row argmax -> (int32[n], int32[n])."""
+    n = s.shape[0]
+    rank = torch.empty(n, dtype=torch.int32, device=s.device)
+    argmax = torch.empty(n, dtype=torch.int32, device=s.device)
+    check(lib().oea_rank_rows(_p(s), n, s.shape[1], s.stride(0), _p(gold_idx), _p(rank), _p(argmax), _stream()))
+    return rank, argmax
+
+
 def rank_metrics(rank, top_k):
     """-> (hits counts list[int], rank_sum int, rr_sum float) with ONE device->host copy."""
     nk = len(top_k)

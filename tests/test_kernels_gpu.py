@@ -103,6 +103,20 @@ def test_rank_metrics(ops):
     assert abs(rr / len(rank) - mrr) < 1e-12
 
 
+def test_calculate_rank_block_matches_oracle(ops):
+    """calculate_rank (alignment.py:146-168) on an explicit row block with ties: oea_rank_rows."""
+    from oracle import np_oracle as orc
+    from openea_amd.modules.finding.alignment import calculate_rank
+    rng = np.random.RandomState(7)
+    sim_mat = np.round(rng.standard_normal((97, 1031)) * 4).astype(np.float32) / 4      # heavy ties
+    sim_mat[::2] *= np.float32(-0.0) + 1
+    idx = rng.randint(0, 1031, 97)
+    got = calculate_rank(idx, sim_mat, [1, 5, 10], True, 97)
+    ref = orc.calculate_rank(idx, sim_mat, [1, 5, 10], True, 97)
+    assert got[0] == ref[0] and abs(got[1] - ref[1]) < 1e-12
+    assert list(got[2]) == list(ref[2]) and got[3] == ref[3]
+
+
 # ---------------------------------------------------------------------------------------------
 # neighbour search
 # ---------------------------------------------------------------------------------------------
