@@ -25,6 +25,7 @@ import torch
 
 from .. import ops
 from ..models.basic_model import BasicModel
+from ..models.graph_ops import CsrOperand
 from ..modules.base.initializers import truncated_normal_host
 from ..modules.finding.evaluation import early_stop, test, valid
 from ..modules.load import read as rd
@@ -114,25 +115,21 @@ class GCN_Utils:
 
 
 class DeviceCSR:
-    """CSR + transposed CSR of a sparse matrix, fp32, on the device."""
+    """CSR + transposed CSR of a sparse matrix, fp32, on the device (models/graph_ops.py:CsrOperand: the
+    aggregates are row-sharded + all-gathered when the job runs under torch.distributed)."""
 
     def __init__(self, mat, dev):
         a = sp.csr_matrix(mat, dtype=np.float32)
-        a.sum_duplicates()
-        a.sort_indices()
-        at = sp.csr_matrix(a.T, dtype=np.float32)
-        at.sort_indices()
         self.shape = a.shape
         self.nnz = a.nnz
-        self.rowptr, self.colidx, self.vals = ops.to_ids(a.indptr, dev), ops.to_ids(a.indices, dev), ops.to_vec(a.data, dev)
-        self.t_rowptr, self.t_colidx, self.t_vals = ops.to_ids(at.indptr, dev), ops.to_ids(at.indices, dev), ops.to_vec(at.data, dev)
-        self.split, self.t_split = ops.csr_split(a.indptr, dev=dev), ops.csr_split(at.indptr, dev=dev)   # hub rows
+        self.fwd, self.bwd = CsrOperand(a, dev), CsrOperand(sp.csr_matrix(a.T, dtype=np.float32), dev)
+        self.rowptr = self.fwd.rowptr
 
     def mm(self, x, dim, act=0, mask_from=None):
-        return ops.spmm_csr(self.rowptr, self.colidx, self.vals, x, dim, act=act, mask_from=mask_from, split=self.split)
+        return self.fwd.apply(x, dim, act=act, mask_from=mask_from)
 
     def tmm(self, x, dim, mask_from=None):
-        return ops.spmm_csr(self.t_rowptr, self.t_colidx, self.t_vals, x, dim, mask_from=mask_from, split=self.t_split)
+        return self.bwd.apply(x, dim, mask_from=mask_from)
 
 
 class GCN_Align_Unit:

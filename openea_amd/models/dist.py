@@ -60,6 +60,40 @@ def allgather_rows(local, n_total, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).to(local.device)
 
 
+def balanced_bounds(indptr, world_size):
+    """row-block boundaries [b_0=0, ..., b_W=n] of a CSR matrix with (almost) equal NONZEROS per block:
+    ids are frequency-ordered (read.py:64-79), so equal row counts would put every hub on rank 0."""
+    indptr = np.asarray(indptr, np.int64)
+    n, nnz = len(indptr) - 1, int(indptr[-1])
+    b = [0]
+    for r in range(1, world_size):
+        # first row whose prefix reaches r/W of the nonzeros (+ rows, so that empty rows spread too)
+        target = (nnz + n) * r / world_size
+        w = indptr[: n + 1] + np.arange(n + 1)
+        b.append(int(min(max(np.searchsorted(w, target), b[-1]), n)))
+    b.append(n)
+    return b
+
+
+def allgather_blocks(full, bounds, group=None):
+    """`full` [n, ...]: rank r has written rows [bounds[r], bounds[r+1]); afterwards every rank has every
+    block (in place; blocks padded to the largest so that ONE all_gather moves everything)."""
+    rank, ws = world(group)
+    if ws == 1:
+        return full
+    sizes = [bounds[r + 1] - bounds[r] for r in range(ws)]
+    m = max(sizes)
+    stage = full.is_cuda and dist.get_backend(group) == "gloo"
+    pad = torch.zeros((m,) + tuple(full.shape[1:]), dtype=full.dtype, device="cpu" if stage else full.device)
+    pad[: sizes[rank]] = full[bounds[rank]: bounds[rank + 1]]
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad, group=group)
+    for r in range(ws):
+        if r != rank and sizes[r]:
+            full[bounds[r]: bounds[r + 1]] = parts[r][: sizes[r]].to(full.device)
+    return full
+
+
 def allreduce_sum_(t, group=None):
     _, ws = world(group)
     if ws > 1:

@@ -25,6 +25,38 @@ def split_ranges(ptr, max_len, drop_empty=False):
     return piece_ptr, owner.astype(np.int64), owner_ptr
 
 
+class CsrOperand:
+    """One sparse matrix as a device CSR operand of the aggregate  y = act(A . x).
+    Under torch.distributed (world > 1) the aggregate is ROW-SHARDED: every rank computes the block of
+    output rows it owns (blocks balanced by nonzeros) from the full, replicated x and the blocks are
+    all-gathered -- one exchange per layer; the transposed operand does the same for the
+    backward, so no reduce-scatter is needed."""
+
+    def __init__(self, a, dev):
+        from . import dist as mdist
+        a = sp.csr_matrix(a, dtype=np.float32)
+        a.sum_duplicates()
+        a.sort_indices()
+        self.shape, self.nnz = a.shape, a.nnz
+        self.indptr_host = a.indptr
+        self.rowptr, self.colidx, self.vals = ops.to_ids(a.indptr, dev), ops.to_ids(a.indices, dev), ops.to_vec(a.data, dev)
+        self.rank, self.world = mdist.world()
+        self.bounds = mdist.balanced_bounds(a.indptr, self.world)
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.split = ops.csr_split(a.indptr, dev=dev, row_range=(self.lo, self.hi) if self.world > 1 else None)
+
+    def apply(self, x, dim, act=0, mask_from=None):
+        if self.world == 1:
+            return ops.spmm_csr(self.rowptr, self.colidx, self.vals, x, dim, act=act, mask_from=mask_from, split=self.split)
+        from . import dist as mdist
+        lo, hi = self.lo, self.hi
+        out = torch.empty((self.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        if hi > lo:
+            ops.spmm_csr(self.rowptr[lo: hi + 1], self.colidx, self.vals, x, dim, act=act,
+                         mask_from=None if mask_from is None else mask_from[lo:hi], out=out[lo:hi], split=self.split)
+        return mdist.allgather_blocks(out, self.bounds)
+
+
 class EdgeGraph:
     """A sparse [n_rows, n_cols] operator given as an ordered edge list (rows, cols, vals), kept in
     the order the reference would feed it to TF, plus the derived device structures:
@@ -50,9 +82,7 @@ class EdgeGraph:
         a.sort_indices()
         at = sp.csr_matrix(a.T)
         at.sort_indices()
-        self.rowptr, self.colidx, self.vals = ops.to_ids(a.indptr, dev), ops.to_ids(a.indices, dev), ops.to_vec(a.data, dev)
-        self.t_rowptr, self.t_colidx, self.t_vals = ops.to_ids(at.indptr, dev), ops.to_ids(at.indices, dev), ops.to_vec(at.data, dev)
-        self.split, self.t_split = ops.csr_split(a.indptr, dev=dev), ops.csr_split(at.indptr, dev=dev)   # hub rows
+        self.fwd, self.bwd = CsrOperand(a, dev), CsrOperand(at, dev)      # A and A^T (row-sharded under torch.distributed)
         # ---- attention structures over the ordered edge list ------------------------------------
         if grouping == 'row':
             order = np.lexsort((cols, rows))                       # canonical row-major order
@@ -90,13 +120,13 @@ class SpmmFn(torch.autograd.Function):
     def forward(ctx, x, graph):
         ctx.graph = graph
         x = x.contiguous()
-        return ops.spmm_csr(graph.rowptr, graph.colidx, graph.vals, x, x.shape[1], split=graph.split)
+        return graph.fwd.apply(x, x.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
         g = ctx.graph
         dy = dy.contiguous()
-        return ops.spmm_csr(g.t_rowptr, g.t_colidx, g.t_vals, dy, dy.shape[1], split=g.t_split), None
+        return g.bwd.apply(dy, dy.shape[1]), None
 
 
 class SparseAttnFn(torch.autograd.Function):

