@@ -60,13 +60,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if os.environ.get("OEA_BENCH_ONE_GPU"):       # test hook: all ranks share GPU 0 (with OEA_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     ops.lib()
     dev = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("OEA_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     # ---- data + model state (identical on every rank: same seeds) ---------------------------------
@@ -130,7 +136,7 @@ def main():
     n_pos_total, n_scored = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    (fwd_ms, apply_ms), n_calls = ops.profile_end(3)
+    (fwd_ms, _gap_ms, apply_ms), n_calls = ops.profile_end(4)
     epoch_loss = trainer.pop_loss()
     epochs.check()
 

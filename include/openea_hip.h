@@ -42,9 +42,11 @@ const char *oea_last_error(void);
 int oea_device_count(void);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
- * roofline figure; no reference counterpart).  Between begin and end, every oea_triple_step
- * records 3 marks: [fwd_bwd kernel][apply kernel].  oea_profile_end(3, ms, &n) returns
- * ms[0] = total fwd_bwd time, ms[1] = total apply time (milliseconds) over n calls.
+ * roofline figure; no reference counterpart).  Between begin and end, every optimiser step
+ * records 4 marks: [m0 fwd_bwd kernel m1] [m2 apply kernel m3] (a GRAD-phase call the first pair,
+ * the APPLY-phase call the second).  oea_profile_end(4, ms, &n) returns ms[0] = total fwd_bwd
+ * time, ms[1] = time between the two kernels (the exchange under data parallelism), ms[2] = total
+ * apply time (milliseconds) over n steps.
  * stride: only every stride-th step records its marks (an event record costs a few microseconds of
  * enqueue time, comparable to the kernels themselves at the 15K shape). */
 int oea_profile_begin(int32_t stride);

@@ -473,19 +473,23 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     const bool grouped = cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN;
     const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
-    oea::prof_call();
-    oea::prof_mark(st);
+    // profiling marks, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3]; a GRAD call records the first pair and
+    // decides whether the step is sampled, the APPLY call that follows records the second pair
     if (phase != OEA_PHASE_APPLY) {
+        oea::prof_call();
+        oea::prof_mark(st);
         if (grouped)
             triple_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, cfg.neg_group_k, cfg, ws);
         else
             triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+        oea::prof_mark(st);
     }
-    oea::prof_mark(st);
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
-    if (phase != OEA_PHASE_GRAD)
+    if (phase != OEA_PHASE_GRAD) {
+        oea::prof_mark(st);
         apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum);
-    oea::prof_mark(st);
+        oea::prof_mark(st);
+    }
     return 0;
 }
 

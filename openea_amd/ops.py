@@ -130,7 +130,7 @@ def profile_begin(stride=1):
     check(lib().oea_profile_begin(int(stride)))
 
 
-def profile_end(group=3):
+def profile_end(group=4):
     ms = (C.c_double * (group - 1))()
     n = C.c_int32(0)
     check(lib().oea_profile_end(group, ms, C.byref(n)))
