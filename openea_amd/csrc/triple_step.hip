@@ -248,8 +248,11 @@ __device__ __forceinline__ double score_independent(const float *__restrict__ en
 // its negatives' 3k, fetched by the lanes of the group in one coalesced load each and handed round
 // with cross-lane reads; (2) every row the group needs, 3 + k gathers issued back to back.  The
 // arithmetic after that is branch-free per negative so the k reduction chains interleave.
+// Occupancy: a batch of 5,000 positives is 2,500 waves; at 2 waves/SIMD the chip holds 2,048, and the 452
+// late-comers doubled the kernel's critical path (25.9 us).  Capping the registers at 3 waves/SIMD (a few
+// spilled dwords for IT >= 2) lets every wave start at once: 19.4 us.
 template <int G, int IT>
-__global__ __launch_bounds__(256) void triple_grouped(
+__global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
     int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
     constexpr int KC = IT <= 4 ? 10 : (IT <= 8 ? 4 : 2);      // negatives in flight: KC * IT row registers
@@ -272,18 +275,21 @@ __global__ __launch_bounds__(256) void triple_grouped(
         bool any = false;
         for (int base = 0; base < k; base += KC) {
             if (base > 0) nid = lane < 3 * min(KC, k - base) ? ng[3 * base + lane] : 0;
-            int ch[KC], cr[KC], ct[KC];
-            bool valid[KC], tail[KC], ok[KC];
+            int ce[KC];                                                // the corrupted entity of slot j
+            unsigned tailm = 0, okm = 0, slow = 0;                     // per-slot flags as bit masks (registers are tight)
             Row<G, IT> yc[KC];
             // ---- round trip 2: the corrupted rows (and, first time round, the positive's) ----------------
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                ch[j] = __shfl(nid, 3 * j, G); cr[j] = __shfl(nid, 3 * j + 1, G); ct[j] = __shfl(nid, 3 * j + 2, G);
-                valid[j] = base + j < k;
-                tail[j] = ch[j] == h;                                  // tail corrupted (or neg == pos): uses yh, yr
-                ok[j] = valid[j] && cr[j] == r && (tail[j] || ct[j] == t);
-                const int e = valid[j] ? (tail[j] ? ct[j] : ch[j]) : h;
-                load_row<G, IT>(ent + (int64_t)e * ld, ld, lane, yc[j]);
+                const int ch = __shfl(nid, 3 * j, G), cr = __shfl(nid, 3 * j + 1, G), ct = __shfl(nid, 3 * j + 2, G);
+                const bool valid = base + j < k;
+                const bool tl = ch == h;                               // tail corrupted (or neg == pos): uses yh, yr
+                const bool ok = valid && cr == r && (tl || ct == t);
+                tailm |= tl ? 1u << j : 0u;
+                okm |= ok ? 1u << j : 0u;
+                slow |= (valid && !ok) ? 1u << j : 0u;                 // entries that are not corruptions of this positive
+                ce[j] = valid ? (tl ? ct : ch) : h;
+                load_row<G, IT>(ent + (int64_t)ce[j] * ld, ld, lane, yc[j]);
             }
             if (base == 0) {
                 normalize<G, IT>(yh, cfg.ent_l2_norm);
@@ -298,9 +304,6 @@ __global__ __launch_bounds__(256) void triple_grouped(
                 for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
                 any = coef != 0.f;
             }
-            unsigned slow = 0;                                         // entries that are not corruptions of this positive
-#pragma unroll
-            for (int j = 0; j < KC; ++j) slow |= (valid[j] && !ok[j]) ? 1u << j : 0u;
             if (slow) {                                                // rare: one copy of the code, ids re-read across lanes
 #pragma unroll 1
                 for (int j = 0; j < KC; ++j)
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(256) void triple_grouped(
                 float s = 0.f;
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
-                    const float a = tail[j] ? yh.v[it] : yc[j].v[it], b = tail[j] ? yc[j].v[it] : yt.v[it];
+                    const bool tl = (tailm >> j) & 1u;
+                    const float a = tl ? yh.v[it] : yc[j].v[it], b = tl ? yc[j].v[it] : yt.v[it];
                     const float d = a + yr.v[it] - b;
                     yc[j].v[it] = d;                                    // the row is not needed again: keep delta in place
                     s += cfg.l1 ? fabsf(d) : d * d;
@@ -324,24 +328,23 @@ __global__ __launch_bounds__(256) void triple_grouped(
             }
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                if (!ok[j]) continue;
+                if (!((okm >> j) & 1u)) continue;
+                const bool tl = (tailm >> j) & 1u;
                 float coef, l;
                 triple_coef(cfg, false, sc[j], coef, l);
                 lsum += (double)l;
                 if (coef != 0.f) {
                     any = true;
                     dscore<G, IT>(yc[j], coef, cfg.l1, g);
-                    if (tail[j]) {
+                    if (tl) {
 #pragma unroll
                         for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
-                        atomic_row<G, IT>(ws.ent_grad + (int64_t)ct[j] * ld, ld, lane, g, -1.f);
-                        if (lane == 0) ws.ent_touched[ct[j]] = 1.f;
                     } else {
 #pragma unroll
                         for (int it = 0; it < IT; ++it) { gr.v[it] += g.v[it]; gt.v[it] -= g.v[it]; }
-                        atomic_row<G, IT>(ws.ent_grad + (int64_t)ch[j] * ld, ld, lane, g, 1.f);
-                        if (lane == 0) ws.ent_touched[ch[j]] = 1.f;
                     }
+                    atomic_row<G, IT>(ws.ent_grad + (int64_t)ce[j] * ld, ld, lane, g, tl ? -1.f : 1.f);
+                    if (lane == 0) ws.ent_touched[ce[j]] = 1.f;
                 }
             }
         }
