@@ -98,8 +98,11 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
     constexpr int NG = 256 / G;
     extern __shared__ __attribute__((aligned(16))) float s_part[];      // [NG][ldy] partial rows
     const int lane = threadIdx.x % G, gid = threadIdx.x / G;
-    for (int64_t row0 = (int64_t)blockIdx.x * NG; row0 < n_rows; row0 += (int64_t)gridDim.x * NG) {
-        const int64_t row = row0 + gid;
+    // rows are dealt out CYCLICALLY: group gid of block b takes rows b + gridDim.x * (gid + NG * i).  Ids are
+    // frequency-ordered, so consecutive rows would hand all hubs to the first few workgroups.
+    const int64_t nb = gridDim.x;
+    for (int64_t base = 0; base < n_rows; base += nb * NG) {
+        const int64_t row = base + (int64_t)gid * nb + blockIdx.x;
         int e0 = 0, e1 = 0;
         if (row < n_rows) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
         if (row < n_rows && e1 - e0 <= kLongRow) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
         }
         // long rows of this batch: workgroup-cooperative (block-uniform control flow)
         for (int r = 0; r < NG; ++r) {
-            const int64_t lrow = row0 + r;
+            const int64_t lrow = base + (int64_t)r * nb + blockIdx.x;
             if (lrow >= n_rows) break;
             const int l0 = rowptr[lrow], l1 = rowptr[lrow + 1];
             if (l1 - l0 <= kLongRow || l1 - l0 > huge) continue;     // huge rows: split across workgroups below
@@ -211,7 +214,10 @@ __global__ __launch_bounds__(256) void spmm_rows_epilogue_kernel(const int32_t *
 
 __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-// One G-lane group per seed link a: A = |x_l - x_r|_1, then the 2*k negatives of that link.
+// One WORKGROUP per seed link a: every G-lane group computes A = |x_l - x_r|_1 (the two rows are shared
+// through L1/L2) and takes the negatives b = group, group + NG, ... of the link's 2k (k is 5 for GCN-Align,
+// 125 for RDGCN: a serial loop over them was the whole kernel); the hinge-active count is combined through
+// LDS and group 0 adds the positive pair's gradient once.
 template <int G, int IT>
 __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restrict__ emb, int dim, int ld,
                                                             const int32_t *__restrict__ ill, int64_t t, int k, float gamma,
@@ -220,12 +226,15 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                                                             const int32_t *__restrict__ neg2_left,
                                                             const int32_t *__restrict__ neg2_right,
                                                             float *__restrict__ grad, double *__restrict__ loss_accum) {
-    const int lane = threadIdx.x % G;
-    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    constexpr int NG = 256 / G;
+    __shared__ int s_active;
+    __shared__ double s_loss[4];
+    const int lane = threadIdx.x % G, gid = threadIdx.x / G;
     const float scale = 1.0f / (2.0f * (float)k * (float)t);
     double loss_local = 0.0;
-    for (int64_t a = grp; a < t; a += ngrp) {
+    for (int64_t a = blockIdx.x; a < t; a += gridDim.x) {
+        if (threadIdx.x == 0) s_active = 0;
+        __syncthreads();
         const int l = ill[2 * a], r = ill[2 * a + 1];
         float4 dp[IT];
         float A = 0.f;
@@ -242,46 +251,48 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
         A = group_sum<G>(A);
         const float D = A + gamma;
         int active = 0;
-        for (int side = 0; side < 2; ++side) {
+        for (int i = gid; i < 2 * k; i += NG) {
+            const int side = i >= k, b = side ? i - k : i;
             const int32_t *nlp = side ? neg2_left : neg_left, *nrp = side ? neg2_right : neg_right;
-            for (int b = 0; b < k; ++b) {
-                const int nl = nlp[a * k + b], nr = nrp[a * k + b];
-                float4 dn[IT];
-                float B = 0.f;
+            const int nl = nlp[a * k + b], nr = nrp[a * k + b];
+            float4 dn[IT];
+            float B = 0.f;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = (it * G + lane) * 4;
+                dn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < ld) {
+                    const float4 xl = oea::ld4(emb + (int64_t)nl * ld + c), xr = oea::ld4(emb + (int64_t)nr * ld + c);
+                    dn[it] = make_float4(xl.x - xr.x, xl.y - xr.y, xl.z - xr.z, xl.w - xr.w);
+                    B += fabsf(dn[it].x) + fabsf(dn[it].y) + fabsf(dn[it].z) + fabsf(dn[it].w);
+                }
+            }
+            B = group_sum<G>(B);
+            const float L = D - B;
+            if (L > 0.f) {
+                ++active;
+                if (lane == 0) loss_local += (double)L;
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
                     const int c = (it * G + lane) * 4;
-                    dn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (c < ld) {
-                        const float4 xl = oea::ld4(emb + (int64_t)nl * ld + c), xr = oea::ld4(emb + (int64_t)nr * ld + c);
-                        dn[it] = make_float4(xl.x - xr.x, xl.y - xr.y, xl.z - xr.z, xl.w - xr.w);
-                        B += fabsf(dn[it].x) + fabsf(dn[it].y) + fabsf(dn[it].z) + fabsf(dn[it].w);
-                    }
-                }
-                B = group_sum<G>(B);
-                const float L = D - B;
-                if (L > 0.f) {
-                    ++active;
-                    if (lane == 0) loss_local += (double)L;
+                        const float g[4] = {-scale * sgnf(dn[it].x), -scale * sgnf(dn[it].y), -scale * sgnf(dn[it].z),
+                                            -scale * sgnf(dn[it].w)};
 #pragma unroll
-                    for (int it = 0; it < IT; ++it) {
-                        const int c = (it * G + lane) * 4;
-                        if (c < ld) {
-                            const float g[4] = {-scale * sgnf(dn[it].x), -scale * sgnf(dn[it].y), -scale * sgnf(dn[it].z),
-                                                -scale * sgnf(dn[it].w)};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (g[q] != 0.f) {
-                                    oea::atomic_add_f32(grad + (int64_t)nl * ld + c + q, g[q]);
-                                    oea::atomic_add_f32(grad + (int64_t)nr * ld + c + q, -g[q]);
-                                }
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            if (g[q] != 0.f) {
+                                oea::atomic_add_f32(grad + (int64_t)nl * ld + c + q, g[q]);
+                                oea::atomic_add_f32(grad + (int64_t)nr * ld + c + q, -g[q]);
+                            }
                     }
                 }
             }
         }
-        if (active) {
-            const float ca = scale * (float)active;
+        if (lane == 0 && active) atomicAdd(&s_active, active);
+        __syncthreads();
+        const int total = s_active;
+        if (gid == 0 && total) {
+            const float ca = scale * (float)total;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = (it * G + lane) * 4;
@@ -296,9 +307,15 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                 }
             }
         }
+        __syncthreads();
     }
     const double w = oea::wave_sum_d(loss_local);
-    if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(loss_accum, w * (double)scale);
+    if ((threadIdx.x & 63) == 0) s_loss[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        if (tot != 0.0) atomicAdd(loss_accum, tot * (double)scale);
+    }
 }
 
 template <int G, int IT>
@@ -394,7 +411,7 @@ int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, 
     if (t == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
 #define CALL(G, IT)                                                                                             \
-    align_loss_l1_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(t, 256 / G), 65535), 256, 0, st>>>(   \
+    align_loss_l1_kernel<G, IT><<<(unsigned)std::min<int64_t>(t, 65535), 256, 0, st>>>(                           \
         out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum)
     OEA_DISPATCH_LD(ld, CALL);
 #undef CALL

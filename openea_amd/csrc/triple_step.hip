@@ -386,14 +386,18 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
         const bool is_rel = row_all < n_rel;            // relation rows first: their 16-copy sums overlap the entity rows
         const int64_t row = is_rel ? row_all : row_all - n_rel;
         float *touched = is_rel ? ws.rel_touched : ws.ent_touched;
-        if (touched[row] == 0.f) continue;
         float *v = (is_rel ? rel : ent) + row * ld;
         float *acc = (is_rel ? rel_acc : ent_acc) + row * ld;
         float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
         const int on = is_rel ? cfg.rel_l2_norm : cfg.ent_l2_norm;
-        Row<G, IT> rv, rg;
+        // the row, its gradient and its accumulator are fetched together with the flag (most rows of a
+        // batch are touched): one dependent round trip instead of two
+        const float flag = touched[row];
+        Row<G, IT> rv, rg, ra;
         load_row<G, IT>(v, ld, lane, rv);
         load_row<G, IT>(g, ld, lane, rg);
+        if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
+        if (flag == 0.f) continue;
         if (is_rel) {                                 // sum (fixed order) and clear the other copies
             constexpr int CB = IT <= 4 ? 5 : 1;       // copies fetched together (all loads issued before use)
             for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             if (c < ld) {
                 const float gv = on ? (rg.v[it] - rv.v[it] * inv * ydg) * inv : rg.v[it];
                 if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
-                    const float a = acc[c] + gv * gv;
+                    const float a = ra.v[it] + gv * gv;
                     acc[c] = a;
                     v[c] = rv.v[it] - cfg.lr * gv / sqrtf(a);
                 } else {
