@@ -218,6 +218,9 @@ __device__ __forceinline__ float sgnf(float x) { return x > 0.f ? 1.f : (x < 0.f
 // through L1/L2) and takes the negatives b = group, group + NG, ... of the link's 2k (k is 5 for GCN-Align,
 // 125 for RDGCN: a serial loop over them was the whole kernel); the hinge-active count is combined through
 // LDS and group 0 adds the positive pair's gradient once.
+// Rows are held LANE-STRIDED here (lane owns columns lane, lane + G, ...): every load and every fp32 atomic of a
+// wave instruction covers one contiguous 128-byte segment per row (a float4-per-lane layout spreads each atomic
+// instruction over four lines and was 2x slower; the kernel is bound by the atomic rate).
 template <int G, int IT>
 __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restrict__ emb, int dim, int ld,
                                                             const int32_t *__restrict__ ill, int64_t t, int k, float gamma,
@@ -236,17 +239,13 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
         if (threadIdx.x == 0) s_active = 0;
         __syncthreads();
         const int l = ill[2 * a], r = ill[2 * a + 1];
-        float4 dp[IT];
+        float dp[IT];
         float A = 0.f;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int c = (it * G + lane) * 4;
-            dp[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < ld) {
-                const float4 xl = oea::ld4(emb + (int64_t)l * ld + c), xr = oea::ld4(emb + (int64_t)r * ld + c);
-                dp[it] = make_float4(xl.x - xr.x, xl.y - xr.y, xl.z - xr.z, xl.w - xr.w);
-                A += fabsf(dp[it].x) + fabsf(dp[it].y) + fabsf(dp[it].z) + fabsf(dp[it].w);
-            }
+            const int c = it * G + lane;
+            dp[it] = c < ld ? emb[(int64_t)l * ld + c] - emb[(int64_t)r * ld + c] : 0.f;
+            A += fabsf(dp[it]);
         }
         A = group_sum<G>(A);
         const float D = A + gamma;
@@ -255,17 +254,13 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
             const int side = i >= k, b = side ? i - k : i;
             const int32_t *nlp = side ? neg2_left : neg_left, *nrp = side ? neg2_right : neg_right;
             const int nl = nlp[a * k + b], nr = nrp[a * k + b];
-            float4 dn[IT];
+            float dn[IT];
             float B = 0.f;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int c = (it * G + lane) * 4;
-                dn[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < ld) {
-                    const float4 xl = oea::ld4(emb + (int64_t)nl * ld + c), xr = oea::ld4(emb + (int64_t)nr * ld + c);
-                    dn[it] = make_float4(xl.x - xr.x, xl.y - xr.y, xl.z - xr.z, xl.w - xr.w);
-                    B += fabsf(dn[it].x) + fabsf(dn[it].y) + fabsf(dn[it].z) + fabsf(dn[it].w);
-                }
+                const int c = it * G + lane;
+                dn[it] = c < ld ? emb[(int64_t)nl * ld + c] - emb[(int64_t)nr * ld + c] : 0.f;
+                B += fabsf(dn[it]);
             }
             B = group_sum<G>(B);
             const float L = D - B;
@@ -274,16 +269,11 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                 if (lane == 0) loss_local += (double)L;
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
-                    const int c = (it * G + lane) * 4;
-                    if (c < ld) {
-                        const float g[4] = {-scale * sgnf(dn[it].x), -scale * sgnf(dn[it].y), -scale * sgnf(dn[it].z),
-                                            -scale * sgnf(dn[it].w)};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (g[q] != 0.f) {
-                                oea::atomic_add_f32(grad + (int64_t)nl * ld + c + q, g[q]);
-                                oea::atomic_add_f32(grad + (int64_t)nr * ld + c + q, -g[q]);
-                            }
+                    const int c = it * G + lane;
+                    const float g = -scale * sgnf(dn[it]);
+                    if (c < ld && g != 0.f) {
+                        oea::atomic_add_f32(grad + (int64_t)nl * ld + c, g);
+                        oea::atomic_add_f32(grad + (int64_t)nr * ld + c, -g);
                     }
                 }
             }
@@ -295,15 +285,11 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
             const float ca = scale * (float)total;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int c = (it * G + lane) * 4;
-                if (c < ld) {
-                    const float g[4] = {ca * sgnf(dp[it].x), ca * sgnf(dp[it].y), ca * sgnf(dp[it].z), ca * sgnf(dp[it].w)};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (g[q] != 0.f) {
-                            oea::atomic_add_f32(grad + (int64_t)l * ld + c + q, g[q]);
-                            oea::atomic_add_f32(grad + (int64_t)r * ld + c + q, -g[q]);
-                        }
+                const int c = it * G + lane;
+                const float g = ca * sgnf(dp[it]);
+                if (c < ld && g != 0.f) {
+                    oea::atomic_add_f32(grad + (int64_t)l * ld + c, g);
+                    oea::atomic_add_f32(grad + (int64_t)r * ld + c, -g);
                 }
             }
         }
@@ -413,7 +399,14 @@ int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, 
 #define CALL(G, IT)                                                                                             \
     align_loss_l1_kernel<G, IT><<<(unsigned)std::min<int64_t>(t, 65535), 256, 0, st>>>(                           \
         out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum)
-    OEA_DISPATCH_LD(ld, CALL);
+    if (ld <= 32) CALL(32, 1);          // lane-strided rows: G * IT >= ld
+    else if (ld <= 64) CALL(32, 2);
+    else if (ld <= 96) CALL(32, 3);
+    else if (ld <= 128) CALL(32, 4);
+    else if (ld <= 256) CALL(64, 4);
+    else if (ld <= 512) CALL(64, 8);
+    else if (ld <= 1280) CALL(64, 20);
+    else { oea::set_error("ld %d > 1280 unsupported", (int)ld); return OEA_EUNSUPPORTED; }
 #undef CALL
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;

@@ -42,7 +42,7 @@ def main():
         t2 = ops.to_table(e1 + 0.4 * unit(rng, n, d))
         timed("eval inner   %6d^2 x %d" % (n, d), lambda: greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, 0), reps=1)
         return
-    for n, d in ((10500, 100), (70000, 100), (10500, 300)):
+    for n, d in (() if only == "gnn" else ((10500, 100), (70000, 100), (10500, 300))):
         e1 = unit(rng, n, d)
         t1 = ops.to_table(e1)
         t2 = ops.to_table(e1 + 0.4 * unit(rng, n, d))
@@ -51,7 +51,7 @@ def main():
         if n <= 10500:
             timed("eval csls10  %6d^2 x %d" % (n, d), lambda: greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, 10))
             timed("eval manhattan %6d^2 x %d" % (n, d), lambda: greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "manhattan", False, 0), reps=2)
-    for n, d, k in ((15000, 100, 1499), (100000, 100, 2000)):
+    for n, d, k in (() if only == "gnn" else ((15000, 100, 1499), (100000, 100, 2000))):
         t = ops.to_table(unit(rng, n, d))
         dt = timed("neighbours   %6d x %d, k=%d" % (n, d, k), lambda: ops.topk_inner(t, t, d, k), reps=2)
         print("   -> %.0f query rows/s" % (n / dt))
