@@ -2,10 +2,14 @@
 
 SURVEY 8(f) rank 1 -- downstream of the kNN / similarity kernels.  Candidate selection
 (threshold filter ∩ per-row top-k, alignment_finder.py:28-76) runs on the device through the
-same top-k kernel as the neighbour search; the maximum-weight matching of the reference uses
-graph_tool / igraph (alignment_finder.py:83-140), neither of which is available here, and is
-replaced by a deterministic greedy weight-descending matching on the host (documented in
-DESIGN.md as the one behavioural substitution on this row).
+same top-k kernel as the neighbour search.  The matching step of the reference calls graph_tool
+(`max_cardinality_matching(heuristic=True, weight=..., minimize=False)`: a linear-time HEURISTIC
+maximal matching, alignment_finder.py:83-112) or igraph (exact maximum-weight bipartite matching,
+alignment_finder.py:115-140); neither library is available here:
+  * heuristic=True  -> deterministic greedy weight-descending maximal matching (the classic
+    1/2-approximation; graph_tool's heuristic is itself unspecified / randomised),
+  * heuristic=False -> EXACT maximum-weight bipartite matching through scipy's sparse assignment
+    solver (same optimum as igraph's, ties aside).
 """
 import time
 
@@ -72,6 +76,28 @@ def greedy_weight_matching(pairs, weights):
     return out
 
 
+def max_weight_matching(pairs, weights):
+    """exact maximum-weight bipartite matching of the candidate edges (mwgm_igraph, alignment_finder.py:115-140):
+    every left node gets a private dummy partner so that a FULL matching of the left side always exists, and
+    with cost C - w on real edges / C on dummy edges the minimum-cost full matching maximises the real weight."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import min_weight_full_bipartite_matching
+    pairs = list(pairs)
+    w = np.asarray(weights, np.float64)
+    lefts = sorted({p[0] for p in pairs})
+    rights = sorted({p[1] for p in pairs})
+    li = {x: i for i, x in enumerate(lefts)}
+    ri = {y: j for j, y in enumerate(rights)}
+    nl, nr = len(lefts), len(rights)
+    big = float(max(w.max(), 0.0)) + 1.0
+    keep = w > 0                                            # a non-positive edge never improves the total
+    rows = np.concatenate([[li[p[0]] for p, kp in zip(pairs, keep) if kp], np.arange(nl)]).astype(np.int64)
+    cols = np.concatenate([[ri[p[1]] for p, kp in zip(pairs, keep) if kp], nr + np.arange(nl)]).astype(np.int64)
+    cost = np.concatenate([big - w[keep], np.full(nl, big)])
+    r, c = min_weight_full_bipartite_matching(sp.csr_matrix((cost, (rows, cols)), shape=(nl, nr + nl)))
+    return {(lefts[i], rights[j]) for i, j in zip(r, c) if j < nr}
+
+
 def find_potential_alignment_mwgm(sim, sim_th, k, heuristic=True):
     """alignment_finder.py:12-25."""
     t = time.time()
@@ -80,7 +106,7 @@ def find_potential_alignment_mwgm(sim, sim_th, k, heuristic=True):
         return None
     check_new_alignment(pairs, context="after filtering by sim and nearest k")
     t1 = time.time()
-    selected = greedy_weight_matching(pairs, w)
+    selected = greedy_weight_matching(pairs, w) if heuristic else max_weight_matching(pairs, w)
     check_new_alignment(selected, context="after mwgm")
     print("mwgm costs time: {:.3f} s".format(time.time() - t1))
     print("selecting potential alignment costs time: {:.3f} s".format(time.time() - t))

@@ -132,3 +132,32 @@ def test_save_formats(tmp_path):
     assert line[0] in kgs.kg1.entities_id_dict and len(line) == 5
     rd.save_results(str(tmp_path) + "/", [(1, 2), (3, 4)])
     assert rd.read_pair_ids(str(tmp_path) + "/alignment_results_12") == [(1, 2), (3, 4)]
+
+
+def test_bootstrapping_matchings():
+    """alignment_finder.py:83-140 stand-ins: the exact matcher reaches the brute-force optimum, the greedy one is a
+    maximal one-to-one matching with at least half of it."""
+    import itertools
+    from openea_amd.modules.bootstrapping.alignment_finder import greedy_weight_matching, max_weight_matching
+    rng = np.random.RandomState(0)
+    for trial in range(20):
+        nl, nr = rng.randint(2, 7), rng.randint(2, 7)
+        pairs = [(i, j) for i in range(nl) for j in range(nr) if rng.rand() < 0.6]
+        if not pairs:
+            continue
+        w = rng.rand(len(pairs)) + 0.05
+        wd = dict(zip(pairs, w))
+        best = 0.0
+        for m in range(1, min(nl, nr) + 1):
+            for sub in itertools.combinations(pairs, m):
+                if len({p[0] for p in sub}) == m and len({p[1] for p in sub}) == m:
+                    best = max(best, sum(wd[p] for p in sub))
+        exact = max_weight_matching(pairs, w)
+        assert len({p[0] for p in exact}) == len(exact) == len({p[1] for p in exact})
+        assert abs(sum(wd[p] for p in exact) - best) < 1e-9
+        greedy = greedy_weight_matching(pairs, w)
+        assert len({p[0] for p in greedy}) == len(greedy) == len({p[1] for p in greedy})
+        assert sum(wd[p] for p in greedy) >= 0.5 * best - 1e-12
+        free_l = set(range(nl)) - {p[0] for p in greedy}
+        free_r = set(range(nr)) - {p[1] for p in greedy}
+        assert not any(p[0] in free_l and p[1] in free_r for p in pairs)       # maximal
