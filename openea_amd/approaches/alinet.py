@@ -119,6 +119,73 @@ def enhance_triples(kg1, kg2, ents1, ents2):
     return e1, e2
 
 
+def check_new_alignment(aligned_pairs, context="check alignment"):
+    if aligned_pairs is None or len(aligned_pairs) == 0:
+        print("{}, empty aligned pairs".format(context))
+        return
+    num = sum(1 for x, y in aligned_pairs if x == y)
+    print("{}, right alignment: {}/{}={:.3f}".format(context, num, len(aligned_pairs), num / len(aligned_pairs)))
+
+
+def update_labeled_alignment_x(pre_labeled_alignment, curr_labeled_alignment, sim_mat):
+    """alinet.py:351-373: per left entity keep the partner with the larger similarity (sim_mat[i, j] lookups)."""
+    check_new_alignment(pre_labeled_alignment, context="before editing (<-)")
+    labeled = dict(pre_labeled_alignment)
+    n1 = n2 = 0
+    for i, j in curr_labeled_alignment:
+        if labeled.get(i, -1) == i and j != i:
+            n2 += 1
+        if i in labeled:
+            pre_j = labeled[i]
+            if pre_j == j:
+                continue
+            if sim_mat[i, j] >= sim_mat[i, pre_j]:
+                if pre_j == i and j != i:
+                    n1 += 1
+                labeled[i] = j
+        else:
+            labeled[i] = j
+    print("update wrongly: ", n1, "greedy update wrongly: ", n2)
+    out = set(labeled.items())
+    check_new_alignment(out, context="after editing (<-)")
+    return out
+
+
+def update_labeled_alignment_y(labeled_alignment, sim_mat):
+    """alinet.py:376-396: per right entity keep the left partner with the largest similarity."""
+    by_j = {}
+    for i, j in labeled_alignment:
+        by_j.setdefault(j, set()).add(i)
+    out = set()
+    for j, i_set in by_j.items():
+        if len(i_set) == 1:
+            out.add((next(iter(i_set)), j))
+        else:
+            max_i, max_sim = -1, -10
+            for i in i_set:
+                if sim_mat[i, j] > max_sim:
+                    max_sim, max_i = sim_mat[i, j], i
+            out.add((max_i, j))
+    check_new_alignment(out, context="after editing (->)")
+    return out
+
+
+class DeviceSim:
+    """expit(sim_mat)[i, j] of AliNet.augment (alinet.py:893-894) read on demand from the device-resident
+    similarity block (the reference holds the n x n matrix on the host)."""
+
+    def __init__(self, s):
+        self.s = s
+        self._cache = {}
+
+    def __getitem__(self, ij):
+        v = self._cache.get(ij)
+        if v is None:
+            x = float(self.s[ij[0], ij[1]].item())
+            v = self._cache[ij] = 1.0 / (1.0 + math.exp(-x))
+        return v
+
+
 class AKG:
     """alinet.py:459-493 (the attributes the path uses)."""
 
@@ -341,6 +408,47 @@ class AliNet(BasicModel):
                 rs.append(r)
         return hs, rs, ts
 
+    def augment(self):
+        """alinet.py:885-898: candidate pairs = (i, argmax_j sim) with expit(sim) > sim_th, on the last layer's
+        normalised output of the reference entities; the matrix stays on the device."""
+        from ..modules.finding.similarity import sim_device
+        with torch.no_grad():
+            last = self._forward()[-1].contiguous()
+        d = last.shape[1]
+        e1 = ops.gather_rows(last, d, ops.to_ids(np.asarray(self.ref_ent1, np.int32), self.dev), normalize=True)
+        e2 = ops.gather_rows(last, d, ops.to_ids(np.asarray(self.ref_ent2, np.int32), self.dev), normalize=True)
+        print("calculate sim mat...")
+        s = sim_device(e1, e2, d, csls_k=self.args.csls)
+        _, argmax = ops.rank_rows(s, torch.zeros(s.shape[0], dtype=torch.int32, device=s.device))
+        am = argmax.cpu().numpy().astype(np.int64)
+        top = s[torch.arange(s.shape[0], device=s.device), argmax.long()].cpu().numpy().astype(np.float64)
+        print("sim th:", self.sim_th)
+        keep = 1.0 / (1.0 + np.exp(-top)) > self.sim_th           # find_alignment(sim_mat, th, 1): > th and the row's nearest
+        pair_index = set(zip(np.flatnonzero(keep).tolist(), am[keep].tolist()))
+        check_new_alignment(pair_index, context="after filtering by sim and nearest k")
+        return (pair_index if pair_index else None), DeviceSim(s)
+
+    def augment_neighborhood(self):
+        """alinet.py:900-920: grow the seed alignment from confident predictions and rebuild the 1-hop adjacency."""
+        pair_index, sim_mat = self.augment()
+        if pair_index is None or len(pair_index) == 0:
+            return
+        self.new_links = update_labeled_alignment_x(self.new_links, pair_index, sim_mat)
+        self.new_links = update_labeled_alignment_y(self.new_links, sim_mat)
+        new_sup_ent1 = [self.ref_ent1[i] for i, _ in self.new_links]
+        new_sup_ent2 = [self.ref_ent2[j] for _, j in self.new_links]
+        self.new_sup_links_set = set(zip(new_sup_ent1, new_sup_ent2))
+        if not new_sup_ent1:
+            return
+        self.new_edges1, self.new_edges2 = enhance_triples(self.kg1, self.kg2, self.sup_ent1 + new_sup_ent1,
+                                                           self.sup_ent2 + new_sup_ent2)
+        triples = self.kg1.triple_list + self.kg2.triple_list + list(self.new_edges1) + list(self.new_edges2)
+        triples = remove_unlinked_triples(triples, self.linked_ents)
+        one = no_weighted_adj(self.kgs.entities_num, triples)
+        self.adj[0] = EdgeGraph(one.row, one.col, one.data, one.shape, self.dev)
+        for layer in self.one_hop_layers:
+            layer.graph = self.adj[0]                               # GraphConvolution.update_adj (alinet.py:586-590)
+
     def find_neighbors(self):
         """alinet.py:1019-1039: cross-KG truncated neighbours on the last layer's normalised output."""
         if self.args.truncated_epsilon <= 0.0:
@@ -434,4 +542,6 @@ class AliNet(BasicModel):
                     print("\n == training stop == \n")
                     break
                 neighbors1, neighbors2 = self.find_neighbors()
+                if epoch >= self.args.start_augment * self.args.eval_freq and self.args.sim_th > 0.0:
+                    self.augment_neighborhood()
         print("Training ends. Total time = {:.3f} s.".format(time.time() - t0))

@@ -13,7 +13,7 @@ mining (fp64 L1 similarity strip + radix select: oea_sim_matrix + oea_topk_rows)
 
 Reproduced quirks: `get_mat` compares head with RELATION id and increments
 degree[relation id] (rdgcn.py:49-51).  The entity input is the summed word vectors of the entity
-names (rdgcn.py:415-464) when `word_embed` exists; the file is not available offline, so the
+names (rdgcn.py:415-464) when the `word_embed` file exists (`_get_desc_input`); without the file the
 default here is the reference's own alternative `get_input_layer` (glorot, rdgcn.py:280-282).
 TF1 semantics restated, not executed: PARITY UNPINNED.
 """
@@ -225,6 +225,42 @@ def get_neg(ill_ids, output_layer, dim, k):
     return ops.topk_rows(s, k, nc=output_layer.shape[0]).reshape(-1)
 
 
+def read_word_vectors(file_path):
+    """fastText .vec text file (header line, then `word v1 ... vd`) -> (words, [n + 1, d] matrix whose LAST row is
+    the zero vector of unknown words) -- rdgcn.py:424-433."""
+    words, vecs = [], []
+    with open(file_path, 'r', encoding='utf-8') as f:
+        f.readline()                                   # "N d" header (rdgcn.py:426: w[1:])
+        for line in f:
+            parts = line.rstrip('\n').split(' ')
+            if len(parts) < 2:
+                continue
+            words.append(parts[0])
+            vecs.append(np.asarray([x for x in parts[1:] if x != ''], dtype=np.float64))
+    mat = np.stack(vecs, axis=0)
+    return words, np.append(mat, np.zeros((1, mat.shape[1])), axis=0)
+
+
+def name_vectors(names_by_entity, entities_num, words, word_em, default_length=4):
+    """rdgcn.py:421-462: a name = its first 4 space-separated words after punctuation is removed; every word maps to
+    its vector (unknown words and padding to the zero vector, see below); the entity input is the SUM of the 4.
+    Padding quirk kept: the reference pads with the id of the LAST entry of its word table, which is the
+    unknown-word id when any name word is unknown and otherwise the last vocabulary word."""
+    import re
+    import string
+    punct = re.compile('[{}]+'.format(re.escape(string.punctuation)))
+    index = {w: i for i, w in enumerate(words)}
+    un_logged_id = len(words)
+    split = {e: punct.sub('', n).split(' ') for e, n in names_by_entity.items()}
+    any_unknown = any(w not in index for ws in split.values() for w in ws)
+    pad_id = un_logged_id if any_unknown else len(words) - 1
+    ids = np.full((entities_num, default_length), un_logged_id, np.int64)
+    for e, ws in split.items():
+        row = [index.get(w, un_logged_id) for w in ws] + [pad_id] * default_length
+        ids[e] = row[:default_length]
+    return word_em[ids].sum(axis=1), ids
+
+
 class RDGCN(BasicModel):
     def __init__(self):
         super().__init__()
@@ -234,12 +270,54 @@ class RDGCN(BasicModel):
 
     def init(self):
         self.dev = ops.device()
-        if os.path.exists(self.word_embed):
-            raise NotImplementedError("word-vector name initialisation (rdgcn.py:415-464) needs the fastText file; "
-                                      "pass model.local_name_vectors = <[E, dim] array> instead")
+        if self.local_name_vectors is None and os.path.exists(self.word_embed):
+            _, _, self.local_name_vectors = self._get_desc_input()       # rdgcn.py:358
         self.gcn_model = Layer(self.args, self.kgs, self.local_name_vectors, self.dev, seed=self._seed,
                                attn_grouping=self.attn_grouping)
         self.optimizer = TFAdam(self.gcn_model.params(), self.args.learning_rate)
+
+    def _get_local_name_by_name_triple(self, name_attribute_list=None):
+        """rdgcn.py:366-413: entity id -> name = value of a name attribute if the dataset has one, else the local
+        part of the URI with '_' -> ' '."""
+        if name_attribute_list is None:
+            if 'D_Y' in self.args.training_data:
+                name_attribute_list = {'skos:prefLabel', 'http://dbpedia.org/ontology/birthName'}
+            elif 'D_W' in self.args.training_data:
+                name_attribute_list = {'http://www.wikidata.org/entity/P373', 'http://www.wikidata.org/entity/P1476'}
+            else:
+                name_attribute_list = {}
+        triples = []
+        for h, a, v in self.kgs.kg1.local_attribute_triples_set | self.kgs.kg2.local_attribute_triples_set:
+            v = v.strip('"')
+            if v.endswith('"@eng'):
+                v = v.rstrip('"@eng')
+            triples.append((h, a, v))
+        id_ent_dict = {}
+        for kg in (self.kgs.kg1, self.kgs.kg2):
+            for e, e_id in (kg.entities_id_dict or {}).items():
+                id_ent_dict[e_id] = e
+        name_ids = set()
+        for kg in (self.kgs.kg1, self.kgs.kg2):
+            for a, a_id in (kg.attributes_id_dict or {}).items():
+                if a in name_attribute_list:
+                    name_ids.add(a_id)
+        local_name_dict = {}
+        for e, a, v in triples:
+            if a in name_ids:
+                local_name_dict[e] = v
+        for e in self.kgs.kg1.entities_set | self.kgs.kg2.entities_set:
+            if e not in local_name_dict:
+                local_name_dict[e] = str(id_ent_dict[e]).split('/')[-1].replace('_', ' ')
+        return [(e, -1, n) for e, n in local_name_dict.items()]
+
+    def _get_desc_input(self):
+        """rdgcn.py:415-464 -> (word_em, e_desc_input ids [E, 4], name_embeds [E, d])."""
+        start = time.time()
+        names = {e: n for e, _, n in self._get_local_name_by_name_triple()}
+        words, word_em = read_word_vectors(self.word_embed)
+        name_embeds, ids = name_vectors(names, self.kgs.entities_num, words, word_em)
+        print('generating desc input costs time: {:.4f}s'.format(time.time() - start))
+        return word_em, ids, name_embeds
 
     def _output(self):
         with torch.no_grad():

@@ -161,3 +161,29 @@ def test_bootstrapping_matchings():
         free_l = set(range(nl)) - {p[0] for p in greedy}
         free_r = set(range(nr)) - {p[1] for p in greedy}
         assert not any(p[0] in free_l and p[1] in free_r for p in pairs)       # maximal
+
+
+def test_rdgcn_name_vectors(tmp_path):
+    """rdgcn.py:415-464 restated: names -> 4 word ids (unknown / padding -> zero vector) -> summed word vectors."""
+    from openea_amd.approaches.rdgcn import name_vectors, read_word_vectors
+    vec = tmp_path / "w.vec"
+    rng = np.random.RandomState(0)
+    vocab = ["alpha", "beta", "gamma", "delta", "e7"]
+    mat = rng.standard_normal((len(vocab), 6))
+    with open(vec, "w") as f:
+        f.write("%d %d\n" % (len(vocab), 6))
+        for w, v in zip(vocab, mat):
+            f.write(w + " " + " ".join("%.6f" % x for x in v) + " \n")        # fastText lines end with a space
+    words, word_em = read_word_vectors(str(vec))
+    assert words == vocab and word_em.shape == (len(vocab) + 1, 6) and not word_em[-1].any()
+    np.testing.assert_allclose(word_em[:-1], np.round(mat, 6), atol=1e-9)
+    names = {0: "alpha beta", 2: "gamma, (delta) unknownword alpha beta", 3: "e7"}
+    emb, ids = name_vectors(names, 5, words, word_em)
+    u = len(vocab)
+    assert ids.tolist() == [[0, 1, u, u], [u, u, u, u], [2, 3, u, 0], [4, u, u, u], [u, u, u, u]]
+    np.testing.assert_allclose(emb[0], word_em[0] + word_em[1])
+    np.testing.assert_allclose(emb[2], word_em[2] + word_em[3] + word_em[0])      # punctuation stripped, 4-word window
+    assert not emb[1].any() and not emb[4].any()
+    # padding quirk: with no unknown word anywhere the pad id is the LAST vocabulary word
+    emb2, ids2 = name_vectors({0: "alpha"}, 1, words, word_em)
+    assert ids2.tolist() == [[0, 4, 4, 4]]
