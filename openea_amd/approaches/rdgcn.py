@@ -270,6 +270,8 @@ class RDGCN(BasicModel):
 
     def init(self):
         self.dev = ops.device()
+        if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0:
+            raise NotImplementedError("dropout > 0 is not built (every shipped args file uses 0)")
         if self.local_name_vectors is None and os.path.exists(self.word_embed):
             _, _, self.local_name_vectors = self._get_desc_input()       # rdgcn.py:358
         self.gcn_model = Layer(self.args, self.kgs, self.local_name_vectors, self.dev, seed=self._seed,
