@@ -171,6 +171,40 @@ class BasicModel:
             ent_ids_rest_12 = [(self.kgs.test_entities1[i], self.kgs.test_entities2[j]) for i, j in rest_12]
             rd.save_results(self.out_folder, ent_ids_rest_12)
 
+    def retest(self):
+        """basic_model.py:140-182: reload the saved embeddings of this run's parent folder and evaluate them both
+        ways + the stable matching."""
+        import os
+        from ..modules.finding.alignment import stable_alignment
+        parts = self.out_folder.split("/")
+        new_dir = "".join(p + "/" for p in parts[:len(parts) - 2])
+        new_dir = new_dir + sorted(os.listdir(new_dir))[0] + "/"
+        embeds = np.load(new_dir + "ent_embeds.npy")
+        embeds1, embeds2 = embeds[self.kgs.test_entities1], embeds[self.kgs.test_entities2]
+        mapping = None
+        print(self.__class__.__name__, type(self.__class__.__name__))
+        if self.__class__.__name__ == "GCN_Align":
+            print(self.__class__.__name__, "loads attr embeds")
+            attr_embeds = np.load(new_dir + "attr_embeds.npy")
+            embeds1 = np.concatenate([embeds1 * self.args.beta, attr_embeds[self.kgs.test_entities1] * (1.0 - self.args.beta)], axis=1)
+            embeds2 = np.concatenate([embeds2 * self.args.beta, attr_embeds[self.kgs.test_entities2] * (1.0 - self.args.beta)], axis=1)
+        if os.path.exists(new_dir + "mapping_mat.npy"):
+            print(self.__class__.__name__, "loads mapping mat")
+            mapping = np.load(new_dir + "mapping_mat.npy")
+        kw = dict(metric=self.args.eval_metric, normalize=self.args.eval_norm, csls_k=0, accurate=True)
+        print("conventional test:")
+        test(embeds1, embeds2, mapping, self.args.top_k, self.args.test_threads_num, **kw)
+        print("conventional reversed test:")
+        if mapping is not None:
+            embeds1 = np.matmul(embeds1, mapping)
+        test(embeds2, embeds1, None, self.args.top_k, self.args.test_threads_num, **kw)
+        print("stable test:")
+        stable_alignment(embeds1, embeds2, self.args.eval_metric, self.args.eval_norm, csls_k=0,
+                         nums_threads=self.args.test_threads_num)
+        print("stable test with csls:")
+        stable_alignment(embeds1, embeds2, self.args.eval_metric, self.args.eval_norm, csls_k=self.args.csls,
+                         nums_threads=self.args.test_threads_num)
+
     def save(self):
         """basic_model.py:184-188: same files, same .npy payloads (the NORMALISED tensors, as
         `self.ent_embeds.eval()` returns them in the reference)."""

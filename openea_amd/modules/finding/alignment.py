@@ -103,3 +103,85 @@ def calculate_rank(idx, sim_mat, top_k, accurate, total_num):
     hits = [int((rank_h < k).sum()) for k in top_k]
     hits1_rest = {(int(idx[i]), int(a)) for i, a in enumerate(argmax.cpu().numpy())}
     return mr, mrr, hits, hits1_rest
+
+
+def galeshapley_topk(cand, cand_sim, sim_lookup, max_iteration):
+    """The reference's Gale-Shapley loop (alignment.py:170-221) on truncated preference lists.
+
+    cand[s]      suitor s's reviewers in preference order (the reference holds the full argsort; a suitor
+                 drops at most one reviewer per round, so `max_iteration` entries are all it can ever use),
+    cand_sim     the matching similarities (unused by the loop, kept for callers),
+    sim_lookup   (s, r) -> similarity: "reviewer r prefers s to its partner" is `index(s) < index(partner)` in
+                 r's argsort of its column in the reference, i.e. a larger similarity (ties: smaller suitor id).
+    Round structure as in the reference: suitors are visited in list order, matches change immediately, a
+    displaced suitor proposes again next round and only then drops the reviewer that left it.
+    -> dict suitor -> reviewer."""
+    n = len(cand)
+    ptr = [0] * n
+    matching, rev_matching = {}, {}
+    suitors = list(range(n))
+    for _ in range(max_iteration):
+        if not suitors:
+            break
+        for s in suitors:
+            if ptr[s] >= len(cand[s]):
+                continue
+            r = int(cand[s][ptr[s]])
+            partner = rev_matching.get(r)
+            if partner is None:
+                matching[s] = r
+                rev_matching[r] = s
+            else:
+                a, b = sim_lookup(s, r), sim_lookup(partner, r)
+                if a > b or (a == b and s < partner):
+                    del matching[partner]
+                    matching[s] = r
+                    rev_matching[r] = s
+                else:
+                    ptr[s] += 1
+        suitors = sorted(set(range(n)) - set(matching.keys()))
+    return matching
+
+
+def stable_alignment(embed1, embed2, metric, normalize, csls_k, nums_threads, cut=100, sim_mat=None):
+    """alignment.py:87-134: stable (Gale-Shapley, at most `cut` rounds) matching of the two embedding blocks and
+    its precision.  The similarity block stays on the device; each suitor's `cut` best reviewers come from the
+    top-k select kernel (sorted by value on the host) instead of a full n x n argsort in both directions."""
+    import torch
+    from .similarity import sim_device
+    t = time.time()
+    if sim_mat is None:
+        e1 = embed1 if hasattr(embed1, "is_cuda") else ops.to_table(np.asarray(embed1, np.float32))
+        e2 = embed2 if hasattr(embed2, "is_cuda") else ops.to_table(np.asarray(embed2, np.float32))
+        dim = embed1.shape[1] if not hasattr(embed1, "is_cuda") else getattr(embed1, "oea_dim", embed1.shape[1])
+        s = sim_device(e1, e2, dim, metric, normalize, csls_k)
+    else:
+        s = torch.from_numpy(np.ascontiguousarray(sim_mat, np.float32)).to(ops.device())
+    n1, n2 = s.shape
+    k = min(cut, n2)
+    ld = (n2 + 31) // 32 * 32
+    sp = torch.empty((n1, ld), dtype=torch.float32, device=s.device)       # the select kernel reads 16-byte aligned rows
+    sp[:, :n2] = s
+    idx = ops.topk_rows(sp, k, nc=n2).long()
+    vals = torch.gather(s, 1, idx).cpu().numpy()
+    idx = idx.cpu().numpy()
+    order = np.lexsort((idx, -vals.astype(np.float64)), axis=1)            # value desc, column asc
+    cand = np.take_along_axis(idx, order, axis=1)
+    cand_sim = np.take_along_axis(vals, order, axis=1)
+    print("generating candidate lists costs time {:.3f} s ".format(time.time() - t))
+    t = time.time()
+    cache = {}
+
+    def lookup(i, j):
+        v = cache.get((i, j))
+        if v is None:
+            v = cache[(i, j)] = float(s[i, j].item())
+        return v
+    for i in range(n1):                                                    # the candidates' own values are known already
+        for j, v in zip(cand[i].tolist(), cand_sim[i].tolist()):
+            cache[(i, j)] = v
+    matching = galeshapley_topk(cand, cand_sim, lookup, cut)
+    n = sum(1 for i, j in matching.items() if i == j)
+    cost = time.time() - t
+    print("stable alignment precision = {:.3f}%, time = {:.3f} s ".format(n / max(len(matching), 1) * 100, cost))
+    return matching

@@ -460,3 +460,37 @@ def adam_tf(p, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     m[...] = beta1 * m + (1 - beta1) * g
     v[...] = beta2 * v + (1 - beta2) * g * g
     p[...] = p - lr_t * m / (np.sqrt(v) + eps)
+
+
+def galeshapley(suitor_pref_dict, reviewer_pref_dict, max_iteration):
+    """alignment.py:170-221 restated (full preference lists, sequential rounds, a displaced suitor keeps the
+    reviewer at the head of its list until it loses the comparison in a later round)."""
+    suitor_pref_dict = {s: list(v) for s, v in suitor_pref_dict.items()}
+    suitors = list(suitor_pref_dict.keys())
+    matching, rev_matching = {}, {}
+    for _ in range(max_iteration):
+        if len(suitors) <= 0:
+            break
+        for s in suitors:
+            r = suitor_pref_dict[s][0]
+            if r not in matching.values():
+                matching[s] = r
+                rev_matching[r] = s
+            else:
+                r_partner = rev_matching.get(r)
+                if reviewer_pref_dict[r].index(s) < reviewer_pref_dict[r].index(r_partner):
+                    del matching[r_partner]
+                    matching[s] = r
+                    rev_matching[r] = s
+                else:
+                    suitor_pref_dict[s].remove(r)
+        suitors = sorted(set(suitor_pref_dict.keys()) - set(matching.keys()))
+    return matching
+
+
+def stable_alignment(sim_mat, cut=100):
+    """alignment.py:87-134 on a given similarity matrix: argsort both ways (stable, ties by index) + galeshapley."""
+    sim_mat = np.asarray(sim_mat)
+    kg1 = {i: np.argsort(-sim_mat[i], kind="stable").tolist() for i in range(sim_mat.shape[0])}
+    kg2 = {j: np.argsort(-sim_mat[:, j], kind="stable").tolist() for j in range(sim_mat.shape[1])}
+    return galeshapley(kg1, kg2, cut)

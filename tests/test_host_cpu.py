@@ -187,3 +187,20 @@ def test_rdgcn_name_vectors(tmp_path):
     # padding quirk: with no unknown word anywhere the pad id is the LAST vocabulary word
     emb2, ids2 = name_vectors({0: "alpha"}, 1, words, word_em)
     assert ids2.tolist() == [[0, 4, 4, 4]]
+
+
+def test_galeshapley_topk_equals_reference_loop():
+    """truncated preference lists + similarity comparisons == the reference's loop on full argsorted lists."""
+    from oracle import np_oracle as orc
+    from openea_amd.modules.finding.alignment import galeshapley_topk
+    rng = np.random.RandomState(0)
+    for n, cut in ((12, 100), (40, 100), (40, 5), (25, 3)):
+        s = rng.rand(n, n)
+        s[np.arange(n), np.arange(n)] += 0.3
+        if n == 25:
+            s = np.round(s, 1)                                   # ties: index order decides, as in a stable argsort
+        ref = orc.stable_alignment(s, cut)
+        order = np.argsort(-s, axis=1, kind="stable")[:, :min(cut, n)]
+        got = galeshapley_topk(order, np.take_along_axis(s, order, 1), lambda i, j: float(s[i, j]), cut)
+        assert got == ref
+        assert len(set(got.values())) == len(got)

@@ -117,6 +117,23 @@ def test_calculate_rank_block_matches_oracle(ops):
     assert list(got[2]) == list(ref[2]) and got[3] == ref[3]
 
 
+@pytest.mark.parametrize("csls_k", [0, 5])
+def test_stable_alignment_matches_oracle(ops, csls_k, capsys):
+    """stable_alignment (alignment.py:87-134): device similarity + top-`cut` candidate lists + the reference's
+    Gale-Shapley loop == the oracle's full-argsort version on the same similarity matrix."""
+    from oracle import np_oracle as orc
+    from openea_amd.modules.finding.alignment import stable_alignment
+    from openea_amd.modules.finding.similarity import sim
+    rng = np.random.RandomState(3)
+    e1 = rng.standard_normal((180, 24)).astype(np.float32)
+    e2 = (e1 + 0.8 * rng.standard_normal((180, 24))).astype(np.float32)
+    for cut in (100, 7):
+        got = stable_alignment(e1, e2, "inner", True, csls_k, 1, cut=cut)
+        ref = orc.stable_alignment(sim(e1, e2, metric="inner", normalize=True, csls_k=csls_k), cut)
+        assert got == ref
+    assert "stable alignment precision = " in capsys.readouterr().out
+
+
 # ---------------------------------------------------------------------------------------------
 # neighbour search
 # ---------------------------------------------------------------------------------------------

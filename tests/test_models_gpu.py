@@ -84,6 +84,10 @@ def test_translational_models_end_to_end(kgs_small, tmp_path, name, mode, kw, ca
         assert os.path.exists(model.out_folder + f)
     if name == "MTransE":
         assert np.load(model.out_folder + "mapping_mat.npy").shape == (32, 32)
+        model.retest()                                        # basic_model.py:140-182: reload + both directions + stable matching
+        out = capsys.readouterr().out
+        assert "conventional reversed test:" in out and "stable test with csls:" in out
+        assert out.count("stable alignment precision = ") == 2
 
 
 def test_gcn_align_epoch_matches_oracle(kgs_small, tmp_path):
