@@ -34,10 +34,16 @@ namespace {
 using oea::group_sum;
 
 struct StepWs {
-    float *ent_grad, *rel_grad;         // rel_grad: [kRelCopies][n_rel][ld]
+    float *ent_grad, *rel_grad;         // rel_grad: copy 0 of the relation scratch [n_rel][ld]
+    float *rel_extra;                   // copies 1 .. kRelCopies-1, [kRelCopies-1][n_rel][ld]
     int64_t rel_copy_stride;            // n_rel * ld
     float *ent_touched, *rel_touched;   // 1.0f = row received gradient (float so one SUM all-reduce covers grads + flags)
     double *partials;                   // [kMaxBlocks]
+    // layout: [ent_grad | rel_grad (copy 0) | ent_touched | rel_touched] is the contiguous prefix that data-parallel
+    // ranks all-reduce (the extra copies are folded into copy 0 first); [rel_extra | partials] follow.
+    __device__ __forceinline__ float *rel_copy(int64_t c) const {
+        return c == 0 ? rel_grad : rel_extra + (c - 1) * rel_copy_stride;
+    }
 };
 constexpr int kMaxBlocks = 4096;
 // Relation rows are few (a few hundred) and shared by the whole batch: with one scratch row per
@@ -53,11 +59,12 @@ static size_t ws_layout(int64_t n_ent, int64_t n_rel, int32_t ld, void *base, St
     char *b = static_cast<char *>(base);
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return b ? b + o : nullptr; };
     float *eg = (float *)take(sizeof(float) * (size_t)n_ent * ld);
-    float *rg = (float *)take(sizeof(float) * (size_t)n_rel * ld * kRelCopies);
+    float *rg = (float *)take(sizeof(float) * (size_t)n_rel * ld);
     float *et = (float *)take(sizeof(float) * (size_t)n_ent);
     float *rt = (float *)take(sizeof(float) * (size_t)n_rel);
+    float *rx = (float *)take(sizeof(float) * (size_t)n_rel * ld * (kRelCopies - 1));
     double *pp = (double *)take(sizeof(double) * kMaxBlocks);
-    if (ws) { ws->rel_copy_stride = n_rel * (int64_t)ld; ws->ent_grad = eg; ws->rel_grad = rg; ws->ent_touched = et; ws->rel_touched = rt; ws->partials = pp; }
+    if (ws) { ws->rel_copy_stride = n_rel * (int64_t)ld; ws->ent_grad = eg; ws->rel_grad = rg; ws->rel_extra = rx; ws->ent_touched = et; ws->rel_touched = rt; ws->partials = pp; }
     return off;
 }
 
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void triple_generic(
             if (lane == 0) loss_local += (double)x;
             dscore<G, IT>(dn, -1.f, cfg.l1, g);
             atomic_row<G, IT>(ws.ent_grad + (int64_t)nh * ld, ld, lane, g, 1.f);
-            atomic_row<G, IT>(ws.rel_grad + (item % kRelCopies) * ws.rel_copy_stride + (int64_t)nr * ld, ld, lane, g, 1.f);
+            atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)nr * ld, ld, lane, g, 1.f);
             atomic_row<G, IT>(ws.ent_grad + (int64_t)nt * ld, ld, lane, g, -1.f);
             if (lane == 0) { ws.ent_touched[nh] = 1.f; ws.ent_touched[nt] = 1.f; ws.rel_touched[nr] = 1.f; }
             coef = 1.f;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void triple_generic(
         }
         dscore<G, IT>(delta, coef, cfg.l1, g);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, g, 1.f);
-        atomic_row<G, IT>(ws.rel_grad + (item % kRelCopies) * ws.rel_copy_stride + (int64_t)r * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, g, 1.f);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, g, -1.f);
         if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; }
     }
@@ -236,7 +243,7 @@ __device__ __forceinline__ double score_independent(const float *__restrict__ en
     if (coef != 0.f) {
         dscore<G, IT>(delta, coef, cfg.l1, g);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)ch * ld, ld, lane, g, 1.f);
-        atomic_row<G, IT>(ws.rel_grad + (item % kRelCopies) * ws.rel_copy_stride + (int64_t)cr * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)cr * ld, ld, lane, g, 1.f);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)ct * ld, ld, lane, g, -1.f);
         if (lane == 0) { ws.ent_touched[ch] = 1.f; ws.ent_touched[ct] = 1.f; ws.rel_touched[cr] = 1.f; }
     }
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
         }
         if (any) {
             atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, gh, 1.f);
-            atomic_row<G, IT>(ws.rel_grad + (p % kRelCopies) * ws.rel_copy_stride + (int64_t)r * ld, ld, lane, gr, 1.f);
+            atomic_row<G, IT>(ws.rel_copy(p % kRelCopies) + (int64_t)r * ld, ld, lane, gr, 1.f);
             atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, gt, 1.f);
             if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; }
         }
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
                                                   int64_t n_ent, float *__restrict__ rel,
                                                   float *__restrict__ rel_acc, int64_t n_rel, int ld,
                                                   oea_step_cfg cfg, StepWs ws, int n_partials,
-                                                  double *__restrict__ loss_accum) {
+                                                  double *__restrict__ loss_accum, int copies_folded) {
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
         load_row<G, IT>(g, ld, lane, rg);
         if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
         if (flag == 0.f) continue;
-        if (is_rel) {                                 // sum (fixed order) and clear the other copies
+        if (is_rel && !copies_folded) {               // sum (fixed order) and clear the other copies
             constexpr int CB = IT <= 4 ? 5 : 1;       // copies fetched together (all loads issued before use)
             for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
                 float tmp[CB][IT];
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
 #pragma unroll
                     for (int it = 0; it < IT; ++it) {
                         const int c = it * G + lane;
-                        tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? g[(cp0 + u) * ws.rel_copy_stride + c] : 0.f;
+                        tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? ws.rel_copy(cp0 + u)[row * ld + c] : 0.f;
                     }
 #pragma unroll
                 for (int u = 0; u < CB; ++u)
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
                     for (int it = 0; it < IT; ++it) {
                         const int c = it * G + lane;
                         rg.v[it] += tmp[u][it];
-                        if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0.f) g[(cp0 + u) * ws.rel_copy_stride + c] = 0.f;
+                        if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0.f) ws.rel_copy(cp0 + u)[row * ld + c] = 0.f;
                     }
             }
         }
@@ -455,6 +462,19 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
     }
 }
 
+// data parallel: fold relation copies 1.. into copy 0 (and clear them) so that only copy 0 is exchanged
+__global__ void fold_rel_copies_kernel(StepWs ws, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < kRelCopies - 1; ++c) {
+            const float v = ws.rel_extra[c * ws.rel_copy_stride + i];
+            if (v != 0.f) { sum += v; ws.rel_extra[c * ws.rel_copy_stride + i] = 0.f; }
+        }
+        if (sum != 0.f) ws.rel_grad[i] += sum;
+    }
+}
+
 // grad[ids[i], c] += src[i, c]  (gradients w.r.t. NORMALISED rows produced outside the fused step,
 // e.g. MTransE's mapping loss, approaches/mtranse.py:84-96) + touched flags, so that apply_rows
 // pulls them through the normalisation and the optimiser like any other row gradient.
@@ -490,11 +510,15 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
         else
             triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         oea::prof_mark(st);
+        if (phase == OEA_PHASE_GRAD)
+            fold_rel_copies_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rel * (int64_t)ld, 256), 1024), 256, 0, st>>>(
+                ws, n_rel * (int64_t)ld);
     }
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
         oea::prof_mark(st);
-        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum);
+        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum,
+                                                 phase == OEA_PHASE_APPLY);
         oea::prof_mark(st);
     }
     return 0;
@@ -511,7 +535,7 @@ size_t oea_step_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld) {
 size_t oea_step_exchange_floats(int64_t n_ent, int64_t n_rel, int32_t ld) {
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, reinterpret_cast<void *>(256), &ws);   // fake base: only offsets matter
-    return (size_t)(reinterpret_cast<char *>(ws.partials) - reinterpret_cast<char *>(256)) / sizeof(float);
+    return (size_t)(reinterpret_cast<char *>(ws.rel_extra) - reinterpret_cast<char *>(256)) / sizeof(float);
 }
 
 int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
