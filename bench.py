@@ -162,7 +162,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_triple_fwd_bwd.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            # PMC traffic was collected on the default workload; it says nothing about another shape
+            same = (args.shape, args.dim, args.batch, args.neg) == ("EN-FR-15K-V1", 75, 5000, 10) and world == 1
+            traffic = tj.get("hbm_bytes_per_launch") if same else None
         except Exception:
             traffic = None
     roofline = {"kernel": "triple_fwd_bwd", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
