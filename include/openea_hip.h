@@ -88,6 +88,7 @@ int oea_fill_f32(float *p, int64_t n, float value, void *stream);
 enum { OEA_LOSS_MARGIN = 0, OEA_LOSS_LIMITED = 1, OEA_LOSS_LOGISTIC = 2, OEA_LOSS_POSITIVE = 3,
        OEA_LOSS_ALIGN = 4 };
 enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1 };
+enum { OEA_SCORE_TRANSE = 0, OEA_SCORE_TRANSH = 1 };
 
 typedef struct oea_step_cfg {
     int32_t loss_kind;   /* OEA_LOSS_* */
@@ -105,6 +106,12 @@ typedef struct oea_step_cfg {
                             oea_sample_negatives writes them -> one workgroup-lane group scores a positive
                             with its negatives (fewer row reads / atomics; identical arithmetic per triple,
                             entries that are not corruptions of pos p are still scored correctly). */
+    int32_t score_kind;  /* OEA_SCORE_TRANSE: s = |h + r - t|;  OEA_SCORE_TRANSH (approaches/bootea_transh.py:58-96):
+                            h, t projected on the relation's hyperplane first, h' = h - (h.n) n with
+                            n = l2_normalize(l2_normalize(normal[r])).  TransH needs neg_group_k > 0 (sampler layout)
+                            or no negatives, and a per-triple loss (not OEA_LOSS_MARGIN). */
+    float *normal;       /* TransH: [n_rel, ld] normal_vector table (trained in place), else NULL */
+    float *normal_acc;   /* TransH + Adagrad: its accumulator, else NULL */
 } oea_step_cfg;
 
 /* Workspace owned by the caller, sized by oea_step_workspace_bytes(); must be zero-initialised

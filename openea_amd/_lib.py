@@ -20,7 +20,8 @@ class StepCfg(C.Structure):
     _fields_ = [("loss_kind", C.c_int32), ("l1", C.c_int32), ("margin", C.c_float),
                 ("pos_margin", C.c_float), ("neg_margin", C.c_float), ("balance", C.c_float),
                 ("ent_l2_norm", C.c_int32), ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32),
-                ("lr", C.c_float), ("neg_group_k", C.c_int32)]
+                ("lr", C.c_float), ("neg_group_k", C.c_int32), ("score_kind", C.c_int32),
+                ("normal", C.c_void_p), ("normal_acc", C.c_void_p)]
 
 
 class SamplerSide(C.Structure):

@@ -38,11 +38,17 @@ struct StepWs {
     float *rel_extra;                   // copies 1 .. kRelCopies-1, [kRelCopies-1][n_rel][ld]
     int64_t rel_copy_stride;            // n_rel * ld
     float *ent_touched, *rel_touched;   // 1.0f = row received gradient (float so one SUM all-reduce covers grads + flags)
+    float *nrm_grad, *nrm_extra;        // TransH normal vectors: copy 0 / copies 1.. (same shapes as the relation scratch)
+    float *nrm_touched;
     double *partials;                   // [kMaxBlocks]
-    // layout: [ent_grad | rel_grad (copy 0) | ent_touched | rel_touched] is the contiguous prefix that data-parallel
-    // ranks all-reduce (the extra copies are folded into copy 0 first); [rel_extra | partials] follow.
+    // layout: [ent_grad | rel_grad (copy 0) | nrm_grad (copy 0) | ent_touched | rel_touched | nrm_touched] is the
+    // contiguous prefix that data-parallel ranks all-reduce (the extra copies are folded into copy 0 first);
+    // [rel_extra | nrm_extra | partials] follow.
     __device__ __forceinline__ float *rel_copy(int64_t c) const {
         return c == 0 ? rel_grad : rel_extra + (c - 1) * rel_copy_stride;
+    }
+    __device__ __forceinline__ float *nrm_copy(int64_t c) const {
+        return c == 0 ? nrm_grad : nrm_extra + (c - 1) * rel_copy_stride;
     }
 };
 constexpr int kMaxBlocks = 4096;
@@ -60,11 +66,17 @@ static size_t ws_layout(int64_t n_ent, int64_t n_rel, int32_t ld, void *base, St
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return b ? b + o : nullptr; };
     float *eg = (float *)take(sizeof(float) * (size_t)n_ent * ld);
     float *rg = (float *)take(sizeof(float) * (size_t)n_rel * ld);
+    float *ng = (float *)take(sizeof(float) * (size_t)n_rel * ld);
     float *et = (float *)take(sizeof(float) * (size_t)n_ent);
     float *rt = (float *)take(sizeof(float) * (size_t)n_rel);
+    float *nt = (float *)take(sizeof(float) * (size_t)n_rel);
     float *rx = (float *)take(sizeof(float) * (size_t)n_rel * ld * (kRelCopies - 1));
+    float *nx = (float *)take(sizeof(float) * (size_t)n_rel * ld * (kRelCopies - 1));
     double *pp = (double *)take(sizeof(double) * kMaxBlocks);
-    if (ws) { ws->rel_copy_stride = n_rel * (int64_t)ld; ws->ent_grad = eg; ws->rel_grad = rg; ws->rel_extra = rx; ws->ent_touched = et; ws->rel_touched = rt; ws->partials = pp; }
+    if (ws) {
+        ws->rel_copy_stride = n_rel * (int64_t)ld; ws->ent_grad = eg; ws->rel_grad = rg; ws->rel_extra = rx;
+        ws->ent_touched = et; ws->rel_touched = rt; ws->nrm_grad = ng; ws->nrm_extra = nx; ws->nrm_touched = nt; ws->partials = pp;
+    }
     return off;
 }
 
@@ -379,6 +391,230 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     block_loss_partial(loss_local, ws.partials);
 }
 
+// ---- TransH (approaches/bootea_transh.py:58-96) ---------------------------------------------------------------
+// h' = h - (h.n) n, t' = t - (t.n) n with n = l2n(l2n(normal[r])); s = |h' + r - t'|.  With P = I - n n^T:
+//   d/dh = P g,  d/dt = -P g,  d/dr = g,  d/dn = ((t.n) - (h.n)) g + (g.n) (t - h)        (g = dL/d delta).
+// A separate, plainer kernel than triple_grouped (one group per positive and its k negatives, negatives
+// two at a time): the TransE kernel's register budget stays what it is.
+template <int G, int IT>
+__device__ __forceinline__ float dot(const Row<G, IT> &a, const Row<G, IT> &b) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) s += a.v[it] * b.v[it];
+    return group_sum<G>(s);
+}
+template <int G, int IT>
+__device__ __forceinline__ void load_normal(const float *__restrict__ nrm, int r, int ld, int lane, Row<G, IT> &yn) {
+    load_row<G, IT>(nrm + (int64_t)r * ld, ld, lane, yn);
+    normalize<G, IT>(yn, 1);          // the variable is created with is_l2_norm=True ...
+    normalize<G, IT>(yn, 1);          // ... and _calc normalises the looked-up row again
+}
+// one full triple with its own relation (positives of a batch without negatives; entries of a grouped batch
+// that are not corruptions of their positive)
+template <int G, int IT>
+__device__ double transh_independent(const float *__restrict__ ent, const float *__restrict__ rel, int ld, int lane,
+                                     int64_t item, int h, int r, int t, bool is_pos, const oea_step_cfg &cfg,
+                                     const StepWs &ws) {
+    Row<G, IT> yh, yr, yt, yn, delta, g;
+    load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+    load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+    load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+    load_normal<G, IT>(cfg.normal, r, ld, lane, yn);
+    normalize<G, IT>(yh, cfg.ent_l2_norm);
+    normalize<G, IT>(yr, cfg.rel_l2_norm);
+    normalize<G, IT>(yt, cfg.ent_l2_norm);
+    const float ah = dot<G, IT>(yh, yn), at = dot<G, IT>(yt, yn);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const float d = (yh.v[it] - ah * yn.v[it]) + yr.v[it] - (yt.v[it] - at * yn.v[it]);
+        delta.v[it] = d;
+        s += cfg.l1 ? fabsf(d) : d * d;
+    }
+    s = group_sum<G>(s);
+    float coef, l;
+    triple_coef(cfg, is_pos, s, coef, l);
+    if (coef != 0.f) {
+        dscore<G, IT>(delta, coef, cfg.l1, g);
+        const float gdn = dot<G, IT>(g, yn);
+        Row<G, IT> pg, gn;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            pg.v[it] = g.v[it] - gdn * yn.v[it];
+            gn.v[it] = (at - ah) * g.v[it] + gdn * (yt.v[it] - yh.v[it]);
+        }
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, pg, 1.f);
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, pg, -1.f);
+        atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, g, 1.f);
+        atomic_row<G, IT>(ws.nrm_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, gn, 1.f);
+        if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; ws.nrm_touched[r] = 1.f; }
+    }
+    return (double)l;
+}
+
+template <int G, int IT>
+__global__ __launch_bounds__(256) void triple_transh_grouped(
+    const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
+    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    double loss_local = 0.0;
+    for (int64_t p = grp; p < n_pos; p += ngrp) {
+        const int h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
+        const int32_t *ng = neg + (int64_t)p * k * 3;
+        Row<G, IT> yh, yr, yt, yn, ph, pt, g, gh, gr, gt, gn;
+        load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+        load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+        load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+        load_normal<G, IT>(cfg.normal, r, ld, lane, yn);
+        normalize<G, IT>(yh, cfg.ent_l2_norm);
+        normalize<G, IT>(yr, cfg.rel_l2_norm);
+        normalize<G, IT>(yt, cfg.ent_l2_norm);
+        const float ah = dot<G, IT>(yh, yn), at = dot<G, IT>(yt, yn);
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            ph.v[it] = yh.v[it] - ah * yn.v[it];
+            pt.v[it] = yt.v[it] - at * yn.v[it];
+            const float d = ph.v[it] + yr.v[it] - pt.v[it];
+            g.v[it] = d;
+            s += cfg.l1 ? fabsf(d) : d * d;
+        }
+        s = group_sum<G>(s);
+        float coef, l;
+        triple_coef(cfg, true, s, coef, l);
+        double lsum = (double)l;
+        bool any = coef != 0.f;
+        {
+            Row<G, IT> d0 = g;
+            dscore<G, IT>(d0, coef, cfg.l1, g);
+            const float gdn = dot<G, IT>(g, yn);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const float pg = g.v[it] - gdn * yn.v[it];
+                gh.v[it] = pg; gt.v[it] = -pg; gr.v[it] = g.v[it];
+                gn.v[it] = (at - ah) * g.v[it] + gdn * (yt.v[it] - yh.v[it]);
+            }
+        }
+        for (int j0 = 0; j0 < k; j0 += 2) {
+            int ch[2], cr[2], ct[2];
+            Row<G, IT> yc[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u < k ? j0 + u : j0;
+                ch[u] = ng[3 * j]; cr[u] = ng[3 * j + 1]; ct[u] = ng[3 * j + 2];
+                load_row<G, IT>(ent + (int64_t)((ch[u] == h) ? ct[u] : ch[u]) * ld, ld, lane, yc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (j0 + u >= k) continue;
+                const bool tail = ch[u] == h;
+                if (!(cr[u] == r && (tail || ct[u] == t))) {              // not a corruption of this positive
+                    lsum += transh_independent<G, IT>(ent, rel, ld, lane, p, ch[u], cr[u], ct[u], false, cfg, ws);
+                    continue;
+                }
+                const int ce = tail ? ct[u] : ch[u];
+                normalize<G, IT>(yc[u], cfg.ent_l2_norm);
+                const float ac = dot<G, IT>(yc[u], yn);
+                Row<G, IT> delta;
+                s = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const float pc = yc[u].v[it] - ac * yn.v[it];
+                    const float d = tail ? ph.v[it] + yr.v[it] - pc : pc + yr.v[it] - pt.v[it];
+                    delta.v[it] = d;
+                    s += cfg.l1 ? fabsf(d) : d * d;
+                }
+                s = group_sum<G>(s);
+                triple_coef(cfg, false, s, coef, l);
+                lsum += (double)l;
+                if (coef == 0.f) continue;
+                any = true;
+                dscore<G, IT>(delta, coef, cfg.l1, g);
+                const float gdn = dot<G, IT>(g, yn);
+                Row<G, IT> pg;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    pg.v[it] = g.v[it] - gdn * yn.v[it];
+                    gr.v[it] += g.v[it];
+                    if (tail) {
+                        gh.v[it] += pg.v[it];
+                        gn.v[it] += (ac - ah) * g.v[it] + gdn * (yc[u].v[it] - yh.v[it]);
+                    } else {
+                        gt.v[it] -= pg.v[it];
+                        gn.v[it] += (at - ac) * g.v[it] + gdn * (yt.v[it] - yc[u].v[it]);
+                    }
+                }
+                atomic_row<G, IT>(ws.ent_grad + (int64_t)ce * ld, ld, lane, pg, tail ? -1.f : 1.f);
+                if (lane == 0) ws.ent_touched[ce] = 1.f;
+            }
+        }
+        if (any) {
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, gh, 1.f);
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, gt, 1.f);
+            atomic_row<G, IT>(ws.rel_copy(p % kRelCopies) + (int64_t)r * ld, ld, lane, gr, 1.f);
+            atomic_row<G, IT>(ws.nrm_copy(p % kRelCopies) + (int64_t)r * ld, ld, lane, gn, 1.f);
+            if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; ws.nrm_touched[r] = 1.f; }
+        }
+        if (lane == 0) loss_local += lsum;
+    }
+    block_loss_partial(loss_local, ws.partials);
+}
+
+// optimiser on the touched normal-vector rows: gradient back through BOTH normalisations
+template <int G, int IT>
+__global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, oea_step_cfg cfg, StepWs ws, int copies_folded) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t row = grp; row < n_rel; row += ngrp) {
+        if (ws.nrm_touched[row] == 0.f) continue;
+        float *v = cfg.normal + row * ld;
+        Row<G, IT> rv, rg, y1, y2;
+        load_row<G, IT>(v, ld, lane, rv);
+        load_row<G, IT>(ws.nrm_grad + row * ld, ld, lane, rg);
+        for (int cp = 1; cp < kRelCopies && !copies_folded; ++cp) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = it * G + lane;
+                if (c < ld) {
+                    const float x = ws.nrm_copy(cp)[row * ld + c];
+                    if (x != 0.f) { rg.v[it] += x; ws.nrm_copy(cp)[row * ld + c] = 0.f; }
+                }
+            }
+        }
+        const float ss1 = sumsq<G, IT>(rv);
+        const float inv1 = rsqrtf(fmaxf(ss1, 1e-12f));
+#pragma unroll
+        for (int it = 0; it < IT; ++it) y1.v[it] = rv.v[it] * inv1;
+        const float ss2 = sumsq<G, IT>(y1);
+        const float inv2 = rsqrtf(fmaxf(ss2, 1e-12f));
+#pragma unroll
+        for (int it = 0; it < IT; ++it) y2.v[it] = y1.v[it] * inv2;
+        const float d2 = dot<G, IT>(y2, rg);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) rg.v[it] = (rg.v[it] - y2.v[it] * d2) * inv2;
+        const float d1 = ss1 > 1e-12f ? dot<G, IT>(y1, rg) : 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * G + lane;
+            if (c < ld) {
+                const float gv = (rg.v[it] - y1.v[it] * d1) * inv1;
+                if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
+                    const float a = cfg.normal_acc[row * ld + c] + gv * gv;
+                    cfg.normal_acc[row * ld + c] = a;
+                    v[c] = rv.v[it] - cfg.lr * gv / sqrtf(a);
+                } else {
+                    v[c] = rv.v[it] - cfg.lr * gv;
+                }
+                ws.nrm_grad[row * ld + c] = 0.f;
+            }
+        }
+        if (lane == 0) ws.nrm_touched[row] = 0.f;
+    }
+}
+
 // ---- kernel 2: optimiser on touched rows (entity rows first, then relation rows) -------------------
 template <int G, int IT>
 __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float *__restrict__ ent_acc,
@@ -463,7 +699,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
 }
 
 // data parallel: fold relation copies 1.. into copy 0 (and clear them) so that only copy 0 is exchanged
-__global__ void fold_rel_copies_kernel(StepWs ws, int64_t n) {
+__global__ void fold_rel_copies_kernel(StepWs ws, int64_t n, int with_normal) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float sum = 0.f;
 #pragma unroll
@@ -472,6 +708,15 @@ __global__ void fold_rel_copies_kernel(StepWs ws, int64_t n) {
             if (v != 0.f) { sum += v; ws.rel_extra[c * ws.rel_copy_stride + i] = 0.f; }
         }
         if (sum != 0.f) ws.rel_grad[i] += sum;
+        if (with_normal) {
+            float sn = 0.f;
+#pragma unroll
+            for (int c = 0; c < kRelCopies - 1; ++c) {
+                const float v = ws.nrm_extra[c * ws.rel_copy_stride + i];
+                if (v != 0.f) { sn += v; ws.nrm_extra[c * ws.rel_copy_stride + i] = 0.f; }
+            }
+            if (sn != 0.f) ws.nrm_grad[i] += sn;
+        }
     }
 }
 
@@ -497,7 +742,8 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
                 const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
-    const bool grouped = cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN;
+    const bool transh = cfg.score_kind == OEA_SCORE_TRANSH;
+    const bool grouped = transh || (cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
     const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
     // profiling marks, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3]; a GRAD call records the first pair and
@@ -505,20 +751,25 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     if (phase != OEA_PHASE_APPLY) {
         oea::prof_call();
         oea::prof_mark(st);
-        if (grouped)
+        if (transh)
+            triple_transh_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
+        else if (grouped)
             triple_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, cfg.neg_group_k, cfg, ws);
         else
             triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         oea::prof_mark(st);
         if (phase == OEA_PHASE_GRAD)
             fold_rel_copies_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rel * (int64_t)ld, 256), 1024), 256, 0, st>>>(
-                ws, n_rel * (int64_t)ld);
+                ws, n_rel * (int64_t)ld, transh ? 1 : 0);
     }
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
         oea::prof_mark(st);
         apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum,
                                                  phase == OEA_PHASE_APPLY);
+        if (transh)
+            apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1), block, 0, st>>>(
+                n_rel, ld, cfg, ws, phase == OEA_PHASE_APPLY);
         oea::prof_mark(st);
     }
     return 0;
@@ -562,6 +813,12 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
         OEA_REQUIRE(n_neg == 0, "positive-only loss takes no negatives");
     OEA_REQUIRE(cfg->neg_group_k >= 0 && (cfg->neg_group_k == 0 || n_neg == n_pos * (int64_t)cfg->neg_group_k),
                 "neg_group_k > 0 needs n_neg == n_pos * neg_group_k");
+    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE || cfg->score_kind == OEA_SCORE_TRANSH, "score_kind");
+    if (cfg->score_kind == OEA_SCORE_TRANSH) {
+        OEA_REQUIRE(cfg->normal && (cfg->opt_kind != OEA_OPT_ADAGRAD || cfg->normal_acc), "TransH needs the normal_vector table (+ accumulator)");
+        OEA_REQUIRE(cfg->loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg->neg_group_k > 0),
+                    "TransH: per-triple loss and negatives in the sampler's grouped layout");
+    }
     if (n_pos + n_neg == 0 && phase != OEA_PHASE_APPLY) return OEA_OK;   // apply-only: externally scattered gradients
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);

@@ -90,10 +90,16 @@ class BasicModel:
         import torch.distributed as tdist
         return tdist.group.WORLD if mdist.world()[1] > 1 else None
 
-    def _step_cfg(self, loss_cfg, neg_group_k):
+    def _step_cfg(self, loss_cfg, neg_group_k, normal=None):
+        """normal: EmbeddingTable of TransH normal vectors -> the step scores projected rows and trains it
+        (its own Adagrad accumulator, created here: one per generate_optimizer call)."""
         cfg = generate_optimizer(loss_cfg, self.args.learning_rate, opt=self.args.optimizer)
+        nv = na = None
+        if normal is not None:
+            nv = normal.var
+            na = torch.full_like(nv, 0.1) if cfg['optimizer'] == 'Adagrad' else None
         return ops.make_step_cfg(ent_l2_norm=self.ent_embeds.is_l2_norm, rel_l2_norm=self.rel_embeds.is_l2_norm,
-                                 neg_group_k=neg_group_k, **cfg), cfg['optimizer']
+                                 neg_group_k=neg_group_k, normal=nv, normal_acc=na, **cfg), cfg['optimizer']
 
     def _define_embed_graph(self):
         """basic_model.py:80-98: lookups + get_loss_func + generate_optimizer."""

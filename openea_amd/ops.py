@@ -87,12 +87,16 @@ def normalize_rows_(table, dim, sklearn=True):
 
 def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, neg_margin=0.0,
                   balance=1.0, ent_l2_norm=True, rel_l2_norm=True, optimizer='Adagrad', lr=0.01,
-                  neg_group_k=0):
+                  neg_group_k=0, normal=None, normal_acc=None):
     """neg_group_k = k when the negatives are laid out as the device sampler writes them
-    (neg[p*k:(p+1)*k] corrupt pos p); 0 for arbitrary lists."""
-    return StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
-                   float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
-                   OPT_KIND[optimizer], float(lr), int(neg_group_k))
+    (neg[p*k:(p+1)*k] corrupt pos p); 0 for arbitrary lists.
+    normal (+ normal_acc for Adagrad): device [n_rel, ld] normal_vector table -> TransH scoring."""
+    cfg = StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
+                  float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
+                  OPT_KIND[optimizer], float(lr), int(neg_group_k), 0 if normal is None else 1,
+                  None if normal is None else normal.data_ptr(), None if normal_acc is None else normal_acc.data_ptr())
+    cfg._keep = (normal, normal_acc)
+    return cfg
 
 
 def step_workspace(n_ent, n_rel, ld, dev=None):

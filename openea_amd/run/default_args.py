@@ -23,6 +23,11 @@ _ARGS = {
                    batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2, neg_sampling="truncated",
                    neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10, eval_metric="inner", eval_norm=False,
                    sim_th=0.7, k=10, likelihood_slice=10, sub_epoch=10),
+    "BootEA_TransH": dict(embedding_module="BootEA_TransH", alignment_module="swapping", dim=100, init="normal",
+                          ent_l2_norm=True, rel_l2_norm=True, loss="limited", loss_norm="L2", learning_rate=0.01,
+                          optimizer="Adagrad", batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2,
+                          neg_sampling="truncated", neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10,
+                          eval_metric="inner", eval_norm=False, sim_th=0.7, k=10, likelihood_slice=10, sub_epoch=10),
     "GCN_Align": dict(embedding_module="GCN_Align", alignment_module="mapping", dim=100, neg_sampling="uniform",
                       neg_triple_num=5, learning_rate=8, batch_size=5000, test_threads_num=3, eval_metric="manhattan",
                       eval_norm=False, support_number=1, se_dim=100, ae_dim=100, hidden1=100, gamma=3,
@@ -43,6 +48,7 @@ _SCALE_100K = {
     "MTransE": dict(batch_size=20000),
     "AlignE": dict(batch_size=20000, truncated_epsilon=0.98),
     "BootEA": dict(batch_size=20000, truncated_epsilon=0.98),
+    "BootEA_TransH": dict(batch_size=20000, truncated_epsilon=0.98),
     "GCN_Align": dict(batch_size=20000, learning_rate=25),
     "AliNet": dict(batch_size=20000, truncated_epsilon=0.995, min_rel_win=15),
     "RDGCN": dict(batch_size=20000, learning_rate=0.001, start_valid=50),

@@ -196,6 +196,23 @@ def triple_step(ent, ent_acc, rel, rel_acc, pos, neg, *, loss="limited", loss_no
                                     C.c_int(0 if neg is None else len(neg)), C.byref(cfg))
 
 
+def triple_step_transh(ent, ent_acc, rel, rel_acc, nrm, nrm_acc, pos, neg, *, loss="limited", loss_norm="L2",
+                       margin=0.0, pos_margin=0.01, neg_margin=2.0, balance=1.0, ent_l2_norm=True,
+                       rel_l2_norm=True, optimizer="Adagrad", lr=0.01):
+    """TransH step (bootea_transh.py:58-96) in place on fp32 tables; returns the batch loss."""
+    for a in (ent, rel, nrm):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    pos = _i32(pos).reshape(-1, 3)
+    neg = _i32(neg).reshape(-1, 3) if neg is not None and len(neg) else None
+    cfg = StepCfg(LOSS[loss], 1 if loss_norm == "L1" else 0, margin, pos_margin, neg_margin,
+                  balance, int(bool(ent_l2_norm)), int(bool(rel_l2_norm)), OPT[optimizer], lr)
+    f = lib().oracle_triple_step_transh
+    f.restype = C.c_double
+    return f(_p(ent), _p(ent_acc), C.c_int(ent.shape[0]), _p(rel), _p(rel_acc), _p(nrm), _p(nrm_acc),
+             C.c_int(rel.shape[0]), C.c_int(ent.shape[1]), _p(pos), C.c_int(len(pos)), _p(neg),
+             C.c_int(0 if neg is None else len(neg)), C.byref(cfg))
+
+
 def spmm_coo(rows, cols, vals, x, n_rows):
     rows, cols, vals, x = _i32(rows), _i32(cols), _f32(vals), _f32(x)
     y = np.empty((n_rows, x.shape[1]), np.float32)

@@ -365,3 +365,57 @@ def test_spmm_bit_exact(ops, d):
                       act=1, mask_from=ops.to_table(mask), split=split)
     np.testing.assert_allclose(ym.cpu().numpy()[:, :d], np.maximum(ref, 0) * (mask > 0), rtol=2e-5, atol=5e-4)
     assert np.array_equal(ym.cpu().numpy()[short][:, :d], (np.maximum(ref, 0) * (mask > 0))[short])
+
+
+# ---------------------------------------------------------------------------------------------
+# TransH scoring (approaches/bootea_transh.py:58-96)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,k,loss,opt", [(40, 5, "limited", "Adagrad"), (75, 10, "limited", "Adagrad"),
+                                           (100, 3, "logistic", "SGD"), (32, 0, "positive", "Adagrad")])
+def test_transh_step_matches_oracle(ops, d, k, loss, opt):
+    import torch
+    from oracle import cport
+    rng = np.random.RandomState(d + k)
+    n_ent, n_rel, n_pos = 600, 17, 400
+    ent = rng.standard_normal((n_ent, d)).astype(np.float32)
+    rel = rng.standard_normal((n_rel, d)).astype(np.float32)
+    nrm = rng.standard_normal((n_rel, d)).astype(np.float32)
+    pos = np.stack([rng.randint(0, n_ent, n_pos), np.minimum(rng.zipf(1.6, n_pos) - 1, n_rel - 1),
+                    rng.randint(0, n_ent, n_pos)], 1).astype(np.int32)
+    neg = None
+    if k:
+        neg = np.repeat(pos, k, axis=0)
+        ch = rng.rand(n_pos * k) < 0.5
+        rnd = rng.randint(0, n_ent, n_pos * k)
+        neg[ch, 0] = rnd[ch]
+        neg[~ch, 2] = rnd[~ch]
+        neg[7] = [3, 2, 5]                                 # entries that are not corruptions of their positive
+        neg[8, 1] = (neg[8, 1] + 1) % n_rel
+    kw = dict(loss=loss, loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer=opt, lr=0.01)
+    # oracle
+    e0, r0, n0 = ent.copy(), rel.copy(), nrm.copy()
+    ea, ra, na = (np.full_like(x, 0.1) for x in (e0, r0, n0))
+    ref_loss = 0.0
+    for _ in range(2):                                     # two steps: accumulators + a clean scratch in between
+        ref_loss += cport.triple_step_transh(e0, ea, r0, ra, n0, na, pos, neg, **kw)
+    # device
+    te, tr, tn = ops.to_table(ent), ops.to_table(rel), ops.to_table(nrm)
+    tea, tra, tna = (torch.full_like(x, 0.1) for x in (te, tr, tn))
+    cfg = ops.make_step_cfg(neg_group_k=k, normal=tn, normal_acc=tna, **kw)
+    ws = ops.step_workspace(n_ent, n_rel, te.shape[1])
+    acc = torch.zeros(1, dtype=torch.float64, device=te.device)
+    for _ in range(2):
+        ops.triple_step(te, tea, tr, tra, d, ops.to_ids(pos), None if neg is None else ops.to_ids(neg), cfg, ws, acc)
+    assert abs(float(acc.item()) - ref_loss) <= 2e-5 * abs(ref_loss)
+    for got, ref in ((te, e0), (tr, r0), (tn, n0)):
+        assert np.linalg.norm(got[:, :d].cpu().numpy() - ref) <= 1e-4 * np.linalg.norm(ref)
+    assert int(ws[: -8 * 4096].count_nonzero()) == 0       # scratch (incl. the normal-vector copies) left clean
+    # the exchange-split step (data parallelism) gives the same update
+    te2, tr2, tn2 = ops.to_table(ent), ops.to_table(rel), ops.to_table(nrm)
+    tea2, tra2, tna2 = (torch.full_like(x, 0.1) for x in (te2, tr2, tn2))
+    cfg2 = ops.make_step_cfg(neg_group_k=k, normal=tn2, normal_acc=tna2, **kw)
+    for _ in range(2):
+        for phase in (ops.PHASE_GRAD, ops.PHASE_APPLY):
+            ops.triple_step(te2, tea2, tr2, tra2, d, ops.to_ids(pos), None if neg is None else ops.to_ids(neg), cfg2, ws, acc, phase=phase)
+    for a, b in ((te, te2), (tr, tr2), (tn, tn2)):
+        assert np.linalg.norm((a - b).cpu().numpy()) <= 2e-6 * np.linalg.norm(a.cpu().numpy())

@@ -60,6 +60,7 @@ def test_aligne_epoch_matches_oracle(kgs_small, tmp_path):
     ("MTransE", "mapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, eval_freq=4)),
     ("AlignE", "swapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, eval_freq=4, truncated_freq=4)),
     ("BootEA", "swapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, sub_epoch=4, sim_th=0.3)),
+    ("BootEA_TransH", "swapping", dict(dim=32, batch_size=2000, max_epoch=12, start_valid=4, sub_epoch=4, sim_th=0.3)),
 ])
 def test_translational_models_end_to_end(kgs_small, tmp_path, name, mode, kw, capsys):
     import openea_amd.approaches as approaches
