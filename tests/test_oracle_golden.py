@@ -137,3 +137,48 @@ def test_sparse_attention_oracle_gradient_by_finite_differences():
         num = ((orc.sparse_attn_forward(z, vp, seg_ptr, seg_row, colidx, n_rows)[0] -
                 orc.sparse_attn_forward(z, vm, seg_ptr, seg_row, colidx, n_rows)[0]) * w).sum() / (2 * eps)
         assert abs(num - dv[j, c]) < 1e-6
+
+
+def test_transh_oracle_gradients_by_finite_differences():
+    """oracle_triple_step_transh restates TF1 autodiff of bootea_transh.py:58-96 by hand (PARITY UNPINNED vs TF):
+    pin the hand-derived gradients against central differences of the loss written independently in numpy."""
+    from oracle import cport
+    rng = np.random.RandomState(0)
+    n_ent, n_rel, d = 12, 3, 7
+    ent = rng.standard_normal((n_ent, d)).astype(np.float32)
+    rel = rng.standard_normal((n_rel, d)).astype(np.float32)
+    nrm = rng.standard_normal((n_rel, d)).astype(np.float32)
+    pos = np.array([[0, 1, 2], [3, 1, 4], [5, 0, 6]], np.int32)
+    neg = np.array([[0, 1, 7], [8, 1, 2], [3, 1, 9], [5, 0, 1], [10, 0, 6], [5, 0, 11]], np.int32)
+
+    def l2n(x):
+        return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))
+
+    def loss_of(e, r, n):
+        e, r, n = l2n(e), l2n(r), l2n(l2n(n))
+
+        def sc(tr):
+            h, t, rr, nn = e[tr[:, 0]], e[tr[:, 2]], r[tr[:, 1]], n[tr[:, 1]]
+            hp = h - (h * nn).sum(1, keepdims=True) * nn
+            tp = t - (t * nn).sum(1, keepdims=True) * nn
+            return ((hp + rr - tp) ** 2).sum(1)
+        return np.maximum(sc(pos) - 0.01, 0).sum() + 0.2 * np.maximum(2.0 - sc(neg), 0).sum()
+
+    lr = 1e-3
+    tabs = [ent.copy(), rel.copy(), nrm.copy()]
+    loss = cport.triple_step_transh(tabs[0], None, tabs[1], None, tabs[2], None, pos, neg, loss="limited", pos_margin=0.01,
+                                    neg_margin=2.0, balance=0.2, optimizer="SGD", lr=lr)
+    base = [ent.astype(np.float64), rel.astype(np.float64), nrm.astype(np.float64)]
+    assert abs(loss - loss_of(*base)) < 1e-6
+    eps = 1e-4
+    for idx in range(3):
+        analytic = (base[idx] - tabs[idx]) / lr                    # SGD: v' = v - lr * grad
+        num = np.zeros_like(analytic)
+        for i in range(analytic.shape[0]):
+            for k in range(d):
+                a = [x.copy() for x in base]
+                b = [x.copy() for x in base]
+                a[idx][i, k] += eps
+                b[idx][i, k] -= eps
+                num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
+        assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)   # fp32 table rounding of the update
