@@ -182,3 +182,91 @@ def test_transh_oracle_gradients_by_finite_differences():
                 b[idx][i, k] -= eps
                 num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
         assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)   # fp32 table rounding of the update
+
+
+@pytest.mark.parametrize("loss,l1", [("limited", False), ("margin-based", False), ("logistic", False), ("limited", True)])
+def test_triple_step_oracle_gradients_by_finite_differences(loss, l1):
+    """oracle_triple_step (losses.py:15-73 + l2_normalize + SGD) against central differences of the loss written
+    independently in numpy -- pins the hand-derived TF1 gradient (through the normalisation, duplicates summed)."""
+    from oracle import cport
+    rng = np.random.RandomState(1)
+    n_ent, n_rel, d = 10, 3, 6
+    ent = rng.standard_normal((n_ent, d)).astype(np.float32)
+    rel = rng.standard_normal((n_rel, d)).astype(np.float32)
+    pos = np.array([[0, 1, 2], [3, 1, 4], [0, 0, 6], [7, 2, 0]], np.int32)           # entity 0 occurs three times
+    neg = np.array([[0, 1, 7], [8, 1, 4], [9, 0, 6], [7, 2, 5]], np.int32)
+
+    def l2n(x):
+        return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))
+
+    def score(e, r, tr):
+        dd = e[tr[:, 0]] + r[tr[:, 1]] - e[tr[:, 2]]
+        return np.abs(dd).sum(1) if l1 else (dd * dd).sum(1)
+
+    def loss_of(e, r):
+        e, r = l2n(e), l2n(r)
+        sp_, sn = score(e, r, pos), score(e, r, neg)
+        if loss == "margin-based":
+            return np.maximum(1.5 + sp_ - sn, 0).sum()
+        if loss == "limited":
+            return np.maximum(sp_ - 0.01, 0).sum() + 0.2 * np.maximum(2.0 - sn, 0).sum()
+        return np.log1p(np.exp(sp_)).sum() + np.log1p(np.exp(-sn)).sum()
+
+    lr = 1e-3
+    e1, r1 = ent.copy(), rel.copy()
+    got = cport.triple_step(e1, None, r1, None, pos, neg, loss=loss, loss_norm="L1" if l1 else "L2", margin=1.5,
+                            pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="SGD", lr=lr)
+    base = [ent.astype(np.float64), rel.astype(np.float64)]
+    assert abs(got - loss_of(*base)) < 1e-6 * max(1.0, abs(got))
+    eps = 1e-5 if l1 else 1e-4
+    for idx, new in enumerate((e1, r1)):
+        analytic = (base[idx] - new) / lr
+        num = np.zeros_like(analytic)
+        for i in range(analytic.shape[0]):
+            for k in range(d):
+                a = [x.copy() for x in base]
+                b = [x.copy() for x in base]
+                a[idx][i, k] += eps
+                b[idx][i, k] -= eps
+                num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
+        assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
+
+
+def test_gcn_epoch_oracle_gradient_by_finite_differences():
+    """gcn_se_epoch (gcn_align.py:204-320,498-539 restated): dW against central differences of the hinge loss."""
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(2)
+    n, d, t, k = 14, 5, 4, 3
+    W = rng.standard_normal((n, d)).astype(np.float32)
+    coords = np.array([(i, j) for i in range(n) for j in range(n) if rng.rand() < 0.3], np.int64)
+    values = rng.rand(len(coords)).astype(np.float32)
+    ILL = np.stack([rng.permutation(n)[:t], rng.permutation(n)[:t]], 1)
+    negs = (np.repeat(ILL[:, 0], k), rng.randint(0, n, t * k), rng.randint(0, n, t * k), np.repeat(ILL[:, 1], k))
+    import scipy.sparse as sp
+    A = sp.csr_matrix((values.astype(np.float64), (coords[:, 0], coords[:, 1])), shape=(n, n))
+
+    def loss_of(Wd):
+        T = Wd / np.sqrt(np.maximum((Wd ** 2).sum(1, keepdims=True), 1e-12))
+        out = A @ np.maximum(A @ T, 0.0)
+        a = np.abs(out[ILL[:, 0]] - out[ILL[:, 1]]).sum(1)
+        l = 0.0
+        for nl, nr in ((negs[0], negs[1]), (negs[2], negs[3])):
+            b = np.abs(out[nl] - out[nr]).sum(1).reshape(t, k)
+            l += np.maximum(a[:, None] + 3.0 - b, 0).sum()
+        return l / (2.0 * k * t)
+
+    lr = 1e-3
+    W1 = W.copy()
+    loss, _ = orc.gcn_se_epoch(W1, coords, values, ILL, 3.0, k, negs, lr)
+    Wd = W.astype(np.float64)
+    assert abs(loss - loss_of(Wd)) < 1e-9
+    analytic = (Wd - W1) / lr
+    num = np.zeros_like(analytic)
+    eps = 1e-6
+    for i in range(n):
+        for c in range(d):
+            a, b = Wd.copy(), Wd.copy()
+            a[i, c] += eps
+            b[i, c] -= eps
+            num[i, c] = (loss_of(a) - loss_of(b)) / (2 * eps)
+    assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
