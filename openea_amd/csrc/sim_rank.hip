@@ -494,19 +494,19 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int32_t *__res
 }
 
 // ---- per-row top-k mean (CSLS) -------------------------------------------------------------------
-// One wave per row.  Each lane keeps the KMAX largest values of its strided slice sorted in
-// registers; the 64 sorted lists are then merged by k rounds of wave-wide "largest head",
-// accumulating in DESCENDING order exactly like oracle_topk_mean.
+// One wave per row, k <= 32.  Pass 1: every lane takes the maximum of its strided slice; the k-th largest of
+// the 64 lane maxima is a lower bound L of the row's k-th largest value (they are k distinct entries >= L).
+// Pass 2 (the row is L2-hot): the handful of entries >= L -- about k of them -- go to an LDS list.  The k
+// largest of the list are then taken by k rounds of wave-wide "largest head" and summed in DESCENDING order
+// exactly like oracle_topk_mean.  Rows with more than kCandMean entries >= L (constant / heavily tied rows)
+// fall back to per-lane sorted insertion lists (the previous algorithm).
+constexpr int kCandMean = 256;
+
 template <int KMAX>
-__global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restrict__ s, int64_t n1, int64_t n2,
-                                                            int64_t ld, int k, float *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= n1) return;
+__device__ float topk_mean_by_insertion(const float *__restrict__ src, int64_t n2, int k, int lane) {
     float top[KMAX];
 #pragma unroll
     for (int p = 0; p < KMAX; ++p) top[p] = -INFINITY;
-    const float *src = s + row * ld;
     for (int64_t j = lane; j < n2; j += 64) {
         float v = src[j];
         if (v > top[KMAX - 1]) {
@@ -526,13 +526,101 @@ __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restr
         float m = head;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        // lowest lane holding the maximum advances
-        const unsigned long long bal = __ballot(head == m);
+        const unsigned long long bal = __ballot(head == m);      // lowest lane holding the maximum advances
         const int winner = __ffsll((long long)bal) - 1;
         if (lane == winner) ++taken;
         acc += m;
     }
-    if (lane == 0) out[row] = acc / (float)k;
+    return acc / (float)k;
+}
+
+__global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restrict__ s, int64_t n1, int64_t n2,
+                                                            int64_t ld, int k, float *__restrict__ out) {
+    __shared__ float s_cand[4][kCandMean];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= n1) return;                                   // whole waves leave: no block-wide barrier below
+    const float *src = s + row * ld;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(s) & 15) == 0);
+    const int64_t n4 = vec ? (n2 & ~(int64_t)3) : 0;        // [0, n4) by float4, the rest scalar
+    // ---- pass 1: lane maxima -> L ------------------------------------------------------------------
+    float mx = -INFINITY;
+    constexpr int U = 4;                                     // 16-byte loads in flight per lane
+    for (int64_t j0 = (int64_t)lane * 4; j0 < n4; j0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + u * 256;
+            v[u] = j < n4 ? *reinterpret_cast<const float4 *>(src + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx = fmaxf(fmaxf(mx, fmaxf(v[u].x, v[u].y)), fmaxf(v[u].z, v[u].w));
+    }
+    for (int64_t j = n4 + lane; j < n2; j += 64) mx = fmaxf(mx, src[j]);
+    float head = mx, L = -INFINITY;
+    for (int round = 0; round < k; ++round) {                // k <= 64 distinct lanes exist only if n2 >= 64 * ...; else L = -inf
+        float m = head;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const unsigned long long bal = __ballot(head == m);
+        if (lane == __ffsll((long long)bal) - 1) head = -INFINITY;
+        L = m;
+    }
+    // ---- pass 2: entries >= L -----------------------------------------------------------------------
+    if (lane == 0) s_cnt[wave] = 0;
+    __builtin_amdgcn_wave_barrier();
+    float *cand = s_cand[wave];
+    for (int64_t j0 = (int64_t)lane * 4; j0 < n4; j0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + u * 256;
+            v[u] = j < n4 ? *reinterpret_cast<const float4 *>(src + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u * 256 >= n4) continue;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (vv[q] >= L) { const int at = atomicAdd(&s_cnt[wave], 1); if (at < kCandMean) cand[at] = vv[q]; }
+        }
+    }
+    for (int64_t j = n4 + lane; j < n2; j += 64) {
+        const float v = src[j];
+        if (v >= L) { const int at = atomicAdd(&s_cnt[wave], 1); if (at < kCandMean) cand[at] = v; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int cnt = s_cnt[wave];
+    float result;
+    if (cnt > kCandMean || cnt < k) {                        // wave-uniform
+        result = k <= 16 ? topk_mean_by_insertion<16>(src, n2, k, lane) : topk_mean_by_insertion<32>(src, n2, k, lane);
+    } else {
+        float c[kCandMean / 64];
+#pragma unroll
+        for (int u = 0; u < kCandMean / 64; ++u) c[u] = (u * 64 + lane) < cnt ? cand[u * 64 + lane] : -INFINITY;
+        float acc = 0.f;
+        for (int round = 0; round < k; ++round) {
+            float h = c[0];
+#pragma unroll
+            for (int u = 1; u < kCandMean / 64; ++u) h = fmaxf(h, c[u]);
+            float m = h;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            const unsigned long long bal = __ballot(h == m);
+            if (lane == __ffsll((long long)bal) - 1) {       // remove ONE instance of the maximum
+                bool done = false;
+#pragma unroll
+                for (int u = 0; u < kCandMean / 64; ++u)
+                    if (!done && c[u] == m) { c[u] = -INFINITY; done = true; }
+            }
+            acc += m;
+        }
+        result = acc / (float)k;
+    }
+    if (lane == 0) out[row] = result;
 }
 
 __global__ void csls_apply_kernel(float *__restrict__ s, int64_t n1, int64_t n2, int64_t ld,
@@ -683,8 +771,7 @@ int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_
     if (n1 == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
     const unsigned grid = (unsigned)oea::ceil_div(n1, 4);
-    if (k <= 16) row_topk_mean_kernel<16><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
-    else row_topk_mean_kernel<32><<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
+    row_topk_mean_kernel<<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

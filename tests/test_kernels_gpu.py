@@ -103,6 +103,24 @@ def test_rank_metrics(ops):
     assert abs(rr / len(rank) - mrr) < 1e-12
 
 
+@pytest.mark.parametrize("n2,k", [(1031, 10), (12, 10), (64, 1), (5000, 32), (257, 16)])
+def test_row_topk_mean_edge_cases(ops, n2, k):
+    """calculate_nearest_k (similarity.py:80-83): ties, constant rows (more than 256 entries at the threshold ->
+    insertion fallback), -inf entries, short rows, rows that are not 16-byte aligned; bit-exact vs the oracle."""
+    import torch
+    from oracle import cport
+    rng = np.random.RandomState(n2 + k)
+    rows = [rng.standard_normal(n2), np.zeros(n2), np.round(rng.standard_normal(n2) * 3) / 3,
+            np.where(rng.rand(n2) < 0.5, -np.inf, rng.standard_normal(n2)), -np.arange(n2, dtype=np.float64),
+            np.arange(n2, dtype=np.float64)]
+    s = np.stack(rows).astype(np.float32)
+    if np.isinf(s[3]).sum() > n2 - k:
+        s[3, :k] = 1.0
+    ref = cport.topk_mean(s, k, axis=1)
+    got = ops.row_topk_mean(torch.from_numpy(s).to(ops.device()), k).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
 def test_calculate_rank_block_matches_oracle(ops):
     """calculate_rank (alignment.py:146-168) on an explicit row block with ties: oea_rank_rows."""
     from oracle import np_oracle as orc

@@ -35,6 +35,13 @@ def main():
     ops.lib()
     rng = np.random.RandomState(0)
     only = os.environ.get("LEGS", "")          # LEGS=eval70k: just the 70,000^2 inner eval (PMC passes)
+    if only == "csls":
+        n, d = 10500, 100
+        e1 = unit(rng, n, d)
+        t1 = ops.to_table(e1)
+        t2 = ops.to_table(e1 + 0.4 * unit(rng, n, d))
+        timed("eval csls10  %6d^2 x %d" % (n, d), lambda: greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, 10), reps=5)
+        return
     if only == "eval70k":
         n, d = 70000, 100
         e1 = unit(rng, n, d)
