@@ -35,7 +35,9 @@ def main():
         p = os.path.join(src, log)
         if os.path.exists(p):
             lines = [l for l in open(p) if not l.startswith("/opt/amdgpu")]
-            open(os.path.join(prof, "%s_%s" % (name, log.replace(".log", "_stdout.txt"))), "w").writelines(lines[-40:])
+            note = "# stdout of the run UNDER rocprofv3 --kernel-trace: wall-clock figures are inflated by the tracer;\n" \
+                   "# the kernel durations in the *_kernel_stats.csv next to this file are what DESIGN.md cites.\n"
+            open(os.path.join(prof, "%s_%s" % (name, log.replace(".log", "_stdout.txt"))), "w").writelines([note] + lines[-40:])
     fetch, n = pmc_avg(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     write, _ = pmc_avg(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     rows = []
@@ -48,7 +50,7 @@ def main():
     dom = [r for r in rows if "triple_grouped" in r[0]]
     if dom:
         r = dom[0]
-        json.dump({"kernel": r[0].split("(")[0].replace("void (anonymous namespace)::", ""),
+        json.dump({"kernel": r[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_pmc_hbm_traffic.csv" % name,
                    "FETCH_SIZE_KB": r[2], "WRITE_SIZE_KB": r[3],
                    "correction": "gfx950: FETCH_SIZE reads 1/2 of the bytes (MI355X_MICROARCH.md HBM section) -> 2*FETCH + WRITE",
