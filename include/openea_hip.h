@@ -213,6 +213,24 @@ int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, floa
                      int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
                      const int64_t *offsets_dev, const int64_t *splits_dev, void *stream);
 
+/* Negative LINKS of AliNet.generate_input_batch (approaches/alinet.py:988-1006), drawn on the device.
+ *   uniform   (nbr1 == NULL): pair q = round * n_pos + i, round < k:  (ents1[pi1_round(i)], ents2[pi2_round(i)])
+ *             -- zip(random.sample(ents1, n_pos), random.sample(ents2, n_pos)) per round; needs n_pos <= n1, n2;
+ *   truncated (nbr1 != NULL): pair q = link * 2k + slot:  slot < k: (e1, nbr1[row1[e1]][pi(slot)]),
+ *             else (nbr2[row2[e2]][pi'(slot - k)], e2) -- random.sample(neighbors[e], k); needs k <= nbr_k;
+ *             nbr1/nbr2: int32 [rows, nbr_k] neighbour entity ids, row1/row2: entity id -> row.
+ * pi = keyed pseudo-random permutation (oea_perm_index; key from Philox4x32-10(seed; round | link, step)), i.e. draws
+ * without replacement.  out_pairs int32 [m, 2] holds every draw, out_valid fp32 [m] is 1 for the pairs of
+ * set(pairs) - exclude (first of equal pairs; exclude = oea_tripleset_build over (e1, 0, e2) triples, or NULL), 0 for
+ * the rest.  m = k * n_pos (uniform) or 2 * k * n_pos.  scratch_keys / scratch_vals: uint64 / int32 [scratch_cap],
+ * scratch_cap a power of two >= 2 m.  Errors mirror random.sample ("Sample larger than population"). */
+uint32_t oea_perm_index(uint32_t i, uint32_t n, uint32_t key);
+int oea_sample_link_negatives(const int32_t *pos_links, int64_t n_pos, int32_t k, const int32_t *ents1, int32_t n1,
+                              const int32_t *ents2, int32_t n2, const int32_t *nbr1, const int32_t *row1,
+                              const int32_t *nbr2, const int32_t *row2, int32_t nbr_k, const uint64_t *exclude,
+                              uint64_t exclude_cap, uint64_t seed, uint32_t step, int32_t *out_pairs, float *out_valid,
+                              uint64_t *scratch_keys, int32_t *scratch_vals, uint64_t scratch_cap, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):
  * np.matmul(sub_embed, embed.T) + per-row np.argpartition(-row, k)[:k].

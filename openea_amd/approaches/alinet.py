@@ -186,6 +186,44 @@ class DeviceSim:
         return v
 
 
+class DeviceNeighbours:
+    """neighbors dict of AliNet.find_neighbors (alinet.py:1019-1039): entity -> its `num` nearest cross-KG entities.
+    The table stays on the device (the negative sampler reads it there); dict-style access copies it to the host
+    once, on first use."""
+
+    def __init__(self, ents, table, n_entities):
+        self.ents = list(ents)
+        self.table = table                                        # device int32 [len(ents), num]
+        row = np.full(n_entities, -1, np.int32)
+        row[np.asarray(self.ents, np.int64)] = np.arange(len(self.ents), dtype=np.int32)
+        self.row = ops.to_ids(row, table.device)                  # entity id -> row
+        self._row_host = row
+        self._host = None
+
+    def _h(self):
+        if self._host is None:
+            self._host = self.table.cpu().numpy()
+        return self._host
+
+    def __len__(self):
+        return len(self.ents)
+
+    def __contains__(self, e):
+        return 0 <= e < len(self._row_host) and self._row_host[e] >= 0
+
+    def __getitem__(self, e):
+        return self._h()[self._row_host[e]].tolist()
+
+    def get(self, e, default=None):
+        return self[e] if e in self else default
+
+    def keys(self):
+        return iter(self.ents)
+
+    def values(self):
+        return (r.tolist() for r in self._h())
+
+
 class AKG:
     """alinet.py:459-493 (the attributes the path uses)."""
 
@@ -366,12 +404,14 @@ class AliNet(BasicModel):
         """alinet.py:835-840: l2n(concat(l2n(out_0), ..., l2n(init)))."""
         return l2n(torch.cat([l2n(o) for o in outs + [self.init_embedding]], dim=1))
 
-    def compute_loss(self, emb, pos_links, neg_links):
-        """alinet.py:828-850."""
+    def compute_loss(self, emb, pos_links, neg_links, neg_valid=None):
+        """alinet.py:828-850.  neg_valid: 0/1 weights of the drawn pairs (device sampler: duplicates and
+        supervised pairs carry 0 instead of being removed from the list)."""
         e1, e2 = emb[pos_links[:, 0]], emb[pos_links[:, 1]]
         pos_loss = ((e1 - e2) ** 2).sum()
         n1, n2 = emb[neg_links[:, 0]], emb[neg_links[:, 1]]
-        neg_loss = torch.relu(self.args.neg_margin - ((n1 - n2) ** 2).sum(1)).sum()
+        hinge = torch.relu(self.args.neg_margin - ((n1 - n2) ** 2).sum(1))
+        neg_loss = hinge.sum() if neg_valid is None else (hinge * neg_valid).sum()
         return pos_loss + self.args.neg_margin_balance * neg_loss
 
     def compute_rel_loss(self, emb, hs, ts):
@@ -401,14 +441,49 @@ class AliNet(BasicModel):
         neg_links = set(neg_links) - self.sup_links_set - self.new_sup_links_set
         return pos_links, np.array(list(neg_links), np.int64).reshape(-1, 2)
 
+    def device_input_batch(self, batch_size, neighbors1=None, neighbors2=None):
+        """generate_input_batch with the negatives drawn on the device (csrc/link_sampler.hip) ->
+        (pos_links int64 [b, 2], neg pairs int64 [m, 2], valid fp32 [m]), all device tensors."""
+        dev = self.dev
+        batch_size = min(batch_size, len(self.sup_ent1))
+        index = np.random.choice(len(self.sup_ent1), batch_size)              # with replacement (alinet.py:986)
+        if getattr(self, "_sup_links_dev", None) is None:
+            self._sup_links_dev = torch.as_tensor(self.sup_links, device=dev)
+            self._ents1_dev = ops.to_ids(np.asarray(self.sup_ent1 + self.ref_ent1, np.int32), dev)
+            self._ents2_dev = ops.to_ids(np.asarray(self.sup_ent2 + self.ref_ent2, np.int32), dev)
+            self._neg_step, self._link_scratch, self._excl, self._excl_of = 0, None, None, None
+        pos = self._sup_links_dev[torch.as_tensor(index, device=dev)]
+        excl_links = self.sup_links_set | self.new_sup_links_set              # sup_links_set stays empty in the reference too
+        if self._excl_of is not excl_links and self._excl_of != excl_links:
+            self._excl = ops.tripleset_build(ops.to_ids(np.asarray([(a, 0, b) for a, b in excl_links], np.int32).reshape(-1, 3), dev)) \
+                if excl_links else None
+            self._excl_of = set(excl_links)
+        self._neg_step += 1
+        k = self.args.neg_triple_num
+        if neighbors1 is None:
+            pairs, valid, self._link_scratch = ops.sample_link_negatives(batch_size, k, ents1=self._ents1_dev, ents2=self._ents2_dev,
+                                                                         exclude=self._excl, seed=self._seed, step=self._neg_step,
+                                                                         scratch=self._link_scratch)
+        else:
+            pairs, valid, self._link_scratch = ops.sample_link_negatives(batch_size, k, pos_links=pos.to(torch.int32).contiguous(),
+                                                                         nbr1=neighbors1.table, row1=neighbors1.row,
+                                                                         nbr2=neighbors2.table, row2=neighbors2.row, exclude=self._excl,
+                                                                         seed=self._seed, step=self._neg_step, scratch=self._link_scratch)
+        return pos, pairs.long(), valid
+
     def generate_rel_batch(self):
-        hs, rs, ts = [], [], []
-        for r, hts in self.rel_ht_dict.items():
-            for h, t in (random.choice(hts) for _ in range(self.rel_win_size)):
-                hs.append(h)
-                ts.append(t)
-                rs.append(r)
-        return hs, rs, ts
+        """alinet.py:1009-1017: rel_win_size random (h, t) pairs per relation (random.choice each) -- index sampling
+        vectorised over a flat copy of rel_ht_dict."""
+        if getattr(self, "_rel_flat", None) is None:
+            rels = list(self.rel_ht_dict.keys())
+            lens = np.asarray([len(self.rel_ht_dict[r]) for r in rels], np.int64)
+            flat = np.asarray([ht for r in rels for ht in self.rel_ht_dict[r]], np.int64).reshape(-1, 2)
+            self._rel_flat = (np.asarray(rels), lens, np.concatenate([[0], np.cumsum(lens)])[:-1], flat)
+        rels, lens, start, flat = self._rel_flat
+        w = self.rel_win_size
+        pick = start[:, None] + (self._rng.random_sample((len(rels), w)) * lens[:, None]).astype(np.int64)
+        ht = flat[pick.reshape(-1)]
+        return ht[:, 0], np.repeat(rels, w), ht[:, 1]
 
     def augment(self):
         """alinet.py:885-898: candidate pairs = (i, argmax_j sim) with expit(sim) > sim_th, on the last layer's
@@ -464,10 +539,11 @@ class AliNet(BasicModel):
         emb2 = ops.gather_rows(last.contiguous(), d, ops.to_ids(np.asarray(ents2, np.int32), self.dev), normalize=True)
         num = int((1 - self.args.truncated_epsilon) * len(ents1))
         print("neighbors num", num)
-        n1 = ops.topk_inner(emb1, emb2, d, num, id_map=ops.to_ids(np.asarray(ents2, np.int32), self.dev)).cpu().numpy()
-        n2 = ops.topk_inner(emb2, emb1, d, num, id_map=ops.to_ids(np.asarray(ents1, np.int32), self.dev)).cpu().numpy()
+        n1 = ops.topk_inner(emb1, emb2, d, num, id_map=ops.to_ids(np.asarray(ents2, np.int32), self.dev))
+        n2 = ops.topk_inner(emb2, emb1, d, num, id_map=ops.to_ids(np.asarray(ents1, np.int32), self.dev))
+        torch.cuda.synchronize()
         print('finding neighbors for sampling costs time: {:.4f}s'.format(time.time() - start))
-        return {e: n1[i].tolist() for i, e in enumerate(ents1)}, {e: n2[i].tolist() for i, e in enumerate(ents2)}
+        return DeviceNeighbours(ents1, n1, self.kgs.entities_num), DeviceNeighbours(ents2, n2, self.kgs.entities_num)
 
     # ---- evaluation (alinet.py:922-966) -------------------------------------------------------------
     def _eval_embeds(self, ent1, ent2):
@@ -509,11 +585,11 @@ class AliNet(BasicModel):
         rd.save_embeddings(self.out_folder, self.kgs, ent_embeds, None, None, mapping_mat=None)
 
     # ---- training (alinet.py:1041-1079) -------------------------------------------------------------
-    def train_step(self, pos_links, neg_links, hs=None, ts=None):
+    def train_step(self, pos_links, neg_links, hs=None, ts=None, neg_valid=None):
         outs = self._forward()
         emb = self._concat_train(outs)
         dev = self.dev
-        loss = self.compute_loss(emb, torch.as_tensor(pos_links, device=dev), torch.as_tensor(neg_links, device=dev))
+        loss = self.compute_loss(emb, torch.as_tensor(pos_links, device=dev), torch.as_tensor(neg_links, device=dev), neg_valid)
         if hs is not None:
             loss = loss + self.compute_rel_loss(emb, torch.as_tensor(hs, device=dev), torch.as_tensor(ts, device=dev))
         loss.backward()
@@ -529,12 +605,12 @@ class AliNet(BasicModel):
             start = time.time()
             epoch_loss = 0.0
             for _ in range(steps):
-                pos, neg = self.generate_input_batch(self.args.batch_size, neighbors1, neighbors2)
+                pos, neg, valid = self.device_input_batch(self.args.batch_size, neighbors1, neighbors2)
                 if self.args.rel_param > 0:
                     hs, _, ts = self.generate_rel_batch()
-                    loss = self.train_step(pos, neg, hs, ts)
+                    loss = self.train_step(pos, neg, hs, ts, neg_valid=valid)
                 else:
-                    loss = self.train_step(pos, neg)
+                    loss = self.train_step(pos, neg, neg_valid=valid)
                 epoch_loss += float(loss.item())
             print('epoch {}, loss: {:.4f}, cost time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
             if epoch % self.args.eval_freq == 0 and epoch >= self.args.start_valid:

@@ -202,6 +202,29 @@ def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, s
                                  _p(offsets_dev), _p(splits_dev), _stream()))
 
 
+def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None, row2=None,
+                          exclude=None, seed=0, step=0, scratch=None):
+    """AliNet.generate_input_batch negatives on the device -> (pairs int32 [m, 2], valid fp32 [m]).
+    uniform: ents1 / ents2 (device int32 lists); truncated: pos_links [n_pos, 2] + nbr1/nbr2 [rows, nbr_k] + row maps.
+    exclude: tripleset over (e1, 0, e2) (tripleset_build) or None."""
+    truncated = nbr1 is not None
+    m = (2 if truncated else 1) * k * n_pos
+    dev = (nbr1 if truncated else ents1).device
+    pairs = torch.empty((m, 2), dtype=torch.int32, device=dev)
+    valid = torch.empty(m, dtype=torch.float32, device=dev)
+    cap = 2
+    while cap < 2 * max(m, 1):
+        cap *= 2
+    if scratch is None or scratch[0].numel() < cap:
+        scratch = (torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+    check(lib().oea_sample_link_negatives(_p(pos_links), n_pos, k, _p(ents1), 0 if ents1 is None else ents1.numel(),
+                                          _p(ents2), 0 if ents2 is None else ents2.numel(), _p(nbr1), _p(row1), _p(nbr2),
+                                          _p(row2), nbr1.shape[1] if truncated else 0, _p(exclude),
+                                          0 if exclude is None else exclude.numel(), int(seed), int(step), _p(pairs),
+                                          _p(valid), _p(scratch[0]), _p(scratch[1]), cap, _stream()))
+    return pairs, valid, scratch
+
+
 # -------------------------------------------------------------------------------------------
 # neighbour search / evaluation
 # -------------------------------------------------------------------------------------------

@@ -494,3 +494,65 @@ def stable_alignment(sim_mat, cut=100):
     kg1 = {i: np.argsort(-sim_mat[i], kind="stable").tolist() for i in range(sim_mat.shape[0])}
     kg2 = {j: np.argsort(-sim_mat[:, j], kind="stable").tolist() for j in range(sim_mat.shape[1])}
     return galeshapley(kg1, kg2, cut)
+
+
+# ----------------------------------------------------------------------------------------
+# AliNet negative links (alinet.py:988-1006) -- the device formulation restated
+# ----------------------------------------------------------------------------------------
+def _feistel_f(r, key, rnd):
+    m = 0xFFFFFFFF
+    v = (r * 0x9E3779B1 + key + rnd * 0x85EBCA6B) & m
+    v ^= v >> 15
+    v = (v * 0x2C1B3C6D) & m
+    v ^= v >> 12
+    v = (v * 0x297A2D39) & m
+    v ^= v >> 15
+    return v
+
+
+def perm_index(i, n, key):
+    """image of i under the keyed pseudo-random permutation of [0, n): 4-round Feistel network on the index bits +
+    cycle walking (random.sample = the first `count` images)."""
+    bits = 2
+    while (1 << bits) < n:
+        bits += 2
+    half = bits >> 1
+    mask = (1 << half) - 1
+    x = i
+    while True:
+        l, r = x >> half, x & mask
+        for rnd in range(4):
+            l, r = r, l ^ (_feistel_f(r, key, rnd) & mask)
+        x = (l << half) | r
+        if x < n:
+            return x
+
+
+def link_negatives(n_pos, k, seed, step, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None,
+                   row2=None, exclude=()):
+    """alinet.py:988-1006: uniform -> k rounds of zip(sample(ents1, n_pos), sample(ents2, n_pos)); truncated -> per link
+    (e1, c) for c in sample(neighbors1[e1], k) and (c, e2) for c in sample(neighbors2[e2], k); then
+    set(pairs) - exclude.  -> (pairs int32 [m, 2] in draw order, valid bool [m]: first of equal pairs, not excluded)."""
+    from . import cport
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    pairs = []
+    if nbr1 is None:
+        for rnd in range(k):
+            w = cport.philox(np.array([rnd, step, 1, 0], np.uint32), key)
+            for i in range(n_pos):
+                pairs.append((int(ents1[perm_index(i, len(ents1), int(w[0]))]), int(ents2[perm_index(i, len(ents2), int(w[1]))])))
+    else:
+        nbr_k = nbr1.shape[1]
+        for link in range(n_pos):
+            e1, e2 = int(pos_links[link][0]), int(pos_links[link][1])
+            w = cport.philox(np.array([link, step, 2, 0], np.uint32), key)
+            for s in range(k):
+                pairs.append((e1, int(nbr1[row1[e1], perm_index(s, nbr_k, int(w[0]))])))
+            for s in range(k):
+                pairs.append((int(nbr2[row2[e2], perm_index(s, nbr_k, int(w[1]))]), e2))
+    seen, valid = set(), []
+    exclude = set(exclude)
+    for p in pairs:
+        valid.append(p not in seen and p not in exclude)
+        seen.add(p)
+    return np.asarray(pairs, np.int32).reshape(-1, 2), np.asarray(valid, bool)

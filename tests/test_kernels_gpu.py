@@ -437,3 +437,56 @@ def test_transh_step_matches_oracle(ops, d, k, loss, opt):
             ops.triple_step(te2, tea2, tr2, tra2, d, ops.to_ids(pos), None if neg is None else ops.to_ids(neg), cfg2, ws, acc, phase=phase)
     for a, b in ((te, te2), (tr, tr2), (tn, tn2)):
         assert np.linalg.norm((a - b).cpu().numpy()) <= 2e-6 * np.linalg.norm(a.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# negative links (AliNet.generate_input_batch, alinet.py:988-1006)
+# ---------------------------------------------------------------------------------------------
+def test_link_negatives_bit_exact_and_set_semantics(ops):
+    import torch
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(5)
+    n_ent = 900
+    ents1 = rng.permutation(n_ent)[:400].astype(np.int32)
+    ents2 = (n_ent + rng.permutation(n_ent)[:380]).astype(np.int32)
+    sup = [(int(ents1[i]), int(ents2[i])) for i in range(0, 120)]
+    excl = ops.tripleset_build(ops.to_ids(np.asarray([(a, 0, b) for a, b in sup], np.int32)))
+    # uniform
+    n_pos, k = 150, 4
+    pairs, valid, scratch = ops.sample_link_negatives(n_pos, k, ents1=ops.to_ids(ents1), ents2=ops.to_ids(ents2), exclude=excl,
+                                                      seed=77, step=3)
+    ref_p, ref_v = orc.link_negatives(n_pos, k, 77, 3, ents1=ents1, ents2=ents2, exclude=sup)
+    assert np.array_equal(pairs.cpu().numpy(), ref_p) and np.array_equal(valid.cpu().numpy() > 0, ref_v)
+    p = pairs.cpu().numpy().reshape(k, n_pos, 2)
+    for r in range(k):                                     # random.sample: no repeats inside a round, members of the lists
+        assert len(set(p[r, :, 0])) == n_pos and len(set(p[r, :, 1])) == n_pos
+    assert set(p[..., 0].ravel()) <= set(ents1) and set(p[..., 1].ravel()) <= set(ents2)
+    kept = {tuple(x) for x, v in zip(pairs.cpu().numpy().tolist(), valid.cpu().numpy()) if v > 0}
+    assert kept == set(map(tuple, ref_p.tolist())) - set(sup) and int((valid > 0).sum()) == len(kept)
+    # every entity about equally often over many steps (uniform sampling)
+    cnt = np.zeros(2 * n_ent)
+    for step in range(40):
+        q, _, scratch = ops.sample_link_negatives(n_pos, k, ents1=ops.to_ids(ents1), ents2=ops.to_ids(ents2), seed=1, step=step, scratch=scratch)
+        np.add.at(cnt, q.cpu().numpy().ravel(), 1)
+    c1 = cnt[ents1]
+    assert c1.min() > 0 and abs(c1.mean() - 40 * k * n_pos / len(ents1)) < 1e-9 and c1.std() < 0.2 * c1.mean()
+    # truncated
+    nbr_k = 37
+    nbr1 = np.stack([rng.permutation(ents2)[:nbr_k] for _ in ents1]).astype(np.int32)
+    nbr2 = np.stack([rng.permutation(ents1)[:nbr_k] for _ in ents2]).astype(np.int32)
+    row1 = np.full(2 * n_ent, -1, np.int32); row1[ents1] = np.arange(len(ents1))
+    row2 = np.full(2 * n_ent, -1, np.int32); row2[ents2] = np.arange(len(ents2))
+    idx = rng.randint(0, 120, 90)                         # positives drawn WITH replacement (alinet.py:986): duplicate links
+    pos = np.asarray([sup[i] for i in idx], np.int32)
+    k = 6
+    pairs, valid, _ = ops.sample_link_negatives(len(pos), k, pos_links=ops.to_ids(pos), nbr1=ops.to_ids(nbr1), row1=ops.to_ids(row1),
+                                                nbr2=ops.to_ids(nbr2), row2=ops.to_ids(row2), exclude=excl, seed=9, step=1)
+    ref_p, ref_v = orc.link_negatives(len(pos), k, 9, 1, pos_links=pos, nbr1=nbr1, row1=row1, nbr2=nbr2, row2=row2, exclude=sup)
+    assert np.array_equal(pairs.cpu().numpy(), ref_p) and np.array_equal(valid.cpu().numpy() > 0, ref_v)
+    assert (~ref_v).sum() > 0                              # duplicates / supervised pairs were really dropped
+    pp = pairs.cpu().numpy().reshape(len(pos), 2, k, 2)
+    for i, (e1, e2) in enumerate(pos):
+        assert len(set(pp[i, 0, :, 1])) == k and set(pp[i, 0, :, 1]) <= set(nbr1[row1[e1]]) and (pp[i, 0, :, 0] == e1).all()
+        assert len(set(pp[i, 1, :, 0])) == k and set(pp[i, 1, :, 0]) <= set(nbr2[row2[e2]]) and (pp[i, 1, :, 1] == e2).all()
+    with pytest.raises(Exception, match="Sample larger than population"):
+        ops.sample_link_negatives(500, 2, ents1=ops.to_ids(ents1), ents2=ops.to_ids(ents2))
