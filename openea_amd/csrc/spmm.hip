@@ -250,6 +250,11 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
         A = group_sum<G>(A);
         const float D = A + gamma;
         int active = 0;
+        // the negative lists of GCN-Align / RDGCN pair the link's OWN entity with k others (neg_left = repeat(l),
+        // neg2_right = repeat(r)): contributions to rows l and r are summed in registers, one atomic row per group
+        float own_l[IT], own_r[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) own_l[it] = own_r[it] = 0.f;
         for (int i = gid; i < 2 * k; i += NG) {
             const int side = i >= k, b = side ? i - k : i;
             const int32_t *nlp = side ? neg2_left : neg_left, *nrp = side ? neg2_right : neg_right;
@@ -272,10 +277,22 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                     const int c = it * G + lane;
                     const float g = -scale * sgnf(dn[it]);
                     if (c < ld && g != 0.f) {
-                        oea::atomic_add_f32(grad + (int64_t)nl * ld + c, g);
-                        oea::atomic_add_f32(grad + (int64_t)nr * ld + c, -g);
+                        if (nl == l) own_l[it] += g;
+                        else if (nl == r) own_r[it] += g;
+                        else oea::atomic_add_f32(grad + (int64_t)nl * ld + c, g);
+                        if (nr == r) own_r[it] -= g;
+                        else if (nr == l) own_l[it] -= g;
+                        else oea::atomic_add_f32(grad + (int64_t)nr * ld + c, -g);
                     }
                 }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = it * G + lane;
+                if (c < ld && own_l[it] != 0.f) oea::atomic_add_f32(grad + (int64_t)l * ld + c, own_l[it]);
+                if (c < ld && own_r[it] != 0.f) oea::atomic_add_f32(grad + (int64_t)r * ld + c, own_r[it]);
             }
         }
         if (lane == 0 && active) atomicAdd(&s_active, active);
