@@ -75,16 +75,22 @@ def get_sparse_tensor(triple_list, ent_num):
 
 
 def dual_adjacency(head, tail, count_r):
-    """rdgcn.py:268-277: Jaccard overlap of head sets + of tail sets, dense [R, R]."""
-    a = np.zeros((count_r, count_r), np.float32)
-    for i in range(count_r):
-        hi, ti = head.get(i, set()), tail.get(i, set())
-        for j in range(count_r):
-            hj, tj = head.get(j, set()), tail.get(j, set())
-            a_h = len(hi & hj) / len(hi | hj) if (hi | hj) else 0.0
-            a_t = len(ti & tj) / len(ti | tj) if (ti | tj) else 0.0
-            a[i, j] = a_h + a_t
-    return a
+    """rdgcn.py:268-277: Jaccard overlap of head sets + of tail sets, dense [R, R].  The R^2 python set
+    intersections of the reference (minutes at 100K) are one sparse incidence product here: |A & B| = (I I^T)[a, b],
+    |A | B| = |A| + |B| - |A & B|; same doubles, same float32 result."""
+    import scipy.sparse as sp
+
+    def jaccard(sets):
+        rows = np.fromiter((r for r, s_ in sets.items() for _ in s_), np.int64)
+        cols = np.fromiter((e for s_ in sets.values() for e in s_), np.int64)
+        n_cols = int(cols.max()) + 1 if len(cols) else 1
+        inc = sp.csr_matrix((np.ones(len(rows), np.float64), (rows, cols)), shape=(count_r, n_cols))
+        inter = np.asarray((inc @ inc.T).todense(), np.float64)
+        size = np.asarray(inc.sum(1)).reshape(-1)
+        union = size[:, None] + size[None, :] - inter
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return np.where(union > 0, inter / union, 0.0)
+    return (jaccard(head) + jaccard(tail)).astype(np.float32)
 
 
 def glorot(rng, shape, dev):

@@ -204,3 +204,21 @@ def test_galeshapley_topk_equals_reference_loop():
         got = galeshapley_topk(order, np.take_along_axis(s, order, 1), lambda i, j: float(s[i, j]), cut)
         assert got == ref
         assert len(set(got.values())) == len(got)
+
+
+def test_rdgcn_dual_adjacency_equals_set_loops():
+    """rdgcn.py:268-277 (R^2 python set intersections) == the sparse incidence product used here, bit for bit."""
+    from openea_amd.approaches.rdgcn import dual_adjacency
+    rng = np.random.RandomState(0)
+    R, E = 23, 200
+    head = {r: set(rng.randint(0, E, rng.randint(1, 40)).tolist()) for r in range(R) if r != 5}
+    tail = {r: set(rng.randint(0, E, rng.randint(1, 40)).tolist()) for r in range(R) if r != 7}
+    ref = np.zeros((R, R), np.float32)
+    for i in range(R):
+        hi, ti = head.get(i, set()), tail.get(i, set())
+        for j in range(R):
+            hj, tj = head.get(j, set()), tail.get(j, set())
+            a_h = len(hi & hj) / len(hi | hj) if (hi | hj) else 0.0
+            a_t = len(ti & tj) / len(ti | tj) if (ti | tj) else 0.0
+            ref[i, j] = a_h + a_t
+    assert np.array_equal(dual_adjacency(head, tail, R), ref)
