@@ -345,7 +345,9 @@ typedef struct oea_attn_graph {
     int32_t t_any_split;         /* some column owns more than one chunk (dV then accumulates atomically) */
 } oea_attn_graph;
 size_t oea_sparse_attn_workspace_floats(int64_t n_sub, int64_t n_seg);
-/* out [n_rows, ld] and (backward) dv [n_cols, ld] must be ZERO on entry. */
+/* out [n_rows, ld] and (backward) dv [n_cols, ld] must be ZERO on entry.
+ * Partial graphs are allowed (row-sharded jobs, one process per GPU): n_tsub == 0 -> the backward only produces dz of
+ * the graph's own segments; n_sub == 0 -> it only produces the dv rows of the listed column chunks. */
 int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v, int32_t dim, int32_t ld,
                         float lrelu_slope, float *out, float *alpha, float *workspace, void *stream);
 int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v, const float *alpha,

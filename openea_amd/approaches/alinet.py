@@ -424,7 +424,7 @@ class AliNet(BasicModel):
     # ---- batches (alinet.py:983-1017) ---------------------------------------------------------------
     def generate_input_batch(self, batch_size, neighbors1=None, neighbors2=None):
         batch_size = min(batch_size, len(self.sup_ent1))
-        index = np.random.choice(len(self.sup_ent1), batch_size)
+        index = self._rng.choice(len(self.sup_ent1), batch_size)     # np.random.choice in the reference; seeded here (DP ranks must agree)
         pos_links = self.sup_links[index]
         neg_links = []
         if neighbors1 is None:
@@ -446,7 +446,7 @@ class AliNet(BasicModel):
         (pos_links int64 [b, 2], neg pairs int64 [m, 2], valid fp32 [m]), all device tensors."""
         dev = self.dev
         batch_size = min(batch_size, len(self.sup_ent1))
-        index = np.random.choice(len(self.sup_ent1), batch_size)              # with replacement (alinet.py:986)
+        index = self._rng.choice(len(self.sup_ent1), batch_size)     # np.random.choice in the reference; seeded here (DP ranks must agree)              # with replacement (alinet.py:986)
         if getattr(self, "_sup_links_dev", None) is None:
             self._sup_links_dev = torch.as_tensor(self.sup_links, device=dev)
             self._ents1_dev = ops.to_ids(np.asarray(self.sup_ent1 + self.ref_ent1, np.int32), dev)

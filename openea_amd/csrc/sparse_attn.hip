@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void attn_bwd_v_kernel(const int32_t *__restri
     } while (0)
 
 static int check_graph(const oea_attn_graph *g) {
-    OEA_REQUIRE(g && g->sub_ptr && g->sub_seg && g->seg_sub_ptr && g->seg_row && g->colidx, "attention graph: null pointer");
+    OEA_REQUIRE(g && (g->n_sub == 0 || (g->sub_ptr && g->sub_seg && g->seg_sub_ptr && g->seg_row && g->colidx)),
+                "attention graph: null pointer");
     OEA_REQUIRE(g->n_sub >= 0 && g->n_seg >= 0 && g->n_sub >= g->n_seg, "n_sub >= n_seg >= 0");
     return OEA_OK;
 }
@@ -283,8 +284,10 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
                         void *stream) {
     const int rc = check_graph(g);
     if (rc != OEA_OK) return rc;
-    OEA_REQUIRE(g->t_sub_ptr && g->t_sub_col && g->t_row && g->t_edge, "attention graph: transposed lists missing");
-    OEA_REQUIRE(z && v && alpha && dout && dz && dv && workspace, "null pointer");
+    // a rank of a row-sharded job passes two partial graphs: its segments only (n_tsub = 0 -> dz of its edges) and
+    // the transposed lists of its column block only (n_sub = 0 -> dv rows of that block, alpha / dout of ALL edges)
+    OEA_REQUIRE(g->n_tsub == 0 || (g->t_sub_ptr && g->t_sub_col && g->t_row && g->t_edge), "attention graph: transposed lists missing");
+    OEA_REQUIRE(v && alpha && dout && dv && workspace && (g->n_sub == 0 || (z && dz)), "null pointer");
     OEA_REQUIRE(dim > 0 && dim <= ld && ld % 4 == 0, "dim <= ld, ld % 4 == 0");
     hipStream_t st = oea::as_stream(stream);
     if (g->n_sub > 0) {

@@ -111,6 +111,36 @@ class EdgeGraph:
                                    ops.to_ids(seg_row, dev), self.e_colidx, ops.to_ids(t_sub_ptr, dev),
                                    ops.to_ids(t_sub_col, dev), ops.to_ids(rows_o[t_order], dev), ops.to_ids(t_order, dev),
                                    self.unique_rows, len(t_sub_col) > int((counts > 0).sum()))
+        # ---- row-sharded attention under torch.distributed (one exchange per operator output) --------
+        # rank r owns a block of SEGMENTS (= output rows, balanced by edges; canonical order makes its edges one
+        # contiguous range) for out / alpha / dz, and a block of COLUMNS (balanced by incoming edges) for dv.
+        from . import dist as mdist
+        rank, ws = mdist.world()
+        self.shard = None
+        if ws > 1 and self.unique_rows and grouping == 'row' and self.nnz > 0:
+            sb = mdist.balanced_bounds(seg_ptr, ws)
+            s_lo, s_hi = sb[rank], sb[rank + 1]
+            e_lo, e_hi = int(seg_ptr[s_lo]), int(seg_ptr[s_hi])
+            l_sub_ptr, l_sub_seg, l_seg_sub_ptr = split_ranges(seg_ptr[s_lo: s_hi + 1] - e_lo, self.SUB)
+            if s_hi == s_lo:
+                l_sub_ptr, l_sub_seg, l_seg_sub_ptr = np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64)
+            row_bounds = [0] + [int(seg_row[sb[r]]) if sb[r] < len(seg_row) else shape[0] for r in range(1, ws)] + [shape[0]]
+            edge_bounds = [int(seg_ptr[b]) for b in sb]
+            cb = mdist.balanced_bounds(t_ptr, ws)
+            c_lo, c_hi = cb[rank], cb[rank + 1]
+            t_lo, t_hi = int(t_ptr[c_lo]), int(t_ptr[c_hi])
+            lt_sub_ptr, lt_sub_col, _ = split_ranges(t_ptr[c_lo: c_hi + 1] - t_lo, self.SUB, drop_empty=True)
+            empty = ops.to_ids(np.zeros(0, np.int32), dev)
+            one0 = ops.to_ids(np.zeros(1, np.int32), dev)
+            seg_part = ops.attn_graph(ops.to_ids(l_sub_ptr, dev), ops.to_ids(l_sub_seg, dev), ops.to_ids(l_seg_sub_ptr, dev),
+                                      ops.to_ids(seg_row[s_lo:s_hi], dev), ops.to_ids(cols_o[e_lo:e_hi], dev),
+                                      one0, empty, empty, empty, True, False)
+            lcounts = counts[c_lo:c_hi]
+            t_part = ops.attn_graph(one0, empty, one0, empty, empty, ops.to_ids(lt_sub_ptr, dev),
+                                    ops.to_ids(lt_sub_col + c_lo, dev), ops.to_ids(rows_o[t_order][t_lo:t_hi], dev),
+                                    ops.to_ids(t_order[t_lo:t_hi], dev), True, len(lt_sub_col) > int((lcounts > 0).sum()))
+            self.shard = dict(seg=seg_part, t=t_part, e_lo=e_lo, e_hi=e_hi, row_bounds=row_bounds, edge_bounds=edge_bounds,
+                              col_bounds=cb)
 
 
 class SpmmFn(torch.autograd.Function):
@@ -136,7 +166,16 @@ class SparseAttnFn(torch.autograd.Function):
     def forward(ctx, z, v, graph, slope):
         z = z.contiguous()
         v = v.contiguous()
-        out, alpha = ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0])
+        sh = graph.shard
+        if sh is None:
+            out, alpha = ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0])
+        else:       # own segments only, then one all-gather of the output rows (and of alpha, for the dv half of the backward)
+            from . import dist as mdist
+            out, a_loc = ops.sparse_attn_fwd(sh['seg'], z[sh['e_lo']: sh['e_hi']].contiguous(), v, v.shape[1], slope, graph.shape[0])
+            out = mdist.allgather_blocks(out, sh['row_bounds'])
+            alpha = torch.empty_like(z)
+            alpha[sh['e_lo']: sh['e_hi']] = a_loc
+            mdist.allgather_blocks(alpha, sh['edge_bounds'])
         ctx.graph, ctx.slope = graph, slope
         ctx.save_for_backward(z, v, alpha)
         return out
@@ -145,7 +184,19 @@ class SparseAttnFn(torch.autograd.Function):
     def backward(ctx, dout):
         z, v, alpha = ctx.saved_tensors
         g = ctx.graph
-        dz, dv = ops.sparse_attn_bwd(g.attn, z, v, alpha, dout.contiguous(), v.shape[1], ctx.slope)
+        dout = dout.contiguous()
+        sh = g.shard
+        if sh is None:
+            dz, dv = ops.sparse_attn_bwd(g.attn, z, v, alpha, dout, v.shape[1], ctx.slope)
+            return dz, dv, None, None
+        from . import dist as mdist
+        lo, hi = sh['e_lo'], sh['e_hi']
+        dz_loc, _ = ops.sparse_attn_bwd(sh['seg'], z[lo:hi].contiguous(), v, alpha[lo:hi].contiguous(), dout, v.shape[1], ctx.slope)
+        dz = torch.empty_like(z)
+        dz[lo:hi] = dz_loc
+        mdist.allgather_blocks(dz, sh['edge_bounds'])
+        _, dv = ops.sparse_attn_bwd(sh['t'], z, v, alpha, dout, v.shape[1], ctx.slope)      # dv rows of this rank's column block
+        mdist.allgather_blocks(dv, sh['col_bounds'])
         return dz, dv, None, None
 
 
