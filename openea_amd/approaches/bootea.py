@@ -118,7 +118,8 @@ class BootEA(AlignE):
         self.alignment_loss = alignment_loss()
         cfg, opt = self._step_cfg(self.alignment_loss, 0)
         self.alignment_optimizer = cfg
-        self._align_trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt)
+        self._align_trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group(),
+                                            replicated=True)
 
     def eval_ref_sim_mat(self):
         """bootea.py:214-219: l2_normalize(lookup(ref1)) . l2_normalize(lookup(ref2))^T, on demand."""

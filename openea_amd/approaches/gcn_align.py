@@ -168,6 +168,8 @@ class GCN_Align_Unit:
         g_pre1 = self.adj.tmm(g_out, d, mask_from=H1)           # relu gate fused
         g_x = self.adj.tmm(g_pre1, d)
         g_T = g_x if self.features is None else self.features.tmm(g_x, d)
+        from ..models import dist as mdist
+        mdist.sync_replicated_(g_T)                     # torch.distributed: the hinge's atomics reorder per process
         ops.sgd_rows_(self.W, g_T, d, True, self.args.learning_rate)
         self.outputs = out
 

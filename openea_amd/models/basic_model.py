@@ -122,7 +122,8 @@ class BasicModel:
         self.mapping_optimizer = dict(optimizer=self.args.optimizer, lr=self.args.learning_rate)
         # a second optimizer instance in the reference (mapping.py:18) = its own Adagrad accumulators
         cfg, opt = self._step_cfg(dict(loss='positive', loss_norm='L2'), 0)
-        self._mapping_trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt)
+        self._mapping_trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group(),
+                                              replicated=True)
 
     # ------------------------------------------------------------------------------------------
     # evaluation (basic_model.py:106-138)
@@ -286,6 +287,8 @@ class BasicModel:
             g2[:, :d] = 2.0 * alpha * diff
             g1[:, :d] = -2.0 * alpha * (diff @ M.t())
             g_m = alpha * (-2.0 * (e1[:, :d].t() @ diff) + 4.0 * (orth @ M))
+            from . import dist as mdist
+            mdist.sync_replicated_(g_m)
             self._mapping_trainer.apply_entity_row_grads(torch.cat([ids1, ids2]), torch.cat([g1, g2]))
             self._mapping_acc += g_m * g_m                        # Adagrad on M (optimizers.py:11)
             self.mapping_mat -= lr * g_m / torch.sqrt(self._mapping_acc)

@@ -101,6 +101,18 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def sync_replicated_(t, group=None):
+    """A quantity every rank computes in FULL from replicated inputs (the losses / dense layers of the GNN approaches)
+    still differs between ranks in the last bits -- fp32 atomics sum in another order in every process -- and an
+    optimiser would let the replicas drift apart.  Averaging it across the ranks (one all-reduce) gives every rank
+    the same bits again.  No-op on a single rank."""
+    _, ws = world(group)
+    if ws > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= ws
+    return t
+
+
 def sharded_rank_metrics(e1, e2, dim, top_k, rank_fn, group=None):
     """Row-sharded greedy_alignment core.  e1 [n1, ld] / e2 [n2, ld]: full (replicated) query and
     candidate blocks.  rank_fn(e1_block, e2, dim, gold_offset) -> (rank int32 [m], argmax int32 [m])

@@ -219,9 +219,12 @@ class TFAdam:
         self.t = 0
 
     def step(self):
+        from . import dist as mdist
         self.t += 1
         for p, m, v in zip(self.params, self.m, self.v):
             if p.grad is None:
                 continue
-            ops.adam_dense_(p.data, p.grad.contiguous(), m, v, self.lr, self.t, self.b1, self.b2, self.eps)
+            g = p.grad.contiguous()
+            mdist.sync_replicated_(g)                   # torch.distributed: replicas must apply the same bits
+            ops.adam_dense_(p.data, g, m, v, self.lr, self.t, self.b1, self.b2, self.eps)
             p.grad = None

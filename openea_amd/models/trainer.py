@@ -46,8 +46,12 @@ class EmbeddingTable:
 
 
 class TripleTrainer:
-    def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None):
+    def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None, replicated=False):
+        """replicated=True (with a dist_group): every rank feeds the SAME full batch (small steps that are not worth
+        sharding: MTransE's mapping step, BootEA's alignment step); the gradient scratch is then averaged instead of
+        summed -- its only purpose is to give every replica the same bits (fp32 atomics reorder per process)."""
         self.ent, self.rel, self.cfg = ent, rel, cfg
+        self.replicated = bool(replicated)
         dev = ent.var.device
         self.dev = dev
         if optimizer == 'Adagrad':        # tf.train.AdagradOptimizer: initial_accumulator_value = 0.1
@@ -71,6 +75,8 @@ class TripleTrainer:
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss, phase=ops.PHASE_GRAD)
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
+            if self.replicated:
+                self.xchg /= dist.get_world_size(self.dist)
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss, phase=ops.PHASE_APPLY)
 
@@ -81,13 +87,15 @@ class TripleTrainer:
         if self.dist is not None:
             import torch.distributed as dist
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
+            if self.replicated:
+                self.xchg /= dist.get_world_size(self.dist)
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
 
     def pop_loss(self):
         """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data
         parallelism every rank holds the loss of its own slices; they are summed here."""
-        if self.dist is not None:
+        if self.dist is not None and not self.replicated:
             import torch.distributed as dist
             dist.all_reduce(self.loss, op=dist.ReduceOp.SUM, group=self.dist)
         v = float(self.loss.item())
