@@ -132,18 +132,13 @@ __device__ __forceinline__ int lin_bin(float v, float lo, float scale) {
     return (int)b;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
-                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
-                                                                 int32_t *__restrict__ out /* [n_rows, k] */) {
-    __shared__ int hist[kBins];
-    __shared__ uint32_t c_key[kCandCap];
-    __shared__ int c_col[kCandCap];
+// the three-read select of one row (every thread of the workgroup calls it)
+__device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int k, const int32_t *__restrict__ id_map,
+                                 int32_t *__restrict__ o, int *hist /*[kBins]*/, uint32_t *c_key /*[kCandCap]*/,
+                                 int *c_col /*[kCandCap]*/) {
     __shared__ float s_red[8];
     __shared__ int s_bstar, s_need, s_ncand, s_gt[4], s_cbefore[4], s_tcol;
     __shared__ uint32_t s_tkey;
-    const int64_t row = blockIdx.x;
-    const float *src = s + row * ld;
-    int32_t *o = out + row * (int64_t)k;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- sampled range ------------------------------------------------------------------------
@@ -309,6 +304,237 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
     }
 }
 
+__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                 int32_t *__restrict__ out /* [n_rows, k] */) {
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col);
+}
+
+// ---- one-read select for long rows -------------------------------------------------------------------------------
+// A SAMPLE of the row (64 contiguous runs of 128 entries spread over it) gives a bucket threshold that the true
+// k-th largest value clears with ~3 sigma; ONE pass over the row then keeps, per wave and in column order, the
+// ~1.25 k entries at or above that bucket in LDS; the exact (value desc, column asc) selection and the ordered
+// compaction run on the LDS copy.  Rows whose candidates overflow the LDS lists or fall short of k (bad sample,
+// heavy ties) take the three-read path -- the result is the same either way.
+constexpr int kWaveCap = 1024;          // candidates per wave (4 waves): 32 KB of LDS, 48 KB in all -> 3 workgroups per CU
+constexpr int kSampleRuns = 64, kSampleRun = 128;
+
+__global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                         int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                         int32_t *__restrict__ out) {
+    __shared__ int hist[kBins];
+    __shared__ float w_val[4][kWaveCap];
+    __shared__ int w_col[4][kWaveCap];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    __shared__ float s_red[8];
+    __shared__ int s_wcnt[4], s_wsel[4], s_bs, s_bstar, s_need, s_ncand, s_tcol;
+    __shared__ uint32_t s_tkey;
+    const int64_t row = blockIdx.x;
+    const float *src = s + row * ld;
+    int32_t *o = out + row * (int64_t)k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- sample: run b starts at (b * (nc - 128) / 63) rounded down to a multiple of 4 ------------------------------
+    float4 sv[8];
+    {
+        const int b = tid >> 2, part = tid & 3;
+        const int64_t start = ((int64_t)b * (nc - kSampleRun) / (kSampleRuns - 1)) & ~(int64_t)3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const float4 *>(src + start + part * 32 + i * 4);
+    }
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mn = fminf(fminf(mn, fminf(sv[i].x, sv[i].y)), fminf(sv[i].z, sv[i].w));
+        mx = fmaxf(fmaxf(mx, fmaxf(sv[i].x, sv[i].y)), fmaxf(sv[i].z, sv[i].w));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+    for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+    if (tid == 0) { s_ncand = 0; s_bs = 0; }
+    __syncthreads();
+    const float lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    const float hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&hist[lin_bin(sv[i].x, lo, scale)], 1);
+        atomicAdd(&hist[lin_bin(sv[i].y, lo, scale)], 1);
+        atomicAdd(&hist[lin_bin(sv[i].z, lo, scale)], 1);
+        atomicAdd(&hist[lin_bin(sv[i].w, lo, scale)], 1);
+    }
+    __syncthreads();
+    {   // bucket where the sample's cumulative count from the top reaches the expectation + 3 sigma + slack
+        const float e = (float)k * (float)(kSampleRuns * kSampleRun) / (float)nc;
+        const int want = (int)(e + 3.0f * sqrtf(e) + 8.0f);
+        if (tid < 64) {
+            constexpr int per = kBins / 64;
+            const int top = kBins - 1 - tid * per;
+            int sum = 0;
+            for (int b = 0; b < per; ++b) sum += hist[top - b];
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += t;
+            }
+            const int before = incl - sum;
+            if (before < want && incl >= want) {
+                int acc = before;
+                for (int b = 0; b < per; ++b) {
+                    acc += hist[top - b];
+                    if (acc >= want) { s_bs = top - b; break; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int bs = s_bs;                 // 0 when the sample never reaches `want`: every entry is a candidate -> overflow -> 3-pass
+
+    // ---- the one pass: per-wave candidate lists in column order -----------------------------------------------------
+    const int64_t tiles = (nc + 255) / 256;
+    const int64_t tiles_per_wave = (tiles + 3) / 4;
+    const int64_t seg0 = wave * tiles_per_wave * 256;
+    const int64_t seg1 = seg0 + tiles_per_wave * 256 < nc ? seg0 + tiles_per_wave * 256 : nc;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    constexpr int U = 4;
+    int running = 0;
+    for (int64_t t0 = seg0 + lane * 4; t0 - lane * 4 < seg1; t0 += 256 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            v[u] = c0 < seg1 ? *reinterpret_cast<const float4 *>(src + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t c0 = t0 + u * 256;
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            bool sel[4];
+            uint64_t bal[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sel[i] = (c0 + i < seg1) && lin_bin(vv[i], lo, scale) >= bs;
+                bal[i] = __ballot(sel[i]);
+            }
+            if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;
+            int p = running + __popcll(bal[0] & lt) + __popcll(bal[1] & lt) + __popcll(bal[2] & lt) + __popcll(bal[3] & lt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (sel[i]) {
+                    if (p < kWaveCap) { w_val[wave][p] = vv[i]; w_col[wave][p] = (int)(c0 + i); }
+                    ++p;
+                }
+            running += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+        }
+    }
+    if (lane == 0) s_wcnt[wave] = running;
+    for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+    __syncthreads();
+    const int n0 = s_wcnt[0], n1 = s_wcnt[1], n2 = s_wcnt[2], n3 = s_wcnt[3];
+    bool fail = n0 > kWaveCap || n1 > kWaveCap || n2 > kWaveCap || n3 > kWaveCap || n0 + n1 + n2 + n3 < k;
+    if (!fail) {
+        // ---- exact k-th among the candidates: bucket histogram, then the threshold bucket ranked pairwise ----------------
+        const int mine = s_wcnt[wave];
+        for (int i = lane; i < mine; i += 64) atomicAdd(&hist[lin_bin(w_val[wave][i], lo, scale)], 1);
+        __syncthreads();
+        if (tid < 64) {
+            constexpr int per = kBins / 64;
+            const int top = kBins - 1 - tid * per;
+            int sum = 0;
+            for (int b = 0; b < per; ++b) sum += hist[top - b];
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += t;
+            }
+            const int before = incl - sum;
+            if (before < k && incl >= k) {
+                int acc = before;
+                for (int b = 0; b < per; ++b) {
+                    const int c = hist[top - b];
+                    if (acc + c >= k) { s_bstar = top - b; s_need = k - acc; break; }
+                    acc += c;
+                }
+            }
+        }
+        __syncthreads();
+        const int bstar = s_bstar, need = s_need;
+        fail = hist[bstar] > kCandCap;                      // block-uniform
+        if (!fail) {
+            for (int i = lane; i < mine; i += 64) {
+                const float v = w_val[wave][i];
+                if (lin_bin(v, lo, scale) == bstar) {
+                    const int p = atomicAdd(&s_ncand, 1);
+                    c_key[p] = f2ord(v);
+                    c_col[p] = w_col[wave][i];
+                }
+            }
+            __syncthreads();
+            const int ncand = s_ncand;
+            for (int i = tid; i < ncand; i += SEL_THREADS) {
+                const uint32_t ki = c_key[i];
+                const int ci = c_col[i];
+                int rank = 0;
+                for (int j = 0; j < ncand; ++j) {
+                    const uint32_t kj = c_key[j];
+                    rank += (kj > ki) || (kj == ki && c_col[j] < ci);
+                }
+                if (rank == need - 1) { s_tkey = ki; s_tcol = ci; }
+            }
+            __syncthreads();
+            const uint32_t tkey = s_tkey;
+            const int tcol = s_tcol;
+            // ---- ordered compaction of the LDS lists: count per wave, then write ----------------------------------------
+            int cnt = 0;
+            for (int i = lane; i < mine; i += 64) {
+                const uint32_t key = f2ord(w_val[wave][i]);
+                cnt += key > tkey || (key == tkey && w_col[wave][i] <= tcol);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (lane == 0) s_wsel[wave] = cnt;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += s_wsel[w];
+            for (int i0 = 0; i0 < mine; i0 += 64) {
+                const int i = i0 + lane;
+                bool sel = false;
+                int col = 0;
+                if (i < mine) {
+                    const uint32_t key = f2ord(w_val[wave][i]);
+                    col = w_col[wave][i];
+                    sel = key > tkey || (key == tkey && col <= tcol);
+                }
+                const uint64_t bal = __ballot(sel);
+                if (sel) o[base + __popcll(bal & lt)] = id_map ? id_map[col] : col;
+                base += __popcll(bal);
+            }
+            return;
+        }
+    }
+    __syncthreads();
+    select_row_3pass(src, nc, k, id_map, o, hist, c_key, c_col);
+}
+
+// long rows with k well inside the LDS candidate lists take the one-read kernel
+static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int k, const int32_t *id_map, int32_t *out,
+                          hipStream_t st) {
+    if (nc >= 16384 && (int64_t)k * 5 <= (int64_t)kWaveCap * 4 * 3)        // expected candidates ~1.3 k <= 3/4 of the lists
+        row_select_sampled_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+    else
+        row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -323,7 +549,7 @@ int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_
     OEA_REQUIRE(s && out_idx, "null pointer");
     OEA_REQUIRE(k >= 1 && k <= nc && ld >= nc && ld % 4 == 0, "1 <= k <= nc <= ld, ld % 4 == 0 (rows are read 16 B at a time)");
     if (n_rows == 0) return OEA_OK;
-    row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, oea::as_stream(stream)>>>(s, n_rows, nc, ld, k, id_map, out_idx);
+    launch_select(s, n_rows, nc, ld, k, id_map, out_idx, oea::as_stream(stream));
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
@@ -346,8 +572,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         const int64_t rows = std::min<int64_t>(rows_per, nq - r0);
         int rc = oea_sim_matrix(q + r0 * ldq, rows, ldq, c, nc, ldc, dim, OEA_METRIC_INNER, strip, ld, stream);
         if (rc != OEA_OK) return rc;
-        row_select_kernel<<<(unsigned)rows, SEL_THREADS, 0, oea::as_stream(stream)>>>(strip, rows, nc, ld, k, id_map,
-                                                                                    out_idx + r0 * (int64_t)k);
+        launch_select(strip, rows, nc, ld, k, id_map, out_idx + r0 * (int64_t)k, oea::as_stream(stream));
     }
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;

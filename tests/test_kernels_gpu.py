@@ -202,6 +202,36 @@ def test_topk_rows_ties_and_ragged(ops, nc, k):
     assert np.array_equal(got, _select_ref(s, k))
 
 
+@pytest.mark.parametrize("nc,k", [(20000, 1500), (16384, 64), (33333, 3000)])
+def test_topk_rows_sampled_path(ops, nc, k):
+    """rows long enough for the one-read (sampled threshold) select, including rows built to defeat the sample:
+    whatever path a row takes, the (value desc, column asc) selection is the oracle's."""
+    import torch
+    rng = np.random.RandomState(nc + k)
+    ld = (nc + 31) // 32 * 32
+    runs = np.zeros(nc, bool)                                    # the columns the kernel samples
+    for b in range(64):
+        st = (b * (nc - 128) // 63) & ~3
+        runs[st:st + 128] = True
+    rows = [rng.standard_normal(nc), np.zeros(nc), np.round(rng.standard_normal(nc) * 2) / 2]
+    x = rng.standard_normal(nc); x[runs] += 10.0                 # sample far above the rest: too few candidates -> 3-pass
+    rows.append(x)
+    x = rng.standard_normal(nc); x[~runs] += 10.0                # sample far below the rest: every entry a candidate -> overflow
+    rows.append(x)
+    x = rng.standard_normal(nc) * 1e-3; x[rng.choice(nc, k // 2, replace=False)] = 5.0
+    rows.append(x)                                               # half of the top-k are outliers
+    rows.append(np.sort(rng.standard_normal(nc)))
+    rows.append(rng.standard_normal(nc) ** 3)                    # heavy tails
+    s = np.stack(rows).astype(np.float32)
+    sp_ = np.full((len(rows), ld), np.nan, np.float32)
+    sp_[:, :nc] = s
+    got = ops.topk_rows(torch.from_numpy(sp_).to(ops.device()), k, nc=nc).cpu().numpy()
+    assert np.array_equal(got, _select_ref(s, k))
+    ids = rng.permutation(nc).astype(np.int32)
+    got = ops.topk_rows(torch.from_numpy(sp_).to(ops.device()), k, id_map=ops.to_ids(ids), nc=nc).cpu().numpy()
+    assert np.array_equal(got, ids[_select_ref(s, k)])
+
+
 def test_topk_matches_reference_fixture(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, "neighbours.npz"))
     emb, ents, k = g['emb'], g['entity_list'], int(g['k'])
