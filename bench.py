@@ -111,7 +111,7 @@ def main():
                 done += steps_per_epoch
                 continue
             pos, neg = epochs.batch(s)
-            if pos.shape[0]:
+            if pos.shape[0] or world > 1:                     # DP: every rank joins every exchange, rows or not
                 trainer.step(pos, neg)
             npos += pos.shape[0]
             nscored += pos.shape[0] * (1 + args.neg)

@@ -765,8 +765,9 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
         oea::prof_mark(st);
-        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, nb1, loss_accum,
-                                                 phase == OEA_PHASE_APPLY);
+        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
+                                                 items > 0 ? nb1 : 0 /* no triples scored: no loss partials to add */,
+                                                 loss_accum, phase == OEA_PHASE_APPLY);
         if (transh)
             apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1), block, 0, st>>>(
                 n_rel, ld, cfg, ws, phase == OEA_PHASE_APPLY);

@@ -170,7 +170,7 @@ class RelationTripleEpochs:
             n = 0
             for step in range(len(self.batches.splits)):
                 pos, neg = self.batch(step)
-                if pos.shape[0]:
+                if pos.shape[0] or trainer.dist is not None:     # DP: every rank joins every exchange, rows or not
                     trainer.step(pos, neg)
                 n += pos.shape[0]
         self.end_epoch()

@@ -520,3 +520,24 @@ def test_link_negatives_bit_exact_and_set_semantics(ops):
         assert len(set(pp[i, 1, :, 0])) == k and set(pp[i, 1, :, 0]) <= set(nbr2[row2[e2]]) and (pp[i, 1, :, 1] == e2).all()
     with pytest.raises(Exception, match="Sample larger than population"):
         ops.sample_link_negatives(500, 2, ents1=ops.to_ids(ents1), ents2=ops.to_ids(ents2))
+
+
+def test_step_with_empty_shard_is_a_clean_noop(ops):
+    """data parallelism: a rank whose slice of a batch is empty still joins the exchange -- GRAD with no rows, then
+    APPLY: tables untouched when nothing was exchanged, and no stale loss partial is added."""
+    import torch
+    rng = np.random.RandomState(0)
+    ent = ops.to_table(rng.standard_normal((50, 16)).astype(np.float32))
+    rel = ops.to_table(rng.standard_normal((5, 16)).astype(np.float32))
+    ea, ra = torch.full_like(ent, 0.1), torch.full_like(rel, 0.1)
+    cfg = ops.make_step_cfg(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2, neg_group_k=2)
+    ws = ops.step_workspace(50, 5, ent.shape[1])
+    loss = torch.zeros(1, dtype=torch.float64, device=ent.device)
+    pos = ops.to_ids(np.array([[1, 2, 3], [4, 0, 5]], np.int32))
+    neg = ops.to_ids(np.array([[1, 2, 9], [7, 2, 3], [4, 0, 8], [6, 0, 5]], np.int32))
+    ops.triple_step(ent, ea, rel, ra, 16, pos, neg, cfg, ws, loss)            # leaves loss partials behind
+    l1, e1 = float(loss.item()), ent.clone()
+    empty = torch.zeros((0, 3), dtype=torch.int32, device=ent.device)
+    for phase in (ops.PHASE_GRAD, ops.PHASE_APPLY):
+        ops.triple_step(ent, ea, rel, ra, 16, empty, None, cfg, ws, loss, phase=phase)
+    assert float(loss.item()) == l1 and torch.equal(ent, e1)
