@@ -23,10 +23,8 @@ import torch
 from .. import ops
 from ..models.basic_model import BasicModel
 from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
-from ..modules.bootstrapping.alignment_finder import find_alignment, PairSim
 from ..modules.finding.evaluation import early_stop
 from ..modules.load import read as rd
-from ..modules.utils.util import generate_out_folder
 
 BN_EPS = 1e-3
 

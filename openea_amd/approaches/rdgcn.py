@@ -8,7 +8,7 @@ L1 nearest-neighbour search every 10 epochs (rdgcn.py:75-87, 466-490); Adam.
 
 Device kernels: the primal sparse attention (csrc/sparse_attn.hip), the GCN aggregate and the
 per-relation head/tail averages (csrc/spmm.hip), the L1 hinge (oea_align_loss_l1), hard-negative
-mining (fp64 L1 similarity strip + radix select: oea_sim_matrix + oea_topk_rows), Adam
+mining (fp64 L1 similarity strip + bucket select: oea_sim_matrix + oea_topk_rows), Adam
 (csrc/optim.hip).  The dual graph is tiny and dense: plain library GEMMs + softmax.
 
 Reproduced quirks: `get_mat` compares head with RELATION id and increments

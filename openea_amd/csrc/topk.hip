@@ -5,7 +5,8 @@
 // k is large here (int((1-eps)*N): 1,499 of 15,000; 2,000 of 100,000), so instead of keeping k
 // candidates per row on chip the search is a per-row SELECT on the fp32 keys:
 //   1. a strip of rows of S is produced by the MFMA tile kernel (sim_rank.hip) into an HBM
-//      workspace (the strip is L2 / Infinity-Cache resident when read back),
+//      workspace (strips of a few thousand rows: a full wave of workgroups per launch matters more than
+//      keeping the strip in the 256 MB Infinity Cache -- see ops.topk_inner),
 //   2. one workgroup per row, three coalesced reads of the row (16 B per lane):
 //        a. histogram over 2048 LINEAR buckets between a sampled [lo, hi] of the row (monotone in
 //           the value, ends clamped) -> the bucket b* holding the k-th largest value,
@@ -14,7 +15,9 @@
 //        c. ordered compaction by wave ballots: key > T, or key == T and column <= T's column.
 //      Rows whose threshold bucket holds more than kCandCap entries (constant / heavily tied rows)
 //      take the radix path instead: three 11+11+10-bit histogram passes + scan compaction.
-//   Both give the (value desc, column asc) selection in ascending column order, bit-identical with
+//      Rows of >= 16,384 columns first try a ONE-read variant (row_select_sampled_kernel, below): bucket threshold
+//      from a sample of the row, candidates kept in LDS, exact selection on the LDS copy.
+//   All paths give the (value desc, column asc) selection in ascending column order, bit-identical with
 //   oracle_topk_inner.
 #include "common.h"
 

@@ -4,7 +4,8 @@ This is what replaces the reference's producer processes + queue + feed_dict +
 ``session.run([triple_loss, triple_optimizer])`` loop
 (``BasicModel.launch_triple_training_1epo``, models/basic_model.py:211-236): positives,
 triple membership set, neighbour lists, tables, optimiser state and the loss accumulator all
-live in HBM; one step = two sampler launches (KG1, KG2 -- batch.py:36-45) + the fused step.
+live in HBM; an epoch = one sampler launch for all its batches (both KGs, batch.py:36-45) + two kernels per step,
+enqueued by one C call (oea_triple_epoch).
 
 Multi-GPU (torch.distributed, backend nccl = RCCL): tables are replicated, each rank scores
 its own slice of every batch, the gradient scratch is summed with ONE all-reduce per step and

@@ -15,7 +15,6 @@ import torch
 
 from .. import _seed
 from ... import ops
-from ..utils.util import merge_dic, task_divide
 
 # ----------------------------------------------------------------------------------------------
 # positive batching (pure index arithmetic, batch.py:17-22, 48-57)
