@@ -204,7 +204,9 @@ int oea_sample_negatives_epoch(const int32_t *pos_all, int64_t n_rows, const int
  * to KG1.  k == 0: positive-only losses (MTransE), no sampling.  When offsets_dev / splits_dev (device
  * copies of the two host arrays) are given, neg_buf must hold (total rows)*k triples and the whole
  * epoch is sampled by ONE launch up front (oea_sample_negatives_epoch); otherwise neg_buf holds
- * max_batch*k triples and every step samples its own batch.  Nothing is synchronised: the host returns after enqueueing ~3 kernels
+ * max_batch*k triples and every step samples its own batch.  side0 == side1 == NULL together with the device
+ * layout: neg_buf ALREADY holds the epoch's negatives (drawn by the caller with oea_sample_negatives_epoch, typically
+ * on a second stream while the previous epoch was still running).  Nothing is synchronised: the host returns after enqueueing ~3 kernels
  * per step, which removes the per-step host round trip of the reference's feed_dict loop. */
 int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                      int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,

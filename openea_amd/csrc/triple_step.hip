@@ -858,10 +858,13 @@ int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, floa
                      const int64_t *offsets_dev, const int64_t *splits_dev, void *stream) {
     OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
-    OEA_REQUIRE(k == 0 || (neg_buf && err_flag && side0 && side1), "sampling needs neg_buf, err_flag and both sides");
     OEA_REQUIRE((offsets_dev == nullptr) == (splits_dev == nullptr), "offsets_dev and splits_dev go together");
+    // side0 == NULL with the device layout given: neg_buf already holds the epoch's negatives (the caller drew them
+    // with oea_sample_negatives_epoch, e.g. on another stream while the previous epoch was running)
+    const bool presampled = k > 0 && side0 == nullptr && side1 == nullptr && offsets_dev != nullptr;
+    OEA_REQUIRE(k == 0 || (neg_buf && (presampled || (err_flag && side0 && side1))), "sampling needs neg_buf, err_flag and both sides");
     const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;
-    if (ahead) {   // the sampler does not read the tables: draw the whole epoch's negatives in one launch
+    if (ahead && !presampled) {   // the sampler does not read the tables: draw the whole epoch's negatives in one launch
         const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0,
                                                   side1, seed, step_base, 10, neg_buf, err_flag, stream);
         if (rc != OEA_OK) return rc;

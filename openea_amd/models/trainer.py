@@ -136,6 +136,8 @@ class RelationTripleEpochs:
     def batch(self, step):
         """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch.
         Under data parallelism this rank takes a contiguous share of the batch rows."""
+        if getattr(self, "_prefetch", None) is not None:      # a prepared epoch is pending: its positives become current
+            self._take_prefetch(torch.cuda.current_stream())
         pos, n_split = self.batches.pos(step)
         off = 0
         if self.world > 1:
@@ -159,14 +161,23 @@ class RelationTripleEpochs:
             if self._sides is None:
                 self._sides = (self.s1.side(), self.s2.side())
             b = self.batches
+            main = torch.cuda.current_stream()
+            presampled = self._take_prefetch(main)
+            if self.k:
+                self._epoch_neg_buf()
+            ev_start = torch.cuda.Event()
+            ev_start.record(main)                         # everything that still reads the spare buffers is before this
             ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
-                             b.dall, b.offsets, b.splits, self.k, self._sides[0] if self.k else None,
-                             self._sides[1] if self.k else None, self.seed, self.global_step,
-                             self._epoch_neg_buf() if self.k else None, self.err if self.k else None, trainer.cfg,
+                             b.dall, b.offsets, b.splits, self.k,
+                             None if (presampled or not self.k) else self._sides[0],
+                             None if (presampled or not self.k) else self._sides[1], self.seed, self.global_step,
+                             self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
                              trainer.ws, trainer.loss, self._off_dev if self.k else None,
                              self._spl_dev if self.k else None)
             self.global_step += len(b.splits)
             n = int(b.offsets[-1])
+            self._prefetch_next(ev_start)
+            return n
         else:
             n = 0
             for step in range(len(self.batches.splits)):
@@ -186,11 +197,48 @@ class RelationTripleEpochs:
             self._spl_dev = torch.from_numpy(b.splits).to(self.dev)
         return self._neg_all
 
+    # ---- next epoch prepared on a side stream while this one runs ------------------------------------------------
+    # The shuffle (basic_model.py:234-235) and the negatives of epoch e+1 depend on nothing epoch e computes (the
+    # sampler reads the triple set and the neighbour lists, not the tables), so they are enqueued on a second HIP
+    # stream into spare buffers right after epoch e's kernels; the next run_epoch swaps the buffers in.  A change of
+    # the neighbour lists in between (truncated-sampling refresh) drops the prepared negatives.
+    def _prefetch_next(self, ev_start):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+            self._neg_next = torch.empty_like(self._neg_all) if self.k else None
+        side = self._side
+        side.wait_event(ev_start)
+        with torch.cuda.stream(side):
+            self.batches.shuffle(self.gen, into_next=True)
+            if self.k:
+                ops.sample_negatives_epoch(self.batches.dall_next, self._off_dev, self._spl_dev, len(self.batches.splits), self.k,
+                                           self._sides[0], self._sides[1], self.seed, self.global_step, self._neg_next, self.err)
+            self._prefetch_ev = torch.cuda.Event()
+            self._prefetch_ev.record(side)
+        self._prefetch = (self._sides, self.global_step)
+
+    def _take_prefetch(self, main):
+        """make the prepared epoch current; -> True when its negatives are usable as they are."""
+        pf = getattr(self, "_prefetch", None)
+        if pf is None:
+            return False
+        self._prefetch = None
+        main.wait_event(self._prefetch_ev)
+        self.batches.swap()
+        ok = self.k > 0 and pf[0] is self._sides and pf[1] == self.global_step
+        if ok:
+            self._neg_all, self._neg_next = self._neg_next, self._neg_all
+        return ok
+
     def end_epoch(self):
+        if getattr(self, "_prefetch", None) is not None:      # already shuffled into the spare buffer: make it current
+            self._take_prefetch(torch.cuda.current_stream())
+            return
         self.batches.shuffle(self.gen)      # basic_model.py:234-235
 
     def check(self):
         """raise random.sample's error if a candidate list was smaller than the sample (one sync)."""
+        torch.cuda.synchronize(self.dev)          # the sampler may have run on the side stream
         if int(self.err.item()) != 0:
             raise ValueError("Sample larger than population or is negative")
 

@@ -127,15 +127,24 @@ class EpochBatches:
         self.dall = self.tall[self.slot].contiguous()
         self.n1, self.n2 = n1, n2
 
-    def shuffle(self, gen=None):
+    def shuffle(self, gen=None, into_next=False):
         """random.shuffle of both lists (basic_model.py:234-235): a device permutation of each KG's
         triples (torch generator = plumbing RNG), then the fixed batch layout gather.  No host
-        round trip; `dall` keeps its address."""
+        round trip.  into_next: the new layout goes to a second buffer (`dall_next`) that `swap()` makes current --
+        the next epoch is laid out on a side stream while the current one is still being consumed."""
         p1 = torch.randperm(self.n1, device=self.dev, generator=gen)
         p2 = torch.randperm(self.n2, device=self.dev, generator=gen) + self.n1
         perm = torch.cat([p1, p2])
         self.tall = self.tall[perm]
-        self.dall.copy_(self.tall[self.slot])
+        if into_next:
+            if getattr(self, "dall_next", None) is None:
+                self.dall_next = torch.empty_like(self.dall)
+            self.dall_next.copy_(self.tall[self.slot])
+        else:
+            self.dall.copy_(self.tall[self.slot])
+
+    def swap(self):
+        self.dall, self.dall_next = self.dall_next, self.dall
 
     def pos(self, step):
         """-> (device [n,3] batch, n_split): rows [0, n_split) come from KG1 (batch.py:45)."""

@@ -188,6 +188,14 @@ def sample_negatives_pair(pos, n_split, k, side0, side1, seed, step, pos_offset,
     return out
 
 
+def sample_negatives_epoch(pos_all, offsets_dev, splits_dev, steps, k, side0, side1, seed, step_base, out, err_flag, max_try=10):
+    """negatives of every batch of an epoch in one launch (on the CURRENT torch stream)."""
+    check(lib().oea_sample_negatives_epoch(_p(pos_all), pos_all.shape[0], _p(offsets_dev), _p(splits_dev), int(steps), int(k),
+                                           C.byref(side0), C.byref(side1), int(seed), int(step_base), int(max_try), _p(out),
+                                           _p(err_flag), _stream()))
+    return out
+
+
 def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
                  neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None):
     """Enqueue every step of an epoch with one call (offsets / splits: host int64 numpy arrays; their
