@@ -105,3 +105,38 @@ def test_step_100k_shape(ops):
     assert 0 < n_touched <= uniq                                     # only referenced rows move
     assert np.isfinite(loss_g) and loss_g > 0
     assert not bool((tg.ws[: tg.ws.numel() - 8 * 4096] != 0).any().item())
+
+
+def test_graph_operators_100k_shape(ops):
+    """EN-DE-100K-like graph (200,000 nodes, ~1.6 M edges with hubs): the aggregate is linear and matches the oracle on
+    sampled rows; the sparse attention's weights sum to one per row, its output is linear in v, and a constant v
+    passes through unchanged."""
+    import scipy.sparse as sp
+    from openea_amd.models.graph_ops import EdgeGraph, sparse_attention, spmm
+    rng = np.random.RandomState(3)
+    n, nnz, d = 200000, 1600000, 64
+    w = 1.0 / np.arange(1, n + 1) ** 0.9
+    rows = rng.choice(n, nnz, p=w / w.sum())
+    cols = rng.randint(0, n, nnz)
+    vals = rng.rand(nnz).astype(np.float32)
+    g = EdgeGraph(rows, cols, vals, (n, n), ops.device())
+    x1 = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    y1, y2, y12 = spmm(g, x1), spmm(g, x2), spmm(g, x1 + x2)
+    assert torch.allclose(y12, y1 + y2, rtol=1e-4, atol=1e-3)
+    a = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    a.sum_duplicates()
+    pick = np.concatenate([np.arange(8), rng.choice(n, 64, replace=False)])            # hubs + random rows
+    ref = a[pick].astype(np.float64) @ x1.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(y1[torch.from_numpy(pick).cuda()].cpu().numpy(), ref, rtol=1e-4, atol=2e-3)
+    # attention
+    z = torch.from_numpy(rng.standard_normal(g.nnz).astype(np.float32)).cuda()
+    ones = torch.ones((n, d), device="cuda")
+    out_c = sparse_attention(g, z, ones)
+    has = torch.zeros(n, dtype=torch.bool, device="cuda")
+    has[g.e_rows] = True
+    assert torch.allclose(out_c[has], torch.ones_like(out_c[has]), rtol=0, atol=1e-4)   # softmax weights sum to 1 per row
+    assert float(out_c[~has].abs().max()) == 0.0                                        # rows without edges stay zero
+    o1, o2, o12 = sparse_attention(g, z, x1), sparse_attention(g, z, x2), sparse_attention(g, z, x1 + x2)
+    assert torch.allclose(o12, o1 + o2, rtol=1e-4, atol=1e-4)
+    assert float(o1.abs().max()) <= float(x1.abs().max()) + 1e-4                       # convex combination of v rows
