@@ -1,7 +1,6 @@
 """BootEA (mirror of openea/approaches/bootea.py): AlignE + bootstrapping of likely alignment
 + the alignment loss -sum log sigmoid(-||h + r - t||^2) on the triples swapped through the newly
 labelled pairs; BASELINE.json config 2."""
-import gc
 import math
 import time
 
@@ -28,7 +27,6 @@ def bootstrapping(sim_mat, unaligned_entities1, unaligned_entities2, labeled_ali
         newly_aligned_entities2 = [unaligned_entities2[pair[1]] for pair in labeled_alignment]
     else:
         newly_aligned_entities1, newly_aligned_entities2 = None, None
-    gc.collect()
     return labeled_alignment, newly_aligned_entities1, newly_aligned_entities2
 
 

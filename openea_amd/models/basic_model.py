@@ -11,7 +11,6 @@ What changes underneath:
 * the truncated-neighbour refresh (basic_model.py:267-289) is an MFMA similarity strip + radix
   select on the device; its result stays there for the sampler.
 """
-import gc
 import math
 import os
 import time
@@ -326,7 +325,9 @@ class BasicModel:
             if self.args.neg_sampling == 'truncated' and i % self.args.truncated_freq == 0:
                 if neighbors1 is not None:
                     del neighbors1, neighbors2
-                gc.collect()
+                # (the reference calls gc.collect() here, basic_model.py:277: it frees the host neighbour dicts; the
+                #  device tables are released by reference count, and a full collection over the KG dictionaries
+                #  costs ~0.1 s -- a hundred epochs' worth of training at 15K)
                 neighbors1, neighbors2 = self._refresh_truncated_neighbours()
         if self._epochs is not None:
             self._epochs.check()
