@@ -151,6 +151,20 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
 int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, const int32_t *ids,
                               int64_t n, const float *src, int32_t src_ld, void *stream);
 
+/* MTransE's mapping step, fused (modules/base/mapping.py:9-19, losses.py:76-80, approaches/mtranse.py:84-96):
+ *   loss = alpha * (sum_n ||e2_n - e1_n M||^2 + ||M M^T - I||_F^2),  e = l2_normalize(ent)[ids] (if ent_l2_norm).
+ * M [dim, dim] row-major is updated in place (Adagrad with M_acc, or SGD); the gradients w.r.t. the NORMALISED
+ * entity rows are added into ent_grad [n_ent, ld] / ent_touched -- the step workspace's scratch, see
+ * oea_step_entity_scratch() -- so that oea_triple_step_phase(..., n_pos = 0, OEA_PHASE_APPLY) finishes the step.
+ * work: oea_mapping_workspace_floats(n, ld, dim) floats.  loss_accum += the batch loss. */
+size_t oea_mapping_workspace_floats(int64_t n_links, int32_t ld, int32_t dim);
+int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_norm, const int32_t *ids1,
+                     const int32_t *ids2, int64_t n, float *M, float *M_acc, float alpha, float lr, int32_t opt_kind,
+                     float *ent_grad, float *ent_touched, float *work, double *loss_accum, void *stream);
+/* addresses of the entity gradient scratch and its touched flags inside a step workspace */
+int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, float **ent_grad,
+                            float **ent_touched);
+
 /* ---------------------------------------------------------------------------------------
  * Negative sampling -- replaces generate_neg_triples_fast (modules/train/batch.py:89-119).
  * The membership set replaces the python set `all_triples_set`.

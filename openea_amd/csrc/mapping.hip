@@ -1,0 +1,132 @@
+// mapping.hip -- MTransE's mapping step, fused.
+//
+// Replaces add_mapping_module + mapping_loss + AdagradOptimizer.minimize (modules/base/mapping.py:9-19,
+// modules/base/losses.py:76-80, approaches/mtranse.py:84-96):
+//     loss = alpha * ( sum_n || e2_n - e1_n M ||^2  +  || M M^T - I ||_F^2 ),   e = l2_normalize(ent)[seed ids]
+// d is 75..300 and a batch a few hundred links, so the reference's five small matmuls (and their autodiff) are
+// launch-bound; here one step is three kernels:
+//   K1  one wave per link: normalise both rows, p = e1 M, diff = e2 - p, entity-row gradients
+//       g2 = 2a diff, g1 = -2a diff M^T straight into the translational step's gradient scratch (so that
+//       apply_rows pulls them through the normalisation and the optimiser), e1 / diff kept for K3,
+//   K2  orth = M M^T - I (one thread per entry) + its share of the loss,
+//   K3  g_M = a (-2 E1^T Diff + 4 orth M), fixed summation order (replicas of a data-parallel job get the same
+//       bits), Adagrad / SGD on M into a second buffer that is copied back (K3 reads all of M).
+#include "common.h"
+
+namespace {
+
+// workspace: [e1: n x ld][diff: n x ld][orth: d x d][m_new: d x d]
+__global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restrict__ ent, int ld, int dim, int l2norm,
+                                                            const int32_t *__restrict__ ids1, const int32_t *__restrict__ ids2,
+                                                            int64_t n, const float *__restrict__ M, float alpha,
+                                                            float *__restrict__ ent_grad, float *__restrict__ ent_touched,
+                                                            float *__restrict__ e1_out, float *__restrict__ diff_out,
+                                                            double *__restrict__ loss_accum) {
+    extern __shared__ float lds[];                       // per wave: y1 [dim], diff [dim]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *y1 = lds + wave * 2 * dim, *df = y1 + dim;
+    double loss_local = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+        const int a = ids1[i], b = ids2[i];
+        const float *r1 = ent + (int64_t)a * ld, *r2 = ent + (int64_t)b * ld;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < dim; c += 64) { const float u = r1[c], v = r2[c]; s1 += u * u; s2 += v * v; }
+        s1 = oea::group_sum<64>(s1);
+        s2 = oea::group_sum<64>(s2);
+        const float i1 = l2norm ? rsqrtf(fmaxf(s1, 1e-12f)) : 1.f, i2 = l2norm ? rsqrtf(fmaxf(s2, 1e-12f)) : 1.f;
+        for (int c = lane; c < dim; c += 64) y1[c] = r1[c] * i1;
+        __builtin_amdgcn_wave_barrier();
+        float sq = 0.f;
+        for (int c = lane; c < dim; c += 64) {           // p[c] = sum_k y1[k] M[k][c]: M rows read coalesced across lanes
+            float p = 0.f;
+            for (int k = 0; k < dim; ++k) p = fmaf(y1[k], M[(int64_t)k * dim + c], p);
+            const float d = r2[c] * i2 - p;
+            df[c] = d;
+            sq += d * d;
+            diff_out[i * ld + c] = d;
+            e1_out[i * ld + c] = y1[c];
+            oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c, 2.f * alpha * d);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < dim; k += 64) {           // g1[k] = -2a sum_c diff[c] M[k][c]
+            const float *mr = M + (int64_t)k * dim;
+            float g = 0.f;
+            for (int c = 0; c < dim; ++c) g = fmaf(df[c], mr[c], g);
+            oea::atomic_add_f32(ent_grad + (int64_t)a * ld + k, -2.f * alpha * g);
+        }
+        if (lane == 0) { ent_touched[a] = 1.f; ent_touched[b] = 1.f; }
+        sq = oea::group_sum<64>(sq);
+        if (lane == 0) loss_local += (double)sq;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && loss_local != 0.0) atomicAdd(loss_accum, (double)alpha * loss_local);
+}
+
+__global__ __launch_bounds__(256) void mapping_orth_kernel(const float *__restrict__ M, int dim, float alpha,
+                                                           float *__restrict__ orth, double *__restrict__ loss_accum) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    double sq = 0.0;
+    if (idx < dim * dim) {
+        const int k = idx / dim, j = idx % dim;
+        const float *a = M + (int64_t)k * dim, *b = M + (int64_t)j * dim;
+        float s = 0.f;
+        for (int c = 0; c < dim; ++c) s = fmaf(a[c], b[c], s);
+        s -= (k == j) ? 1.f : 0.f;
+        orth[idx] = s;
+        sq = (double)s * (double)s;
+    }
+    sq = oea::wave_sum_d(sq);
+    if ((threadIdx.x & 63) == 0 && sq != 0.0) atomicAdd(loss_accum, (double)alpha * sq);
+}
+
+__global__ __launch_bounds__(256) void mapping_update_kernel(const float *__restrict__ M, float *__restrict__ M_acc, int dim,
+                                                             const float *__restrict__ e1, const float *__restrict__ diff,
+                                                             int64_t n, int ld, const float *__restrict__ orth, float alpha,
+                                                             float lr, int opt_kind, float *__restrict__ M_new) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= dim * dim) return;
+    const int k = idx / dim, c = idx % dim;
+    float ed = 0.f;
+    for (int64_t i = 0; i < n; ++i) ed = fmaf(e1[i * ld + k], diff[i * ld + c], ed);      // (E1^T Diff)[k][c]
+    float om = 0.f;
+    for (int j = 0; j < dim; ++j) om = fmaf(orth[k * dim + j], M[(int64_t)j * dim + c], om);
+    const float g = alpha * (-2.f * ed + 4.f * om);
+    const float m = M[idx];
+    if (opt_kind == OEA_OPT_ADAGRAD) {
+        const float acc = M_acc[idx] + g * g;
+        M_acc[idx] = acc;
+        M_new[idx] = m - lr * g / sqrtf(acc);
+    } else {
+        M_new[idx] = m - lr * g;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t oea_mapping_workspace_floats(int64_t n_links, int32_t ld, int32_t dim) {
+    return (size_t)(2 * n_links * ld + 2 * (int64_t)dim * dim + 64);
+}
+
+int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_norm, const int32_t *ids1,
+                     const int32_t *ids2, int64_t n, float *M, float *M_acc, float alpha, float lr, int32_t opt_kind,
+                     float *ent_grad, float *ent_touched, float *work, double *loss_accum, void *stream) {
+    OEA_REQUIRE(ent && ids1 && ids2 && M && ent_grad && ent_touched && work && loss_accum, "null pointer");
+    OEA_REQUIRE(dim > 0 && dim <= ld && n >= 0, "dim <= ld");
+    OEA_REQUIRE(opt_kind == OEA_OPT_SGD || (opt_kind == OEA_OPT_ADAGRAD && M_acc), "Adagrad needs the accumulator of M");
+    OEA_REQUIRE(dim <= 2000, "dim <= 2000 (per-wave rows live in the default 64 KB of LDS)");
+    hipStream_t st = oea::as_stream(stream);
+    float *e1 = work, *diff = e1 + n * ld, *orth = diff + n * ld, *m_new = orth + (int64_t)dim * dim;
+    if (n > 0)
+        mapping_links_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n, 4), 4096), 256, sizeof(float) * 8 * dim, st>>>(
+            ent, ld, dim, ent_l2_norm, ids1, ids2, n, M, alpha, ent_grad, ent_touched, e1, diff, loss_accum);
+    const unsigned nb = (unsigned)oea::ceil_div((int64_t)dim * dim, 256);
+    mapping_orth_kernel<<<nb, 256, 0, st>>>(M, dim, alpha, orth, loss_accum);
+    mapping_update_kernel<<<nb, 256, 0, st>>>(M, M_acc, dim, e1, diff, n, ld, orth, alpha, lr, opt_kind, m_new);
+    OEA_CHECK_HIP(hipMemcpyAsync(M, m_new, sizeof(float) * (size_t)dim * dim, hipMemcpyDeviceToDevice, st));
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+}  // extern "C"

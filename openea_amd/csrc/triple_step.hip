@@ -838,6 +838,15 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     return OEA_OK;
 }
 
+int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, float **ent_grad, float **ent_touched) {
+    OEA_REQUIRE(workspace && ent_grad && ent_touched, "null pointer");
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    *ent_grad = ws.ent_grad;
+    *ent_touched = ws.ent_touched;
+    return OEA_OK;
+}
+
 int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, const int32_t *ids,
                               int64_t n, const float *src, int32_t src_ld, void *stream) {
     OEA_REQUIRE(workspace && ids && src && ld % 4 == 0 && src_ld >= ld, "shapes");

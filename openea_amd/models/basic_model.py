@@ -261,37 +261,27 @@ class BasicModel:
         print('epoch {}, avg. triple loss: {:.4f}, cost time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
 
     def launch_mapping_training_1epo(self, epoch, triple_steps):
-        """basic_model.py:238-250 / mtranse.py:84-96: triple_steps steps on |train| // steps random seed
-        links each; Adagrad on the entity rows (through the normalisation) and on M."""
+        """basic_model.py:238-250 / mtranse.py:84-96: triple_steps steps on |train| // steps random seed links each
+        (random.sample); Adagrad on the entity rows (through the normalisation) and on M.  One step = the fused
+        oea_mapping_step (3 kernels) + the apply phase of the step engine; the epoch's batches go up in one copy."""
         start = time.time()
-        epoch_loss = 0.0
-        trained_samples_num = 0
         links = np.asarray(self.kgs.train_links, np.int32)
         n_batch = len(links) // triple_steps
         rng = np.random.RandomState(self._seed + 1000 + epoch)
-        d, alpha, lr = self.args.dim, float(self.args.alpha), float(self.args.learning_rate)
-        loss_dev = torch.zeros((), dtype=torch.float64, device=self.mapping_mat.device)
-        for _ in range(triple_steps):
-            batch = links[rng.choice(len(links), n_batch, replace=False)]       # random.sample
-            ids1 = ops.to_ids(batch[:, 0], self.mapping_mat.device)
-            ids2 = ops.to_ids(batch[:, 1], self.mapping_mat.device)
-            e1 = self.ent_embeds.lookup(ids1)
-            e2 = self.ent_embeds.lookup(ids2)
-            M = self.mapping_mat
-            diff = e2[:, :d] - e1[:, :d] @ M                      # library GEMMs (K4: d <= 300)
-            orth = M @ M.t() - self.eye_mat
-            loss_dev += alpha * ((diff.double() ** 2).sum() + (orth.double() ** 2).sum())
-            g1 = torch.zeros_like(e1)
-            g2 = torch.zeros_like(e2)
-            g2[:, :d] = 2.0 * alpha * diff
-            g1[:, :d] = -2.0 * alpha * (diff @ M.t())
-            g_m = alpha * (-2.0 * (e1[:, :d].t() @ diff) + 4.0 * (orth @ M))
-            from . import dist as mdist
-            mdist.sync_replicated_(g_m)
-            self._mapping_trainer.apply_entity_row_grads(torch.cat([ids1, ids2]), torch.cat([g1, g2]))
-            self._mapping_acc += g_m * g_m                        # Adagrad on M (optimizers.py:11)
-            self.mapping_mat -= lr * g_m / torch.sqrt(self._mapping_acc)
-            trained_samples_num += n_batch
+        picks = np.stack([rng.choice(len(links), n_batch, replace=False) for _ in range(triple_steps)])
+        dev = self.mapping_mat.device
+        batches = ops.to_ids(np.ascontiguousarray(links[picks].transpose(0, 2, 1)), dev)      # [steps, 2, n_batch]
+        t = self._mapping_trainer
+        loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+        opt = self.mapping_optimizer['optimizer']
+        for s in range(triple_steps):
+            self._mapping_work = ops.mapping_step(self.ent_embeds.var, self.args.dim, self.ent_embeds.is_l2_norm,
+                                                  batches[s, 0], batches[s, 1], self.mapping_mat,
+                                                  self._mapping_acc if opt == 'Adagrad' else None, float(self.args.alpha),
+                                                  float(self.args.learning_rate), opt, t.ws, self.ent_embeds.rows,
+                                                  self.rel_embeds.rows, loss_dev, getattr(self, "_mapping_work", None))
+            t.apply_scratch()
+        trained_samples_num = n_batch * triple_steps
         epoch_loss = float(loss_dev.item()) / max(trained_samples_num, 1)
         print('epoch {}, avg. mapping loss: {:.4f}, cost time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
 

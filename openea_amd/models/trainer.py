@@ -93,6 +93,17 @@ class TripleTrainer:
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
 
+    def apply_scratch(self):
+        """optimiser step for whatever a kernel outside the fused step has added to the gradient scratch
+        (oea_mapping_step): the exchange (if any), then the apply phase."""
+        if self.dist is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
+            if self.replicated:
+                self.xchg /= dist.get_world_size(self.dist)
+        ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
+                        self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
+
     def pop_loss(self):
         """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data
         parallelism every rank holds the loss of its own slices; they are summed here."""

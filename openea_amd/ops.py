@@ -123,6 +123,22 @@ def step_scatter_ent_rows(workspace, n_ent, n_rel, ld, ids, src):
                                           src.shape[1], _stream()))
 
 
+def mapping_step(ent, dim, ent_l2_norm, ids1, ids2, mapping, mapping_acc, alpha, lr, optimizer, workspace, n_ent, n_rel,
+                 loss_accum, work=None):
+    """MTransE mapping step (oea_mapping_step): updates `mapping` in place and adds the entity-row gradients into
+    the step workspace's scratch; follow with triple_step(..., empty, phase=PHASE_APPLY)."""
+    n = ids1.numel()
+    need = lib().oea_mapping_workspace_floats(n, ent.shape[1], dim)
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.float32, device=ent.device)
+    eg, et = C.c_void_p(), C.c_void_p()
+    check(lib().oea_step_entity_scratch(_p(workspace), n_ent, n_rel, ent.shape[1], C.byref(eg), C.byref(et)))
+    check(lib().oea_mapping_step(_p(ent), ent.shape[1], dim, int(bool(ent_l2_norm)), _p(ids1), _p(ids2), n, _p(mapping),
+                                 _p(mapping_acc), float(alpha), float(lr), OPT_KIND[optimizer], eg, et, _p(work),
+                                 _p(loss_accum), _stream()))
+    return work
+
+
 def step_exchange_view(workspace, n_ent, n_rel, ld):
     """fp32 view of the workspace region (gradient scratch + touched flags) that data-parallel
     ranks sum with one all-reduce."""

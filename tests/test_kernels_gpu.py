@@ -541,3 +541,54 @@ def test_step_with_empty_shard_is_a_clean_noop(ops):
     for phase in (ops.PHASE_GRAD, ops.PHASE_APPLY):
         ops.triple_step(ent, ea, rel, ra, 16, empty, None, cfg, ws, loss, phase=phase)
     assert float(loss.item()) == l1 and torch.equal(ent, e1)
+
+
+# ---------------------------------------------------------------------------------------------
+# MTransE mapping step (modules/base/mapping.py:9-19, losses.py:76-80)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,n,opt", [(75, 250, "Adagrad"), (32, 37, "SGD"), (130, 64, "Adagrad")])
+def test_mapping_step_matches_oracle(ops, d, n, opt):
+    import torch
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(d)
+    n_ent = 900
+    ent = rng.standard_normal((n_ent, d)).astype(np.float32)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    M = (q + 0.05 * rng.standard_normal((d, d))).astype(np.float32)
+    links = np.stack([rng.choice(n_ent, n, replace=False), rng.choice(n_ent, n, replace=False)], 1).astype(np.int32)
+    links[3, 0] = links[5, 0]                                   # a repeated entity: gradients are summed
+    alpha, lr = 5.0, 0.01
+    e0, m0 = ent.copy(), M.copy()
+    ea0, ma0 = np.full_like(e0, 0.1), np.full_like(m0, 0.1)
+    ref_loss = 0.0
+    for _ in range(2):
+        if opt == "Adagrad":
+            ref_loss += orc.mapping_step(e0, m0, ea0, ma0, links, alpha, lr)
+        else:                                                   # SGD restated from the same gradients
+            v = e0.astype(np.float64); Mm = m0.astype(np.float64)
+            inv = 1.0 / np.sqrt(np.maximum((v ** 2).sum(1, keepdims=True), 1e-12)); y = v * inv
+            e1, e2 = y[links[:, 0]], y[links[:, 1]]
+            diff = e2 - e1 @ Mm; orth = Mm @ Mm.T - np.eye(d)
+            ref_loss += alpha * ((diff ** 2).sum() + (orth ** 2).sum())
+            gy = np.zeros_like(v); np.add.at(gy, links[:, 0], -2 * alpha * diff @ Mm.T); np.add.at(gy, links[:, 1], 2 * alpha * diff)
+            gv = (gy - y * (y * gy).sum(1, keepdims=True)) * inv
+            e0 = (v - lr * gv).astype(np.float32)
+            m0 = (Mm - lr * alpha * (-2.0 * e1.T @ diff + 4.0 * orth @ Mm)).astype(np.float32)
+    te = ops.to_table(ent)
+    tm = torch.from_numpy(M).to(te.device).contiguous()
+    tea, tma = torch.full_like(te, 0.1), torch.full_like(tm, 0.1)
+    rel = ops.to_table(rng.standard_normal((3, d)).astype(np.float32))
+    cfg = ops.make_step_cfg(loss="positive", optimizer=opt, lr=lr)
+    ws = ops.step_workspace(n_ent, 3, te.shape[1])
+    loss = torch.zeros(1, dtype=torch.float64, device=te.device)
+    dummy = torch.zeros(1, dtype=torch.float64, device=te.device)
+    empty = torch.zeros((0, 3), dtype=torch.int32, device=te.device)
+    ids1, ids2 = ops.to_ids(links[:, 0].copy()), ops.to_ids(links[:, 1].copy())
+    work = None
+    for _ in range(2):
+        work = ops.mapping_step(te, d, True, ids1, ids2, tm, tma if opt == "Adagrad" else None, alpha, lr, opt, ws, n_ent, 3, loss, work)
+        ops.triple_step(te, tea, rel, torch.full_like(rel, 0.1), d, empty, None, cfg, ws, dummy, phase=ops.PHASE_APPLY)
+    assert abs(float(loss.item()) - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert np.linalg.norm(te[:, :d].cpu().numpy() - e0) <= 1e-4 * np.linalg.norm(e0)
+    assert np.linalg.norm(tm.cpu().numpy() - m0) <= 1e-4 * np.linalg.norm(m0)
+    assert int(ws[: -8 * 4096].count_nonzero()) == 0
