@@ -171,7 +171,12 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
     if (i >= n1) return;
     const float *a = e1 + i * ld1, *b = e2 + i * ld2;
     float acc = 0.f;
-    for (int k = 0; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+    int k = 0;
+    for (; k + 4 <= dim; k += 4) {                    // 16-byte loads (ld % 4 == 0), the chain itself stays k-ordered
+        const float4 x = oea::ld4(a + k), y = oea::ld4(b + k);
+        acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+    }
+    for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
     if (csls_r) acc = (2.0f * acc - csls_r[i]) - csls_c[i];
     gold[i] = acc;
 }
@@ -699,7 +704,8 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
     const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
     int tpc = 1;
     if (metric == OEA_METRIC_INNER) {
-        gold_inner_kernel<<<gb, 256, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r, csls_c ? csls_c + gold_offset : nullptr, gold);
+        gold_inner_kernel<<<(unsigned)oea::ceil_div(n1, 64), 64, 0, st>>>(e1, n1, ld1, e2 + gold_offset * ld2, ld2, dim, csls_r,
+                                                                          csls_c ? csls_c + gold_offset : nullptr, gold);
         const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
         if (csls_r)
