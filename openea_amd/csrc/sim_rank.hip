@@ -479,23 +479,37 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int32_t *__res
         rs += r + 1;
         rr += 1.0 / (double)(r + 1);
     }
-    for (int k = 0; k <= nk; ++k) {
-        s_i[threadIdx.x] = k < nk ? h[k] : rs;
-        __syncthreads();
-        for (int off = blockDim.x / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) s_i[threadIdx.x] += s_i[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { if (k < nk) hits[k] = s_i[0]; else *rank_sum = s_i[0]; }
-        __syncthreads();
+    // wave butterflies (fixed pairing), then the 16 wave results in wave order: deterministic, two barriers in all
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long v[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = h[k];
+    v[8] = rs;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_i[wave * 9 + k] = v[k];
+        s_d[wave] = rr;
     }
-    s_d[threadIdx.x] = rr;
     __syncthreads();
-    for (int off = blockDim.x / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s_d[threadIdx.x] += s_d[threadIdx.x + off];
-        __syncthreads();
+    if (threadIdx.x <= 9) {
+        const int nw = blockDim.x >> 6;
+        if (threadIdx.x < 9) {
+            long long t = 0;
+            for (int w = 0; w < nw; ++w) t += s_i[w * 9 + threadIdx.x];
+            if ((int)threadIdx.x < nk) hits[threadIdx.x] = t;
+            else if (threadIdx.x == 8) *rank_sum = t;
+        } else {
+            double t = 0.0;
+            for (int w = 0; w < nw; ++w) t += s_d[w];
+            *rr_sum = t;
+        }
     }
-    if (threadIdx.x == 0) *rr_sum = s_d[0];
 }
 
 // ---- per-row top-k mean (CSLS) -------------------------------------------------------------------
