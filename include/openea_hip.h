@@ -247,6 +247,16 @@ int oea_sample_link_negatives(const int32_t *pos_links, int64_t n_pos, int32_t k
                               uint64_t exclude_cap, uint64_t seed, uint32_t step, int32_t *out_pairs, float *out_valid,
                               uint64_t *scratch_keys, int32_t *scratch_vals, uint64_t scratch_cap, void *stream);
 
+/* HOST arrays (the only entry point that takes host pointers besides oea_store_load/save_host): one-to-one
+ * selection among candidate pairs by descending weight (ties: smaller left, then smaller right id), standing in for
+ * the heuristic matching of modules/bootstrapping/alignment_finder.py:83-112.  selected[e] = 1 for the kept edges. */
+int oea_greedy_matching(const int32_t *left, const int32_t *right, const float *weight, int64_t n_edges,
+                        uint8_t *selected);
+/* out[i] = <e1[ii[i]], e2[jj[i]]> over the first dim columns (device arrays): similarities of listed pairs
+ * (sim_mat[x, y] lookups of the bootstrapping code). */
+int oea_pair_dots(const float *e1, int32_t ld1, const float *e2, int32_t ld2, int32_t dim, const int32_t *ii,
+                  const int32_t *jj, int64_t n, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):
  * np.matmul(sub_embed, embed.T) + per-row np.argpartition(-row, k)[:k].

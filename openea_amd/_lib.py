@@ -91,6 +91,8 @@ PROTOTYPES = {
     "oea_mapping_step": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp,
                                    _vp, _vp, _vp]),
     "oea_step_entity_scratch": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "oea_greedy_matching": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "oea_pair_dots": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "oea_perm_index": (_u32, [_u32, _u32, _u32]),
     "oea_sample_link_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _u64,
                                             _u64, _u32, _vp, _vp, _vp, _vp, _u64, _vp]),

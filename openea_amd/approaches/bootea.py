@@ -126,7 +126,7 @@ class BootEA(AlignE):
         r2 = self.ent_embeds.lookup(self.ref_ent2)
         ops.normalize_rows_(r1, d, sklearn=False)
         ops.normalize_rows_(r2, d, sklearn=False)
-        return PairSim(r1[:, :d].cpu().numpy(), r2[:, :d].cpu().numpy())
+        return PairSim(r1, r2, d)
 
     def launch_training_k_epo(self, iter, iter_nums, triple_steps, steps_tasks, training_batch_queue, neighbors1,
                               neighbors2):

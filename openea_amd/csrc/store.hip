@@ -43,6 +43,21 @@ struct oea_store {
     float *dev;
 };
 
+namespace {
+__global__ __launch_bounds__(256) void pair_dots_kernel(const float *__restrict__ e1, int ld1, const float *__restrict__ e2, int ld2,
+                                                        int dim, const int32_t *__restrict__ ii, const int32_t *__restrict__ jj,
+                                                        int64_t n, float *__restrict__ out) {
+    const int lane = threadIdx.x & 15;                                   // 16 lanes per pair
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (p >= n) return;
+    const float *a = e1 + (int64_t)ii[p] * ld1, *b = e2 + (int64_t)jj[p] * ld2;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 16) s = fmaf(a[c], b[c], s);
+    s = oea::group_sum<16>(s);
+    if (lane == 0) out[p] = s;
+}
+}  // namespace
+
 extern "C" {
 
 int oea_version(void) { return 100; }
@@ -78,6 +93,15 @@ int oea_profile_end(int32_t group, double *out_ms_host, int32_t *n_calls_host) {
         }
     *n_calls_host = (int32_t)n;
     oea::g_nmarks = 0;
+    return OEA_OK;
+}
+
+int oea_pair_dots(const float *e1, int32_t ld1, const float *e2, int32_t ld2, int32_t dim, const int32_t *ii,
+                  const int32_t *jj, int64_t n, float *out, void *stream) {
+    OEA_REQUIRE(e1 && e2 && (n == 0 || (ii && jj && out)) && dim > 0 && dim <= ld1 && dim <= ld2, "shapes");
+    if (n == 0) return OEA_OK;
+    pair_dots_kernel<<<(unsigned)oea::ceil_div(n * 16, 256), 256, 0, oea::as_stream(stream)>>>(e1, ld1, e2, ld2, dim, ii, jj, n, out);
+    OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
 

@@ -20,12 +20,37 @@ from ... import ops
 
 class PairSim:
     """sim_mat[i, j] of eval_ref_sim_mat (bootea.py:214-219) evaluated on demand from the two
-    L2-normalised reference embedding blocks instead of a materialised n x n matrix."""
+    L2-normalised reference embedding blocks instead of a materialised n x n matrix.  The blocks stay on the
+    device for the candidate search; single lookups (update_labeled_alignment_*) use a host copy."""
 
-    def __init__(self, embeds1, embeds2):
-        self.e1 = np.asarray(embeds1, np.float32)
-        self.e2 = np.asarray(embeds2, np.float32)
-        self.shape = (len(self.e1), len(self.e2))
+    def __init__(self, embeds1, embeds2, dim=None):
+        if hasattr(embeds1, "is_cuda"):
+            self.t1, self.t2 = embeds1, embeds2
+            self.dim = int(dim if dim is not None else embeds1.shape[1])
+            self._e1 = self._e2 = None
+        else:
+            self._e1 = np.asarray(embeds1, np.float32)
+            self._e2 = np.asarray(embeds2, np.float32)
+            self.dim = self._e1.shape[1]
+            self.t1 = self.t2 = None
+        self.shape = (len(embeds1), len(embeds2))
+
+    @property
+    def e1(self):
+        if self._e1 is None:
+            self._e1 = self.t1[:, :self.dim].cpu().numpy()
+        return self._e1
+
+    @property
+    def e2(self):
+        if self._e2 is None:
+            self._e2 = self.t2[:, :self.dim].cpu().numpy()
+        return self._e2
+
+    def tables(self):
+        if self.t1 is None:
+            self.t1, self.t2 = ops.to_table(self._e1), ops.to_table(self._e2)
+        return self.t1, self.t2
 
     def __getitem__(self, ij):
         i, j = ij
@@ -37,30 +62,48 @@ class PairSim:
 
 def search_nearest_k_device(sim, k):
     """alignment_finder.py:66-76: the k nearest columns of every row -> int32 [n, k] (host)."""
-    d = sim.e1.shape[1]
-    return ops.topk_inner(ops.to_table(sim.e1), ops.to_table(sim.e2), d, k).cpu().numpy()
+    t1, t2 = sim.tables()
+    return ops.topk_inner(t1, t2, sim.dim, k).cpu().numpy()
+
+
+def find_alignment_arrays(sim, sim_th, k):
+    """alignment_finder.py:28-51 without python tuples: (rows, cols, weights) host arrays of the pairs with
+    sim > sim_th that are among the row's k nearest; candidate search AND the pair similarities on the device."""
+    import torch
+    assert k > 0
+    t1, t2 = sim.tables()
+    idx = ops.topk_inner(t1, t2, sim.dim, k)                              # device [n, k]
+    n = idx.shape[0]
+    ii = torch.arange(n, dtype=torch.int32, device=idx.device).repeat_interleave(k)
+    jj = idx.reshape(-1).contiguous()
+    w = ops.pair_dots(t1, t2, sim.dim, ii, jj)
+    keep = (w > sim_th).cpu().numpy()
+    if not keep.any():
+        return None
+    return ii.cpu().numpy()[keep], jj.cpu().numpy()[keep], w.cpu().numpy()[keep]
 
 
 def find_alignment(sim, sim_th, k):
     """alignment_finder.py:28-51: pairs with sim > sim_th that are among the row's k nearest."""
-    assert k > 0
-    idx = search_nearest_k_device(sim, k)
-    ii = np.repeat(np.arange(idx.shape[0]), k)
-    jj = idx.reshape(-1)
-    w = sim.pairs(ii, jj)
-    keep = w > sim_th
-    if not keep.any():
+    r = find_alignment_arrays(sim, sim_th, k)
+    if r is None:
         return None, None
-    return list(zip(ii[keep].tolist(), jj[keep].tolist())), w[keep]
+    return list(zip(r[0].tolist(), r[1].tolist())), r[2]
 
 
 def check_new_alignment(aligned_pairs, context="check alignment"):
-    """alignment_finder.py:143-151."""
+    """alignment_finder.py:143-151 (also takes a (rows, cols) pair of arrays)."""
     if aligned_pairs is None or len(aligned_pairs) == 0:
         print("{}, empty aligned pairs".format(context))
         return
-    num = sum(1 for x, y in aligned_pairs if x == y)
-    print("{}, right alignment: {}/{}={:.3f}".format(context, num, len(aligned_pairs), num / len(aligned_pairs)))
+    if isinstance(aligned_pairs, tuple) and len(aligned_pairs) == 2 and hasattr(aligned_pairs[0], "dtype"):
+        num, total = int((aligned_pairs[0] == aligned_pairs[1]).sum()), len(aligned_pairs[0])
+        if total == 0:
+            print("{}, empty aligned pairs".format(context))
+            return
+    else:
+        num, total = sum(1 for x, y in aligned_pairs if x == y), len(aligned_pairs)
+    print("{}, right alignment: {}/{}={:.3f}".format(context, num, total, num / total))
 
 
 def greedy_weight_matching(pairs, weights):
@@ -101,12 +144,17 @@ def max_weight_matching(pairs, weights):
 def find_potential_alignment_mwgm(sim, sim_th, k, heuristic=True):
     """alignment_finder.py:12-25."""
     t = time.time()
-    pairs, w = find_alignment(sim, sim_th, k)
-    if pairs is None:
+    cand = find_alignment_arrays(sim, sim_th, k)
+    if cand is None:
         return None
-    check_new_alignment(pairs, context="after filtering by sim and nearest k")
+    ii, jj, w = cand
+    check_new_alignment((ii, jj), context="after filtering by sim and nearest k")
     t1 = time.time()
-    selected = greedy_weight_matching(pairs, w) if heuristic else max_weight_matching(pairs, w)
+    if heuristic:                       # native weight-descending selection (csrc/match.hip)
+        m = ops.greedy_matching(ii, jj, w)
+        selected = set(zip(ii[m].tolist(), jj[m].tolist()))
+    else:
+        selected = max_weight_matching(list(zip(ii.tolist(), jj.tolist())), w)
     check_new_alignment(selected, context="after mwgm")
     print("mwgm costs time: {:.3f} s".format(time.time() - t1))
     print("selecting potential alignment costs time: {:.3f} s".format(time.time() - t))

@@ -249,6 +249,25 @@ def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1
     return pairs, valid, scratch
 
 
+def greedy_matching(left, right, weight):
+    """HOST numpy arrays -> bool mask of the edges kept by the weight-descending one-to-one selection."""
+    left = np.ascontiguousarray(left, np.int32)
+    right = np.ascontiguousarray(right, np.int32)
+    weight = np.ascontiguousarray(weight, np.float32)
+    sel = np.zeros(len(left), np.uint8)
+    check(_lib.load(require_device=False).oea_greedy_matching(left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p),
+                                                              weight.ctypes.data_as(C.c_void_p), len(left),
+                                                              sel.ctypes.data_as(C.c_void_p)))
+    return sel.astype(bool)
+
+
+def pair_dots(e1, e2, dim, ii, jj):
+    """device: out[i] = <e1[ii[i]], e2[jj[i]]>."""
+    out = torch.empty(ii.numel(), dtype=torch.float32, device=e1.device)
+    check(lib().oea_pair_dots(_p(e1), e1.shape[1], _p(e2), e2.shape[1], dim, _p(ii), _p(jj), ii.numel(), _p(out), _stream()))
+    return out
+
+
 # -------------------------------------------------------------------------------------------
 # neighbour search / evaluation
 # -------------------------------------------------------------------------------------------
