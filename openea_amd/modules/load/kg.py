@@ -1,117 +1,114 @@
-"""In-memory KG (mirror of openea/modules/load/kg.py: same attribute names, kg.py:10-141)."""
+"""In-memory KG: the attribute surface of openea/modules/load/kg.py:10-141 (every `<x>_set`, `<x>_list`,
+`<x>_num` and `*_dict` a model or a loader of the reference reads), built from two generic helpers.
 
-
-def _ordered(s):
-    """list of a set in SORTED order.  The reference takes `list(set)` (kg.py:58,63,...), i.e. an arbitrary
-    order that changes with PYTHONHASHSEED for URI strings; data-parallel ranks (one process each) must
-    lay out identical batches and candidate lists, so the order is fixed here."""
-    return sorted(s)
+Every list is in SORTED order.  The reference takes `list(set)` (kg.py:58,63,...), an arbitrary order that
+changes with PYTHONHASHSEED for URI strings; data-parallel ranks (one process each) must lay out identical
+batches and candidate lists, so the order is fixed here."""
+from collections import defaultdict
 
 
 def parse_triples(triples):
-    subjects, predicates, objects = set(), set(), set()
-    for s, p, o in triples:
-        subjects.add(s)
-        predicates.add(p)
-        objects.add(o)
-    return subjects, predicates, objects
+    """The three column sets of a triple collection (kg.py:1-7)."""
+    columns = (set(), set(), set())
+    for triple in triples:
+        for column, item in zip(columns, triple):
+            column.add(item)
+    return columns
+
+
+def _grouped(triples, key, value):
+    """{triple[key]: {value(triple)}} as a plain dict of sets."""
+    groups = defaultdict(set)
+    for triple in triples:
+        groups[triple[key]].add(value(triple))
+    return dict(groups)
 
 
 class KG:
+    _STATS = (("entities", "entities"), ("relations", "relations"), ("attributes", "attributes"),
+              ("relation triples", "relation_triples"), ("attribute triples", "attribute_triples"),
+              ("local relation triples", "local_relation_triples"),
+              ("local attribute triples", "local_attribute_triples"))
+
     def __init__(self, relation_triples, attribute_triples, verbose=True):
-        self.entities_id_dict = None
-        self.relations_id_dict = None
-        self.attributes_id_dict = None
-        self.sup_relation_triples_set, self.sup_relation_triples_list = None, None
-        self.sup_attribute_triples_set, self.sup_attribute_triples_list = None, None
+        for name in ("entities", "relations", "attributes"):
+            setattr(self, name + "_id_dict", None)
+        for kind in ("relation", "attribute"):
+            setattr(self, "sup_%s_triples_set" % kind, None)
+            setattr(self, "sup_%s_triples_list" % kind, None)
         self.set_relations(relation_triples)
         self.set_attributes(attribute_triples)
         if verbose:
-            print()
-            print("KG statistics:")
-            print("Number of entities:", self.entities_num)
-            print("Number of relations:", self.relations_num)
-            print("Number of attributes:", self.attributes_num)
-            print("Number of relation triples:", self.relation_triples_num)
-            print("Number of attribute triples:", self.attribute_triples_num)
-            print("Number of local relation triples:", self.local_relation_triples_num)
-            print("Number of local attribute triples:", self.local_attribute_triples_num)
+            print("\nKG statistics:")
+            for label, name in self._STATS:
+                print("Number of %s:" % label, getattr(self, name + "_num"))
             print()
 
+    def _publish(self, name, items, aliases=()):
+        """<name>_set / _list / _num (and the same objects under each alias)."""
+        as_set = items if isinstance(items, set) else set(items)
+        as_list = sorted(as_set)
+        for prefix in (name,) + tuple(aliases):
+            setattr(self, prefix + "_set", as_set)
+            setattr(self, prefix + "_list", as_list)
+            setattr(self, prefix + "_num", len(as_list))
+
     def set_relations(self, relation_triples):
-        """kg.py:56-72."""
-        self.relation_triples_set = set(relation_triples)
-        self.relation_triples_list = _ordered(self.relation_triples_set)
-        self.local_relation_triples_set = self.relation_triples_set
-        self.local_relation_triples_list = self.relation_triples_list
+        """kg.py:56-72: the local triples ARE the training triples until sup triples are added."""
+        self._publish("relation_triples", set(relation_triples), aliases=("local_relation_triples",))
         heads, relations, tails = parse_triples(self.relation_triples_set)
-        self.entities_set = heads | tails
-        self.relations_set = relations
-        self.entities_list = _ordered(self.entities_set)
-        self.relations_list = _ordered(self.relations_set)
-        self.entities_num = len(self.entities_set)
-        self.relations_num = len(self.relations_set)
-        self.relation_triples_num = len(self.relation_triples_set)
-        self.local_relation_triples_num = len(self.local_relation_triples_set)
+        self._publish("entities", heads | tails)
+        self._publish("relations", relations)
         self.generate_relation_triple_dict()
         self.parse_relations()
 
     def set_attributes(self, attribute_triples):
         """kg.py:74-93 (entities that only occur in attribute triples join the entity set)."""
-        self.attribute_triples_set = set(attribute_triples)
-        self.attribute_triples_list = _ordered(self.attribute_triples_set)
-        self.local_attribute_triples_set = self.attribute_triples_set
-        self.local_attribute_triples_list = self.attribute_triples_list
-        entities, attributes, _ = parse_triples(self.attribute_triples_set)
-        self.attributes_set = attributes
-        self.attributes_list = _ordered(self.attributes_set)
-        self.attributes_num = len(self.attributes_set)
-        self.entities_set |= entities
-        self.entities_list = _ordered(self.entities_set)
-        self.entities_num = len(self.entities_set)
-        self.attribute_triples_num = len(self.attribute_triples_set)
-        self.local_attribute_triples_num = len(self.local_attribute_triples_set)
+        self._publish("attribute_triples", set(attribute_triples), aliases=("local_attribute_triples",))
+        subjects, attributes, _ = parse_triples(self.attribute_triples_set)
+        self._publish("attributes", attributes)
+        self.entities_set |= subjects
+        self._publish("entities", self.entities_set)
         self.generate_attribute_triple_dict()
         self.parse_attributes()
 
     def generate_relation_triple_dict(self):
         """kg.py:95-105: rt_dict[h] = {(r,t)}, hr_dict[t] = {(h,r)}."""
-        self.rt_dict, self.hr_dict = dict(), dict()
-        for h, r, t in self.local_relation_triples_list:
-            self.rt_dict.setdefault(h, set()).add((r, t))
-            self.hr_dict.setdefault(t, set()).add((h, r))
+        local = self.local_relation_triples_list
+        self.rt_dict = _grouped(local, 0, lambda x: (x[1], x[2]))
+        self.hr_dict = _grouped(local, 2, lambda x: (x[0], x[1]))
 
     def generate_attribute_triple_dict(self):
-        self.av_dict = dict()
-        for h, a, v in self.local_attribute_triples_list:
-            self.av_dict.setdefault(h, set()).add((a, v))
+        """kg.py:107-114: av_dict[e] = {(a,v)}."""
+        self.av_dict = _grouped(self.local_attribute_triples_list, 0, lambda x: (x[1], x[2]))
 
     def parse_relations(self):
-        self.entity_relations_dict = dict()
-        for ent, rel, _ in self.local_relation_triples_set:
-            self.entity_relations_dict.setdefault(ent, set()).add(rel)
+        """kg.py:116-122."""
+        self.entity_relations_dict = _grouped(self.local_relation_triples_list, 0, lambda x: x[1])
 
     def parse_attributes(self):
-        self.entity_attributes_dict = dict()
-        for ent, attr, _ in self.local_attribute_triples_set:
-            self.entity_attributes_dict.setdefault(ent, set()).add(attr)
+        """kg.py:124-130."""
+        self.entity_attributes_dict = _grouped(self.local_attribute_triples_list, 0, lambda x: x[1])
 
     def set_id_dict(self, entities_id_dict, relations_id_dict, attributes_id_dict):
-        self.entities_id_dict = entities_id_dict
-        self.relations_id_dict = relations_id_dict
-        self.attributes_id_dict = attributes_id_dict
+        self.entities_id_dict, self.relations_id_dict, self.attributes_id_dict = \
+            entities_id_dict, relations_id_dict, attributes_id_dict
+
+    def _add_sup(self, kind, sup_triples):
+        """The seed-swapped triples join the training triples IN PLACE, as kg.py:136-141 does: the
+        local_*_set is the same set object and grows with it (the aliasing of kg.py:59/77, kept because
+        the golden loader statistics come from the reference), while local_*_list/_num and the dicts built
+        from them keep the pre-swap triples."""
+        sup = set(sup_triples)
+        setattr(self, "sup_%s_triples_set" % kind, sup)
+        setattr(self, "sup_%s_triples_list" % kind, sorted(sup))
+        training = getattr(self, "%s_triples_set" % kind)
+        training |= sup
+        self._publish("%s_triples" % kind, training)
 
     def add_sup_relation_triples(self, sup_triples):
-        """kg.py:136-141 (seed-swapped triples join the training triples, not rt/hr_dict)."""
-        self.sup_relation_triples_set = set(sup_triples)
-        self.sup_relation_triples_list = _ordered(self.sup_relation_triples_set)
-        self.relation_triples_set |= sup_triples
-        self.relation_triples_list = _ordered(self.relation_triples_set)
-        self.relation_triples_num = len(self.relation_triples_list)
+        """kg.py:136-141."""
+        self._add_sup("relation", sup_triples)
 
     def add_sup_attribute_triples(self, sup_triples):
-        self.sup_attribute_triples_set = set(sup_triples)
-        self.sup_attribute_triples_list = _ordered(self.sup_attribute_triples_set)
-        self.attribute_triples_set |= sup_triples
-        self.attribute_triples_list = _ordered(self.attribute_triples_set)
-        self.attribute_triples_num = len(self.attribute_triples_list)
+        self._add_sup("attribute", sup_triples)
