@@ -88,7 +88,7 @@ int oea_fill_f32(float *p, int64_t n, float value, void *stream);
 enum { OEA_LOSS_MARGIN = 0, OEA_LOSS_LIMITED = 1, OEA_LOSS_LOGISTIC = 2, OEA_LOSS_POSITIVE = 3,
        OEA_LOSS_ALIGN = 4 };
 enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1 };
-enum { OEA_SCORE_TRANSE = 0, OEA_SCORE_TRANSH = 1 };
+enum { OEA_SCORE_TRANSE = 0, OEA_SCORE_TRANSH = 1, OEA_SCORE_TRANSD = 2 };
 
 typedef struct oea_step_cfg {
     int32_t loss_kind;   /* OEA_LOSS_* */
@@ -108,10 +108,16 @@ typedef struct oea_step_cfg {
                             entries that are not corruptions of pos p are still scored correctly). */
     int32_t score_kind;  /* OEA_SCORE_TRANSE: s = |h + r - t|;  OEA_SCORE_TRANSH (approaches/bootea_transh.py:58-96):
                             h, t projected on the relation's hyperplane first, h' = h - (h.n) n with
-                            n = l2_normalize(l2_normalize(normal[r])).  TransH needs neg_group_k > 0 (sampler layout)
-                            or no negatives, and a per-triple loss (not OEA_LOSS_MARGIN). */
+                            n = l2_normalize(l2_normalize(normal[r])) -- also models/trans/transh.py:16-51 (margin
+                            pairs, free negative lists).  OEA_SCORE_TRANSD (models/trans/transd.py:16-57):
+                            h' = l2_normalize(h + (h.hp) rp) with the transfer vectors hp = ent[ent_transfer_base + h],
+                            rp = rel[rel_transfer_base + r] stored in the same tables (below). */
     float *normal;       /* TransH: [n_rel, ld] normal_vector table (trained in place), else NULL */
     float *normal_acc;   /* TransH + Adagrad: its accumulator, else NULL */
+    int32_t ent_transfer_base; /* TransD: `ent` has 2*base rows, [0, base) = ent_embeds, [base, 2 base) = ent_transfer */
+    int32_t rel_transfer_base; /* TransD: `rel` has 2*base rows, [0, base) = rel_embeds, [base, 2 base) = rel_transfer;
+                                  triple ids stay in [0, base); both halves share the l2_norm flag and the optimiser
+                                  (transd.py:16-24), so scratch, exchange and apply see ordinary rows */
 } oea_step_cfg;
 
 /* Workspace owned by the caller, sized by oea_step_workspace_bytes(); must be zero-initialised

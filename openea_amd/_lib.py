@@ -21,7 +21,8 @@ class StepCfg(C.Structure):
                 ("pos_margin", C.c_float), ("neg_margin", C.c_float), ("balance", C.c_float),
                 ("ent_l2_norm", C.c_int32), ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32),
                 ("lr", C.c_float), ("neg_group_k", C.c_int32), ("score_kind", C.c_int32),
-                ("normal", C.c_void_p), ("normal_acc", C.c_void_p)]
+                ("normal", C.c_void_p), ("normal_acc", C.c_void_p),
+                ("ent_transfer_base", C.c_int32), ("rel_transfer_base", C.c_int32)]
 
 
 class SamplerSide(C.Structure):

@@ -562,6 +562,172 @@ __global__ __launch_bounds__(256) void triple_transh_grouped(
     block_loss_partial(loss_local, ws.partials);
 }
 
+// ---- projected scores, one group per work item (models/trans/transh.py:16-51, models/trans/transd.py:16-57) ------
+// The plain ModelFamily members: margin loss on pairs (pos i, neg i) or a per-triple loss on arbitrary lists, rows
+// projected before the translation.
+//   TransH  h' = h - (h.n) n                        n = l2n(l2n(normal[r]))            (transh.py:48-51)
+//   TransD  h' = l2n(h + (h.hp) rp)                 hp = ent_transfer[h], rp = rel_transfer[r]  (transd.py:56-57)
+// TransD keeps its transfer vectors in the SAME tables, rows [base, base + n): the gradient scratch, the exchange
+// and apply_rows treat them like any other row (same l2_norm flag, same optimiser -- transd.py:16-24).
+// mode 0: score only; 1: score + gradient with the given dL/ds; 2: dL/ds from the per-triple loss (returns it in l).
+template <int G, int IT>
+__device__ float transd_triple(const float *__restrict__ ent, const float *__restrict__ rel, int ld, int lane,
+                               int64_t item, int h, int r, int t, bool is_pos, const oea_step_cfg &cfg,
+                               const StepWs &ws, int mode, float coef, float &l) {
+    const int64_t eb = cfg.ent_transfer_base, rb = cfg.rel_transfer_base;
+    Row<G, IT> yh, yt, yr, hp, tp, rp, H, T, g;
+    load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+    load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+    load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+    load_row<G, IT>(ent + (eb + h) * ld, ld, lane, hp);
+    load_row<G, IT>(ent + (eb + t) * ld, ld, lane, tp);
+    load_row<G, IT>(rel + (rb + r) * ld, ld, lane, rp);
+    normalize<G, IT>(yh, cfg.ent_l2_norm);
+    normalize<G, IT>(yt, cfg.ent_l2_norm);
+    normalize<G, IT>(yr, cfg.rel_l2_norm);
+    normalize<G, IT>(hp, cfg.ent_l2_norm);
+    normalize<G, IT>(tp, cfg.ent_l2_norm);
+    normalize<G, IT>(rp, cfg.rel_l2_norm);
+    const float ah = dot<G, IT>(yh, hp), at = dot<G, IT>(yt, tp);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        H.v[it] = yh.v[it] + ah * rp.v[it];
+        T.v[it] = yt.v[it] + at * rp.v[it];
+    }
+    const float ssh = sumsq<G, IT>(H), sst = sumsq<G, IT>(T);
+    const float ih = rsqrtf(fmaxf(ssh, 1e-12f)), itl = rsqrtf(fmaxf(sst, 1e-12f));
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        H.v[it] *= ih;
+        T.v[it] *= itl;
+        const float d = H.v[it] + yr.v[it] - T.v[it];
+        g.v[it] = d;
+        s += cfg.l1 ? fabsf(d) : d * d;
+    }
+    s = group_sum<G>(s);
+    l = 0.f;
+    if (mode == 0) return s;
+    if (mode == 2) triple_coef(cfg, is_pos, s, coef, l);
+    if (coef == 0.f) return s;
+    {
+        Row<G, IT> d0 = g;
+        dscore<G, IT>(d0, coef, cfg.l1, g);
+    }
+    // back through the two projections' normalisation: q = (g - (g.H) H) / |u|  (the clamp branch passes g / |u|)
+    const float ch = ssh > 1e-12f ? dot<G, IT>(g, H) : 0.f, ct = sst > 1e-12f ? dot<G, IT>(g, T) : 0.f;
+    Row<G, IT> qh, qt;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        qh.v[it] = (g.v[it] - ch * H.v[it]) * ih;
+        qt.v[it] = (ct * T.v[it] - g.v[it]) * itl;
+    }
+    const float bh = dot<G, IT>(qh, rp), bt = dot<G, IT>(qt, rp);
+    Row<G, IT> o;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) o.v[it] = qh.v[it] + bh * hp.v[it];
+    atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, o, 1.f);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) o.v[it] = bh * yh.v[it];
+    atomic_row<G, IT>(ws.ent_grad + (eb + h) * ld, ld, lane, o, 1.f);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) o.v[it] = qt.v[it] + bt * tp.v[it];
+    atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, o, 1.f);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) o.v[it] = bt * yt.v[it];
+    atomic_row<G, IT>(ws.ent_grad + (eb + t) * ld, ld, lane, o, 1.f);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) o.v[it] = ah * qh.v[it] + at * qt.v[it];
+    atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (rb + r) * ld, ld, lane, o, 1.f);
+    atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, g, 1.f);
+    if (lane == 0) {
+        ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.ent_touched[eb + h] = 1.f; ws.ent_touched[eb + t] = 1.f;
+        ws.rel_touched[r] = 1.f; ws.rel_touched[rb + r] = 1.f;
+    }
+    return s;
+}
+
+template <int G, int IT>
+__device__ float transh_triple(const float *__restrict__ ent, const float *__restrict__ rel, int ld, int lane,
+                               int64_t item, int h, int r, int t, bool is_pos, const oea_step_cfg &cfg,
+                               const StepWs &ws, int mode, float coef, float &l) {
+    Row<G, IT> yh, yr, yt, yn, g;
+    load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
+    load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
+    load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+    load_normal<G, IT>(cfg.normal, r, ld, lane, yn);
+    normalize<G, IT>(yh, cfg.ent_l2_norm);
+    normalize<G, IT>(yr, cfg.rel_l2_norm);
+    normalize<G, IT>(yt, cfg.ent_l2_norm);
+    const float ah = dot<G, IT>(yh, yn), at = dot<G, IT>(yt, yn);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const float d = (yh.v[it] - ah * yn.v[it]) + yr.v[it] - (yt.v[it] - at * yn.v[it]);
+        g.v[it] = d;
+        s += cfg.l1 ? fabsf(d) : d * d;
+    }
+    s = group_sum<G>(s);
+    l = 0.f;
+    if (mode == 0) return s;
+    if (mode == 2) triple_coef(cfg, is_pos, s, coef, l);
+    if (coef == 0.f) return s;
+    {
+        Row<G, IT> d0 = g;
+        dscore<G, IT>(d0, coef, cfg.l1, g);
+    }
+    const float gdn = dot<G, IT>(g, yn);
+    Row<G, IT> pg, gn;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        pg.v[it] = g.v[it] - gdn * yn.v[it];
+        gn.v[it] = (at - ah) * g.v[it] + gdn * (yt.v[it] - yh.v[it]);
+    }
+    atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, pg, 1.f);
+    atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, pg, -1.f);
+    atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, g, 1.f);
+    atomic_row<G, IT>(ws.nrm_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, gn, 1.f);
+    if (lane == 0) { ws.ent_touched[h] = 1.f; ws.ent_touched[t] = 1.f; ws.rel_touched[r] = 1.f; ws.nrm_touched[r] = 1.f; }
+    return s;
+}
+
+template <int G, int IT, int KIND>
+__global__ __launch_bounds__(256) void triple_projected(
+    const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
+    int64_t n_pos, const int32_t *__restrict__ neg, int64_t n_neg, oea_step_cfg cfg, StepWs ws) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    const bool margin = cfg.loss_kind == OEA_LOSS_MARGIN;
+    const int64_t items = margin ? n_pos : n_pos + n_neg;
+    double loss_local = 0.0;
+    auto one = [&](int64_t item, const int32_t *tr, bool is_pos, int mode, float coef, float &l) {
+        if (KIND == OEA_SCORE_TRANSD)
+            return transd_triple<G, IT>(ent, rel, ld, lane, item, tr[0], tr[1], tr[2], is_pos, cfg, ws, mode, coef, l);
+        return transh_triple<G, IT>(ent, rel, ld, lane, item, tr[0], tr[1], tr[2], is_pos, cfg, ws, mode, coef, l);
+    };
+    for (int64_t item = grp; item < items; item += ngrp) {
+        float l;
+        if (!margin) {
+            const bool is_pos = item < n_pos;
+            one(item, is_pos ? pos + 3 * item : neg + 3 * (item - n_pos), is_pos, 2, 0.f, l);
+            if (lane == 0) loss_local += (double)l;
+            continue;
+        }
+        // losses.py:15-27: sum relu(margin + s+ - s-), pos i paired with neg i; both are scored first, the active
+        // pairs are evaluated again for their gradients (dL/ds+ = 1, dL/ds- = -1)
+        float sc[2];
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) sc[u] = one(item, (u ? neg : pos) + 3 * item, u == 0, 0, 0.f, l);
+        const float x = cfg.margin + sc[0] - sc[1];
+        if (x <= 0.f) continue;
+        if (lane == 0) loss_local += (double)x;
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) one(item, (u ? neg : pos) + 3 * item, u == 0, 1, u ? -1.f : 1.f, l);
+    }
+    block_loss_partial(loss_local, ws.partials);
+}
+
 // optimiser on the touched normal-vector rows: gradient back through BOTH normalisations
 template <int G, int IT>
 __global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, oea_step_cfg cfg, StepWs ws, int copies_folded) {
@@ -742,8 +908,12 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
                 const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
-    const bool transh = cfg.score_kind == OEA_SCORE_TRANSH;
-    const bool grouped = transh || (cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
+    const bool transh = cfg.score_kind == OEA_SCORE_TRANSH, transd = cfg.score_kind == OEA_SCORE_TRANSD;
+    // TransH with a per-triple loss on the sampler's grouped layout keeps its grouped kernel; margin pairs, free
+    // negative lists and TransD take the one-item-per-group kernel
+    const bool transh_grouped = transh && cfg.loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg.neg_group_k > 0);
+    const bool projected = transd || (transh && !transh_grouped);
+    const bool grouped = transh_grouped || (!projected && cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
     const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
     // profiling marks, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3]; a GRAD call records the first pair and
@@ -751,7 +921,11 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     if (phase != OEA_PHASE_APPLY) {
         oea::prof_call();
         oea::prof_mark(st);
-        if (transh)
+        if (transd)
+            triple_projected<G, IT, OEA_SCORE_TRANSD><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+        else if (projected)
+            triple_projected<G, IT, OEA_SCORE_TRANSH><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+        else if (transh)
             triple_transh_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
         else if (grouped)
             triple_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, cfg.neg_group_k, cfg, ws);
@@ -814,12 +988,13 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
         OEA_REQUIRE(n_neg == 0, "positive-only loss takes no negatives");
     OEA_REQUIRE(cfg->neg_group_k >= 0 && (cfg->neg_group_k == 0 || n_neg == n_pos * (int64_t)cfg->neg_group_k),
                 "neg_group_k > 0 needs n_neg == n_pos * neg_group_k");
-    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE || cfg->score_kind == OEA_SCORE_TRANSH, "score_kind");
-    if (cfg->score_kind == OEA_SCORE_TRANSH) {
+    OEA_REQUIRE(cfg->score_kind >= OEA_SCORE_TRANSE && cfg->score_kind <= OEA_SCORE_TRANSD, "score_kind");
+    if (cfg->score_kind == OEA_SCORE_TRANSH)
         OEA_REQUIRE(cfg->normal && (cfg->opt_kind != OEA_OPT_ADAGRAD || cfg->normal_acc), "TransH needs the normal_vector table (+ accumulator)");
-        OEA_REQUIRE(cfg->loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg->neg_group_k > 0),
-                    "TransH: per-triple loss and negatives in the sampler's grouped layout");
-    }
+    if (cfg->score_kind == OEA_SCORE_TRANSD)
+        OEA_REQUIRE(cfg->ent_transfer_base > 0 && cfg->rel_transfer_base > 0 && 2 * (int64_t)cfg->ent_transfer_base == n_ent &&
+                        2 * (int64_t)cfg->rel_transfer_base == n_rel,
+                    "TransD: the tables hold the embeddings in rows [0, base) and the transfer vectors in [base, 2 base)");
     if (n_pos + n_neg == 0 && phase != OEA_PHASE_APPLY) return OEA_OK;   // apply-only: externally scattered gradients
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);

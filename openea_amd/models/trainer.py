@@ -23,10 +23,13 @@ class EmbeddingTable:
     """A trainable table: raw variable [rows, ld] on the device + the l2_norm flag that the
     reference bakes into the tensor returned by init_embeddings (initializers.py:26)."""
 
-    def __init__(self, host_init, is_l2_norm, name, dev=None):
+    def __init__(self, host_init, is_l2_norm, name, dev=None, visible_rows=None):
+        """visible_rows: the rows that ARE the reference's variable when further rows are stacked below them
+        (TransD keeps ent_transfer / rel_transfer in rows [visible_rows, rows) of the same table)."""
         host_init = np.asarray(host_init, np.float32)
         self.name = name
         self.rows, self.dim = host_init.shape
+        self.visible_rows = self.rows if visible_rows is None else int(visible_rows)
         self.is_l2_norm = bool(is_l2_norm)
         self.var = ops.to_table(host_init, dev=dev)          # [rows, ld], pad columns zero
         self.ld = self.var.shape[1]
@@ -39,11 +42,11 @@ class EmbeddingTable:
 
     def eval(self, session=None):
         """`.eval(session=...)` of the reference: the (normalised) table on the host [rows, dim]."""
-        ids = torch.arange(self.rows, dtype=torch.int32, device=self.var.device)
+        ids = torch.arange(self.visible_rows, dtype=torch.int32, device=self.var.device)
         return self.lookup(ids)[:, :self.dim].cpu().numpy()
 
     def raw(self):
-        return self.var[:, :self.dim].cpu().numpy()
+        return self.var[:self.visible_rows, :self.dim].cpu().numpy()
 
 
 class TripleTrainer:

@@ -85,16 +85,24 @@ def normalize_rows_(table, dim, sklearn=True):
 # -------------------------------------------------------------------------------------------
 
 
+SCORE_TRANSE, SCORE_TRANSH, SCORE_TRANSD = 0, 1, 2
+
+
 def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, neg_margin=0.0,
                   balance=1.0, ent_l2_norm=True, rel_l2_norm=True, optimizer='Adagrad', lr=0.01,
-                  neg_group_k=0, normal=None, normal_acc=None):
+                  neg_group_k=0, normal=None, normal_acc=None, transfer_bases=None):
     """neg_group_k = k when the negatives are laid out as the device sampler writes them
     (neg[p*k:(p+1)*k] corrupt pos p); 0 for arbitrary lists.
-    normal (+ normal_acc for Adagrad): device [n_rel, ld] normal_vector table -> TransH scoring."""
+    normal (+ normal_acc for Adagrad): device [n_rel, ld] normal_vector table -> TransH scoring.
+    transfer_bases = (n_ent, n_rel): TransD scoring on stacked tables (rows [n, 2n) hold the transfer vectors)."""
+    assert normal is None or transfer_bases is None
+    score = SCORE_TRANSH if normal is not None else (SCORE_TRANSD if transfer_bases is not None else SCORE_TRANSE)
+    eb, rb = transfer_bases if transfer_bases is not None else (0, 0)
     cfg = StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
                   float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
-                  OPT_KIND[optimizer], float(lr), int(neg_group_k), 0 if normal is None else 1,
-                  None if normal is None else normal.data_ptr(), None if normal_acc is None else normal_acc.data_ptr())
+                  OPT_KIND[optimizer], float(lr), int(neg_group_k), score,
+                  None if normal is None else normal.data_ptr(), None if normal_acc is None else normal_acc.data_ptr(),
+                  int(eb), int(rb))
     cfg._keep = (normal, normal_acc)
     return cfg
 

@@ -1,6 +1,6 @@
 """Hyper-parameter sets of the approaches on the hot path, as python dicts.
 
-The values are the ones the reference ships in run/args/{mtranse,bootea,aligne,gcnalign}_args_{15K,100K}.json
+The values are the ones the reference ships in run/args/{mtranse,bootea,aligne,gcnalign,transh,transd,...}_args_{15K,100K}.json
 (the `args_*` API: one attribute per key).  ``get_args(name, scale)`` returns an ``ARGs`` object that any
 model accepts through ``set_args``; a reference JSON file loaded with ``load_args`` works the same way.
 """
@@ -28,6 +28,11 @@ _ARGS = {
                           optimizer="Adagrad", batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2,
                           neg_sampling="truncated", neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10,
                           eval_metric="inner", eval_norm=False, sim_th=0.7, k=10, likelihood_slice=10, sub_epoch=10),
+    # run/args/trans{h,d}_args_*.json (TransE takes the same set: models/trans/transe.py:20-29 asserts it)
+    **{name: dict(embedding_module=name, alignment_module="sharing", dim=100, init="normal", ent_l2_norm=True,
+                  rel_l2_norm=True, loss="margin-based", loss_norm="L2", margin=1.5, neg_sampling="uniform",
+                  neg_triple_num=1, learning_rate=0.01, optimizer="Adagrad", batch_size=5000, eval_metric="inner",
+                  eval_norm=False) for name in ("TransE", "TransH", "TransD")},
     "GCN_Align": dict(embedding_module="GCN_Align", alignment_module="mapping", dim=100, neg_sampling="uniform",
                       neg_triple_num=5, learning_rate=8, batch_size=5000, test_threads_num=3, eval_metric="manhattan",
                       eval_norm=False, support_number=1, se_dim=100, ae_dim=100, hidden1=100, gamma=3,
@@ -49,6 +54,9 @@ _SCALE_100K = {
     "AlignE": dict(batch_size=20000, truncated_epsilon=0.98),
     "BootEA": dict(batch_size=20000, truncated_epsilon=0.98),
     "BootEA_TransH": dict(batch_size=20000, truncated_epsilon=0.98),
+    "TransE": dict(batch_size=20000),
+    "TransH": dict(batch_size=20000),
+    "TransD": dict(batch_size=20000),
     "GCN_Align": dict(batch_size=20000, learning_rate=25),
     "AliNet": dict(batch_size=20000, truncated_epsilon=0.995, min_rel_win=15),
     "RDGCN": dict(batch_size=20000, learning_rate=0.001, start_valid=50),

@@ -213,6 +213,24 @@ def triple_step_transh(ent, ent_acc, rel, rel_acc, nrm, nrm_acc, pos, neg, *, lo
              C.c_int(0 if neg is None else len(neg)), C.byref(cfg))
 
 
+def triple_step_transd(ent, ent_acc, rel, rel_acc, pos, neg, *, loss="margin-based", loss_norm="L2", margin=1.0,
+                       pos_margin=0.01, neg_margin=2.0, balance=1.0, ent_l2_norm=True, rel_l2_norm=True,
+                       optimizer="Adagrad", lr=0.01):
+    """TransD step (models/trans/transd.py:16-57) in place on STACKED fp32 tables, ent = [ent_embeds ; ent_transfer]
+    and rel = [rel_embeds ; rel_transfer]; returns the batch loss."""
+    for a in (ent, rel):
+        assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape[0] % 2 == 0
+    pos = _i32(pos).reshape(-1, 3)
+    neg = _i32(neg).reshape(-1, 3) if neg is not None and len(neg) else None
+    cfg = StepCfg(LOSS[loss], 1 if loss_norm == "L1" else 0, margin, pos_margin, neg_margin,
+                  balance, int(bool(ent_l2_norm)), int(bool(rel_l2_norm)), OPT[optimizer], lr)
+    f = lib().oracle_triple_step_transd
+    f.restype = C.c_double
+    return f(_p(ent), _p(ent_acc), C.c_int(ent.shape[0]), _p(rel), _p(rel_acc), C.c_int(rel.shape[0]),
+             C.c_int(ent.shape[1]), _p(pos), C.c_int(len(pos)), _p(neg), C.c_int(0 if neg is None else len(neg)),
+             C.byref(cfg))
+
+
 def spmm_coo(rows, cols, vals, x, n_rows):
     rows, cols, vals, x = _i32(rows), _i32(cols), _f32(vals), _f32(x)
     y = np.empty((n_rows, x.shape[1]), np.float32)

@@ -469,6 +469,89 @@ def test_transh_step_matches_oracle(ops, d, k, loss, opt):
         assert np.linalg.norm((a - b).cpu().numpy()) <= 2e-6 * np.linalg.norm(a.cpu().numpy())
 
 
+@pytest.mark.parametrize("d,loss,free_list", [(40, "margin-based", False), (100, "margin-based", False),
+                                              (75, "limited", True), (300, "margin-based", False)])
+def test_transh_margin_and_free_lists_match_oracle(ops, d, loss, free_list):
+    """models/trans/transh.py:16-51: margin pairs (pos i, neg i) -- and a per-triple loss on an UNGROUPED negative
+    list (3 negatives for 400 positives: not the sampler layout) -- take the one-item-per-group kernel."""
+    import torch
+    from oracle import cport
+    rng = np.random.RandomState(d)
+    n_ent, n_rel, n_pos = 500, 13, 400
+    ent, rel, nrm = (rng.standard_normal((n, d)).astype(np.float32) for n in (n_ent, n_rel, n_rel))
+    pos = np.stack([rng.randint(0, n_ent, n_pos), np.minimum(rng.zipf(1.6, n_pos) - 1, n_rel - 1),
+                    rng.randint(0, n_ent, n_pos)], 1).astype(np.int32)
+    n_neg = 3 if free_list else n_pos
+    neg = np.stack([rng.randint(0, n_ent, n_neg), rng.randint(0, n_rel, n_neg), rng.randint(0, n_ent, n_neg)], 1).astype(np.int32)
+    kw = dict(loss=loss, loss_norm="L2", margin=1.5, pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.01)
+    e0, r0, n0 = ent.copy(), rel.copy(), nrm.copy()
+    ea, ra, na = (np.full_like(x, 0.1) for x in (e0, r0, n0))
+    ref_loss = sum(cport.triple_step_transh(e0, ea, r0, ra, n0, na, pos, neg, **kw) for _ in range(2))
+    te, tr, tn = ops.to_table(ent), ops.to_table(rel), ops.to_table(nrm)
+    tea, tra, tna = (torch.full_like(x, 0.1) for x in (te, tr, tn))
+    cfg = ops.make_step_cfg(neg_group_k=0, normal=tn, normal_acc=tna, **kw)
+    ws = ops.step_workspace(n_ent, n_rel, te.shape[1])
+    acc = torch.zeros(1, dtype=torch.float64, device=te.device)
+    for _ in range(2):
+        ops.triple_step(te, tea, tr, tra, d, ops.to_ids(pos), ops.to_ids(neg), cfg, ws, acc)
+    assert ref_loss > 0 and abs(float(acc.item()) - ref_loss) <= 2e-5 * abs(ref_loss)
+    for got, ref in ((te, e0), (tr, r0), (tn, n0)):
+        assert np.linalg.norm(got[:, :d].cpu().numpy() - ref) <= 1e-4 * np.linalg.norm(ref)
+    assert int(ws[: -8 * 4096].count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("d,loss,l1,opt", [(40, "margin-based", False, "Adagrad"), (100, "margin-based", False, "Adagrad"),
+                                           (75, "margin-based", True, "SGD"), (64, "limited", False, "Adagrad"),
+                                           (200, "margin-based", False, "Adagrad")])
+def test_transd_step_matches_oracle(ops, d, loss, l1, opt):
+    """OEA_SCORE_TRANSD (models/trans/transd.py:16-57) on stacked tables against oracle_triple_step_transd, two steps,
+    plus the exchange-split form."""
+    import torch
+    from oracle import cport
+    rng = np.random.RandomState(d + 1)
+    E, R, n_pos = 450, 11, 380
+    ent = rng.standard_normal((2 * E, d)).astype(np.float32)
+    rel = rng.standard_normal((2 * R, d)).astype(np.float32)
+    pos = np.stack([rng.randint(0, E, n_pos), np.minimum(rng.zipf(1.6, n_pos) - 1, R - 1), rng.randint(0, E, n_pos)], 1).astype(np.int32)
+    neg = pos.copy()
+    ch = rng.rand(n_pos) < 0.5
+    rnd = rng.randint(0, E, n_pos)
+    neg[ch, 0] = rnd[ch]
+    neg[~ch, 2] = rnd[~ch]
+    kw = dict(loss=loss, loss_norm="L1" if l1 else "L2", margin=1.0, pos_margin=0.01, neg_margin=2.5, balance=0.3,
+              optimizer=opt, lr=0.01)
+    e0, r0 = ent.copy(), rel.copy()
+    ea, ra = np.full_like(e0, 0.1), np.full_like(r0, 0.1)
+    ref_loss = sum(cport.triple_step_transd(e0, ea, r0, ra, pos, neg, **kw) for _ in range(2))
+    assert ref_loss > 0
+
+    def device_run(split):
+        te, tr = ops.to_table(ent), ops.to_table(rel)
+        tea, tra = torch.full_like(te, 0.1), torch.full_like(tr, 0.1)
+        cfg = ops.make_step_cfg(neg_group_k=0, transfer_bases=(E, R), **kw)
+        ws = ops.step_workspace(2 * E, 2 * R, te.shape[1])
+        acc = torch.zeros(1, dtype=torch.float64, device=te.device)
+        for _ in range(2):
+            for phase in ((ops.PHASE_GRAD, ops.PHASE_APPLY) if split else (ops.PHASE_BOTH,)):
+                ops.triple_step(te, tea, tr, tra, d, ops.to_ids(pos), ops.to_ids(neg), cfg, ws, acc, phase=phase)
+        assert int(ws[: -8 * 4096].count_nonzero()) == 0
+        return te, tr, float(acc.item())
+
+    te, tr, loss_dev = device_run(False)
+    assert abs(loss_dev - ref_loss) <= 2e-5 * abs(ref_loss)
+    for got, ref in ((te, e0), (tr, r0)):
+        assert np.linalg.norm(got[:, :d].cpu().numpy() - ref) <= 1e-4 * np.linalg.norm(ref)
+    assert np.abs(te[E:, :d].cpu().numpy() - ent[E:]).max() > 1e-4       # the transfer vectors were trained
+    te2, tr2, _ = device_run(True)
+    for a, b in ((te, te2), (tr, tr2)):
+        assert np.linalg.norm((a - b).cpu().numpy()) <= 2e-6 * np.linalg.norm(a.cpu().numpy())
+    # ids outside [0, base) / tables that are not stacked are refused
+    with pytest.raises(RuntimeError):
+        bad = ops.make_step_cfg(neg_group_k=0, transfer_bases=(E - 1, R), **kw)
+        ops.triple_step(te, torch.full_like(te, 0.1), tr, torch.full_like(tr, 0.1), d, ops.to_ids(pos), ops.to_ids(neg), bad,
+                        ops.step_workspace(2 * E, 2 * R, te.shape[1]), torch.zeros(1, dtype=torch.float64, device=te.device))
+
+
 # ---------------------------------------------------------------------------------------------
 # negative links (AliNet.generate_input_batch, alinet.py:988-1006)
 # ---------------------------------------------------------------------------------------------

@@ -270,3 +270,96 @@ def test_gcn_epoch_oracle_gradient_by_finite_differences():
             b[i, c] -= eps
             num[i, c] = (loss_of(a) - loss_of(b)) / (2 * eps)
     assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
+
+
+@pytest.mark.parametrize("loss,l1", [("margin-based", False), ("limited", False), ("margin-based", True)])
+def test_transd_oracle_gradients_by_finite_differences(loss, l1):
+    """oracle_triple_step_transd restates TF1 autodiff of models/trans/transd.py:16-57 by hand (PARITY UNPINNED vs
+    TF): pin the gradients of all four variables against central differences of the loss written in numpy."""
+    from oracle import cport
+    rng = np.random.RandomState(3)
+    E, R, d = 9, 3, 6
+    ent = rng.standard_normal((2 * E, d)).astype(np.float32)       # [ent_embeds ; ent_transfer]
+    rel = rng.standard_normal((2 * R, d)).astype(np.float32)       # [rel_embeds ; rel_transfer]
+    pos = np.array([[0, 1, 2], [3, 1, 4], [0, 0, 6], [7, 2, 0]], np.int32)
+    neg = np.array([[0, 1, 7], [8, 1, 4], [5, 0, 6], [7, 2, 5]], np.int32)
+
+    def l2n(x):
+        return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))
+
+    def loss_of(e, r):
+        e, r = l2n(e), l2n(r)
+
+        def sc(tr):
+            h, t, hp, tp = e[tr[:, 0]], e[tr[:, 2]], e[E + tr[:, 0]], e[E + tr[:, 2]]
+            rr, rp = r[tr[:, 1]], r[R + tr[:, 1]]
+            hh = l2n(h + (h * hp).sum(1, keepdims=True) * rp)
+            tt = l2n(t + (t * tp).sum(1, keepdims=True) * rp)
+            dlt = hh + rr - tt
+            return np.abs(dlt).sum(1) if l1 else (dlt ** 2).sum(1)
+        if loss == "margin-based":
+            return np.maximum(0.7 + sc(pos) - sc(neg), 0).sum()
+        return np.maximum(sc(pos) - 0.01, 0).sum() + 0.2 * np.maximum(2.5 - sc(neg), 0).sum()
+
+    lr = 1e-3
+    tabs = [ent.copy(), rel.copy()]
+    got = cport.triple_step_transd(tabs[0], None, tabs[1], None, pos, neg, loss=loss, loss_norm="L1" if l1 else "L2",
+                                   margin=0.7, pos_margin=0.01, neg_margin=2.5, balance=0.2, optimizer="SGD", lr=lr)
+    base = [ent.astype(np.float64), rel.astype(np.float64)]
+    assert abs(got - loss_of(*base)) < 1e-6
+    assert got > 0
+    eps = 1e-5
+    for idx in range(2):
+        analytic = (base[idx] - tabs[idx]) / lr
+        num = np.zeros_like(analytic)
+        for i in range(analytic.shape[0]):
+            for k in range(d):
+                a = [x.copy() for x in base]
+                b = [x.copy() for x in base]
+                a[idx][i, k] += eps
+                b[idx][i, k] -= eps
+                num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
+        assert np.abs(num).max() > 1e-2
+        assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
+
+
+def test_transh_margin_oracle_gradients_by_finite_differences():
+    """the margin-loss form of the TransH step (models/trans/transh.py:16-51: margin_loss on projected rows)."""
+    from oracle import cport
+    rng = np.random.RandomState(4)
+    n_ent, n_rel, d = 10, 3, 5
+    ent = rng.standard_normal((n_ent, d)).astype(np.float32)
+    rel = rng.standard_normal((n_rel, d)).astype(np.float32)
+    nrm = rng.standard_normal((n_rel, d)).astype(np.float32)
+    pos = np.array([[0, 1, 2], [3, 1, 4], [5, 0, 6]], np.int32)
+    neg = np.array([[0, 1, 7], [8, 1, 4], [5, 0, 9]], np.int32)
+
+    def l2n(x):
+        return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))
+
+    def loss_of(e, r, n):
+        e, r, n = l2n(e), l2n(r), l2n(l2n(n))
+
+        def sc(tr):
+            h, t, rr, nn = e[tr[:, 0]], e[tr[:, 2]], r[tr[:, 1]], n[tr[:, 1]]
+            return ((h - (h * nn).sum(1, keepdims=True) * nn + rr - t + (t * nn).sum(1, keepdims=True) * nn) ** 2).sum(1)
+        return np.maximum(1.5 + sc(pos) - sc(neg), 0).sum()
+
+    lr = 1e-3
+    tabs = [ent.copy(), rel.copy(), nrm.copy()]
+    got = cport.triple_step_transh(tabs[0], None, tabs[1], None, tabs[2], None, pos, neg, loss="margin-based", margin=1.5,
+                                   optimizer="SGD", lr=lr)
+    base = [ent.astype(np.float64), rel.astype(np.float64), nrm.astype(np.float64)]
+    assert abs(got - loss_of(*base)) < 1e-6 and got > 0
+    eps = 1e-5
+    for idx in range(3):
+        analytic = (base[idx] - tabs[idx]) / lr
+        num = np.zeros_like(analytic)
+        for i in range(analytic.shape[0]):
+            for k in range(d):
+                a = [x.copy() for x in base]
+                b = [x.copy() for x in base]
+                a[idx][i, k] += eps
+                b[idx][i, k] -= eps
+                num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
+        assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
