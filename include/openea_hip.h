@@ -87,7 +87,7 @@ int oea_fill_f32(float *p, int64_t n, float value, void *stream);
  * ------------------------------------------------------------------------------------- */
 enum { OEA_LOSS_MARGIN = 0, OEA_LOSS_LIMITED = 1, OEA_LOSS_LOGISTIC = 2, OEA_LOSS_POSITIVE = 3,
        OEA_LOSS_ALIGN = 4 };
-enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1 };
+enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1, OEA_OPT_ADAM = 2 /* oea_rotate_step only */ };
 enum { OEA_SCORE_TRANSE = 0, OEA_SCORE_TRANSH = 1, OEA_SCORE_TRANSD = 2 };
 
 typedef struct oea_step_cfg {
@@ -156,6 +156,42 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
  * library GEMMs on the host side. */
 int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, const int32_t *ids,
                               int64_t n, const float *src, int32_t src_ld, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RotatE step in fp64 -- replaces session.run([triple_loss, triple_optimizer]) and
+ * session.run([alignment_loss, alignment_optimizer]) of BootEA_RotatE (approaches/bootea_rotate.py:50-109,148-158,
+ * 193-203): variables re_ent_embeds / im_ent_embeds / rel_embeds are tf.float64 (bootea_rotate.py:50-57),
+ *   theta = l2n?(rel)[r] * phase_scale,  (a, b) = (h_re + i h_im) e^{i theta} - (t_re + i t_im),  dist = sum_d |(a, b)_d|,
+ *   loss = sum softplus(dist+ - gamma) + sum softplus(gamma - dist-)        (= -sum log sigmoid(score), :59-81)
+ * and TF's optimiser semantics (optimizers.py:4-20): Adam moves EVERY row every step.
+ * ent: [2 n_ent, ld] doubles, rows [0, n_ent) = re_ent_embeds, [n_ent, 2 n_ent) = im_ent_embeds; rel: [n_rel, ld].
+ * ent_state / rel_state: Adagrad accumulator [rows, ld] (initial 0.1), or Adam m then v [2, rows, ld] (zeros), NULL for SGD.
+ * neg == NULL / n_neg == 0: the positive half alone (alignment loss).  neg_group_k as in oea_step_cfg.
+ * phase: OEA_PHASE_*; the exchanged prefix of the workspace is oea_rotate_exchange_doubles() doubles.
+ * workspace: oea_rotate_workspace_bytes(), zeroed once; the step leaves it zeroed. ------------------------------- */
+typedef struct oea_rotate_cfg {
+    double gamma;        /* args.gamma */
+    double phase_scale;  /* pi / embedding_range, embedding_range = (gamma + 2.0) / dim  (bootea_rotate.py:29-33,90) */
+    double lr;           /* args.learning_rate */
+    double beta1, beta2, eps; /* Adam: 0.9, 0.999, 1e-8 (tf.train.AdamOptimizer defaults) */
+    int64_t t;           /* Adam: 1-based step count of THIS optimiser instance */
+    int32_t ent_l2_norm; /* args.ent_l2_norm (both entity tables) */
+    int32_t rel_l2_norm; /* args.rel_l2_norm */
+    int32_t opt_kind;    /* OEA_OPT_* */
+    int32_t reserved;
+} oea_rotate_cfg;
+size_t oea_rotate_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld);
+size_t oea_rotate_exchange_doubles(int64_t n_ent, int64_t n_rel, int32_t ld);
+int oea_rotate_step(double *ent, double *ent_state, int64_t n_ent, double *rel, double *rel_state, int64_t n_rel,
+                    int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
+                    int32_t neg_group_k, const oea_rotate_cfg *cfg, void *workspace, double *loss_accum, int32_t phase,
+                    void *stream);
+/* out[i, 0:dim] = (float)( l2n?( part(re[ids[i]]) + part(im[ids[i]]) ) ), part = l2_normalize when part_norm: the
+ * embeddings that evaluation, bootstrapping and the neighbour search of BootEA_RotatE read
+ * (bootea_rotate.py:111-146,160-167: `re_ent_embeds + im_ent_embeds`, normalised again when sum_norm).
+ * ids == NULL: rows 0..n-1.  out is fp32 [n, out_ld], pad columns zero -- the evaluation kernels are fp32. */
+int oea_rotate_lookup(const double *ent, int64_t n_ent, int32_t dim, int32_t ld, const int32_t *ids, int64_t n,
+                      int32_t part_norm, int32_t sum_norm, float *out, int32_t out_ld, void *stream);
 
 /* MTransE's mapping step, fused (modules/base/mapping.py:9-19, losses.py:76-80, approaches/mtranse.py:84-96):
  *   loss = alpha * (sum_n ||e2_n - e1_n M||^2 + ||M M^T - I||_F^2),  e = l2_normalize(ent)[ids] (if ent_l2_norm).

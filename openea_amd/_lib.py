@@ -45,8 +45,15 @@ class AttnGraph(C.Structure):
                 ("unique_rows", C.c_int32), ("t_any_split", C.c_int32)]
 
 
+class RotateCfg(C.Structure):
+    """mirror of `oea_rotate_cfg` (include/openea_hip.h)."""
+    _fields_ = [("gamma", C.c_double), ("phase_scale", C.c_double), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("t", C.c_int64), ("ent_l2_norm", C.c_int32),
+                ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32), ("reserved", C.c_int32)]
+
+
 LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
-OPT_KIND = {"SGD": 0, "Adagrad": 1}
+OPT_KIND = {"SGD": 0, "Adagrad": 1, "Adam": 2}       # Adam: oea_rotate_step only
 METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2}
 
 _vp, _i32, _i64, _u32, _u64, _f32, _sz = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64,
@@ -88,6 +95,11 @@ PROTOTYPES = {
     "oea_triple_epoch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32,
                                    C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
                                    C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp]),
+    "oea_rotate_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "oea_rotate_exchange_doubles": (_sz, [_i64, _i64, _i32]),
+    "oea_rotate_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
+                                  C.POINTER(RotateCfg), _vp, _vp, _i32, _vp]),
+    "oea_rotate_lookup": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "oea_mapping_workspace_floats": (_sz, [_i64, _i32, _i32]),
     "oea_mapping_step": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp,
                                    _vp, _vp, _vp]),

@@ -170,8 +170,9 @@ class RelationTripleEpochs:
 
     def run_epoch(self, trainer):
         """All `triple_steps` steps of one epoch.  Single GPU: one C call enqueues the whole epoch
-        (oea_triple_epoch); data parallel: per-step loop with the all-reduce between the phases."""
-        if self.world == 1:
+        (oea_triple_epoch); data parallel (or a trainer without the fused epoch call, fused_epoch = False): per-step loop
+        with the all-reduce between the phases."""
+        if self.world == 1 and getattr(trainer, "fused_epoch", True):
             if self._sides is None:
                 self._sides = (self.s1.side(), self.s2.side())
             b = self.batches

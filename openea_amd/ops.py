@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LOSS_KIND, METRIC, OPT_KIND, StepCfg, check
+from ._lib import LOSS_KIND, METRIC, OPT_KIND, RotateCfg, StepCfg, check
 
 
 def lib():
@@ -122,6 +122,63 @@ def triple_step(ent, ent_acc, rel, rel_acc, dim, pos, neg, cfg, workspace, loss_
     check(lib().oea_triple_step_phase(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0],
                                       dim, ent.shape[1], _p(pos), pos.shape[0], _p(neg), n_neg,
                                       C.byref(cfg), _p(workspace), _p(loss_accum), int(phase), _stream()))
+
+
+# ---- RotatE (fp64) --------------------------------------------------------------------------------------------
+def to_table64(array, dev=None):
+    """host [n, d] -> device fp64 [n, ld] zero-padded (ld % 4 == 0)."""
+    a = np.ascontiguousarray(np.asarray(array, dtype=np.float64))
+    n, d = a.shape
+    t = torch.zeros((n, pad4(d)), dtype=torch.float64, device=dev or device())
+    if n:
+        t[:, :d].copy_(torch.from_numpy(a))
+    return t
+
+
+def make_rotate_cfg(gamma, dim, ent_l2_norm=True, rel_l2_norm=False, optimizer='Adam', lr=0.01, beta1=0.9, beta2=0.999,
+                    eps=1e-8, epsilon=2.0):
+    """bootea_rotate.py:29-33,90: embedding_range = (gamma + epsilon) / dim, phase = rel / (embedding_range / pi)."""
+    import math
+    rng = (float(gamma) + float(epsilon)) / dim
+    return RotateCfg(float(gamma), 3.14159265358979323846 / rng, float(lr), float(beta1), float(beta2), float(eps), 0,
+                     int(bool(ent_l2_norm)), int(bool(rel_l2_norm)), OPT_KIND[optimizer], 0)
+
+
+def rotate_workspace(n_ent, n_rel, ld, dev=None):
+    return torch.zeros(lib().oea_rotate_workspace_bytes(n_ent, n_rel, ld), dtype=torch.uint8, device=dev or device())
+
+
+def rotate_exchange_view(workspace, n_ent, n_rel, ld):
+    """fp64 view of the workspace prefix that data-parallel ranks sum between PHASE_GRAD and PHASE_APPLY."""
+    n = lib().oea_rotate_exchange_doubles(n_ent, n_rel, ld)
+    return workspace[: n * 8].view(torch.float64)
+
+
+def rotate_state(table, optimizer):
+    """optimiser state of one fp64 table: Adagrad accumulator (0.1), Adam [m ; v] (zeros), None for SGD."""
+    if optimizer == 'Adagrad':
+        return torch.full_like(table, 0.1)
+    if optimizer == 'Adam':
+        return torch.zeros((2,) + tuple(table.shape), dtype=torch.float64, device=table.device)
+    return None
+
+
+def rotate_step(ent, ent_state, rel, rel_state, dim, pos, neg, neg_group_k, cfg, workspace, loss_accum, phase=PHASE_BOTH):
+    """One RotatE optimiser step in place (ent: fp64 [2E, ld], re rows then im rows).  cfg.t must hold the 1-based
+    step count of this optimiser when it is Adam."""
+    n_neg = 0 if neg is None else neg.shape[0]
+    check(lib().oea_rotate_step(_p(ent), _p(ent_state), ent.shape[0] // 2, _p(rel), _p(rel_state), rel.shape[0], dim,
+                                ent.shape[1], _p(pos), pos.shape[0], _p(neg), n_neg, int(neg_group_k), C.byref(cfg),
+                                _p(workspace), _p(loss_accum), int(phase), _stream()))
+
+
+def rotate_lookup(ent, dim, ids, part_norm=True, sum_norm=False):
+    """fp32 [n, pad4(dim)] block of l2n?(l2n?(re[ids]) + l2n?(im[ids])) for the evaluation kernels."""
+    n = ent.shape[0] // 2 if ids is None else ids.numel()
+    out = torch.empty((n, pad4(dim)), dtype=torch.float32, device=ent.device)
+    check(lib().oea_rotate_lookup(_p(ent), ent.shape[0] // 2, dim, ent.shape[1], _p(ids), n, int(bool(part_norm)),
+                                  int(bool(sum_norm)), _p(out), out.shape[1], _stream()))
+    return out
 
 
 def step_scatter_ent_rows(workspace, n_ent, n_rel, ld, ids, src):

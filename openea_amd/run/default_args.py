@@ -28,6 +28,11 @@ _ARGS = {
                           optimizer="Adagrad", batch_size=5000, pos_margin=0.01, neg_margin=2.0, neg_margin_balance=0.2,
                           neg_sampling="truncated", neg_triple_num=10, truncated_epsilon=0.9, truncated_freq=10,
                           eval_metric="inner", eval_norm=False, sim_th=0.7, k=10, likelihood_slice=10, sub_epoch=10),
+    "BootEA_RotatE": dict(embedding_module="BootEA_RotatE", alignment_module="swapping", dim=100, init="normal",
+                          ent_l2_norm=True, rel_l2_norm=False, gamma=12.0, learning_rate=0.01, optimizer="Adam",
+                          batch_size=5000, min_iter=40, neg_sampling="uniform", neg_triple_num=10, truncated_epsilon=0.9,
+                          truncated_freq=10, batch_threads_num=4, start_valid=10, start_bp=5000, eval_metric="inner",
+                          eval_norm=True, sim_th=0.75, k=10, sub_epoch=10, align_times=1),
     # run/args/trans{h,d}_args_*.json (TransE takes the same set: models/trans/transe.py:20-29 asserts it)
     **{name: dict(embedding_module=name, alignment_module="sharing", dim=100, init="normal", ent_l2_norm=True,
                   rel_l2_norm=True, loss="margin-based", loss_norm="L2", margin=1.5, neg_sampling="uniform",

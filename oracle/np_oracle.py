@@ -556,3 +556,116 @@ def link_negatives(n_pos, k, seed, step, pos_links=None, ents1=None, ents2=None,
         valid.append(p not in seen and p not in exclude)
         seen.add(p)
     return np.asarray(pairs, np.int32).reshape(-1, 2), np.asarray(valid, bool)
+
+
+# ----------------------------------------------------------------------------------------------------
+# RotatE step of BootEA_RotatE (approaches/bootea_rotate.py:50-109,148-158) -- PARITY UNPINNED vs TF (hand-restated
+# autodiff + optimisers); the gradients are pinned by finite differences in tests/test_oracle_golden.py.
+# ----------------------------------------------------------------------------------------------------
+def _l2n_rows(x):
+    """tf.nn.l2_normalize(x, 1): x * rsqrt(max(sum x^2, 1e-12))."""
+    return x / np.sqrt(np.maximum((x * x).sum(1, keepdims=True), 1e-12))
+
+
+def rotate_loss(ent, rel, pos, neg, gamma, phase_scale, ent_l2_norm=True, rel_l2_norm=False):
+    """The loss alone (forward only), written as the TF graph reads: lookup_all (bootea_rotate.py:83-94),
+    _generate_scores (:59-70), _generate_loss (:72-81).  ent = [re ; im] stacked [2E, d], fp64."""
+    E = ent.shape[0] // 2
+    re, im = ent[:E], ent[E:]
+    if ent_l2_norm:
+        re, im = _l2n_rows(re), _l2n_rows(im)
+    rl = _l2n_rows(rel) if rel_l2_norm else rel
+
+    def scores(tr, is_pos):
+        if tr is None or len(tr) == 0:
+            return np.zeros(0)
+        h, r, t = tr[:, 0], tr[:, 1], tr[:, 2]
+        theta = rl[r] * phase_scale
+        rr, ir = np.cos(theta), np.sin(theta)
+        re_s = re[h] * rr - im[h] * ir - re[t]
+        im_s = re[h] * ir + im[h] * rr - im[t]
+        sc = gamma - np.sqrt(re_s ** 2 + im_s ** 2).sum(-1)
+        return sc if is_pos else -sc
+
+    def log_sigmoid(x):
+        return -np.logaddexp(0.0, -x)
+    return -log_sigmoid(scores(pos, True)).sum() - log_sigmoid(scores(neg, False)).sum()
+
+
+def rotate_step(ent, rel, pos, neg, state, *, gamma, phase_scale, ent_l2_norm=True, rel_l2_norm=False, optimizer="Adam",
+                lr=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One optimiser step in place on fp64 ent [2E, d] / rel [R, d]; returns the batch loss.
+    state: dict created by the caller ({} at first); holds Adagrad accumulators (0.1) or Adam m, v, t.
+    Gradient by hand (duplicates summed with np.add.at), back through the row normalisations, then
+    tf.train.{GradientDescent,Adagrad,Adam}Optimizer on the WHOLE variables (Adam moves every row)."""
+    E, d = ent.shape[0] // 2, ent.shape[1]
+    inv_e = 1.0 / np.sqrt(np.maximum((ent * ent).sum(1, keepdims=True), 1e-12)) if ent_l2_norm else np.ones((2 * E, 1))
+    inv_r = 1.0 / np.sqrt(np.maximum((rel * rel).sum(1, keepdims=True), 1e-12)) if rel_l2_norm else np.ones((len(rel), 1))
+    ye, yr = ent * inv_e, rel * inv_r
+    ge, gr = np.zeros_like(ent), np.zeros_like(rel)
+    loss = 0.0
+    for tr, is_pos in ((pos, True), (neg, False)):
+        if tr is None or len(tr) == 0:
+            continue
+        tr = np.asarray(tr)
+        h, r, t = tr[:, 0], tr[:, 1], tr[:, 2]
+        theta = yr[r] * phase_scale
+        c, s = np.cos(theta), np.sin(theta)
+        rh, ih, rt, it = ye[h], ye[E + h], ye[t], ye[E + t]
+        a = rh * c - ih * s - rt
+        b = rh * s + ih * c - it
+        n = np.sqrt(a * a + b * b)
+        dist = n.sum(1)
+        x = dist - gamma if is_pos else gamma - dist
+        loss += np.logaddexp(0.0, x).sum()
+        coef = 1.0 / (1.0 + np.exp(-x))
+        coef = coef if is_pos else -coef
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = np.where(n > 0, 1.0 / n, 0.0)
+        da, db = coef[:, None] * a * inv, coef[:, None] * b * inv
+        np.add.at(ge, h, da * c + db * s)
+        np.add.at(ge, E + h, db * c - da * s)
+        np.add.at(ge, t, -da)
+        np.add.at(ge, E + t, -db)
+        np.add.at(gr, r, (da * (-rh * s - ih * c) + db * (rh * c - ih * s)) * phase_scale)
+
+    def back(y, g, inv, on, raw):
+        if not on:
+            return g
+        ss = (raw * raw).sum(1, keepdims=True)
+        ydg = np.where(ss > 1e-12, (y * g).sum(1, keepdims=True), 0.0)
+        return (g - y * ydg) * inv
+    gv_e = back(ye, ge, inv_e, ent_l2_norm, ent)
+    gv_r = back(yr, gr, inv_r, rel_l2_norm, rel)
+    if optimizer == "Adam":
+        state["t"] = t_ = state.get("t", 0) + 1
+        lr_t = lr * np.sqrt(1.0 - beta2 ** t_) / (1.0 - beta1 ** t_)
+        for name, var, g in (("ent", ent, gv_e), ("rel", rel, gv_r)):
+            m = state.setdefault("m_" + name, np.zeros_like(var))
+            v = state.setdefault("v_" + name, np.zeros_like(var))
+            m *= beta1
+            m += (1.0 - beta1) * g
+            v *= beta2
+            v += (1.0 - beta2) * g * g
+            var -= lr_t * m / (np.sqrt(v) + eps)
+    elif optimizer == "Adagrad":
+        for name, var, g in (("ent", ent, gv_e), ("rel", rel, gv_r)):
+            acc = state.setdefault("acc_" + name, np.full_like(var, 0.1))
+            acc += g * g
+            var -= lr * g / np.sqrt(acc)
+    else:
+        ent -= lr * gv_e
+        rel -= lr * gv_r
+    return float(loss)
+
+
+def rotate_lookup(ent, ids, part_norm=True, sum_norm=False):
+    """re + im of the looked-up rows as the evaluation reads them (bootea_rotate.py:111-146,160-167) -> fp32."""
+    E = ent.shape[0] // 2
+    re, im = ent[:E][ids], ent[E:][ids]
+    if part_norm:
+        re, im = _l2n_rows(re), _l2n_rows(im)
+    out = re + im
+    if sum_norm:
+        out = _l2n_rows(out)
+    return out.astype(np.float32)

@@ -553,6 +553,66 @@ def test_transd_step_matches_oracle(ops, d, loss, l1, opt):
 
 
 # ---------------------------------------------------------------------------------------------
+# RotatE step in fp64 (approaches/bootea_rotate.py:50-109,148-158)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,k,opt,ent_norm,rel_norm", [(100, 10, "Adam", True, False), (40, 3, "Adagrad", True, True),
+                                                       (75, 0, "Adam", True, False), (200, 2, "SGD", False, False),
+                                                       (300, 1, "Adam", True, False)])
+def test_rotate_step_matches_oracle(ops, d, k, opt, ent_norm, rel_norm):
+    """three steps (Adam's bias correction and moments, a clean scratch) against np_oracle.rotate_step; k = 0 is the
+    alignment loss (positives only); one negative is not a corruption of its positive; the split step agrees."""
+    import torch
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(d + k)
+    E, R, n_pos = 400, 9, 350
+    ent = rng.standard_normal((2 * E, d)) / np.sqrt(d)
+    rel = rng.standard_normal((R, d)) / np.sqrt(d)
+    pos = np.stack([rng.randint(0, E, n_pos), np.minimum(rng.zipf(1.6, n_pos) - 1, R - 1), rng.randint(0, E, n_pos)], 1).astype(np.int32)
+    neg = None
+    if k:
+        neg = np.repeat(pos, k, axis=0)
+        ch = rng.rand(n_pos * k) < 0.5
+        rnd = rng.randint(0, E, n_pos * k)
+        neg[ch, 0] = rnd[ch]
+        neg[~ch, 2] = rnd[~ch]
+        neg[5, 1] = (neg[5, 1] + 1) % R
+    cfg = ops.make_rotate_cfg(6.0, d, ent_l2_norm=ent_norm, rel_l2_norm=rel_norm, optimizer=opt, lr=0.01)
+    kw = dict(gamma=6.0, phase_scale=cfg.phase_scale, ent_l2_norm=ent_norm, rel_l2_norm=rel_norm, optimizer=opt, lr=0.01)
+    assert abs(cfg.phase_scale - np.pi / (8.0 / d)) < 1e-9
+    e0, r0, st = ent.copy(), rel.copy(), {}
+    ref_loss = sum(orc.rotate_step(e0, r0, pos, neg, st, **kw) for _ in range(3))
+
+    def device_run(split):
+        te, tr = ops.to_table64(ent), ops.to_table64(rel)
+        se, sr = ops.rotate_state(te, opt), ops.rotate_state(tr, opt)
+        ws = ops.rotate_workspace(E, R, te.shape[1])
+        acc = torch.zeros(1, dtype=torch.float64, device=te.device)
+        dpos, dneg = ops.to_ids(pos), None if neg is None else ops.to_ids(neg)
+        for step in range(3):
+            cfg.t = step + 1
+            for phase in ((ops.PHASE_GRAD, ops.PHASE_APPLY) if split else (ops.PHASE_BOTH,)):
+                ops.rotate_step(te, se, tr, sr, d, dpos, dneg, k, cfg, ws, acc, phase=phase)
+        assert int(ws[: -8 * 4096].count_nonzero()) == 0
+        return te, tr, float(acc.item())
+
+    te, tr, loss_dev = device_run(False)
+    assert abs(loss_dev - ref_loss) <= 1e-10 * abs(ref_loss)
+    for got, ref in ((te, e0), (tr, r0)):
+        assert np.linalg.norm(got[:, :d].cpu().numpy() - ref) <= 1e-9 * np.linalg.norm(ref)
+        assert float(got[:, d:].abs().sum()) == 0.0
+    te2, tr2, _ = device_run(True)
+    for a, b in ((te, te2), (tr, tr2)):
+        assert np.linalg.norm((a - b).cpu().numpy()) <= 1e-12 * np.linalg.norm(a.cpu().numpy())
+    # the lookups evaluation reads
+    ids = rng.permutation(E)[:97].astype(np.int32)
+    for part_norm, sum_norm in ((True, False), (True, True), (False, True)):
+        got = ops.rotate_lookup(te, d, ops.to_ids(ids), part_norm, sum_norm)
+        ref = orc.rotate_lookup(te[:, :d].cpu().numpy(), ids, part_norm, sum_norm)
+        assert got.shape[1] % 4 == 0 and float(got[:, d:].abs().sum()) == 0.0
+        np.testing.assert_allclose(got[:, :d].cpu().numpy(), ref, rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
 # negative links (AliNet.generate_input_batch, alinet.py:988-1006)
 # ---------------------------------------------------------------------------------------------
 def test_link_negatives_bit_exact_and_set_semantics(ops):

@@ -363,3 +363,45 @@ def test_transh_margin_oracle_gradients_by_finite_differences():
                 b[idx][i, k] -= eps
                 num[i, k] = (loss_of(*a) - loss_of(*b)) / (2 * eps)
         assert np.abs(analytic - num).max() < 5e-4 * max(np.abs(num).max(), 1.0)
+
+
+@pytest.mark.parametrize("ent_norm,rel_norm", [(True, False), (True, True), (False, False)])
+def test_rotate_oracle_gradients_by_finite_differences(ent_norm, rel_norm):
+    """np_oracle.rotate_step restates TF1 autodiff of bootea_rotate.py:59-109 by hand (PARITY UNPINNED vs TF): pin the
+    gradients to the real / imaginary / phase tables against central differences of rotate_loss, which is written the
+    way the TF graph reads."""
+    rng = np.random.RandomState(7)
+    E, R, d = 8, 3, 5
+    ent = rng.standard_normal((2 * E, d)) * 0.5
+    rel = rng.standard_normal((R, d)) * 0.3
+    pos = np.array([[0, 1, 2], [3, 1, 4], [0, 0, 6]])
+    neg = np.array([[0, 1, 7], [5, 1, 2], [3, 1, 0], [0, 0, 1], [2, 0, 6], [7, 2, 6]])
+    kw = dict(gamma=1.2, phase_scale=2.6, ent_l2_norm=ent_norm, rel_l2_norm=rel_norm)
+    lr = 1e-6
+    e1, r1 = ent.copy(), rel.copy()
+    got = orc.rotate_step(e1, r1, pos, neg, {}, optimizer="SGD", lr=lr, **kw)
+    assert abs(got - orc.rotate_loss(ent, rel, pos, neg, **kw)) < 1e-10
+    eps = 1e-6
+    for idx, (base, after) in enumerate(((ent, e1), (rel, r1))):
+        analytic = (base - after) / lr
+        num = np.zeros_like(base)
+        for i in range(base.shape[0]):
+            for k in range(d):
+                a, b = [ent.copy(), rel.copy()], [ent.copy(), rel.copy()]
+                a[idx][i, k] += eps
+                b[idx][i, k] -= eps
+                num[i, k] = (orc.rotate_loss(a[0], a[1], pos, neg, **kw) - orc.rotate_loss(b[0], b[1], pos, neg, **kw)) / (2 * eps)
+        assert np.abs(num).max() > 1e-2
+        assert np.abs(analytic - num).max() < 1e-6 * max(np.abs(num).max(), 1.0)
+
+
+def test_rotate_oracle_adam_moves_every_row():
+    """tf.train.AdamOptimizer semantics: rows without gradient keep moving while their first moment decays."""
+    rng = np.random.RandomState(8)
+    ent, rel = rng.standard_normal((8, 4)), rng.standard_normal((2, 4))
+    st = {}
+    kw = dict(gamma=1.0, phase_scale=2.0, ent_l2_norm=False, rel_l2_norm=False, optimizer="Adam", lr=0.01)
+    orc.rotate_step(ent, rel, np.array([[0, 0, 1]]), None, st, **kw)
+    before = ent.copy()
+    orc.rotate_step(ent, rel, np.array([[2, 1, 3]]), None, st, **kw)      # rows 0, 1 (and 4, 5) get no gradient now
+    assert st["t"] == 2 and np.abs(ent[0] - before[0]).max() > 1e-4 and np.abs(ent[4] - before[4]).max() > 1e-4
