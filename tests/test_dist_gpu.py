@@ -27,7 +27,8 @@ if world > 1:
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["OEA_PORT"],
                             rank=int(os.environ["RANK"]), world_size=world)
 torch.cuda.set_device(0)
-from openea_amd.approaches import AlignE, AliNet, BootEA, GCN_Align, MTransE
+from openea_amd.approaches import AlignE, AliNet, BootEA, BootEA_RotatE, GCN_Align, MTransE
+from openea_amd.models.trans import TransD
 from openea_amd.modules.load.synth import make_kgs
 from openea_amd.run.default_args import get_args
 from openea_amd.modules.finding.alignment import greedy_alignment
@@ -82,17 +83,21 @@ with contextlib.redirect_stdout(buf):
     # replicated small steps (MTransE mapping step, BootEA alignment step) must keep the replicas in lock-step
     extra = {}
     for cls, nm, mode, kw in ((MTransE, "MTransE", "mapping", dict(max_epoch=4, start_valid=100, eval_freq=100)),
-                              (BootEA, "BootEA", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, sim_th=0.3))):
+                              (BootEA, "BootEA", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, sim_th=0.3)),
+                              (TransD, "TransD", "sharing", dict(max_epoch=4, start_valid=100, eval_freq=100)),
+                              (BootEA_RotatE, "BootEA_RotatE", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, start_bp=2,
+                                                                                sim_th=0.3, gamma=6.0, neg_triple_num=4))):
         b = cls()
         b.set_args(get_args(nm, output=os.environ["OEA_OUT"] + "/out/", training_data="synthetic/small/", dataset_division="f/",
                             dim=32, batch_size=2000, **kw))
         b.set_kgs(make_kgs("small", mode=mode, seed=0))
         b.init()
         b.run()
-        extra[nm] = b.ent_embeds.raw()
+        extra[nm] = b.ent_embeds.raw() if hasattr(b.ent_embeds, "raw") else b.ent_embeds.var.cpu().numpy()
 rank = int(os.environ.get("RANK", "0"))
 np.savez(os.environ["OEA_OUT"] + "/result_w%d_r%d.npz" % (world, rank), ent=m.ent_embeds.raw(), rel=m.rel_embeds.raw(),
-         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], alinet=alinet_out, mtranse=extra["MTransE"], bootea=extra["BootEA"])
+         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], alinet=alinet_out, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
+         rotate=extra["BootEA_RotatE"])
 if world > 1:
     dist.barrier()
 '''
@@ -155,6 +160,7 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         np.testing.assert_allclose(r0[key], single[key], rtol=1e-5, atol=1e-5)
     assert np.array_equal(r0["alinet"], r1["alinet"])                  # replicas stay in lock-step through 4 Adam epochs
     assert np.linalg.norm(r0["alinet"] - single["alinet"]) <= 5e-3 * np.linalg.norm(single["alinet"])   # Adam amplifies the rounding
-    for key in ("mtranse", "bootea"):
+    for key in ("mtranse", "bootea", "transd", "rotate"):
         assert np.array_equal(r0[key], r1[key])
         assert np.linalg.norm(r0[key] - single[key]) <= 1e-3 * np.linalg.norm(single[key])
+    assert single["rotate"].dtype == np.float64
