@@ -26,8 +26,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        src = os.path.join(_HERE, "c", "oracle.c")
+        if not os.path.exists(_LIB_PATH) or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            build()                                   # missing or older than its source
         _lib = C.CDLL(_LIB_PATH)
         _lib.oracle_triple_step.restype = C.c_double
         _lib.oracle_sample_negatives.restype = C.c_int
