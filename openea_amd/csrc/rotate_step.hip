@@ -10,9 +10,9 @@
 //
 // Layout: the two entity tables are STACKED in one [2E, ld] fp64 array (rows [0, E) real, [E, 2E) imaginary parts: same
 // l2_norm flag, same optimiser), the relation phases are [R, ld].  Kernel 1 (rotate_triples): one G-lane group per
-// positive and its k negatives (the sampler's layout; free lists run one triple per group): cos / sin of the relation
-// row are evaluated once per group, the relation-row gradient of the whole group leaves as one row of atomics into one
-// of kRelCopies scratch copies; entity-row gradients leave per triple (global_atomic_add_f64).  Kernel 2 (rotate_apply)
+// chunk of up to 6 triples of a positive's family (itself + its k negatives, the sampler's layout; free lists run one
+// triple per group): cos / sin of the shared relation row are evaluated once per group, the relation-row gradient of
+// the group leaves as one row of atomics into one of kRelCopies scratch copies; entity-row gradients leave per triple (global_atomic_add_f64).  Kernel 2 (rotate_apply)
 // visits EVERY row: TF's AdamOptimizer moves all rows of a variable every step (dense gradient through l2_normalize
 // for the entity tables; _apply_sparse decays m, v and updates the whole variable for the raw relation table), so there
 // are no touched flags -- Adagrad / SGD rows with a zero gradient do not move anyway.
@@ -25,6 +25,7 @@ using oea::group_sum_d;
 
 constexpr int kMaxBlocks = 4096;
 constexpr int kRelCopies = 8;
+constexpr int kChunk = 6;          // triples of one positive's family per lane group (k = 10: 6 + 5)
 
 struct RotWs {
     double *ent_grad;      // [2E, ld]  w.r.t. the normalised rows
@@ -150,27 +151,36 @@ __global__ __launch_bounds__(256) void rotate_triples(const double *__restrict__
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
-    const int64_t items = k > 0 ? n_pos : n_pos + n_neg;
+    // grouped layout: the 1 + k triples of a positive are dealt to `chunks` groups of <= kChunk triples; every chunk
+    // evaluates cos / sin of the shared relation row itself and sends its own row of relation gradient.  (Measured at
+    // the 15K shape, k = 10, rocprofv3: 222 us per step with chunks of 3, ~190 us with the whole family in one group --
+    // the kernel is bound by its 22 M fp64 atomics per step, not by the number of resident waves.)
+    const int chunks = k > 0 ? (k + 1 + kChunk - 1) / kChunk : 1;
+    const int64_t items = k > 0 ? n_pos * chunks : n_pos + n_neg;
     double loss_local = 0.0;
     for (int64_t item = grp; item < items; item += ngrp) {
-        const bool lead_pos = item < n_pos;
-        const int32_t *lead = lead_pos ? pos + 3 * item : neg + 3 * (item - n_pos);
+        const int64_t fam = k > 0 ? item / chunks : item;                 // the positive this group works for
+        const int j0 = k > 0 ? (int)(item % chunks) * kChunk : 0;
+        const int j1 = k > 0 ? min(j0 + kChunk, k + 1) : 1;
+        const bool free_neg = k == 0 && item >= n_pos;
+        const int32_t *lead = free_neg ? neg + 3 * (item - n_pos) : pos + 3 * fam;
         const int r = lead[1];
         RowD<G, IT> c, s, gth;
         phase_row<G, IT>(rel, r, ld, lane, cfg, c, s);
 #pragma unroll
         for (int it = 0; it < IT; ++it) gth.v[it] = 0.0;
-        double l = rotate_triple<G, IT>(ent, E, ld, lane, lead[0], lead[2], lead_pos, c, s, cfg, ws, gth);
-        for (int j = 0; j < k; ++j) {
-            const int32_t *tr = neg + 3 * (item * k + j);
+        double l = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            const int32_t *tr = j == 0 ? lead : neg + 3 * (fam * k + j - 1);
+            const bool is_pos = j == 0 && !free_neg;
             if (tr[1] == r) {
-                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], false, c, s, cfg, ws, gth);
+                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], is_pos, c, s, cfg, ws, gth);
             } else {                                    // not a corruption of this positive: its own relation row
                 RowD<G, IT> c2, s2, g2;
                 phase_row<G, IT>(rel, tr[1], ld, lane, cfg, c2, s2);
 #pragma unroll
                 for (int it = 0; it < IT; ++it) g2.v[it] = 0.0;
-                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], false, c2, s2, cfg, ws, g2);
+                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], is_pos, c2, s2, cfg, ws, g2);
 #pragma unroll
                 for (int it = 0; it < IT; ++it) g2.v[it] *= cfg.phase_scale;
                 atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)tr[1] * ld, ld, lane, g2);
@@ -306,7 +316,7 @@ int launch_rotate(double *ent, double *ent_state, int64_t E, double *rel, double
                   const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg, int k, const oea_rotate_cfg &cfg,
                   const RotWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
-    const int64_t items = k > 0 ? n_pos : n_pos + n_neg;
+    const int64_t items = k > 0 ? n_pos * ((k + 1 + kChunk - 1) / kChunk) : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
     if (phase != OEA_PHASE_APPLY && items > 0) {
         rotate_triples<G, IT><<<nb1, block, 0, st>>>(ent, E, rel, ld, pos, n_pos, neg, n_neg, k, cfg, ws);
