@@ -10,9 +10,10 @@
 //
 // Layout: the two entity tables are STACKED in one [2E, ld] fp64 array (rows [0, E) real, [E, 2E) imaginary parts: same
 // l2_norm flag, same optimiser), the relation phases are [R, ld].  Kernel 1 (rotate_triples): one G-lane group per
-// chunk of up to 6 triples of a positive's family (itself + its k negatives, the sampler's layout; free lists run one
+// chunk of up to 16 triples of a positive's family (itself + its k negatives, the sampler's layout; free lists run one
 // triple per group): cos / sin of the shared relation row are evaluated once per group, the relation-row gradient of
-// the group leaves as one row of atomics into one of kRelCopies scratch copies; entity-row gradients leave per triple (global_atomic_add_f64).  Kernel 2 (rotate_apply)
+// the group leaves as one row of atomics into one of kRelCopies scratch copies, so do the rows of the family's own
+// head and tail; the corrupted entities' rows leave per triple (global_atomic_add_f64).  Kernel 2 (rotate_apply)
 // visits EVERY row: TF's AdamOptimizer moves all rows of a variable every step (dense gradient through l2_normalize
 // for the entity tables; _apply_sparse decays m, v and updates the whole variable for the raw relation table), so there
 // are no touched flags -- Adagrad / SGD rows with a zero gradient do not move anyway.
@@ -25,7 +26,7 @@ using oea::group_sum_d;
 
 constexpr int kMaxBlocks = 4096;
 constexpr int kRelCopies = 8;
-constexpr int kChunk = 6;          // triples of one positive's family per lane group (k = 10: 6 + 5)
+constexpr int kChunk = 16;         // triples of one positive's family per lane group (k = 10: the whole family)
 
 struct RotWs {
     double *ent_grad;      // [2E, ld]  w.r.t. the normalised rows
@@ -97,11 +98,20 @@ __device__ __forceinline__ void phase_row(const double *__restrict__ rel, int r,
     for (int it = 0; it < IT; ++it) sincos(yr.v[it] * cfg.phase_scale, &s.v[it], &c.v[it]);
 }
 
-// one triple: loss term returned, entity gradients scattered, d loss / d theta ADDED to gth
+// the gradient rows of a family's own head and tail, summed in registers over its triples (a corruption keeps one
+// side of its positive) and sent once: 24 instead of 44 rows of fp64 atomics per positive at k = 10
 template <int G, int IT>
+struct FamilyAcc {
+    int h0, t0;
+    RowD<G, IT> h_re, h_im, t_re, t_im;
+};
+
+// one triple: loss term returned, entity gradients scattered (or kept in `fam`), d loss / d theta ADDED to gth
+template <int G, int IT, bool ACC>
 __device__ __forceinline__ double rotate_triple(const double *__restrict__ ent, int64_t E, int ld, int lane, int h, int t,
                                                 bool is_pos, const RowD<G, IT> &c, const RowD<G, IT> &s,
-                                                const oea_rotate_cfg &cfg, const RotWs &ws, RowD<G, IT> &gth) {
+                                                const oea_rotate_cfg &cfg, const RotWs &ws, RowD<G, IT> &gth,
+                                                FamilyAcc<G, IT> &fam) {
     RowD<G, IT> rh, ih, rt, it_;
     load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, rh);
     load_row<G, IT>(ent + (E + h) * ld, ld, lane, ih);
@@ -136,10 +146,20 @@ __device__ __forceinline__ double rotate_triple(const double *__restrict__ ent, 
         a.v[it] = -da;                                                 // d/d t_re
         b.v[it] = -db;                                                 // d/d t_im
     }
-    atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, g1);
-    atomic_row<G, IT>(ws.ent_grad + (E + h) * ld, ld, lane, g2);
-    atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, a);
-    atomic_row<G, IT>(ws.ent_grad + (E + t) * ld, ld, lane, b);
+    if (ACC && h == fam.h0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { fam.h_re.v[it] += g1.v[it]; fam.h_im.v[it] += g2.v[it]; }
+    } else {
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)h * ld, ld, lane, g1);
+        atomic_row<G, IT>(ws.ent_grad + (E + h) * ld, ld, lane, g2);
+    }
+    if (ACC && t == fam.t0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { fam.t_re.v[it] += a.v[it]; fam.t_im.v[it] += b.v[it]; }
+    } else {
+        atomic_row<G, IT>(ws.ent_grad + (int64_t)t * ld, ld, lane, a);
+        atomic_row<G, IT>(ws.ent_grad + (E + t) * ld, ld, lane, b);
+    }
     return softplus_(x);
 }
 
@@ -152,9 +172,10 @@ __global__ __launch_bounds__(256) void rotate_triples(const double *__restrict__
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
     // grouped layout: the 1 + k triples of a positive are dealt to `chunks` groups of <= kChunk triples; every chunk
-    // evaluates cos / sin of the shared relation row itself and sends its own row of relation gradient.  (Measured at
-    // the 15K shape, k = 10, rocprofv3: 222 us per step with chunks of 3, ~190 us with the whole family in one group --
-    // the kernel is bound by its 22 M fp64 atomics per step, not by the number of resident waves.)
+    // evaluates cos / sin of the shared relation row itself and sends its own rows of relation / head / tail gradient.
+    // (Measured at the 15K shape, k = 10, rocprofv3: 222 us per step with chunks of 3, ~190 us with the whole family in
+    // one group, ~130 us with the family rows summed in registers: the kernel is bound by its fp64 atomics -- 22 M per
+    // step before, 12 M after -- not by the number of resident waves.)
     const int chunks = k > 0 ? (k + 1 + kChunk - 1) / kChunk : 1;
     const int64_t items = k > 0 ? n_pos * chunks : n_pos + n_neg;
     double loss_local = 0.0;
@@ -167,20 +188,24 @@ __global__ __launch_bounds__(256) void rotate_triples(const double *__restrict__
         const int r = lead[1];
         RowD<G, IT> c, s, gth;
         phase_row<G, IT>(rel, r, ld, lane, cfg, c, s);
+        constexpr bool ACC = IT <= 4;                   // 4 more rows of fp64 accumulators: not at the 256-VGPR shapes
+        FamilyAcc<G, IT> facc;
+        facc.h0 = lead[0];
+        facc.t0 = lead[2];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) gth.v[it] = 0.0;
+        for (int it = 0; it < IT; ++it) gth.v[it] = facc.h_re.v[it] = facc.h_im.v[it] = facc.t_re.v[it] = facc.t_im.v[it] = 0.0;
         double l = 0.0;
         for (int j = j0; j < j1; ++j) {
             const int32_t *tr = j == 0 ? lead : neg + 3 * (fam * k + j - 1);
             const bool is_pos = j == 0 && !free_neg;
             if (tr[1] == r) {
-                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], is_pos, c, s, cfg, ws, gth);
+                l += rotate_triple<G, IT, ACC>(ent, E, ld, lane, tr[0], tr[2], is_pos, c, s, cfg, ws, gth, facc);
             } else {                                    // not a corruption of this positive: its own relation row
                 RowD<G, IT> c2, s2, g2;
                 phase_row<G, IT>(rel, tr[1], ld, lane, cfg, c2, s2);
 #pragma unroll
                 for (int it = 0; it < IT; ++it) g2.v[it] = 0.0;
-                l += rotate_triple<G, IT>(ent, E, ld, lane, tr[0], tr[2], is_pos, c2, s2, cfg, ws, g2);
+                l += rotate_triple<G, IT, ACC>(ent, E, ld, lane, tr[0], tr[2], is_pos, c2, s2, cfg, ws, g2, facc);
 #pragma unroll
                 for (int it = 0; it < IT; ++it) g2.v[it] *= cfg.phase_scale;
                 atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)tr[1] * ld, ld, lane, g2);
@@ -189,6 +214,12 @@ __global__ __launch_bounds__(256) void rotate_triples(const double *__restrict__
 #pragma unroll
         for (int it = 0; it < IT; ++it) gth.v[it] *= cfg.phase_scale;       // theta = y_r * phase_scale
         atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)r * ld, ld, lane, gth);
+        if (ACC) {
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)facc.h0 * ld, ld, lane, facc.h_re);
+            atomic_row<G, IT>(ws.ent_grad + (E + facc.h0) * ld, ld, lane, facc.h_im);
+            atomic_row<G, IT>(ws.ent_grad + (int64_t)facc.t0 * ld, ld, lane, facc.t_re);
+            atomic_row<G, IT>(ws.ent_grad + (E + facc.t0) * ld, ld, lane, facc.t_im);
+        }
         if (lane == 0) loss_local += l;
     }
     __shared__ double sred[4];

@@ -557,10 +557,11 @@ def test_transd_step_matches_oracle(ops, d, loss, l1, opt):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d,k,opt,ent_norm,rel_norm", [(100, 10, "Adam", True, False), (40, 3, "Adagrad", True, True),
                                                        (75, 0, "Adam", True, False), (200, 2, "SGD", False, False),
-                                                       (300, 1, "Adam", True, False)])
+                                                       (300, 1, "Adam", True, False), (32, 17, "Adam", True, False)])
 def test_rotate_step_matches_oracle(ops, d, k, opt, ent_norm, rel_norm):
     """three steps (Adam's bias correction and moments, a clean scratch) against np_oracle.rotate_step; k = 0 is the
-    alignment loss (positives only); one negative is not a corruption of its positive; the split step agrees."""
+    alignment loss (positives only); one negative is not a corruption of its positive; k = 17 spreads a family over two
+    lane groups (chunks of 16); d = 300 runs without the register accumulation of the family rows; the split step agrees."""
     import torch
     from oracle import np_oracle as orc
     rng = np.random.RandomState(d + k)
