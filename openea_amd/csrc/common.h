@@ -32,6 +32,13 @@ void prof_mark(hipStream_t st);   // records the next event of the current profi
         }                                                                   \
     } while (0)
 
+// packed-operand path of the similarity tiles (sim_rank.hip), for the kNN strips of topk.hip
+bool tile_glds_enabled();
+int pack_rows(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, float **packed, int *kp);
+int release_packed_rows(hipStream_t st);
+void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
+                            int64_t ld_out, hipStream_t st);
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

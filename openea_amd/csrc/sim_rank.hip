@@ -16,6 +16,7 @@
 // lane its operand for four consecutive MFMA k-steps in natural k order.  Row stride 36
 // floats (144 B) makes the b128 reads bank-conflict free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -163,6 +164,125 @@ __device__ __forceinline__ void tile_pipeline(const float *__restrict__ am, int6
     }
 }
 
+// ---- packed operands + LDS-DMA staging --------------------------------------------------------------------------
+// The same pipeline fed by `global_load_lds_dwordx4` (gfx950): a chunk goes HBM/L2 -> LDS without passing through
+// registers and without ds_write instructions.  The LDS-DMA destination of one wave instruction is lane-linear
+// (base + 16 B * lane), so the k permutation of the reg-staged path cannot be applied on the way: the operands are
+// packed once per call by pack_rows_kernel ([n_pad, Kp] with n_pad % 128 == 0 and Kp % 32 == 0, zero filled, every
+// group of 8 k stored as k = 0,2,4,6,1,3,5,7 -- O(n d) work in front of an O(n^2 d) sweep).  The LDS image of a chunk
+// is 128 rows x 32 floats WITHOUT padding; bank conflicts are avoided by an XOR swizzle of the eight 16-byte columns
+// of a row with (row & 7), applied to the per-lane SOURCE address of the DMA and to the ds_read address (the same
+// involution on both sides).
+constexpr int PLD = BK;                 // unpadded LDS row stride (floats)
+
+__global__ void pack_rows_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, float *__restrict__ dst,
+                                 int64_t n_pad, int kp) {
+    const int cpr = kp / 4;                                            // 16-byte columns per packed row
+    const int64_t total = n_pad * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const int k = 8 * (c >> 1) + (c & 1);                          // k, k+2, k+4, k+6
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) {
+            const float *r = src + row * ld;
+            if (k < dim) v.x = r[k];
+            if (k + 2 < dim) v.y = r[k + 2];
+            if (k + 4 < dim) v.z = r[k + 4];
+            if (k + 6 < dim) v.w = r[k + 6];
+        }
+        oea::st4(dst + row * kp + 4 * c, v);
+    }
+}
+
+// rows [row0, row0 + 128) x packed k [k0, k0 + 32) -> LDS buffer `dst` (128 x 32 floats), 4 DMA instructions per wave
+__device__ __forceinline__ void stage_packed(const float *__restrict__ packed, int kp, int64_t row0, int k0,
+                                             float *__restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3;                                         // row inside the instruction's 8-row block
+    const float *src = packed + (row0 + wave * 32 + sub) * kp + k0 + 4 * ((lane & 7) ^ sub);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float *base = dst + (wave * 4 + j) * 8 * PLD;                  // wave-uniform: 1 KB per instruction
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (int64_t)j * 8 * kp),
+                                         reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
+                                         16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void mma_chunk_packed(const float *__restrict__ As, const float *__restrict__ Bs, int groups,
+                                                 f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 7, half = lane >> 5;                          // (row & 7) == (lane & 7): tile offsets are multiples of 8
+    const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
+    const float *bp = Bs + (wn * 64 + (lane & 31)) * PLD;
+    for (int g = 0; g < groups; ++g) {
+        const int off = 4 * ((2 * g + half) ^ x);
+        const float4 a0 = *reinterpret_cast<const float4 *>(ap + off);
+        const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * PLD + off);
+        const float4 b0 = *reinterpret_cast<const float4 *>(bp + off);
+        const float4 b1 = *reinterpret_cast<const float4 *>(bp + 32 * PLD + off);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[0][s], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[1][s], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[0][s], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[1][s], acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+// tile_pipeline on packed operands (am / bn: packed arrays, lda = ldb = Kp; rows are padded, so no clamping): the DMA of
+// chunk i+1 is issued into the other LDS buffer before chunk i goes to the matrix cores; the barrier at the end of the
+// iteration (with the vmcnt(0) the compiler puts in front of it) makes it visible and frees the buffer just read.
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_packed(const float *__restrict__ am, int kp, const float *__restrict__ bn,
+                                                     int dim, int64_t n0, int64_t n_tiles, MTile m_tile, float *As,
+                                                     float *Bs, Epilogue epilogue) {
+    const int kend = (dim + 7) / 8 * 8;
+    const int nchunk = (kend + BK - 1) / BK;
+    const int64_t total = n_tiles * nchunk;
+    if (total == 0) return;
+    constexpr int BUF = TILE * LDS_LD;                                // the buffers keep the reg-staged path's size
+    stage_packed(am, kp, m_tile(0), 0, As);
+    stage_packed(bn, kp, n0, 0, Bs);
+    __syncthreads();
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    int64_t t = 0;
+    int kc = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        const int cur = (int)(it & 1);
+        if (it + 1 < total) {
+            int kc1 = kc + 1;
+            int64_t t1 = t;
+            if (kc1 == nchunk) { kc1 = 0; ++t1; }
+            stage_packed(am, kp, m_tile(t1), kc1 * BK, As + (cur ^ 1) * BUF);
+            stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
+        }
+        mma_chunk_packed(As + cur * BUF, Bs + cur * BUF, min(BK, kend - kc * BK) / 8, acc);
+        __syncthreads();
+        if (++kc == nchunk) {
+            epilogue(t, acc);
+            zero_acc(acc);
+            kc = 0;
+            ++t;
+        }
+    }
+}
+
+// one call site for both stagings: PACKED kernels receive packed operands and their Kp in the ld arguments
+template <bool PACKED, class MTile, class Epilogue>
+__device__ __forceinline__ void run_tiles(const float *__restrict__ am, int64_t m_rows, int lda, const float *__restrict__ bn,
+                                          int64_t n_rows, int ldb, int dim, int64_t n0, int64_t n_tiles, MTile m_tile,
+                                          float *As, float *Bs, Epilogue epilogue) {
+    if constexpr (PACKED) tile_pipeline_packed(am, lda, bn, dim, n0, n_tiles, m_tile, As, Bs, epilogue);
+    else tile_pipeline(am, m_rows, lda, bn, n_rows, ldb, dim, n0, n_tiles, m_tile, As, Bs, epilogue);
+}
+
 // ---- gold similarity: S_ii as the same k-ordered fmaf chain (one lane per query) ---------------
 __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2,
                                   int ld2, int dim, const float *__restrict__ csls_r,
@@ -185,7 +305,7 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
 // grid.x = query tiles, grid.y = candidate chunks.  Per lane: one query (MFMA column) and 16
 // candidates per MFMA tile, so the per-query reductions stay in registers across the whole
 // candidate sweep; partial results are merged with integer atomics (order independent).
-template <bool CSLS>
+template <bool CSLS, bool PACKED>
 __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
     const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2,
     int dim, const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
@@ -211,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
         g[tn] = ok ? gold[qi[tn]] : 0.f;
         rq[tn] = (ok && CSLS) ? csls_r[qi[tn]] : 0.f;
     }
-    tile_pipeline(
+    run_tiles<PACKED>(
         e2, n2, ld2, e1, n1, ld1, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
         [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
         [&](int64_t t, f32x16 (&acc)[2][2]) {
@@ -281,6 +401,7 @@ __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best
 }
 
 // ---- store epilogue: M = e1 rows (output rows), N = e2 rows (output columns) ----------------------
+template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void sim_inner_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
                                                               const float *__restrict__ e2, int64_t n2, int ld2,
                                                               int dim, float *__restrict__ out, int64_t ld_out) {
@@ -289,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void sim_inner_store_kernel(const float *__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
-    tile_pipeline(
+    run_tiles<PACKED>(
         e1, n1, ld1, e2, n2, ld2, dim, c0, 1, [=](int64_t) { return m0; }, As, Bs,
         [&](int64_t, f32x16 (&acc)[2][2]) {
             float *tile = out + m0 * ld_out + c0;                                    // wave-uniform
@@ -693,7 +814,85 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(const float *__restrict_
     }
 }
 
+// ---- host side of the packed path ---------------------------------------------------------------------------------
+// OEA_TILE_GLDS=0 selects the register-staged pipeline (kept for A/B measurements and as the reference of the
+// bit-exactness test between the two stagings).
+static bool use_glds() {
+    static const bool on = [] { const char *e = getenv("OEA_TILE_GLDS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+struct PackedOp {
+    float *p = nullptr;      // [n_pad, kp] in the process-wide scratch slot
+    int kp = 0;
+};
+
+// Two grow-only scratch slots (one per operand) instead of an allocation per call: at 10,500^2 two stream-ordered
+// allocations + frees cost 0.12 ms on a 0.37 ms evaluation.  Reuse is ordered by the stream; a call on ANOTHER stream
+// first waits for the event recorded after the previous use.  Growing a slot frees the old one (hipFree waits for the
+// device), so kernels still reading it are done.
+struct PackSlot {
+    float *p = nullptr;
+    size_t cap = 0;
+    hipStream_t last = nullptr;
+    hipEvent_t used = nullptr;
+};
+static PackSlot g_slot[2];
+
+static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
+    PackSlot &sl = g_slot[slot];
+    const int64_t n_pad = (n + TILE - 1) / TILE * TILE;
+    out->kp = (dim + BK - 1) / BK * BK;
+    const size_t need = sizeof(float) * (size_t)n_pad * out->kp;
+    if (!sl.used) OEA_CHECK_HIP(hipEventCreateWithFlags(&sl.used, hipEventDisableTiming));
+    if (need > sl.cap) {
+        if (sl.p) OEA_CHECK_HIP(hipFree(sl.p));
+        sl.p = nullptr;
+        sl.cap = 0;
+        OEA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&sl.p), need + need / 4));
+        sl.cap = need + need / 4;
+    } else if (sl.last != st) {
+        OEA_CHECK_HIP(hipStreamWaitEvent(st, sl.used, 0));
+    }
+    sl.last = st;
+    out->p = sl.p;
+    const int64_t total = n_pad * (out->kp / 4);
+    pack_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 16384), 256, 0, st>>>(src, n, ld, dim, out->p, n_pad,
+                                                                                                   out->kp);
+    return OEA_OK;
+}
+// after the kernels that read the packed operands have been enqueued
+static int release_packed(hipStream_t st) {
+    for (int i = 0; i < 2; ++i)
+        if (g_slot[i].used && g_slot[i].last == st) OEA_CHECK_HIP(hipEventRecord(g_slot[i].used, st));
+    return OEA_OK;
+}
+
+static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
+                                int64_t ld_out, hipStream_t st) {
+    sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
+        e1p, n1, kp, e2p, n2, kp, dim, out, ld_out);
+}
+
 }  // namespace
+
+namespace oea {
+// kNN strips (topk.hip): both operands packed once (slot 0 = queries, slot 1 = candidates), every strip produced from
+// the packed copies; release_packed_rows() after the last strip
+bool tile_glds_enabled() { return use_glds(); }
+int pack_rows(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, float **packed, int *kp) {
+    PackedOp op;
+    const int rc = pack_operand(slot, src, n, ld, dim, st, &op);
+    *packed = op.p;
+    *kp = op.kp;
+    return rc;
+}
+int release_packed_rows(hipStream_t st) { return release_packed(st); }
+void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
+                            int64_t ld_out, hipStream_t st) {
+    launch_store_packed(e1p, n1, e2p, n2, kp, dim, out, ld_out, st);
+}
+}  // namespace oea
 
 extern "C" {
 
@@ -722,12 +921,27 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
                                                                           csls_c ? csls_c + gold_offset : nullptr, gold);
         const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
-        if (csls_r)
-            rank_inner_kernel<true><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
-                                                                                        csls_c, tpc, gold_offset, rank, keys);
-        else
-            rank_inner_kernel<false><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r,
-                                                                                         csls_c, tpc, gold_offset, rank, keys);
+        const dim3 grid((unsigned)qt, (unsigned)chunks);
+        if (use_glds()) {
+            PackedOp p1, p2;
+            int rc = pack_operand(0, e1, n1, ld1, dim, st, &p1);
+            if (rc == OEA_OK) rc = pack_operand(1, e2, n2, ld2, dim, st, &p2);
+            if (rc != OEA_OK) return rc;
+            if (csls_r)
+                rank_inner_kernel<true, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
+                                                                    gold_offset, rank, keys);
+            else
+                rank_inner_kernel<false, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
+                                                                     gold_offset, rank, keys);
+            rc = release_packed(st);
+            if (rc != OEA_OK) return rc;
+        } else if (csls_r) {
+            rank_inner_kernel<true, false><<<grid, 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset,
+                                                                 rank, keys);
+        } else {
+            rank_inner_kernel<false, false><<<grid, 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset,
+                                                                  rank, keys);
+        }
     } else if (metric == OEA_METRIC_MANHATTAN || metric == OEA_METRIC_EUCLIDEAN) {
         const int64_t qt = oea::ceil_div(n1, VT), ctiles = oea::ceil_div(n2, VT);
         const int chunks = pick_chunks(qt, ctiles, &tpc);
@@ -768,8 +982,16 @@ int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && ld_out >= n2 && ld_out < (1 << 24), "shapes");
     if (n1 == 0 || n2 == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
-    if (metric == OEA_METRIC_INNER) {
-        sim_inner_store_kernel<<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
+    if (metric == OEA_METRIC_INNER && use_glds()) {
+        PackedOp p1, p2;
+        int rc = pack_operand(0, e1, n1, ld1, dim, st, &p1);
+        if (rc == OEA_OK) rc = pack_operand(1, e2, n2, ld2, dim, st, &p2);
+        if (rc != OEA_OK) return rc;
+        launch_store_packed(p1.p, n1, p2.p, n2, p1.kp, dim, out, ld_out, st);
+        rc = release_packed(st);
+        if (rc != OEA_OK) return rc;
+    } else if (metric == OEA_METRIC_INNER) {
+        sim_inner_store_kernel<false><<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
             e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
     } else if (metric == OEA_METRIC_MANHATTAN) {
         sim_valu_store_kernel<OEA_METRIC_MANHATTAN><<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(

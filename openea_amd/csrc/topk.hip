@@ -562,6 +562,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
                    size_t ws_bytes, void *stream) {
     OEA_REQUIRE(q && c && out_idx && workspace, "null pointer");
     OEA_REQUIRE(k >= 1 && k <= nc, "1 <= k <= nc");
+    OEA_REQUIRE(nc < (1 << 24) - 32, "nc < 2^24");
     OEA_REQUIRE(ldq % 4 == 0 && ldc % 4 == 0 && dim > 0 && dim <= ldq && dim <= ldc, "ld % 4 == 0, dim <= ld");
     if (nq == 0) return OEA_OK;
     const int64_t ld = (nc + 31) / 32 * 32;
@@ -571,11 +572,28 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
                 "workspace smaller than one 128-row strip");
     if (rows_per < 128) rows_per = nq;
     float *strip = static_cast<float *>(workspace);
-    for (int64_t r0 = 0; r0 < nq; r0 += rows_per) {
-        const int64_t rows = std::min<int64_t>(rows_per, nq - r0);
-        int rc = oea_sim_matrix(q + r0 * ldq, rows, ldq, c, nc, ldc, dim, OEA_METRIC_INNER, strip, ld, stream);
+    hipStream_t st = oea::as_stream(stream);
+    const bool packed = oea::tile_glds_enabled();
+    float *qp = nullptr, *cp = nullptr;
+    int kp = 0;
+    if (packed) {                                   // both operands packed once for all strips (sim_rank.hip)
+        int rc = oea::pack_rows(0, q, nq, ldq, dim, st, &qp, &kp);
+        if (rc == OEA_OK) rc = oea::pack_rows(1, c, nc, ldc, dim, st, &cp, &kp);
         if (rc != OEA_OK) return rc;
-        launch_select(strip, rows, nc, ld, k, id_map, out_idx + r0 * (int64_t)k, oea::as_stream(stream));
+    }
+    for (int64_t r0 = 0; r0 < nq; r0 += rows_per) {              // r0 is a multiple of 128: strips start on tile rows
+        const int64_t rows = std::min<int64_t>(rows_per, nq - r0);
+        if (packed) {
+            oea::sim_inner_store_packed(qp + r0 * kp, rows, cp, nc, kp, dim, strip, ld, st);
+        } else {
+            int rc = oea_sim_matrix(q + r0 * ldq, rows, ldq, c, nc, ldc, dim, OEA_METRIC_INNER, strip, ld, stream);
+            if (rc != OEA_OK) return rc;
+        }
+        launch_select(strip, rows, nc, ld, k, id_map, out_idx + r0 * (int64_t)k, st);
+    }
+    if (packed) {
+        const int rc = oea::release_packed_rows(st);
+        if (rc != OEA_OK) return rc;
     }
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;

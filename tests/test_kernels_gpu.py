@@ -736,3 +736,40 @@ def test_mapping_step_matches_oracle(ops, d, n, opt):
     assert np.linalg.norm(te[:, :d].cpu().numpy() - e0) <= 1e-4 * np.linalg.norm(e0)
     assert np.linalg.norm(tm.cpu().numpy() - m0) <= 1e-4 * np.linalg.norm(m0)
     assert int(ws[: -8 * 4096].count_nonzero()) == 0
+
+
+def test_tile_stagings_agree_bitwise(tmp_path):
+    """The similarity tiles have two stagings -- LDS-DMA from packed operands (default) and the register-staged
+    pipeline (OEA_TILE_GLDS=0, read once per process): same k order on the matrix cores, hence identical bits for
+    the similarity strip, the fused ranks / argmax (plain and CSLS) and the kNN sets."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, %r)
+from openea_amd import ops
+rng = np.random.RandomState(5)
+h = hashlib.sha256()
+for n1, n2, d in ((300, 517, 75), (129, 1000, 100), (640, 640, 300), (1, 130, 8)):
+    e1 = rng.standard_normal((n1, d)).astype(np.float32); e2 = rng.standard_normal((n2, d)).astype(np.float32)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    h.update(ops.sim_matrix(t1, t2, d).cpu().numpy().tobytes())
+    if n1 <= n2:
+        r, a = ops.rank_eval(t1, t2, d)
+        h.update(r.cpu().numpy().tobytes()); h.update(a.cpu().numpy().tobytes())
+        cr = torch.from_numpy(rng.rand(n1).astype(np.float32)).cuda(); cc = torch.from_numpy(rng.rand(n2).astype(np.float32)).cuda()
+        r, a = ops.rank_eval(t1, t2, d, csls_r=cr, csls_c=cc)
+        h.update(r.cpu().numpy().tobytes()); h.update(a.cpu().numpy().tobytes())
+    k = min(37, n2)
+    h.update(np.sort(ops.topk_inner(t1, t2, d, k).cpu().numpy(), axis=1).tobytes())
+print("DIGEST", h.hexdigest())
+''' % root
+    digests = []
+    for flag in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, OEA_TILE_GLDS=flag), capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
