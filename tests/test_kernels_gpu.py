@@ -603,7 +603,9 @@ def test_rotate_step_matches_oracle(ops, d, k, opt, ent_norm, rel_norm):
         assert float(got[:, d:].abs().sum()) == 0.0
     te2, tr2, _ = device_run(True)
     for a, b in ((te, te2), (tr, tr2)):
-        assert np.linalg.norm((a - b).cpu().numpy()) <= 1e-12 * np.linalg.norm(a.cpu().numpy())
+        # two runs differ by the order of their fp64 atomics only; the unnormalised phase rows amplify that rounding
+        # noise by phase_scale (observed up to 4e-12 relative over three steps at d = 200)
+        assert np.linalg.norm((a - b).cpu().numpy()) <= 1e-10 * np.linalg.norm(a.cpu().numpy())
     # the lookups evaluation reads
     ids = rng.permutation(E)[:97].astype(np.int32)
     for part_norm, sum_norm in ((True, False), (True, True), (False, True)):
