@@ -27,11 +27,32 @@ def main():
     src, name = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
-    for leg, out in (("stats", "bench_kernel_stats"), ("legs", "legs_kernel_stats")):
+    for leg, out in (("stats", "bench_kernel_stats"), ("legs", "legs_kernel_stats"), ("models", "models_kernel_stats")):
         fs = glob.glob(os.path.join(src, leg, "*", "*_kernel_stats.csv"))
         if fs:
             shutil.copy(fs[0], os.path.join(prof, "%s_%s.csv" % (name, out)))
-    for log in ("bench_stats.log", "legs.log"):
+    up = os.path.join(src, "bench_unprofiled.json")
+    if os.path.exists(up):
+        lines = [l for l in open(up) if l.startswith("{")]
+        if lines:
+            open(os.path.join(prof, "%s_bench_unprofiled.json" % name), "w").write(lines[-1])
+    # matrix-core counters of the evaluation sweep: raw per-kernel averages
+    rows = collections.defaultdict(dict)
+    for f in glob.glob(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv")):
+        acc, cnt = collections.defaultdict(float), collections.Counter()
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"])
+            cnt[(r["Kernel_Name"], r["Counter_Name"])] += 1
+        for (k, c), v in acc.items():
+            rows[k][c] = v / cnt[(k, c)]
+            rows[k]["calls"] = cnt[(k, c)]
+    if rows:
+        names = sorted({c for d in rows.values() for c in d if c != "calls"})
+        with open(os.path.join(prof, "%s_pmc_mfma_eval70k.csv" % name), "w") as f:
+            f.write("kernel,calls," + ",".join(n + "_avg" for n in names) + "\n")
+            for k, d in sorted(rows.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
+                f.write('"%s",%d,' % (k[:100], d["calls"]) + ",".join("%.0f" % d.get(n, 0.0) for n in names) + "\n")
+    for log in ("bench_stats.log", "legs.log", "models.log"):
         p = os.path.join(src, log)
         if os.path.exists(p):
             lines = [l for l in open(p) if not l.startswith("/opt/amdgpu")]
