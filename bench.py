@@ -218,6 +218,7 @@ def extra_legs(torch, ops, ent, kgs, d, k1):
     torch.cuda.synchronize()
     out["eval_pairs_per_s_manhattan"] = round(e1.shape[0] / (time.perf_counter() - t0), 1)
     from openea_amd.models.trainer import refresh_neighbours
+    refresh_neighbours(ent, kgs.kg1.entities_list, k1)                                 # warm (first-use allocations)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 3

@@ -849,8 +849,9 @@ static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, 
         if (sl.p) OEA_CHECK_HIP(hipFree(sl.p));
         sl.p = nullptr;
         sl.cap = 0;
-        OEA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&sl.p), need + need / 4));
-        sl.cap = need + need / 4;
+        const size_t cap = std::max<size_t>(need + need / 4, (size_t)64 << 20);   // 64 MB = 131,072 rows of K = 128: growth is rare
+        OEA_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&sl.p), cap));
+        sl.cap = cap;
     } else if (sl.last != st) {
         OEA_CHECK_HIP(hipStreamWaitEvent(st, sl.used, 0));
     }
