@@ -138,7 +138,6 @@ def to_table64(array, dev=None):
 def make_rotate_cfg(gamma, dim, ent_l2_norm=True, rel_l2_norm=False, optimizer='Adam', lr=0.01, beta1=0.9, beta2=0.999,
                     eps=1e-8, epsilon=2.0):
     """bootea_rotate.py:29-33,90: embedding_range = (gamma + epsilon) / dim, phase = rel / (embedding_range / pi)."""
-    import math
     rng = (float(gamma) + float(epsilon)) / dim
     return RotateCfg(float(gamma), 3.14159265358979323846 / rng, float(lr), float(beta1), float(beta2), float(eps), 0,
                      int(bool(ent_l2_norm)), int(bool(rel_l2_norm)), OPT_KIND[optimizer], 0)
