@@ -1,0 +1,159 @@
+"""Host-side graph builders and bootstrapping helpers against outputs of the REFERENCE's own functions
+(tests/golden/graphs.npz, written by tests/golden/make_graph_golden.py from approaches/gcn_align.py, alinet.py, rdgcn.py,
+bootea.py, modules/bootstrapping/alignment_finder.py, modules/finding/alignment.py on the synthetic "tiny" KG pair).
+The device halves (candidate search, stable matching on the device similarity) are at the end, marked gpu."""
+import contextlib
+import io
+import os
+import types
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(HERE, "golden", "graphs.npz"))
+
+
+@pytest.fixture(scope="module")
+def kgs():
+    from openea_amd.modules.load.synth import make_kgs
+    return make_kgs("tiny", mode="mapping", seed=0)
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def coo_sorted(rows, cols, values):
+    rows, cols = np.asarray(rows, np.int64), np.asarray(cols, np.int64)
+    values = np.asarray(values, np.float64)
+    order = np.lexsort((cols, rows))
+    return np.stack([rows[order].astype(np.float64), cols[order].astype(np.float64), values[order]], axis=1)
+
+
+def triples_sorted(triples):
+    return np.array(sorted(tuple(int(x) for x in t) for t in triples), np.int64).reshape(-1, 3)
+
+
+def assert_coo(mine, ref, tol=1e-12):
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine[:, :2], ref[:, :2])
+    np.testing.assert_allclose(mine[:, 2], ref[:, 2], rtol=tol, atol=tol)
+
+
+def test_gcn_align_adjacency_matches_reference(g, kgs):
+    """gcn_align.py:610-664 (functionality weights, weighted adjacency) and :566-578 (D^-1/2 (A + I) D^-1/2)."""
+    from openea_amd.approaches.gcn_align import GCN_Utils, load_attr
+    triples = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+    u = GCN_Utils(types.SimpleNamespace(), kgs)
+    r2f, r2if = u.func(triples), u.ifunc(triples)
+    np.testing.assert_array_equal(np.array([r2f[r] for r in sorted(r2f)]), g["gcn_r2f"])
+    np.testing.assert_array_equal(np.array([r2if[r] for r in sorted(r2if)]), g["gcn_r2if"])
+    adj = u.get_weighted_adj(kgs.entities_num, triples)
+    assert_coo(coo_sorted(adj.row, adj.col, adj.data), g["gcn_adj"])
+    sup = u.preprocess_adj(adj).tocoo()
+    assert_coo(coo_sorted(sup.row, sup.col, sup.data), g["gcn_support"])
+    attr_kgs = types.SimpleNamespace(
+        kg1=types.SimpleNamespace(entity_attributes_dict={e: {(e * 7 + j) % 23 for j in range(1 + e % 4)} for e in range(0, 60, 2)}),
+        kg2=types.SimpleNamespace(entity_attributes_dict={e: {(e * 5 + j) % 23 for j in range(1 + e % 3)} for e in range(1, 60, 2)}))
+    np.testing.assert_array_equal(np.asarray(load_attr(60, attr_kgs).todense(), np.float32), g["gcn_attr"])
+
+
+def test_alinet_builders_match_reference(g, kgs):
+    """alinet.py:155-181 (1-hop adjacency), :250-287 (2-hop triples incl. the pattern cut), :399-416 (seed-edge
+    enhancement), :138-144."""
+    from openea_amd.approaches import alinet
+    sup1 = [a for a, _ in kgs.train_links]
+    sup2 = [b for _, b in kgs.train_links]
+    kg1, kg2 = alinet.AKG(kgs.kg1.relation_triples_set), alinet.AKG(kgs.kg2.relation_triples_set)
+    en1, en2 = quiet(alinet.enhance_triples, kg1, kg2, sup1, sup2)
+    assert np.array_equal(triples_sorted(en1), g["alinet_enhanced1"]) and np.array_equal(triples_sorted(en2), g["alinet_enhanced2"])
+    half = len(kgs.test_entities1) // 2
+    linked = set(sup1 + sup2 + kgs.valid_entities1 + kgs.valid_entities2 + kgs.test_entities1[:half] + kgs.test_entities2[:half])
+    for name, kg in (("kg1", kg1), ("kg2", kg2)):
+        assert np.array_equal(triples_sorted(quiet(alinet.generate_2hop_triples, kg, linked_ents=linked)), g["alinet_2hop_" + name])
+        assert np.array_equal(triples_sorted(quiet(alinet.generate_2hop_triples, kg)), g["alinet_2hop_all_" + name])
+    one = alinet.no_weighted_adj(kgs.entities_num, list(kg1.triples | kg2.triples | en1 | en2))
+    one = one.tocoo() if hasattr(one, "tocoo") else one
+    if isinstance(one, tuple):
+        mine = coo_sorted(one[0][:, 0], one[0][:, 1], one[1])
+    else:
+        mine = coo_sorted(one.row, one.col, one.data)
+    assert_coo(mine, g["alinet_one_adj"])
+    rel_ht = alinet.generate_rel_ht(sorted(kgs.kg1.relation_triples_set))
+    assert np.array_equal(np.array([len(rel_ht[r]) for r in sorted(rel_ht)]), g["alinet_rel_ht_sizes"])
+
+
+def test_rdgcn_structures_match_reference(g, kgs):
+    """rdgcn.py:17-72: per-relation head / tail sets, the relation-labelled edge list in triple order, the primal
+    adjacency 1 / sqrt(deg deg) with the reference's degree rule."""
+    from openea_amd.approaches import rdgcn
+    triples = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+    n_ent, n_rel = kgs.entities_num, kgs.relations_num
+    head, tail, ind, val = rdgcn.rfunc(triples, n_ent, n_rel)
+    assert np.array_equal(np.array([len(head.get(r, ())) for r in range(n_rel)]), g["rdgcn_head_sizes"])
+    assert np.array_equal(np.array([len(tail.get(r, ())) for r in range(n_rel)]), g["rdgcn_tail_sizes"])
+    for sets, dense in ((head, g["rdgcn_head_r"]), (tail, g["rdgcn_tail_r"])):
+        mine = np.zeros_like(dense)
+        for r, ents in sets.items():
+            mine[list(ents), r] = 1
+        assert np.array_equal(mine, dense)
+    assert np.array_equal(np.concatenate([ind, val[:, None]], 1), g["rdgcn_r_mat"])
+    rows, cols, vals = rdgcn.get_sparse_tensor(triples, n_ent)
+    assert_coo(coo_sorted(rows, cols, vals), g["rdgcn_primal"], tol=1e-7)        # ours hands the values over as fp32
+
+
+def test_bootstrapping_helpers_match_reference(g, kgs):
+    """bootea.py:35-77 (label editing), :107-138 (supervised triples, positive batches)."""
+    from openea_amd.approaches import bootea
+    sim_mat = np.matmul(g["boot_e1"], g["boot_e2"].T)
+    pre = {(i, (i * 7) % 90) for i in range(0, 90, 3)}
+    cur = {(i, (i * 11) % 90) for i in range(0, 90, 2)}
+    lab_x = quiet(bootea.update_labeled_alignment_x, pre, cur, sim_mat)
+    assert np.array_equal(np.array(sorted(lab_x)), g["boot_update_x"])
+    assert np.array_equal(np.array(sorted(quiet(bootea.update_labeled_alignment_y, lab_x, sim_mat))), g["boot_update_y"])
+    sup1 = [a for a, _ in kgs.train_links][:25]
+    sup2 = [b for _, b in kgs.train_links][:25]
+    t1, t2 = quiet(bootea.generate_supervised_triples, kgs.kg1.rt_dict, kgs.kg1.hr_dict, kgs.kg2.rt_dict, kgs.kg2.hr_dict, sup1, sup2)
+    assert np.array_equal(triples_sorted(t1), g["boot_sup_triples1"]) and np.array_equal(triples_sorted(t2), g["boot_sup_triples2"])
+    b1, b2 = bootea.generate_pos_batch(sorted(t1), sorted(t2), 2, 37)
+    assert np.array_equal(np.array(list(b1) + list(b2)).reshape(-1, 3), g["boot_pos_batch"])
+
+
+def test_stable_matching_oracle_matches_reference(g):
+    """alignment.py:87-224 printed 'stable alignment precision = x%': the oracle's Gale-Shapley restatement on the
+    same similarity matrices (plain and CSLS) reaches the same precision."""
+    from oracle import np_oracle as orc
+    for csls in (0, 5):
+        s = orc.sim(g["boot_e1"], g["boot_e2"], metric="inner", normalize=False, csls_k=csls)
+        match = orc.stable_alignment(s)
+        pairs = match.items() if isinstance(match, dict) else match
+        correct = sum(1 for i, j in pairs if i == j)
+        assert abs(correct / len(s) * 100 - float(g["stable_precision_csls%d" % csls][0])) < 1e-3
+
+
+# ---- device halves ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_candidate_search_and_stable_matching_on_device(g, capsys):
+    """alignment_finder.py:28-76 (threshold & top-k candidates, nearest-k lists) and alignment.py:87-134 through the
+    device path: same candidate sets, same precision."""
+    pytest.importorskip("torch")
+    from openea_amd.modules.bootstrapping import alignment_finder as af
+    from openea_amd.modules.finding.alignment import stable_alignment
+    sim = af.PairSim(g["boot_e1"], g["boot_e2"])
+    for th, k in ((0.5, 5), (0.7, 10), (0.2, 3)):
+        pairs, _ = af.find_alignment(sim, th, k)
+        assert np.array_equal(np.array(sorted(pairs), np.int64).reshape(-1, 2), g["boot_find_%g_%d" % (th, k)])
+    near = af.search_nearest_k_device(sim, 7)
+    mine = sorted((i, int(j)) for i in range(near.shape[0]) for j in near[i])
+    assert np.array_equal(np.array(mine, np.int64), g["boot_nearest_7"])
+    for csls in (0, 5):
+        stable_alignment(g["boot_e1"], g["boot_e2"], "inner", False, csls, 1)
+        out = capsys.readouterr().out
+        line = [ln for ln in out.splitlines() if "stable alignment precision" in ln][-1]
+        assert abs(float(line.split("=")[1].split("%")[0]) - float(g["stable_precision_csls%d" % csls][0])) < 1e-3
