@@ -126,6 +126,13 @@ def main():
     pos = ref.rdgcn.get_sparse_tensor(triples, n_ent)
     out['rdgcn_primal'] = coo_sorted(pos['indices'], pos['values'])
 
+    # hard negatives (rdgcn.py:75-87): the k L1-nearest entities of every seed entity, in ascending distance
+    rng = np.random.RandomState(5)
+    layer = rng.standard_normal((300, 24)).astype(np.float32)
+    ill = rng.permutation(300)[:40]
+    out['rdgcn_neg_layer'], out['rdgcn_neg_ill'] = layer, ill.astype(np.int64)
+    out['rdgcn_neg'] = ref.rdgcn.get_neg(ill, layer, 9).reshape(40, 9).astype(np.int64)
+
     # ---- bootstrapping (alignment_finder.py:12-76, bootea.py:35-138) ----------------------------------------------
     rng = np.random.RandomState(99)
     e1 = rng.standard_normal((90, 16)).astype(np.float32)

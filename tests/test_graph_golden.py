@@ -157,3 +157,15 @@ def test_candidate_search_and_stable_matching_on_device(g, capsys):
         out = capsys.readouterr().out
         line = [ln for ln in out.splitlines() if "stable alignment precision" in ln][-1]
         assert abs(float(line.split("=")[1].split("%")[0]) - float(g["stable_precision_csls%d" % csls][0])) < 1e-3
+
+
+@pytest.mark.gpu
+def test_rdgcn_hard_negatives_on_device(g):
+    """rdgcn.py:75-87 (scipy cdist cityblock + argsort[:k]) -> the fp64 manhattan tiles + row select: the same k
+    entities for every seed (the reference lists them by ascending distance; the loss sums over them)."""
+    pytest.importorskip("torch")
+    from openea_amd import ops
+    from openea_amd.approaches.rdgcn import get_neg
+    layer = ops.to_table(g["rdgcn_neg_layer"])
+    got = get_neg(ops.to_ids(g["rdgcn_neg_ill"].astype(np.int32)), layer, 24, 9).cpu().numpy().reshape(40, 9)
+    assert np.array_equal(np.sort(got, axis=1), np.sort(g["rdgcn_neg"], axis=1))
