@@ -165,6 +165,24 @@ def main():
         line = [ln for ln in buf.getvalue().splitlines() if 'stable alignment precision' in ln][-1]
         out['stable_precision_csls%d' % csls] = np.array([float(line.split('=')[1].split('%')[0])])
 
+    # ---- writers (read.py:282-366): byte content of every file save_embeddings / save_results produce ---------------
+    import hashlib
+    import json
+    import tempfile
+    ref_read = importlib.import_module('openea.modules.load.read')
+    wr = np.random.RandomState(3)
+    ent = (wr.standard_normal((n_ent, 5)) * np.array([1, 1e-3, 1e3, 1e-8, 1])).astype(np.float32)
+    rel = wr.standard_normal((n_rel, 5)).astype(np.float32)
+    digests = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        folder = tmp + "/out/"
+        quiet(ref_read.save_embeddings, folder, kgs, ent, rel, None, mapping_mat=np.eye(5, dtype=np.float32))
+        quiet(ref_read.save_results, folder, [(3, 4), (10, 7), (5, 5)])
+        for name in sorted(os.listdir(folder)):
+            digests[name] = hashlib.sha256(open(folder + name, 'rb').read()).hexdigest()
+    with open(os.path.join(HERE, 'writers.json'), 'w') as fh:
+        json.dump(digests, fh, indent=1)
+
     np.savez_compressed(os.path.join(HERE, 'graphs.npz'), **out)
     print('wrote', os.path.join(HERE, 'graphs.npz'), {k: v.shape for k, v in out.items()})
 

@@ -137,6 +137,24 @@ def test_stable_matching_oracle_matches_reference(g):
         assert abs(correct / len(s) * 100 - float(g["stable_precision_csls%d" % csls][0])) < 1e-3
 
 
+def test_writers_are_byte_compatible_with_reference(kgs, tmp_path):
+    """read.py:282-366: every file save_embeddings / save_results write (.npy payloads, id tsv files, the text dumps of the
+    embeddings, the result pairs) has the bytes the reference's own writer produced for the same inputs."""
+    import hashlib
+    import json
+    from openea_amd.modules.load import read as rd
+    golden = json.load(open(os.path.join(HERE, "golden", "writers.json")))
+    wr = np.random.RandomState(3)
+    ent = (wr.standard_normal((kgs.entities_num, 5)) * np.array([1, 1e-3, 1e3, 1e-8, 1])).astype(np.float32)
+    rel = wr.standard_normal((kgs.relations_num, 5)).astype(np.float32)
+    folder = str(tmp_path) + "/out/"
+    quiet(rd.save_embeddings, folder, kgs, ent, rel, None, mapping_mat=np.eye(5, dtype=np.float32))
+    quiet(rd.save_results, folder, [(3, 4), (10, 7), (5, 5)])
+    assert sorted(os.listdir(folder)) == sorted(golden)
+    for name, digest in golden.items():
+        assert hashlib.sha256(open(folder + name, "rb").read()).hexdigest() == digest, name
+
+
 # ---- device halves ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_candidate_search_and_stable_matching_on_device(g, capsys):
