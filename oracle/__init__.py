@@ -11,13 +11,20 @@ Pinning (details in DESIGN.md, section "Oracle"):
   the reference's own modules in place (``/root/reference``, this container only) and
   stores their outputs as small fixtures; ``tests/test_oracle_golden.py`` checks every
   restatement here against them.
-* TensorFlow-1 half (l2_normalize, translational losses, gradient through the gather,
-  Adagrad/SGD/Adam, sparse_tensor_dense_matmul, sparse_softmax, BatchNormalization) --
-  PARITY UNPINNED: TF1 is not installable here and the reference ships no golden vectors.
-  The restatements follow the cited reference lines plus the TF1 op semantics written down
-  in DESIGN.md (assumptions H1/H3/H4).  What can be pinned without TF is: every hand-derived
-  gradient (translational step for all losses, TransH, GCN-Align epoch, sparse attention) is
-  checked against finite differences of the loss in ``tests/test_oracle_golden.py``.
+* TensorFlow-1 half, translational graphs -- FORWARD GRAPH PINNED, optimiser arithmetic unpinned: TF1 is not
+  installable here, but ``tests/golden/make_tf_graph_golden.py`` installs a lazily evaluated numpy stand-in for the few
+  dozen TF ops involved (``tests/golden/tf_shim.py``) and lets the REFERENCE's own code build its graphs --
+  ``_define_variables`` / ``_define_embed_graph`` / ``_define_alignment_graph`` / ``_define_mapping_graph`` of
+  basic_model.py, mtranse.py, aligne.py, bootea.py, bootea_transh.py, bootea_rotate.py and models/trans/{transe,transh,
+  transd}.py with losses.py, initializers.py, mapping.py underneath.  The loss of a fixed batch and its finite-difference
+  gradient w.r.t. every variable are stored (``tests/golden/tf_graphs.npz``); the step functions here reproduce both
+  (``tests/test_oracle_golden.py::*reference_graph``).  What stays an assumption is the meaning of the individual TF ops
+  (l2_normalize = x * rsqrt(max(sum x^2, 1e-12)), gather gradients summed per row, relu'(0) = 0) and the optimisers'
+  arithmetic (Adagrad accumulator 0.1 and no epsilon, TF-Adam's epsilon-hat and its dense updates), as written down in
+  DESIGN.md (H1/H3/H4).
+* TensorFlow-1 half, GNN graphs (sparse_tensor_dense_matmul, sparse_softmax, BatchNormalization, Adam) -- PARITY
+  UNPINNED: restatements of the cited lines; every hand-derived gradient (GCN-Align epoch, sparse attention, and the
+  translational steps above) is additionally checked against finite differences of a loss written independently.
 * Random draws (negative triples, negative links): the reference uses python ``random``; the
   restatements here define the Philox / keyed-permutation formulation the device kernels
   reproduce bit for bit, and the tests check the reference's invariants on them

@@ -1,0 +1,173 @@
+"""Golden loss values and gradients of the translational graphs, from the REFERENCE's own graph-definition code.
+
+TensorFlow 1.x cannot be installed here, so `tensorflow` is replaced by tests/golden/tf_shim.py (a lazily evaluated numpy
+stand-in for the few dozen ops these files use) and the reference's classes build their graphs with it:
+`_define_variables`, `_define_embed_graph`, `_define_alignment_graph`, `_define_mapping_graph` of
+models/basic_model.py, approaches/{mtranse,aligne,bootea,bootea_transh,bootea_rotate}.py and models/trans/{transe,transh,
+transd}.py run UNMODIFIED (with modules/base/{losses,initializers,optimizers,mapping}.py underneath).  For one fixed batch
+per model the loss node is evaluated in float64 at float32-representable variable values, and its gradient w.r.t. every
+variable is taken by central finite differences.  What the shim contributes is the meaning of the individual ops
+(l2_normalize, embedding_lookup, reduce_sum, ...); the composition -- which rows are looked up, normalised how often,
+projected how, which loss with which constants -- is the reference's source.
+
+Run in the build container only:  python tests/golden/make_tf_graph_golden.py   -> tests/golden/tf_graphs.npz
+"""
+import contextlib
+import importlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+ROOT = '/root/reference/src/openea'
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+
+class Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        m = Stub(self.__name__ + '.' + k)
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return None
+
+
+def import_reference():
+    import tf_shim
+    shim = types.ModuleType('tensorflow')
+    shim.__dict__.update({k: v for k, v in vars(tf_shim).items() if not k.startswith('__')})
+    sys.modules['tensorflow'] = shim
+    for name in ('igraph', 'graph_tool', 'graph_tool.all', 'gensim', 'gensim.models', 'gensim.models.word2vec', 'Levenshtein'):
+        sys.modules[name] = Stub(name)
+
+    def _pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    _pkg('openea', ROOT)
+    _pkg('openea.modules', ROOT + '/modules')
+    for sub in ('utils', 'load', 'train', 'finding', 'args', 'base', 'bootstrapping'):
+        _pkg('openea.modules.' + sub, ROOT + '/modules/' + sub)
+    _pkg('openea.models', ROOT + '/models')
+    _pkg('openea.models.trans', ROOT + '/models/trans')
+    _pkg('openea.approaches', ROOT + '/approaches')
+    ref = types.SimpleNamespace(tf=tf_shim)
+    ref.MTransE = importlib.import_module('openea.approaches.mtranse').MTransE
+    ref.AlignE = importlib.import_module('openea.approaches.aligne').AlignE
+    ref.BootEA = importlib.import_module('openea.approaches.bootea').BootEA
+    ref.BootEA_TransH = importlib.import_module('openea.approaches.bootea_transh').BootEA_TransH
+    ref.BootEA_RotatE = importlib.import_module('openea.approaches.bootea_rotate').BootEA_RotatE
+    ref.TransE = importlib.import_module('openea.models.trans.transe').TransE
+    ref.TransH = importlib.import_module('openea.models.trans.transh').TransH
+    ref.TransD = importlib.import_module('openea.models.trans.transd').TransD
+    return ref
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def fd_gradients(tf, loss, feed, variables, eps=1e-6):
+    """central differences of the evaluated loss w.r.t. every element of every variable"""
+    grads = []
+    for v in variables:
+        base = v.data
+        g = np.zeros_like(base)
+        flat = g.reshape(-1)
+        for i in range(base.size):
+            hi, lo = base.copy().reshape(-1), base.copy().reshape(-1)
+            hi[i] += eps
+            lo[i] -= eps
+            up = tf.evaluate(loss, feed, {id(v): hi.reshape(base.shape)})
+            dn = tf.evaluate(loss, feed, {id(v): lo.reshape(base.shape)})
+            flat[i] = (up - dn) / (2 * eps)
+        grads.append(g)
+    return grads
+
+
+def main():
+    ref = import_reference()
+    tf = ref.tf
+    from openea_amd.run.default_args import get_args
+    rng = np.random.RandomState(11)
+    n_ent, n_rel, d = 14, 4, 5
+    kgs = types.SimpleNamespace(entities_num=n_ent, relations_num=n_rel)
+    pos = np.array([[0, 1, 2], [3, 1, 4], [0, 0, 6], [7, 2, 0], [8, 3, 9]], np.int64)
+    neg1 = np.array([[0, 1, 10], [11, 1, 4], [12, 0, 6], [7, 2, 5], [8, 3, 13]], np.int64)           # one per positive
+    neg2 = np.concatenate([neg1, np.array([[1, 1, 2], [3, 1, 12], [0, 0, 9], [13, 2, 0], [8, 3, 1]], np.int64)])
+    out = {'pos': pos, 'neg1': neg1, 'neg2': neg2}
+
+    def build(cls, name, **kw):
+        del tf.VARIABLES[:]
+        m = cls()
+        quiet(m.set_args, get_args(name, dim=d, output='/tmp/oea_golden/', training_data='synthetic/tiny/', dataset_division='f/', **kw))
+        m.set_kgs(kgs)
+        for fn in ('_define_variables', '_define_mapping_variables', '_define_embed_graph', '_define_alignment_graph',
+                   '_define_mapping_graph'):
+            if fn in ('_define_mapping_variables', '_define_mapping_graph') and name != 'MTransE':
+                continue
+            if hasattr(m, fn):
+                if name == 'BootEA_RotatE' and fn == '_define_variables':
+                    m.embedding_range = (m.args.gamma + m.epsilon) / m.args.dim
+                getattr(m, fn)()
+        variables = list(tf.VARIABLES)
+        for v in variables:                      # float32-representable values, moderately sized
+            v.data = (rng.standard_normal(v.data.shape) * 0.6).astype(np.float32).astype(np.float64)
+        return m, variables
+
+    def record(tag, m, variables, loss, feed):
+        value = float(tf.evaluate(loss, feed))
+        grads = fd_gradients(tf, loss, feed, variables)
+        out[tag + '_loss'] = np.array([value])
+        for v, g in zip(variables, grads):
+            out['%s_var_%s' % (tag, v.name)] = v.data.copy()
+            out['%s_grad_%s' % (tag, v.name)] = g
+        print('%-28s loss %.6f  variables %s' % (tag, value, [v.name for v in variables]))
+
+    def triple_feed(m, neg):
+        feed = {m.pos_hs: pos[:, 0], m.pos_rs: pos[:, 1], m.pos_ts: pos[:, 2]}
+        if neg is not None:
+            feed.update({m.neg_hs: neg[:, 0], m.neg_rs: neg[:, 1], m.neg_ts: neg[:, 2]})
+        return feed
+
+    # AlignE / BootEA: limited loss (+ BootEA's alignment loss), two negatives per positive
+    m, vs = build(ref.AlignE, 'AlignE')
+    record('aligne_triple', m, vs, m.triple_loss, triple_feed(m, neg2))
+    m, vs = build(ref.BootEA, 'BootEA')
+    record('bootea_triple', m, vs, m.triple_loss, triple_feed(m, neg2))
+    record('bootea_align', m, vs, m.alignment_loss, {m.new_h: pos[:, 0], m.new_r: pos[:, 1], m.new_t: pos[:, 2]})
+    # MTransE: positive loss + the mapping loss on three seed links
+    m, vs = build(ref.MTransE, 'MTransE', init='normal')      # ('unit' needs np.matrix support in sklearn; the values are replaced anyway)
+    record('mtranse_triple', m, vs, m.triple_loss, triple_feed(m, None))
+    record('mtranse_mapping', m, vs, m.mapping_loss, {m.seed_entities1: np.array([0, 3, 8]), m.seed_entities2: np.array([2, 4, 9])})
+    out['mtranse_alpha'] = np.array([float(m.args.alpha)])
+    # BootEA_TransH: limited loss on projected rows
+    m, vs = build(ref.BootEA_TransH, 'BootEA_TransH')
+    record('bootea_transh_triple', m, vs, m.triple_loss, triple_feed(m, neg2))
+    # model family: margin pairs
+    for cls, name in ((ref.TransE, 'TransE'), (ref.TransH, 'TransH'), (ref.TransD, 'TransD')):
+        m, vs = build(cls, name)
+        record(name.lower() + '_triple', m, vs, m.triple_loss, triple_feed(m, neg1))
+        out[name.lower() + '_margin'] = np.array([float(m.args.margin)])
+    # BootEA_RotatE (float64 variables): triple loss with two negatives per positive, alignment loss
+    m, vs = build(ref.BootEA_RotatE, 'BootEA_RotatE', gamma=3.0)
+    record('rotate_triple', m, vs, m.triple_loss, triple_feed(m, neg2))
+    record('rotate_align', m, vs, m.alignment_loss, {m.new_h: pos[:, 0], m.new_r: pos[:, 1], m.new_t: pos[:, 2]})
+    out['rotate_gamma'] = np.array([3.0])
+    out['rotate_phase_scale'] = np.array([m.pi / m.embedding_range])
+
+    np.savez_compressed(os.path.join(HERE, 'tf_graphs.npz'), **out)
+    print('wrote', os.path.join(HERE, 'tf_graphs.npz'))
+
+
+if __name__ == '__main__':
+    main()

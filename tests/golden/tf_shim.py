@@ -1,0 +1,212 @@
+"""A lazily evaluated numpy stand-in for the TensorFlow-1 surface that the reference's translational graph code touches
+(placeholders, variables, lookups, l2_normalize, the element-wise / reduction ops of modules/base/losses.py and of the
+approach classes' `_define_*_graph` methods).  TEST INFRASTRUCTURE for tests/golden/make_tf_graph_golden.py, which
+installs it as `tensorflow`, lets the REFERENCE's own code build its loss graphs and evaluates them in float64: the
+forward semantics then come from the reference's source, not from a restatement.  Gradients are NOT provided (optimisers
+are inert); the generator takes central finite differences of the evaluated loss instead.
+
+Op semantics supplied here (TF-1 documented behaviour): l2_normalize(x, axis) = x * rsqrt(max(sum(x^2, axis), 1e-12));
+embedding_lookup = row gather; reduce_sum(axis, keep_dims); norm(axis) = sqrt(sum(x^2)); everything else is numpy's.
+"""
+import contextlib
+import types
+
+import numpy as np
+
+float32, float64, int32, int64 = np.float32, np.float64, np.int32, np.int64
+
+
+class Node:
+    def __init__(self, fn, *inputs, name=None):
+        self.fn, self.inputs, self.name = fn, inputs, name
+
+    def value(self, env):
+        key = id(self)
+        if key not in env["cache"]:
+            env["cache"][key] = self.fn(*[_val(x, env) for x in self.inputs])
+        return env["cache"][key]
+
+    def eval(self, session=None, feed_dict=None):
+        return evaluate(self, feed_dict)
+
+    def __add__(self, o): return Node(np.add, self, o)
+    def __radd__(self, o): return Node(np.add, o, self)
+    def __sub__(self, o): return Node(np.subtract, self, o)
+    def __rsub__(self, o): return Node(np.subtract, o, self)
+    def __mul__(self, o): return Node(np.multiply, self, o)
+    def __rmul__(self, o): return Node(np.multiply, o, self)
+    def __truediv__(self, o): return Node(np.divide, self, o)
+    def __rtruediv__(self, o): return Node(np.divide, o, self)
+    def __neg__(self): return Node(np.negative, self)
+    def __pow__(self, o): return Node(np.power, self, o)
+    __array_priority__ = 1000
+    __array_ufunc__ = None          # numpy operands defer to the reflected methods above
+
+
+class Variable(Node):
+    def __init__(self, data, name=None, **_):
+        self.data, self.name = np.array(data, np.float64), name
+        VARIABLES.append(self)
+
+    def value(self, env):
+        return env["vars"].get(id(self), self.data)
+
+
+class Placeholder(Node):
+    def __init__(self, dtype=None, shape=None, name=None):
+        self.name = name
+
+    def value(self, env):
+        for k, v in env["feed"].items():
+            if k is self:
+                return np.asarray(v)
+        raise KeyError("placeholder not fed")
+
+
+VARIABLES = []
+_RNG = np.random.RandomState(20190719)
+
+
+def _val(x, env):
+    return x.value(env) if isinstance(x, Node) else x
+
+
+def evaluate(fetch, feed_dict=None, var_overrides=None):
+    env = {"feed": feed_dict or {}, "cache": {}, "vars": var_overrides or {}}
+    if isinstance(fetch, dict):
+        return {k: _val(v, env) for k, v in fetch.items()}
+    if isinstance(fetch, (list, tuple)):
+        return [_val(v, env) for v in fetch]
+    return _val(fetch, env)
+
+
+# ---- graph construction API -------------------------------------------------------------------------------------------
+def placeholder(dtype=None, shape=None, name=None):
+    return Placeholder(dtype, shape, name)
+
+
+def constant(value, dtype=None, name=None):
+    return np.asarray(value, np.float64) if not isinstance(value, (int, float)) else float(value)
+
+
+def get_variable(name, shape=None, dtype=None, initializer=None, **_):
+    return Variable(initializer(shape), name=name)
+
+
+def name_scope(*a, **k):
+    return contextlib.nullcontext()
+
+
+variable_scope = name_scope
+
+
+def global_variables_initializer():
+    return types.SimpleNamespace(run=lambda session=None: None)
+
+
+def _op(fn):
+    return lambda *a, name=None, **k: Node((lambda *v: fn(*v, **k)), *a)
+
+
+def _reduce_sum(x, axis=None, keep_dims=False, keepdims=False):
+    return np.sum(x, axis=axis, keepdims=bool(keep_dims or keepdims))
+
+
+def reduce_sum(x, axis=None, keep_dims=False, keepdims=False, name=None):
+    return Node(lambda v: _reduce_sum(v, axis, keep_dims, keepdims), x)
+
+
+def reduce_mean(x, axis=None, keep_dims=False, keepdims=False, name=None):
+    return Node(lambda v: np.mean(v, axis=axis, keepdims=bool(keep_dims or keepdims)), x)
+
+
+abs = _op(np.abs)                      # noqa: A001 (the names are TensorFlow's)
+square = _op(np.square)
+exp = _op(np.exp)
+log = _op(np.log)
+sin = _op(np.sin)
+cos = _op(np.cos)
+add = _op(np.add)
+multiply = _op(np.multiply)
+pow = _op(np.power)                    # noqa: A001
+sigmoid = _op(lambda x: 1.0 / (1.0 + np.exp(-x)))
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    return Node(lambda x, y: np.matmul(x.T if transpose_a else x, y.T if transpose_b else y), a, b)
+
+
+def reshape(x, shape, name=None):
+    return Node(lambda v: np.reshape(v, shape), x)
+
+
+def stack(values, axis=0, name=None):
+    return Node(lambda *v: np.stack(v, axis=axis), *values)
+
+
+def norm(x, ord="euclidean", axis=None, name=None, **_):
+    return Node(lambda v: np.sqrt(np.sum(v * v, axis=axis)), x)
+
+
+def _l2_normalize(x, axis=None, epsilon=1e-12, dim=None, name=None):
+    ax = axis if axis is not None else dim
+    return Node(lambda v: v / np.sqrt(np.maximum(np.sum(v * v, axis=ax, keepdims=True), epsilon)), x)
+
+
+nn = types.SimpleNamespace(
+    embedding_lookup=lambda params, ids, name=None: Node(lambda p, i: np.asarray(p)[np.asarray(i, np.int64)], params, ids),
+    l2_normalize=_l2_normalize,
+    relu=_op(lambda x: np.maximum(x, 0.0)),
+)
+
+
+def _truncated_normal(stddev=1.0, **_):
+    def init(shape):
+        v = _RNG.standard_normal(shape)
+        while True:
+            bad = np.abs(v) > 2.0
+            if not bad.any():
+                return v * stddev
+            v[bad] = _RNG.standard_normal(int(bad.sum()))
+    return init
+
+
+initializers = types.SimpleNamespace(
+    truncated_normal=_truncated_normal,
+    random_uniform=lambda minval=0, maxval=None, **_: (lambda shape: _RNG.uniform(minval, 1.0 if maxval is None else maxval, shape)),
+    orthogonal=lambda **_: (lambda shape: np.linalg.qr(_RNG.standard_normal(shape))[0]),
+)
+contrib = types.SimpleNamespace(layers=types.SimpleNamespace(
+    xavier_initializer=lambda uniform=False, **_: (lambda shape: _RNG.standard_normal(shape) * np.sqrt(2.0 / sum(shape)))))
+
+
+class _InertOptimizer:
+    """compute_gradients / apply_gradients of tf.train.*Optimizer: the golden generator differentiates numerically."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def compute_gradients(self, loss, var_list=None):
+        return []
+
+    def apply_gradients(self, grads_and_vars):
+        return Node(lambda: None)
+
+    def minimize(self, loss, **_):
+        return Node(lambda: None)
+
+
+train = types.SimpleNamespace(GradientDescentOptimizer=_InertOptimizer, AdagradOptimizer=_InertOptimizer,
+                              AdadeltaOptimizer=_InertOptimizer, AdamOptimizer=_InertOptimizer)
+
+
+class Session:
+    def __init__(self, *a, **k):
+        pass
+
+    def run(self, fetches=None, feed_dict=None):
+        return evaluate(fetches, feed_dict)
+
+
+def ConfigProto(*a, **k):
+    return types.SimpleNamespace(gpu_options=types.SimpleNamespace(allow_growth=False))

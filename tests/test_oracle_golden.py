@@ -405,3 +405,101 @@ def test_rotate_oracle_adam_moves_every_row():
     before = ent.copy()
     orc.rotate_step(ent, rel, np.array([[2, 1, 3]]), None, st, **kw)      # rows 0, 1 (and 4, 5) get no gradient now
     assert st["t"] == 2 and np.abs(ent[0] - before[0]).max() > 1e-4 and np.abs(ent[4] - before[4]).max() > 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's OWN graph code (losses.py, basic_model.py, the approach classes' _define_*_graph methods), executed
+# under tests/golden/tf_shim.py by tests/golden/make_tf_graph_golden.py: loss value + finite-difference gradients
+# w.r.t. every variable.  The oracle's step must reproduce both (its gradient read back from one SGD step).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tfg(golden_dir):
+    return np.load(os.path.join(golden_dir, "tf_graphs.npz"))
+
+
+def _sgd_grads(before, after, lr):
+    return [(b.astype(np.float64) - a.astype(np.float64)) / lr for b, a in zip(before, after)]
+
+
+def _check(tfg, tag, names, loss, grads, tol=5e-4):
+    ref_loss = float(tfg[tag + "_loss"][0])
+    assert abs(loss - ref_loss) <= 1e-6 * max(abs(ref_loss), 1.0), (tag, loss, ref_loss)
+    for name, g in zip(names, grads):
+        ref = tfg["%s_grad_%s" % (tag, name)]
+        assert np.abs(ref).max() > 1e-3
+        assert np.abs(g - ref).max() <= tol * max(np.abs(ref).max(), 1.0), (tag, name, np.abs(g - ref).max())
+
+
+@pytest.mark.parametrize("tag,kw,neg_key", [
+    ("aligne_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2"),
+    ("bootea_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2"),
+    ("bootea_align", dict(loss="align"), None),
+    ("mtranse_triple", dict(loss="positive"), None),
+    ("transe_triple", dict(loss="margin-based", margin=1.5), "neg1"),
+])
+def test_triple_step_oracle_equals_reference_graph(tfg, tag, kw, neg_key):
+    """basic_model.py:80-98 / aligne.py:47-66 / bootea.py:190-199 / mtranse.py:46-57 / models/trans/transe.py:31-49."""
+    ent = tfg[tag + "_var_ent_embeds"].astype(np.float32)
+    rel = tfg[tag + "_var_rel_embeds"].astype(np.float32)
+    e1, r1 = ent.copy(), rel.copy()
+    lr = 1e-3
+    loss = cport.triple_step(e1, None, r1, None, tfg["pos"], tfg[neg_key] if neg_key else None, loss_norm="L2",
+                             ent_l2_norm=True, rel_l2_norm=True, optimizer="SGD", lr=lr, **kw)
+    _check(tfg, tag, ["ent_embeds", "rel_embeds"], loss, _sgd_grads([ent, rel], [e1, r1], lr))
+
+
+@pytest.mark.parametrize("tag,kw,neg_key", [
+    ("bootea_transh_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2"),
+    ("transh_triple", dict(loss="margin-based", margin=1.5), "neg1"),
+])
+def test_transh_step_oracle_equals_reference_graph(tfg, tag, kw, neg_key):
+    """bootea_transh.py:58-96 and models/trans/transh.py:16-51 (normal vectors normalised at creation and in _calc)."""
+    tabs = [tfg["%s_var_%s" % (tag, n)].astype(np.float32) for n in ("ent_embeds", "rel_embeds", "normal_vector")]
+    new = [t.copy() for t in tabs]
+    lr = 1e-3
+    loss = cport.triple_step_transh(new[0], None, new[1], None, new[2], None, tfg["pos"], tfg[neg_key], loss_norm="L2",
+                                    ent_l2_norm=True, rel_l2_norm=True, optimizer="SGD", lr=lr, **kw)
+    _check(tfg, tag, ["ent_embeds", "rel_embeds", "normal_vector"], loss, _sgd_grads(tabs, new, lr))
+
+
+def test_transd_step_oracle_equals_reference_graph(tfg):
+    """models/trans/transd.py:16-57: four variables; the oracle (like the device step) takes them stacked."""
+    tag = "transd_triple"
+    v = {n: tfg["%s_var_%s" % (tag, n)].astype(np.float32) for n in ("ent_embeds", "rel_embeds", "ent_transfer", "rel_transfer")}
+    ent = np.concatenate([v["ent_embeds"], v["ent_transfer"]])
+    rel = np.concatenate([v["rel_embeds"], v["rel_transfer"]])
+    e1, r1 = ent.copy(), rel.copy()
+    lr = 1e-3
+    loss = cport.triple_step_transd(e1, None, r1, None, tfg["pos"], tfg["neg1"], loss="margin-based", margin=1.5, loss_norm="L2",
+                                    ent_l2_norm=True, rel_l2_norm=True, optimizer="SGD", lr=lr)
+    ge, gr = _sgd_grads([ent, rel], [e1, r1], lr)
+    E, R = len(v["ent_embeds"]), len(v["rel_embeds"])
+    _check(tfg, tag, ["ent_embeds", "ent_transfer", "rel_embeds", "rel_transfer"], loss, [ge[:E], ge[E:], gr[:R], gr[R:]])
+
+
+def test_mapping_step_oracle_equals_reference_graph(tfg):
+    """modules/base/mapping.py:9-19 + losses.py:76-80 (alpha * (map loss + orthogonality loss))."""
+    tag = "mtranse_mapping"
+    ent = tfg[tag + "_var_ent_embeds"].astype(np.float32)
+    M = tfg[tag + "_var_mapping_matrix"].astype(np.float32)
+    e1, m1 = ent.copy(), M.copy()
+    big = 1e12                                   # Adagrad with a huge accumulator = a plain gradient step of lr / 1e6
+    loss = orc.mapping_step(e1, m1, np.full_like(ent, big), np.full_like(M, big), np.array([[0, 2], [3, 4], [8, 9]]),
+                            alpha=float(tfg["mtranse_alpha"][0]), lr=1e3, ent_l2_norm=True)
+    _check(tfg, tag, ["ent_embeds", "mapping_matrix"], loss, _sgd_grads([ent, M], [e1, m1], 1e-3), tol=2e-3)
+
+
+@pytest.mark.parametrize("tag,neg_key", [("rotate_triple", "neg2"), ("rotate_align", None)])
+def test_rotate_oracle_equals_reference_graph(tfg, tag, neg_key):
+    """bootea_rotate.py:59-109 (lookup_all, _generate_scores, _generate_loss) and :148-158, in float64."""
+    ent = np.concatenate([tfg[tag + "_var_re_ent_embeds"], tfg[tag + "_var_im_ent_embeds"]])
+    rel = tfg[tag + "_var_rel_embeds"].copy()
+    kw = dict(gamma=float(tfg["rotate_gamma"][0]), phase_scale=float(tfg["rotate_phase_scale"][0]), ent_l2_norm=True, rel_l2_norm=False)
+    neg = tfg[neg_key] if neg_key else None
+    assert abs(orc.rotate_loss(ent, rel, tfg["pos"], neg, **kw) - float(tfg[tag + "_loss"][0])) < 1e-10
+    e1, r1 = ent.copy(), rel.copy()
+    lr = 1e-6
+    loss = orc.rotate_step(e1, r1, tfg["pos"], neg, {}, optimizer="SGD", lr=lr, **kw)
+    ge, gr = _sgd_grads([ent, rel], [e1, r1], lr)
+    E = len(ent) // 2
+    _check(tfg, tag, ["re_ent_embeds", "im_ent_embeds", "rel_embeds"], loss, [ge[:E], ge[E:], gr], tol=1e-5)
