@@ -370,26 +370,31 @@ def align_loss_and_grad(out, ILL, gamma, k, neg_left, neg_right, neg2_left, neg2
     return loss * scale, g * scale
 
 
-def gcn_se_epoch(W, coords, values, ILL, gamma, k, negs, lr):
-    """One full-batch SGD epoch of the GCN-Align structure model (gcn_align.py:498-539,
-    204-267, 737-785): T = l2_normalize(W) (trunc_normal returns the normalised tensor,
-    gcn_align.py:52-56); H1 = relu(A T); out = A H1; loss = align_loss; W -= lr * dW.
-    fp64 internals; returns (loss, out_before_update fp32)."""
-    n = W.shape[0]
+def gcn_se_epoch(W, coords, values, ILL, gamma, k, negs, lr, features=None):
+    """One full-batch SGD epoch of a GCN-Align unit (gcn_align.py:498-539, 204-267, 737-785): T = l2_normalize(W)
+    (trunc_normal returns the normalised tensor, gcn_align.py:52-56); structure unit (featureless): H1 = relu(A T);
+    attribute unit (features = scipy sparse X [n, f], W [f, d]): H1 = relu(A (X T)); out = A H1; loss = align_loss;
+    W -= lr * dW.  fp64 internals; returns (loss, out_before_update fp32).  The forward pass and the gradient are pinned
+    by the reference's own GCN_Align_Unit code run under tests/golden/tf_shim.py (tests/golden/tf_graphs.npz)."""
     Wd = W.astype(np.float64)
     ss = np.maximum((Wd ** 2).sum(1, keepdims=True), 1e-12)
     inv = 1.0 / np.sqrt(ss)
     T = Wd * inv
     import scipy.sparse as sp
+    n = int(max(coords[:, 0].max(), coords[:, 1].max())) + 1 if features is None else features.shape[0]
+    n = W.shape[0] if features is None else n
     A = sp.csr_matrix((np.asarray(values, np.float32).astype(np.float64),
                        (coords[:, 0], coords[:, 1])), shape=(n, n))
-    pre1 = A @ T
+    X = None if features is None else sp.csr_matrix(features, dtype=np.float64)
+    x = T if X is None else X @ T
+    pre1 = A @ x
     H1 = np.maximum(pre1, 0.0)
     out = A @ H1
     loss, g_out = align_loss_and_grad(out, ILL, gamma, k, *negs)
     g_H1 = A.T @ g_out
     g_pre1 = g_H1 * (pre1 > 0)
-    g_T = A.T @ g_pre1
+    g_x = A.T @ g_pre1
+    g_T = g_x if X is None else X.T @ g_x
     g_W = (g_T - T * (T * g_T).sum(1, keepdims=True)) * inv
     W[...] = (Wd - lr * g_W).astype(np.float32)
     return float(loss), out.astype(np.float32)

@@ -4,7 +4,7 @@ TensorFlow 1.x cannot be installed here, so `tensorflow` is replaced by tests/go
 stand-in for the few dozen ops these files use) and the reference's classes build their graphs with it:
 `_define_variables`, `_define_embed_graph`, `_define_alignment_graph`, `_define_mapping_graph` of
 models/basic_model.py, approaches/{mtranse,aligne,bootea,bootea_transh,bootea_rotate}.py and models/trans/{transe,transh,
-transd}.py run UNMODIFIED (with modules/base/{losses,initializers,optimizers,mapping}.py underneath).  For one fixed batch
+transd}.py -- and `GCN_Align_Unit` of approaches/gcn_align.py (structure and attribute units) -- run UNMODIFIED (with modules/base/{losses,initializers,optimizers,mapping}.py underneath).  For one fixed batch
 per model the loss node is evaluated in float64 at float32-representable variable values, and its gradient w.r.t. every
 variable is taken by central finite differences.  What the shim contributes is the meaning of the individual ops
 (l2_normalize, embedding_lookup, reduce_sum, ...); the composition -- which rows are looked up, normalised how often,
@@ -164,6 +164,39 @@ def main():
     record('rotate_align', m, vs, m.alignment_loss, {m.new_h: pos[:, 0], m.new_r: pos[:, 1], m.new_t: pos[:, 2]})
     out['rotate_gamma'] = np.array([3.0])
     out['rotate_phase_scale'] = np.array([m.pi / m.embedding_range])
+
+    # ---- GCN-Align units (gcn_align.py:27-56 inits, 204-267 GraphConvolution, 298-320 align_loss, 498-539) ----------
+    import scipy.sparse as sp
+    sys.modules['scipy.sparse.linalg.eigen'] = Stub('scipy.sparse.linalg.eigen')
+    sys.modules['scipy.sparse.linalg.eigen.arpack'] = Stub('scipy.sparse.linalg.eigen.arpack')
+    gcn = importlib.import_module('openea.approaches.gcn_align')
+    n, f, dg, t, k = 26, 9, 4, 6, 3
+    a = sp.random(n, n, density=0.15, random_state=3, format='coo')
+    a = (a + a.T + sp.eye(n)).tocoo()
+    support = (np.stack([a.row, a.col], 1), a.data.astype(np.float32).astype(np.float64), a.shape)
+    feats = sp.random(n, f, density=0.3, random_state=4, format='coo')
+    feats = (np.stack([feats.row, feats.col], 1), np.ones(feats.nnz), feats.shape)
+    ill = np.stack([rng.permutation(n)[:t], rng.permutation(n)[:t]], 1)
+    negs = {name: rng.randint(0, n, t * k) for name in ('neg_left', 'neg_right', 'neg2_left', 'neg2_right')}
+    gargs = types.SimpleNamespace(learning_rate=1.0, gamma=3.0, neg_triple_num=k)
+    out.update({'gcn_support_coords': support[0], 'gcn_support_values': support[1], 'gcn_feat_coords': feats[0], 'gcn_ill': ill,
+                **{'gcn_' + kk: v for kk, v in negs.items()}})
+    for tag, sparse_inputs in (('gcn_se', False), ('gcn_ae', True)):
+        del tf.VARIABLES[:]
+        tf.PLACEHOLDERS.clear()
+        ph = {'support': [tf.sparse_placeholder(tf.float32)],
+              'features': tf.sparse_placeholder(tf.float32) if sparse_inputs else tf.placeholder(tf.float32),
+              'dropout': tf.placeholder_with_default(0., shape=()), 'num_features_nonzero': tf.placeholder_with_default(0, shape=())}
+        unit = quiet(gcn.GCN_Align_Unit, gargs, ph, input_dim=f if sparse_inputs else n, output_dim=dg, ILL=ill,
+                     sparse_inputs=sparse_inputs, featureless=not sparse_inputs, logging=False)
+        variables = list(tf.VARIABLES)
+        assert len(variables) == 1                       # the first layer's weight; the second layer has none
+        variables[0].name = 'weights'
+        variables[0].data = (rng.standard_normal(variables[0].data.shape) * 0.5).astype(np.float32).astype(np.float64)
+        feed = {ph['support'][0]: support, ph['features']: feats if sparse_inputs else 1.0}
+        feed.update({kk + ':0': v for kk, v in negs.items()})
+        out[tag + '_outputs'] = tf.evaluate(unit.outputs, feed)
+        record(tag, unit, variables, unit.loss, feed)
 
     np.savez_compressed(os.path.join(HERE, 'tf_graphs.npz'), **out)
     print('wrote', os.path.join(HERE, 'tf_graphs.npz'))

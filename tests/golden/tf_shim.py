@@ -53,17 +53,22 @@ class Variable(Node):
 
 
 class Placeholder(Node):
-    def __init__(self, dtype=None, shape=None, name=None):
-        self.name = name
+    def __init__(self, dtype=None, shape=None, name=None, default=None):
+        self.name, self.default = name, default
+        if name:
+            PLACEHOLDERS[name] = self
 
     def value(self, env):
         for k, v in env["feed"].items():
-            if k is self:
-                return np.asarray(v)
-        raise KeyError("placeholder not fed")
+            if k is self or (isinstance(k, str) and self.name and k == self.name + ":0"):
+                return v if isinstance(v, tuple) else np.asarray(v)
+        if self.default is not None:
+            return self.default
+        raise KeyError("placeholder %r not fed" % (self.name,))
 
 
 VARIABLES = []
+PLACEHOLDERS = {}
 _RNG = np.random.RandomState(20190719)
 
 
@@ -83,6 +88,62 @@ def evaluate(fetch, feed_dict=None, var_overrides=None):
 # ---- graph construction API -------------------------------------------------------------------------------------------
 def placeholder(dtype=None, shape=None, name=None):
     return Placeholder(dtype, shape, name)
+
+
+def sparse_placeholder(dtype=None, shape=None, name=None):
+    """fed with the (coords [nnz, 2], values [nnz], dense_shape) tuples of sparse_to_tuple"""
+    return Placeholder(dtype, shape, name)
+
+
+def placeholder_with_default(input, shape=None, name=None):      # noqa: A002
+    return Placeholder(None, shape, name, default=input)
+
+
+class _Graph:
+    def get_tensor_by_name(self, name):
+        return PLACEHOLDERS[name.split(":")[0]]                    # KeyError -> the caller creates the placeholder
+
+
+def get_default_graph():
+    return _Graph()
+
+
+GraphKeys = types.SimpleNamespace(GLOBAL_VARIABLES="variables")
+
+
+def get_collection(key, scope=None):
+    return list(VARIABLES)
+
+
+def truncated_normal(shape, mean=0.0, stddev=1.0, dtype=None, seed=None, name=None):
+    return _truncated_normal(stddev)(shape) + mean
+
+
+def random_uniform(shape, minval=0.0, maxval=1.0, dtype=None, seed=None, name=None):
+    return _RNG.uniform(minval, maxval, shape)
+
+
+def zeros(shape, dtype=None, name=None):
+    return np.zeros(shape)
+
+
+def ones(shape, dtype=None, name=None):
+    return np.ones(shape)
+
+
+def add_n(inputs, name=None):
+    return Node(lambda *v: sum(v[1:], v[0]), *inputs)
+
+
+def _spmm(a, x):
+    import scipy.sparse as sp
+    coords, values, shape = a
+    coords = np.asarray(coords, np.int64)
+    return sp.csr_matrix((np.asarray(values, np.float64), (coords[:, 0], coords[:, 1])), shape=tuple(shape)) @ x
+
+
+def sparse_tensor_dense_matmul(sp_a, b, name=None):
+    return Node(_spmm, sp_a, b)
 
 
 def constant(value, dtype=None, name=None):

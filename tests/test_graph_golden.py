@@ -187,3 +187,37 @@ def test_rdgcn_hard_negatives_on_device(g):
     layer = ops.to_table(g["rdgcn_neg_layer"])
     got = get_neg(ops.to_ids(g["rdgcn_neg_ill"].astype(np.int32)), layer, 24, 9).cpu().numpy().reshape(40, 9)
     assert np.array_equal(np.sort(got, axis=1), np.sort(g["rdgcn_neg"], axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["gcn_se", "gcn_ae"])
+def test_gcn_units_on_device_equal_reference_graph(tag):
+    """The device GCN_Align_Unit (structure and attribute unit) on the inputs of tests/golden/tf_graphs.npz: outputs, loss
+    and the weight after one SGD epoch equal what the reference's own GCN_Align_Unit graph gives (its loss and its
+    finite-difference gradient, gcn_align.py:498-539 under tests/golden/tf_shim.py)."""
+    pytest.importorskip("torch")
+    import scipy.sparse as sp
+    from openea_amd import ops
+    from openea_amd.approaches.gcn_align import DeviceCSR, GCN_Align_Unit
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    W = t[tag + "_var_weights"].astype(np.float32)
+    coords, values = t["gcn_support_coords"], t["gcn_support_values"]
+    n, d = int(coords.max()) + 1, W.shape[1]
+    dev = ops.device()
+    adj = DeviceCSR(sp.csr_matrix((values, (coords[:, 0], coords[:, 1])), shape=(n, n)), dev)
+    feats = None
+    if tag == "gcn_ae":
+        fc = t["gcn_feat_coords"]
+        feats = DeviceCSR(sp.csr_matrix((np.ones(len(fc)), (fc[:, 0], fc[:, 1])), shape=(n, W.shape[0])), dev)
+    lr = 1e-2
+    unit = GCN_Align_Unit(types.SimpleNamespace(neg_triple_num=3, gamma=3.0, learning_rate=lr), adj, W.shape[0], d, t["gcn_ill"],
+                          features=feats)
+    unit.W[:, :d] = ops.to_table(W)[:, :d]
+    negs = tuple(ops.to_ids(t["gcn_" + k].astype(np.int32)) for k in ("neg_left", "neg_right", "neg2_left", "neg2_right"))
+    unit.train_step(negs)
+    np.testing.assert_allclose(unit.outputs[:, :d].cpu().numpy(), t[tag + "_outputs"], rtol=1e-5, atol=1e-5)
+    ref_loss = float(t[tag + "_loss"][0])
+    assert abs(unit.pop_loss() - ref_loss) <= 1e-5 * ref_loss
+    grad = (W.astype(np.float64) - unit.W[:, :d].cpu().numpy().astype(np.float64)) / lr
+    ref = t[tag + "_grad_weights"]
+    assert np.abs(grad - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1.0)

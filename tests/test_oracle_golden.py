@@ -503,3 +503,23 @@ def test_rotate_oracle_equals_reference_graph(tfg, tag, neg_key):
     ge, gr = _sgd_grads([ent, rel], [e1, r1], lr)
     E = len(ent) // 2
     _check(tfg, tag, ["re_ent_embeds", "im_ent_embeds", "rel_embeds"], loss, [ge[:E], ge[E:], gr], tol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["gcn_se", "gcn_ae"])
+def test_gcn_unit_oracle_equals_reference_graph(tfg, tag):
+    """gcn_align.py:498-539 (GCN_Align_Unit: two GraphConvolution layers + align_loss), structure and attribute units,
+    built by the reference's own code under the numpy TensorFlow stand-in."""
+    import scipy.sparse as sp
+    W = tfg[tag + "_var_weights"].astype(np.float32)
+    coords, values = tfg["gcn_support_coords"], tfg["gcn_support_values"]
+    n = int(coords.max()) + 1
+    feats = None
+    if tag == "gcn_ae":
+        fc = tfg["gcn_feat_coords"]
+        feats = sp.csr_matrix((np.ones(len(fc)), (fc[:, 0], fc[:, 1])), shape=(n, W.shape[0]))
+    negs = [tfg["gcn_" + k] for k in ("neg_left", "neg_right", "neg2_left", "neg2_right")]
+    w1 = W.copy()
+    lr = 1e-3
+    loss, out = orc.gcn_se_epoch(w1, coords, values, tfg["gcn_ill"], 3.0, 3, negs, lr, features=feats)
+    np.testing.assert_allclose(out, tfg[tag + "_outputs"], rtol=1e-5, atol=1e-6)
+    _check(tfg, tag, ["weights"], loss, _sgd_grads([W], [w1], lr))
