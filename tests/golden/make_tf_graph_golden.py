@@ -198,6 +198,31 @@ def main():
         out[tag + '_outputs'] = tf.evaluate(unit.outputs, feed)
         record(tag, unit, variables, unit.loss, feed)
 
+    # ---- RDGCN (rdgcn.py:162-338): dual / primal attention interaction, diagonal GCN layers, highway gates, L1 hinge --
+    rd_mod = importlib.import_module('openea.approaches.rdgcn')
+    n, nr, dr, t, k = 36, 5, 4, 7, 3
+    tri1 = sorted({(int(rng.randint(0, n // 2)) * 2, int(rng.randint(0, 3)), int(rng.randint(0, n // 2)) * 2) for _ in range(60)})
+    tri2 = sorted({(int(rng.randint(0, n // 2)) * 2 + 1, int(rng.randint(2, nr)), int(rng.randint(0, n // 2)) * 2 + 1) for _ in range(55)})
+    links = np.stack([rng.permutation(n // 2)[:t] * 2, rng.permutation(n // 2)[:t] * 2 + 1], 1)
+    rkgs = types.SimpleNamespace(train_links=[tuple(int(x) for x in p_) for p_ in links], entities_num=n, relations_num=nr,
+                                 kg1=types.SimpleNamespace(relation_triples_list=tri1),
+                                 kg2=types.SimpleNamespace(relation_triples_list=tri2))
+    rargs = types.SimpleNamespace(dim=dr, dropout=0.0, gamma=1.0, neg_triple_num=k, alpha=0.1, beta=0.3)
+    emb = (rng.standard_normal((n, dr)) * 0.7).astype(np.float32)
+    del tf.VARIABLES[:]
+    layer = rd_mod.Layer(rargs, rkgs, emb)
+    output_layer, rloss = quiet(layer.build)
+    variables = list(tf.VARIABLES)
+    for i, v in enumerate(variables):
+        v.name = 'v%02d' % i
+        if i > 0:                                    # v00 is the pretrained input; diag / bias variables get values too
+            v.data = (rng.standard_normal(v.data.shape) * 0.5).astype(np.float32).astype(np.float64)
+    rnegs = {name: rng.randint(0, n, t * k) for name in ('neg_left', 'neg_right', 'neg2_left', 'neg2_right')}
+    feed = {kk + ':0': v for kk, v in rnegs.items()}
+    out.update({'rdgcn_tri1': np.array(tri1), 'rdgcn_tri2': np.array(tri2), 'rdgcn_links': links, 'rdgcn_outputs': tf.evaluate(output_layer, feed),
+                'rdgcn_n_vars': np.array([len(variables)]), **{'rdgcn_' + kk: v for kk, v in rnegs.items()}})
+    record('rdgcn', layer, variables, rloss, feed)
+
     np.savez_compressed(os.path.join(HERE, 'tf_graphs.npz'), **out)
     print('wrote', os.path.join(HERE, 'tf_graphs.npz'))
 

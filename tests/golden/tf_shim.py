@@ -142,8 +142,74 @@ def _spmm(a, x):
     return sp.csr_matrix((np.asarray(values, np.float64), (coords[:, 0], coords[:, 1])), shape=tuple(shape)) @ x
 
 
+class SparseTensor:
+    """indices [nnz, 2] (host), values (host array or Node), dense_shape"""
+
+    def __init__(self, indices, values, dense_shape):
+        self.indices, self.values, self.dense_shape = np.asarray(indices, np.int64).reshape(-1, 2), values, tuple(dense_shape)
+
+
 def sparse_tensor_dense_matmul(sp_a, b, name=None):
+    if isinstance(sp_a, SparseTensor):
+        return Node(lambda vals, x: _spmm((sp_a.indices, vals, sp_a.dense_shape), x), sp_a.values, b)
     return Node(_spmm, sp_a, b)
+
+
+def _run_softmax(rows, vals):
+    """tf.sparse_softmax on a 2-D SparseTensor: softmax over each RUN of consecutive entries with the same row index (for
+    a canonically ordered tensor: over each row)."""
+    out = np.empty_like(vals, dtype=np.float64)
+    start = 0
+    for i in range(1, len(rows) + 1):
+        if i == len(rows) or rows[i] != rows[start]:
+            seg = vals[start:i] - vals[start:i].max()
+            e = np.exp(seg)
+            out[start:i] = e / e.sum()
+            start = i
+    return out
+
+
+def sparse_softmax(sp_input, name=None):
+    rows = sp_input.indices[:, 0]
+    return SparseTensor(sp_input.indices, Node(lambda v: _run_softmax(rows, np.asarray(v, np.float64)), sp_input.values),
+                        sp_input.dense_shape)
+
+
+def expand_dims(x, axis=None, name=None, dim=None):
+    return Node(lambda v: np.expand_dims(v, axis if axis is not None else dim), x)
+
+
+def transpose(x, perm=None, name=None):
+    return Node(lambda v: np.transpose(v, perm), x)
+
+
+def concat(values, axis, name=None):
+    return Node(lambda *v: np.concatenate(v, axis=axis), *values)
+
+
+def cast(x, dtype=None, name=None):
+    return Node(lambda v: np.asarray(v, np.float64), x) if isinstance(x, Node) else np.asarray(x, np.float64)
+
+
+def reset_default_graph():
+    PLACEHOLDERS.clear()
+
+
+def _conv1d(inputs, filters, kernel_size, use_bias=True, **_):
+    """tf.layers.conv1d with kernel size 1 = a dense layer over the last axis: glorot-uniform kernel [1, C, F], zero bias.
+    The channel count comes from evaluating the (placeholder-free) input once."""
+    assert kernel_size == 1
+    c_in = np.shape(evaluate(inputs))[-1]
+    lim = np.sqrt(6.0 / (c_in + filters))
+    kernel = Variable(_RNG.uniform(-lim, lim, (1, c_in, filters)), name="conv1d_kernel_%d" % len(VARIABLES))
+    out = Node(lambda x, k: np.matmul(x, k[0]), inputs, kernel)
+    if use_bias:
+        bias = Variable(np.zeros(filters), name="conv1d_bias_%d" % len(VARIABLES))
+        out = out + bias
+    return out
+
+
+layers = types.SimpleNamespace(conv1d=_conv1d)
 
 
 def constant(value, dtype=None, name=None):
@@ -214,11 +280,26 @@ def _l2_normalize(x, axis=None, epsilon=1e-12, dim=None, name=None):
     return Node(lambda v: v / np.sqrt(np.maximum(np.sum(v * v, axis=ax, keepdims=True), epsilon)), x)
 
 
+def _softmax(x, axis=-1):
+    e = np.exp(x - np.max(x, axis=axis, keepdims=True))
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def _dropout(x, keep_prob=None, **_):
+    assert keep_prob in (None, 1, 1.0), "the golden graphs are built with dropout off"
+    return x
+
+
 nn = types.SimpleNamespace(
     embedding_lookup=lambda params, ids, name=None: Node(lambda p, i: np.asarray(p)[np.asarray(i, np.int64)], params, ids),
     l2_normalize=_l2_normalize,
     relu=_op(lambda x: np.maximum(x, 0.0)),
+    leaky_relu=lambda x, alpha=0.2, name=None: Node(lambda v: np.where(v > 0, v, alpha * v), x),
+    softmax=lambda x, axis=-1, name=None: Node(lambda v: _softmax(v, axis), x),
+    sigmoid=_op(lambda x: 1.0 / (1.0 + np.exp(-x))),
+    dropout=_dropout,
 )
+keras = types.SimpleNamespace(activations=types.SimpleNamespace(get=lambda name: {"relu": nn.relu, "tanh": _op(np.tanh)}[name]))
 
 
 def _truncated_normal(stddev=1.0, **_):

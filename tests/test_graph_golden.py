@@ -221,3 +221,45 @@ def test_gcn_units_on_device_equal_reference_graph(tag):
     grad = (W.astype(np.float64) - unit.W[:, :d].cpu().numpy().astype(np.float64)) / lr
     ref = t[tag + "_grad_weights"]
     assert np.abs(grad - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1.0)
+
+
+@pytest.mark.gpu
+def test_rdgcn_layer_on_device_equals_reference_graph():
+    """rdgcn.py:162-338 (Layer.build: relation features -> dual self / dual attention -> primal sparse attention, twice;
+    two diagonal GCN layers with highway gates; L1 hinge) built by the reference's own code under tests/golden/tf_shim.py:
+    with the 22 variables copied over in creation order, our Layer gives the same output layer, the same loss and
+    (autograd) the reference graph's finite-difference gradients."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    from openea_amd.approaches import rdgcn
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    tri1 = [tuple(int(x) for x in r) for r in t["rdgcn_tri1"]]
+    tri2 = [tuple(int(x) for x in r) for r in t["rdgcn_tri2"]]
+    n, nr, d, k = 36, 5, 4, 3
+    kgs = types.SimpleNamespace(train_links=[tuple(int(x) for x in p) for p in t["rdgcn_links"]], entities_num=n, relations_num=nr,
+                                kg1=types.SimpleNamespace(relation_triples_list=tri1), kg2=types.SimpleNamespace(relation_triples_list=tri2))
+    args = types.SimpleNamespace(dim=d, dropout=0.0, gamma=1.0, neg_triple_num=k, alpha=0.1, beta=0.3)
+    dev = ops.device()
+    layer = rdgcn.Layer(args, kgs, t["rdgcn_var_v00"].astype(np.float32), dev)
+    params = layer.params()
+    assert len(params) == int(t["rdgcn_n_vars"][0]) == 22
+    with torch.no_grad():
+        for i, p in enumerate(params):
+            v = t["rdgcn_var_v%02d" % i]
+            v = v[0] if v.ndim == 3 else v                       # conv1d kernels are [1, C, F]
+            p.copy_(torch.from_numpy(v.astype(np.float32)).reshape(p.shape).to(dev))
+    out = layer.forward()
+    np.testing.assert_allclose(out.detach().cpu().numpy()[:, :d], t["rdgcn_outputs"], rtol=1e-4, atol=1e-5)
+    negs = tuple(ops.to_ids(t["rdgcn_" + kk].astype(np.int32)) for kk in ("neg_left", "neg_right", "neg2_left", "neg2_right"))
+    loss = layer.loss(out, negs)
+    ref_loss = float(t["rdgcn_loss"][0])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * ref_loss
+    loss.backward()
+    checked = 0
+    for i, p in enumerate(params):
+        ref = t["rdgcn_grad_v%02d" % i]
+        ref = ref[0] if ref.ndim == 3 else ref
+        got = p.grad.detach().cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), i
+        checked += 1
+    assert checked == 22
