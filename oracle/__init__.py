@@ -22,9 +22,12 @@ Pinning (details in DESIGN.md, section "Oracle"):
   (l2_normalize = x * rsqrt(max(sum x^2, 1e-12)), gather gradients summed per row, relu'(0) = 0) and the optimisers'
   arithmetic (Adagrad accumulator 0.1 and no epsilon, TF-Adam's epsilon-hat and its dense updates), as written down in
   DESIGN.md (H1/H3/H4).
-* TensorFlow-1 half, GNN graphs (sparse_tensor_dense_matmul, sparse_softmax, BatchNormalization, Adam) -- PARITY
-  UNPINNED: restatements of the cited lines; every hand-derived gradient (GCN-Align epoch, sparse attention, and the
-  translational steps above) is additionally checked against finite differences of a loss written independently.
+* TensorFlow-1 half, GNN graphs -- FORWARD GRAPHS PINNED the same way: ``GCN_Align_Unit`` (structure and attribute unit),
+  RDGCN's ``Layer.build()`` and AliNet's ``_generate_rel_graph`` are built by the reference's own code under the
+  stand-in; ``gcn_se_epoch`` here, and on the GPU the device models themselves, reproduce outputs, loss and every
+  variable's finite-difference gradient (``tests/test_graph_golden.py``).  Assumptions that remain: the single ops
+  (``sparse_tensor_dense_matmul``, ``sparse_softmax`` grouping runs of equal rows, keras ``BatchNormalization`` in
+  inference mode with epsilon 1e-3, ``conv1d`` with kernel size 1 = a dense layer) and Adam's arithmetic.
 * Random draws (negative triples, negative links): the reference uses python ``random``; the
   restatements here define the Philox / keyed-permutation formulation the device kernels
   reproduce bit for bit, and the tests check the reference's invariants on them

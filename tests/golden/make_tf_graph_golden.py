@@ -223,6 +223,39 @@ def main():
                 'rdgcn_n_vars': np.array([len(variables)]), **{'rdgcn_' + kk: v for kk, v in rnegs.items()}})
     record('rdgcn', layer, variables, rloss, feed)
 
+    # ---- AliNet (alinet.py:539-677 layers, 784-866 model + losses, 868-882 graphs) ------------------------------------
+    al_mod = importlib.import_module('openea.approaches.alinet')
+    n, dims, win = 30, [8, 8, 4], 3       # multiples of 4: the device aggregates take 16-byte aligned rows
+
+    def sym_adj(seed, density):
+        a = sp.random(n, n, density=density, random_state=seed, format='coo')
+        a = ((a + a.T) > 0).astype(np.float64)
+        return al_mod.preprocess_adj(sp.coo_matrix(a))          # the reference's own normalisation -> (coords, values, shape)
+    one_adj, two_adj = sym_adj(7, 0.12), sym_adj(8, 0.2)
+    del tf.VARIABLES[:]
+    tf.PLACEHOLDERS.clear()
+    am = al_mod.AliNet()
+    am.args = types.SimpleNamespace(layer_dims=dims, num_features_nonzero=0, dropout=0.0, neg_margin=1.5, neg_margin_balance=0.1,
+                                    rel_param=0.01, learning_rate=0.001)
+    am.kgs = types.SimpleNamespace(entities_num=n)
+    am.adj = [one_adj, two_adj]
+    am.rel_win_size = win
+    am._get_variable()
+    quiet(am._generate_rel_graph)                   # pos/neg link loss + relation loss on one model instance (:875-882)
+    variables = list(tf.VARIABLES)
+    for v in variables:
+        v.data = (v.data + rng.standard_normal(v.data.shape) * 0.3).astype(np.float32).astype(np.float64)
+    pos_links = np.stack([rng.randint(0, n, 8), rng.randint(0, n, 8), np.zeros(8, np.int64)], 1)
+    neg_links = np.stack([rng.randint(0, n, 20), rng.randint(0, n, 20)], 1)
+    hs, ts = rng.randint(0, n, 4 * win), rng.randint(0, n, 4 * win)
+    feed = {am.rel_pos_links: pos_links, am.rel_neg_links: neg_links, am.hs: hs, am.ts: ts}
+    out.update({'alinet_one_coords': one_adj[0], 'alinet_one_values': one_adj[1], 'alinet_two_coords': two_adj[0],
+                'alinet_two_values': two_adj[1], 'alinet_pos': pos_links, 'alinet_neg': neg_links, 'alinet_hs': hs, 'alinet_ts': ts,
+                'alinet_var_names': np.array([v.name for v in variables])})
+    for i, o in enumerate(am.output_embeds_list):
+        out['alinet_out%d' % i] = tf.evaluate(o, feed)
+    record('alinet', am, variables, am.loss, feed)
+
     np.savez_compressed(os.path.join(HERE, 'tf_graphs.npz'), **out)
     print('wrote', os.path.join(HERE, 'tf_graphs.npz'))
 

@@ -38,6 +38,11 @@ class Node:
     def __truediv__(self, o): return Node(np.divide, self, o)
     def __rtruediv__(self, o): return Node(np.divide, o, self)
     def __neg__(self): return Node(np.negative, self)
+    def __getitem__(self, idx): return Node(lambda v: v[idx], self)
+
+    @property
+    def shape(self):
+        return np.shape(evaluate(self))                 # static shapes: only asked of placeholder-free nodes
     def __pow__(self, o): return Node(np.power, self, o)
     __array_priority__ = 1000
     __array_ufunc__ = None          # numpy operands defer to the reflected methods above
@@ -148,6 +153,16 @@ class SparseTensor:
     def __init__(self, indices, values, dense_shape):
         self.indices, self.values, self.dense_shape = np.asarray(indices, np.int64).reshape(-1, 2), values, tuple(dense_shape)
 
+    def __mul__(self, dense):
+        """sparse * dense with broadcasting of a [n, 1] column or a [1, n] row (alinet.py:665-666)"""
+        rows, cols = self.indices[:, 0], self.indices[:, 1]
+
+        def fn(vals, d):
+            d = np.asarray(d)
+            picked = d[rows, 0] if d.shape[1] == 1 and d.shape[0] != 1 else (d[0, cols] if d.shape[0] == 1 else d[rows, cols])
+            return np.asarray(vals, np.float64) * picked
+        return SparseTensor(self.indices, Node(fn, self.values, dense), self.dense_shape)
+
 
 def sparse_tensor_dense_matmul(sp_a, b, name=None):
     if isinstance(sp_a, SparseTensor):
@@ -175,6 +190,28 @@ def sparse_softmax(sp_input, name=None):
                         sp_input.dense_shape)
 
 
+def sparse_add(a, b, name=None):
+    assert np.array_equal(a.indices, b.indices)
+    return SparseTensor(a.indices, Node(np.add, a.values, b.values), a.dense_shape)
+
+
+def sparse_reshape(sp_input, shape, name=None):
+    assert tuple(shape) == tuple(sp_input.dense_shape)
+    return sp_input
+
+
+def tile(x, multiples, name=None):
+    return Node(lambda v: np.tile(v, multiples), x)
+
+
+def glorot_uniform_initializer(**_):
+    return lambda shape: _RNG.uniform(-np.sqrt(6.0 / (shape[0] + shape[1])), np.sqrt(6.0 / (shape[0] + shape[1])), shape)
+
+
+def zeros_initializer(**_):
+    return lambda shape: np.zeros(shape)
+
+
 def expand_dims(x, axis=None, name=None, dim=None):
     return Node(lambda v: np.expand_dims(v, axis if axis is not None else dim), x)
 
@@ -188,7 +225,10 @@ def concat(values, axis, name=None):
 
 
 def cast(x, dtype=None, name=None):
-    return Node(lambda v: np.asarray(v, np.float64), x) if isinstance(x, Node) else np.asarray(x, np.float64)
+    if isinstance(x, SparseTensor):
+        return x
+    to = np.int64 if dtype in (np.int32, np.int64) else np.float64
+    return Node(lambda v: np.asarray(v, to), x) if isinstance(x, Node) else np.asarray(x, to)
 
 
 def reset_default_graph():
@@ -257,9 +297,10 @@ add = _op(np.add)
 multiply = _op(np.multiply)
 pow = _op(np.power)                    # noqa: A001
 sigmoid = _op(lambda x: 1.0 / (1.0 + np.exp(-x)))
+tanh = _op(np.tanh)
 
 
-def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None, a_is_sparse=False, b_is_sparse=False):
     return Node(lambda x, y: np.matmul(x.T if transpose_a else x, y.T if transpose_b else y), a, b)
 
 
@@ -299,7 +340,31 @@ nn = types.SimpleNamespace(
     sigmoid=_op(lambda x: 1.0 / (1.0 + np.exp(-x))),
     dropout=_dropout,
 )
-keras = types.SimpleNamespace(activations=types.SimpleNamespace(get=lambda name: {"relu": nn.relu, "tanh": _op(np.tanh)}[name]))
+nn.bias_add = lambda value, bias, name=None: Node(np.add, value, bias)
+
+
+class _BatchNormalization:
+    """tf.keras.layers.BatchNormalization called without `training` in a TF-1 graph: inference mode with the initial moving
+    statistics (mean 0, variance 1), epsilon 1e-3: y = gamma * x / sqrt(1 + 1e-3) + beta.  gamma / beta are created at the
+    first call, like keras builds a layer."""
+    count = 0
+
+    def __init__(self, **_):
+        self.gamma = self.beta = None
+        _BatchNormalization.count += 1
+        self.uid = _BatchNormalization.count
+
+    def __call__(self, x, training=None):
+        if self.gamma is None:
+            dim = np.shape(evaluate(x))[-1]
+            self.gamma = Variable(np.ones(dim), name="bn%d_gamma" % self.uid)
+            self.beta = Variable(np.zeros(dim), name="bn%d_beta" % self.uid)
+        return x * (self.gamma / np.sqrt(1.0 + 1e-3)) + self.beta
+
+
+keras = types.SimpleNamespace(
+    activations=types.SimpleNamespace(get=lambda name: {"relu": nn.relu, "tanh": tanh}[name], relu=nn.relu, tanh=tanh),
+    layers=types.SimpleNamespace(BatchNormalization=_BatchNormalization))
 
 
 def _truncated_normal(stddev=1.0, **_):
@@ -319,7 +384,8 @@ initializers = types.SimpleNamespace(
     orthogonal=lambda **_: (lambda shape: np.linalg.qr(_RNG.standard_normal(shape))[0]),
 )
 contrib = types.SimpleNamespace(layers=types.SimpleNamespace(
-    xavier_initializer=lambda uniform=False, **_: (lambda shape: _RNG.standard_normal(shape) * np.sqrt(2.0 / sum(shape)))))
+    xavier_initializer=lambda uniform=False, **_: (lambda shape: _RNG.standard_normal(shape) * np.sqrt(2.0 / sum(shape))),
+    l2_regularizer=lambda scale=0.0, **_: None))        # regularisation losses are collected by TF but never added to a loss
 
 
 class _InertOptimizer:

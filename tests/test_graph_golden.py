@@ -263,3 +263,54 @@ def test_rdgcn_layer_on_device_equals_reference_graph():
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), i
         checked += 1
     assert checked == 22
+
+
+@pytest.mark.gpu
+def test_alinet_model_on_device_equals_reference_graph():
+    """alinet.py:539-677 (GraphConvolution, AliNetGraphAttentionLayer, HighwayLayer with keras BatchNormalization in
+    inference mode), :784-866 (_define_model, compute_loss, compute_rel_loss) built by the reference's own
+    `_generate_rel_graph` under tests/golden/tf_shim.py: with the 17 variables copied over by name, our layers give the
+    same layer outputs, the same loss and (autograd through the HIP aggregate / attention operators) the reference
+    graph's finite-difference gradients."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    from openea_amd.approaches import alinet
+    from openea_amd.models.graph_ops import EdgeGraph
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    n, dims, dev = 30, [8, 8, 4], ops.device()
+    # preprocess_adj (alinet.py:44-57) hands the edges over in COLUMN-major order; the stand-in's sparse_softmax groups runs
+    # of consecutive equal rows (TF-1's kernel on a non-canonical tensor, SURVEY H3) -> grouping="runs" on the same order
+    assert not (np.diff(t["alinet_two_coords"][:, 0]) >= 0).all()
+    m = alinet.AliNet()
+    m.args = types.SimpleNamespace(layer_dims=dims, neg_margin=1.5, neg_margin_balance=0.1, rel_param=0.01, dropout=0.0,
+                                   learning_rate=0.001)
+    m.kgs = types.SimpleNamespace(entities_num=n)
+    m.dev, m._rng, m.rel_win_size = dev, np.random.RandomState(0), 3
+    m.adj = [EdgeGraph(t["alinet_one_coords"][:, 0], t["alinet_one_coords"][:, 1], t["alinet_one_values"], (n, n), dev),
+             EdgeGraph(t["alinet_two_coords"][:, 0], t["alinet_two_coords"][:, 1], t["alinet_two_values"], (n, n), dev, grouping="runs")]
+    m._get_variable()
+    m._define_model()
+    g0, g1, att, hw = m.one_hop_layers[0], m.one_hop_layers[1], m.two_hop_layers[0], m.highways[0]
+    by_name = {"init_embedding": m.init_embedding, "gcn_0_kernel_0": g0.kernel, "gcn_0_bias": g0.bias, "bn1_gamma": g0.bn.gamma,
+               "bn1_beta": g0.bn.beta, "alinet_0_kernel": att.kernel, "alinet_0_kernel_1": att.kernel1, "alinet_0_kernel_2": att.kernel2,
+               "bn2_gamma": att.bn.gamma, "bn2_beta": att.bn.beta, "highwaykernel": hw.weight, "bn3_gamma": hw.bn.gamma,
+               "bn3_beta": hw.bn.beta, "gcn_1_kernel_0": g1.kernel, "gcn_1_bias": g1.bias, "bn4_gamma": g1.bn.gamma, "bn4_beta": g1.bn.beta}
+    assert sorted(by_name) == sorted(str(x) for x in t["alinet_var_names"]) and len(by_name) == len(m._params)
+    with torch.no_grad():
+        for name, p in by_name.items():
+            p.copy_(torch.from_numpy(t["alinet_var_" + name].astype(np.float32)).reshape(p.shape).to(dev))
+    outs = m._forward()
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), t["alinet_out%d" % i], rtol=1e-4, atol=1e-5)
+    emb = m._concat_train(outs)
+    pos = torch.from_numpy(t["alinet_pos"]).to(dev)
+    neg = torch.from_numpy(t["alinet_neg"]).to(dev)
+    loss = m.compute_loss(emb, pos, neg) + m.compute_rel_loss(emb, torch.from_numpy(t["alinet_hs"]).to(dev),
+                                                              torch.from_numpy(t["alinet_ts"]).to(dev))
+    ref_loss = float(t["alinet_loss"][0])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * ref_loss
+    loss.backward()
+    for name, p in by_name.items():
+        ref = t["alinet_grad_" + name]
+        got = p.grad.detach().cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), name
