@@ -314,3 +314,80 @@ def test_alinet_model_on_device_equals_reference_graph():
         ref = t["alinet_grad_" + name]
         got = p.grad.detach().cpu().numpy().reshape(ref.shape)
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw,neg_key,kind", [
+    ("aligne_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2", "transe"),
+    ("bootea_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2", "transe"),
+    ("bootea_align", dict(loss="align"), None, "transe"),
+    ("mtranse_triple", dict(loss="positive"), None, "transe"),
+    ("transe_triple", dict(loss="margin-based", margin=1.5), "neg1", "transe"),
+    ("bootea_transh_triple", dict(loss="limited", pos_margin=0.01, neg_margin=2.0, balance=0.2), "neg2", "transh"),
+    ("transh_triple", dict(loss="margin-based", margin=1.5), "neg1", "transh"),
+    ("transd_triple", dict(loss="margin-based", margin=1.5), "neg1", "transd"),
+])
+def test_device_step_equals_reference_graph(tag, kw, neg_key, kind):
+    """The HIP translational step itself against the reference's own graph code (tests/golden/tf_graphs.npz): batch loss and
+    the gradient of every variable, read back from one SGD step."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    names = {"transe": ["ent_embeds", "rel_embeds"], "transh": ["ent_embeds", "rel_embeds", "normal_vector"],
+             "transd": ["ent_embeds", "ent_transfer", "rel_embeds", "rel_transfer"]}[kind]
+    host = {nm: t["%s_var_%s" % (tag, nm)].astype(np.float32) for nm in names}
+    d = host["ent_embeds"].shape[1]
+    if kind == "transd":
+        ent_h = np.concatenate([host["ent_embeds"], host["ent_transfer"]])
+        rel_h = np.concatenate([host["rel_embeds"], host["rel_transfer"]])
+    else:
+        ent_h, rel_h = host["ent_embeds"], host["rel_embeds"]
+    ent, rel = ops.to_table(ent_h), ops.to_table(rel_h)
+    nrm = ops.to_table(host["normal_vector"]) if kind == "transh" else None
+    lr = 1e-3
+    cfg = ops.make_step_cfg(loss_norm="L2", ent_l2_norm=True, rel_l2_norm=True, optimizer="SGD", lr=lr, neg_group_k=0, normal=nrm,
+                            transfer_bases=(len(host["ent_embeds"]), len(host["rel_embeds"])) if kind == "transd" else None, **kw)
+    ws = ops.step_workspace(ent.shape[0], rel.shape[0], ent.shape[1])
+    acc = torch.zeros(1, dtype=torch.float64, device=ent.device)
+    pos = ops.to_ids(t["pos"].astype(np.int32))
+    neg = ops.to_ids(t[neg_key].astype(np.int32)) if neg_key else None
+    ops.triple_step(ent, None, rel, None, d, pos, neg, cfg, ws, acc)
+    ref_loss = float(t[tag + "_loss"][0])
+    assert abs(float(acc.item()) - ref_loss) <= 2e-5 * ref_loss
+    ge = (ent_h.astype(np.float64) - ent[:, :d].cpu().numpy()) / lr
+    gr = (rel_h.astype(np.float64) - rel[:, :d].cpu().numpy()) / lr
+    E, R = len(host["ent_embeds"]), len(host["rel_embeds"])
+    got = {"ent_embeds": ge[:E], "rel_embeds": gr[:R]}
+    if kind == "transd":
+        got.update(ent_transfer=ge[E:], rel_transfer=gr[R:])
+    if kind == "transh":
+        got["normal_vector"] = (host["normal_vector"].astype(np.float64) - nrm[:, :d].cpu().numpy()) / lr
+    for nm in names:
+        ref = t["%s_grad_%s" % (tag, nm)]
+        assert np.abs(got[nm] - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1.0), nm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,neg_key", [("rotate_triple", "neg2"), ("rotate_align", None)])
+def test_device_rotate_step_equals_reference_graph(tag, neg_key):
+    """oea_rotate_step (fp64) against bootea_rotate.py's own graph code: loss to 1e-10, gradients to the accuracy of the
+    finite differences."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    re_, im_, rel_h = t[tag + "_var_re_ent_embeds"], t[tag + "_var_im_ent_embeds"], t[tag + "_var_rel_embeds"]
+    d, E = re_.shape[1], len(re_)
+    ent_h = np.concatenate([re_, im_])
+    ent, rel = ops.to_table64(ent_h), ops.to_table64(rel_h)
+    cfg = ops.make_rotate_cfg(float(t["rotate_gamma"][0]), d, ent_l2_norm=True, rel_l2_norm=False, optimizer="SGD", lr=1e-6)
+    assert abs(cfg.phase_scale - float(t["rotate_phase_scale"][0])) < 1e-9
+    ws = ops.rotate_workspace(E, len(rel_h), ent.shape[1])
+    acc = torch.zeros(1, dtype=torch.float64, device=ent.device)
+    neg = ops.to_ids(t[neg_key].astype(np.int32)) if neg_key else None
+    ops.rotate_step(ent, None, rel, None, d, ops.to_ids(t["pos"].astype(np.int32)), neg, 0, cfg, ws, acc)
+    assert abs(float(acc.item()) - float(t[tag + "_loss"][0])) < 1e-10
+    ge = (ent_h - ent[:, :d].cpu().numpy()) / 1e-6
+    gr = (rel_h - rel[:, :d].cpu().numpy()) / 1e-6
+    for got, nm in ((ge[:E], "re_ent_embeds"), (ge[E:], "im_ent_embeds"), (gr, "rel_embeds")):
+        ref = t["%s_grad_%s" % (tag, nm)]
+        assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0), nm
