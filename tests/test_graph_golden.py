@@ -391,3 +391,33 @@ def test_device_rotate_step_equals_reference_graph(tag, neg_key):
     for got, nm in ((ge[:E], "re_ent_embeds"), (ge[E:], "im_ent_embeds"), (gr, "rel_embeds")):
         ref = t["%s_grad_%s" % (tag, nm)]
         assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0), nm
+
+
+@pytest.mark.gpu
+def test_device_mapping_step_equals_reference_graph():
+    """oea_mapping_step + the apply phase (SGD) against the reference's own add_mapping_module graph
+    (modules/base/mapping.py:9-19, losses.py:76-80): loss, gradient of the entity table and of the mapping matrix."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    t = np.load(os.path.join(HERE, "golden", "tf_graphs.npz"))
+    tag = "mtranse_mapping"
+    ent_h = t[tag + "_var_ent_embeds"].astype(np.float32)
+    m_h = t[tag + "_var_mapping_matrix"].astype(np.float32)
+    n_ent, d = ent_h.shape
+    te = ops.to_table(ent_h)
+    tm = torch.from_numpy(m_h).to(te.device).contiguous()
+    rel = ops.to_table(np.zeros((2, d), np.float32))
+    lr, alpha = 1e-3, float(t["mtranse_alpha"][0])
+    cfg = ops.make_step_cfg(loss="positive", optimizer="SGD", lr=lr, ent_l2_norm=True, rel_l2_norm=True)
+    ws = ops.step_workspace(n_ent, 2, te.shape[1])
+    loss = torch.zeros(1, dtype=torch.float64, device=te.device)
+    dummy = torch.zeros(1, dtype=torch.float64, device=te.device)
+    empty = torch.zeros((0, 3), dtype=torch.int32, device=te.device)
+    ids1, ids2 = ops.to_ids(np.array([0, 3, 8], np.int32)), ops.to_ids(np.array([2, 4, 9], np.int32))
+    ops.mapping_step(te, d, True, ids1, ids2, tm, None, alpha, lr, "SGD", ws, n_ent, 2, loss, None)
+    ops.triple_step(te, None, rel, None, d, empty, None, cfg, ws, dummy, phase=ops.PHASE_APPLY)
+    ref_loss = float(t[tag + "_loss"][0])
+    assert abs(float(loss.item()) - ref_loss) <= 2e-5 * ref_loss
+    for got, ref in (((ent_h.astype(np.float64) - te[:, :d].cpu().numpy()) / lr, t[tag + "_grad_ent_embeds"]),
+                     ((m_h.astype(np.float64) - tm.cpu().numpy()) / lr, t[tag + "_grad_mapping_matrix"])):
+        assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1.0)
