@@ -342,6 +342,7 @@ class AliNet(BasicModel):
         if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0:
             raise NotImplementedError("dropout > 0 is not built (every shipped args file uses 0)")
         self.ref_ent1 = self.kgs.test_entities1 + self.kgs.valid_entities1
+        self.attn_grouping = getattr(self.args, 'attn_grouping', self.attn_grouping)      # 'row' | 'runs' 
         self.ref_ent2 = self.kgs.test_entities2 + self.kgs.valid_entities2
         self.sup_ent1, self.sup_ent2 = self.kgs.train_entities1, self.kgs.train_entities2
         self.linked_ents = set(self.kgs.train_entities1 + self.kgs.train_entities2 + self.kgs.valid_entities1 +

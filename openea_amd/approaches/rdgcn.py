@@ -281,7 +281,7 @@ class RDGCN(BasicModel):
         if self.local_name_vectors is None and os.path.exists(self.word_embed):
             _, _, self.local_name_vectors = self._get_desc_input()       # rdgcn.py:358
         self.gcn_model = Layer(self.args, self.kgs, self.local_name_vectors, self.dev, seed=self._seed,
-                               attn_grouping=self.attn_grouping)
+                               attn_grouping=getattr(self.args, 'attn_grouping', self.attn_grouping))   # 'row' | 'runs' 
         self.optimizer = TFAdam(self.gcn_model.params(), self.args.learning_rate)
 
     def _get_local_name_by_name_triple(self, name_attribute_list=None):
