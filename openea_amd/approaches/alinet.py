@@ -46,19 +46,20 @@ def preprocess_adj(adj):
     return normalize_adj(adj + sp.eye(adj.shape[0]))
 
 
+def _triple_array(triples):
+    """[n, 3] int64 in the iteration order of `triples` (a set keeps its own order: the pattern ranking below depends on it)."""
+    arr = np.fromiter((x for tr in triples for x in tr), np.int64, count=3 * len(triples))
+    return arr.reshape(-1, 3)
+
+
 def no_weighted_adj(total_ent_num, triple_list):
-    """alinet.py:155-181 (1-hop part): undirected 0/1 adjacency, +I, symmetric normalisation."""
-    edge = {}
-    for h, _, t in triple_list:
-        edge.setdefault(h, set()).add(t)
-        edge.setdefault(t, set()).add(h)
-    row, col = [], []
-    for i in range(total_ent_num):
-        if i in edge:
-            row.extend([i] * len(edge[i]))
-            col.extend(list(edge[i]))
-    data = np.ones(len(row))
-    return preprocess_adj(sp.coo_matrix((data, (row, col)), shape=(total_ent_num, total_ent_num)))
+    """alinet.py:155-181 (1-hop part): undirected 0/1 adjacency, +I, symmetric normalisation.  The reference's
+    dict-of-sets edge map is the set of distinct (h, t) / (t, h) pairs: one np.unique over packed keys."""
+    tri = _triple_array(triple_list) if not isinstance(triple_list, np.ndarray) else triple_list
+    n = int(total_ent_num)
+    keys = np.unique(np.concatenate([tri[:, 0] * n + tri[:, 2], tri[:, 2] * n + tri[:, 0]]))
+    row, col = keys // n, keys % n
+    return preprocess_adj(sp.coo_matrix((np.ones(len(keys)), (row, col)), shape=(n, n)))
 
 
 def remove_unlinked_triples(triples, linked_ents):
@@ -74,28 +75,61 @@ def generate_rel_ht(triples):
     return d
 
 
-def generate_2hop_triples(kg, linked_ents=None):
+def generate_2hop_triples(kg, linked_ents=None, as_array=False):
     """alinet.py:250-287: 2-step paths h -r1-> m -r2-> t whose endpoints are not 1-hop neighbours,
-    all but the 5 most frequent (r1, r2) patterns kept, plus self loops (h, 0, h)."""
+    all but the 5 most frequent (r1, r2) patterns kept, plus self loops (h, 0, h).
+
+    The reference joins the triple table with itself in pandas and walks the result with iterrows; here the join is
+    numpy (rows in the same order: left triple major, matching right triples in table order), the neighbour test one
+    sorted-key membership, and the pattern ranking `sorted(counts, reverse=True)` -- stable, i.e. ties keep first-seen
+    order -- a lexsort over (first occurrence, -count).  Output equal to the reference's on tests/golden/graphs.npz."""
     triples = kg.triples
     if linked_ents is not None:
         triples = remove_unlinked_triples(triples, linked_ents)
-    by_head = {}
-    for h, r, t in triples:
-        by_head.setdefault(h, []).append((r, t))
-    quads, patterns = set(), {}
-    for h, r1, m in triples:                         # pd.merge(left_on='t', right_on='h')
-        for r2, t in by_head.get(m, ()):
-            if t not in kg.out_related_ents_dict.get(h, set()) and h not in kg.in_related_ents_dict.get(t, set()):
-                patterns[(r1, r2)] = patterns.get((r1, r2), 0) + 1   # counted per merged row, like iterrows
-                quads.add((h, r1, r2, t))
-    ranked = sorted(patterns.items(), key=lambda x: x[1], reverse=True)
-    selected = {p for p, _ in ranked[5:]}
-    out = set()
-    for h, r1, r2, t in quads:
-        if (r1, r2) in selected:
-            out.add((h, 0, h))
-            out.add((h, r1 + r2, t))
+    tri = _triple_array(triples)
+    empty = np.zeros((0, 3), np.int64) if as_array else set()
+    if len(tri) == 0:
+        return empty
+    n = int(max(tri[:, 0].max(), tri[:, 2].max())) + 1
+    # right side grouped by head, table order kept inside a group (pd.merge(left_on='t', right_on='h'))
+    by_head = np.argsort(tri[:, 0], kind="stable")
+    heads_sorted = tri[by_head, 0]
+    lo = np.searchsorted(heads_sorted, tri[:, 2], side="left")
+    hi = np.searchsorted(heads_sorted, tri[:, 2], side="right")
+    cnt = hi - lo
+    left = np.repeat(np.arange(len(tri)), cnt)                               # merged row -> left triple
+    offs = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    right = by_head[np.repeat(lo, cnt) + offs]                               # merged row -> right triple
+    h, r1, r2, t = tri[left, 0], tri[left, 1], tri[right, 1], tri[right, 2]
+    # "tail not in out[head] and head not in in[tail]": (head, tail) is not an edge of the FULL kg (not of the filtered table)
+    full = _triple_array(kg.triples) if linked_ents is not None else tri
+    nn = max(n, int(max(full[:, 0].max(), full[:, 2].max())) + 1)
+    edges = np.unique(full[:, 0] * nn + full[:, 2])
+    keep = ~np.isin(h * nn + t, edges)
+    h, r1, r2, t = h[keep], r1[keep], r2[keep], t[keep]
+    if len(h) == 0:
+        print("total 2-hop neighbors:", 0)
+        return empty
+    n_rel = int(max(r1.max(), r2.max())) + 1
+    pat = r1 * n_rel + r2
+    print("total 2-hop neighbors:", len(np.unique((h * (n_rel * n_rel) + pat) * nn + t)))     # distinct (h, r1, r2, t)
+    uniq, first, counts = np.unique(pat, return_index=True, return_counts=True)   # counted per merged row, like iterrows
+    ranked = uniq[np.lexsort((first, -counts))]
+    print("total 2-hop relation patterns:", len(uniq))
+    selected = ranked[5:]
+    print("selected relation patterns:", len(selected))
+    sel = np.isin(pat, selected)
+    h, r1, r2, t = h[sel], r1[sel], r2[sel], t[sel]
+    hop_keys = np.unique((h * (2 * n_rel) + (r1 + r2)) * nn + t)               # distinct (h, r1 + r2, t)
+    hops = np.stack([hop_keys // nn // (2 * n_rel), hop_keys // nn % (2 * n_rel), hop_keys % nn], 1)
+    loops = np.unique(h)
+    loops = np.stack([loops, np.zeros_like(loops), loops], 1)
+    if as_array:
+        out = np.unique(np.concatenate([hops, loops]), axis=0) if len(hops) else loops
+        print("selected 2-hop neighbors:", len(out))
+        return out
+    out = set(map(tuple, hops.tolist()))
+    out.update(map(tuple, loops.tolist()))
     print("selected 2-hop neighbors:", len(out))
     return out
 
@@ -353,8 +387,8 @@ class AliNet(BasicModel):
         self.rel_ht_dict = generate_rel_ht(triples)
         n = self.kgs.entities_num
         one = no_weighted_adj(n, triples)
-        two = no_weighted_adj(n, generate_2hop_triples(self.kg1, self.linked_ents) |
-                              generate_2hop_triples(self.kg2, self.linked_ents))
+        two = no_weighted_adj(n, np.concatenate([generate_2hop_triples(self.kg1, self.linked_ents, as_array=True),
+                                                 generate_2hop_triples(self.kg2, self.linked_ents, as_array=True)]))
         self.adj = [EdgeGraph(one.row, one.col, one.data, one.shape, dev),
                     EdgeGraph(two.row, two.col, two.data, two.shape, dev, grouping=self.attn_grouping)]
         self.rel_win_size = self.args.batch_size // max(len(self.rel_ht_dict), 1)

@@ -421,3 +421,11 @@ def test_device_mapping_step_equals_reference_graph():
     for got, ref in (((ent_h.astype(np.float64) - te[:, :d].cpu().numpy()) / lr, t[tag + "_grad_ent_embeds"]),
                      ((m_h.astype(np.float64) - tm.cpu().numpy()) / lr, t[tag + "_grad_mapping_matrix"])):
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1.0)
+
+
+def test_alinet_2hop_array_form_equals_set_form(kgs):
+    from openea_amd.approaches import alinet
+    kg = alinet.AKG(kgs.kg1.relation_triples_set)
+    as_set = quiet(alinet.generate_2hop_triples, kg)
+    as_arr = quiet(alinet.generate_2hop_triples, kg, as_array=True)
+    assert as_arr.dtype == np.int64 and np.array_equal(as_arr, triples_sorted(as_set))
