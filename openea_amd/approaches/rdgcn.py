@@ -64,14 +64,20 @@ def get_mat(triple_list, ent_num):
 
 
 def get_sparse_tensor(triple_list, ent_num):
-    """rdgcn.py:63-72: M[sec, fir] = 1 / sqrt(deg[fir]) / sqrt(deg[sec])."""
-    pos, degree = get_mat(triple_list, ent_num)
-    rows, cols, vals = [], [], []
-    for fir, sec in pos:
-        rows.append(sec)
-        cols.append(fir)
-        vals.append(pos[(fir, sec)] / math.sqrt(degree[fir]) / math.sqrt(degree[sec]))
-    return np.asarray(rows), np.asarray(cols), np.asarray(vals, np.float32)
+    """rdgcn.py:63-72 on top of get_mat (:45-59): M[sec, fir] = 1 / sqrt(deg[fir]) / sqrt(deg[sec]) over the symmetric
+    closure of the (h, t) pairs plus the diagonal, with get_mat's degree rule (a triple whose head id differs from its
+    RELATION id adds one to degree[head] and to degree[relation id]).  Same entries and the same fp64 arithmetic as the
+    dictionary walk of get_mat, as numpy set operations (5.7 s -> 0.5 s at the 100K shape); entries come back sorted."""
+    tri = np.fromiter((x for tr in triple_list for x in tr), np.int64, count=3 * len(triple_list)).reshape(-1, 3)
+    h, r, t = tri[:, 0], tri[:, 1], tri[:, 2]
+    n = int(ent_num)
+    counted = h != r
+    degree = 1 + np.bincount(h[counted], minlength=n) + np.bincount(r[counted], minlength=n)
+    off = h != t
+    keys = np.unique(np.concatenate([h[off] * n + t[off], t[off] * n + h[off], np.arange(n, dtype=np.int64) * (n + 1)]))
+    fir, sec = keys // n, keys % n
+    vals = 1.0 / np.sqrt(degree[fir].astype(np.float64)) / np.sqrt(degree[sec].astype(np.float64))
+    return sec, fir, vals.astype(np.float32)
 
 
 def dual_adjacency(head, tail, count_r):
