@@ -16,11 +16,17 @@ def parse_triples(triples):
     return columns
 
 
-def _grouped(triples, key, value):
-    """{triple[key]: {value(triple)}} as a plain dict of sets."""
+def _grouped(triples, key, cols):
+    """{triple[key]: {triple[cols]}} (cols an index) or {triple[key]: {(triple[a], triple[b])}} (cols = (a, b)) as a plain
+    dict of sets."""
     groups = defaultdict(set)
-    for triple in triples:
-        groups[triple[key]].add(value(triple))
+    if isinstance(cols, int):
+        for triple in triples:
+            groups[triple[key]].add(triple[cols])
+    else:
+        a, b = cols
+        for triple in triples:
+            groups[triple[key]].add((triple[a], triple[b]))
     return dict(groups)
 
 
@@ -75,20 +81,20 @@ class KG:
     def generate_relation_triple_dict(self):
         """kg.py:95-105: rt_dict[h] = {(r,t)}, hr_dict[t] = {(h,r)}."""
         local = self.local_relation_triples_list
-        self.rt_dict = _grouped(local, 0, lambda x: (x[1], x[2]))
-        self.hr_dict = _grouped(local, 2, lambda x: (x[0], x[1]))
+        self.rt_dict = _grouped(local, 0, (1, 2))
+        self.hr_dict = _grouped(local, 2, (0, 1))
 
     def generate_attribute_triple_dict(self):
         """kg.py:107-114: av_dict[e] = {(a,v)}."""
-        self.av_dict = _grouped(self.local_attribute_triples_list, 0, lambda x: (x[1], x[2]))
+        self.av_dict = _grouped(self.local_attribute_triples_list, 0, (1, 2))
 
     def parse_relations(self):
         """kg.py:116-122."""
-        self.entity_relations_dict = _grouped(self.local_relation_triples_list, 0, lambda x: x[1])
+        self.entity_relations_dict = _grouped(self.local_relation_triples_list, 0, 1)
 
     def parse_attributes(self):
         """kg.py:124-130."""
-        self.entity_attributes_dict = _grouped(self.local_attribute_triples_list, 0, lambda x: x[1])
+        self.entity_attributes_dict = _grouped(self.local_attribute_triples_list, 0, 1)
 
     def set_id_dict(self, entities_id_dict, relations_id_dict, attributes_id_dict):
         self.entities_id_dict, self.relations_id_dict, self.attributes_id_dict = \
