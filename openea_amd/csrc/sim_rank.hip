@@ -171,8 +171,10 @@ __device__ __forceinline__ void tile_pipeline(const float *__restrict__ am, int6
 // packed once per call by pack_rows_kernel ([n_pad, Kp] with n_pad % 128 == 0 and Kp % 32 == 0, zero filled, every
 // group of 8 k stored as k = 0,2,4,6,1,3,5,7 -- O(n d) work in front of an O(n^2 d) sweep).  The LDS image of a chunk
 // is 128 rows x 32 floats WITHOUT padding; bank conflicts are avoided by an XOR swizzle of the eight 16-byte columns
-// of a row with (row & 7), applied to the per-lane SOURCE address of the DMA and to the ds_read address (the same
-// involution on both sides).
+// of a row with ((row >> 1) & 7), applied to the per-lane SOURCE address of the DMA and to the ds_read address (the same
+// involution on both sides).  A 128-byte row covers half of the 64 banks, so 16 consecutive rows of one column must
+// land on all 16 (row parity, position) combinations: with (row & 7) rows r and r + 8 collided -- SQ_LDS_BANK_CONFLICT
+// was half of SQ_LDS_IDX_ACTIVE -- with ((row >> 1) & 7) they do not.
 constexpr int PLD = BK;                 // unpadded LDS row stride (floats)
 
 __global__ void pack_rows_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, float *__restrict__ dst,
@@ -200,11 +202,12 @@ __device__ __forceinline__ void stage_packed(const float *__restrict__ packed, i
                                              float *__restrict__ dst) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 3;                                         // row inside the instruction's 8-row block
-    const float *src = packed + (row0 + wave * 32 + sub) * kp + k0 + 4 * ((lane & 7) ^ sub);
+    const float *src = packed + (row0 + wave * 32 + sub) * kp + k0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float *base = dst + (wave * 4 + j) * 8 * PLD;                  // wave-uniform: 1 KB per instruction
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (int64_t)j * 8 * kp),
+        const int swz = (4 * j + (sub >> 1)) & 7;                      // ((row >> 1) & 7) of row = 32 wave + 8 j + sub
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (int64_t)j * 8 * kp + 4 * ((lane & 7) ^ swz)),
                                          reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
                                          16, 0, 0);
     }
@@ -214,7 +217,7 @@ __device__ __forceinline__ void mma_chunk_packed(const float *__restrict__ As, c
                                                  f32x16 (&acc)[2][2]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int x = lane & 7, half = lane >> 5;                          // (row & 7) == (lane & 7): tile offsets are multiples of 8
+    const int x = (lane >> 1) & 7, half = lane >> 5;                   // ((row >> 1) & 7): tile offsets are multiples of 16
     const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
     const float *bp = Bs + (wn * 64 + (lane & 31)) * PLD;
     for (int g = 0; g < groups; ++g) {
