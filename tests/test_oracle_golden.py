@@ -523,3 +523,48 @@ def test_gcn_unit_oracle_equals_reference_graph(tfg, tag):
     loss, out = orc.gcn_se_epoch(w1, coords, values, tfg["gcn_ill"], 3.0, 3, negs, lr, features=feats)
     np.testing.assert_allclose(out, tfg[tag + "_outputs"], rtol=1e-5, atol=1e-6)
     _check(tfg, tag, ["weights"], loss, _sgd_grads([W], [w1], lr))
+
+
+@pytest.mark.parametrize("mode", ["truncated", "uniform"])
+def test_sampler_statistics_match_reference(golden_dir, mode):
+    """The Philox restatement of generate_neg_triples_fast (batch.py:89-119) cannot agree with python's `random` draw by
+    draw; over 300 batches it must agree in distribution with 300 runs of the REFERENCE sampler
+    (tests/golden/neg_stats.npz): how often a positive's k negatives all corrupt the head, how often a family mixes both
+    sides (a re-draw after a true triple flips a new coin), and the same histogram over the candidate-list positions."""
+    g = np.load(os.path.join(golden_dir, "neg_sampling.npz"))
+    st = np.load(os.path.join(golden_dir, "neg_stats.npz"))
+    runs, k = int(st["runs"][0]), 10
+    pos, ents = g["pos"], g["entity_list"]
+    table = cport.tripleset_build(g["triples"])
+    ent_pos = np.full(int(ents.max()) + 1, -1, np.int32)
+    ent_pos[ents] = np.arange(len(ents), dtype=np.int32)
+    nbr = g["nbr"] if mode == "truncated" else None
+    n_cand = nbr.shape[1] if nbr is not None else len(ents)
+    pure = mixed = 0
+    hist = np.zeros(n_cand, np.int64)
+    where = {int(e): i for i, e in enumerate(ents)}
+    for step in range(runs):
+        neg = cport.sample_negatives(pos, k, table, ents, ent_pos if nbr is not None else None, nbr, seed=77, step=step)
+        neg = neg.reshape(len(pos), k, 3)
+        head_side = neg[:, :, 0] != pos[:, None, 0]
+        tail_side = neg[:, :, 2] != pos[:, None, 2]
+        pure += int(head_side.all(1).sum())
+        mixed += int((head_side.any(1) & tail_side.any(1)).sum())
+        drawn = np.where(head_side, neg[:, :, 0], neg[:, :, 2])
+        owner = np.where(head_side, pos[:, None, 0], pos[:, None, 2])
+        valid = head_side | tail_side
+        if nbr is None:
+            idx = ent_pos[drawn[valid]]
+        else:                                   # position of the drawn entity in the corrupted entity's neighbour list
+            rows = nbr[ent_pos[owner[valid]]]
+            idx = (rows == drawn[valid][:, None]).argmax(1)
+        hist += np.bincount(idx, minlength=n_cand)
+    families = runs * len(pos)
+    for ours, key in ((pure, mode + "_pure_head"), (mixed, mode + "_mixed")):
+        ref = int(st[key][0])
+        assert abs(ours - ref) / families < 0.012, (key, ours, ref)          # sigma of the difference ~ 0.0025
+    ref_hist = st[mode + "_hist"].astype(np.float64)
+    ours_n, ref_n = hist / hist.sum(), ref_hist / ref_hist.sum()
+    # neither histogram is flat (positions that would give a true triple are rejected and re-drawn): the two samplers
+    # must show the same profile; sigma of the difference of two multinomial frequencies ~ sqrt(2 p / N)
+    assert np.abs(ours_n - ref_n).max() < 6 * np.sqrt(2 * ref_n.max() / ref_hist.sum())
