@@ -31,7 +31,8 @@ Pinning (details in DESIGN.md, section "Oracle"):
 * Random draws (negative triples, negative links): the reference uses python ``random``; the
   restatements here define the Philox / keyed-permutation formulation the device kernels
   reproduce bit for bit, and the tests check the reference's invariants on them
-  (distinctness, membership, set semantics, exclusion of true triples / seed links).
+  (distinctness, membership, set semantics, exclusion of true triples / seed links) and, for the triple sampler, agreement
+  in distribution with 300 runs of the reference's own function (``tests/golden/neg_stats.npz``).
 * Host-side matchings (``galeshapley``, ``stable_alignment``): literal restatements of
   ``modules/finding/alignment.py:87-221``.
 """
