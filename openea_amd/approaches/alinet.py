@@ -7,7 +7,8 @@ loss.  Sparse operators (tf.sparse_tensor_dense_matmul, leaky_relu -> tf.sparse_
 and their gradients) are HIP kernels (csrc/spmm.hip, csrc/sparse_attn.hip); the dense feature
 transforms are plain library GEMMs; Adam is csrc/optim.hip.
 
-TF1 semantics restated, not executed -- PARITY UNPINNED: BatchNormalization is called
+TF1 op semantics restated, not executed (the composition of the model is pinned by the reference's own
+_generate_rel_graph run under a numpy stand-in, tests/golden/tf_graphs.npz): BatchNormalization is called
 without `training=` -> inference mode with never-updated moving statistics, i.e. the per-feature
 affine y = gamma * x / sqrt(1 + 1e-3) + beta; tf.sparse_softmax grouping is selectable
 (`attn_grouping`: 'row' = per row, 'runs' = TF1 CPU consecutive-run behaviour).

@@ -14,7 +14,8 @@ Device side, per epoch and per model (csrc/spmm.hip):
     W  -= lr * (d T through the normalisation)                             GradientDescentOptimizer (:511)
 
 i.e. 4 (SE) / 6 (AE) CSR aggregates per epoch, no atomics in the aggregates, fixed summation
-order.  TF1 semantics are restated, not executed: PARITY UNPINNED against TF.
+order.  TF1 op semantics are restated, not executed; the composition of the unit's graph is pinned by the reference's own
+GCN_Align_Unit code run under a numpy stand-in (tests/golden/tf_graphs.npz).
 """
 import math
 import time

@@ -15,7 +15,8 @@ Reproduced quirks: `get_mat` compares head with RELATION id and 
 degree[relation id] (rdgcn.py:49-51).  The entity input is the summed word vectors of the entity
 names (rdgcn.py:415-464) when the `word_embed` file exists (`_get_desc_input`); without the file the
 default here is the reference's own alternative `get_input_layer` (glorot, rdgcn.py:280-282).
-TF1 semantics restated, not executed: PARITY UNPINNED.
+TF1 op semantics restated, not executed; the composition of Layer.build() is pinned by the reference's own code run
+under a numpy stand-in (tests/golden/tf_graphs.npz).
 """
 import math
 import os

@@ -209,7 +209,7 @@ def early_stop(flag1, flag2, flag):
 
 
 # ----------------------------------------------------------------------------------------
-# TF1 graph pieces (PARITY UNPINNED -- restatements of TF1 semantics)
+# TF1 graph pieces (restatements of TF1 semantics; the graphs' composition is pinned by tests/golden/tf_graphs.npz)
 # ----------------------------------------------------------------------------------------
 
 
@@ -401,7 +401,7 @@ def gcn_se_epoch(W, coords, values, ILL, gamma, k, negs, lr, features=None):
 
 
 # ----------------------------------------------------------------------------------------
-# Sparse attention pieces (alinet.py:656-677, rdgcn.py:202-215) -- PARITY UNPINNED (H3)
+# Sparse attention pieces (alinet.py:656-677, rdgcn.py:202-215) -- which grouping tf.sparse_softmax applies is unpinned (H3)
 # ----------------------------------------------------------------------------------------
 
 
@@ -564,7 +564,8 @@ def link_negatives(n_pos, k, seed, step, pos_links=None, ents1=None, ents2=None,
 
 
 # ----------------------------------------------------------------------------------------------------
-# RotatE step of BootEA_RotatE (approaches/bootea_rotate.py:50-109,148-158) -- PARITY UNPINNED vs TF (hand-restated
+# RotatE step of BootEA_RotatE (approaches/bootea_rotate.py:50-109,148-158) -- loss and gradients reproduce the reference's
+# own graph code run under tests/golden/tf_shim.py; optimiser arithmetic unpinned vs TF (hand-restated
 # autodiff + optimisers); the gradients are pinned by finite differences in tests/test_oracle_golden.py.
 # ----------------------------------------------------------------------------------------------------
 def _l2n_rows(x):
