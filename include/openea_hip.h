@@ -331,6 +331,10 @@ int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_
  * metric: OEA_METRIC_*; csls_r / csls_c: per-row / per-column top-k means (NULL = no CSLS),
  * S'_ij = (2*S_ij - r_i) - c_j (similarity.py:74-76).
  * rank / argmax: int32 [n1].  workspace: oea_rank_workspace_bytes(n1) bytes.
+ * Inner-product tiles (this call, oea_sim_matrix, oea_topk_inner): both operands are first copied into two
+ * process-wide, grow-only scratch buffers in the packed layout the LDS-DMA staging reads ([n_pad, Kp], see
+ * DESIGN.md "Packed similarity operands"); reuse is ordered by `stream` (a call on another stream waits for
+ * the previous use).  OEA_TILE_GLDS=0 in the environment selects the register-staged tiles (same bits, no scratch).
  * ------------------------------------------------------------------------------------- */
 enum { OEA_METRIC_INNER = 0, OEA_METRIC_MANHATTAN = 1, OEA_METRIC_EUCLIDEAN = 2 };
 size_t oea_rank_workspace_bytes(int64_t n1);
