@@ -1,4 +1,6 @@
 """Pair of KGs in id space (mirror of openea/modules/load/kgs.py:5-99)."""
+import os
+
 from .kg import KG
 from .read import (generate_mapping_id, generate_sharing_id, generate_sup_attribute_triples,
                    generate_sup_relation_triples, read_attribute_triples, read_links,
@@ -76,22 +78,66 @@ def remove_unlinked_triples(triples, links):
     return {(h, r, t) for h, r, t in triples if h in linked and t in linked}
 
 
-def read_kgs_from_folder(training_data_folder, division, mode, ordered, remove_unlinked=False):
-    """kgs.py:79-99: rel_triples_{1,2}, attr_triples_{1,2}, <division>{train,valid,test}_links."""
-    kg1_rel, _, _ = read_relation_triples(training_data_folder + 'rel_triples_1')
-    kg2_rel, _, _ = read_relation_triples(training_data_folder + 'rel_triples_2')
-    kg1_attr, _, _ = read_attribute_triples(training_data_folder + 'attr_triples_1')
-    kg2_attr, _, _ = read_attribute_triples(training_data_folder + 'attr_triples_2')
-    train_links = read_links(training_data_folder + division + 'train_links')
-    valid_links = read_links(training_data_folder + division + 'valid_links')
-    test_links = read_links(training_data_folder + division + 'test_links')
+def _read_standard_folder(folder, division, mode, ordered, remove_unlinked, reverse):
+    """rel_triples_{1,2}, attr_triples_{1,2}, <division>{train,valid,test}_links; reverse=True swaps the roles of the two
+    KGs and the direction of every link (kgs.py:102-123)."""
+    first, second = ('2', '1') if reverse else ('1', '2')
+    rels = [read_relation_triples(folder + 'rel_triples_' + side)[0] for side in (first, second)]
+    attrs = [read_attribute_triples(folder + 'attr_triples_' + side)[0] for side in (first, second)]
+    links = {}
+    for part in ('train', 'valid', 'test'):
+        pairs = read_links(folder + division + part + '_links')
+        links[part] = [(j, i) for i, j in pairs] if reverse else pairs
     if remove_unlinked:
-        links = train_links + valid_links + test_links
-        kg1_rel = remove_unlinked_triples(kg1_rel, links)
-        kg2_rel = remove_unlinked_triples(kg2_rel, links)
-    kg1 = KG(kg1_rel, kg1_attr)
-    kg2 = KG(kg2_rel, kg2_attr)
-    return KGs(kg1, kg2, train_links, test_links, valid_links=valid_links, mode=mode, ordered=ordered)
+        every = links['train'] + links['valid'] + links['test']
+        rels = [remove_unlinked_triples(r, every) for r in rels]
+    return KGs(KG(rels[0], attrs[0]), KG(rels[1], attrs[1]), links['train'], links['test'], valid_links=links['valid'],
+               mode=mode, ordered=ordered)
+
+
+def read_kgs_from_folder(training_data_folder, division, mode, ordered, remove_unlinked=False):
+    """kgs.py:79-99 (DBP15K / DWY100K folders go to read_kgs_from_dbp_dwy, :80-81)."""
+    lowered = training_data_folder.lower()
+    if 'dbp15k' in lowered or 'dwy100k' in lowered:
+        return read_kgs_from_dbp_dwy(training_data_folder, division, mode, ordered, remove_unlinked=remove_unlinked)
+    return _read_standard_folder(training_data_folder, division, mode, ordered, remove_unlinked, reverse=False)
+
+
+def read_reversed_kgs_from_folder(training_data_folder, division, mode, ordered, remove_unlinked=False):
+    """kgs.py:102-123: KG2 takes the role of KG1 and every link is turned round (run/main_from_args_reversed.py)."""
+    return _read_standard_folder(training_data_folder, division, mode, ordered, remove_unlinked, reverse=True)
+
+
+def remove_no_triples_link(kg1_relation_triples, kg2_relation_triples, train_links, test_links):
+    """kgs.py:172-189: links whose two entities both still occur in a relation triple."""
+    ents1 = {e for h, _, t in kg1_relation_triples for e in (h, t)}
+    ents2 = {e for h, _, t in kg2_relation_triples for e in (h, t)}
+    print("before removing links with no triples:", len(train_links), len(test_links))
+    kept = [list({(i, j) for i, j in part if i in ents1 and j in ents2}) for part in (train_links, test_links)]
+    print("after removing links with no triples:", len(kept[0]), len(kept[1]))
+    return kept[0], kept[1]
+
+
+def read_kgs_from_dbp_dwy(folder, division, mode, ordered, remove_unlinked=False):
+    """kgs.py:134-169: the DBP15K / DWY100K layout -- triples_{1,2}, sup_pairs | sup_ent_ids, ref_pairs | ref_ent_ids under
+    <folder><division>, no attribute triples, no validation links; remove_unlinked alternates the two filters until
+    neither removes anything."""
+    folder = folder + division
+    rel1 = read_relation_triples(folder + 'triples_1')[0]
+    rel2 = read_relation_triples(folder + 'triples_2')[0]
+    train_links = read_links(folder + ('sup_pairs' if os.path.exists(folder + 'sup_pairs') else 'sup_ent_ids'))
+    test_links = read_links(folder + ('ref_pairs' if os.path.exists(folder + 'ref_pairs') else 'ref_ent_ids'))
+    print()
+    while remove_unlinked:
+        rel1 = remove_unlinked_triples(rel1, train_links + test_links)
+        rel2 = remove_unlinked_triples(rel2, train_links + test_links)
+        before = (len(rel1), len(rel2))
+        train_links, test_links = remove_no_triples_link(rel1, rel2, train_links, test_links)
+        rel1 = remove_unlinked_triples(rel1, train_links + test_links)
+        rel2 = remove_unlinked_triples(rel2, train_links + test_links)
+        if before == (len(rel1), len(rel2)):
+            break
+    return KGs(KG(rel1, list()), KG(rel2, list()), train_links, test_links, mode=mode, ordered=ordered)
 
 
 def read_kgs_from_files(kg1_relation_triples, kg2_relation_triples, kg1_attribute_triples, kg2_attribute_triples,

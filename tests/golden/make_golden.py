@@ -174,9 +174,37 @@ def make_load_golden():
                 "kg2_triples": sorted(map(list, kgs.kg2.relation_triples_set)),
                 "kg1_local_triples": len(kgs.kg1.local_relation_triples_set),
             }
+        # reversed reading (kgs.py:102-123) and the DBP15K / DWY100K layout (kgs.py:134-169, with and without
+        # remove_unlinked) on the same tiny dataset
+        def summary(kgs):
+            return {"ent_ids1": kgs.kg1.entities_id_dict, "ent_ids2": kgs.kg2.entities_id_dict,
+                    "rel_ids1": kgs.kg1.relations_id_dict, "rel_ids2": kgs.kg2.relations_id_dict,
+                    "train_links": sorted(list(map(int, x)) for x in kgs.train_links),
+                    "valid_links": sorted(list(map(int, x)) for x in kgs.valid_links),
+                    "test_links": sorted(list(map(int, x)) for x in kgs.test_links),
+                    "entities_num": kgs.entities_num, "relations_num": kgs.relations_num,
+                    "kg1_triples": sorted(map(list, kgs.kg1.relation_triples_set)),
+                    "kg2_triples": sorted(map(list, kgs.kg2.relation_triples_set))}
+        out["reversed_mapping"] = summary(quiet(ref_kgs.read_reversed_kgs_from_folder, folder, "721_5fold/1/", "mapping", True))
+        dbp = make_dbp_layout(folder, tmp + "/dbp15k_tiny/")
+        for remove in (False, True):
+            out["dbp_%d" % remove] = summary(quiet(ref_kgs.read_kgs_from_folder, dbp, "0_3/", "mapping", True, remove))
     with open(os.path.join(HERE, 'load.json'), 'w') as fh:
         json.dump(out, fh)
     print('load golden written')
+
+
+def make_dbp_layout(src_folder, dst_folder, division="0_3/"):
+    """the tiny dataset in the DBP15K / DWY100K file layout; a third of the links is dropped so that remove_unlinked has work"""
+    import shutil
+    os.makedirs(dst_folder + division, exist_ok=True)
+    shutil.copy(src_folder + "rel_triples_1", dst_folder + division + "triples_1")
+    shutil.copy(src_folder + "rel_triples_2", dst_folder + division + "triples_2")
+    train = open(src_folder + "721_5fold/1/train_links").read().splitlines()
+    test = open(src_folder + "721_5fold/1/test_links").read().splitlines()
+    open(dst_folder + division + "sup_ent_ids", "w").write("\n".join(train[: len(train) * 2 // 3]) + "\n")
+    open(dst_folder + division + "ref_pairs", "w").write("\n".join(test[: len(test) * 2 // 3]) + "\n")
+    return dst_folder
 
 
 if __name__ == '__main__':

@@ -81,6 +81,37 @@ def test_loader_matches_reference(golden_dir, mode):
         assert all(v % 2 == 1 for v in kgs.kg2.entities_id_dict.values())
 
 
+@pytest.mark.parametrize("variant", ["reversed_mapping", "dbp_0", "dbp_1"])
+def test_reversed_and_dbp_loaders_match_reference(golden_dir, variant):
+    """kgs.py:102-123 (KGs and links turned round) and :134-189 (DBP15K / DWY100K layout: triples_{1,2}, sup_ent_ids,
+    ref_pairs; remove_unlinked iterates the two filters to a fixed point) against the reference loader's output."""
+    import shutil
+    from openea_amd.modules.load.kgs import read_kgs_from_folder, read_reversed_kgs_from_folder
+    from openea_amd.modules.load.synth import write_dataset
+    g = json.load(open(os.path.join(golden_dir, "load.json")))[variant]
+    with tempfile.TemporaryDirectory() as tmp:
+        folder = write_dataset(tmp + "/tiny/", "tiny", seed=4)
+        if variant == "reversed_mapping":
+            kgs = read_reversed_kgs_from_folder(folder, "721_5fold/1/", "mapping", True)
+        else:
+            dst = tmp + "/dbp15k_tiny/"
+            os.makedirs(dst + "0_3/")
+            shutil.copy(folder + "rel_triples_1", dst + "0_3/triples_1")
+            shutil.copy(folder + "rel_triples_2", dst + "0_3/triples_2")
+            train = open(folder + "721_5fold/1/train_links").read().splitlines()
+            test = open(folder + "721_5fold/1/test_links").read().splitlines()
+            open(dst + "0_3/sup_ent_ids", "w").write("\n".join(train[: len(train) * 2 // 3]) + "\n")
+            open(dst + "0_3/ref_pairs", "w").write("\n".join(test[: len(test) * 2 // 3]) + "\n")
+            kgs = read_kgs_from_folder(dst, "0_3/", "mapping", True, variant == "dbp_1")      # dispatched on the folder name
+    assert kgs.kg1.entities_id_dict == g["ent_ids1"] and kgs.kg2.entities_id_dict == g["ent_ids2"]
+    assert kgs.kg1.relations_id_dict == g["rel_ids1"] and kgs.kg2.relations_id_dict == g["rel_ids2"]
+    for part in ("train_links", "valid_links", "test_links"):
+        assert sorted(list(x) for x in getattr(kgs, part)) == g[part]
+    assert kgs.entities_num == g["entities_num"] and kgs.relations_num == g["relations_num"]
+    assert sorted(map(list, kgs.kg1.relation_triples_set)) == g["kg1_triples"]
+    assert sorted(map(list, kgs.kg2.relation_triples_set)) == g["kg2_triples"]
+
+
 def test_pos_batching_matches_reference(golden_dir):
     from openea_amd.modules.train import batch as bat
     g = np.load(os.path.join(golden_dir, "pos_batch.npz"))
