@@ -357,3 +357,31 @@ class BasicModel:
                     file.write(str(entity1) + "\t" + str(entity2) + "\t" + str(confidence) + "\n")
             print(self.out_folder + output_file_name, "saved")
         return res
+
+    def predict_entities(self, entities_file_path, output_file_name=None):
+        """basic_model.py:354-413: the similarity of the (entity1 \\t entity2) URI pairs listed in a tsv file, as
+        [(uri1, uri2, confidence)] (and written to <out_folder><output_file_name> if given)."""
+        ids1, ids2 = [], []
+        with open(entities_file_path, 'r', encoding='utf-8') as fh:
+            for line in fh:
+                uri1, uri2 = line.strip('\n').split('\t')[:2]
+                ids1.append(self.kgs.kg1.entities_id_dict[uri1])
+                ids2.append(self.kgs.kg2.entities_id_dict[uri2])
+        distinct1, distinct2 = sorted(set(ids1)), sorted(set(ids2))
+        row = {e: i for i, e in enumerate(distinct1)}
+        col = {e: i for i, e in enumerate(distinct2)}
+        d = self.args.dim
+        embeds1 = self._apply_mapping(self._lookup(distinct1), self.mapping_mat)
+        embeds2 = self._lookup(distinct2)
+        sim_mat = sim(embeds1[:, :d].cpu().numpy(), embeds2[:, :d].cpu().numpy(), metric=self.args.eval_metric,
+                      normalize=self.args.eval_norm, csls_k=0)
+        uri1 = {v: k for k, v in self.kgs.kg1.entities_id_dict.items()}
+        uri2 = {v: k for k, v in self.kgs.kg2.entities_id_dict.items()}
+        res = [(uri1[a], uri2[b], sim_mat[row[a], col[b]]) for a, b in zip(ids1, ids2)]
+        if output_file_name is not None:
+            os.makedirs(self.out_folder, exist_ok=True)
+            with open(self.out_folder + output_file_name, 'w', encoding='utf8') as fh:
+                for entity1, entity2, confidence in res:
+                    fh.write(str(entity1) + "\t" + str(entity2) + "\t" + str(confidence) + "\n")
+            print(self.out_folder + output_file_name, "saved")
+        return res

@@ -165,3 +165,47 @@ def find_potential_alignment_greedily(sim, sim_th):
     """alignment_finder.py:8-9."""
     pairs, _ = find_alignment(sim, sim_th, 1)
     return None if pairs is None else set(pairs)
+
+
+# ---- the reference's host-matrix helpers under their own names (alignment_finder.py:54-140) --------------------------
+def filter_sim_mat(mat, threshold, greater=True, equal=False):
+    """alignment_finder.py:54-63: the (row, column) pairs on the chosen side of the threshold, as a set."""
+    mat = np.asarray(mat)
+    keep = (mat >= threshold if equal else mat > threshold) if greater else (mat <= threshold if equal else mat < threshold)
+    rows, cols = np.nonzero(keep)
+    return set(zip(rows, cols))
+
+
+def search_nearest_k(sim_mat, k):
+    """alignment_finder.py:66-76 on a host matrix: {(i, j)} for the k nearest columns j of every row i (np.argpartition,
+    like the reference; PairSim inputs go through the device search)."""
+    assert k > 0
+    if isinstance(sim_mat, PairSim):
+        near = search_nearest_k_device(sim_mat, k)
+    else:
+        near = np.argpartition(-np.asarray(sim_mat), k, axis=1)[:, :k]
+    pairs = {(i, j) for i in range(near.shape[0]) for j in near[i]}
+    assert len(pairs) == near.shape[0] * k
+    return pairs
+
+
+def _pair_weights(pairs, sim_mat):
+    pairs = list(pairs)
+    return pairs, np.array([sim_mat[i, j] for i, j in pairs], np.float64)
+
+
+def mwgm_igraph(pairs, sim_mat):
+    """alignment_finder.py:124-140 (igraph maximum_bipartite_matching = the exact maximum-weight matching)."""
+    pairs, weights = _pair_weights(pairs, sim_mat)
+    return max_weight_matching(pairs, weights)
+
+
+def mwgm_graph_tool(pairs, sim_mat):
+    """alignment_finder.py:83-121 (graph_tool's heuristic matching) -> the greedy weight-descending matching."""
+    pairs, weights = _pair_weights(pairs, sim_mat)
+    return greedy_weight_matching(pairs, weights)
+
+
+def mwgm(pairs, sim_mat, func):
+    """alignment_finder.py:79-80."""
+    return func(pairs, sim_mat)

@@ -143,6 +143,35 @@ def galeshapley_topk(cand, cand_sim, sim_lookup, max_iteration):
     return matching
 
 
+def arg_sort(idx, sim_mat, prefix1, prefix2):
+    """alignment.py:136-143: {prefix1 + row id: [prefix2 + column, ...] by descending similarity} (host matrix)."""
+    order = np.argsort(-np.asarray(sim_mat), axis=1)
+    return {prefix1 + str(idx[i]): [prefix2 + str(j) for j in order[i]] for i in range(len(idx))}
+
+
+def galeshapley(suitor_pref_dict, reviewer_pref_dict, max_iteration):
+    """alignment.py:170-224 with the reference's round structure (every unmatched suitor proposes once per round to the
+    head of its list; a rejected suitor drops that reviewer; at most max_iteration rounds), on rank tables instead of
+    list.index / `in dict.values()` scans.  Mutates the suitors' lists like the reference does."""
+    rank_of = {r: {s: i for i, s in enumerate(prefs)} for r, prefs in reviewer_pref_dict.items()}
+    matching, holder = {}, {}
+    waiting = list(suitor_pref_dict.keys())
+    for _ in range(max_iteration):
+        if not waiting:
+            break
+        for s in waiting:
+            r = suitor_pref_dict[s][0]
+            if r not in holder:
+                matching[s], holder[r] = r, s
+            elif rank_of[r][s] < rank_of[r][holder[r]]:
+                del matching[holder[r]]
+                matching[s], holder[r] = r, s
+            else:
+                suitor_pref_dict[s].remove(r)
+        waiting = list(set(suitor_pref_dict.keys()) - set(matching.keys()))
+    return matching
+
+
 def stable_alignment(embed1, embed2, metric, normalize, csls_k, nums_threads, cut=100, sim_mat=None):
     """alignment.py:87-134: stable (Gale-Shapley, at most `cut` rounds) matching of the two embedding blocks and
     its precision.  The similarity block stays on the device; each suitor's `cut` best reviewers come from the

@@ -92,3 +92,19 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
             del s
         return out
     return strip_means(t1, t2), (strip_means(t2, t1) if cols else None)
+
+
+# ---- the reference's thread- / block-parallel spellings of the same products (similarity.py:86-127) ------------------
+def sim_multi_threads(embeds1, embeds2, threads_num=16):
+    """np.dot of row blocks in a process pool in the reference (similarity.py:105-116): one device call here."""
+    return sim(embeds1, embeds2, metric='inner', normalize=False, csls_k=0)
+
+
+def sim_multi_blocks(embeds1, embeds2, blocks_num=16):
+    """similarity.py:119-127."""
+    return sim(embeds1, embeds2, metric='inner', normalize=False, csls_k=0)
+
+
+def csls_sim_multi_threads(sim_mat, k, nums_threads):
+    """similarity.py:86-102: calculate_nearest_k over row blocks = calculate_nearest_k."""
+    return calculate_nearest_k(sim_mat, k)

@@ -279,3 +279,15 @@ def save_embeddings(folder, kgs, ent_embeds, rel_embeds, attr_embeds, mapping_ma
     embed2file(folder, 'rel_embeds_txt', rel_embeds, kgs.kg1.relations_id_dict, kgs.kg2.relations_id_dict)
     embed2file(folder, 'attr_embeds_txt', attr_embeds, kgs.kg1.attributes_id_dict, kgs.kg2.attributes_id_dict)
     print("Embeddings saved!")
+
+
+def generate_sup_attribute_triples_one_link(e1, e2, av_dict):
+    """read.py:154-158: e1's attribute triples re-headed to e2."""
+    return {(e2, a, v) for a, v in av_dict.get(e1, set())}
+
+
+def radio_2file(radio, folder):
+    """read.py:311-315: <folder><ratio with '_' for '.'>/ (created)."""
+    path = folder + str(radio).replace('.', '_')
+    os.makedirs(path, exist_ok=True)
+    return path + '/'

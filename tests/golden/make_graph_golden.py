@@ -157,6 +157,18 @@ def main():
     b1, b2 = ref.bootea.generate_pos_batch(sorted(t1), sorted(t2), 2, 37)
     out['boot_pos_batch'] = np.array(list(b1) + list(b2), np.int64).reshape(-1, 3)
 
+    for name, (greater, equal) in (('gt', (True, False)), ('ge', (True, True)), ('lt', (False, False)), ('le', (False, True))):
+        th = float(sim_mat[3, 4]) if equal else 0.55            # an exact hit for the inclusive variants
+        out['boot_filter_' + name] = np.array(sorted(ref.finder.filter_sim_mat(sim_mat, th, greater, equal)), np.int64).reshape(-1, 2)
+        out['boot_filter_th_' + name] = np.array([th])
+    # Gale-Shapley on the reference's own preference dictionaries (alignment.py:136-143, 170-224)
+    idx = list(range(sim_mat.shape[0]))
+    for rounds in (3, 100):
+        suitors = ref.ali.arg_sort(idx, sim_mat, 'x', 'y')
+        reviewers = ref.ali.arg_sort(idx, sim_mat.T, 'y', 'x')
+        match = ref.ali.galeshapley(suitors, reviewers, rounds)
+        out['gs_match_%d' % rounds] = np.array(sorted((int(a[1:]), int(b[1:])) for a, b in match.items()), np.int64).reshape(-1, 2)
+
     # ---- stable matching (alignment.py:87-224) ----------------------------------------------------------------------
     for csls in (0, 5):
         buf = io.StringIO()

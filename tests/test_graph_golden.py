@@ -429,3 +429,29 @@ def test_alinet_2hop_array_form_equals_set_form(kgs):
     as_set = quiet(alinet.generate_2hop_triples, kg)
     as_arr = quiet(alinet.generate_2hop_triples, kg, as_array=True)
     assert as_arr.dtype == np.int64 and np.array_equal(as_arr, triples_sorted(as_set))
+
+
+def test_host_matrix_helpers_match_reference(g):
+    """alignment_finder.py:54-76 (filter_sim_mat, search_nearest_k) and alignment.py:136-224 (arg_sort, galeshapley with
+    its round limit) under the reference's names, on host matrices."""
+    from openea_amd.modules.bootstrapping import alignment_finder as af
+    from openea_amd.modules.finding import alignment as ali
+    sim_mat = np.matmul(g["boot_e1"], g["boot_e2"].T)
+    for name, (greater, equal) in (("gt", (True, False)), ("ge", (True, True)), ("lt", (False, False)), ("le", (False, True))):
+        got = af.filter_sim_mat(sim_mat, float(g["boot_filter_th_" + name][0]), greater, equal)
+        assert np.array_equal(np.array(sorted(got), np.int64).reshape(-1, 2), g["boot_filter_" + name])
+    near = af.search_nearest_k(sim_mat, 7)
+    assert np.array_equal(np.array(sorted((int(i), int(j)) for i, j in near), np.int64), g["boot_nearest_7"])
+    idx = list(range(sim_mat.shape[0]))
+    for rounds in (3, 100):
+        suitors = ali.arg_sort(idx, sim_mat, "x", "y")
+        reviewers = ali.arg_sort(idx, sim_mat.T, "y", "x")
+        match = ali.galeshapley(suitors, reviewers, rounds)
+        got = np.array(sorted((int(a[1:]), int(b[1:])) for a, b in match.items()), np.int64).reshape(-1, 2)
+        assert np.array_equal(got, g["gs_match_%d" % rounds])
+    # the matchers under the reference's names: one-to-one, and the exact one is at least as heavy as the greedy one
+    pairs = {(int(i), int(j)) for i, j in g["boot_find_0.5_5"]}
+    exact, greedy = af.mwgm(pairs, sim_mat, af.mwgm_igraph), af.mwgm(pairs, sim_mat, af.mwgm_graph_tool)
+    for m in (exact, greedy):
+        assert len({i for i, _ in m}) == len(m) == len({j for _, j in m}) and set(m) <= pairs
+    assert sum(sim_mat[i, j] for i, j in exact) >= sum(sim_mat[i, j] for i, j in greedy) - 1e-9

@@ -183,3 +183,39 @@ def test_bootea_rotate_end_to_end(kgs_small, tmp_path, capsys, sampling):
     assert ent.shape == (kgs.entities_num, 32) and ent.dtype == np.float64
     np.testing.assert_allclose(np.linalg.norm(ent, axis=1), 1.0, rtol=1e-12)
     assert np.load(m.out_folder + "rel_embeds.npy").shape == (kgs.relations_num, 32)
+
+
+def test_predict_and_predict_entities(kgs_small, tmp_path):
+    """basic_model.py:292-413: predict (top-k both ways / similarity floor) and predict_entities (listed URI pairs) against
+    the host similarity of the model's own embeddings; the thread / block spellings of sim give the same matrix."""
+    from openea_amd.approaches import AlignE
+    from openea_amd.modules.base import initializers
+    from openea_amd.modules.finding.similarity import sim, sim_multi_blocks, sim_multi_threads
+    initializers.seed(7)
+    kgs = kgs_small["swapping"]
+    m = AlignE()
+    m.set_args(_args("AlignE", tmp_path, dim=32, batch_size=2000, max_epoch=1))
+    m.set_kgs(kgs)
+    m.init()
+    e1, e2 = m.eval_kg1_ent_embeddings(), m.eval_kg2_ent_embeddings()
+    ref = np.matmul(e1, e2.T)
+    s = sim(e1, e2, metric="inner", normalize=False, csls_k=0)
+    np.testing.assert_allclose(s, ref, rtol=0, atol=1e-5)
+    assert np.array_equal(sim_multi_blocks(e1, e2, 4), s) and np.array_equal(sim_multi_threads(e1, e2, 2), s)
+    top = m.predict(top_k=1)
+    row_of = {v: i for i, v in enumerate(kgs.kg1.entities_list)}
+    col_of = {v: j for j, v in enumerate(kgs.kg2.entities_list)}
+    got = {(row_of[kgs.kg1.entities_id_dict[a]], col_of[kgs.kg2.entities_id_dict[b]]) for a, b, _ in top}
+    want = {(i, int(np.argmax(ref[i]))) for i in range(ref.shape[0])} | {(int(np.argmax(ref[:, j])), j) for j in range(ref.shape[1])}
+    assert len(got ^ want) <= 2                                     # argmax ties at fp32 resolution aside
+    floor = float(np.sort(ref.ravel())[-50])
+    assert 45 <= len(m.predict(top_k=None, min_sim_value=floor)) <= 55
+    pairs_file = tmp_path / "pairs.tsv"
+    uris1 = list(kgs.kg1.entities_id_dict.items())[:5]
+    uris2 = list(kgs.kg2.entities_id_dict.items())[:5]
+    pairs_file.write_text("".join("%s\t%s\n" % (a[0], b[0]) for a, b in zip(uris1, uris2)))
+    res = m.predict_entities(str(pairs_file), output_file_name="conf.tsv")
+    assert [r[:2] for r in res] == [(a[0], b[0]) for a, b in zip(uris1, uris2)]
+    for (_, _, conf), a, b in zip(res, uris1, uris2):
+        assert abs(conf - ref[row_of[a[1]], col_of[b[1]]]) < 1e-5
+    assert os.path.exists(m.out_folder + "conf.tsv")
