@@ -65,3 +65,29 @@ def init_embeddings(shape, name, init, is_l2_norm, dtype=None):
     else:
         raise ValueError("unknown init %r" % (init,))
     return EmbeddingTable(host, is_l2_norm, name)
+
+
+# ---- the reference's per-kind entry points (initializers.py:22-56) -> the same tables as init_embeddings -----------------
+def xavier_init(shape, name, is_l2_norm, dtype=None):
+    return init_embeddings(shape, name, 'xavier', is_l2_norm, dtype)
+
+
+def truncated_normal_init(shape, name, is_l2_norm, dtype=None):
+    return init_embeddings(shape, name, 'normal', is_l2_norm, dtype)
+
+
+def random_uniform_init(shape, name, is_l2_norm, minval=0, maxval=None, dtype=None):
+    from ...models.trainer import EmbeddingTable
+    host = _rng.uniform(minval, 1.0 if maxval is None else maxval, shape).astype(np.float32)
+    return EmbeddingTable(host, is_l2_norm, name)
+
+
+def random_unit_init(shape, name, is_l2_norm, dtype=None):
+    return init_embeddings(shape, name, 'unit', is_l2_norm, dtype)
+
+
+def orthogonal_init(shape, name, dtype=None):
+    """initializers.py:53-56 -> device fp32 [rows, cols] matrix (the mapping matrix of MTransE)."""
+    import torch
+    from ... import ops
+    return torch.from_numpy(orthogonal_host(_rng, tuple(shape))).to(ops.device())

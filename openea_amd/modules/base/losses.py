@@ -30,6 +30,12 @@ def alignment_loss():
     return dict(loss='align', loss_norm='L2')
 
 
+def mapping_loss():
+    """losses.py:76-80: sum ||e2 - e1 M||^2 + sum (M M^T - I)^2 (scaled by args.alpha in mapping.py:17) -- evaluated by
+    oea_mapping_step."""
+    return dict(loss='mapping', loss_norm='L2')
+
+
 def get_loss_func(args):
     """losses.py:4-12 (note: balance is NOT passed on this path, losses.py:11 -> default 1.0)."""
     if args.loss == 'margin-based':
