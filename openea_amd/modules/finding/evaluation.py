@@ -1,31 +1,35 @@
-"""valid / test / early_stop (mirror of openea/modules/finding/evaluation.py:6-33)."""
+"""valid / test / early_stop with the signatures of openea/modules/finding/evaluation.py:6-33; both wrappers are one
+call of greedy_alignment on (embeds1 [x mapping], embeds2)."""
 import numpy as np
 
 from .alignment import greedy_alignment
 
 
-def _map(embeds1, mapping):
-    if mapping is None:
-        return embeds1
-    if hasattr(embeds1, "is_cuda"):
-        raise TypeError("pass host arrays when a mapping matrix is given")
-    return np.matmul(embeds1, mapping)      # evaluation.py:11,22 (n x d times d x d, host)
+def _aligned(embeds1, embeds2, mapping, top_k, threads_num, metric, normalize, csls_k, accurate):
+    """-> (alignment_rest_12, hits1_12, mr_12, mrr_12); a mapping matrix is applied on the host (evaluation.py:11,22:
+    an n x d by d x d product), which needs host arrays."""
+    if mapping is not None:
+        if hasattr(embeds1, "is_cuda"):
+            raise TypeError("pass host arrays when a mapping matrix is given")
+        embeds1 = np.matmul(embeds1, mapping)
+    return greedy_alignment(embeds1, embeds2, top_k, threads_num, metric, normalize, csls_k, accurate)
 
 
 def valid(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False, csls_k=0, accurate=False):
-    _, hits1_12, mr_12, mrr_12 = greedy_alignment(_map(embeds1, mapping), embeds2, top_k, threads_num, metric,
-                                                  normalize, csls_k, accurate)
-    return hits1_12, mrr_12
+    """evaluation.py:6-14 -> (hits@1, mrr)."""
+    result = _aligned(embeds1, embeds2, mapping, top_k, threads_num, metric, normalize, csls_k, accurate)
+    return result[1], result[3]
 
 
 def test(embeds1, embeds2, mapping, top_k, threads_num, metric='inner', normalize=False, csls_k=0, accurate=True):
-    alignment_rest_12, hits1_12, mr_12, mrr_12 = greedy_alignment(_map(embeds1, mapping), embeds2, top_k, threads_num,
-                                                                  metric, normalize, csls_k, accurate)
-    return alignment_rest_12, hits1_12, mrr_12
+    """evaluation.py:17-25 -> (alignment pairs, hits@1, mrr)."""
+    result = _aligned(embeds1, embeds2, mapping, top_k, threads_num, metric, normalize, csls_k, accurate)
+    return result[0], result[1], result[3]
 
 
 def early_stop(flag1, flag2, flag):
-    if flag <= flag2 <= flag1:
+    """evaluation.py:28-33: stop when the metric fell twice in a row; -> (flag2, flag, stop)."""
+    stop = flag <= flag2 <= flag1
+    if stop:
         print("\n == should early stop == \n")
-        return flag2, flag, True
-    return flag2, flag, False
+    return flag2, flag, stop
