@@ -1,21 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json metric on MI355X.
 
-Workload (BASELINE.json configs[1]): BootEA/AlignE-style translational step -- truncated
-negative sampling (eps = 0.9 -> 1,499 neighbours, k = 10 negatives per positive) + limited
-loss + Adagrad -- on a synthetic KG pair with the EN-FR-15K-V1 shape (no dataset on disk),
-batch 5,000 positives per GPU, dim = 75 (BASELINE.json; the shipped bootea_args_15K.json
-uses 100: pass --dim 100).
+Workload (BASELINE.json configs[1]): BootEA/AlignE-style translational step -- truncated negative sampling
+(eps = 0.9 -> 1,499 neighbours, k = 10 negatives per positive) + limited loss + Adagrad -- on a synthetic KG pair with
+the EN-FR-15K-V1 shape (no dataset on disk), batch 5,000 positives per GPU, dim = 75 (BASELINE.json; the shipped
+bootea_args_15K.json uses 100: pass --dim 100).
 
-A "step" = sample the negatives of one batch on the device + one fused optimiser step.
-value = positives (training triples) consumed per second, whole job.
+A "step" = the negatives of one batch drawn on the device + one fused optimiser step, enqueued the way the product
+does it (RelationTripleEpochs.run_steps -> oea_triple_epoch_range: ONE C call per epoch touched, next epoch's shuffle
+and negatives on a side stream).  value = positives (training triples) consumed per second, whole job.
 
   python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
 
-One JSON line on stdout (rank 0).  Extra legs, outside the timed region:
-  * roofline   -- dominant kernel (triple_fwd_bwd) timed with HIP events on its stream
-  * cpu_baseline -- the C oracle port of the same step on ONE host core, bounded sample
-  * extra      -- alignment-eval pairs/s (10,500 test pairs, inner + CSLS) and neighbour-search rows/s
+Timing: W untimed warm-up steps, then the K-step region -- barrier + synchronize on both sides, MAX over ranks --
+is timed --repeats times (default 50) and the MEDIAN region is reported (a single region is ~1 ms at this shape: one
+sample of it says little).  All region times are in `regions_ms`.
+
+One JSON line on stdout (rank 0) with, besides the contract's keys:
+  roofline      dominant kernel (triple_grouped, fwd + bwd): HIP events on its stream, algorithmic bytes (SURVEY 8d:
+                24*d B per scored triple), counter traffic from the committed rocprofv3 FETCH/WRITE passes of the same
+                command (profiles/traffic_<shape>.json), `frac` = algorithmic, `hbm_frac` = counter bytes, `step_frac` =
+                algorithmic bytes of the whole step (scoring + Adagrad on the touched rows) over the step's wall time
+  cpu_baseline  the C oracle port of the same step on 1 host thread and on all host cores (OpenMP), bounded sample;
+                the reference's own numpy functions cannot travel to the GPU box: their timings (BASELINE.md, section 3,
+                measured in the build container) are quoted with provenance
+  extra         the EN-FR-100K-V1 shape (dim 100, batch 20,000, eps 0.98 -> k = 2,000; tables 80 MB: HBM / Infinity
+                Cache traffic means something there) measured the same way, alignment-eval pairs/s and neighbour rows/s
 """
 import argparse
 import json
@@ -29,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_STRIDE = 8        # HIP-event marks on every 8th step of the timed region (a record costs ~3 us of enqueue)
+PROFILE_STRIDE = 8        # HIP-event marks on every 8th step of the timed regions (a record costs ~3 us of enqueue)
 
 
 def parse():
@@ -37,23 +47,131 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=50, help="timed K-step regions (median reported)")
     ap.add_argument("--dim", type=int, default=75)
     ap.add_argument("--shape", default="EN-FR-15K-V1")
     ap.add_argument("--batch", type=int, default=5000, help="positives per GPU per step")
     ap.add_argument("--neg", type=int, default=10)
     ap.add_argument("--eps", type=float, default=0.9, help="truncated_epsilon")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour / 100K-shape legs")
     return ap.parse_args()
+
+
+class Workload:
+    """tables + samplers + trainer of one shape, and the timed K-step regions on it"""
+
+    def __init__(self, torch, ops, shape, dim, batch, neg, eps, dev, rank=0, world=1, group=None):
+        from openea_amd.models.trainer import EmbeddingTable, RelationTripleEpochs, TripleTrainer, refresh_neighbours
+        from openea_amd.modules.base.initializers import truncated_normal_host
+        from openea_amd.modules.load.synth import make_kgs
+        self.torch, self.ops, self.shape, self.d, self.batch, self.neg, self.eps = torch, ops, shape, dim, batch, neg, eps
+        self.world, self.rank = world, rank
+        # ---- data + model state (identical on every rank: same seeds) ---------------------------------
+        self.kgs = kgs = make_kgs(shape, mode="swapping", seed=0)
+        rng = np.random.RandomState(1)
+        self.ent = EmbeddingTable(truncated_normal_host(rng, (kgs.entities_num, dim), 1.0 / np.sqrt(dim)), True, "ent_embeds", dev)
+        self.rel = EmbeddingTable(truncated_normal_host(rng, (kgs.relations_num, dim), 1.0 / np.sqrt(dim)), True, "rel_embeds", dev)
+        cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
+                                ent_l2_norm=True, rel_l2_norm=True, optimizer="Adagrad", lr=0.01, neg_group_k=neg)
+        self.trainer = TripleTrainer(self.ent, self.rel, cfg, "Adagrad", dist_group=group)
+        self.epochs = RelationTripleEpochs(kgs, batch * world, neg, seed=2, dev=dev, rank=rank, world=world)
+        self.k1 = int((1 - eps) * kgs.kg1.entities_num)      # basic_model.py:270-271 (1499 at eps=0.9, N=15000)
+        self.k2 = int((1 - eps) * kgs.kg2.entities_num)
+        t0 = time.time()
+        nbr1 = refresh_neighbours(self.ent, kgs.kg1.entities_list, self.k1)
+        nbr2 = refresh_neighbours(self.ent, kgs.kg2.entities_list, self.k2)
+        torch.cuda.synchronize()
+        self.nbr_first_s = time.time() - t0
+        self.epochs.set_neighbours(nbr1, nbr2)
+        self.steps_per_epoch = len(self.epochs.batches.splits)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup, repeats):
+        """-> dict(times_s [repeats] (max over ranks), pos [repeats] (all ranks), kernel marks)."""
+        torch, ops, ep, tr = self.torch, self.ops, self.epochs, self.trainer
+        # priming (untimed, before the W warm-up steps): one whole epoch + its end-of-epoch shuffle, so that the
+        # first-use costs of the enqueue path and of the permutation kernels are not inside the timed regions
+        ep.run_steps(tr, self.steps_per_epoch - ep.in_epoch)
+        ep.run_steps(tr, warmup)
+        self.barrier()
+        ops.profile_begin(stride=PROFILE_STRIDE)
+        times, pos = [], []
+        for _ in range(repeats):
+            self.barrier()
+            t0 = time.perf_counter()
+            n = ep.run_steps(tr, steps)                 # exactly K optimiser steps
+            self.barrier()
+            times.append(time.perf_counter() - t0)
+            pos.append(n)
+        (fwd_ms, _gap_ms, apply_ms), n_calls = ops.profile_end(4)
+        loss = tr.pop_loss()
+        ep.check()
+        t = torch.tensor(times, dtype=torch.float64, device=self.ent.var.device)
+        c = torch.tensor(pos, dtype=torch.float64, device=self.ent.var.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        return dict(times=t.cpu().numpy(), pos=c.cpu().numpy(), pos_local=np.asarray(pos, np.float64),
+                    fwd_ms=fwd_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss)
+
+    def summarize(self, m, steps):
+        """median region -> (value, ms_per_step, roofline dict)"""
+        order = np.argsort(m["times"])
+        i_med = int(order[len(order) // 2])
+        t_med = float(m["times"][i_med])
+        value = float(m["pos"][i_med]) / t_med
+        ms_per_step = t_med / steps * 1e3
+        d, neg = self.d, self.neg
+        launches = max(m["n_calls"], 1)
+        scored_per_launch = float(m["pos_local"].mean()) / steps * (1 + neg)       # this rank's triples per launch
+        alg_bytes = 24.0 * d * scored_per_launch                                   # SURVEY 8d: 24*d B per scored triple
+        fwd_s = m["fwd_ms"] / 1e3 / launches
+        apply_s = m["apply_ms"] / 1e3 / launches
+        achieved = alg_bytes / fwd_s / 1e9 if fwd_s > 0 else 0.0
+        traffic = _traffic(self.shape, d, self.batch, neg, self.world)
+        # whole step: scoring + Adagrad (20*d B per touched row; touched rows <= unique ids of the batch, estimated
+        # by the table rows here: at both shapes a batch touches most of the table)
+        touched = min(self.kgs.entities_num + self.kgs.relations_num, scored_per_launch * 2)
+        step_bytes = alg_bytes + 20.0 * d * touched
+        roofline = {"kernel": "triple_grouped (fwd + bwd)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "hbm_frac": round(traffic / fwd_s / 1e9 / HBM_PEAK_GBS, 4) if (traffic and fwd_s > 0) else None,
+                    "step_frac": round(step_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "avg_kernel_us": round(fwd_s * 1e6, 2), "apply_rows_avg_us": round(apply_s * 1e6, 2),
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_per_step": int(step_bytes),
+                    "launches_timed": int(m["n_calls"]),
+                    "note": "frac = algorithmic bytes / kernel time / peak: the tables are cache-resident (L2 / Infinity "
+                            "Cache), so it is NOT an HBM-bandwidth figure; hbm_frac = rocprofv3 FETCH/WRITE counter bytes "
+                            "(2*FETCH+WRITE, gfx950 correction) / kernel time / peak; the kernel is latency-bound at 15K"}
+        return value, ms_per_step, roofline
+
+
+def _traffic(shape, d, batch, neg, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this very workload, else None"""
+    p = os.path.join(ROOT, "profiles", "traffic_%s.json" % shape)
+    if world != 1 or not os.path.exists(p):
+        return None
+    try:
+        tj = json.load(open(p))
+        if tj.get("workload") == [shape, d, batch, neg]:
+            return tj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def main():
     args = parse()
     import torch
     from openea_amd import ops
-    from openea_amd.models.trainer import (EmbeddingTable, RelationTripleEpochs, TripleTrainer,
-                                            refresh_neighbours)
-    from openea_amd.modules.load.synth import make_kgs
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,125 +193,64 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
-    # ---- data + model state (identical on every rank: same seeds) ---------------------------------
-    kgs = make_kgs(args.shape, mode="swapping", seed=0)
-    d = args.dim
-    rng = np.random.RandomState(1)
-    from openea_amd.modules.base.initializers import truncated_normal_host
-    ent = EmbeddingTable(truncated_normal_host(rng, (kgs.entities_num, d), 1.0 / np.sqrt(d)), True, "ent_embeds", dev)
-    rel = EmbeddingTable(truncated_normal_host(rng, (kgs.relations_num, d), 1.0 / np.sqrt(d)), True, "rel_embeds", dev)
-    cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
-                            ent_l2_norm=True, rel_l2_norm=True, optimizer="Adagrad", lr=0.01, neg_group_k=args.neg)
-    trainer = TripleTrainer(ent, rel, cfg, "Adagrad", dist_group=group)
-    epochs = RelationTripleEpochs(kgs, args.batch * world, args.neg, seed=2, dev=dev, rank=rank, world=world)
-    k1 = int((1 - args.eps) * kgs.kg1.entities_num)      # basic_model.py:270-271 (1499 at eps=0.9, N=15000)
-    k2 = int((1 - args.eps) * kgs.kg2.entities_num)
-    t0 = time.time()
-    nbr1 = refresh_neighbours(ent, kgs.kg1.entities_list, k1)
-    nbr2 = refresh_neighbours(ent, kgs.kg2.entities_list, k2)
-    torch.cuda.synchronize()
-    nbr_first_s = time.time() - t0
-    epochs.set_neighbours(nbr1, nbr2)
-
-    steps_per_epoch = len(epochs.batches.splits)
-
-    def run_steps(n_steps):
-        """n_steps optimiser steps = whole epochs (one enqueue call each on a single GPU) plus a
-        per-step tail; returns (positives consumed, triples scored) on this rank."""
-        npos = nscored = 0
-        done = 0
-        while done < n_steps:
-            s = epochs.global_step % steps_per_epoch
-            if s == 0 and n_steps - done >= steps_per_epoch:
-                n = epochs.run_epoch(trainer)
-                npos += n
-                nscored += n * (1 + args.neg)
-                done += steps_per_epoch
-                continue
-            pos, neg = epochs.batch(s)
-            if pos.shape[0] or world > 1:                     # DP: every rank joins every exchange, rows or not
-                trainer.step(pos, neg)
-            npos += pos.shape[0]
-            nscored += pos.shape[0] * (1 + args.neg)
-            done += 1
-            if epochs.global_step % steps_per_epoch == 0:
-                epochs.end_epoch()
-        return npos, nscored
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # priming (untimed, before the W warm-up steps): one whole epoch + its end-of-epoch shuffle, so that the
-    # first-use costs of both enqueue paths and of the permutation kernels are not inside the timed region
-    run_steps(steps_per_epoch - epochs.global_step % steps_per_epoch)
-    run_steps(args.warmup)
-    barrier()
-    ops.profile_begin(stride=PROFILE_STRIDE)
-    t0 = time.perf_counter()
-    n_pos_total, n_scored = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    (fwd_ms, _gap_ms, apply_ms), n_calls = ops.profile_end(4)
-    epoch_loss = trainer.pop_loss()
-    epochs.check()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([n_pos_total], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t.item())
-    total_pos = float(cnt.item())
-
+    wl = Workload(torch, ops, args.shape, args.dim, args.batch, args.neg, args.eps, dev, rank, world, group)
+    m = wl.measure(args.steps, args.warmup, args.repeats)
     if rank != 0:
         return
-    value = total_pos / elapsed_max
+    value, ms_per_step, roofline = wl.summarize(m, args.steps)
+    exchange = None
+    if world > 1:
+        exchange = wl.trainer.exchange_bytes_per_step()
 
-    # ---- roofline of the dominant kernel (per launch, this rank) ---------------------------------
-    launches = max(n_calls, 1)
-    alg_bytes_per_launch = 24.0 * d * (n_scored / max(args.steps, 1))     # SURVEY 8d: 24*d B per scored triple
-    fwd_avg_s = fwd_ms / 1e3 / launches
-    achieved = alg_bytes_per_launch / fwd_avg_s / 1e9 if fwd_avg_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_triple_fwd_bwd.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            # PMC traffic was collected on the default workload; it says nothing about another shape
-            same = (args.shape, args.dim, args.batch, args.neg) == ("EN-FR-15K-V1", 75, 5000, 10) and world == 1
-            traffic = tj.get("hbm_bytes_per_launch") if same else None
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "triple_fwd_bwd", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_kernel_us": round(fwd_avg_s * 1e6, 2), "apply_rows_avg_us": round(apply_ms / launches * 1e3, 2),
-                "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                "launches_timed": int(n_calls), "launches_total": int(args.steps)}
-
-    extra = {"neighbour_refresh_first_call_s": round(nbr_first_s, 3), "epoch_loss_sum": epoch_loss,
-             "triple_steps_per_epoch": steps_per_epoch, "neighbours_k": [k1, k2]}
+    extra = {"neighbour_refresh_first_call_s": round(wl.nbr_first_s, 3), "epoch_loss_sum": m["loss"],
+             "triple_steps_per_epoch": wl.steps_per_epoch, "neighbours_k": [wl.k1, wl.k2],
+             "regions_ms": [round(float(x) * 1e3, 4) for x in m["times"]],
+             "ms_per_step_min": round(float(m["times"].min()) / args.steps * 1e3, 4),
+             "ms_per_step_max": round(float(m["times"].max()) / args.steps * 1e3, 4)}
+    if exchange is not None:
+        extra["exchange_bytes_per_step_per_rank"] = exchange
     if not args.no_extra and world == 1:
-        extra.update(extra_legs(torch, ops, ent, kgs, d, k1))
+        extra.update(extra_legs(torch, ops, wl.ent, wl.kgs, args.dim, wl.k1))
     cpu = None
     if not args.no_cpu and world == 1:
-        cpu = cpu_baseline(kgs, d, args, k1, k2)
+        cpu = cpu_baseline(wl.kgs, args.dim, args, wl.k1, wl.k2)
+    if not args.no_extra and world == 1 and args.shape == "EN-FR-15K-V1":
+        del wl
+        torch.cuda.empty_cache()
+        extra["shape_100k"] = shape_100k(torch, ops, dev, args)
 
     out = {
         "metric": "training triples/sec (positives consumed; truncated negative sampling k=%d + limited loss + Adagrad)" % args.neg,
         "value": round(value, 1), "unit": "triples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "repeats": args.repeats, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BootEA/AlignE translational step, %s shape (synthetic), dim=%d, batch=%d positives/GPU, "
-                               "k=%d, truncated eps=%.2f" % (args.shape, d, args.batch, args.neg, args.eps),
-                   "entities": kgs.entities_num, "relations": kgs.relations_num,
-                   "parallelism": "dp%d" % world if world > 1 else "single"},
+                               "k=%d, truncated eps=%.2f; extra.shape_100k: EN-FR-100K-V1 shape, dim=100, batch=20000, eps=0.98"
+                               % (args.shape, args.dim, args.batch, args.neg, args.eps),
+                   "entities": extra_entities(args.shape), "parallelism": "dp%d" % world if world > 1 else "single",
+                   "timing": "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (args.repeats, args.steps),
+                   "parity_note": "TF1 op semantics / optimiser arithmetic are restated, not executed (no TensorFlow "
+                                  "here): SURVEY H1/H3/H4, DESIGN.md section 5"},
         "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
     }
     print(json.dumps(out))
+
+
+def extra_entities(shape):
+    from openea_amd.modules.load.synth import SHAPES
+    return 2 * SHAPES[shape][0]
+
+
+def shape_100k(torch, ops, dev, args):
+    """EN-FR-100K-V1 shape (bootea_args_100K.json: dim 100, batch 20,000, truncated_epsilon 0.98, k = 10)."""
+    wl = Workload(torch, ops, "EN-FR-100K-V1", 100, 20000, 10, 0.98, dev)
+    steps = min(args.steps, 58)
+    m = wl.measure(steps, min(args.warmup, 10), max(5, min(args.repeats, 20)))
+    value, ms_per_step, roofline = wl.summarize(m, steps)
+    return {"workload": "EN-FR-100K-V1 shape (synthetic), dim=100, batch=20000, k=10, truncated eps=0.98 (k_nbr=%d)" % wl.k1,
+            "value": round(value, 1), "unit": "triples/s", "ms_per_step": round(ms_per_step, 4), "steps": steps,
+            "repeats": len(m["times"]), "roofline": roofline, "neighbour_refresh_first_call_s": round(wl.nbr_first_s, 3),
+            "triple_steps_per_epoch": wl.steps_per_epoch}
 
 
 def extra_legs(torch, ops, ent, kgs, d, k1):
@@ -230,20 +287,29 @@ def extra_legs(torch, ops, ent, kgs, d, k1):
     return out
 
 
+# the reference's OWN numpy functions (imported in place) timed in the build
+# container (8 host cores, numpy 2.2.6 / OpenBLAS); they cannot run on the GPU box (/root/reference is not there)
+REFERENCE_TIMINGS = {
+    "provenance": "BASELINE.md section 3: reference functions imported from /root/reference, build container, 8 cores",
+    "generate_neg_triples_fast_truncated_neg_per_s_per_core": 6.3e4,
+    "generate_neighbours_single_thread_rows_per_s_15000x100_k1500": 2062,
+    "find_neighbours_rows_per_s_100000x100_k2000": 618,
+    "greedy_alignment_pairs_per_s_10500_inner_1thread": 4548,
+    "greedy_alignment_pairs_per_s_10500_inner_csls10": 813,
+    "greedy_alignment_pairs_per_s_10500_manhattan": 551,
+}
+
+
 def cpu_baseline(kgs, d, args, k1, k2):
-    """The C oracle port of the same step (sampler + fused step), ONE host thread, a bounded
-    sample of the same workload.  Reported baseline, not the target."""
-    os.environ["OMP_NUM_THREADS"] = "1"
+    """The C oracle port of the same step (sampler + fused step) on ONE host thread and on ALL host cores (OpenMP), each
+    on a bounded sample of the same workload.  Reported baseline, not the target."""
     from oracle import cport
-    rng = np.random.RandomState(1)
     from openea_amd.modules.base.initializers import truncated_normal_host
-    ent = truncated_normal_host(rng, (kgs.entities_num, d), 1.0 / np.sqrt(d))
-    rel = truncated_normal_host(rng, (kgs.relations_num, d), 1.0 / np.sqrt(d))
-    ent_acc, rel_acc = np.full_like(ent, 0.1), np.full_like(rel, 0.1)
     t1 = np.asarray(kgs.kg1.relation_triples_list, np.int32)
     t2 = np.asarray(kgs.kg2.relation_triples_list, np.int32)
     b1 = int(len(t1) / (len(t1) + len(t2)) * args.batch)
     b2 = args.batch - b1
+    rng = np.random.RandomState(1)
     # candidate lists: uniform-random neighbour lists of the right length (the cost of sampling does
     # not depend on which ids are in the list; computing the real top-k on one core would blow the budget)
     tabs, ents, eposs, nbrs = [], [], [], []
@@ -255,24 +321,38 @@ def cpu_baseline(kgs, d, args, k1, k2):
         ents.append(e)
         eposs.append(ep)
         nbrs.append(e[rng.randint(0, len(e), (len(e), k))].astype(np.int32))
-    steps, t0 = 0, time.perf_counter()
     per_epoch = max(min(len(t1) // b1, len(t2) // b2), 1)
-    while True:
-        s_ = steps % per_epoch
-        p1 = t1[s_ * b1:(s_ + 1) * b1]
-        p2 = t2[s_ * b2:(s_ + 1) * b2]
-        n1 = cport.sample_negatives(p1, args.neg, tabs[0], ents[0], eposs[0], nbrs[0], seed=2, step=steps)
-        n2 = cport.sample_negatives(p2, args.neg, tabs[1], ents[1], eposs[1], nbrs[1], seed=2, step=steps)
-        cport.triple_step(ent, ent_acc, rel, rel_acc, np.concatenate([p1, p2]), np.concatenate([n1, n2]),
-                          loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
-                          optimizer="Adagrad", lr=0.01)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > 12.0:
-            break
-    return {"value": round(steps * args.batch / el, 1), "unit": "triples/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of the same workload (batch %d, k=%d, dim=%d): oracle/c/oracle.c sampler + step, "
-                      "fp64 internals, 1 thread, %.1f s" % (steps, args.batch, args.neg, d, el)}
+
+    def run(threads, budget_s):
+        cport.set_num_threads(threads)
+        ent = truncated_normal_host(np.random.RandomState(1), (kgs.entities_num, d), 1.0 / np.sqrt(d))
+        rel = truncated_normal_host(np.random.RandomState(2), (kgs.relations_num, d), 1.0 / np.sqrt(d))
+        ent_acc, rel_acc = np.full_like(ent, 0.1), np.full_like(rel, 0.1)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            s_ = steps % per_epoch
+            p1 = t1[s_ * b1:(s_ + 1) * b1]
+            p2 = t2[s_ * b2:(s_ + 1) * b2]
+            n1 = cport.sample_negatives(p1, args.neg, tabs[0], ents[0], eposs[0], nbrs[0], seed=2, step=steps)
+            n2 = cport.sample_negatives(p2, args.neg, tabs[1], ents[1], eposs[1], nbrs[1], seed=2, step=steps)
+            cport.triple_step(ent, ent_acc, rel, rel_acc, np.concatenate([p1, p2]), np.concatenate([n1, n2]),
+                              loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
+                              optimizer="Adagrad", lr=0.01)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s:
+                return steps, el
+    host_cores = os.cpu_count()
+    s1, e1 = run(1, 10.0)
+    sa, ea = run(host_cores, 8.0)
+    return {"value": round(max(s1 * args.batch / e1, sa * args.batch / ea), 1), "unit": "triples/s",
+            "cores": host_cores if sa * args.batch / ea >= s1 * args.batch / e1 else 1, "kind": "port",
+            "host_cores": host_cores,
+            "value_1_thread": round(s1 * args.batch / e1, 1), "value_all_cores": round(sa * args.batch / ea, 1),
+            "sample": "%d steps on 1 thread (%.1f s) and %d steps on %d OpenMP threads (%.1f s) of the same workload (batch %d, "
+                      "k=%d, dim=%d): oracle/c/oracle.c sampler + step, fp64 internals; the box has %d host cores"
+                      % (s1, e1, sa, host_cores, ea, args.batch, args.neg, d, host_cores),
+            "reference_functions": REFERENCE_TIMINGS}
 
 
 if __name__ == "__main__":

@@ -87,7 +87,7 @@ int oea_fill_f32(float *p, int64_t n, float value, void *stream);
  * ------------------------------------------------------------------------------------- */
 enum { OEA_LOSS_MARGIN = 0, OEA_LOSS_LIMITED = 1, OEA_LOSS_LOGISTIC = 2, OEA_LOSS_POSITIVE = 3,
        OEA_LOSS_ALIGN = 4 };
-enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1, OEA_OPT_ADAM = 2 /* oea_rotate_step only */ };
+enum { OEA_OPT_SGD = 0, OEA_OPT_ADAGRAD = 1, OEA_OPT_ADAM = 2, OEA_OPT_ADADELTA = 3 };
 enum { OEA_SCORE_TRANSE = 0, OEA_SCORE_TRANSH = 1, OEA_SCORE_TRANSD = 2 };
 
 typedef struct oea_step_cfg {
@@ -118,6 +118,13 @@ typedef struct oea_step_cfg {
     int32_t rel_transfer_base; /* TransD: `rel` has 2*base rows, [0, base) = rel_embeds, [base, 2 base) = rel_transfer;
                                   triple ids stay in [0, base); both halves share the l2_norm flag and the optimiser
                                   (transd.py:16-24), so scratch, exchange and apply see ordinary rows */
+    /* OEA_OPT_ADAM / OEA_OPT_ADADELTA (optimizers.py:13-16; tf.train defaults): the update is DENSE -- the tables are
+     * l2_normalize(variable), the gather gradient comes back through it as a dense tensor -- so every row moves every
+     * step.  ent_acc / rel_acc then hold [2, rows, ld]: Adam (m, v) zeros; Adadelta (accum, accum_update) zeros. */
+    float beta1;         /* Adam beta1 = 0.9;  Adadelta rho = 0.95 */
+    float beta2;         /* Adam beta2 = 0.999 */
+    float eps;           /* 1e-8 */
+    int32_t opt_t;       /* Adam: 1-based step count of THIS optimiser instance */
 } oea_step_cfg;
 
 /* Workspace owned by the caller, sized by oea_step_workspace_bytes(); must be zero-initialised
@@ -127,7 +134,7 @@ size_t oea_step_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld);
 /* One optimiser step.  pos/neg: int32 [n,3].  For OEA_LOSS_MARGIN n_neg must equal n_pos
  * (pairs aligned, losses.py:26); neg may be NULL when n_neg == 0 (positive / align losses).
  * ent_acc / rel_acc: Adagrad accumulators (same shape as the tables, initial value 0.1 =
- * tf.train.AdagradOptimizer default), ignored for SGD.
+ * tf.train.AdagradOptimizer default), ignored for SGD; Adam / Adadelta: [2, rows, ld] (see oea_step_cfg).
  * loss_accum: device double; the batch loss (sum over the batch, as in the reference) is
  * ADDED to it, so an epoch's loss is read back once (basic_model.py:231-233). */
 int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
@@ -270,6 +277,18 @@ int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, floa
                      const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
                      int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
                      const int64_t *offsets_dev, const int64_t *splits_dev, void *stream);
+/* The same for steps [step_begin, step_end) of the epoch only (a caller that stops or resumes inside an epoch -- e.g.
+ * a benchmark timing K steps -- still enqueues them with one call).  step_base is the Philox step of the epoch's
+ * step 0.  A range with step_begin == 0 draws the whole epoch's negatives into neg_buf in one launch when the device
+ * layout is given; a later range of the same epoch either passes side0 == side1 == NULL (neg_buf still holds them) or
+ * both sides (its steps are then drawn again batch by batch -- identical draws). */
+int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                           int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                           const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                           const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                           uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                           void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                           void *stream);
 
 /* Negative LINKS of AliNet.generate_input_batch (approaches/alinet.py:988-1006), drawn on the device.
  *   uniform   (nbr1 == NULL): pair q = round * n_pos + i, round < k:  (ents1[pi1_round(i)], ents2[pi2_round(i)])

@@ -22,7 +22,8 @@ class StepCfg(C.Structure):
                 ("ent_l2_norm", C.c_int32), ("rel_l2_norm", C.c_int32), ("opt_kind", C.c_int32),
                 ("lr", C.c_float), ("neg_group_k", C.c_int32), ("score_kind", C.c_int32),
                 ("normal", C.c_void_p), ("normal_acc", C.c_void_p),
-                ("ent_transfer_base", C.c_int32), ("rel_transfer_base", C.c_int32)]
+                ("ent_transfer_base", C.c_int32), ("rel_transfer_base", C.c_int32),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("opt_t", C.c_int32)]
 
 
 class SamplerSide(C.Structure):
@@ -53,7 +54,7 @@ class RotateCfg(C.Structure):
 
 
 LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
-OPT_KIND = {"SGD": 0, "Adagrad": 1, "Adam": 2}       # Adam: oea_rotate_step only
+OPT_KIND = {"SGD": 0, "Adagrad": 1, "Adam": 2, "Adadelta": 3}
 METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2}
 
 _vp, _i32, _i64, _u32, _u64, _f32, _sz = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64,
@@ -95,6 +96,9 @@ PROTOTYPES = {
     "oea_triple_epoch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32,
                                    C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
                                    C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp]),
+    "oea_triple_epoch_range": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                         C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
+                                         C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp]),
     "oea_rotate_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oea_rotate_exchange_doubles": (_sz, [_i64, _i64, _i32]),
     "oea_rotate_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _i32,

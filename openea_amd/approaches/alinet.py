@@ -10,8 +10,11 @@ transforms are plain library GEMMs; Adam is csrc/optim.hip.
 TF1 op semantics restated, not executed (the composition of the model is pinned by the reference's own
 _generate_rel_graph run under a numpy stand-in, tests/golden/tf_graphs.npz): BatchNormalization is called
 without `training=` -> inference mode with never-updated moving statistics, i.e. the per-feature
-affine y = gamma * x / sqrt(1 + 1e-3) + beta; tf.sparse_softmax grouping is selectable
-(`attn_grouping`: 'row' = per row, 'runs' = TF1 CPU consecutive-run behaviour).
+affine y = gamma * x / sqrt(1 + 1e-3) + beta; what tf.sparse_softmax does with the column-major adjacency
+is selectable (`args.attn_grouping`): 'runs' (default; SURVEY H3: consecutive runs of equal rows), 'row' (per row), 'reorder'
+(sorted copy normalised per row, values re-attached in sorted order: models/graph_ops.py:ReorderAttnFn) -- all three are
+pinned by the reference's own graph code under the matching stand-in (tests/golden/tf_graphs.npz: alinet_*, alinet_row_*,
+alinet_reorder_*).
 """
 import math
 import random
@@ -23,6 +26,7 @@ import torch
 
 from .. import ops
 from ..models.basic_model import BasicModel
+from ..modules.base.optimizers import generate_optimizer
 from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
 from ..modules.finding.evaluation import early_stop
 from ..modules.load import read as rd
@@ -360,7 +364,7 @@ class AliNet(BasicModel):
     def __init__(self):
         super().__init__()
         self.is_two = True
-        self.attn_grouping = 'row'
+        self.attn_grouping = 'runs'
         self.new_links = set()
         self.sup_links_set = set()
         self.new_sup_links_set = set()
@@ -401,7 +405,7 @@ class AliNet(BasicModel):
         random.seed(self._seed)
         self._get_variable()
         self._define_model()
-        self.optimizer = TFAdam(self._params, self.args.learning_rate)
+        self.optimizer = generate_optimizer(None, self.args.learning_rate, var_list=self._params, opt='Adam')     # alinet.py:871
 
     def _get_variable(self):
         self.init_embedding = glorot_uniform(self._rng, (self.kgs.entities_num, self.args.layer_dims[0]), self.dev)

@@ -219,8 +219,8 @@ class GCN_Align(BasicModel):
         neg2_right = ops.to_ids(np.repeat(train_links[:, 1], neg_num).astype(np.int32), dev)
         neg2_left = neg_right = None
         rng = np.random.RandomState(self._seed + 7)
+        last_report, t_report = 0, time.time()
         for i in range(1, self.args.max_epoch + 1):
-            start = time.time()
             if i % 10 == 1:
                 neg2_left = self._negatives(rng, train_num, neg_num, dev)
                 neg_right = self._negatives(rng, train_num, neg_num, dev)
@@ -230,8 +230,14 @@ class GCN_Align(BasicModel):
                 self.model_ae.train_step(negs)
             self.model_se.train_step(negs)
             if i % 10 == 0 or i == 1:          # the reference prints every epoch; one sync per 10 here
-                batch_loss = self.model_se.pop_loss() + (self.model_ae.pop_loss() if self.model_ae else 0.0)
-                print('epoch {}, avg. relation triple loss: {:.4f}, cost time: {:.4f}s'.format(i, batch_loss, time.time() - start))
+                # the device accumulator holds the SUM over the epochs since the last read-back: report the per-epoch
+                # mean (comparable with the reference's per-epoch value); the read-back synchronises, so the time is
+                # the wall time of those epochs divided by their number
+                n_ep = i - last_report
+                batch_loss = (self.model_se.pop_loss() + (self.model_ae.pop_loss() if self.model_ae else 0.0)) / n_ep
+                now = time.time()
+                print('epoch {}, avg. relation triple loss: {:.4f}, cost time: {:.4f}s'.format(i, batch_loss, (now - t_report) / n_ep))
+                last_report, t_report = i, now
             if i >= self.args.start_valid and i % self.args.eval_freq == 0:
                 flag = self.valid_(self.args.stop_metric)
                 self.flag1, self.flag2, self.early_stop = early_stop(self.flag1, self.flag2, flag)

@@ -27,6 +27,7 @@ import torch
 
 from .. import ops
 from ..models.basic_model import BasicModel
+from ..modules.base.optimizers import generate_optimizer
 from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
 from ..modules.finding.evaluation import early_stop, test, valid
 from ..modules.load import read as rd
@@ -126,7 +127,7 @@ class AlignLossL1(torch.autograd.Function):
 class Layer:
     """rdgcn.py:162-338."""
 
-    def __init__(self, args, kgs, embedding, dev, seed=0, attn_grouping='row'):
+    def __init__(self, args, kgs, embedding, dev, seed=0, attn_grouping='runs'):
         self.args, self.dev = args, dev
         self.dim = args.dim
         self.gamma, self.k, self.alpha, self.beta = args.gamma, args.neg_triple_num, args.alpha, args.beta
@@ -279,17 +280,24 @@ class RDGCN(BasicModel):
         super().__init__()
         self.word_embed = '../../datasets/wiki-news-300d-1M.vec'
         self.local_name_vectors = None
-        self.attn_grouping = 'row'
+        self.attn_grouping = 'runs'
 
     def init(self):
         self.dev = ops.device()
         if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0:
             raise NotImplementedError("dropout > 0 is not built (every shipped args file uses 0)")
-        if self.local_name_vectors is None and os.path.exists(self.word_embed):
-            _, _, self.local_name_vectors = self._get_desc_input()       # rdgcn.py:358
+        if self.local_name_vectors is None:
+            # rdgcn.py:358,424: the name vectors ARE the model's input (accuracy rests on them); the reference raises
+            # FileNotFoundError when the word-vector file is missing.  Random initialisation must be asked for.
+            if os.path.exists(self.word_embed):
+                _, _, self.local_name_vectors = self._get_desc_input()
+            elif not getattr(self.args, 'random_name_init', False):
+                raise FileNotFoundError("word vectors %r not found (RDGCN initialises the entity features from them, "
+                                        "rdgcn.py:424); set args.random_name_init = True for a glorot-random input"
+                                        % self.word_embed)
         self.gcn_model = Layer(self.args, self.kgs, self.local_name_vectors, self.dev, seed=self._seed,
                                attn_grouping=getattr(self.args, 'attn_grouping', self.attn_grouping))   # 'row' | 'runs' 
-        self.optimizer = TFAdam(self.gcn_model.params(), self.args.learning_rate)
+        self.optimizer = generate_optimizer(None, self.args.learning_rate, var_list=list(self.gcn_model.params()), opt='Adam')     # rdgcn.py:332
 
     def _get_local_name_by_name_triple(self, name_attribute_list=None):
         """rdgcn.py:366-413: entity id -> name = value of a name attribute if the dataset has one, else the local

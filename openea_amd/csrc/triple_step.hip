@@ -27,6 +27,8 @@
 //   their scratch row, so the scratch is clean for the next step.
 //
 // Algorithmic bytes per scored triple: 3 rows read + 3 rows of gradient = 24*d.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -781,8 +783,45 @@ __global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, 
     }
 }
 
-// ---- kernel 2: optimiser on touched rows (entity rows first, then relation rows) -------------------
+// ---- kernel 2: optimiser on touched rows (relation rows first, then entity rows) -------------------
+// pull the summed gradient of one row back through the normalisation, apply Adagrad / SGD, clear the scratch row
 template <int G, int IT>
+__device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__restrict__ acc, float *__restrict__ g,
+                                              float *__restrict__ touched_flag, int ld, int lane, int on,
+                                              const oea_step_cfg &cfg, const Row<G, IT> &rv, Row<G, IT> &rg,
+                                              const Row<G, IT> &ra) {
+    float inv = 1.f, ydg = 0.f;
+    if (on) {
+        const float ss = sumsq<G, IT>(rv);
+        inv = rsqrtf(fmaxf(ss, 1e-12f));
+        float dot = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) dot += rv.v[it] * rg.v[it];
+        dot = group_sum<G>(dot) * inv;           // y . g
+        ydg = ss > 1e-12f ? dot : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = it * G + lane;
+        if (c < ld) {
+            const float gv = on ? (rg.v[it] - rv.v[it] * inv * ydg) * inv : rg.v[it];
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
+                const float a = ra.v[it] + gv * gv;
+                acc[c] = a;
+                v[c] = rv.v[it] - cfg.lr * gv / sqrtf(a);
+            } else {
+                v[c] = rv.v[it] - cfg.lr * gv;
+            }
+            g[c] = 0.f;
+        }
+    }
+    if (lane == 0) *touched_flag = 0.f;
+}
+
+// Work item w of the grid: w < n_rel -> relation row w (sums its 16 scratch copies); else R consecutive entity rows.
+// The kernel is a few thousand very short waves (three row loads, two reductions, two row stores): R > 1 keeps R rows'
+// loads in flight per group and divides the wave count by R (latency-bound at the 15K shape).
+template <int G, int IT, int R>
 __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float *__restrict__ ent_acc,
                                                   int64_t n_ent, float *__restrict__ rel,
                                                   float *__restrict__ rel_acc, int64_t n_rel, int ld,
@@ -791,23 +830,41 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
-    for (int64_t row_all = grp; row_all < n_ent + n_rel; row_all += ngrp) {
-        const bool is_rel = row_all < n_rel;            // relation rows first: their 16-copy sums overlap the entity rows
-        const int64_t row = is_rel ? row_all : row_all - n_rel;
-        float *touched = is_rel ? ws.rel_touched : ws.ent_touched;
-        float *v = (is_rel ? rel : ent) + row * ld;
-        float *acc = (is_rel ? rel_acc : ent_acc) + row * ld;
-        float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
-        const int on = is_rel ? cfg.rel_l2_norm : cfg.ent_l2_norm;
-        // the row, its gradient and its accumulator are fetched together with the flag (most rows of a
-        // batch are touched): one dependent round trip instead of two
-        const float flag = touched[row];
+    const int64_t n_items = n_rel + (n_ent + R - 1) / R;
+    for (int64_t w = grp; w < n_items; w += ngrp) {
+        if (w >= n_rel) {                                // ---- R entity rows ---------------------------------------
+            const int64_t row0 = (w - n_rel) * R;
+            float flag[R];
+            Row<G, IT> rv[R], rg[R], ra[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = row0 + r < n_ent ? row0 + r : n_ent - 1;
+                flag[r] = row0 + r < n_ent ? ws.ent_touched[row] : 0.f;
+                load_row<G, IT>(ent + row * ld, ld, lane, rv[r]);
+                load_row<G, IT>(ws.ent_grad + row * ld, ld, lane, rg[r]);
+                if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(ent_acc + row * ld, ld, lane, ra[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (flag[r] == 0.f) continue;
+                const int64_t row = row0 + r;
+                apply_one_row<G, IT>(ent + row * ld, ent_acc + row * ld, ws.ent_grad + row * ld, ws.ent_touched + row, ld,
+                                     lane, cfg.ent_l2_norm, cfg, rv[r], rg[r], ra[r]);
+            }
+            continue;
+        }
+        // ---- one relation row: fetched together with the flag (most rows of a batch are touched) ------------------
+        const int64_t row = w;
+        float *v = rel + row * ld;
+        float *acc = rel_acc + row * ld;
+        float *g = ws.rel_grad + row * ld;
+        const float flag = ws.rel_touched[row];
         Row<G, IT> rv, rg, ra;
         load_row<G, IT>(v, ld, lane, rv);
         load_row<G, IT>(g, ld, lane, rg);
         if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
         if (flag == 0.f) continue;
-        if (is_rel && !copies_folded) {               // sum (fixed order) and clear the other copies
+        if (!copies_folded) {               // sum (fixed order) and clear the other copies
             constexpr int CB = IT <= 4 ? 5 : 1;       // copies fetched together (all loads issued before use)
             for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
                 float tmp[CB][IT];
@@ -828,6 +885,47 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
                     }
             }
         }
+        apply_one_row<G, IT>(v, acc, g, ws.rel_touched + row, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
+    }
+    // fixed-order reduction of the loss partials by one wave of block 0
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 64) s += ws.partials[i];
+        s = oea::wave_sum_d(s);
+        if (threadIdx.x == 0) *loss_accum += s;
+    }
+}
+
+// ---- kernel 2b: optimisers whose update is DENSE (tf.train.AdamOptimizer / AdadeltaOptimizer, optimizers.py:13-16) -------
+// The tables are l2_normalize(variable): the gradient of a gather comes back through the normalisation as a dense
+// tensor, so TF's dense kernels run -- Adam moves every row every step (m and v decay where the gradient is zero),
+// Adadelta's accumulators decay everywhere.  state: [2, rows, ld] = (m, v) for Adam, (accum, accum_update) for
+// Adadelta.  The relation scratch copies must have been folded into copy 0 (fold_rel_copies_kernel).
+template <int G, int IT>
+__global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent, float *__restrict__ ent_state,
+                                                        int64_t n_ent, float *__restrict__ rel,
+                                                        float *__restrict__ rel_state, int64_t n_rel, int ld,
+                                                        oea_step_cfg cfg, StepWs ws, int n_partials,
+                                                        double *__restrict__ loss_accum, float lr_t) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t row_all = grp; row_all < n_ent + n_rel; row_all += ngrp) {
+        const bool is_rel = row_all < n_rel;
+        const int64_t row = is_rel ? row_all : row_all - n_rel;
+        const int64_t rows = is_rel ? n_rel : n_ent;
+        float *touched = is_rel ? ws.rel_touched : ws.ent_touched;
+        float *v = (is_rel ? rel : ent) + row * ld;
+        float *s0 = (is_rel ? rel_state : ent_state) + row * ld;
+        float *s1 = s0 + rows * (int64_t)ld;
+        float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
+        const int on = is_rel ? cfg.rel_l2_norm : cfg.ent_l2_norm;
+        const float flag = touched[row];
+        Row<G, IT> rv, rg, r0, r1;
+        load_row<G, IT>(v, ld, lane, rv);
+        load_row<G, IT>(g, ld, lane, rg);
+        load_row<G, IT>(s0, ld, lane, r0);
+        load_row<G, IT>(s1, ld, lane, r1);
         float inv = 1.f, ydg = 0.f;
         if (on) {
             const float ss = sumsq<G, IT>(rv);
@@ -835,7 +933,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             float dot = 0.f;
 #pragma unroll
             for (int it = 0; it < IT; ++it) dot += rv.v[it] * rg.v[it];
-            dot = group_sum<G>(dot) * inv;           // y . g
+            dot = group_sum<G>(dot) * inv;
             ydg = ss > 1e-12f ? dot : 0.f;
         }
 #pragma unroll
@@ -843,19 +941,23 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             const int c = it * G + lane;
             if (c < ld) {
                 const float gv = on ? (rg.v[it] - rv.v[it] * inv * ydg) * inv : rg.v[it];
-                if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
-                    const float a = ra.v[it] + gv * gv;
-                    acc[c] = a;
-                    v[c] = rv.v[it] - cfg.lr * gv / sqrtf(a);
-                } else {
-                    v[c] = rv.v[it] - cfg.lr * gv;
+                if (cfg.opt_kind == OEA_OPT_ADAM) {          // training_ops ApplyAdam
+                    const float m = r0.v[it] + (gv - r0.v[it]) * (1.f - cfg.beta1);
+                    const float vv = r1.v[it] + (gv * gv - r1.v[it]) * (1.f - cfg.beta2);
+                    s0[c] = m; s1[c] = vv;
+                    v[c] = rv.v[it] - lr_t * m / (sqrtf(vv) + cfg.eps);
+                } else {                                     // ApplyAdadelta (rho = beta1)
+                    const float acc = r0.v[it] * cfg.beta1 + gv * gv * (1.f - cfg.beta1);
+                    const float upd = sqrtf(r1.v[it] + cfg.eps) * rsqrtf(acc + cfg.eps) * gv;
+                    s0[c] = acc;
+                    s1[c] = r1.v[it] * cfg.beta1 + upd * upd * (1.f - cfg.beta1);
+                    v[c] = rv.v[it] - cfg.lr * upd;
                 }
-                g[c] = 0.f;
+                if (flag != 0.f) g[c] = 0.f;
             }
         }
-        if (lane == 0) touched[row] = 0.f;
+        if (flag != 0.f && lane == 0) touched[row] = 0.f;
     }
-    // fixed-order reduction of the loss partials by one wave of block 0
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         double s = 0.0;
         for (int i = threadIdx.x; i < n_partials; i += 64) s += ws.partials[i];
@@ -909,6 +1011,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                 const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
     const int block = 256, gpb = block / G;
     const bool transh = cfg.score_kind == OEA_SCORE_TRANSH, transd = cfg.score_kind == OEA_SCORE_TRANSD;
+    const bool dense_opt = cfg.opt_kind == OEA_OPT_ADAM || cfg.opt_kind == OEA_OPT_ADADELTA;
     // TransH with a per-triple loss on the sampler's grouped layout keeps its grouped kernel; margin pairs, free
     // negative lists and TransD take the one-item-per-group kernel
     const bool transh_grouped = transh && cfg.loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg.neg_group_k > 0);
@@ -932,16 +1035,36 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
         else
             triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         oea::prof_mark(st);
-        if (phase == OEA_PHASE_GRAD)
+        if (phase == OEA_PHASE_GRAD || dense_opt)
             fold_rel_copies_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rel * (int64_t)ld, 256), 1024), 256, 0, st>>>(
                 ws, n_rel * (int64_t)ld, transh ? 1 : 0);
     }
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
         oea::prof_mark(st);
-        apply_rows<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
-                                                 items > 0 ? nb1 : 0 /* no triples scored: no loss partials to add */,
-                                                 loss_accum, phase == OEA_PHASE_APPLY);
+        if (dense_opt) {
+            // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (AdamOptimizer._apply_dense)
+            const double t = (double)cfg.opt_t;
+            const float lr_t = cfg.opt_kind == OEA_OPT_ADAM
+                                   ? (float)((double)cfg.lr * std::sqrt(1.0 - std::pow((double)cfg.beta2, t)) / (1.0 - std::pow((double)cfg.beta1, t)))
+                                   : cfg.lr;
+            apply_rows_dense<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
+                                                           items > 0 ? nb1 : 0, loss_accum, lr_t);
+        } else {
+            // rows per lane group: 2 for the narrow rows (latency-bound: half the waves, twice the loads in flight),
+            // 1 once a row alone fills the registers; OEA_APPLY_ROWS overrides (1 / 2 / 4) for experiments
+            static const int env_r = [] { const char *e = getenv("OEA_APPLY_ROWS"); return e ? atoi(e) : 0; }();
+            const int R = env_r ? env_r : (IT <= 4 ? 2 : 1);
+            const int n_part = items > 0 ? nb1 : 0;   /* no triples scored: no loss partials to add */
+            const int folded = phase == OEA_PHASE_APPLY;
+            auto nb = [&](int r) { return (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + oea::ceil_div(n_ent, r), gpb), 1), 16384); };
+            if (R >= 4 && IT <= 4)
+                apply_rows<G, IT, 4><<<nb(4), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+            else if (R >= 2 && IT <= 8)
+                apply_rows<G, IT, 2><<<nb(2), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+            else
+                apply_rows<G, IT, 1><<<nb(1), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+        }
         if (transh)
             apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1), block, 0, st>>>(
                 n_rel, ld, cfg, ws, phase == OEA_PHASE_APPLY);
@@ -981,8 +1104,13 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     OEA_REQUIRE(ld % 4 == 0 && dim <= ld && dim > 0, "ld % 4 == 0 and dim <= ld");
     OEA_REQUIRE(n_pos >= 0 && n_neg >= 0 && (neg || n_neg == 0), "neg == NULL needs n_neg == 0");
     OEA_REQUIRE(cfg->loss_kind >= OEA_LOSS_MARGIN && cfg->loss_kind <= OEA_LOSS_ALIGN, "loss_kind");
-    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || cfg->opt_kind == OEA_OPT_ADAGRAD, "opt_kind");
-    OEA_REQUIRE(cfg->opt_kind != OEA_OPT_ADAGRAD || (ent_acc && rel_acc), "Adagrad needs accumulators");
+    OEA_REQUIRE(cfg->opt_kind >= OEA_OPT_SGD && cfg->opt_kind <= OEA_OPT_ADADELTA, "opt_kind");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (ent_acc && rel_acc), "Adagrad / Adam / Adadelta need their state arrays");
+    if (cfg->opt_kind == OEA_OPT_ADAM || cfg->opt_kind == OEA_OPT_ADADELTA) {
+        OEA_REQUIRE(cfg->score_kind != OEA_SCORE_TRANSH, "Adam / Adadelta are not built for the TransH normal-vector table");
+        OEA_REQUIRE(cfg->opt_kind != OEA_OPT_ADAM || cfg->opt_t >= 1, "Adam: opt_t = 1-based step count");
+        OEA_REQUIRE(cfg->beta1 > 0.f && cfg->beta1 < 1.f && cfg->eps > 0.f, "beta1 / eps");
+    }
     if (cfg->loss_kind == OEA_LOSS_MARGIN) OEA_REQUIRE(n_neg == n_pos, "margin loss pairs pos i with neg i");
     if (cfg->loss_kind == OEA_LOSS_POSITIVE || cfg->loss_kind == OEA_LOSS_ALIGN)
         OEA_REQUIRE(n_neg == 0, "positive-only loss takes no negatives");
@@ -1040,33 +1168,52 @@ int oea_triple_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, floa
                      const oea_sampler_side *side1, uint64_t seed, uint32_t step_base, int32_t *neg_buf,
                      int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
                      const int64_t *offsets_dev, const int64_t *splits_dev, void *stream) {
+    return oea_triple_epoch_range(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos_all, offsets_host, splits_host,
+                                  steps, 0, steps, k, side0, side1, seed, step_base, neg_buf, err_flag, cfg, workspace,
+                                  loss_accum, offsets_dev, splits_dev, stream);
+}
+
+int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                           int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                           const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                           const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                           uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                           void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                           void *stream) {
     OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
+    OEA_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= steps, "0 <= step_begin <= step_end <= steps");
     OEA_REQUIRE((offsets_dev == nullptr) == (splits_dev == nullptr), "offsets_dev and splits_dev go together");
     // side0 == NULL with the device layout given: neg_buf already holds the epoch's negatives (the caller drew them
     // with oea_sample_negatives_epoch, e.g. on another stream while the previous epoch was running)
     const bool presampled = k > 0 && side0 == nullptr && side1 == nullptr && offsets_dev != nullptr;
     OEA_REQUIRE(k == 0 || (neg_buf && (presampled || (err_flag && side0 && side1))), "sampling needs neg_buf, err_flag and both sides");
-    const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;
-    if (ahead && !presampled) {   // the sampler does not read the tables: draw the whole epoch's negatives in one launch
+    const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;      // neg_buf covers the whole epoch
+    // the sampler does not read the tables: a range that starts the epoch draws ALL its negatives in one launch
+    // (later ranges of the same epoch find them in neg_buf: pass side0 = side1 = NULL, or let them be drawn again
+    // step by step -- the Philox streams are the same either way)
+    const bool sample_all = ahead && !presampled && step_begin == 0;
+    if (sample_all) {
         const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0,
                                                   side1, seed, step_base, 10, neg_buf, err_flag, stream);
         if (rc != OEA_OK) return rc;
     }
-    for (int32_t s = 0; s < steps; ++s) {
+    oea_step_cfg step_cfg = *cfg;             // Adam: opt_t counts the steps actually run (cfg->opt_t = count of the first)
+    for (int32_t s = step_begin; s < step_end; ++s) {
         const int64_t lo = offsets_host[s], n = offsets_host[s + 1] - lo;
         if (n <= 0) continue;
         const int32_t *pos = pos_all + 3 * lo;
         int32_t *negs = ahead ? neg_buf + 3 * lo * (int64_t)k : neg_buf;
-        if (k > 0 && !ahead) {
+        if (k > 0 && !presampled && !sample_all) {
             const int rc = oea_sample_negatives_pair(pos, n, splits_host[s], k, side0, side1, seed, step_base + (uint32_t)s,
                                                      0u, 10, negs, err_flag, stream);
             if (rc != OEA_OK) return rc;
         }
         const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
-                                             k > 0 ? negs : nullptr, n * (int64_t)k, cfg, workspace, loss_accum,
+                                             k > 0 ? negs : nullptr, n * (int64_t)k, &step_cfg, workspace, loss_accum,
                                              OEA_PHASE_BOTH, stream);
         if (rc != OEA_OK) return rc;
+        ++step_cfg.opt_t;
     }
     return OEA_OK;
 }

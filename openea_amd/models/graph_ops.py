@@ -87,10 +87,13 @@ class EdgeGraph:
         if grouping == 'row':
             order = np.lexsort((cols, rows))                       # canonical row-major order
             rows_o, cols_o, vals_o = rows[order], cols[order], vals[order]
-        elif grouping == 'runs':
+        elif grouping in ('runs', 'reorder'):
             rows_o, cols_o, vals_o = rows, cols, vals              # as fed
         else:
             raise ValueError(grouping)
+        self.grouping = grouping
+        if grouping == 'reorder':
+            self._init_reorder(rows, cols, dev)
         change = np.flatnonzero(np.diff(rows_o)) + 1 if self.nnz else np.zeros(0, np.int64)
         seg_start = np.concatenate([[0], change]).astype(np.int64) if self.nnz else np.zeros(0, np.int64)
         seg_ptr = np.concatenate([seg_start, [self.nnz]]).astype(np.int64)
@@ -141,6 +144,62 @@ class EdgeGraph:
                                     ops.to_ids(t_order[t_lo:t_hi], dev), True, len(lt_sub_col) > int((lcounts > 0).sum()))
             self.shard = dict(seg=seg_part, t=t_part, e_lo=e_lo, e_hi=e_hi, row_bounds=row_bounds, edge_bounds=edge_bounds,
                               col_bounds=cb)
+
+
+def _pattern_csr(major, minor, n_major, dev):
+    """CSR of an edge pattern that keeps duplicates apart: (rowptr, colidx, edge id of every CSR slot)"""
+    order = np.lexsort((minor, major))
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(major, minlength=n_major))]).astype(np.int32)
+    return ops.to_ids(ptr, dev), ops.to_ids(minor[order], dev), torch.from_numpy(order.astype(np.int64)).to(dev), ptr
+
+
+def _init_reorder(self, rows, cols, dev):
+    """grouping='reorder' (tests/golden/tf_shim.py, third reading of tf.sparse_softmax): the softmax runs over the rows of
+    the CANONICALLY sorted tensor and its p-th output value is attached to the p-th index of the tensor as fed."""
+    perm = np.lexsort((cols, rows))                                            # sorted position -> edge as fed
+    self.r_perm = torch.from_numpy(perm.astype(np.int64)).to(dev)
+    self.r_seg = torch.from_numpy(rows[perm]).to(dev)                           # softmax group of every sorted position
+    self.r_fwd = _pattern_csr(rows, cols, self.shape[0], dev)                   # out = P . v,  P[rows[p], cols[p]] = alpha_sorted[p]
+    self.r_bwd = _pattern_csr(cols, rows, self.shape[1], dev)                   # dv = P^T . dout
+    self.r_rows32, self.r_cols32 = ops.to_ids(rows, dev), ops.to_ids(cols, dev)
+    self.r_split = (ops.csr_split(self.r_fwd[3], dev=dev), ops.csr_split(self.r_bwd[3], dev=dev))
+
+
+EdgeGraph._init_reorder = _init_reorder
+
+
+class ReorderAttnFn(torch.autograd.Function):
+    """sparse attention under grouping='reorder': a per-row softmax of the sorted logits (1-D torch segment ops: plumbing
+    on [nnz] vectors) whose values are re-attached to the as-fed pattern; the aggregate, its transpose and the per-edge
+    dots dout[row] . v[col] are the HIP kernels (oea_spmm_csr, oea_pair_dots)."""
+
+    @staticmethod
+    def forward(ctx, z, v, g, slope):
+        v = v.contiguous()
+        zs = torch.nn.functional.leaky_relu(z[g.r_perm], slope)
+        mx = torch.full((g.shape[0],), -torch.inf, device=z.device).scatter_reduce(0, g.r_seg, zs, 'amax')
+        e = torch.exp(zs - mx[g.r_seg])
+        alpha = e / torch.zeros(g.shape[0], device=z.device).index_add_(0, g.r_seg, e)[g.r_seg]
+        rowptr, colidx, slot_edge, _ = g.r_fwd
+        out = ops.spmm_csr(rowptr, colidx, alpha[slot_edge].contiguous(), v, v.shape[1], split=g.r_split[0])
+        ctx.g, ctx.slope = g, slope
+        ctx.save_for_backward(z, v, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, v, alpha = ctx.saved_tensors
+        g, dout = ctx.g, dout.contiguous()
+        rowptr, colidx, slot_edge, _ = g.r_bwd
+        dv = ops.spmm_csr(rowptr, colidx, alpha[slot_edge].contiguous(), dout, dout.shape[1], split=g.r_split[1])
+        dalpha = ops.pair_dots(dout, v, v.shape[1], g.r_rows32, g.r_cols32)         # position p: the edge as fed
+        s = torch.zeros(g.shape[0], device=z.device).index_add_(0, g.r_seg, alpha * dalpha)
+        dzs = alpha * (dalpha - s[g.r_seg])
+        zs = z[g.r_perm]
+        dzs = torch.where(zs > 0, dzs, dzs * ctx.slope)
+        dz = torch.empty_like(z)
+        dz[g.r_perm] = dzs
+        return dz, dv, None, None
 
 
 class SpmmFn(torch.autograd.Function):
@@ -205,6 +264,8 @@ def spmm(graph, x):
 
 
 def sparse_attention(graph, z, v, slope=0.2):
+    if getattr(graph, "grouping", "row") == 'reorder':
+        return ReorderAttnFn.apply(z, v, graph, slope)
     return SparseAttnFn.apply(z, v, graph, slope)
 
 
@@ -227,4 +288,27 @@ class TFAdam:
             g = p.grad.contiguous()
             mdist.sync_replicated_(g)                   # torch.distributed: replicas must apply the same bits
             ops.adam_dense_(p.data, g, m, v, self.lr, self.t, self.b1, self.b2, self.eps)
+            p.grad = None
+
+
+class DenseSGD:
+    """tf.train.GradientDescentOptimizer over dense device parameters (p -= lr * grad; oea_sgd_rows without the
+    normalisation pull-back)."""
+
+    def __init__(self, params, lr):
+        self.params, self.lr = list(params), lr
+
+    def step(self):
+        from . import dist as mdist
+        for p in self.params:
+            if p.grad is None:
+                continue
+            g = p.grad.contiguous()
+            mdist.sync_replicated_(g)
+            w = p.data.view(-1, p.shape[-1]) if p.dim() > 1 else p.data.view(1, -1)
+            gg = g.view_as(w)
+            if w.shape[1] % 4 == 0:
+                ops.sgd_rows_(w, gg, w.shape[1], False, self.lr)
+            else:                                   # oea_sgd_rows wants 16-byte rows: flatten to one padded row is not
+                p.data.add_(g, alpha=-self.lr)      # possible in place; tiny parameters take the element-wise add
             p.grad = None

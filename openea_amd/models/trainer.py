@@ -61,16 +61,26 @@ class TripleTrainer:
         if optimizer == 'Adagrad':        # tf.train.AdagradOptimizer: initial_accumulator_value = 0.1
             self.ent_acc = torch.full_like(ent.var, 0.1)
             self.rel_acc = torch.full_like(rel.var, 0.1)
+        elif optimizer in ('Adam', 'Adadelta'):       # (m, v) / (accum, accum_update): zeros, [2, rows, ld]
+            self.ent_acc = torch.zeros((2,) + tuple(ent.var.shape), dtype=torch.float32, device=dev)
+            self.rel_acc = torch.zeros((2,) + tuple(rel.var.shape), dtype=torch.float32, device=dev)
         else:
             self.ent_acc = self.rel_acc = None
+        self.t = 0                        # optimiser steps taken (Adam's bias correction counts them)
         self.ws = ops.step_workspace(ent.rows, rel.rows, ent.ld, dev)
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self._empty = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         self.dist = dist_group
         self.xchg = ops.step_exchange_view(self.ws, ent.rows, rel.rows, ent.ld) if dist_group is not None else None
 
+    def count_steps(self, n=1):
+        """n more optimiser steps are about to run: cfg.opt_t = 1-based count of the first of them"""
+        self.cfg.opt_t = self.t + 1
+        self.t += n
+
     def step(self, pos, neg):
         """pos / neg: device int32 [n,3] (neg may be None)."""
+        self.count_steps()
         if self.dist is None:
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss)
@@ -88,6 +98,7 @@ class TripleTrainer:
         """optimiser step for gradients w.r.t. the normalised entity rows `ids` computed outside the
         fused kernel (device [n, ld] fp32): scatter into the scratch, then the apply phase."""
         ops.step_scatter_ent_rows(self.ws, self.ent.rows, self.rel.rows, self.ent.ld, ids, grads)
+        self.count_steps()
         if self.dist is not None:
             import torch.distributed as dist
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
@@ -99,6 +110,7 @@ class TripleTrainer:
     def apply_scratch(self):
         """optimiser step for whatever a kernel outside the fused step has added to the gradient scratch
         (oea_mapping_step): the exchange (if any), then the apply phase."""
+        self.count_steps()
         if self.dist is not None:
             import torch.distributed as dist
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
@@ -106,6 +118,15 @@ class TripleTrainer:
                 self.xchg /= dist.get_world_size(self.dist)
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
+
+    def exchange_bytes_per_step(self):
+        """bytes this rank sends (= receives) per optimiser step in the data-parallel exchange: a ring all-reduce of the
+        gradient scratch + touched flags moves 2 (G-1)/G of the buffer"""
+        if self.dist is None:
+            return 0
+        import torch.distributed as dist
+        g = dist.get_world_size(self.dist)
+        return int(self.xchg.numel() * 4 * 2 * (g - 1) / g)
 
     def pop_loss(self):
         """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data
@@ -137,6 +158,8 @@ class RelationTripleEpochs:
         triples_num = len(self.batches.t1) + len(self.batches.t2)
         self.triple_steps = int(np.ceil(triples_num / batch_size))      # basic_model.py:255
         self.global_step = 0
+        self._epoch_base = 0                  # global_step at the start of the current epoch (Philox step of its step 0)
+        self._epoch_negs_ready = False        # _neg_all holds the current epoch's negatives
         b = self.batches
         self.neg_buf = torch.empty(((b.b1 + b.b2) * max(self.k, 1), 3), dtype=torch.int32, device=self.dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -146,11 +169,12 @@ class RelationTripleEpochs:
         self.s1.set_neighbours(nbr1)
         self.s2.set_neighbours(nbr2)
         self._sides = None
+        self._epoch_negs_ready = False        # negatives drawn ahead with the old lists are not used any further
 
     def batch(self, step):
         """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch.
         Under data parallelism this rank takes a contiguous share of the batch rows."""
-        if getattr(self, "_prefetch", None) is not None:      # a prepared epoch is pending: its positives become current
+        if getattr(self, "_prefetch", None) is not None and self.in_epoch == 0:   # a prepared epoch becomes current
             self._take_prefetch(torch.cuda.current_stream())
         pos, n_split = self.batches.pos(step)
         off = 0
@@ -171,36 +195,70 @@ class RelationTripleEpochs:
     def run_epoch(self, trainer):
         """All `triple_steps` steps of one epoch.  Single GPU: one C call enqueues the whole epoch
         (oea_triple_epoch); data parallel (or a trainer without the fused epoch call, fused_epoch = False): per-step loop
-        with the all-reduce between the phases."""
+        with the exchange between the phases."""
+        assert self.in_epoch == 0, "run_epoch in the middle of an epoch: use run_steps"
+        return self.run_steps(trainer, len(self.batches.splits))
+
+    @property
+    def in_epoch(self):
+        """steps of the current epoch already run"""
+        return self.global_step - self._epoch_base
+
+    def run_steps(self, trainer, n_steps):
+        """The next n_steps optimiser steps, continuing where the previous call stopped (epochs end -- shuffle, next
+        epoch's negatives -- wherever they fall).  Single GPU: ONE C call per epoch touched (oea_triple_epoch_range).
+        -> positives consumed on this rank."""
+        S = len(self.batches.splits)
+        n = done = 0
+        while done < n_steps:
+            lo = self.in_epoch
+            hi = min(S, lo + n_steps - done)
+            n += self._run_range(trainer, lo, hi)
+            done += hi - lo
+        return n
+
+    def _run_range(self, trainer, lo, hi):
+        S = len(self.batches.splits)
+        b = self.batches
         if self.world == 1 and getattr(trainer, "fused_epoch", True):
             if self._sides is None:
                 self._sides = (self.s1.side(), self.s2.side())
-            b = self.batches
             main = torch.cuda.current_stream()
-            presampled = self._take_prefetch(main)
+            if lo == 0:
+                self._epoch_negs_ready = self._take_prefetch(main)      # the prepared epoch's positives (and negatives) become current
             if self.k:
                 self._epoch_neg_buf()
-            ev_start = torch.cuda.Event()
-            ev_start.record(main)                         # everything that still reads the spare buffers is before this
+            ev_start = None
+            if lo == 0:
+                ev_start = torch.cuda.Event()
+                ev_start.record(main)                     # everything that still reads the spare buffers is before this
+            have = self.k and self._epoch_negs_ready
+            if hasattr(trainer, "count_steps"):
+                trainer.count_steps(int((np.diff(b.offsets[lo:hi + 1]) > 0).sum()))
             ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
                              b.dall, b.offsets, b.splits, self.k,
-                             None if (presampled or not self.k) else self._sides[0],
-                             None if (presampled or not self.k) else self._sides[1], self.seed, self.global_step,
+                             None if (have or not self.k) else self._sides[0],
+                             None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
                              self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
                              trainer.ws, trainer.loss, self._off_dev if self.k else None,
-                             self._spl_dev if self.k else None)
-            self.global_step += len(b.splits)
-            n = int(b.offsets[-1])
-            self._prefetch_next(ev_start)
+                             self._spl_dev if self.k else None, step_range=(lo, hi))
+            if lo == 0 and self.k:
+                self._epoch_negs_ready = True             # a range that starts the epoch draws all its negatives
+            self.global_step += hi - lo
+            n = int(b.offsets[hi] - b.offsets[lo])
+            if ev_start is not None:
+                self._prefetch_next(ev_start)             # next epoch's shuffle + negatives on the side stream
+            if hi == S:
+                self._epoch_base = self.global_step
             return n
-        else:
-            n = 0
-            for step in range(len(self.batches.splits)):
-                pos, neg = self.batch(step)
-                if pos.shape[0] or trainer.dist is not None:     # DP: every rank joins every exchange, rows or not
-                    trainer.step(pos, neg)
-                n += pos.shape[0]
-        self.end_epoch()
+        n = 0
+        for step in range(lo, hi):
+            pos, neg = self.batch(step)
+            if pos.shape[0] or trainer.dist is not None:     # DP: every rank joins every exchange, rows or not
+                trainer.step(pos, neg)
+            n += pos.shape[0]
+        if hi == S:
+            self.end_epoch()
         return n
 
     def _epoch_neg_buf(self):
@@ -222,15 +280,16 @@ class RelationTripleEpochs:
             self._side = torch.cuda.Stream(device=self.dev)
             self._neg_next = torch.empty_like(self._neg_all) if self.k else None
         side = self._side
+        next_base = self._epoch_base + len(self.batches.splits)     # Philox step of the NEXT epoch's step 0
         side.wait_event(ev_start)
         with torch.cuda.stream(side):
             self.batches.shuffle(self.gen, into_next=True)
             if self.k:
                 ops.sample_negatives_epoch(self.batches.dall_next, self._off_dev, self._spl_dev, len(self.batches.splits), self.k,
-                                           self._sides[0], self._sides[1], self.seed, self.global_step, self._neg_next, self.err)
+                                           self._sides[0], self._sides[1], self.seed, next_base, self._neg_next, self.err)
             self._prefetch_ev = torch.cuda.Event()
             self._prefetch_ev.record(side)
-        self._prefetch = (self._sides, self.global_step)
+        self._prefetch = (self._sides, next_base)
 
     def _take_prefetch(self, main):
         """make the prepared epoch current; -> True when its negatives are usable as they are."""
@@ -240,12 +299,15 @@ class RelationTripleEpochs:
         self._prefetch = None
         main.wait_event(self._prefetch_ev)
         self.batches.swap()
-        ok = self.k > 0 and pf[0] is self._sides and pf[1] == self.global_step
+        ok = self.k > 0 and pf[0] is self._sides and pf[1] == self._epoch_base
         if ok:
             self._neg_all, self._neg_next = self._neg_next, self._neg_all
         return ok
 
     def end_epoch(self):
+        """per-step path: the epoch's last batch() has been taken"""
+        self._epoch_base = self.global_step
+        self._epoch_negs_ready = False
         if getattr(self, "_prefetch", None) is not None:      # already shuffled into the spare buffer: make it current
             self._take_prefetch(torch.cuda.current_stream())
             return

@@ -70,19 +70,28 @@ class TripleSampler:
         self.ent_pos = ops.to_ids(ent_pos, dev)
         self.table = ops.tripleset_build(ops.to_ids(tri, dev))
         self.nbr = None                       # int32 [N, k] entity ids; row = position in entity_list
+        self.nbr_pos = None
+        # the membership keys pack (head 24 bits | relation 16 bits | tail 24 bits): larger ids would alias silently
+        if len(tri) and (int(tri[:, [0, 2]].max()) >= 1 << 24 or int(tri[:, 1].max()) >= 1 << 16 or int(tri.min()) < 0):
+            raise ops.OpenEAHipError("triple ids out of range for the packed membership keys "
+                                     "(entity ids < 16,777,216, relation ids < 65,536)")
         self.err = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def set_neighbours(self, nbr):
-        """nbr: device int32 [len(entity_list), k] (rows in entity_list order) or None."""
+    def set_neighbours(self, nbr, nbr_pos=None):
+        """nbr: device int32 [rows, k] or None; rows in entity_list order unless nbr_pos (device int32
+        [num_entities_total]: entity id -> row, -1 = no list: the whole entity list is the candidate set) is given."""
         self.nbr = nbr
+        self.nbr_pos = nbr_pos
 
     def side(self):
         """this KG's state packed for ops.sample_negatives_pair."""
-        return ops.sampler_side(self.table, self.entity_list, self.ent_pos, self.nbr)
+        pos = self.nbr_pos if (self.nbr is not None and getattr(self, "nbr_pos", None) is not None) else self.ent_pos
+        return ops.sampler_side(self.table, self.entity_list, pos, self.nbr)
 
     def sample(self, pos, k, seed, step, pos_offset=0, out=None, max_try=10):
         """pos: device int32 [n,3] -> device int32 [n*k, 3]."""
-        out, _ = ops.sample_negatives(pos, k, self.table, self.entity_list, self.ent_pos, self.nbr, seed=seed,
+        ent_pos = self.nbr_pos if (self.nbr is not None and getattr(self, "nbr_pos", None) is not None) else self.ent_pos
+        out, _ = ops.sample_negatives(pos, k, self.table, self.entity_list, ent_pos, self.nbr, seed=seed,
                                       step=step, pos_offset=pos_offset, max_try=max_try, out=out, err_flag=self.err)
         return out
 
@@ -109,9 +118,10 @@ class EpochBatches:
         batch `step` is ONE contiguous device slice (no per-step concatenation).  The layout is a
         fixed gather map over cat(list1, list2); an epoch's shuffle only permutes its input."""
         n1, n2, b1, b2 = len(self.t1), len(self.t2), self.b1, self.b2
-        steps = 0
-        while steps * b1 < n1 or steps * b2 < n2:
-            steps += 1
+        # basic_model.py:255: triple_steps = ceil((n1 + n2) / batch_size).  b1 rounds down, so the last steps hold
+        # short (or empty) slices and a few tail triples of the list with the rounded-down share are not visited in
+        # this epoch -- exactly as in the reference (the lists are reshuffled every epoch).
+        steps = int(np.ceil((n1 + n2) / max(b1 + b2, 1)))
         slot, offsets, splits = [], [0], []
         for s in range(steps):
             i1 = np.arange(s * b1, min(s * b1 + b1, n1)) if b1 else np.zeros(0, np.int64)
@@ -160,12 +170,16 @@ _sampler_cache = {}
 
 
 def _cached_sampler(all_triples_set, entities_list):
-    key = (id(all_triples_set), id(entities_list), len(all_triples_set), len(entities_list))
+    """one device sampler per (triple set, entity list) CONTENT: the key is a hash of the sorted triples and of the
+    list, so a set mutated in place (or a recycled id()) never returns a stale table."""
+    tri = np.asarray(sorted(all_triples_set), dtype=np.int32).reshape(-1, 3)
+    ents = np.asarray(entities_list, dtype=np.int32)
+    key = (hash(tri.tobytes()), hash(ents.tobytes()), len(tri), len(ents))
     s = _sampler_cache.get(key)
     if s is None:
         if len(_sampler_cache) > 8:
             _sampler_cache.clear()
-        s = TripleSampler(all_triples_set, entities_list)
+        s = TripleSampler(tri, ents)
         _sampler_cache[key] = s
     return s
 
@@ -178,11 +192,14 @@ def generate_neg_triples_fast(pos_batch, all_triples_set, entities_list, neg_tri
         return []
     sampler = _cached_sampler(all_triples_set, entities_list)
     if neighbor:
+        # neighbor.get(e, entities_list) (batch.py:96-97): entities without a list draw from the WHOLE entity list --
+        # ent_pos = -1 makes the kernel fall back to it
         k_n = len(next(iter(neighbor.values())))
-        nbr = np.empty((len(entities_list), k_n), np.int32)
-        for i, e in enumerate(entities_list):
-            nbr[i] = neighbor.get(e, entities_list[:k_n])
-        sampler.set_neighbours(ops.to_ids(nbr))
+        have = [e for e in entities_list if e in neighbor]
+        nbr = np.asarray([neighbor[e] for e in have], np.int32).reshape(len(have), k_n)
+        ent_pos = np.full(sampler.ent_pos.numel(), -1, np.int32)
+        ent_pos[np.asarray(have, np.int64)] = np.arange(len(have), dtype=np.int32)
+        sampler.set_neighbours(ops.to_ids(nbr), ops.to_ids(ent_pos))
     else:
         sampler.set_neighbours(None)
     pos = ops.to_ids(np.asarray(pos_batch, np.int32).reshape(-1, 3))

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LOSS_KIND, METRIC, OPT_KIND, RotateCfg, StepCfg, check
+from ._lib import LOSS_KIND, METRIC, OPT_KIND, OpenEAHipError, RotateCfg, StepCfg, check
 
 
 def lib():
@@ -98,11 +98,13 @@ def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, ne
     assert normal is None or transfer_bases is None
     score = SCORE_TRANSH if normal is not None else (SCORE_TRANSD if transfer_bases is not None else SCORE_TRANSE)
     eb, rb = transfer_bases if transfer_bases is not None else (0, 0)
+    # tf.train defaults: AdamOptimizer(beta1=0.9, beta2=0.999, epsilon=1e-8), AdadeltaOptimizer(rho=0.95, epsilon=1e-8)
+    b1 = 0.95 if optimizer == 'Adadelta' else 0.9
     cfg = StepCfg(LOSS_KIND[loss], 1 if loss_norm == 'L1' else 0, float(margin), float(pos_margin),
                   float(neg_margin), float(balance), int(bool(ent_l2_norm)), int(bool(rel_l2_norm)),
                   OPT_KIND[optimizer], float(lr), int(neg_group_k), score,
                   None if normal is None else normal.data_ptr(), None if normal_acc is None else normal_acc.data_ptr(),
-                  int(eb), int(rb))
+                  int(eb), int(rb), b1, 0.999, 1e-8, 0)
     cfg._keep = (normal, normal_acc)
     return cfg
 
@@ -229,6 +231,11 @@ def profile_end(group=4):
 def tripleset_build(triples):
     """device int32 [n,3] -> device uint64 table (viewed as int64)."""
     n = triples.shape[0]
+    if n:   # key layout (csrc/common.h:pack_triple): head 24 | relation 16 | tail 24 bits -- larger ids would alias
+        mx = triples.max(dim=0).values.cpu()
+        if int(mx[0]) >= 1 << 24 or int(mx[2]) >= 1 << 24 or int(mx[1]) >= 1 << 16 or int(triples.min().item()) < 0:
+            raise OpenEAHipError("triple ids out of range for the packed membership keys "
+                                 "(entity ids < 16,777,216, relation ids < 65,536)")
     cap = lib().oea_tripleset_capacity(n)
     table = torch.empty(cap, dtype=torch.int64, device=triples.device)
     check(lib().oea_tripleset_build(_p(triples), n, _p(table), cap, _stream()))
@@ -277,17 +284,19 @@ def sample_negatives_epoch(pos_all, offsets_dev, splits_dev, steps, k, side0, si
 
 
 def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
-                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None):
-    """Enqueue every step of an epoch with one call (offsets / splits: host int64 numpy arrays; their
-    device copies enable sampling the whole epoch ahead in one launch -- neg_buf then covers the epoch)."""
+                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None, step_range=None):
+    """Enqueue every step of an epoch (or steps [lo, hi) of it: step_range) with one call (offsets / splits: host int64
+    numpy arrays; their device copies enable sampling the whole epoch ahead in one launch -- neg_buf then covers the
+    epoch).  step_base: Philox step of the epoch's step 0."""
     steps = len(splits)
-    check(lib().oea_triple_epoch(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
-                                 ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
-                                 splits.ctypes.data_as(C.c_void_p), steps, int(k),
-                                 C.byref(side0) if side0 is not None else None,
-                                 C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
-                                 _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
-                                 _p(offsets_dev), _p(splits_dev), _stream()))
+    lo, hi = (0, steps) if step_range is None else step_range
+    check(lib().oea_triple_epoch_range(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+                                       ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
+                                       splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
+                                       C.byref(side0) if side0 is not None else None,
+                                       C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
+                                       _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
+                                       _p(offsets_dev), _p(splits_dev), _stream()))
 
 
 def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None, row2=None,

@@ -60,6 +60,11 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def set_num_threads(n):
+    """OpenMP threads of the parallel loops (bench.py's cpu_baseline: 1 thread and all host cores)"""
+    lib().oracle_set_num_threads(C.c_int(int(n)))
+
+
 def l2_normalize_rows(x):
     x = _f32(x)
     out = np.empty_like(x)

@@ -255,6 +255,14 @@ def main():
     for i, o in enumerate(am.output_embeds_list):
         out['alinet_out%d' % i] = tf.evaluate(o, feed)
     record('alinet', am, variables, am.loss, feed)
+    # the same graph under the two other readings of tf.sparse_softmax on AliNet's column-major adjacency (tf_shim.py)
+    import tf_shim as _shim                          # the functions of the stand-in read THIS module's globals
+    for mode in ('row', 'reorder'):
+        _shim.SPARSE_SOFTMAX_MODE = mode
+        for i, o in enumerate(am.output_embeds_list):
+            out['alinet_%s_out%d' % (mode, i)] = tf.evaluate(o, feed)
+        record('alinet_' + mode, am, variables, am.loss, feed)
+    _shim.SPARSE_SOFTMAX_MODE = 'runs'
 
     np.savez_compressed(os.path.join(HERE, 'tf_graphs.npz'), **out)
     print('wrote', os.path.join(HERE, 'tf_graphs.npz'))

@@ -170,9 +170,20 @@ def sparse_tensor_dense_matmul(sp_a, b, name=None):
     return Node(_spmm, sp_a, b)
 
 
+# What tf.sparse_softmax does with a tensor whose indices are NOT in canonical row-major order cannot be checked here (no
+# TensorFlow).  Three candidate readings, selected by SPARSE_SOFTMAX_MODE at evaluation time:
+#   'runs'    softmax over each RUN of consecutive entries with the same row (SparseTensor::group on the
+#             tensor as fed; on canonical order this is the per-row softmax);
+#   'row'     softmax over all entries of a row wherever they stand (the documented meaning of the op);
+#   'reorder' the builder's recollection of sparse_softmax_op.cc: the kernel deep-copies the tensor, Reorder()s it to
+#             row-major order, normalises each row's group and writes the groups back to back -- i.e. output value p is
+#             the softmax value of the p-th entry in SORTED order, and the python wrapper pairs it with the p-th index
+#             of the tensor AS FED (for a symmetric sparsity pattern fed column-major, as AliNet does: alpha[r, c]
+#             becomes the row-c softmax weight of entry (c, r), the transposed attention).
+SPARSE_SOFTMAX_MODE = 'runs'
+
+
 def _run_softmax(rows, vals):
-    """tf.sparse_softmax on a 2-D SparseTensor: softmax over each RUN of consecutive entries with the same row index (for
-    a canonically ordered tensor: over each row)."""
     out = np.empty_like(vals, dtype=np.float64)
     start = 0
     for i in range(1, len(rows) + 1):
@@ -184,9 +195,23 @@ def _run_softmax(rows, vals):
     return out
 
 
+def _sparse_softmax_values(indices, vals):
+    rows = indices[:, 0]
+    if SPARSE_SOFTMAX_MODE == 'runs':
+        return _run_softmax(rows, vals)
+    order = np.lexsort((indices[:, 1], rows))                    # canonical row-major order
+    sorted_out = _run_softmax(rows[order], vals[order])
+    if SPARSE_SOFTMAX_MODE == 'reorder':
+        return sorted_out                                        # left in sorted order, paired with the indices as fed
+    assert SPARSE_SOFTMAX_MODE == 'row'
+    out = np.empty_like(sorted_out)
+    out[order] = sorted_out
+    return out
+
+
 def sparse_softmax(sp_input, name=None):
-    rows = sp_input.indices[:, 0]
-    return SparseTensor(sp_input.indices, Node(lambda v: _run_softmax(rows, np.asarray(v, np.float64)), sp_input.values),
+    idx = np.asarray(sp_input.indices)
+    return SparseTensor(sp_input.indices, Node(lambda v: _sparse_softmax_values(idx, np.asarray(v, np.float64)), sp_input.values),
                         sp_input.dense_shape)
 
 

@@ -84,26 +84,43 @@ def test_neighbours_100k(ops):
     assert np.array_equal(out_h[rows], ids[ref])
 
 
-def test_step_100k_shape(ops):
-    """EN-FR-100K batch shape: 20,000 positives x 10 negatives, 200,000 entities, dim 100."""
+def test_step_100k_shape(ops, capsys):
+    """EN-FR-100K batch shape (20,000 positives x 10 negatives, 200,000 entities, dim 100): one fused step against the
+    C oracle's step on the same batch, at the north-star tolerance (every embedding within 1e-4 L2)."""
+    from _tol import assert_rows_close
     from openea_amd.models.trainer import EmbeddingTable, TripleTrainer
+    from oracle import cport
     rng = np.random.RandomState(3)
     n_ent, n_rel, d, B, k = 200000, 700, 100, 20000, 10
-    ent = EmbeddingTable(rng.standard_normal((n_ent, d)).astype(np.float32), True, "e")
-    rel = EmbeddingTable(rng.standard_normal((n_rel, d)).astype(np.float32), True, "r")
-    pos = np.stack([rng.randint(0, n_ent, B), rng.randint(0, n_rel, B), rng.randint(0, n_ent, B)], 1).astype(np.int32)
+    ent_h = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32)
+    rel_h = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32)
+    ent = EmbeddingTable(ent_h, True, "e")
+    rel = EmbeddingTable(rel_h, True, "r")
+    w = 1.0 / np.arange(1, n_ent + 1) ** 0.9                                  # Zipf heads: hub rows collect many gradients
+    pos = np.stack([rng.choice(n_ent, B, p=w / w.sum()), rng.randint(0, n_rel, B), rng.randint(0, n_ent, B)], 1).astype(np.int32)
     neg = np.repeat(pos, k, 0)
-    neg[:, 2] = rng.randint(0, n_ent, len(neg))
+    flip = rng.rand(len(neg)) < 0.5
+    neg[flip, 0] = rng.randint(0, n_ent, int(flip.sum()))
+    neg[~flip, 2] = rng.randint(0, n_ent, int((~flip).sum()))
     kw = dict(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.01)
     tg = TripleTrainer(ent, rel, ops.make_step_cfg(neg_group_k=k, **kw))
     e0 = ent.var.clone()
-    tg.step(ops.to_ids(pos), ops.to_ids(neg))
+    losses = []
+    e_ref, r_ref = ent_h.copy(), rel_h.copy()
+    ea, ra = np.full_like(e_ref, 0.1), np.full_like(r_ref, 0.1)
+    for _ in range(2):                                                         # two steps: the accumulators matter in the second
+        tg.step(ops.to_ids(pos), ops.to_ids(neg))
+        losses.append(cport.triple_step(e_ref, ea, r_ref, ra, pos, neg, **kw))
     loss_g = tg.pop_loss()
     touched = (ent.var != e0).any(1)
     n_touched = int(touched.sum().item())
-    uniq = len(np.unique(np.concatenate([pos[:, 0], pos[:, 2], neg[:, 2]])))
+    uniq = len(np.unique(np.concatenate([pos[:, 0], pos[:, 2], neg[:, 0], neg[:, 2]])))
     assert 0 < n_touched <= uniq                                     # only referenced rows move
-    assert np.isfinite(loss_g) and loss_g > 0
+    with capsys.disabled():
+        assert_rows_close(ent.raw(), e_ref, "100K-shape step, entity table")
+        assert_rows_close(rel.raw(), r_ref, "100K-shape step, relation table")
+    assert abs(loss_g - sum(losses)) <= 1e-5 * abs(sum(losses))
+    np.testing.assert_allclose(tg.ent_acc[:, :d].cpu().numpy(), ea, rtol=2e-4, atol=1e-7)
     assert not bool((tg.ws[: tg.ws.numel() - 8 * 4096] != 0).any().item())
 
 
@@ -140,3 +157,18 @@ def test_graph_operators_100k_shape(ops):
     o1, o2, o12 = sparse_attention(g, z, x1), sparse_attention(g, z, x2), sparse_attention(g, z, x1 + x2)
     assert torch.allclose(o12, o1 + o2, rtol=1e-4, atol=1e-4)
     assert float(o1.abs().max()) <= float(x1.abs().max()) + 1e-4                       # convex combination of v rows
+    # oracle (float64 softmax + aggregate over the row's edges in the graph's canonical order) on hub + random rows
+    er, ec = g.e_rows.cpu().numpy(), g.e_cols.cpu().numpy()
+    zh, xh = z.cpu().numpy().astype(np.float64), x1.cpu().numpy().astype(np.float64)
+    o1h = o1.cpu().numpy()
+    order = np.argsort(er, kind="stable")
+    starts = np.searchsorted(er[order], np.arange(n + 1))
+    for r in np.concatenate([np.arange(6), rng.choice(n, 48, replace=False)]):
+        e = order[starts[r]:starts[r + 1]]
+        if len(e) == 0:
+            assert not o1h[r].any()
+            continue
+        lg = np.where(zh[e] > 0, zh[e], 0.2 * zh[e])
+        a = np.exp(lg - lg.max())
+        a /= a.sum()
+        np.testing.assert_allclose(o1h[r], a @ xh[ec[e]], rtol=1e-4, atol=2e-5)

@@ -157,6 +157,9 @@ def test_rdgcn_end_to_end(ops, tmp_path, capsys):
     m.set_args(get_args("RDGCN", output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/",
                         dim=32, neg_triple_num=8, max_epoch=30, start_valid=10, eval_freq=10, learning_rate=0.005))
     m.set_kgs(kgs)
+    with pytest.raises(FileNotFoundError):          # rdgcn.py:424: no word vectors, no silent random input
+        m.init()
+    m.args.random_name_init = True
     m.init()
     before = m.valid_("hits1")
     m.run()

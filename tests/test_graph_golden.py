@@ -266,7 +266,8 @@ def test_rdgcn_layer_on_device_equals_reference_graph():
 
 
 @pytest.mark.gpu
-def test_alinet_model_on_device_equals_reference_graph():
+@pytest.mark.parametrize("grouping", ["runs", "row", "reorder"])
+def test_alinet_model_on_device_equals_reference_graph(grouping):
     """alinet.py:539-677 (GraphConvolution, AliNetGraphAttentionLayer, HighwayLayer with keras BatchNormalization in
     inference mode), :784-866 (_define_model, compute_loss, compute_rel_loss) built by the reference's own
     `_generate_rel_graph` under tests/golden/tf_shim.py: with the 17 variables copied over by name, our layers give the
@@ -287,7 +288,8 @@ def test_alinet_model_on_device_equals_reference_graph():
     m.kgs = types.SimpleNamespace(entities_num=n)
     m.dev, m._rng, m.rel_win_size = dev, np.random.RandomState(0), 3
     m.adj = [EdgeGraph(t["alinet_one_coords"][:, 0], t["alinet_one_coords"][:, 1], t["alinet_one_values"], (n, n), dev),
-             EdgeGraph(t["alinet_two_coords"][:, 0], t["alinet_two_coords"][:, 1], t["alinet_two_values"], (n, n), dev, grouping="runs")]
+             EdgeGraph(t["alinet_two_coords"][:, 0], t["alinet_two_coords"][:, 1], t["alinet_two_values"], (n, n), dev, grouping=grouping)]
+    tag = "alinet" if grouping == "runs" else "alinet_" + grouping          # the reference graph under the matching tf.sparse_softmax stand-in
     m._get_variable()
     m._define_model()
     g0, g1, att, hw = m.one_hop_layers[0], m.one_hop_layers[1], m.two_hop_layers[0], m.highways[0]
@@ -301,17 +303,17 @@ def test_alinet_model_on_device_equals_reference_graph():
             p.copy_(torch.from_numpy(t["alinet_var_" + name].astype(np.float32)).reshape(p.shape).to(dev))
     outs = m._forward()
     for i, o in enumerate(outs):
-        np.testing.assert_allclose(o.detach().cpu().numpy(), t["alinet_out%d" % i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o.detach().cpu().numpy(), t[tag + "_out%d" % i], rtol=1e-4, atol=1e-5)
     emb = m._concat_train(outs)
     pos = torch.from_numpy(t["alinet_pos"]).to(dev)
     neg = torch.from_numpy(t["alinet_neg"]).to(dev)
     loss = m.compute_loss(emb, pos, neg) + m.compute_rel_loss(emb, torch.from_numpy(t["alinet_hs"]).to(dev),
                                                               torch.from_numpy(t["alinet_ts"]).to(dev))
-    ref_loss = float(t["alinet_loss"][0])
+    ref_loss = float(t[tag + "_loss"][0])
     assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * ref_loss
     loss.backward()
     for name, p in by_name.items():
-        ref = t["alinet_grad_" + name]
+        ref = t[tag + "_grad_" + name]
         got = p.grad.detach().cpu().numpy().reshape(ref.shape)
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), name
 

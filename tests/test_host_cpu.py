@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     from openea_amd import _lib
-    assert C.sizeof(_lib.StepCfg) == 72            # 12 x 4-byte fields + 2 pointers (8-byte aligned) + 2 x int32 of oea_step_cfg
+    assert C.sizeof(_lib.StepCfg) == 88            # 12 x 4-byte fields + 2 pointers (8-byte aligned) + 2 x int32 + 3 floats + int32 of oea_step_cfg
     assert C.sizeof(_lib.SamplerSide) == 48        # 5 pointers/u64 + 2 int32
     assert C.sizeof(_lib.RotateCfg) == 72          # 6 doubles + int64 + 4 x int32 of oea_rotate_cfg
 

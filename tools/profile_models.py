@@ -39,6 +39,7 @@ def main():
         m.set_args(get_args(name, scale=scale, output="/tmp/oea_prof/", training_data="synthetic/%s/" % shape, dataset_division="f/",
                             max_epoch=epochs, start_valid=10 ** 6, eval_freq=10 ** 6, sub_epoch=10))
         m.set_kgs(kgs)
+        m.args.random_name_init = True              # RDGCN: no word-vector file on the box
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             t0 = time.time()
