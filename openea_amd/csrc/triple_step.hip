@@ -1051,10 +1051,11 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             apply_rows_dense<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
                                                            items > 0 ? nb1 : 0, loss_accum, lr_t);
         } else {
-            // rows per lane group: 2 for the narrow rows (latency-bound: half the waves, twice the loads in flight),
-            // 1 once a row alone fills the registers; OEA_APPLY_ROWS overrides (1 / 2 / 4) for experiments
+            // rows per lane group: 1.  Measured at the 15K shape (gpurun_out r02a, in-epoch HIP events): R = 1 17.4 us,
+            // R = 2 20.1, R = 4 20.4 -- more (shorter) waves hide the row latency better than more loads per wave.
+            // OEA_APPLY_ROWS overrides (1 / 2 / 4) for experiments.
             static const int env_r = [] { const char *e = getenv("OEA_APPLY_ROWS"); return e ? atoi(e) : 0; }();
-            const int R = env_r ? env_r : (IT <= 4 ? 2 : 1);
+            const int R = env_r ? env_r : 1;
             const int n_part = items > 0 ? nb1 : 0;   /* no triples scored: no loss partials to add */
             const int folded = phase == OEA_PHASE_APPLY;
             auto nb = [&](int r) { return (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + oea::ceil_div(n_ent, r), gpb), 1), 16384); };
