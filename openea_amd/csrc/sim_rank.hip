@@ -397,6 +397,66 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
     }
 }
 
+// ---- threshold-append epilogue (strip-free neighbour search, topk.hip): M = candidates, N = queries -------------------
+// Same sweep as rank_inner_kernel; the epilogue keeps only the similarities at or above the query's threshold thr[q]
+// (estimated from a column sample, so that a few thousand of the n2 candidates survive) and appends (value bits, column)
+// to a list segment PRIVATE to the lane: a query's survivors of chunk y come from the two wave rows (wm) and the two
+// half-waves that share it, hence 4 * gridDim.y segments of `cap` entries per query, each in ascending column order.
+// No atomics, no N x N strip in HBM.  counts[q * nseg + seg] may exceed cap: the entries past cap were dropped and the
+// selection falls back for that query.
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void topk_append_kernel(
+    const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
+    const float *__restrict__ thr, int tiles_per_chunk, int cap, uint2 *__restrict__ lists, int32_t *__restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t q0 = (int64_t)blockIdx.x * TILE;
+    const int64_t nct = (nc + TILE - 1) / TILE;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
+    const int nseg = 4 * (int)gridDim.y;
+    const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + (lane >> 5);
+    float th[2];
+    int napp[2] = {0, 0};
+    uint2 *seg[2];
+    int64_t qi[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
+        const bool ok = qi[tn] < nq;
+        th[tn] = ok ? thr[qi[tn]] : INFINITY;                 // padding rows never append
+        seg[tn] = lists + ((ok ? qi[tn] : 0) * nseg + sidx) * (int64_t)cap;
+    }
+    run_tiles<PACKED>(
+        c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
+        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
+        [&](int64_t t, f32x16 (&acc)[2][2]) {
+            const int64_t c0 = (ct_begin + t) * TILE;
+            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+            const bool full = c0 + TILE <= nc;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);       // ascending in (tm, r >> 2, r & 3)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const float v = acc[tm][tn][r];
+                        if (v >= th[tn] && (full || j < nc)) {
+                            if (napp[tn] < cap) seg[tn][napp[tn]] = make_uint2(__float_as_uint(v), (uint32_t)j);
+                            ++napp[tn];
+                        }
+                    }
+                }
+            }
+        });
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+        if (qi[tn] < nq) counts[qi[tn] * nseg + sidx] = napp[tn];
+}
+
 __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best_key, int64_t n1,
                                      int32_t *__restrict__ argmax) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -840,7 +900,7 @@ struct PackSlot {
     hipStream_t last = nullptr;
     hipEvent_t used = nullptr;
 };
-static PackSlot g_slot[2];
+static PackSlot g_slot[3];       // 0 = queries, 1 = candidates, 2 = the neighbour search's column sample
 
 static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
     PackSlot &sl = g_slot[slot];
@@ -867,7 +927,7 @@ static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, 
 }
 // after the kernels that read the packed operands have been enqueued
 static int release_packed(hipStream_t st) {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if (g_slot[i].used && g_slot[i].last == st) OEA_CHECK_HIP(hipEventRecord(g_slot[i].used, st));
     return OEA_OK;
 }
@@ -895,6 +955,18 @@ int release_packed_rows(hipStream_t st) { return release_packed(st); }
 void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
                             int64_t ld_out, hipStream_t st) {
     launch_store_packed(e1p, n1, e2p, n2, kp, dim, out, ld_out, st);
+}
+// strip-free neighbour search: survivors of the threshold sweep into per-query list segments (see topk_append_kernel);
+// -> number of segments per query (4 * chunks); chunks is chosen here so that the grid fills the chip
+int topk_append_chunks(int64_t nq, int64_t nc) {
+    int tpc;
+    return pick_chunks(ceil_div(nq, TILE), ceil_div(nc, TILE), &tpc);
+}
+void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
+                        int chunks, void *lists, int32_t *counts, hipStream_t st) {
+    const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);       // chunks planned by topk_append_chunks
+    topk_append_kernel<true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
+        qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, static_cast<uint2 *>(lists), counts);
 }
 }  // namespace oea
 

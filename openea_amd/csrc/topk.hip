@@ -19,6 +19,11 @@
 //      from a sample of the row, candidates kept in LDS, exact selection on the LDS copy.
 //   All paths give the (value desc, column asc) selection in ascending column order, bit-identical with
 //   oracle_topk_inner.
+#include <math.h>
+#include <stdlib.h>
+
+#include <cmath>
+
 #include "common.h"
 
 namespace {
@@ -529,6 +534,277 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
     select_row_3pass(src, nc, k, id_map, o, hist, c_key, c_col);
 }
 
+
+// ---- strip-free search for long candidate lists ---------------------------------------------------------------------
+// (1) thr[q] = the r-th largest similarity of query q to a strided SAMPLE of kSample candidates: with r a little above
+//     k * kSample / nc (3 sigma + slack) the whole row holds >= k values at or above it, and only ~1.35 k of them;
+// (2) the tile sweep appends exactly those survivors to per-query list segments (sim_rank.hip: topk_append_kernel) --
+//     the nq x nc strip is never written (it was 2 x 40 GB of traffic at 100,000 x 100,000);
+// (3) list_select_kernel picks the exact top-k by (value desc, column asc) among a query's survivors in LDS and writes
+//     them in ascending column order (bitonic sort of the k selected columns);
+// (4) queries whose lists overflowed, fell short of k or are tie-heavy are redone by fallback_rows_kernel: the row is
+//     recomputed with the same k-ordered fmaf chain as the matrix cores and selected by the three-read path.
+// Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
+constexpr int kSample = 4096;
+constexpr int kListCap = 4096;          // survivors of one query that fit the LDS copy
+constexpr int kMaxSeg = 256;
+
+__device__ __forceinline__ float ord2f(uint32_t key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+
+// one wave per row: radix select of the r-th largest of kSample values held in registers
+__global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict__ s, int64_t n_rows, int64_t ld, int r,
+                                                        float *__restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;                        // whole waves exit together
+    constexpr int PER = kSample / 64;
+    uint32_t key[PER];
+    const float *src = s + row * ld;
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + (i * 64 + lane) * 4);
+        key[4 * i] = f2ord(v.x); key[4 * i + 1] = f2ord(v.y); key[4 * i + 2] = f2ord(v.z); key[4 * i + 3] = f2ord(v.w);
+    }
+    uint32_t prefix = 0;
+    int need = r;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = prefix | (1u << bit), mask = ~((1u << bit) - 1u);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) cnt += (key[i] & mask) == cand;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (cnt >= need) prefix = cand; else need -= cnt;
+    }
+    if (lane == 0) thr[row] = ord2f(prefix);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *__restrict__ lists, const int32_t *__restrict__ counts,
+                                                                   int nseg, int cap, int64_t n_rows, int k,
+                                                                   const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
+                                                                   int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
+    __shared__ float l_val[kListCap];
+    __shared__ int l_col[kListCap];
+    __shared__ int s_sel[kListCap];
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    __shared__ int s_off[kMaxSeg + 1];
+    __shared__ float s_red[8];
+    __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol, s_nsel;
+    __shared__ uint32_t s_tkey;
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_bad = 0; s_ncand = 0; s_nsel = 0; }
+    __syncthreads();
+    for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
+        const int c = counts[row * nseg + sg];
+        s_off[sg + 1] = c;
+        if (c > cap) s_bad = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        s_off[0] = 0;
+        for (int sg = 0; sg < nseg; ++sg) { acc += s_off[sg + 1]; s_off[sg + 1] = acc; }
+        if (acc < k || acc > kListCap) s_bad = 1;
+    }
+    __syncthreads();
+    const int total = s_off[nseg];
+    bool fail = s_bad != 0;                                      // block-uniform from here on
+    if (!fail) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int o = s_off[sg], n = s_off[sg + 1] - o;
+            const uint2 *src = lists + (row * nseg + sg) * (int64_t)cap;
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const uint2 e = src[i];
+                const float v = __uint_as_float(e.x);
+                l_val[o + i] = v;
+                l_col[o + i] = (int)e.y;
+                mn = fminf(mn, v);
+                mx = fmaxf(mx, v);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, off, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+        for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+        __syncthreads();
+        const float lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        const float hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+        const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
+        for (int i = tid; i < total; i += SEL_THREADS) atomicAdd(&hist[lin_bin(l_val[i], lo, scale)], 1);
+        __syncthreads();
+        if (tid < 64) {          // the bucket (from the top) where the cumulative count reaches k
+            constexpr int per = kBins / 64;
+            const int top = kBins - 1 - tid * per;
+            int sum = 0;
+            for (int b = 0; b < per; ++b) sum += hist[top - b];
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += t;
+            }
+            const int before = incl - sum;
+            if (before < k && incl >= k) {
+                int acc = before;
+                for (int b = 0; b < per; ++b) {
+                    const int c = hist[top - b];
+                    if (acc + c >= k) { s_bstar = top - b; s_need = k - acc; break; }
+                    acc += c;
+                }
+            }
+        }
+        __syncthreads();
+        const int bstar = s_bstar, need = s_need;
+        fail = hist[bstar] > kCandCap;                          // tie-heavy row: the fallback's radix path handles it
+        if (!fail) {
+            for (int i = tid; i < total; i += SEL_THREADS) {
+                const float v = l_val[i];
+                if (lin_bin(v, lo, scale) == bstar) {
+                    const int p = atomicAdd(&s_ncand, 1);
+                    c_key[p] = f2ord(v);
+                    c_col[p] = l_col[i];
+                }
+            }
+            __syncthreads();
+            const int ncand = s_ncand;
+            for (int i = tid; i < ncand; i += SEL_THREADS) {
+                const uint32_t ki = c_key[i];
+                const int ci = c_col[i];
+                int rank = 0;
+                for (int j = 0; j < ncand; ++j) {
+                    const uint32_t kj = c_key[j];
+                    rank += (kj > ki) || (kj == ki && c_col[j] < ci);
+                }
+                if (rank == need - 1) { s_tkey = ki; s_tcol = ci; }
+            }
+            __syncthreads();
+            const uint32_t tkey = s_tkey;
+            const int tcol = s_tcol;
+            int n2 = 1;
+            while (n2 < k) n2 <<= 1;                            // k <= total <= kListCap = 4096
+            for (int i = tid; i < n2; i += SEL_THREADS) s_sel[i] = 0x7fffffff;
+            __syncthreads();
+            for (int i = tid; i < total; i += SEL_THREADS) {
+                const uint32_t key = f2ord(l_val[i]);
+                const int col = l_col[i];
+                if (key > tkey || (key == tkey && col <= tcol)) s_sel[atomicAdd(&s_nsel, 1)] = col;     // exactly k of them
+            }
+            __syncthreads();
+            for (int size = 2; size <= n2; size <<= 1)           // bitonic sort, ascending columns
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = tid; i < n2 / 2; i += SEL_THREADS) {
+                        const int a = 2 * i - (i & (stride - 1)), b = a + stride;
+                        const int x = s_sel[a], y = s_sel[b];
+                        const bool asc = (a & size) == 0;
+                        if ((x > y) == asc) { s_sel[a] = y; s_sel[b] = x; }
+                    }
+                    __syncthreads();
+                }
+            int32_t *o = out + row * (int64_t)k;
+            for (int i = tid; i < k; i += SEL_THREADS) o[i] = id_map ? id_map[s_sel[i]] : s_sel[i];
+            return;
+        }
+    }
+    if (tid == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
+}
+
+// the rare rows list_select_kernel gave up on: similarity row by the k-ordered fmaf chain (== the MFMA tiles, bit for bit)
+// into a scratch row per workgroup, then the three-read select
+__global__ __launch_bounds__(SEL_THREADS) void fallback_rows_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ c,
+                                                                     int64_t nc, int ldc, int dim, int k,
+                                                                     const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
+                                                                     const int32_t *__restrict__ fail_rows,
+                                                                     const int32_t *__restrict__ n_fail, float *__restrict__ scratch,
+                                                                     int64_t ld) {
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    __shared__ float qs[2048];
+    const int nf = *n_fail;
+    float *srow = scratch + (int64_t)blockIdx.x * ld;
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int64_t row = fail_rows[f];
+        for (int i = threadIdx.x; i < dim; i += SEL_THREADS) qs[i] = q[row * ldq + i];
+        __syncthreads();
+        for (int64_t j = threadIdx.x; j < nc; j += SEL_THREADS) {
+            const float *b = c + j * ldc;
+            float acc = 0.f;
+            int kk = 0;
+            for (; kk + 4 <= dim; kk += 4) {
+                const float4 y = oea::ld4(b + kk);
+                acc = fmaf(qs[kk], y.x, acc); acc = fmaf(qs[kk + 1], y.y, acc);
+                acc = fmaf(qs[kk + 2], y.z, acc); acc = fmaf(qs[kk + 3], y.w, acc);
+            }
+            for (; kk < dim; ++kk) acc = fmaf(qs[kk], b[kk], acc);
+            srow[j] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        select_row_3pass(srow, nc, k, id_map, out + row * (int64_t)k, hist, c_key, c_col);
+        __syncthreads();
+    }
+}
+
+constexpr int kFallbackBlocks = 256;
+
+struct ListPlan {
+    bool ok = false;
+    int r = 0, cap = 0, chunks = 0, nseg = 0;
+    int64_t rows_per = 0, stride = 0, ld = 0;
+    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0;
+};
+
+// workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
+static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
+    ListPlan p;
+    if (nq < 4096 || nc < 32768) return p;
+    const double e = (double)k * kSample / (double)nc;
+    p.r = (int)(e + 3.0 * std::sqrt(e) + 8.0);
+    const double m_total = (double)p.r * (double)nc / kSample;
+    if (p.r >= kSample / 2 || m_total * 1.25 > kListCap) return p;
+    p.stride = nc / kSample;
+    p.ld = (nc + 31) / 32 * 32;
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t fixed = a256(sizeof(float) * (size_t)kFallbackBlocks * p.ld) + 4096;
+    if (ws_bytes <= fixed) return p;
+    int64_t rows = nq;
+    for (int iter = 0; iter < 8; ++iter) {
+        const int chunks = oea::topk_append_chunks(rows, nc);
+        const int nseg = 4 * chunks;
+        if (nseg > kMaxSeg) return p;
+        const double m = m_total / nseg;
+        const int cap = ((int)(m + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
+        const size_t per_row = sizeof(float) * kSample + (size_t)nseg * cap * 8 + (size_t)nseg * 4 + 4 + 4 + 16;
+        int64_t fit = (int64_t)((ws_bytes - fixed) / per_row) / 128 * 128;
+        if (fit >= nq) fit = nq;
+        if (fit < 128) return p;
+        p.chunks = chunks; p.nseg = nseg; p.cap = cap;
+        if (fit >= rows) { p.rows_per = rows; p.ok = true; break; }
+        rows = fit;
+    }
+    if (!p.ok) return p;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += a256(bytes); return o; };
+    p.off_thr = take(sizeof(float) * (size_t)p.rows_per);
+    p.off_counts = take(sizeof(int32_t) * (size_t)p.rows_per * p.nseg);
+    p.off_fail = take(sizeof(int32_t) * (size_t)p.rows_per);
+    p.off_nfail = take(256);
+    p.off_lists = take((size_t)p.rows_per * p.nseg * p.cap * 8);
+    p.off_strip = take(sizeof(float) * (size_t)p.rows_per * kSample);
+    p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
+    p.ok = off <= ws_bytes;
+    return p;
+}
+
 // long rows with k well inside the LDS candidate lists take the one-read kernel
 static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int k, const int32_t *id_map, int32_t *out,
                           hipStream_t st) {
@@ -580,6 +856,38 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         int rc = oea::pack_rows(0, q, nq, ldq, dim, st, &qp, &kp);
         if (rc == OEA_OK) rc = oea::pack_rows(1, c, nc, ldc, dim, st, &cp, &kp);
         if (rc != OEA_OK) return rc;
+    }
+    static const bool lists_on = [] { const char *e = getenv("OEA_TOPK_LISTS"); return !(e && e[0] == '0'); }();
+    const ListPlan lp = (packed && lists_on && dim <= 2048) ? plan_lists(nq, nc, k, ws_bytes) : ListPlan();
+    if (lp.ok) {                                    // strip-free path (see above)
+        char *w = static_cast<char *>(workspace);
+        float *thr = reinterpret_cast<float *>(w + lp.off_thr);
+        int32_t *counts = reinterpret_cast<int32_t *>(w + lp.off_counts);
+        int32_t *fail_rows = reinterpret_cast<int32_t *>(w + lp.off_fail);
+        int32_t *n_fail = reinterpret_cast<int32_t *>(w + lp.off_nfail);
+        void *lists = w + lp.off_lists;
+        float *sstrip = reinterpret_cast<float *>(w + lp.off_strip);
+        float *scratch = reinterpret_cast<float *>(w + lp.off_scratch);
+        float *sp = nullptr;
+        int kps = 0;
+        int rc = oea::pack_rows(2, c, kSample, ldc * (int)lp.stride, dim, st, &sp, &kps);   // every stride-th candidate row
+        if (rc != OEA_OK) return rc;
+        for (int64_t r0 = 0; r0 < nq; r0 += lp.rows_per) {
+            const int64_t rows = std::min<int64_t>(lp.rows_per, nq - r0);
+            oea::sim_inner_store_packed(qp + r0 * kp, rows, sp, kSample, kp, dim, sstrip, kSample, st);
+            kth_value_kernel<<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
+            OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
+            // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
+            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, lists, counts, st);
+            list_select_kernel<<<(unsigned)rows, SEL_THREADS, 0, st>>>(static_cast<const uint2 *>(lists), counts, lp.nseg, lp.cap, rows,
+                                                                      k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail);
+            fallback_rows_kernel<<<kFallbackBlocks, SEL_THREADS, 0, st>>>(q + r0 * ldq, ldq, c, nc, ldc, dim, k, id_map,
+                                                                        out_idx + r0 * (int64_t)k, fail_rows, n_fail, scratch, lp.ld);
+        }
+        rc = oea::release_packed_rows(st);
+        if (rc != OEA_OK) return rc;
+        OEA_CHECK_HIP(hipGetLastError());
+        return OEA_OK;
     }
     for (int64_t r0 = 0; r0 < nq; r0 += rows_per) {              // r0 is a multiple of 128: strips start on tile rows
         const int64_t rows = std::min<int64_t>(rows_per, nq - r0);

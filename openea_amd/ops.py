@@ -352,7 +352,10 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     # default: strips of <= 2 GB.  Measured at 100,000 x 100,000, k = 2,000: 64 MB strips 169 ms, 192 MB (Infinity-
     # Cache resident) 77 ms, 1.5 GB 51 ms, 12 GB 46 ms -- thousands of rows per launch (a full wave of workgroups
     # for both kernels, few launch tails) matter more than keeping the strip in the 256 MB cache.
-    ws_bytes = min(full, max(2 << 30, 128 * ((nc + 31) // 32 * 32) * 4)) if ws_bytes is None else min(full, ws_bytes)
+    # Long candidate lists (nc >= 32,768, nq >= 4,096) take the strip-free path (csrc/topk.hip): ~55 KB of workspace per
+    # query row (sample strip + survivor lists); 8 GB covers 100,000 queries in one pass.
+    big = nc >= 32768 and nq >= 4096
+    ws_bytes = min(full, max((8 << 30) if big else (2 << 30), 128 * ((nc + 31) // 32 * 32) * 4)) if ws_bytes is None else min(full, ws_bytes)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     out = torch.empty((nq, k), dtype=torch.int32, device=q.device)
     check(lib().oea_topk_inner(_p(q), nq, q.shape[1], _p(c), nc, c.shape[1], dim, k, _p(id_map), _p(out),

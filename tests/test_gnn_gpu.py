@@ -124,7 +124,8 @@ def test_alinet_neighbourhood_augmentation(ops, tmp_path, capsys):
     m = AliNet()
     m.set_args(get_args("AliNet", output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/",
                         layer_dims=[64, 48, 32], batch_size=600, max_epoch=12, start_valid=1000, eval_freq=4,
-                        truncated_epsilon=0.9, sim_th=0.55, start_augment=1))
+                        truncated_epsilon=0.9, sim_th=0.55, start_augment=1,
+                        attn_grouping="row"))      # per-row attention: the toy run gets confident pairs within 12 epochs
     m.set_kgs(kgs)
     m.init()
     nnz0 = m.adj[0].nnz

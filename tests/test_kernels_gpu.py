@@ -821,3 +821,28 @@ def test_triple_step_dense_optimisers_vs_oracle(ops, opt, capsys):
     if opt == "Adam":
         assert float(np.abs(d_ent.cpu().numpy()[:, :d] - ent).max()) > 1e-3
     assert not bool((ws[: ws.numel() - 8 * 4096] != 0).any().item())
+
+
+@pytest.mark.parametrize("case", ["random", "clusters", "ties"])
+def test_topk_strip_free_path_bit_exact(ops, case, monkeypatch):
+    """nc >= 32,768 and nq >= 4,096 take the threshold-append sweep + list select (no similarity strip in HBM); rows whose
+    survivor lists overflow / fall short / are tie-heavy are redone by the fallback kernel.  All of it must equal the
+    oracle's (value desc, column asc) selection bit for bit -- and the strip path (OEA_TOPK_LISTS=0 is read once per
+    process, so the comparison with it is through the oracle)."""
+    from oracle import cport
+    rng = np.random.RandomState(7)
+    n, d, k = 33000, 40, 700
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    if case == "clusters":                       # 30 tight clusters in id order: whole candidate tiles survive for their members
+        cen = rng.standard_normal((30, d)).astype(np.float32)
+        x = cen[np.arange(n) * 30 // n] + 0.05 * x
+    if case == "ties":                           # 3,000 identical rows: thousands of exact ties at the k-th value
+        x[5000:8000] = x[5000]
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    t = ops.to_table(x)
+    ids = ops.to_ids((np.arange(n, dtype=np.int32) * 3 + 1))
+    out = ops.topk_inner(t, t, d, k, id_map=ids).cpu().numpy()
+    assert out.shape == (n, k) and np.all(np.diff(out, axis=1) > 0)
+    rows = np.concatenate([rng.choice(n, 40, replace=False), np.array([5000, 5001, 7999, 8000, 0, n - 1])])
+    ref = cport.topk_inner(x[rows], x, k)
+    assert np.array_equal(out[rows], ref * 3 + 1)
