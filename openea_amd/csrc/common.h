@@ -38,6 +38,8 @@ int pack_rows(int slot, const float *src, int64_t n, int ld, int dim, hipStream_
 int release_packed_rows(hipStream_t st);
 void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
                             int64_t ld_out, hipStream_t st);
+void sim_inner_store_packed_gated(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
+                                  int64_t ld_out, const int32_t *gate, hipStream_t st);
 int topk_append_chunks(int64_t nq, int64_t nc);
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
                         int chunks, void *lists, int32_t *counts, hipStream_t st);

@@ -467,9 +467,11 @@ __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best
 template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void sim_inner_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
                                                               const float *__restrict__ e2, int64_t n2, int ld2,
-                                                              int dim, float *__restrict__ out, int64_t ld_out) {
+                                                              int dim, float *__restrict__ out, int64_t ld_out,
+                                                              const int32_t *__restrict__ gate) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    if (gate && *gate == 0) return;          // device-side gate (the neighbour search's fallback sweep: nothing failed)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
@@ -935,7 +937,7 @@ static int release_packed(hipStream_t st) {
 static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
                                 int64_t ld_out, hipStream_t st) {
     sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
-        e1p, n1, kp, e2p, n2, kp, dim, out, ld_out);
+        e1p, n1, kp, e2p, n2, kp, dim, out, ld_out, nullptr);
 }
 
 }  // namespace
@@ -958,6 +960,11 @@ void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int6
 }
 // strip-free neighbour search: survivors of the threshold sweep into per-query list segments (see topk_append_kernel);
 // -> number of segments per query (4 * chunks); chunks is chosen here so that the grid fills the chip
+void sim_inner_store_packed_gated(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
+                                  int64_t ld_out, const int32_t *gate, hipStream_t st) {
+    sim_inner_store_kernel<true><<<dim3((unsigned)ceil_div(n2, TILE), (unsigned)ceil_div(n1, TILE)), 256, 0, st>>>(
+        e1p, n1, kp, e2p, n2, kp, dim, out, ld_out, gate);
+}
 int topk_append_chunks(int64_t nq, int64_t nc) {
     int tpc;
     return pick_chunks(ceil_div(nq, TILE), ceil_div(nc, TILE), &tpc);
@@ -1068,7 +1075,7 @@ int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         if (rc != OEA_OK) return rc;
     } else if (metric == OEA_METRIC_INNER) {
         sim_inner_store_kernel<false><<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
-            e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
+            e1, n1, ld1, e2, n2, ld2, dim, out, ld_out, nullptr);
     } else if (metric == OEA_METRIC_MANHATTAN) {
         sim_valu_store_kernel<OEA_METRIC_MANHATTAN><<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(
             e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);

@@ -546,7 +546,6 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
 //     recomputed with the same k-ordered fmaf chain as the matrix cores and selected by the three-read path.
 // Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
 constexpr int kSample = 4096;
-constexpr int kListCap = 4096;          // survivors of one query that fit the LDS copy
 constexpr int kMaxSeg = 256;
 
 __device__ __forceinline__ float ord2f(uint32_t key) {
@@ -581,23 +580,29 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     if (lane == 0) thr[row] = ord2f(prefix);
 }
 
+constexpr int kPerThread = 24;            // list entries a thread keeps in registers: lists of up to 6,144 survivors
+constexpr int kBitWords = 16384;          // bitmap of selected columns in LDS: nc <= 524,288
+
+// One workgroup per query: the survivors (a few thousand (value, column) pairs in <= kMaxSeg segments) are read ONCE into
+// registers; the exact k-th by (value desc, column asc) comes from a 2048-bucket histogram over [thr, row max] plus a
+// pairwise ranking inside the threshold bucket (as in the strip select); the selected columns are set in an LDS bitmap
+// and enumerated in ascending order -- no sort.
 __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *__restrict__ lists, const int32_t *__restrict__ counts,
-                                                                   int nseg, int cap, int64_t n_rows, int k,
-                                                                   const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
+                                                                   const float *__restrict__ thr, int nseg, int cap, int64_t nc,
+                                                                   int k, const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
                                                                    int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
-    __shared__ float l_val[kListCap];
-    __shared__ int l_col[kListCap];
-    __shared__ int s_sel[kListCap];
     __shared__ int hist[kBins];
     __shared__ uint32_t c_key[kCandCap];
     __shared__ int c_col[kCandCap];
     __shared__ int s_off[kMaxSeg + 1];
-    __shared__ float s_red[8];
-    __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol, s_nsel;
+    __shared__ uint32_t bitmap[kBitWords];
+    __shared__ float s_red[4];
+    __shared__ int s_wave[4];
+    __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol;
     __shared__ uint32_t s_tkey;
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_bad = 0; s_ncand = 0; s_nsel = 0; }
+    if (tid == 0) { s_bad = 0; s_ncand = 0; }
     __syncthreads();
     for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
         const int c = counts[row * nseg + sg];
@@ -609,37 +614,46 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
         int acc = 0;
         s_off[0] = 0;
         for (int sg = 0; sg < nseg; ++sg) { acc += s_off[sg + 1]; s_off[sg + 1] = acc; }
-        if (acc < k || acc > kListCap) s_bad = 1;
+        if (acc < k || acc > kPerThread * SEL_THREADS) s_bad = 1;
     }
+    const int words = (int)((nc + 31) / 32);
+    for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+    for (int w = tid; w < words; w += SEL_THREADS) bitmap[w] = 0u;
     __syncthreads();
     const int total = s_off[nseg];
     bool fail = s_bad != 0;                                      // block-uniform from here on
     if (!fail) {
-        float mn = INFINITY, mx = -INFINITY;
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int o = s_off[sg], n = s_off[sg + 1] - o;
-            const uint2 *src = lists + (row * nseg + sg) * (int64_t)cap;
-            for (int i = tid; i < n; i += SEL_THREADS) {
-                const uint2 e = src[i];
-                const float v = __uint_as_float(e.x);
-                l_val[o + i] = v;
-                l_col[o + i] = (int)e.y;
-                mn = fminf(mn, v);
-                mx = fmaxf(mx, v);
+        float val[kPerThread];
+        int col[kPerThread];
+        float mx = -INFINITY;
+        const uint2 *base = lists + row * nseg * (int64_t)cap;
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e) {
+            const int i = tid + e * SEL_THREADS;
+            val[e] = -INFINITY;
+            col[e] = -1;
+            if (i < total) {
+                int lo_s = 0, hi_s = nseg;                       // s_off[lo_s] <= i < s_off[hi_s]
+                while (hi_s - lo_s > 1) {
+                    const int mid = (lo_s + hi_s) >> 1;
+                    if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
+                }
+                const uint2 en = base[(int64_t)lo_s * cap + (i - s_off[lo_s])];
+                val[e] = __uint_as_float(en.x);
+                col[e] = (int)en.y;
+                mx = fmaxf(mx, val[e]);
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            mn = fminf(mn, __shfl_xor(mn, off, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        }
-        if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
-        for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0) s_red[wave] = mx;
         __syncthreads();
-        const float lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
-        const float hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+        const float lo = thr[row];                               // every survivor is >= thr
+        const float hi = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
-        for (int i = tid; i < total; i += SEL_THREADS) atomicAdd(&hist[lin_bin(l_val[i], lo, scale)], 1);
+#pragma unroll
+        for (int e = 0; e < kPerThread; ++e)
+            if (col[e] >= 0) atomicAdd(&hist[lin_bin(val[e], lo, scale)], 1);
         __syncthreads();
         if (tid < 64) {          // the bucket (from the top) where the cumulative count reaches k
             constexpr int per = kBins / 64;
@@ -664,16 +678,15 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
         }
         __syncthreads();
         const int bstar = s_bstar, need = s_need;
-        fail = hist[bstar] > kCandCap;                          // tie-heavy row: the fallback's radix path handles it
+        fail = hist[bstar] > kCandCap || words > kBitWords;     // tie-heavy row / very long candidate list: the fallback handles it
         if (!fail) {
-            for (int i = tid; i < total; i += SEL_THREADS) {
-                const float v = l_val[i];
-                if (lin_bin(v, lo, scale) == bstar) {
+#pragma unroll
+            for (int e = 0; e < kPerThread; ++e)
+                if (col[e] >= 0 && lin_bin(val[e], lo, scale) == bstar) {
                     const int p = atomicAdd(&s_ncand, 1);
-                    c_key[p] = f2ord(v);
-                    c_col[p] = l_col[i];
+                    c_key[p] = f2ord(val[e]);
+                    c_col[p] = col[e];
                 }
-            }
             __syncthreads();
             const int ncand = s_ncand;
             for (int i = tid; i < ncand; i += SEL_THREADS) {
@@ -689,36 +702,65 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
             __syncthreads();
             const uint32_t tkey = s_tkey;
             const int tcol = s_tcol;
-            int n2 = 1;
-            while (n2 < k) n2 <<= 1;                            // k <= total <= kListCap = 4096
-            for (int i = tid; i < n2; i += SEL_THREADS) s_sel[i] = 0x7fffffff;
-            __syncthreads();
-            for (int i = tid; i < total; i += SEL_THREADS) {
-                const uint32_t key = f2ord(l_val[i]);
-                const int col = l_col[i];
-                if (key > tkey || (key == tkey && col <= tcol)) s_sel[atomicAdd(&s_nsel, 1)] = col;     // exactly k of them
+#pragma unroll
+            for (int e = 0; e < kPerThread; ++e) {
+                if (col[e] < 0) continue;
+                const uint32_t key = f2ord(val[e]);
+                if (key > tkey || (key == tkey && col[e] <= tcol)) atomicOr(&bitmap[col[e] >> 5], 1u << (col[e] & 31));   // exactly k bits
             }
             __syncthreads();
-            for (int size = 2; size <= n2; size <<= 1)           // bitonic sort, ascending columns
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int i = tid; i < n2 / 2; i += SEL_THREADS) {
-                        const int a = 2 * i - (i & (stride - 1)), b = a + stride;
-                        const int x = s_sel[a], y = s_sel[b];
-                        const bool asc = (a & size) == 0;
-                        if ((x > y) == asc) { s_sel[a] = y; s_sel[b] = x; }
-                    }
-                    __syncthreads();
-                }
+            // enumerate the set bits in ascending column order: contiguous word ranges per thread + block scan
+            const int wpt = (words + SEL_THREADS - 1) / SEL_THREADS;
+            const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
+            int cnt = 0;
+            for (int w = w0; w < w1; ++w) cnt += __popc(bitmap[w]);
+            int tot;
+            int pos = block_excl_scan(cnt, s_wave, &tot);
             int32_t *o = out + row * (int64_t)k;
-            for (int i = tid; i < k; i += SEL_THREADS) o[i] = id_map ? id_map[s_sel[i]] : s_sel[i];
+            for (int w = w0; w < w1; ++w) {
+                uint32_t bits = bitmap[w];
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    const int c = 32 * w + b;
+                    o[pos++] = id_map ? id_map[c] : c;
+                }
+            }
             return;
         }
     }
     if (tid == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
 }
 
-// the rare rows list_select_kernel gave up on: similarity row by the k-ordered fmaf chain (== the MFMA tiles, bit for bit)
-// into a scratch row per workgroup, then the three-read select
+// ---- the rows list_select_kernel gave up on ----------------------------------------------------------------------------
+// The first kFbRows of them are redone in bulk: their packed query rows are gathered into one tile row, the tile kernel
+// writes their similarity strip (a 128-row sweep: tens of microseconds), the three-read select runs on it.  Any further
+// rows (adversarial inputs only) take the slow per-row kernel: the k-ordered fmaf chain of one thread per candidate.
+constexpr int kFbRows = 128;
+
+__global__ void gather_fail_rows_kernel(const float *__restrict__ qp, int kp, const int32_t *__restrict__ fail_rows,
+                                        const int32_t *__restrict__ n_fail, float *__restrict__ dst) {
+    const int nf = min(*n_fail, kFbRows);
+    const int cpr = kp / 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kFbRows * cpr; i += gridDim.x * blockDim.x) {
+        const int f = i / cpr, c = i - f * cpr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nf) v = oea::ld4(qp + (int64_t)fail_rows[f] * kp + 4 * c);
+        oea::st4(dst + (int64_t)f * kp + 4 * c, v);
+    }
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void row_select_indirect_kernel(const float *__restrict__ s, int64_t nc, int64_t ld, int k,
+                                                                          const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
+                                                                          const int32_t *__restrict__ fail_rows,
+                                                                          const int32_t *__restrict__ n_fail) {
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    if ((int)blockIdx.x >= min(*n_fail, kFbRows)) return;
+    select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)fail_rows[blockIdx.x] * k, hist, c_key, c_col);
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void fallback_rows_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ c,
                                                                      int64_t nc, int ldc, int dim, int k,
                                                                      const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
@@ -731,7 +773,7 @@ __global__ __launch_bounds__(SEL_THREADS) void fallback_rows_kernel(const float 
     __shared__ float qs[2048];
     const int nf = *n_fail;
     float *srow = scratch + (int64_t)blockIdx.x * ld;
-    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+    for (int f = kFbRows + blockIdx.x; f < nf; f += gridDim.x) {       // rows past the bulk path
         const int64_t row = fail_rows[f];
         for (int i = threadIdx.x; i < dim; i += SEL_THREADS) qs[i] = q[row * ldq + i];
         __syncthreads();
@@ -760,7 +802,7 @@ struct ListPlan {
     bool ok = false;
     int r = 0, cap = 0, chunks = 0, nseg = 0;
     int64_t rows_per = 0, stride = 0, ld = 0;
-    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0;
+    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0;
 };
 
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
@@ -768,13 +810,15 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     ListPlan p;
     if (nq < 4096 || nc < 32768) return p;
     const double e = (double)k * kSample / (double)nc;
-    p.r = (int)(e + 3.0 * std::sqrt(e) + 8.0);
+    // sample rank of the threshold: the row then holds N * Beta(r, S - r + 1) survivors, i.e. about r N / S +- a relative
+    // 1 / sqrt(r); 4.5 sigma above k * S / N keeps "fewer than k survivors" below 1e-5 per row (those rows fall back)
+    p.r = (int)(e + 4.5 * std::sqrt(e) + 8.0);
     const double m_total = (double)p.r * (double)nc / kSample;
-    if (p.r >= kSample / 2 || m_total * 1.25 > kListCap) return p;
+    if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || nc > (int64_t)kBitWords * 32) return p;
     p.stride = nc / kSample;
     p.ld = (nc + 31) / 32 * 32;
     auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t fixed = a256(sizeof(float) * (size_t)kFallbackBlocks * p.ld) + 4096;
+    const size_t fixed = a256(sizeof(float) * (size_t)(kFallbackBlocks + kFbRows) * p.ld) + a256(sizeof(float) * kFbRows * 4096) + 4096;
     if (ws_bytes <= fixed) return p;
     int64_t rows = nq;
     for (int iter = 0; iter < 8; ++iter) {
@@ -801,6 +845,8 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     p.off_lists = take((size_t)p.rows_per * p.nseg * p.cap * 8);
     p.off_strip = take(sizeof(float) * (size_t)p.rows_per * kSample);
     p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
+    p.off_fbstrip = take(sizeof(float) * (size_t)kFbRows * p.ld);
+    p.off_fbq = take(sizeof(float) * kFbRows * 4096);
     p.ok = off <= ws_bytes;
     return p;
 }
@@ -868,6 +914,9 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         void *lists = w + lp.off_lists;
         float *sstrip = reinterpret_cast<float *>(w + lp.off_strip);
         float *scratch = reinterpret_cast<float *>(w + lp.off_scratch);
+        float *fbstrip = reinterpret_cast<float *>(w + lp.off_fbstrip);
+        float *fbq = reinterpret_cast<float *>(w + lp.off_fbq);
+        OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
         float *sp = nullptr;
         int kps = 0;
         int rc = oea::pack_rows(2, c, kSample, ldc * (int)lp.stride, dim, st, &sp, &kps);   // every stride-th candidate row
@@ -879,8 +928,13 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
             oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, lists, counts, st);
-            list_select_kernel<<<(unsigned)rows, SEL_THREADS, 0, st>>>(static_cast<const uint2 *>(lists), counts, lp.nseg, lp.cap, rows,
+            list_select_kernel<<<(unsigned)rows, SEL_THREADS, 0, st>>>(static_cast<const uint2 *>(lists), counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail);
+            // fallback: bulk for the first kFbRows failed rows (gather -> gated tile sweep -> select), slow kernel for the rest
+            gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp + r0 * kp, kp, fail_rows, n_fail, fbq);
+            oea::sim_inner_store_packed_gated(fbq, kFbRows, cp, nc, kp, dim, fbstrip, lp.ld, n_fail, st);
+            row_select_indirect_kernel<<<kFbRows, SEL_THREADS, 0, st>>>(fbstrip, nc, lp.ld, k, id_map, out_idx + r0 * (int64_t)k,
+                                                                       fail_rows, n_fail);
             fallback_rows_kernel<<<kFallbackBlocks, SEL_THREADS, 0, st>>>(q + r0 * ldq, ldq, c, nc, ldc, dim, k, id_map,
                                                                         out_idx + r0 * (int64_t)k, fail_rows, n_fail, scratch, lp.ld);
         }
