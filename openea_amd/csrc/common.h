@@ -42,7 +42,7 @@ void sim_inner_store_packed_gated(const float *e1p, int64_t n1, const float *e2p
                                   int64_t ld_out, const int32_t *gate, hipStream_t st);
 int topk_append_chunks(int64_t nq, int64_t nc);
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
-                        int chunks, void *lists, int32_t *counts, hipStream_t st);
+                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

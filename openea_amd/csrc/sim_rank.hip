@@ -399,15 +399,17 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
 
 // ---- threshold-append epilogue (strip-free neighbour search, topk.hip): M = candidates, N = queries -------------------
 // Same sweep as rank_inner_kernel; the epilogue keeps only the similarities at or above the query's threshold thr[q]
-// (estimated from a column sample, so that a few thousand of the n2 candidates survive) and appends (value bits, column)
-// to a list segment PRIVATE to the lane: a query's survivors of chunk y come from the two wave rows (wm) and the two
-// half-waves that share it, hence 4 * gridDim.y segments of `cap` entries per query, each in ascending column order.
-// No atomics, no N x N strip in HBM.  counts[q * nseg + seg] may exceed cap: the entries past cap were dropped and the
-// selection falls back for that query.
+// (estimated from a column sample, so that a few thousand of the n2 candidates survive) and appends (value, column) to a
+// list segment PRIVATE to the lane: a query's survivors of chunk y come from the two wave rows (wm) and the two half-waves
+// that share it, hence 4 * gridDim.y segments of `cap` entries per query, each in ascending column order.  No atomics, no
+// N x N strip in HBM.  Values and columns go to two arrays (one dword store each from the register that holds them) at a
+// 32-bit byte offset from a wave-uniform base.  counts[q * nseg + seg] may exceed cap: the entries past cap were dropped
+// and the selection falls back for that query.
 template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
-    const float *__restrict__ thr, int tiles_per_chunk, int cap, uint2 *__restrict__ lists, int32_t *__restrict__ counts) {
+    const float *__restrict__ thr, int tiles_per_chunk, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols,
+    int32_t *__restrict__ counts) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -419,42 +421,49 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     const int nseg = 4 * (int)gridDim.y;
     const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + (lane >> 5);
     float th[2];
-    int napp[2] = {0, 0};
-    uint2 *seg[2];
+    uint32_t boff[2], bbeg[2], blast[2];                          // byte offsets in the lane's segment from the workgroup's base
     int64_t qi[2];
+    char *__restrict__ vbase = reinterpret_cast<char *>(list_vals + q0 * nseg * (int64_t)cap);      // wave-uniform
+    char *__restrict__ cbase = reinterpret_cast<char *>(list_cols + q0 * nseg * (int64_t)cap);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
-        const bool ok = qi[tn] < nq;
-        th[tn] = ok ? thr[qi[tn]] : INFINITY;                 // padding rows never append
-        seg[tn] = lists + ((ok ? qi[tn] : 0) * nseg + sidx) * (int64_t)cap;
+        const int ql = wn * 64 + tn * 32 + (lane & 31);
+        qi[tn] = q0 + ql;
+        th[tn] = qi[tn] < nq ? thr[qi[tn]] : INFINITY;            // padding rows never append
+        bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
+        blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);          // survivors past cap overwrite the last slot; boff keeps counting
     }
+    auto sweep = [&](f32x16 (&acc)[2][2], int jb, int j_end) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);       // ascending in (tm, r >> 2, r & 3)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const float v = acc[tm][tn][r];
+                    if (v >= th[tn] && j < j_end) {
+                        const uint32_t at = min(boff[tn], blast[tn]);
+                        *reinterpret_cast<float *>(vbase + at) = v;
+                        *reinterpret_cast<int32_t *>(cbase + at) = j;
+                        boff[tn] += 4u;
+                    }
+                }
+            }
+        }
+    };
     run_tiles<PACKED>(
         c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
         [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
         [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * TILE;
             const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
-            const bool full = c0 + TILE <= nc;
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);       // ascending in (tm, r >> 2, r & 3)
-#pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) {
-                        const float v = acc[tm][tn][r];
-                        if (v >= th[tn] && (full || j < nc)) {
-                            if (napp[tn] < cap) seg[tn][napp[tn]] = make_uint2(__float_as_uint(v), (uint32_t)j);
-                            ++napp[tn];
-                        }
-                    }
-                }
-            }
+            if (c0 + TILE <= nc) sweep(acc, jb, 0x7fffffff);      // interior tile: the bound folds away
+            else sweep(acc, jb, (int)nc);
         });
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
-        if (qi[tn] < nq) counts[qi[tn] * nseg + sidx] = napp[tn];
+        if (qi[tn] < nq) counts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
 }
 
 __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best_key, int64_t n1,
@@ -970,10 +979,10 @@ int topk_append_chunks(int64_t nq, int64_t nc) {
     return pick_chunks(ceil_div(nq, TILE), ceil_div(nc, TILE), &tpc);
 }
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
-                        int chunks, void *lists, int32_t *counts, hipStream_t st) {
+                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st) {
     const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);       // chunks planned by topk_append_chunks
     topk_append_kernel<true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
-        qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, static_cast<uint2 *>(lists), counts);
+        qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts);
 }
 }  // namespace oea
 

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
 // (4) queries whose lists overflowed, fell short of k or are tie-heavy are redone by fallback_rows_kernel: the row is
 //     recomputed with the same k-ordered fmaf chain as the matrix cores and selected by the three-read path.
 // Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
-constexpr int kSample = 4096;
+constexpr int kSample = 2048;          // 2,048 sampled candidates: survivors ~ r N / S +- 1/sqrt(r) (r ~ 71 at k/N = 2 %)
 constexpr int kMaxSeg = 256;
 
 __device__ __forceinline__ float ord2f(uint32_t key) {
@@ -581,13 +581,14 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
 }
 
 constexpr int kPerThread = 24;            // list entries a thread keeps in registers: lists of up to 6,144 survivors
-constexpr int kBitWords = 16384;          // bitmap of selected columns in LDS: nc <= 524,288
+constexpr int kBitWords = 8192;           // bitmap of selected columns in (dynamic) LDS: nc <= 262,144
 
 // One workgroup per query: the survivors (a few thousand (value, column) pairs in <= kMaxSeg segments) are read ONCE into
 // registers; the exact k-th by (value desc, column asc) comes from a 2048-bucket histogram over [thr, row max] plus a
 // pairwise ranking inside the threshold bucket (as in the strip select); the selected columns are set in an LDS bitmap
 // and enumerated in ascending order -- no sort.
-__global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *__restrict__ lists, const int32_t *__restrict__ counts,
+__global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *__restrict__ list_vals, const int32_t *__restrict__ list_cols,
+                                                                   const int32_t *__restrict__ counts,
                                                                    const float *__restrict__ thr, int nseg, int cap, int64_t nc,
                                                                    int k, const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
                                                                    int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
     __shared__ uint32_t c_key[kCandCap];
     __shared__ int c_col[kCandCap];
     __shared__ int s_off[kMaxSeg + 1];
-    __shared__ uint32_t bitmap[kBitWords];
+    extern __shared__ uint32_t bitmap[];      // ceil(nc / 32) words (dynamic: 12.5 KB at nc = 100,000 keeps 5 workgroups per CU)
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
     __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol;
@@ -626,7 +627,8 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
         float val[kPerThread];
         int col[kPerThread];
         float mx = -INFINITY;
-        const uint2 *base = lists + row * nseg * (int64_t)cap;
+        const float *vb = list_vals + row * nseg * (int64_t)cap;
+        const int32_t *cb = list_cols + row * nseg * (int64_t)cap;
 #pragma unroll
         for (int e = 0; e < kPerThread; ++e) {
             const int i = tid + e * SEL_THREADS;
@@ -638,9 +640,9 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
                     const int mid = (lo_s + hi_s) >> 1;
                     if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
                 }
-                const uint2 en = base[(int64_t)lo_s * cap + (i - s_off[lo_s])];
-                val[e] = __uint_as_float(en.x);
-                col[e] = (int)en.y;
+                const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
+                val[e] = vb[at];
+                col[e] = cb[at];
                 mx = fmaxf(mx, val[e]);
             }
         }
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const uint2 *_
         }
         __syncthreads();
         const int bstar = s_bstar, need = s_need;
-        fail = hist[bstar] > kCandCap || words > kBitWords;     // tie-heavy row / very long candidate list: the fallback handles it
+        fail = hist[bstar] > kCandCap;                          // tie-heavy row: the fallback's radix path handles it
         if (!fail) {
 #pragma unroll
             for (int e = 0; e < kPerThread; ++e)
@@ -802,7 +804,7 @@ struct ListPlan {
     bool ok = false;
     int r = 0, cap = 0, chunks = 0, nseg = 0;
     int64_t rows_per = 0, stride = 0, ld = 0;
-    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0;
+    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, cols_off = 0;
 };
 
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
@@ -811,8 +813,9 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     if (nq < 4096 || nc < 32768) return p;
     const double e = (double)k * kSample / (double)nc;
     // sample rank of the threshold: the row then holds N * Beta(r, S - r + 1) survivors, i.e. about r N / S +- a relative
-    // 1 / sqrt(r); 4.5 sigma above k * S / N keeps "fewer than k survivors" below 1e-5 per row (those rows fall back)
-    p.r = (int)(e + 4.5 * std::sqrt(e) + 8.0);
+    // 1 / sqrt(r); 3.5 sigma above k * S / N leaves "fewer than k survivors" at ~2e-4 per row -- those rows go through the
+    // bulk fallback (one gated 128-row tile sweep), which costs less than longer lists for every row would
+    p.r = (int)(e + 3.5 * std::sqrt(e) + 8.0);
     const double m_total = (double)p.r * (double)nc / kSample;
     if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || nc > (int64_t)kBitWords * 32) return p;
     p.stride = nc / kSample;
@@ -828,6 +831,7 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
         const double m = m_total / nseg;
         const int cap = ((int)(m + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
         const size_t per_row = sizeof(float) * kSample + (size_t)nseg * cap * 8 + (size_t)nseg * 4 + 4 + 4 + 16;
+        if ((size_t)128 * nseg * cap * 4 >= ((size_t)1 << 31)) return p;          // 32-bit byte offsets inside a query tile
         int64_t fit = (int64_t)((ws_bytes - fixed) / per_row) / 128 * 128;
         if (fit >= nq) fit = nq;
         if (fit < 128) return p;
@@ -842,7 +846,8 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     p.off_counts = take(sizeof(int32_t) * (size_t)p.rows_per * p.nseg);
     p.off_fail = take(sizeof(int32_t) * (size_t)p.rows_per);
     p.off_nfail = take(256);
-    p.off_lists = take((size_t)p.rows_per * p.nseg * p.cap * 8);
+    p.cols_off = a256((size_t)p.rows_per * p.nseg * p.cap * 4);
+    p.off_lists = take(2 * p.cols_off);
     p.off_strip = take(sizeof(float) * (size_t)p.rows_per * kSample);
     p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
     p.off_fbstrip = take(sizeof(float) * (size_t)kFbRows * p.ld);
@@ -911,7 +916,8 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         int32_t *counts = reinterpret_cast<int32_t *>(w + lp.off_counts);
         int32_t *fail_rows = reinterpret_cast<int32_t *>(w + lp.off_fail);
         int32_t *n_fail = reinterpret_cast<int32_t *>(w + lp.off_nfail);
-        void *lists = w + lp.off_lists;
+        float *list_vals = reinterpret_cast<float *>(w + lp.off_lists);
+        int32_t *list_cols = reinterpret_cast<int32_t *>(w + lp.off_lists + lp.cols_off);
         float *sstrip = reinterpret_cast<float *>(w + lp.off_strip);
         float *scratch = reinterpret_cast<float *>(w + lp.off_scratch);
         float *fbstrip = reinterpret_cast<float *>(w + lp.off_fbstrip);
@@ -927,8 +933,9 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             kth_value_kernel<<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
-            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, lists, counts, st);
-            list_select_kernel<<<(unsigned)rows, SEL_THREADS, 0, st>>>(static_cast<const uint2 *>(lists), counts, thr, lp.nseg, lp.cap, nc,
+            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, st);
+            list_select_kernel<<<(unsigned)rows, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
+                list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail);
             // fallback: bulk for the first kFbRows failed rows (gather -> gated tile sweep -> select), slow kernel for the rest
             gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp + r0 * kp, kp, fail_rows, n_fail, fbq);
