@@ -155,6 +155,30 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                           double *loss_accum, int32_t phase, void *stream);
 
+/* Entity-id partitioning of the same step across `world` processes (one per GPU): owner of entity row id = id mod world
+ * (BASELINE.json north_star; SURVEY 8e: ids are degree-ordered, contiguous ranges would put every hub on rank 0).  Every rank
+ * keeps a full read copy of the entity table and the optimiser state of ITS rows only (acc_own [rows_per_rank, ld]).
+ *   oea_triple_step_phase(..., OEA_PHASE_GRAD)        local gradients into the workspace scratch
+ *   oea_part_pack      scratch -> `send` in owner-major order: world chunks of rpr*(ld+1) floats (rpr rows, then their
+ *                      touched flags; rpr = oea_part_rows_per_rank), scratch cleared on the way; relation gradients + flags
+ *                      -> rel_x [n_rel*(ld+1)]
+ *   reduce-scatter of `send` over the ranks (chunk r to rank r: oea_comm_reduce_scatter_f32 / torch.distributed) -> `own`;
+ *   all-reduce of rel_x (relations are few: replicated, every rank applies the same update)
+ *   oea_part_apply     optimiser on the owned rows (in place in the natural-order table) + relation rows; the owned rows
+ *                      after the update also go to `upd` [rpr, ld]; adds the step's loss (n_items = work items of the GRAD call:
+ *                      n_pos for grouped negatives / margin pairs, else n_pos + n_neg)
+ *   all-gather of `upd` -> `all` [world][rpr][ld]
+ *   oea_part_unpack    the other ranks' rows into the local read copy
+ * SGD / Adagrad, TransE score.  Result = the single-process step on the concatenated batch. */
+int64_t oea_part_rows_per_rank(int64_t n_ent, int32_t world);
+size_t oea_part_send_floats(int64_t n_ent, int32_t ld, int32_t world);
+int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, float *send, float *rel_x,
+                  void *stream);
+int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t ld,
+                   int32_t world, int32_t rank, float *own, float *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
+                   int64_t n_items, double *loss_accum, void *stream);
+int oea_part_unpack(float *ent, int64_t n_ent, int32_t ld, int32_t world, int32_t rank, const float *all, void *stream);
+
 /* Add externally computed gradients w.r.t. the (normalised) entity rows `ids` into the step's
  * gradient scratch: grad[ids[i]] += src[i].  Followed by oea_triple_step_phase(...,
  * n_pos = n_neg = 0, OEA_PHASE_APPLY) this runs the optimiser for losses that are not
@@ -464,6 +488,29 @@ int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, 
  * normalize == 0: plain SGD. */
 int oea_sgd_rows(float *w, const float *grad_t, int64_t rows, int32_t dim, int32_t ld,
                  int32_t normalize, float lr, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Collective group (one process per GPU, RCCL over xGMI) -- no reference counterpart (the reference is single-device,
+ * SURVEY F2).  The exchange points of the multi-GPU path for a host that is not Python: reduce-scatter / all-gather of
+ * the partitioned step (oea_part_*), int64 / fp64 sums of the row-sharded evaluation's metrics, all-gather of row blocks
+ * (argmax, neighbour lists, a graph layer's output rows).  RCCL is dlopen'ed by oea_comm_unique_id / oea_comm_init: a
+ * single-GPU process never loads it.  The Python host uses torch.distributed (backend "nccl" = the same RCCL).
+ *   rank 0: oea_comm_unique_id(id) -> ship the 128 bytes to the other ranks (any channel) -> every rank, after
+ *   hipSetDevice(its GPU): oea_comm_init(id, rank, nranks, &comm).  Calls are asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------- */
+typedef struct oea_comm *oea_comm_t;
+int oea_comm_unique_id(void *id_out_128);
+int oea_comm_init(const void *unique_id_128, int32_t rank, int32_t nranks, oea_comm_t *out);
+int oea_comm_destroy(oea_comm_t c);
+int32_t oea_comm_rank(oea_comm_t c);
+int32_t oea_comm_size(oea_comm_t c);
+/* recv [nranks][rows_per_rank, ld] <- every rank's send [rows_per_rank, ld] */
+int oea_allgather_rows(oea_comm_t c, const float *send, float *recv, int64_t rows_per_rank, int32_t ld, void *stream);
+/* recv [n_per_rank] = sum over ranks of send[rank * n_per_rank ...] (send holds nranks * n_per_rank floats) */
+int oea_comm_reduce_scatter_f32(oea_comm_t c, const float *send, float *recv, int64_t n_per_rank, void *stream);
+int oea_allreduce_f32(oea_comm_t c, float *buf, int64_t n, void *stream);
+int oea_allreduce_f64(oea_comm_t c, double *buf, int64_t n, void *stream);
+int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,12 @@ PROTOTYPES = {
     "oea_step_exchange_floats": (_sz, [_i64, _i64, _i32]),
     "oea_triple_step_phase": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
                                         C.POINTER(StepCfg), _vp, _vp, _i32, _vp]),
+    "oea_part_rows_per_rank": (_i64, [_i64, _i32]),
+    "oea_part_send_floats": (_sz, [_i64, _i32, _i32]),
+    "oea_part_pack": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "oea_part_apply": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.POINTER(StepCfg), _vp, _i64,
+                                 _vp, _vp]),
+    "oea_part_unpack": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "oea_step_scatter_ent_rows": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "oea_tripleset_capacity": (_u64, [_i64]),
     "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
@@ -131,6 +137,16 @@ PROTOTYPES = {
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "oea_sgd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "oea_comm_unique_id": (C.c_int, [_vp]),
+    "oea_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "oea_comm_destroy": (C.c_int, [_vp]),
+    "oea_comm_rank": (_i32, [_vp]),
+    "oea_comm_size": (_i32, [_vp]),
+    "oea_allgather_rows": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "oea_comm_reduce_scatter_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "oea_allreduce_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "oea_allreduce_f64": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "oea_allreduce_i64": (C.c_int, [_vp, _vp, _i64, _vp]),
 }
 
 _lib = None

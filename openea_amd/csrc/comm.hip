@@ -1,0 +1,140 @@
+// comm.hip -- the collective group of the C ABI (oea_comm_init, oea_allgather_rows, oea_allreduce_i64, ...).
+//
+// One process per GPU; the collectives are RCCL's (ring / tree over xGMI).  The reference has no distributed code at all
+// (SURVEY F2), so nothing is replaced here: these calls are the multi-GPU exchange points of the partitioned
+// translational step (oea_part_*: reduce-scatter of the packed gradients, all-gather of the updated rows), of the
+// row-sharded evaluation (int64 / fp64 sums of the metrics, all-gather of argmax rows) and of the row-sharded graph
+// aggregates (all-gather of a layer's output rows), for a host that is not Python.  The Python host uses
+// torch.distributed (backend "nccl" = the same RCCL).
+//
+// RCCL is resolved with dlopen at oea_comm_init time: libopenea_hip.so has no link-time dependency on it, a single-GPU
+// process never loads it, and a process that already holds an RCCL (PyTorch's) shares that copy.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+// the subset of rccl.h this file needs (ABI-stable NCCL 2 API)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8 };       // ncclDataType_t
+enum { ncclSum = 0 };                                            // ncclRedOp_t
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return nullptr;
+#define OEA_SYM(field, name)                                                        \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));          \
+    if (!r.field) { r.handle = nullptr; return nullptr; }
+    OEA_SYM(GetUniqueId, "ncclGetUniqueId")
+    OEA_SYM(CommInitRank, "ncclCommInitRank")
+    OEA_SYM(CommDestroy, "ncclCommDestroy")
+    OEA_SYM(AllReduce, "ncclAllReduce")
+    OEA_SYM(AllGather, "ncclAllGather")
+    OEA_SYM(ReduceScatter, "ncclReduceScatter")
+    OEA_SYM(GetErrorString, "ncclGetErrorString")
+#undef OEA_SYM
+    return &r;
+}
+
+}  // namespace
+
+struct oea_comm {
+    ncclComm_t comm;
+    int rank, nranks;
+};
+
+#define OEA_CHECK_RCCL(expr)                                                                       \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != 0) {                                                                             \
+            oea::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rccl()->GetErrorString(_r)); \
+            return OEA_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+extern "C" {
+
+int oea_comm_unique_id(void *id_out_128) {
+    OEA_REQUIRE(id_out_128, "null pointer");
+    Rccl *r = rccl();
+    if (!r) { oea::set_error("RCCL (librccl.so.1) cannot be loaded: %s", dlerror()); return OEA_EUNSUPPORTED; }
+    OEA_CHECK_RCCL(r->GetUniqueId(static_cast<ncclUniqueId *>(id_out_128)));
+    return OEA_OK;
+}
+
+int oea_comm_init(const void *unique_id_128, int32_t rank, int32_t nranks, oea_comm_t *out) {
+    OEA_REQUIRE(unique_id_128 && out && nranks >= 1 && rank >= 0 && rank < nranks, "arguments");
+    Rccl *r = rccl();
+    if (!r) { oea::set_error("RCCL (librccl.so.1) cannot be loaded: %s", dlerror()); return OEA_EUNSUPPORTED; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128, sizeof(id));
+    ncclComm_t c = nullptr;
+    OEA_CHECK_RCCL(r->CommInitRank(&c, nranks, id, rank));       // binds the calling thread's current HIP device
+    *out = new oea_comm{c, rank, nranks};
+    return OEA_OK;
+}
+
+int oea_comm_destroy(oea_comm_t c) {
+    if (!c) return OEA_OK;
+    OEA_CHECK_RCCL(rccl()->CommDestroy(c->comm));
+    delete c;
+    return OEA_OK;
+}
+
+int32_t oea_comm_rank(oea_comm_t c) { return c ? c->rank : -1; }
+int32_t oea_comm_size(oea_comm_t c) { return c ? c->nranks : 0; }
+
+int oea_allgather_rows(oea_comm_t c, const float *send, float *recv, int64_t rows_per_rank, int32_t ld, void *stream) {
+    OEA_REQUIRE(c && send && recv && rows_per_rank >= 0 && ld > 0, "arguments");
+    OEA_CHECK_RCCL(rccl()->AllGather(send, recv, (size_t)rows_per_rank * ld, ncclFloat32, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_comm_reduce_scatter_f32(oea_comm_t c, const float *send, float *recv, int64_t n_per_rank, void *stream) {
+    OEA_REQUIRE(c && send && recv && n_per_rank >= 0, "arguments");
+    OEA_CHECK_RCCL(rccl()->ReduceScatter(send, recv, (size_t)n_per_rank, ncclFloat32, ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_allreduce_f32(oea_comm_t c, float *buf, int64_t n, void *stream) {
+    OEA_REQUIRE(c && buf && n >= 0, "arguments");
+    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_allreduce_f64(oea_comm_t c, double *buf, int64_t n, void *stream) {
+    OEA_REQUIRE(c && buf && n >= 0, "arguments");
+    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream) {
+    OEA_REQUIRE(c && buf && n >= 0, "arguments");
+    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclInt64, ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+}  // extern "C"

@@ -966,6 +966,122 @@ __global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent,
     }
 }
 
+// ---- entity-id partitioning of the step (one process per GPU; BASELINE.json north_star) -----------------------
+// Owner of entity row id = id mod G (ids are degree-ordered with the two KGs interleaved, read.py:64-79: contiguous ranges
+// would put every hub on rank 0).  Every rank keeps a full READ copy of the table for its gathers and the optimiser state
+// of its own rows only.  Per step:
+//   GRAD phase (unchanged kernels)        -> local gradient scratch
+//   part_pack_kernel                      -> send buffer in OWNER-MAJOR order [G][rpr * (ld + 1)] (rows then touched flags),
+//                                            scratch rows + flags cleared on the way; relation rows to a small buffer
+//   reduce-scatter (RCCL)                 -> this rank's rows summed over the ranks [rpr * (ld + 1)]
+//   all-reduce of the relation buffer     (a few hundred rows: replicated, every rank applies the same update)
+//   part_apply_kernel                     -> optimiser on the owned rows (strided in the natural table), updated rows also
+//                                            written to a contiguous block for the all-gather; relation rows
+//   all-gather (RCCL)                     -> everyone's updated rows [G][rpr][ld]
+//   part_unpack_kernel                    -> the other ranks' rows into the local read copy
+// The collectives move (G-1)/G * E * (2 ld + 1) * 4 bytes per rank and step -- the volume of the all-reduce they replace --
+// but the optimiser runs on 1/G of the rows and its state is sharded.
+template <int G, int IT>
+__global__ __launch_bounds__(256) void part_pack_kernel(StepWs ws, int64_t n_ent, int64_t n_rel, int ld, int world, int64_t rpr,
+                                                        float *__restrict__ send, float *__restrict__ rel_x) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    const int64_t chunk = rpr * (ld + 1);
+    const int64_t slots = (int64_t)world * rpr;
+    for (int64_t w = grp; w < slots + n_rel; w += ngrp) {
+        if (w >= slots) {                                          // relation row: grads (copies folded by the GRAD phase) + flag
+            const int64_t r = w - slots;
+            const float f = ws.rel_touched[r];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = it * G + lane;
+                if (c < ld) {
+                    rel_x[r * ld + c] = f != 0.f ? ws.rel_grad[r * ld + c] : 0.f;
+                    if (f != 0.f) ws.rel_grad[r * ld + c] = 0.f;
+                }
+            }
+            if (lane == 0) { rel_x[n_rel * ld + r] = f; ws.rel_touched[r] = 0.f; }
+            continue;
+        }
+        const int64_t o = w / rpr, j = w - o * rpr, id = j * world + o;        // slot (o, j) holds entity id
+        const float f = id < n_ent ? ws.ent_touched[id] : 0.f;
+        float *dst = send + o * chunk + j * ld;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * G + lane;
+            if (c < ld) {
+                dst[c] = f != 0.f ? ws.ent_grad[id * ld + c] : 0.f;
+                if (f != 0.f) ws.ent_grad[id * ld + c] = 0.f;
+            }
+        }
+        if (lane == 0) {
+            send[o * chunk + rpr * ld + j] = f;
+            if (f != 0.f) ws.ent_touched[id] = 0.f;
+        }
+    }
+}
+
+template <int G, int IT>
+__global__ __launch_bounds__(256) void part_apply_kernel(float *__restrict__ ent, float *__restrict__ acc_own, int64_t n_ent,
+                                                         float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel,
+                                                         int ld, int world, int rank, int64_t rpr, float *__restrict__ own /* [rpr*(ld+1)] */,
+                                                         float *__restrict__ rel_x, float *__restrict__ upd /* [rpr, ld] */,
+                                                         oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t w = grp; w < rpr + n_rel; w += ngrp) {
+        Row<G, IT> rv, rg, ra;
+        if (w >= rpr) {
+            const int64_t r = w - rpr;
+            if (rel_x[n_rel * ld + r] == 0.f) continue;
+            load_row<G, IT>(rel + r * ld, ld, lane, rv);
+            load_row<G, IT>(rel_x + r * ld, ld, lane, rg);
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(rel_acc + r * ld, ld, lane, ra);
+            float dummy;
+            apply_one_row<G, IT>(rel + r * ld, rel_acc + r * ld, rel_x + r * ld, &dummy, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
+            continue;
+        }
+        const int64_t j = w, id = j * world + rank;
+        if (id >= n_ent) {                                         // padding slot of the last stripe
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { const int c = it * G + lane; if (c < ld) upd[j * ld + c] = 0.f; }
+            continue;
+        }
+        float *v = ent + id * ld;
+        load_row<G, IT>(v, ld, lane, rv);
+        if (own[rpr * ld + j] != 0.f) {
+            load_row<G, IT>(own + j * ld, ld, lane, rg);
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc_own + j * ld, ld, lane, ra);
+            float dummy;
+            apply_one_row<G, IT>(v, acc_own + j * ld, own + j * ld, &dummy, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
+            load_row<G, IT>(v, ld, lane, rv);                      // the updated row (same lanes wrote it)
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { const int c = it * G + lane; if (c < ld) upd[j * ld + c] = rv.v[it]; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {                      // fixed-order reduction of the loss partials
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 64) s += ws.partials[i];
+        s = oea::wave_sum_d(s);
+        if (threadIdx.x == 0) *loss_accum += s;
+    }
+}
+
+__global__ void part_unpack_kernel(float *__restrict__ ent, int64_t n_ent, int ld, int world, int rank, int64_t rpr,
+                                   const float *__restrict__ all /* [G][rpr][ld] */) {
+    const int cpr = ld / 4;
+    const int64_t total = n_ent * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = i / cpr;
+        const int c = (int)(i - id * cpr);
+        const int o = (int)(id % world);
+        if (o == rank) continue;
+        oea::st4(ent + id * ld + 4 * c, oea::ld4(all + ((int64_t)o * rpr + id / world) * ld + 4 * c));
+    }
+}
+
 // data parallel: fold relation copies 1.. into copy 0 (and clear them) so that only copy 0 is exchanged
 __global__ void fold_rel_copies_kernel(StepWs ws, int64_t n, int with_normal) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1106,7 +1222,8 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     OEA_REQUIRE(n_pos >= 0 && n_neg >= 0 && (neg || n_neg == 0), "neg == NULL needs n_neg == 0");
     OEA_REQUIRE(cfg->loss_kind >= OEA_LOSS_MARGIN && cfg->loss_kind <= OEA_LOSS_ALIGN, "loss_kind");
     OEA_REQUIRE(cfg->opt_kind >= OEA_OPT_SGD && cfg->opt_kind <= OEA_OPT_ADADELTA, "opt_kind");
-    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (ent_acc && rel_acc), "Adagrad / Adam / Adadelta need their state arrays");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || phase == OEA_PHASE_GRAD || (ent_acc && rel_acc),
+                "Adagrad / Adam / Adadelta need their state arrays (the GRAD phase alone does not)");
     if (cfg->opt_kind == OEA_OPT_ADAM || cfg->opt_kind == OEA_OPT_ADADELTA) {
         OEA_REQUIRE(cfg->score_kind != OEA_SCORE_TRANSH, "Adam / Adadelta are not built for the TransH normal-vector table");
         OEA_REQUIRE(cfg->opt_kind != OEA_OPT_ADAM || cfg->opt_t >= 1, "Adam: opt_t = 1-based step count");
@@ -1159,6 +1276,73 @@ int oea_step_scatter_ent_rows(void *workspace, int64_t n_ent, int64_t n_rel, int
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     scatter_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n * ld, 256), 65535), 256, 0, oea::as_stream(stream)>>>(
         ws.ent_grad, ws.ent_touched, ld, ids, n, src, src_ld);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int64_t oea_part_rows_per_rank(int64_t n_ent, int32_t world) { return world > 0 ? (n_ent + world - 1) / world : 0; }
+
+size_t oea_part_send_floats(int64_t n_ent, int32_t ld, int32_t world) {
+    return (size_t)world * (size_t)oea_part_rows_per_rank(n_ent, world) * (size_t)(ld + 1);
+}
+
+#define OEA_PART_DISPATCH(CALL)                                         \
+    if (ld <= 32) { CALL(32, 1); }                                      \
+    else if (ld <= 64) { CALL(32, 2); }                                 \
+    else if (ld <= 96) { CALL(32, 3); }                                 \
+    else if (ld <= 128) { CALL(32, 4); }                                \
+    else if (ld <= 256) { CALL(64, 4); }                                \
+    else if (ld <= 512) { CALL(64, 8); }                                \
+    else if (ld <= 1280) { CALL(64, 20); }                              \
+    else { oea::set_error("ld %d > 1280 unsupported", ld); return OEA_EUNSUPPORTED; }
+
+int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, float *send, float *rel_x,
+                  void *stream) {
+    OEA_REQUIRE(workspace && send && rel_x && world >= 1 && ld % 4 == 0, "arguments");
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    const int64_t rpr = oea_part_rows_per_rank(n_ent, world);
+    hipStream_t st = oea::as_stream(stream);
+#define OEA_CALL(G, IT)                                                                                                   \
+    part_pack_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(world * rpr + n_rel, 256 / G), 16384), 256, 0, st>>>( \
+        ws, n_ent, n_rel, ld, world, rpr, send, rel_x)
+    OEA_PART_DISPATCH(OEA_CALL)
+#undef OEA_CALL
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t ld,
+                   int32_t world, int32_t rank, float *own, float *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
+                   int64_t n_items, double *loss_accum, void *stream) {
+    OEA_REQUIRE(ent && rel && own && rel_x && upd && cfg && workspace && loss_accum, "null pointer");
+    OEA_REQUIRE(world >= 1 && rank >= 0 && rank < world && ld % 4 == 0, "world / rank / ld");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (cfg->opt_kind == OEA_OPT_ADAGRAD && acc_own && rel_acc), "SGD or Adagrad (+ state)");
+    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE, "the partitioned step covers the TransE score");
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    const int64_t rpr = oea_part_rows_per_rank(n_ent, world);
+    hipStream_t st = oea::as_stream(stream);
+    // loss partials: one per workgroup of the GRAD kernel that just ran on n_items work items (launch_step's nb1)
+#define OEA_CALL(G, IT)                                                                                                       \
+    {                                                                                                                         \
+        const int gpb = 256 / G;                                                                                              \
+        const int n_part = n_items > 0 ? (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_items, gpb), 1), kMaxBlocks) : 0; \
+        part_apply_kernel<G, IT><<<(unsigned)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(rpr + n_rel, gpb), 1), 16384), 256, 0, st>>>( \
+            ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, rpr, own, rel_x, upd, *cfg, ws, n_part, loss_accum);   \
+    }
+    OEA_PART_DISPATCH(OEA_CALL)
+#undef OEA_CALL
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_part_unpack(float *ent, int64_t n_ent, int32_t ld, int32_t world, int32_t rank, const float *all, void *stream) {
+    OEA_REQUIRE(ent && all && world >= 1 && rank >= 0 && rank < world && ld % 4 == 0, "arguments");
+    if (world == 1) return OEA_OK;
+    const int64_t rpr = oea_part_rows_per_rank(n_ent, world);
+    part_unpack_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_ent * (ld / 4), 256), 16384), 256, 0, oea::as_stream(stream)>>>(
+        ent, n_ent, ld, world, rank, rpr, all);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

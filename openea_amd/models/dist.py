@@ -7,9 +7,11 @@ What shards and how:
   row block [lo_r, hi_r) of the queries, the candidate block is replicated (it is an embedding
   lookup of a replicated table), no data-path collective; the integer metrics are summed with
   one small all-reduce, per-row outputs (argmax / neighbour ids) are all-gathered.
-* translational step -- one exchange per step: tables replicated, every rank scores its slice
-  of the batch, the gradient scratch is summed with ONE all-reduce, every rank applies the same
-  update (models/trainer.py).
+* translational step -- entity rows are OWNED cyclically by id (owner = id mod G); every rank keeps a read copy
+  of the table, scores its slice of the batch, the packed gradients are reduce-scattered to their owners,
+  the owners run the optimiser on their rows (1/G of the state and of the work) and the updated rows are
+  all-gathered (models/trainer.py: TripleTrainer._step_partitioned).  The small replicated steps (MTransE's
+  mapping step, BootEA's alignment step) and the projected scores keep one dense all-reduce.
 
 Everything here is index arithmetic + collectives on whatever device the tensors live on, so it
 is exercised on CPU with gloo (tests/test_dist_cpu.py); the compute callbacks default to the HIP
@@ -24,6 +26,11 @@ def world(group=None):
     if not dist.is_available() or not dist.is_initialized():
         return 0, 1
     return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _staged(t, group):
+    """gloo (CPU tests, and the N-processes-on-one-GPU wiring tests) has no device collectives: stage on the host"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def shard_range(n, rank, world_size):
@@ -45,19 +52,25 @@ def shard_sizes(n, world_size):
 
 def allgather_rows(local, n_total, group=None):
     """local: this rank's row block [hi-lo, ...] -> the full [n_total, ...] tensor on every rank.
-    Blocks are padded to the largest block so that one all_gather moves everything."""
+    ONE all_gather_into_tensor of blocks padded to the largest block (no per-rank list, no torch.cat)."""
     rank, ws = world(group)
     if ws == 1:
         return local
     sizes = shard_sizes(n_total, ws)
     m = max(sizes)
-    # gloo (CPU tests, and the 2-processes-on-one-GPU wiring test) has no device all_gather: stage on the host
-    stage = local.is_cuda and dist.get_backend(group) == "gloo"
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device="cpu" if stage else local.device)
-    pad[: local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0).to(local.device)
+    stage = _staged(local, group)
+    dev = "cpu" if stage else local.device
+    if local.shape[0] == m and not stage:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+        pad[: local.shape[0]] = local
+    out = torch.empty((ws * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)     # concatenation along dim 0
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view((ws, m) + tuple(local.shape[1:]))
+    if all(sz == m for sz in sizes):
+        return out.reshape((ws * m,) + tuple(local.shape[1:])).to(local.device)
+    return torch.cat([out[r, :sz] for r, sz in enumerate(sizes)], dim=0).to(local.device)
 
 
 def balanced_bounds(indptr, world_size):
@@ -77,20 +90,22 @@ def balanced_bounds(indptr, world_size):
 
 def allgather_blocks(full, bounds, group=None):
     """`full` [n, ...]: rank r has written rows [bounds[r], bounds[r+1]); afterwards every rank has every
-    block (in place; blocks padded to the largest so that ONE all_gather moves everything)."""
+    block (in place; ONE all_gather_into_tensor of blocks padded to the largest)."""
     rank, ws = world(group)
     if ws == 1:
         return full
     sizes = [bounds[r + 1] - bounds[r] for r in range(ws)]
     m = max(sizes)
-    stage = full.is_cuda and dist.get_backend(group) == "gloo"
-    pad = torch.zeros((m,) + tuple(full.shape[1:]), dtype=full.dtype, device="cpu" if stage else full.device)
+    stage = _staged(full, group)
+    dev = "cpu" if stage else full.device
+    pad = torch.zeros((m,) + tuple(full.shape[1:]), dtype=full.dtype, device=dev)
     pad[: sizes[rank]] = full[bounds[rank]: bounds[rank + 1]]
-    parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad, group=group)
+    out = torch.empty((ws * m,) + tuple(full.shape[1:]), dtype=full.dtype, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view((ws, m) + tuple(full.shape[1:]))
     for r in range(ws):
         if r != rank and sizes[r]:
-            full[bounds[r]: bounds[r + 1]] = parts[r][: sizes[r]].to(full.device)
+            full[bounds[r]: bounds[r + 1]] = out[r, : sizes[r]].to(full.device)
     return full
 
 
@@ -99,6 +114,37 @@ def allreduce_sum_(t, group=None):
     if ws > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def reduce_scatter_(out, inp, group=None):
+    """out [chunk] = sum over ranks of inp[rank * chunk : (rank + 1) * chunk]  (one RCCL reduce-scatter)"""
+    rank, ws = world(group)
+    if ws == 1:
+        out.copy_(inp)
+        return out
+    if _staged(inp, group):
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(o)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def all_gather_into_(out, inp, group=None):
+    """out [G, ...] <- every rank's inp [...]  (one RCCL all-gather, no list / cat copies)"""
+    rank, ws = world(group)
+    if ws == 1:
+        out.view(inp.shape).copy_(inp)
+        return out
+    flat = (out.shape[0] * out.shape[1],) + tuple(out.shape[2:])                 # [G, rows, ...] viewed as the dim-0 concatenation
+    if _staged(inp, group):
+        o = torch.empty(flat, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=group)
+        out.view(flat).copy_(o)
+    else:
+        dist.all_gather_into_tensor(out.view(flat), inp.contiguous(), group=group)
+    return out
 
 
 def sync_replicated_(t, group=None):

@@ -72,6 +72,48 @@ class TripleTrainer:
         self._empty = torch.zeros((0, 3), dtype=torch.int32, device=dev)
         self.dist = dist_group
         self.xchg = ops.step_exchange_view(self.ws, ent.rows, rel.rows, ent.ld) if dist_group is not None else None
+        # entity-id partitioning (owner = id mod G: include/openea_hip.h, oea_part_*): the sharded main step of the
+        # translational models.  OEA_DP_EXCHANGE=allreduce keeps the replicated update with one dense all-reduce.
+        self.part = None
+        import os
+        if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD') and cfg.score_kind == ops.SCORE_TRANSE
+                and os.environ.get("OEA_DP_EXCHANGE", "partition") == "partition"):
+            self._init_partition(optimizer)
+
+    def _init_partition(self, optimizer):
+        import torch.distributed as dist
+        g, rk = dist.get_world_size(self.dist), dist.get_rank(self.dist)
+        ent, rel, dev = self.ent, self.rel, self.dev
+        rpr = ops.part_rows_per_rank(ent.rows, g)
+        chunk = rpr * (ent.ld + 1)
+        p = dict(world=g, rank=rk, rpr=rpr, chunk=chunk,
+                 send=torch.empty(g * chunk, dtype=torch.float32, device=dev),
+                 own=torch.empty(chunk, dtype=torch.float32, device=dev),
+                 rel_x=torch.empty(rel.rows * (rel.ld + 1), dtype=torch.float32, device=dev),
+                 upd=torch.empty((rpr, ent.ld), dtype=torch.float32, device=dev),
+                 all=torch.empty((g, rpr, ent.ld), dtype=torch.float32, device=dev))
+        if optimizer == 'Adagrad':                 # the state of the owned rows only: row j <-> entity id j * G + rank
+            p['acc_own'] = torch.full((rpr, ent.ld), 0.1, dtype=torch.float32, device=dev)
+            self.ent_acc = None                    # 1/G of the optimiser state per rank
+        else:
+            p['acc_own'] = None
+        self.part = p
+
+    def _step_partitioned(self, pos, neg):
+        """GRAD | pack | reduce-scatter + relation all-reduce | apply owned rows | all-gather | unpack"""
+        from . import dist as mdist
+        p = self.part
+        ops.triple_step(self.ent.var, None, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg, self.ws, self.loss,
+                        phase=ops.PHASE_GRAD)
+        ops.part_pack(self.ws, self.ent.rows, self.rel.rows, self.ent.ld, p['world'], p['send'], p['rel_x'])
+        mdist.reduce_scatter_(p['own'], p['send'], self.dist)
+        mdist.allreduce_sum_(p['rel_x'], self.dist)
+        grouped = self.cfg.neg_group_k > 0 or self.cfg.loss_kind == 0
+        n_items = pos.shape[0] if grouped else pos.shape[0] + (0 if neg is None else neg.shape[0])
+        ops.part_apply(self.ent.var, p['acc_own'], self.rel.var, self.rel_acc, p['world'], p['rank'], p['own'], p['rel_x'],
+                       p['upd'], self.cfg, self.ws, n_items, self.loss)
+        mdist.all_gather_into_(p['all'], p['upd'], self.dist)
+        ops.part_unpack(self.ent.var, p['world'], p['rank'], p['all'])
 
     def count_steps(self, n=1):
         """n more optimiser steps are about to run: cfg.opt_t = 1-based count of the first of them"""
@@ -81,7 +123,9 @@ class TripleTrainer:
     def step(self, pos, neg):
         """pos / neg: device int32 [n,3] (neg may be None)."""
         self.count_steps()
-        if self.dist is None:
+        if self.part is not None:
+            self._step_partitioned(pos, neg)
+        elif self.dist is None:
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss)
         else:
@@ -126,6 +170,9 @@ class TripleTrainer:
             return 0
         import torch.distributed as dist
         g = dist.get_world_size(self.dist)
+        if self.part is not None:       # reduce-scatter of the packed gradients + all-gather of the updated rows + relation all-reduce
+            p = self.part
+            return int((p['send'].numel() + p['all'].numel()) * 4 * (g - 1) / g + p['rel_x'].numel() * 4 * 2 * (g - 1) / g)
         return int(self.xchg.numel() * 4 * 2 * (g - 1) / g)
 
     def pop_loss(self):

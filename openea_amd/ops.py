@@ -205,6 +205,23 @@ def mapping_step(ent, dim, ent_l2_norm, ids1, ids2, mapping, mapping_acc, alpha,
     return work
 
 
+def part_rows_per_rank(n_ent, world):
+    return int(lib().oea_part_rows_per_rank(int(n_ent), int(world)))
+
+
+def part_pack(workspace, n_ent, n_rel, ld, world, send, rel_x):
+    check(lib().oea_part_pack(_p(workspace), n_ent, n_rel, ld, world, _p(send), _p(rel_x), _stream()))
+
+
+def part_apply(ent, acc_own, rel, rel_acc, world, rank, own, rel_x, upd, cfg, workspace, n_items, loss_accum):
+    check(lib().oea_part_apply(_p(ent), _p(acc_own), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], ent.shape[1], world, rank,
+                               _p(own), _p(rel_x), _p(upd), C.byref(cfg), _p(workspace), int(n_items), _p(loss_accum), _stream()))
+
+
+def part_unpack(ent, world, rank, all_rows):
+    check(lib().oea_part_unpack(_p(ent), ent.shape[0], ent.shape[1], world, rank, _p(all_rows), _stream()))
+
+
 def step_exchange_view(workspace, n_ent, n_rel, ld):
     """fp32 view of the workspace region (gradient scratch + touched flags) that data-parallel
     ranks sum with one all-reduce."""
