@@ -44,8 +44,8 @@ for step in range(4):
     neg = np.repeat(pos, k, 0)
     neg[:, 2] = rng.randint(0, n_ent, len(neg))
     lo, hi = shard_range(B, rank, world)
-    if step == 3 and world > 1 and rank == world - 1:
-        lo = hi                                                  # an empty shard still joins every collective
+    if step == 3 and world > 1:                                  # the last rank gets an EMPTY shard and still joins every collective
+        lo, hi = shard_range(B, rank, world - 1) if rank < world - 1 else (B, B)
     tr.step(ops.to_ids(pos[lo:hi]), ops.to_ids(neg[lo * k: hi * k]))
 loss = tr.pop_loss()
 state_rows = tr.part["acc_own"].shape[0] if (tr.part is not None and tr.part["acc_own"] is not None) else (0 if tr.ent_acc is None else tr.ent_acc.shape[0])
