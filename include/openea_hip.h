@@ -405,6 +405,13 @@ int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
  * summed in descending order in fp32.  k <= 64. */
 int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_t k, float *out,
                       void *stream);
+/* CSLS means in one sweep (calculate_nearest_k of S and of S^T, similarity.py:60-65,80-83) for the inner-product metric,
+ * without S in HBM: r_out[i] = mean of the k largest of row i of e1 e2^T, c_out[j] = the same for column j -- equal to
+ * oea_row_topk_mean on the strips of S and S^T bit for bit.  n1, n2 >= 4096 and k <= 32 (otherwise OEA_EUNSUPPORTED and
+ * the caller takes the strip route); workspace: oea_csls_means_workspace_bytes (0 = shape not covered). */
+size_t oea_csls_means_workspace_bytes(int64_t n1, int64_t n2, int32_t k);
+int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, int32_t k,
+                   float *r_out, float *c_out, void *workspace, size_t ws_bytes, void *stream);
 /* in place S'_ij = (2*S_ij - r_i) - c_j (csls_sim, similarity.py:74-76) */
 int oea_csls_apply(float *s, int64_t n1, int64_t n2, int64_t ld, const float *r, const float *c,
                    void *stream);

@@ -128,6 +128,8 @@ PROTOTYPES = {
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "oea_sim_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "oea_csls_means_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "oea_csls_means": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, C.POINTER(CsrSplit), _vp]),
     "oea_sparse_attn_workspace_floats": (_sz, [_i64, _i64]),
@@ -148,6 +150,11 @@ PROTOTYPES = {
     "oea_allreduce_f64": (C.c_int, [_vp, _vp, _i64, _vp]),
     "oea_allreduce_i64": (C.c_int, [_vp, _vp, _i64, _vp]),
 }
+
+def tile_glds():
+    """the packed (LDS-DMA) tile path is on unless OEA_TILE_GLDS=0 (csrc/sim_rank.hip)"""
+    return os.environ.get("OEA_TILE_GLDS", "1")[:1] != "0"
+
 
 _lib = None
 

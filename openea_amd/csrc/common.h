@@ -41,6 +41,8 @@ void sim_inner_store_packed(const float *e1p, int64_t n1, const float *e2p, int6
 void sim_inner_store_packed_gated(const float *e1p, int64_t n1, const float *e2p, int64_t n2, int kp, int dim, float *out,
                                   int64_t ld_out, const int32_t *gate, hipStream_t st);
 int topk_append_chunks(int64_t nq, int64_t nc);
+int kth_value(const float *strip, int64_t rows, int sample, int r, float *thr, hipStream_t st);          // topk.hip
+void gather_packed_rows(const float *qp, int kp, const int32_t *rows, const int32_t *n_rows, float *dst, hipStream_t st);   // <= 128 rows
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
                         int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st);
 

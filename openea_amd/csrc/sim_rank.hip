@@ -17,6 +17,7 @@
 // floats (144 B) makes the b128 reads bank-conflict free.
 #include "common.h"
 #include <stdlib.h>
+#include <cmath>
 
 namespace {
 
@@ -749,12 +750,14 @@ __device__ float topk_mean_by_insertion(const float *__restrict__ src, int64_t n
 }
 
 __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restrict__ s, int64_t n1, int64_t n2,
-                                                            int64_t ld, int k, float *__restrict__ out) {
+                                                            int64_t ld, int k, float *__restrict__ out,
+                                                            const int32_t *__restrict__ out_index /* may be NULL */,
+                                                            const int32_t *__restrict__ n_active /* may be NULL */) {
     __shared__ float s_cand[4][kCandMean];
     __shared__ int s_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= n1) return;                                   // whole waves leave: no block-wide barrier below
+    if (row >= n1 || (n_active && row >= *n_active)) return;  // whole waves leave: no block-wide barrier below
     const float *src = s + row * ld;
     const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(s) & 15) == 0);
     const int64_t n4 = vec ? (n2 & ~(int64_t)3) : 0;        // [0, n4) by float4, the rest scalar
@@ -834,7 +837,7 @@ __global__ __launch_bounds__(256) void row_topk_mean_kernel(const float *__restr
         }
         result = acc / (float)k;
     }
-    if (lane == 0) out[row] = result;
+    if (lane == 0) out[out_index ? out_index[row] : row] = result;
 }
 
 __global__ void csls_apply_kernel(float *__restrict__ s, int64_t n1, int64_t n2, int64_t ld,
@@ -850,6 +853,199 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
     int64_t chunks = std::min<int64_t>(want, c_tiles);
     *tiles_per_chunk = (int)((c_tiles + chunks - 1) / chunks);
     return (int)((c_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk);
+}
+
+
+// ---- CSLS means in ONE sweep (similarity.py:57-83 without S or S^T in HBM) ------------------------------------------------
+// r_i = mean of the k largest of row i of S = e1 e2^T, c_j = the same for column j.  Both are top-k problems with k ~ 10, so
+// a per-row / per-column threshold estimated from a strided sample (as in the strip-free neighbour search, topk.hip) lets
+// the tile sweep keep the few hundred values that can matter: the query side in lane-private list segments (no atomics),
+// the candidate side in one list per candidate (a returning atomic per survivor: ~1 % of the values).  The exact top-k
+// means come from the lists, summed in DESCENDING order like row_topk_mean_kernel (bit-identical with oracle_topk_mean).
+// Rows / columns whose list overflowed or fell short are redone from a recomputed strip (bulk: <= 128 of each).
+template <bool PACKED>
+__global__ __launch_bounds__(256, 2) void csls_append_kernel(
+    const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
+    const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
+    float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t q0 = (int64_t)blockIdx.x * TILE;
+    const int64_t nct = (nc + TILE - 1) / TILE;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
+    const int nseg = 4 * (int)gridDim.y;
+    const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + (lane >> 5);
+    float th[2];
+    uint32_t boff[2], bbeg[2], blast[2];
+    int64_t qi[2];
+    char *__restrict__ vbase = reinterpret_cast<char *>(qlists + q0 * nseg * (int64_t)cap);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int ql = wn * 64 + tn * 32 + (lane & 31);
+        qi[tn] = q0 + ql;
+        th[tn] = qi[tn] < nq ? thr_q[qi[tn]] : INFINITY;
+        bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
+        blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);
+    }
+    run_tiles<PACKED>(
+        c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
+        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
+        [&](int64_t t, f32x16 (&acc)[2][2]) {
+            const int64_t c0 = (ct_begin + t) * TILE;
+            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool jin = j < nc;
+                    const float tc = jin ? thr_c[j] : INFINITY;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const float v = acc[tm][tn][r];
+                        if (v >= th[tn] && jin) {
+                            *reinterpret_cast<float *>(vbase + min(boff[tn], blast[tn])) = v;
+                            boff[tn] += 4u;
+                        }
+                        if (v >= tc && qi[tn] < nq) {
+                            const int pos = atomicAdd(ccounts + j, 1);
+                            if (pos < ccap) clists[(int64_t)j * ccap + pos] = v;
+                        }
+                    }
+                }
+            }
+        });
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+        if (qi[tn] < nq) qcounts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
+}
+
+constexpr int kMeanRegs = 16;                 // list values per lane: lists of up to 1,024 survivors
+constexpr int kMeanSeg = 256;
+
+// mean of the k largest of `cnt` values held kMeanRegs per lane (-inf padded): k rounds of wave-wide maximum, summed in
+// descending order -- the arithmetic of row_topk_mean_kernel
+__device__ __forceinline__ float wave_topk_mean(float (&c)[kMeanRegs], int k, int lane) {
+    float acc = 0.f;
+    for (int round = 0; round < k; ++round) {
+        float h = c[0];
+#pragma unroll
+        for (int u = 1; u < kMeanRegs; ++u) h = fmaxf(h, c[u]);
+        float m = h;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        const unsigned long long bal = __ballot(h == m);
+        if (lane == __ffsll((long long)bal) - 1) {       // remove ONE instance of the maximum
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < kMeanRegs; ++u)
+                if (!done && c[u] == m) { c[u] = -INFINITY; done = true; }
+        }
+        acc += m;
+    }
+    return acc / (float)k;
+}
+
+// one wave per query row: its survivors sit in nseg segments of `cap`
+__global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__restrict__ lists, const int32_t *__restrict__ counts,
+                                                             int nseg, int cap, int64_t n_rows, int k, float *__restrict__ out,
+                                                             int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
+    __shared__ int s_off[4][kMeanSeg + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= n_rows) return;
+    int *off = s_off[wave];
+    bool bad = false;
+    for (int sg = lane; sg < nseg; sg += 64) {
+        const int c = counts[row * nseg + sg];
+        off[sg + 1] = c;
+        bad |= c > cap;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (lane == 0) {
+        int acc = 0;
+        off[0] = 0;
+        for (int sg = 0; sg < nseg; ++sg) { acc += off[sg + 1]; off[sg + 1] = acc; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int total = off[nseg];
+    bad = __ballot(bad) != 0ull || total < k || total > kMeanRegs * 64;
+    if (bad) {
+        if (lane == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
+        return;
+    }
+    float c[kMeanRegs];
+    const float *base = lists + row * nseg * (int64_t)cap;
+#pragma unroll
+    for (int u = 0; u < kMeanRegs; ++u) {
+        const int i = u * 64 + lane;
+        c[u] = -INFINITY;
+        if (i < total) {
+            int lo = 0, hi = nseg;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] <= i) lo = mid; else hi = mid;
+            }
+            c[u] = base[(int64_t)lo * cap + (i - off[lo])];
+        }
+    }
+    const float res = wave_topk_mean(c, k, lane);
+    if (lane == 0) out[row] = res;
+}
+
+// one wave per candidate: one contiguous list
+__global__ __launch_bounds__(256) void list_mean_cols_kernel(const float *__restrict__ lists, const int32_t *__restrict__ counts,
+                                                             int ccap, int64_t n, int k, float *__restrict__ out,
+                                                             int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int cnt = counts[j];
+    if (cnt > ccap || cnt < k || cnt > kMeanRegs * 64) {
+        if (lane == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)j;
+        return;
+    }
+    float c[kMeanRegs];
+#pragma unroll
+    for (int u = 0; u < kMeanRegs; ++u) {
+        const int i = u * 64 + lane;
+        c[u] = i < cnt ? lists[j * ccap + i] : -INFINITY;
+    }
+    const float res = wave_topk_mean(c, k, lane);
+    if (lane == 0) out[j] = res;
+}
+
+// failed rows beyond the bulk path (adversarial inputs): the row by the k-ordered fmaf chain into scratch, then the exact mean
+__global__ __launch_bounds__(256) void slow_mean_rows_kernel(const float *__restrict__ a, int lda, const float *__restrict__ b, int64_t nb,
+                                                             int ldb, int dim, int k, float *__restrict__ out,
+                                                             const int32_t *__restrict__ fail_rows, const int32_t *__restrict__ n_fail,
+                                                             int first, float *__restrict__ scratch, int64_t ld) {
+    __shared__ float qs[2048];
+    const int nf = *n_fail;
+    float *srow = scratch + (int64_t)blockIdx.x * ld;
+    for (int f = first + blockIdx.x; f < nf; f += gridDim.x) {
+        const int64_t row = fail_rows[f];
+        for (int i = threadIdx.x; i < dim; i += 256) qs[i] = a[row * lda + i];
+        __syncthreads();
+        for (int64_t j = threadIdx.x; j < nb; j += 256) {
+            const float *br = b + j * ldb;
+            float acc = 0.f;
+            for (int kk = 0; kk < dim; ++kk) acc = fmaf(qs[kk], br[kk], acc);
+            srow[j] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const float res = k <= 16 ? topk_mean_by_insertion<16>(srow, nb, k, threadIdx.x) : topk_mean_by_insertion<32>(srow, nb, k, threadIdx.x);
+            if (threadIdx.x == 0) out[row] = res;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- rank of given gold columns on an explicit similarity block (calculate_rank, alignment.py:146-168)
@@ -911,7 +1107,7 @@ struct PackSlot {
     hipStream_t last = nullptr;
     hipEvent_t used = nullptr;
 };
-static PackSlot g_slot[3];       // 0 = queries, 1 = candidates, 2 = the neighbour search's column sample
+static PackSlot g_slot[4];       // 0 = queries, 1 = candidates, 2 / 3 = column / row samples (neighbour search, CSLS means)
 
 static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
     PackSlot &sl = g_slot[slot];
@@ -938,7 +1134,7 @@ static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, 
 }
 // after the kernels that read the packed operands have been enqueued
 static int release_packed(hipStream_t st) {
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 4; ++i)
         if (g_slot[i].used && g_slot[i].last == st) OEA_CHECK_HIP(hipEventRecord(g_slot[i].used, st));
     return OEA_OK;
 }
@@ -947,6 +1143,51 @@ static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, 
                                 int64_t ld_out, hipStream_t st) {
     sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(
         e1p, n1, kp, e2p, n2, kp, dim, out, ld_out, nullptr);
+}
+
+
+// workspace layout of oea_csls_means
+struct CslsPlan {
+    bool ok = false;
+    int sample = 0, r1 = 0, r2 = 0, cap = 0, ccap = 0, chunks = 0, nseg = 0, tpc = 0;
+    int64_t ld1 = 0, ld2 = 0;
+    size_t off_thr1, off_thr2, off_qcnt, off_ccnt, off_fail1, off_fail2, off_nfail, off_qlists, off_clists, off_strip, off_fbq,
+        off_scratch, total;
+};
+constexpr int kCslsFb = 128, kCslsSlow = 64;
+
+static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
+    CslsPlan p;
+    if (n1 < 4096 || n2 < 4096 || k > 32) return p;
+    p.sample = 1024;
+    auto rank_of = [&](int64_t n) { const double e = (double)k * p.sample / (double)n; return (int)(e + 3.5 * std::sqrt(e) + 8.0); };
+    p.r1 = rank_of(n2);                       // thresholds of the rows of S (queries against sampled candidates)
+    p.r2 = rank_of(n1);
+    const double m1 = (double)p.r1 * n2 / p.sample, m2 = (double)p.r2 * n1 / p.sample;      // survivors per row / per column
+    if (m1 * 1.5 > kMeanRegs * 64 || m2 * 1.5 > kMeanRegs * 64) return p;
+    p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, TILE), &p.tpc);
+    p.nseg = 4 * p.chunks;
+    if (p.nseg > kMeanSeg) return p;
+    const double ms = m1 / p.nseg;
+    p.cap = ((int)(ms + 8.0 * std::sqrt(ms) + 24.0) + 7) / 8 * 8;
+    p.ccap = ((int)(m2 + 8.0 * std::sqrt(m2) + 32.0) + 7) / 8 * 8;
+    if ((size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
+    p.ld1 = (n1 + 31) / 32 * 32;
+    p.ld2 = (n2 + 31) / 32 * 32;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    p.off_thr1 = take(4 * (size_t)n1); p.off_thr2 = take(4 * (size_t)n2);
+    p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2);
+    p.off_fail1 = take(4 * (size_t)n1); p.off_fail2 = take(4 * (size_t)n2); p.off_nfail = take(256);
+    p.off_qlists = take(4 * (size_t)n1 * p.nseg * p.cap);
+    p.off_clists = take(4 * (size_t)n2 * p.ccap);
+    // sample strips; the fallback strip [kCslsFb, max ld] reuses the space after the thresholds are taken
+    p.off_strip = take(4 * std::max<size_t>((size_t)std::max(n1, n2) * p.sample, (size_t)kCslsFb * std::max(p.ld1, p.ld2)));
+    p.off_fbq = take(4 * (size_t)kCslsFb * 4096);
+    p.off_scratch = take(4 * (size_t)kCslsSlow * std::max(p.ld1, p.ld2));
+    p.total = off;
+    p.ok = true;
+    return p;
 }
 
 }  // namespace
@@ -1105,7 +1346,65 @@ int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_
     if (n1 == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
     const unsigned grid = (unsigned)oea::ceil_div(n1, 4);
-    row_topk_mean_kernel<<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out);
+    row_topk_mean_kernel<<<grid, 256, 0, st>>>(s, n1, n2, ld, k, out, nullptr, nullptr);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+size_t oea_csls_means_workspace_bytes(int64_t n1, int64_t n2, int32_t k) {
+    const CslsPlan p = plan_csls(n1, n2, k);
+    return p.ok ? p.total : 0;
+}
+
+int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, int32_t k,
+                   float *r_out, float *c_out, void *workspace, size_t ws_bytes, void *stream) {
+    OEA_REQUIRE(e1 && e2 && r_out && c_out && workspace, "null pointer");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 2048, "ld % 4 == 0, dim <= min(ld, 2048)");
+    OEA_REQUIRE(k >= 1 && k <= n1 && k <= n2, "1 <= k <= min(n1, n2)");
+    const CslsPlan p = plan_csls(n1, n2, k);
+    if (!p.ok || !use_glds()) { oea::set_error("oea_csls_means: shape not covered (n1, n2 >= 4096, k <= 32, packed tiles)"); return OEA_EUNSUPPORTED; }
+    OEA_REQUIRE(ws_bytes >= p.total, "workspace smaller than oea_csls_means_workspace_bytes");
+    hipStream_t st = oea::as_stream(stream);
+    char *w = static_cast<char *>(workspace);
+    float *thr1 = reinterpret_cast<float *>(w + p.off_thr1), *thr2 = reinterpret_cast<float *>(w + p.off_thr2);
+    int32_t *qcnt = reinterpret_cast<int32_t *>(w + p.off_qcnt), *ccnt = reinterpret_cast<int32_t *>(w + p.off_ccnt);
+    int32_t *fail1 = reinterpret_cast<int32_t *>(w + p.off_fail1), *fail2 = reinterpret_cast<int32_t *>(w + p.off_fail2);
+    int32_t *nfail = reinterpret_cast<int32_t *>(w + p.off_nfail);          // [0] rows, [1] columns
+    float *qlists = reinterpret_cast<float *>(w + p.off_qlists), *clists = reinterpret_cast<float *>(w + p.off_clists);
+    float *strip = reinterpret_cast<float *>(w + p.off_strip), *fbq = reinterpret_cast<float *>(w + p.off_fbq);
+    float *scratch = reinterpret_cast<float *>(w + p.off_scratch);
+    PackedOp p1, p2, s1, s2;
+    int rc = pack_operand(0, e1, n1, ld1, dim, st, &p1);
+    if (rc == OEA_OK) rc = pack_operand(1, e2, n2, ld2, dim, st, &p2);
+    if (rc == OEA_OK) rc = pack_operand(2, e2, p.sample, ld2 * (int)(n2 / p.sample), dim, st, &s2);      // every (n2/S)-th candidate
+    if (rc == OEA_OK) rc = pack_operand(3, e1, p.sample, ld1 * (int)(n1 / p.sample), dim, st, &s1);
+    if (rc != OEA_OK) return rc;
+    const int kp = p1.kp;
+    OEA_REQUIRE(kp <= 4096, "dim <= 4096");
+    // thresholds: rows of S against sampled candidates, columns against sampled queries
+    launch_store_packed(p1.p, n1, s2.p, p.sample, kp, dim, strip, p.sample, st);
+    rc = oea::kth_value(strip, n1, p.sample, p.r1, thr1, st);
+    if (rc != OEA_OK) return rc;
+    launch_store_packed(p2.p, n2, s1.p, p.sample, kp, dim, strip, p.sample, st);
+    rc = oea::kth_value(strip, n2, p.sample, p.r2, thr2, st);
+    if (rc != OEA_OK) return rc;
+    OEA_CHECK_HIP(hipMemsetAsync(ccnt, 0, sizeof(int32_t) * (size_t)n2, st));
+    OEA_CHECK_HIP(hipMemsetAsync(nfail, 0, 256, st));
+    csls_append_kernel<true><<<dim3((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks), 256, 0, st>>>(
+        p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt);
+    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail);
+    list_mean_cols_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, p.ccap, n2, k, c_out, fail2, nfail + 1);
+    // fallbacks (normally empty): bulk for the first kCslsFb failed rows / columns, slow kernel for the rest
+    oea::gather_packed_rows(p1.p, kp, fail1, nfail, fbq, st);
+    sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), 1), 256, 0, st>>>(fbq, kCslsFb, kp, p2.p, n2, kp, dim, strip, p.ld2, nfail);
+    row_topk_mean_kernel<<<kCslsFb / 4, 256, 0, st>>>(strip, kCslsFb, n2, p.ld2, k, r_out, fail1, nfail);
+    slow_mean_rows_kernel<<<kCslsSlow, 256, 0, st>>>(e1, ld1, e2, n2, ld2, dim, k, r_out, fail1, nfail, kCslsFb, scratch, p.ld2);
+    oea::gather_packed_rows(p2.p, kp, fail2, nfail + 1, fbq, st);
+    sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n1, TILE), 1), 256, 0, st>>>(fbq, kCslsFb, kp, p1.p, n1, kp, dim, strip, p.ld1, nfail + 1);
+    row_topk_mean_kernel<<<kCslsFb / 4, 256, 0, st>>>(strip, kCslsFb, n1, p.ld1, k, c_out, fail2, nfail + 1);
+    slow_mean_rows_kernel<<<kCslsSlow, 256, 0, st>>>(e2, ld2, e1, n1, ld1, dim, k, c_out, fail2, nfail + 1, kCslsFb, scratch, p.ld1);
+    rc = release_packed(st);
+    if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -552,13 +552,13 @@ __device__ __forceinline__ float ord2f(uint32_t key) {
     return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
 }
 
-// one wave per row: radix select of the r-th largest of kSample values held in registers
+// one wave per row: radix select of the r-th largest of S = 64 * PER values held in registers
+template <int PER>
 __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict__ s, int64_t n_rows, int64_t ld, int r,
                                                         float *__restrict__ thr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;                        // whole waves exit together
-    constexpr int PER = kSample / 64;
     uint32_t key[PER];
     const float *src = s + row * ld;
 #pragma unroll
@@ -867,6 +867,21 @@ static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld
 
 }  // namespace
 
+namespace oea {
+// shared with the one-sweep CSLS means (sim_rank.hip)
+int kth_value(const float *strip, int64_t rows, int sample, int r, float *thr, hipStream_t st) {
+    const unsigned grid = (unsigned)ceil_div(rows, 4);
+    if (sample == 1024) kth_value_kernel<16><<<grid, 256, 0, st>>>(strip, rows, sample, r, thr);
+    else if (sample == 2048) kth_value_kernel<32><<<grid, 256, 0, st>>>(strip, rows, sample, r, thr);
+    else if (sample == 4096) kth_value_kernel<64><<<grid, 256, 0, st>>>(strip, rows, sample, r, thr);
+    else return OEA_EINVAL;
+    return OEA_OK;
+}
+void gather_packed_rows(const float *qp, int kp, const int32_t *rows, const int32_t *n_rows, float *dst, hipStream_t st) {
+    gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp, kp, rows, n_rows, dst);
+}
+}  // namespace oea
+
 extern "C" {
 
 size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
@@ -930,7 +945,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         for (int64_t r0 = 0; r0 < nq; r0 += lp.rows_per) {
             const int64_t rows = std::min<int64_t>(lp.rows_per, nq - r0);
             oea::sim_inner_store_packed(qp + r0 * kp, rows, sp, kSample, kp, dim, sstrip, kSample, st);
-            kth_value_kernel<<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
+            kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
             oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, st);

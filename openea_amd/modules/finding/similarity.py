@@ -9,12 +9,6 @@ import numpy as np
 from ... import ops
 
 
-def _prepare(embed, normalize):
-    """host [n, d] -> device [n, ld]; optional sklearn row-L2 normalisation (similarity.py:32-33)."""
-    t = embed if hasattr(embed, "is_cuda") else ops.to_table(embed)
-    return t
-
-
 def device_metric(metric, normalize):
     """Map the reference's (metric, normalize) switch (similarity.py:34-51) onto a kernel metric
     and an extra row normalisation.  'cosine' without normalize is 1 - cdist(cosine) = the
@@ -81,6 +75,10 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
     and of S^T are produced and reduced one after the other (each strip <= max_bytes).
     cols=False: only the row means (second result None)."""
     import torch
+    if kmetric == 'inner' and cols:        # one sweep, no strips of S / S^T (n1, n2 >= 4096)
+        rc = ops.csls_means(t1, t2, dim, k)
+        if rc is not None:
+            return rc
 
     def strip_means(a, b):
         n, m = a.shape[0], b.shape[0]

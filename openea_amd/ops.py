@@ -440,6 +440,19 @@ def row_topk_mean(s, k):
     return out
 
 
+def csls_means(e1, e2, dim, k):
+    """one-sweep CSLS means (oea_csls_means) -> (r [n1], c [n2]) or None when the shape is not covered"""
+    n1, n2 = e1.shape[0], e2.shape[0]
+    nbytes = lib().oea_csls_means_workspace_bytes(n1, n2, int(k))
+    if nbytes == 0 or not _lib.tile_glds():
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=e1.device)
+    r = torch.empty(n1, dtype=torch.float32, device=e1.device)
+    c = torch.empty(n2, dtype=torch.float32, device=e1.device)
+    check(lib().oea_csls_means(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, int(k), _p(r), _p(c), _p(ws), nbytes, _stream()))
+    return r, c
+
+
 def csls_apply_(s, r, c):
     check(lib().oea_csls_apply(_p(s), s.shape[0], s.shape[1], s.stride(0), _p(r), _p(c), _stream()))
     return s

@@ -846,3 +846,28 @@ def test_topk_strip_free_path_bit_exact(ops, case, monkeypatch):
     rows = np.concatenate([rng.choice(n, 40, replace=False), np.array([5000, 5001, 7999, 8000, 0, n - 1])])
     ref = cport.topk_inner(x[rows], x, k)
     assert np.array_equal(out[rows], ref * 3 + 1)
+
+
+@pytest.mark.parametrize("case", ["random", "duplicates", "constant"])
+def test_csls_means_one_sweep_bit_exact(ops, case):
+    """oea_csls_means (thresholded one-sweep lists + fallbacks) == row_topk_mean over the strips of S and S^T, bit for
+    bit, also when duplicate rows overflow lists or a constant matrix sends every row through the fallbacks."""
+    rng = np.random.RandomState(21)
+    n1, n2, d, k = (10500, 10500, 75, 10) if case == "random" else (4300, 4700, 32, 10)
+    e1 = rng.standard_normal((n1, d)).astype(np.float32)
+    e2 = rng.standard_normal((n2, d)).astype(np.float32)
+    if case == "duplicates":
+        e2[1000:1900] = e2[1000]                 # 900 identical candidates: their column lists and the rows near them overflow
+        e1[10:60] = e1[10]
+    if case == "constant":
+        e1[:] = e1[0]
+        e2[:] = e2[0]
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 /= np.linalg.norm(e2, axis=1, keepdims=True)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    got = ops.csls_means(t1, t2, d, k)
+    assert got is not None
+    r, c = got
+    r_ref = ops.row_topk_mean(ops.sim_matrix(t1, t2, d, "inner"), k)
+    c_ref = ops.row_topk_mean(ops.sim_matrix(t2, t1, d, "inner"), k)
+    assert torch.equal(r, r_ref) and torch.equal(c, c_ref)
