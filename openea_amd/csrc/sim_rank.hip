@@ -870,6 +870,8 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    __shared__ int ccnt_l[TILE];                                   // survivors of the current candidate tile, per candidate
+    const int nqt = (int)gridDim.x, qt = (int)blockIdx.x;          // candidate j owns nqt segments of ccap: one per query tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t q0 = (int64_t)blockIdx.x * TILE;
@@ -895,12 +897,15 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
         [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
         [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * TILE;
-            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+            const int jl0 = wm * 64 + 4 * (lane >> 5);
+            if (tid < TILE) ccnt_l[tid] = 0;
+            __syncthreads();                                     // the epilogue is reached by the whole workgroup together
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    const int jl = jl0 + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    const int j = (int)c0 + jl;
                     const bool jin = j < nc;
                     const float tc = jin ? thr_c[j] : INFINITY;
 #pragma unroll
@@ -910,13 +915,15 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
                             *reinterpret_cast<float *>(vbase + min(boff[tn], blast[tn])) = v;
                             boff[tn] += 4u;
                         }
-                        if (v >= tc && qi[tn] < nq) {
-                            const int pos = atomicAdd(ccounts + j, 1);
-                            if (pos < ccap) clists[(int64_t)j * ccap + pos] = v;
+                        if (v >= tc && qi[tn] < nq) {             // an LDS counter hands out the slot: no global round trip
+                            const int pos = atomicAdd(&ccnt_l[jl], 1);
+                            if (pos < ccap) clists[((int64_t)j * nqt + qt) * ccap + pos] = v;
                         }
                     }
                 }
             }
+            __syncthreads();
+            if (tid < TILE && c0 + tid < nc) ccounts[(c0 + tid) * nqt + qt] = ccnt_l[tid];
         });
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
 }
 
 constexpr int kMeanRegs = 16;                 // list values per lane: lists of up to 1,024 survivors
-constexpr int kMeanSeg = 256;
+constexpr int kMeanSeg = 1024;               // segments per list (rows: 4 * chunks; columns: one per query tile)
 
 // mean of the k largest of `cnt` values held kMeanRegs per lane (-inf padded): k rounds of wave-wide maximum, summed in
 // descending order -- the arithmetic of row_topk_mean_kernel
@@ -996,28 +1003,6 @@ __global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__rest
     }
     const float res = wave_topk_mean(c, k, lane);
     if (lane == 0) out[row] = res;
-}
-
-// one wave per candidate: one contiguous list
-__global__ __launch_bounds__(256) void list_mean_cols_kernel(const float *__restrict__ lists, const int32_t *__restrict__ counts,
-                                                             int ccap, int64_t n, int k, float *__restrict__ out,
-                                                             int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    const int cnt = counts[j];
-    if (cnt > ccap || cnt < k || cnt > kMeanRegs * 64) {
-        if (lane == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)j;
-        return;
-    }
-    float c[kMeanRegs];
-#pragma unroll
-    for (int u = 0; u < kMeanRegs; ++u) {
-        const int i = u * 64 + lane;
-        c[u] = i < cnt ? lists[j * ccap + i] : -INFINITY;
-    }
-    const float res = wave_topk_mean(c, k, lane);
-    if (lane == 0) out[j] = res;
 }
 
 // failed rows beyond the bulk path (adversarial inputs): the row by the k-ordered fmaf chain into scratch, then the exact mean
@@ -1149,7 +1134,7 @@ static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, 
 // workspace layout of oea_csls_means
 struct CslsPlan {
     bool ok = false;
-    int sample = 0, r1 = 0, r2 = 0, cap = 0, ccap = 0, chunks = 0, nseg = 0, tpc = 0;
+    int sample = 0, r1 = 0, r2 = 0, cap = 0, ccap = 0, chunks = 0, nseg = 0, tpc = 0, nqt = 0;
     int64_t ld1 = 0, ld2 = 0;
     size_t off_thr1, off_thr2, off_qcnt, off_ccnt, off_fail1, off_fail2, off_nfail, off_qlists, off_clists, off_strip, off_fbq,
         off_scratch, total;
@@ -1159,28 +1144,32 @@ constexpr int kCslsFb = 128, kCslsSlow = 64;
 static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     CslsPlan p;
     if (n1 < 4096 || n2 < 4096 || k > 32) return p;
-    p.sample = 1024;
+    p.sample = std::max(n1, n2) >= 32768 ? 4096 : 1024;       // keeps r n / S, the survivors per row, in the low hundreds
     auto rank_of = [&](int64_t n) { const double e = (double)k * p.sample / (double)n; return (int)(e + 3.5 * std::sqrt(e) + 8.0); };
     p.r1 = rank_of(n2);                       // thresholds of the rows of S (queries against sampled candidates)
     p.r2 = rank_of(n1);
     const double m1 = (double)p.r1 * n2 / p.sample, m2 = (double)p.r2 * n1 / p.sample;      // survivors per row / per column
-    if (m1 * 1.5 > kMeanRegs * 64 || m2 * 1.5 > kMeanRegs * 64) return p;
+    if (m1 * (1.0 + 5.0 / std::sqrt((double)p.r1)) > kMeanRegs * 64 || m2 * (1.0 + 5.0 / std::sqrt((double)p.r2)) > kMeanRegs * 64) return p;
     p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, TILE), &p.tpc);
     p.nseg = 4 * p.chunks;
     if (p.nseg > kMeanSeg) return p;
-    const double ms = m1 / p.nseg;
-    p.cap = ((int)(ms + 8.0 * std::sqrt(ms) + 24.0) + 7) / 8 * 8;
-    p.ccap = ((int)(m2 + 8.0 * std::sqrt(m2) + 32.0) + 7) / 8 * 8;
+    // the threshold is the r-th of a sample: the survivor count of a row scales with a factor of relative spread 1 / sqrt(r)
+    // COMMON to its segments, on top of each segment's own sqrt(m) noise
+    p.nqt = (int)oea::ceil_div(n1, TILE);
+    if (p.nqt > kMeanSeg) return p;
+    const double ms = m1 / p.nseg, mc = m2 / p.nqt;
+    p.cap = ((int)(ms * (1.0 + 5.0 / std::sqrt((double)p.r1)) + 8.0 * std::sqrt(ms) + 16.0) + 7) / 8 * 8;
+    p.ccap = ((int)(mc * (1.0 + 5.0 / std::sqrt((double)p.r2)) + 8.0 * std::sqrt(mc) + 8.0) + 3) / 4 * 4;
     if ((size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
     p.ld1 = (n1 + 31) / 32 * 32;
     p.ld2 = (n2 + 31) / 32 * 32;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.off_thr1 = take(4 * (size_t)n1); p.off_thr2 = take(4 * (size_t)n2);
-    p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2);
+    p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2 * p.nqt);
     p.off_fail1 = take(4 * (size_t)n1); p.off_fail2 = take(4 * (size_t)n2); p.off_nfail = take(256);
     p.off_qlists = take(4 * (size_t)n1 * p.nseg * p.cap);
-    p.off_clists = take(4 * (size_t)n2 * p.ccap);
+    p.off_clists = take(4 * (size_t)n2 * p.nqt * p.ccap);
     // sample strips; the fallback strip [kCslsFb, max ld] reuses the space after the thresholds are taken
     p.off_strip = take(4 * std::max<size_t>((size_t)std::max(n1, n2) * p.sample, (size_t)kCslsFb * std::max(p.ld1, p.ld2)));
     p.off_fbq = take(4 * (size_t)kCslsFb * 4096);
@@ -1388,12 +1377,12 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     launch_store_packed(p2.p, n2, s1.p, p.sample, kp, dim, strip, p.sample, st);
     rc = oea::kth_value(strip, n2, p.sample, p.r2, thr2, st);
     if (rc != OEA_OK) return rc;
-    OEA_CHECK_HIP(hipMemsetAsync(ccnt, 0, sizeof(int32_t) * (size_t)n2, st));
+    // every (candidate, query tile) count is written by the sweep when chunks cover all candidate tiles -- they do
     OEA_CHECK_HIP(hipMemsetAsync(nfail, 0, 256, st));
     csls_append_kernel<true><<<dim3((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks), 256, 0, st>>>(
         p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt);
     list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail);
-    list_mean_cols_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, p.ccap, n2, k, c_out, fail2, nfail + 1);
+    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, p.nqt, p.ccap, n2, k, c_out, fail2, nfail + 1);
     // fallbacks (normally empty): bulk for the first kCslsFb failed rows / columns, slow kernel for the rest
     oea::gather_packed_rows(p1.p, kp, fail1, nfail, fbq, st);
     sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), 1), 256, 0, st>>>(fbq, kCslsFb, kp, p2.p, n2, kp, dim, strip, p.ld2, nfail);
