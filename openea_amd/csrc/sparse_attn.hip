@@ -57,19 +57,39 @@ __global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__re
     if (lane == 0) { sub_m[s] = m; sub_l[s] = l; }
 }
 
-// K2: per segment (M, L) from its consecutive sub-segments (fixed order)
-__global__ void attn_seg_combine_kernel(const int32_t *__restrict__ seg_sub_ptr, int64_t n_seg,
-                                        const float *__restrict__ sub_m, const float *__restrict__ sub_l,
-                                        float *__restrict__ seg_m, float *__restrict__ seg_l) {
+// K2: per segment (M, L) from its consecutive sub-segments.  One lane per segment for the usual few sub-segments; a hub
+// segment (power-law degrees: hundreds of sub-segments) is combined by the WHOLE wave, lanes striding over its
+// sub-segments (it was one thread's serial loop: 270 us of a 1.7 ms attention on the hub graph).
+constexpr int kSerialSubs = 8;
+__global__ __launch_bounds__(256) void attn_seg_combine_kernel(const int32_t *__restrict__ seg_sub_ptr, int64_t n_seg,
+                                                               const float *__restrict__ sub_m, const float *__restrict__ sub_l,
+                                                               float *__restrict__ seg_m, float *__restrict__ seg_l) {
+    const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_seg) return;
-    const int s0 = seg_sub_ptr[g], s1 = seg_sub_ptr[g + 1];
-    float m = -INFINITY;
-    for (int s = s0; s < s1; ++s) m = fmaxf(m, sub_m[s]);
-    float l = 0.f;
-    for (int s = s0; s < s1; ++s) l += sub_l[s] * expf(sub_m[s] - m);
-    seg_m[g] = m;
-    seg_l[g] = l;
+    const bool valid = g < n_seg;
+    const int s0 = valid ? seg_sub_ptr[g] : 0, s1 = valid ? seg_sub_ptr[g + 1] : 0;
+    const bool hub = s1 - s0 > kSerialSubs;
+    if (valid && !hub) {
+        float m = -INFINITY;
+        for (int s = s0; s < s1; ++s) m = fmaxf(m, sub_m[s]);
+        float l = 0.f;
+        for (int s = s0; s < s1; ++s) l += sub_l[s] * expf(sub_m[s] - m);
+        seg_m[g] = m;
+        seg_l[g] = l;
+    }
+    unsigned long long todo = __ballot(hub);
+    while (todo) {                                               // wave-uniform loop over this wave's hub segments
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int a = __shfl(s0, src, 64), b = __shfl(s1, src, 64);
+        float m = -INFINITY;
+        for (int s = a + lane; s < b; s += W) m = fmaxf(m, sub_m[s]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int s = a + lane; s < b; s += W) l += sub_l[s] * expf(sub_m[s] - m);
+        l = wave_sum(l);
+        if (lane == src) { seg_m[g] = m; seg_l[g] = l; }
+    }
 }
 
 // K3: alpha + partial aggregate of one sub-segment
@@ -183,8 +203,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restr
     const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_sub) return;
     const int g = sub_seg[s];
+    const int q0 = seg_sub_ptr[g], q1 = seg_sub_ptr[g + 1];
     float c = 0.f;
-    for (int q = seg_sub_ptr[g]; q < seg_sub_ptr[g + 1]; ++q) c += sub_c[q];
+    if (q1 - q0 <= kSerialSubs) {
+        for (int q = q0; q < q1; ++q) c += sub_c[q];
+    } else {                                                     // hub segment: lanes stride over its sub-segments
+        for (int q = q0 + lane; q < q1; q += W) c += sub_c[q];
+        c = wave_sum(c);
+    }
     for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += W) {
         const float de = alpha[e] * (dz[e] - c);
         dz[e] = de * (z[e] > 0.f ? 1.f : slope);

@@ -570,11 +570,9 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     int need = r;
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = prefix | (1u << bit), mask = ~((1u << bit) - 1u);
-        int cnt = 0;
+        int cnt = 0;                                  // wave total straight from the compare masks (scalar popcounts, no shuffles)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) cnt += (key[i] & mask) == cand;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        for (int i = 0; i < PER; ++i) cnt += __popcll(__ballot((key[i] & mask) == cand));
         if (cnt >= need) prefix = cand; else need -= cnt;
     }
     if (lane == 0) thr[row] = ord2f(prefix);
