@@ -1,23 +1,36 @@
 #!/bin/bash
-# Run ON the GPU box (through gpurun): kernel-trace stats of the default bench + the two HBM-traffic PMC
-# passes (FETCH_SIZE / WRITE_SIZE in their own runs, no other trace domains), into gpurun_out/$1.
-#   gpurun -- 'bash tools/collect_profiles.sh r01d'
-# then on the build host: python tools/summarize_profiles.py gpurun_out/r01d r01d   (writes profiles/)
+# Run ON the GPU box (through gpurun): kernel-trace stats of the default bench + the HBM-traffic PMC passes (FETCH_SIZE /
+# WRITE_SIZE in their own runs, no other trace domains) for both bench shapes and for the neighbour search, into gpurun_out/$1.
+#   gpurun -- 'bash tools/collect_profiles.sh r02'
+# then on the build host: python tools/summarize_profiles.py gpurun_out/r02 r02   (writes profiles/)
 set -u
 TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 60 --warmup 10"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_stats.log 2>&1
-PMCBENCH="$BENCH --no-cpu --no-extra"     # the counter passes need the step kernels only
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCBENCH > $OUT/bench_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCBENCH > $OUT/bench_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs -- python $R/tools/profile_legs.py > $OUT/legs.log 2>&1
+BENCH="python $R/bench.py --steps 60 --warmup 10 --repeats 10"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_stats.log 2>&1
+PMC15="$BENCH --no-cpu --no-extra"     # the counter passes need the step kernels only
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMC15 > $OUT/bench_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMC15 > $OUT/bench_write.log 2>&1
+PMC100="python $R/bench.py --shape EN-FR-100K-V1 --dim 100 --batch 20000 --eps 0.98 --steps 40 --warmup 10 --repeats 5 --no-cpu --no-extra"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats100k -- $PMC100 > $OUT/bench100k_stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch100k -- $PMC100 > $OUT/bench100k_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write100k -- $PMC100 > $OUT/bench100k_write.log 2>&1
+# neighbour search at 100,000 x 100,000, k = 2,000: kernel stats + traffic of the strip-free path and of the strip path
+KNN="python $R/tools/_exp/knn_time.py"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/knn_stats -- $KNN > $OUT/knn_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/knn_fetch -- $KNN > $OUT/knn_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knn_write -- $KNN > $OUT/knn_write.log 2>&1
+OEA_TOPK_LISTS=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/knnstrip_fetch -- $KNN > $OUT/knnstrip_fetch.log 2>&1
+OEA_TOPK_LISTS=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knnstrip_write -- $KNN > $OUT/knnstrip_write.log 2>&1
+# evaluation (with / without CSLS at 10,500^2 and 70,000^2), GNN legs
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/csls -- python $R/tools/_exp/csls_time.py > $OUT/csls.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs -- python $R/tools/profile_legs.py > $OUT/legs.log 2>&1
 # matrix-core utilisation of the evaluation sweep (70,000^2 x 100), counters in their own pass
 LEGS=eval70k timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python $R/tools/profile_legs.py > $OUT/legs_mfma.log 2>&1
-# the other model families (TransE / TransH / TransD, BootEA_RotatE): kernel stats of a few epochs
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/models -- python $R/tools/profile_models.py 15K TransE,TransH,TransD,BootEA_RotatE > $OUT/models.log 2>&1
 python $R/bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
-tail -1 $OUT/bench_stats.log
+python $R/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_like.json 2> $OUT/bench_driver_like.err
+grep -h kNN $OUT/knn_stats.log | head -4
+tail -3 $OUT/csls.log

@@ -27,15 +27,17 @@ def main():
     src, name = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
-    for leg, out in (("stats", "bench_kernel_stats"), ("legs", "legs_kernel_stats"), ("models", "models_kernel_stats")):
+    for leg, out in (("stats", "bench_kernel_stats"), ("stats100k", "bench100k_kernel_stats"), ("legs", "legs_kernel_stats"),
+                     ("models", "models_kernel_stats"), ("knn_stats", "knn_kernel_stats"), ("csls", "eval_csls_kernel_stats")):
         fs = glob.glob(os.path.join(src, leg, "*", "*_kernel_stats.csv"))
         if fs:
             shutil.copy(fs[0], os.path.join(prof, "%s_%s.csv" % (name, out)))
-    up = os.path.join(src, "bench_unprofiled.json")
-    if os.path.exists(up):
-        lines = [l for l in open(up) if l.startswith("{")]
-        if lines:
-            open(os.path.join(prof, "%s_bench_unprofiled.json" % name), "w").write(lines[-1])
+    for fn in ("bench_unprofiled", "bench_driver_like"):
+        up = os.path.join(src, fn + ".json")
+        if os.path.exists(up):
+            lines = [l for l in open(up) if l.startswith("{")]
+            if lines:
+                open(os.path.join(prof, "%s_%s.json" % (name, fn)), "w").write(lines[-1])
     # matrix-core counters of the evaluation sweep: raw per-kernel averages
     rows = collections.defaultdict(dict)
     for f in glob.glob(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv")):
@@ -52,30 +54,40 @@ def main():
             f.write("kernel,calls," + ",".join(n + "_avg" for n in names) + "\n")
             for k, d in sorted(rows.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)):
                 f.write('"%s",%d,' % (k[:100], d["calls"]) + ",".join("%.0f" % d.get(n, 0.0) for n in names) + "\n")
-    for log in ("bench_stats.log", "legs.log", "models.log"):
+    for log in ("bench_stats.log", "legs.log", "models.log", "knn_stats.log", "csls.log"):
         p = os.path.join(src, log)
         if os.path.exists(p):
             lines = [l for l in open(p) if not l.startswith("/opt/amdgpu")]
             note = "# stdout of the run UNDER rocprofv3 --kernel-trace: wall-clock figures are inflated by the tracer;\n" \
                    "# the kernel durations in the *_kernel_stats.csv next to this file are what DESIGN.md cites.\n"
             open(os.path.join(prof, "%s_%s" % (name, log.replace(".log", "_stdout.txt"))), "w").writelines([note] + lines[-40:])
-    fetch, n = pmc_avg(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
-    write, _ = pmc_avg(os.path.join(src, "pmc_write"), "WRITE_SIZE")
-    rows = []
-    for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0)) * n[k]):
-        rows.append((k[:90], n[k], fetch[k], write.get(k, 0.0), int((2 * fetch[k] + write.get(k, 0.0)) * 1024)))
-    with open(os.path.join(prof, "%s_pmc_hbm_traffic.csv" % name), "w") as f:
-        f.write("kernel,calls,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
-        for r in rows:
-            f.write('"%s",%d,%.1f,%.1f,%d\n' % r)
-    dom = [r for r in rows if "triple_grouped" in r[0]]
-    if dom:
-        r = dom[0]
-        json.dump({"kernel": r[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_pmc_hbm_traffic.csv" % name,
-                   "FETCH_SIZE_KB": r[2], "WRITE_SIZE_KB": r[3],
-                   "correction": "gfx950: FETCH_SIZE reads 1/2 of the bytes (MI355X_MICROARCH.md HBM section) -> 2*FETCH + WRITE",
-                   "hbm_bytes_per_launch": r[4]}, open(os.path.join(prof, "traffic_triple_fwd_bwd.json"), "w"), indent=1)
+    workloads = {"": ("EN-FR-15K-V1", 75, 5000, 10), "100k": ("EN-FR-100K-V1", 100, 20000, 10)}
+    for suffix, tag in (("", "pmc_hbm_traffic"), ("100k", "pmc_hbm_traffic_100k"), ("knn", "pmc_hbm_traffic_knn_lists"),
+                        ("knnstrip", "pmc_hbm_traffic_knn_strip")):
+        fdir = os.path.join(src, "pmc_fetch" + suffix if suffix in ("", "100k") else suffix + "_fetch")
+        wdir = os.path.join(src, "pmc_write" + suffix if suffix in ("", "100k") else suffix + "_write")
+        if not os.path.isdir(fdir):
+            continue
+        fetch, n = pmc_avg(fdir, "FETCH_SIZE")
+        write, _ = pmc_avg(wdir, "WRITE_SIZE")
+        rows = []
+        for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0)) * n[k]):
+            rows.append((k[:90], n[k], fetch[k], write.get(k, 0.0), int((2 * fetch[k] + write.get(k, 0.0)) * 1024)))
+        with open(os.path.join(prof, "%s_%s.csv" % (name, tag)), "w") as f:
+            f.write("kernel,calls,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+            for r in rows:
+                f.write('"%s",%d,%.1f,%.1f,%d\n' % r)
+        if suffix in workloads:
+            dom = [r for r in rows if "triple_grouped" in r[0]]
+            if dom:
+                r = dom[0]
+                shape = workloads[suffix][0]
+                json.dump({"kernel": r[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
+                           "workload": list(workloads[suffix]),
+                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_%s.csv" % (name, tag),
+                           "FETCH_SIZE_KB": r[2], "WRITE_SIZE_KB": r[3],
+                           "correction": "gfx950: FETCH_SIZE reads 1/2 of the bytes (MI355X_MICROARCH.md HBM section) -> 2*FETCH + WRITE",
+                           "hbm_bytes_per_launch": r[4]}, open(os.path.join(prof, "traffic_%s.json" % shape), "w"), indent=1)
     print("wrote", sorted(os.listdir(prof)))
 
 
