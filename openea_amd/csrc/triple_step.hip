@@ -145,9 +145,10 @@ __device__ __forceinline__ float softplusf_(float x) { return x > 0.f ? x + log1
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // dL/ds and the loss term of ONE triple for the per-triple losses (not margin).
-__device__ __forceinline__ void triple_coef(const oea_step_cfg &cfg, bool is_pos, float s, float &coef, float &l) {
+__device__ __forceinline__ void triple_coef_kind(int loss_kind, const oea_step_cfg &cfg, bool is_pos, float s, float &coef,
+                                                 float &l) {
     coef = 0.f; l = 0.f;
-    switch (cfg.loss_kind) {
+    switch (loss_kind) {
     case OEA_LOSS_LIMITED:  // losses.py:53-55
         if (is_pos) { const float x = s - cfg.pos_margin; if (x > 0.f) { l = x; coef = 1.f; } }
         else { const float x = cfg.neg_margin - s; if (x > 0.f) { l = cfg.balance * x; coef = -cfg.balance; } }
@@ -164,6 +165,9 @@ __device__ __forceinline__ void triple_coef(const oea_step_cfg &cfg, bool is_pos
         break;
     default: break;
     }
+}
+__device__ __forceinline__ void triple_coef(const oea_step_cfg &cfg, bool is_pos, float s, float &coef, float &l) {
+    triple_coef_kind(cfg.loss_kind, cfg, is_pos, s, coef, l);
 }
 
 __device__ __forceinline__ void block_loss_partial(double loss_local, double *partials) {
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void triple_generic(
 template <int G, int IT>
 __device__ __forceinline__ double score_independent(const float *__restrict__ ent, const float *__restrict__ rel, int ld,
                                                     int lane, int64_t item, int ch, int cr, int ct, bool is_pos,
-                                                    const oea_step_cfg &cfg, const StepWs &ws) {
+                                                    const oea_step_cfg &cfg, const StepWs &ws, int lk, int l1) {
     Row<G, IT> zh, zr, zt, delta, g;
     load_row<G, IT>(ent + (int64_t)ch * ld, ld, lane, zh);
     load_row<G, IT>(rel + (int64_t)cr * ld, ld, lane, zr);
@@ -251,11 +255,11 @@ __device__ __forceinline__ double score_independent(const float *__restrict__ en
     normalize<G, IT>(zh, cfg.ent_l2_norm);
     normalize<G, IT>(zr, cfg.rel_l2_norm);
     normalize<G, IT>(zt, cfg.ent_l2_norm);
-    const float s = score<G, IT>(zh, zr, zt, cfg.l1, delta);
+    const float s = score<G, IT>(zh, zr, zt, l1, delta);
     float coef, l;
-    triple_coef(cfg, is_pos, s, coef, l);
+    triple_coef_kind(lk, cfg, is_pos, s, coef, l);
     if (coef != 0.f) {
-        dscore<G, IT>(delta, coef, cfg.l1, g);
+        dscore<G, IT>(delta, coef, l1, g);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)ch * ld, ld, lane, g, 1.f);
         atomic_row<G, IT>(ws.rel_copy(item % kRelCopies) + (int64_t)cr * ld, ld, lane, g, 1.f);
         atomic_row<G, IT>(ws.ent_grad + (int64_t)ct * ld, ld, lane, g, -1.f);
@@ -272,7 +276,7 @@ __device__ __forceinline__ double score_independent(const float *__restrict__ en
 // Occupancy: a batch of 5,000 positives is 2,500 waves; at 2 waves/SIMD the chip holds 2,048, and the 452
 // late-comers doubled the kernel's critical path (25.9 us).  Capping the registers at 3 waves/SIMD (a few
 // spilled dwords for IT >= 2) lets every wave start at once: 19.4 us.
-template <int G, int IT>
+template <int G, int IT, int LOSS, int L1>
 __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
     int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
@@ -281,6 +285,10 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    // LOSS / L1 >= 0: the loss kind and the norm are compile-time constants (one compact code path per kind: with the
+    // run-time switch every call site carried the exp / log1p expansions of the logistic losses, 12,000 instructions)
+    const int lk = LOSS >= 0 ? LOSS : cfg.loss_kind;
+    const int l1 = L1 >= 0 ? L1 : cfg.l1;
     double loss_local = 0.0;
     for (int64_t p = grp; p < n_pos; p += ngrp) {
         const int32_t *ng = neg + (int64_t)p * k * 3;
@@ -316,11 +324,11 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
                 normalize<G, IT>(yh, cfg.ent_l2_norm);
                 normalize<G, IT>(yr, cfg.rel_l2_norm);
                 normalize<G, IT>(yt, cfg.ent_l2_norm);
-                const float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+                const float s = score<G, IT>(yh, yr, yt, l1, delta);
                 float coef, l;
-                triple_coef(cfg, true, s, coef, l);
+                triple_coef_kind(lk, cfg, true, s, coef, l);
                 lsum = (double)l;
-                dscore<G, IT>(delta, coef, cfg.l1, g);
+                dscore<G, IT>(delta, coef, l1, g);
 #pragma unroll
                 for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
                 any = coef != 0.f;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
                 for (int j = 0; j < KC; ++j)
                     if ((slow >> j) & 1u)
                         lsum += score_independent<G, IT>(ent, rel, ld, lane, p, __shfl(nid, 3 * j, G), __shfl(nid, 3 * j + 1, G),
-                                                         __shfl(nid, 3 * j + 2, G), false, cfg, ws);
+                                                         __shfl(nid, 3 * j + 2, G), false, cfg, ws, lk, l1);
             }
             float sc[KC];
 #pragma unroll
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
                     const float a = tl ? yh.v[it] : yc[j].v[it], b = tl ? yc[j].v[it] : yt.v[it];
                     const float d = a + yr.v[it] - b;
                     yc[j].v[it] = d;                                    // the row is not needed again: keep delta in place
-                    s += cfg.l1 ? fabsf(d) : d * d;
+                    s += l1 ? fabsf(d) : d * d;
                 }
                 sc[j] = group_sum<G>(s);
             }
@@ -352,11 +360,11 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
                 if (!((okm >> j) & 1u)) continue;
                 const bool tl = (tailm >> j) & 1u;
                 float coef, l;
-                triple_coef(cfg, false, sc[j], coef, l);
+                triple_coef_kind(lk, cfg, false, sc[j], coef, l);
                 lsum += (double)l;
                 if (coef != 0.f) {
                     any = true;
-                    dscore<G, IT>(yc[j], coef, cfg.l1, g);
+                    dscore<G, IT>(yc[j], coef, l1, g);
                     if (tl) {
 #pragma unroll
                         for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
@@ -373,11 +381,11 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
             normalize<G, IT>(yh, cfg.ent_l2_norm);
             normalize<G, IT>(yr, cfg.rel_l2_norm);
             normalize<G, IT>(yt, cfg.ent_l2_norm);
-            const float s = score<G, IT>(yh, yr, yt, cfg.l1, delta);
+            const float s = score<G, IT>(yh, yr, yt, l1, delta);
             float coef, l;
-            triple_coef(cfg, true, s, coef, l);
+            triple_coef_kind(lk, cfg, true, s, coef, l);
             lsum = (double)l;
-            dscore<G, IT>(delta, coef, cfg.l1, g);
+            dscore<G, IT>(delta, coef, l1, g);
 #pragma unroll
             for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
             any = coef != 0.f;
@@ -1121,6 +1129,22 @@ __global__ void scatter_rows_kernel(float *__restrict__ grad, float *__restrict_
     }
 }
 
+// triple_grouped specialised on (loss kind, norm) -- the per-triple losses that reach it (margin pairs go to
+// triple_generic); OEA_STEP_RUNTIME_KIND=1 keeps the one kernel with the run-time switch (experiments).
+template <int G, int IT>
+void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
+                    int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
+    static const int runtime_kind = [] { const char *e = getenv("OEA_STEP_RUNTIME_KIND"); return e ? atoi(e) : 0; }();
+    const int k = cfg.neg_group_k;
+#define OEA_GROUPED(LOSS, L1) triple_grouped<G, IT, LOSS, L1><<<nb, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, k, cfg, ws)
+    if (runtime_kind) OEA_GROUPED(-1, -1);
+    else if (cfg.loss_kind == OEA_LOSS_LIMITED) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_LIMITED, 1); else OEA_GROUPED(OEA_LOSS_LIMITED, 0); }
+    else if (cfg.loss_kind == OEA_LOSS_LOGISTIC) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_LOGISTIC, 1); else OEA_GROUPED(OEA_LOSS_LOGISTIC, 0); }
+    else if (cfg.loss_kind == OEA_LOSS_POSITIVE) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_POSITIVE, 1); else OEA_GROUPED(OEA_LOSS_POSITIVE, 0); }
+    else OEA_GROUPED(-1, -1);
+#undef OEA_GROUPED
+}
+
 template <int G, int IT>
 int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
@@ -1147,7 +1171,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
         else if (transh)
             triple_transh_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
         else if (grouped)
-            triple_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, cfg.neg_group_k, cfg, ws);
+            launch_grouped<G, IT>(nb1, block, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
         else
             triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         oea::prof_mark(st);
