@@ -39,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_STRIDE = 8        # HIP-event marks on every 8th step of the timed regions (a record costs ~3 us of enqueue)
+PROFILE_STRIDE = int(os.environ.get("OEA_BENCH_PROFILE_STRIDE", "1"))   # steps of the kernel-timing regions that carry HIP events
+KERNEL_TIMING_REGIONS = 2
 
 
 def parse():
@@ -100,7 +101,6 @@ class Workload:
         ep.run_steps(tr, self.steps_per_epoch - ep.in_epoch)
         ep.run_steps(tr, warmup)
         self.barrier()
-        ops.profile_begin(stride=PROFILE_STRIDE)
         times, pos = [], []
         for _ in range(repeats):
             self.barrier()
@@ -109,7 +109,14 @@ class Workload:
             self.barrier()
             times.append(time.perf_counter() - t0)
             pos.append(n)
-        (fwd_ms, _gap_ms, apply_ms), n_calls = ops.profile_end(4)
+        # kernel timing: the same K-step region once more, every PROFILE_STRIDE-th step carrying HIP events attached to
+        # its kernels' dispatches.  Kept out of the throughput regions above: a dispatch with events is not pipelined
+        # behind its predecessor (42.8 instead of 33.7 us per step with events on every step at the 15K shape).
+        ops.profile_begin(stride=PROFILE_STRIDE)
+        for _ in range(KERNEL_TIMING_REGIONS):
+            ep.run_steps(tr, steps)
+        self.barrier()
+        (fwd_ms, gap_ms, apply_ms), n_calls = ops.profile_end(4)
         loss = tr.pop_loss()
         ep.check()
         t = torch.tensor(times, dtype=torch.float64, device=self.ent.var.device)
@@ -119,7 +126,7 @@ class Workload:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(times=t.cpu().numpy(), pos=c.cpu().numpy(), pos_local=np.asarray(pos, np.float64),
-                    fwd_ms=fwd_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss)
+                    fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss)
 
     def summarize(self, m, steps):
         """median region -> (value, ms_per_step, roofline dict)"""
@@ -146,6 +153,12 @@ class Workload:
                     "hbm_frac": round(traffic / fwd_s / 1e9 / HBM_PEAK_GBS, 4) if (traffic and fwd_s > 0) else None,
                     "step_frac": round(step_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                     "avg_kernel_us": round(fwd_s * 1e6, 2), "apply_rows_avg_us": round(apply_s * 1e6, 2),
+                    "gap_between_kernels_us": round(m["gap_ms"] * 1e3 / launches, 2),
+                    "timing": "HIP start/stop events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on every "
+                              "%d-th step of %d further K-step regions run right after the throughput regions (events on a "
+                              "dispatch stop it from being pipelined behind its predecessor, so they stay out of `value`): the "
+                              "dispatch's own begin/end timestamps, as in rocprofv3's kernel trace"
+                              % (PROFILE_STRIDE, KERNEL_TIMING_REGIONS),
                     "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_per_step": int(step_bytes),
                     "launches_timed": int(m["n_calls"]),
                     "note": "frac = algorithmic bytes / kernel time / peak: the tables are cache-resident (L2 / Infinity "

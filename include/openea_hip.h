@@ -41,10 +41,12 @@ const char *oea_last_error(void);
 /* number of visible HIP devices, <0 on error (used by the host side to fail loudly) */
 int oea_device_count(void);
 
-/* Per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
- * roofline figure; no reference counterpart).  Between begin and end, every optimiser step
- * records 4 marks: [m0 fwd_bwd kernel m1] [m2 apply kernel m3] (a GRAD-phase call the first pair,
- * the APPLY-phase call the second).  oea_profile_end(4, ms, &n) returns ms[0] = total fwd_bwd
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline
+ * figure; no reference counterpart).  Between begin and end, every sampled optimiser step carries 4
+ * events: [m0 fwd_bwd kernel m1] [m2 apply kernel m3] (a GRAD-phase call the first pair, the
+ * APPLY-phase call the second), each pair ATTACHED to its kernel's dispatch (hipExtLaunchKernelGGL
+ * start / stop events = the dispatch's own begin / end timestamps, the figure rocprofv3's kernel
+ * trace reports) rather than recorded as separate barrier packets around it.  oea_profile_end(4, ms, &n) returns ms[0] = total fwd_bwd
  * time, ms[1] = time between the two kernels (the exchange under data parallelism), ms[2] = total
  * apply time (milliseconds) over n steps.
  * stride: only every stride-th step records its marks (an event record costs a few microseconds of

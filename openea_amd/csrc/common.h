@@ -1,6 +1,7 @@
 // common.h -- shared helpers for libopenea_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -14,6 +15,10 @@ void set_error(const char *fmt, ...);
 bool prof_enabled();
 void prof_call();                  // start of a profiled call: is it one of the sampled ones?
 void prof_mark(hipStream_t st);   // records the next event of the current profile session (sampled calls only)
+// sampled call: the next TWO events of the session, to be attached to one kernel dispatch (hipExtLaunchKernelGGL start /
+// stop events: the dispatch's own begin / end timestamps -- what rocprofv3's kernel trace reports -- instead of two
+// hipEventRecord barrier packets around it, which add ~5 us of packet processing to a 17 us kernel)
+bool prof_pair(hipEvent_t *start, hipEvent_t *stop);
 
 #define OEA_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \
@@ -49,6 +54,14 @@ void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// kernel launch that carries the profile session's events when this call is a sampled one
+template <class K, class... A>
+static inline void launch_timed(K kernel, dim3 grid, dim3 block, hipStream_t st, A... args) {
+    hipEvent_t e0, e1;
+    if (prof_pair(&e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
 
 // ---- wave64 helpers ---------------------------------------------------------------------
 // Sum over the G-lane group (G power of two <= 64) containing this lane; every lane of the

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
                                                   int64_t n_ent, float *__restrict__ rel,
                                                   float *__restrict__ rel_acc, int64_t n_rel, int ld,
                                                   oea_step_cfg cfg, StepWs ws, int n_partials,
-                                                  double *__restrict__ loss_accum, int copies_folded) {
+                                                  double *__restrict__ loss_accum, int copies_folded, int flag_first) {
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
@@ -844,6 +844,12 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             const int64_t row0 = (w - n_rel) * R;
             float flag[R];
             Row<G, IT> rv[R], rg[R], ra[R];
+            if (flag_first) {          // large tables: a batch leaves many rows untouched -- look before fetching 3 rows
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) any |= row0 + r < n_ent && ws.ent_touched[row0 + r] != 0.f;
+                if (!any) continue;
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t row = row0 + r < n_ent ? row0 + r : n_ent - 1;
@@ -1136,7 +1142,7 @@ void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const f
                     int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
     static const int runtime_kind = [] { const char *e = getenv("OEA_STEP_RUNTIME_KIND"); return e ? atoi(e) : 0; }();
     const int k = cfg.neg_group_k;
-#define OEA_GROUPED(LOSS, L1) triple_grouped<G, IT, LOSS, L1><<<nb, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, k, cfg, ws)
+#define OEA_GROUPED(LOSS, L1) oea::launch_timed(triple_grouped<G, IT, LOSS, L1>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws)
     if (runtime_kind) OEA_GROUPED(-1, -1);
     else if (cfg.loss_kind == OEA_LOSS_LIMITED) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_LIMITED, 1); else OEA_GROUPED(OEA_LOSS_LIMITED, 0); }
     else if (cfg.loss_kind == OEA_LOSS_LOGISTIC) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_LOGISTIC, 1); else OEA_GROUPED(OEA_LOSS_LOGISTIC, 0); }
@@ -1159,37 +1165,35 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     const bool grouped = transh_grouped || (!projected && cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
     const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
-    // profiling marks, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3]; a GRAD call records the first pair and
-    // decides whether the step is sampled, the APPLY call that follows records the second pair
+    // profiling events, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3], each pair attached to its kernel's dispatch
+    // (oea::launch_timed); a GRAD call takes the first pair and decides whether the step is sampled, the APPLY call
+    // that follows takes the second pair
     if (phase != OEA_PHASE_APPLY) {
         oea::prof_call();
-        oea::prof_mark(st);
         if (transd)
-            triple_projected<G, IT, OEA_SCORE_TRANSD><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+            oea::launch_timed(triple_projected<G, IT, OEA_SCORE_TRANSD>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         else if (projected)
-            triple_projected<G, IT, OEA_SCORE_TRANSH><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
+            oea::launch_timed(triple_projected<G, IT, OEA_SCORE_TRANSH>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         else if (transh)
-            triple_transh_grouped<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
+            oea::launch_timed(triple_transh_grouped<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
         else if (grouped)
             launch_grouped<G, IT>(nb1, block, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
         else
-            triple_generic<G, IT><<<nb1, block, 0, st>>>(ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
-        oea::prof_mark(st);
+            oea::launch_timed(triple_generic<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         if (phase == OEA_PHASE_GRAD || dense_opt)
             fold_rel_copies_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rel * (int64_t)ld, 256), 1024), 256, 0, st>>>(
                 ws, n_rel * (int64_t)ld, transh ? 1 : 0);
     }
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
-        oea::prof_mark(st);
         if (dense_opt) {
             // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (AdamOptimizer._apply_dense)
             const double t = (double)cfg.opt_t;
             const float lr_t = cfg.opt_kind == OEA_OPT_ADAM
                                    ? (float)((double)cfg.lr * std::sqrt(1.0 - std::pow((double)cfg.beta2, t)) / (1.0 - std::pow((double)cfg.beta1, t)))
                                    : cfg.lr;
-            apply_rows_dense<G, IT><<<nb2, block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
-                                                           items > 0 ? nb1 : 0, loss_accum, lr_t);
+            oea::launch_timed(apply_rows_dense<G, IT>, nb2, block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
+                              items > 0 ? nb1 : 0, loss_accum, lr_t);
         } else {
             // rows per lane group: 1.  Measured at the 15K shape (gpurun_out r02a, in-epoch HIP events): R = 1 17.4 us,
             // R = 2 20.1, R = 4 20.4 -- more (shorter) waves hide the row latency better than more loads per wave.
@@ -1198,18 +1202,21 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             const int R = env_r ? env_r : 1;
             const int n_part = items > 0 ? nb1 : 0;   /* no triples scored: no loss partials to add */
             const int folded = phase == OEA_PHASE_APPLY;
+            // OEA_APPLY_FLAG_FIRST=1: look at the touched flag before fetching the three rows.  Measured (gpurun_out r02d):
+            // 15K shape 11.1 -> 12.8 us, 100K shape 64.0 -> 72.5 us -- a batch touches most of the table at both shapes
+            // and the dependent round trip costs more than the rows it saves; off by default.
+            static const int flag_first = [] { const char *e = getenv("OEA_APPLY_FLAG_FIRST"); return e ? atoi(e) : 0; }();
             auto nb = [&](int r) { return (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + oea::ceil_div(n_ent, r), gpb), 1), 16384); };
             if (R >= 4 && IT <= 4)
-                apply_rows<G, IT, 4><<<nb(4), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+                oea::launch_timed(apply_rows<G, IT, 4>, nb(4), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
             else if (R >= 2 && IT <= 8)
-                apply_rows<G, IT, 2><<<nb(2), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+                oea::launch_timed(apply_rows<G, IT, 2>, nb(2), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
             else
-                apply_rows<G, IT, 1><<<nb(1), block, 0, st>>>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded);
+                oea::launch_timed(apply_rows<G, IT, 1>, nb(1), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
         }
         if (transh)
             apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1), block, 0, st>>>(
                 n_rel, ld, cfg, ws, phase == OEA_PHASE_APPLY);
-        oea::prof_mark(st);
     }
     return 0;
 }
