@@ -499,6 +499,39 @@ int oea_sgd_rows(float *w, const float *grad_t, int64_t rows, int32_t dim, int32
                  int32_t normalize, float lr, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Graph builders on the device (csrc/graph_build.hip) -- the per-init adjacency construction of the GNN approaches.
+ * Inputs: triples int32 [n, 3] (device).  Outputs are sorted by (row, col); their sizes are data dependent: the caller
+ * passes buffers of `cap` entries (cap >= 2 * n_tri + n_ent covers every case) and reads *nnz_dev back.  All sums run in
+ * a fixed order (stable sort + segmented reduction): two processes build bit-identical operands.  These calls
+ * synchronise the stream (they read intermediate counts back): they run once per model init, not in an epoch.
+ * ------------------------------------------------------------------------------------- */
+/* approaches/alinet.py:155-181: distinct undirected (h, t) pairs as 0/1 entries, + I, D^-1/2 . D^-1/2
+ * (preprocess_adj, alinet.py:114-132).  fp64 values like scipy's. */
+int oea_build_unweighted_adj(const int32_t *tri, int64_t n_tri, int64_t n_ent, int32_t *row, int32_t *col, double *val,
+                             int64_t cap, int64_t *nnz_dev, void *stream);
+/* approaches/gcn_align.py:610-640 (r2f / r2if [n_rel] fp64 = distinct heads / tails per triple of a relation),
+ * :642-664 (M[(h,t)] += max(r2if, .3), M[(t,h)] += max(r2f, .3); entry of key (a, b) at row b, column a; optional raw
+ * adjacency outputs adj_*: NULL to skip) and :566-578 (support = normalize_adj(adj + I) = (A' D^-1/2)^T D^-1/2). */
+int oea_build_weighted_adj(const int32_t *tri, int64_t n_tri, int64_t n_ent, int64_t n_rel, double *r2f, double *r2if,
+                           int32_t *adj_row, int32_t *adj_col, double *adj_val, int64_t *adj_nnz_dev, int32_t *row,
+                           int32_t *col, double *val, int64_t cap, int64_t *nnz_dev, void *stream);
+/* approaches/rdgcn.py:45-72 (get_mat + get_sparse_tensor): M[sec, fir] = 1 / sqrt(deg[fir]) / sqrt(deg[sec]) over the
+ * symmetric closure of the (h, t) pairs with h != t plus the diagonal, with get_mat's degree rule; values as fp32. */
+int oea_build_primal_adj(const int32_t *tri, int64_t n_tri, int64_t n_ent, int32_t *row, int32_t *col, float *val,
+                         int64_t cap, int64_t *nnz_dev, void *stream);
+/* approaches/rdgcn.py:17-42 + :268-277: out [n_rel, n_rel] fp32 = Jaccard overlap of the relations' head sets + of
+ * their tail sets. */
+int oea_build_dual_adj(const int32_t *tri, int64_t n_tri, int64_t n_rel, float *out, void *stream);
+/* approaches/alinet.py:250-287 (generate_2hop_triples): self-join of `tri` (tail == head, left triple major, matches in
+ * table order), rows whose (h, t) is an edge of `full_tri` dropped, the n_cut most frequent (r1, r2) patterns dropped
+ * (ties: first appearance in the joined table, i.e. python's stable sort), out = distinct (h, r1 + r2, t) of the kept
+ * rows plus (h, 0, h) for their heads, sorted.  stats_host[4] = the reference's four log counts (distinct joined
+ * (h, r1, r2, t); patterns; patterns kept; triples out). */
+int oea_build_2hop(const int32_t *tri, int64_t n_tri, const int32_t *full_tri, int64_t n_full, int64_t n_ent,
+                   int64_t n_rel, int32_t n_cut, int32_t *out, int64_t cap, int64_t *n_out_dev, int64_t *stats_host,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Collective group (one process per GPU, RCCL over xGMI) -- no reference counterpart (the reference is single-device,
  * SURVEY F2).  The exchange points of the multi-GPU path for a host that is not Python: reduce-scatter / all-gather of
  * the partitioned step (oea_part_*), int64 / fp64 sums of the row-sharded evaluation's metrics, all-gather of row blocks

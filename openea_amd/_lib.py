@@ -139,6 +139,11 @@ PROTOTYPES = {
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "oea_sgd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "oea_build_unweighted_adj": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "oea_build_weighted_adj": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "oea_build_primal_adj": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "oea_build_dual_adj": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "oea_build_2hop": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, C.POINTER(_i64), _vp]),
     "oea_comm_unique_id": (C.c_int, [_vp]),
     "oea_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "oea_comm_destroy": (C.c_int, [_vp]),

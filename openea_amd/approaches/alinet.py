@@ -139,6 +139,37 @@ def generate_2hop_triples(kg, linked_ents=None, as_array=False):
     return out
 
 
+def no_weighted_adj_device(total_ent_num, triple_list):
+    """no_weighted_adj on the device (oea_build_unweighted_adj): same entries, same fp64 values, same entry order (sorted
+    by (col, row), as scipy's csc -> coo conversion leaves them)."""
+    n = int(total_ent_num)
+    row, col, val = ops.build_unweighted_adj(triple_list, n)
+    return sp.coo_matrix((val, (row, col)), shape=(n, n))
+
+
+def generate_2hop_triples_device(kg, linked_ents=None):
+    """generate_2hop_triples(..., as_array=True) on the device (oea_build_2hop): the join, the neighbour filter, the pattern
+    ranking and the de-duplication are sorts / run-length encodings of packed keys; the python-set order of the filtered
+    triple table (which decides ties of the pattern ranking) is fixed on the host before the upload."""
+    triples = kg.triples
+    if linked_ents is not None:
+        triples = remove_unlinked_triples(triples, linked_ents)
+    tri = _triple_array(triples)
+    if len(tri) == 0:
+        return np.zeros((0, 3), np.int64)
+    full = _triple_array(kg.triples) if linked_ents is not None else tri
+    n_ent = int(max(full[:, 0].max(), full[:, 2].max(), tri[:, 0].max(), tri[:, 2].max())) + 1
+    n_rel = int(max(full[:, 1].max(), tri[:, 1].max())) + 1
+    out, stats = ops.build_2hop(tri, full if linked_ents is not None else None, n_ent, n_rel, 5)
+    print("total 2-hop neighbors:", stats[0])
+    if stats[0] == 0:
+        return np.zeros((0, 3), np.int64)
+    print("total 2-hop relation patterns:", stats[1])
+    print("selected relation patterns:", stats[2])
+    print("selected 2-hop neighbors:", stats[3])
+    return out
+
+
 def enhance_triples(kg1, kg2, ents1, ents2):
     """alinet.py:399-416: triples implied in the other KG by the seed links."""
     assert len(ents1) == len(ents2)
@@ -391,9 +422,14 @@ class AliNet(BasicModel):
         triples = remove_unlinked_triples(ori_triples + list(e1) + list(e2), self.linked_ents)
         self.rel_ht_dict = generate_rel_ht(triples)
         n = self.kgs.entities_num
-        one = no_weighted_adj(n, triples)
-        two = no_weighted_adj(n, np.concatenate([generate_2hop_triples(self.kg1, self.linked_ents, as_array=True),
-                                                 generate_2hop_triples(self.kg2, self.linked_ents, as_array=True)]))
+        if getattr(self.args, 'graph_builders', 'device') == 'host':       # the numpy restatements (same outputs)
+            one = no_weighted_adj(n, triples)
+            two = no_weighted_adj(n, np.concatenate([generate_2hop_triples(self.kg1, self.linked_ents, as_array=True),
+                                                     generate_2hop_triples(self.kg2, self.linked_ents, as_array=True)]))
+        else:
+            one = no_weighted_adj_device(n, triples)
+            two = no_weighted_adj_device(n, np.concatenate([generate_2hop_triples_device(self.kg1, self.linked_ents),
+                                                            generate_2hop_triples_device(self.kg2, self.linked_ents)]))
         self.adj = [EdgeGraph(one.row, one.col, one.data, one.shape, dev),
                     EdgeGraph(two.row, two.col, two.data, two.shape, dev, grouping=self.attn_grouping)]
         self.rel_win_size = self.args.batch_size // max(len(self.rel_ht_dict), 1)
@@ -559,7 +595,8 @@ class AliNet(BasicModel):
                                                            self.sup_ent2 + new_sup_ent2)
         triples = self.kg1.triple_list + self.kg2.triple_list + list(self.new_edges1) + list(self.new_edges2)
         triples = remove_unlinked_triples(triples, self.linked_ents)
-        one = no_weighted_adj(self.kgs.entities_num, triples)
+        host = getattr(self.args, 'graph_builders', 'device') == 'host'
+        one = (no_weighted_adj if host else no_weighted_adj_device)(self.kgs.entities_num, triples)
         self.adj[0] = EdgeGraph(one.row, one.col, one.data, one.shape, self.dev)
         for layer in self.one_hop_layers:
             layer.graph = self.adj[0]                               # GraphConvolution.update_adj (alinet.py:586-590)

@@ -114,6 +114,20 @@ class GCN_Utils:
         train = np.array(self.kgs.train_links)
         return adj, attr, train
 
+    def load_data_device(self, attr):
+        """load_data + preprocess_adj with the functionality weights, the weighted adjacency and its normalisation built on
+        the device (oea_build_weighted_adj) -> (adj, support, attr, train); same entries and fp64 values as the host
+        functions above (sums of duplicate pairs in triple order)."""
+        triples = self.kgs.kg1.relation_triples_list + self.kgs.kg2.relation_triples_list
+        e = self.kgs.entities_num
+        n_rel = max(int(self.kgs.relations_num), 1 + max((r for _, r, _ in triples), default=0))
+        b = ops.build_weighted_adj(triples, e, n_rel, raw=True)
+        ar, ac, av = b["adj"]
+        sr, sc, sv = b["support"]
+        adj = sp.coo_matrix((av, (ar, ac)), shape=(e, e))
+        support = sp.coo_matrix((sv, (sr, sc)), shape=(e, e))
+        return adj, support, attr, np.array(self.kgs.train_links)
+
 
 class DeviceCSR:
     """CSR + transposed CSR of a sparse matrix, fp32, on the device (models/graph_ops.py:CsrOperand: the
@@ -196,9 +210,13 @@ class GCN_Align(BasicModel):
         dev = ops.device()
         self.utils = GCN_Utils(self.args, self.kgs)
         self.attr = load_attr(self.kgs.entities_num, self.kgs)
-        self.adj, self.ae_input, self.train = self.utils.load_data(self.attr)
         self.e = self.kgs.entities_num
-        self.support = DeviceCSR(self.utils.preprocess_adj(self.adj), dev)
+        if getattr(self.args, 'graph_builders', 'device') == 'host':       # the python restatements (same outputs)
+            self.adj, self.ae_input, self.train = self.utils.load_data(self.attr)
+            self.support = DeviceCSR(self.utils.preprocess_adj(self.adj), dev)
+        else:
+            self.adj, support, self.ae_input, self.train = self.utils.load_data_device(self.attr)
+            self.support = DeviceCSR(support, dev)
         self.model_ae = None
         if self.attr.shape[1] > 0:
             self.model_ae = GCN_Align_Unit(self.args, self.support, self.attr.shape[1], self.args.ae_dim, self.train,

@@ -136,25 +136,40 @@ class Layer:
         self.triple_list = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
         self.rel_num, self.ent_num = kgs.relations_num, kgs.entities_num
         rng = np.random.RandomState(seed)
-        self.head, self.tail, r_ind, r_val = rfunc(self.triple_list, self.ent_num, self.rel_num)
-        self.count_r = len(self.head)
-        rows, cols, vals = get_sparse_tensor(self.triple_list, self.ent_num)
+        if getattr(args, 'graph_builders', 'device') == 'host':           # the python / numpy restatements (same outputs)
+            self.head, self.tail, r_ind, r_val = rfunc(self.triple_list, self.ent_num, self.rel_num)
+            self.count_r = len(self.head)
+            rows, cols, vals = get_sparse_tensor(self.triple_list, self.ent_num)
+            hr = np.array([(r, h) for r, hs in self.head.items() for h in hs], np.int64).reshape(-1, 2)
+            tr = np.array([(r, t) for r, ts in self.tail.items() for t in ts], np.int64).reshape(-1, 2)
+            dual = torch.from_numpy(dual_adjacency(self.head, self.tail, self.count_r)).to(dev)
+        else:
+            # device builders (csrc/graph_build.hip): primal adjacency and the Jaccard overlaps; the per-relation head /
+            # tail sets are the distinct (relation, entity) pairs of the triple table
+            tri = np.fromiter((x for t in self.triple_list for x in t), np.int64, count=3 * len(self.triple_list)).reshape(-1, 3)
+            r_ind, r_val = tri[:, [0, 2]], tri[:, 1]
+            n_r = int(tri[:, 1].max()) + 1 if len(tri) else 0
+            hr = np.unique(tri[:, 1] * self.ent_num + tri[:, 0])
+            tr = np.unique(tri[:, 1] * self.ent_num + tri[:, 2])
+            hr = np.stack([hr // self.ent_num, hr % self.ent_num], 1)
+            tr = np.stack([tr // self.ent_num, tr % self.ent_num], 1)
+            self.count_r = len(np.unique(tri[:, 1]))
+            assert self.count_r == n_r, "relation ids must be dense (rdgcn.py:268-277 indexes the overlap matrix by id)"
+            self.head = self.tail = None
+            rows, cols, vals = ops.build_primal_adj(tri, self.ent_num)
+            dual = ops.build_dual_adj(tri, self.count_r)
         self.M = EdgeGraph(rows, cols, vals, (self.ent_num, self.ent_num), dev)
         self.r_graph = EdgeGraph(r_ind[:, 0], r_ind[:, 1], np.ones(len(r_ind), np.float32),
                                  (self.ent_num, self.ent_num), dev, grouping=attn_grouping)
         # relation id of every attention edge, in the graph's (possibly re-ordered) edge order
         order = np.lexsort((r_ind[:, 1], r_ind[:, 0])) if attn_grouping == 'row' else np.arange(len(r_ind))
-        self.edge_rel = torch.from_numpy(r_val[order]).to(dev)
+        self.edge_rel = torch.from_numpy(np.ascontiguousarray(r_val[order])).to(dev)
         # compute_r (rdgcn.py:258-266): per-relation mean of its head / tail entity embeddings
-        hr = [(r, h) for r, hs in self.head.items() for h in hs]
-        tr = [(r, t) for r, ts in self.tail.items() for t in ts]
-        hcnt = np.bincount([r for r, _ in hr], minlength=self.count_r).astype(np.float32)
-        tcnt = np.bincount([r for r, _ in tr], minlength=self.count_r).astype(np.float32)
-        self.head_mean = EdgeGraph([r for r, _ in hr], [h for _, h in hr], [1.0 / hcnt[r] for r, _ in hr],
-                                   (self.count_r, self.ent_num), dev)
-        self.tail_mean = EdgeGraph([r for r, _ in tr], [t for _, t in tr], [1.0 / tcnt[r] for r, _ in tr],
-                                   (self.count_r, self.ent_num), dev)
-        self.dual_A = torch.from_numpy(dual_adjacency(self.head, self.tail, self.count_r)).to(dev)
+        hcnt = np.bincount(hr[:, 0], minlength=self.count_r).astype(np.float32)
+        tcnt = np.bincount(tr[:, 0], minlength=self.count_r).astype(np.float32)
+        self.head_mean = EdgeGraph(hr[:, 0], hr[:, 1], 1.0 / hcnt[hr[:, 0]], (self.count_r, self.ent_num), dev)
+        self.tail_mean = EdgeGraph(tr[:, 0], tr[:, 1], 1.0 / tcnt[tr[:, 0]], (self.count_r, self.ent_num), dev)
+        self.dual_A = dual
         self.dual_bias = -1e9 * (1.0 - (self.dual_A > 0).float())
         d = self.dim
         # ---- variables (creation order of rdgcn.py:317-338) ---------------------------------------

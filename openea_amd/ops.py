@@ -459,6 +459,99 @@ def csls_apply_(s, r, c):
 
 
 # -------------------------------------------------------------------------------------------
+# graph builders (csrc/graph_build.hip): triples in, sorted COO out (host numpy: the operands are cut into CSR / chunk
+# layouts by the constructors of models/graph_ops.py afterwards)
+# -------------------------------------------------------------------------------------------
+
+
+def _triples_dev(triples, dev=None):
+    """list / set iteration order / ndarray [n, 3] -> device int32 [n, 3]"""
+    if isinstance(triples, torch.Tensor):
+        return triples.to(dtype=torch.int32).contiguous()
+    if isinstance(triples, np.ndarray):
+        a = np.ascontiguousarray(triples, dtype=np.int32).reshape(-1, 3)
+    else:
+        a = np.fromiter((x for tr in triples for x in tr), np.int32, count=3 * len(triples)).reshape(-1, 3)
+    return torch.from_numpy(a).to(dev or device())
+
+
+def _coo_out(cap, dev, val_dtype):
+    return (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+            torch.empty(cap, dtype=val_dtype, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+
+
+def build_unweighted_adj(triples, n_ent):
+    """alinet.py:155-181 -> (row, col, val fp64) numpy, sorted by (row, col)."""
+    tri = _triples_dev(triples)
+    n = tri.shape[0]
+    cap = 2 * n + int(n_ent)
+    row, col, val, nnz = _coo_out(cap, tri.device, torch.float64)
+    check(lib().oea_build_unweighted_adj(_p(tri), n, int(n_ent), _p(row), _p(col), _p(val), cap, _p(nnz), _stream()))
+    m = int(nnz.item())
+    return row[:m].cpu().numpy(), col[:m].cpu().numpy(), val[:m].cpu().numpy()
+
+
+def build_weighted_adj(triples, n_ent, n_rel, raw=False):
+    """gcn_align.py:610-664 + 566-578 -> dict(r2f, r2if [n_rel], support = (row, col, val), adj = (row, col, val) if raw)."""
+    tri = _triples_dev(triples)
+    n = tri.shape[0]
+    dev = tri.device
+    cap = 2 * n + int(n_ent)
+    r2f = torch.zeros(int(n_rel), dtype=torch.float64, device=dev)
+    r2if = torch.zeros(int(n_rel), dtype=torch.float64, device=dev)
+    row, col, val, nnz = _coo_out(cap, dev, torch.float64)
+    a_row, a_col, a_val, a_nnz = _coo_out(cap, dev, torch.float64) if raw else (None, None, None, None)
+    check(lib().oea_build_weighted_adj(_p(tri), n, int(n_ent), int(n_rel), _p(r2f), _p(r2if), _p(a_row), _p(a_col), _p(a_val),
+                                       _p(a_nnz), _p(row), _p(col), _p(val), cap, _p(nnz), _stream()))
+    m = int(nnz.item())
+    out = dict(r2f=r2f.cpu().numpy(), r2if=r2if.cpu().numpy(),
+               support=(row[:m].cpu().numpy(), col[:m].cpu().numpy(), val[:m].cpu().numpy()))
+    if raw:
+        ma = int(a_nnz.item())
+        out["adj"] = (a_row[:ma].cpu().numpy(), a_col[:ma].cpu().numpy(), a_val[:ma].cpu().numpy())
+    return out
+
+
+def build_primal_adj(triples, n_ent):
+    """rdgcn.py:45-72 -> (row, col, val fp32) numpy."""
+    tri = _triples_dev(triples)
+    n = tri.shape[0]
+    cap = 2 * n + int(n_ent)
+    row, col, val, nnz = _coo_out(cap, tri.device, torch.float32)
+    check(lib().oea_build_primal_adj(_p(tri), n, int(n_ent), _p(row), _p(col), _p(val), cap, _p(nnz), _stream()))
+    m = int(nnz.item())
+    return row[:m].cpu().numpy(), col[:m].cpu().numpy(), val[:m].cpu().numpy()
+
+
+def build_dual_adj(triples, n_rel):
+    """rdgcn.py:17-42 + 268-277 -> device fp32 [n_rel, n_rel]."""
+    tri = _triples_dev(triples)
+    out = torch.empty((int(n_rel), int(n_rel)), dtype=torch.float32, device=tri.device)
+    check(lib().oea_build_dual_adj(_p(tri), tri.shape[0], int(n_rel), _p(out), _stream()))
+    return out
+
+
+def build_2hop(triples, full_triples, n_ent, n_rel, n_cut=5):
+    """alinet.py:250-287 -> (int64 [m, 3] numpy sorted by (h, r, t), stats = the reference's four log counts)."""
+    tri = _triples_dev(triples)
+    full = tri if full_triples is None else _triples_dev(full_triples)
+    n = tri.shape[0]
+    stats = (C.c_int64 * 4)()
+    n_out = torch.zeros(1, dtype=torch.int64, device=tri.device)
+    cap = max(4 * n, 1 << 16)
+    while True:
+        out = torch.empty((cap, 3), dtype=torch.int32, device=tri.device)
+        rc = lib().oea_build_2hop(_p(tri), n, _p(full), full.shape[0], int(n_ent), int(n_rel), int(n_cut), _p(out), cap, _p(n_out),
+                                  stats, _stream())
+        m = int(n_out.item())
+        if rc != 0 and m > cap:            # the count is known now: once more with room for it
+            cap = m
+            continue
+        check(rc)
+        return out[:m].cpu().numpy().astype(np.int64), [int(x) for x in stats]
+
+
+# -------------------------------------------------------------------------------------------
 # graph aggregate
 # -------------------------------------------------------------------------------------------
 

@@ -457,3 +457,92 @@ def test_host_matrix_helpers_match_reference(g):
     for m in (exact, greedy):
         assert len({i for i, _ in m}) == len(m) == len({j for _, j in m}) and set(m) <= pairs
     assert sum(sim_mat[i, j] for i, j in exact) >= sum(sim_mat[i, j] for i, j in greedy) - 1e-9
+
+
+# ---- the same builders on the device (csrc/graph_build.hip) against the reference's outputs ------------------------------
+@pytest.mark.gpu
+def test_device_gcn_align_adjacency_matches_reference(g, kgs):
+    """oea_build_weighted_adj == gcn_align.py:610-664 + 566-578 (reference fixtures), entry ORDER of the support included."""
+    from openea_amd import ops
+    from openea_amd.approaches.gcn_align import GCN_Utils
+    triples = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+    n_rel = 1 + max(r for _, r, _ in triples)
+    b = ops.build_weighted_adj(triples, kgs.entities_num, n_rel, raw=True)
+    rels = sorted({r for _, r, _ in triples})
+    np.testing.assert_array_equal(b["r2f"][rels], g["gcn_r2f"])
+    np.testing.assert_array_equal(b["r2if"][rels], g["gcn_r2if"])
+    assert_coo(coo_sorted(*b["adj"]), g["gcn_adj"])
+    assert_coo(coo_sorted(*b["support"]), g["gcn_support"])
+    u = GCN_Utils(types.SimpleNamespace(), kgs)
+    sup = u.preprocess_adj(u.get_weighted_adj(kgs.entities_num, triples)).tocoo()
+    assert np.array_equal(sup.row, b["support"][0]) and np.array_equal(sup.col, b["support"][1])     # scipy's (col, row) order
+
+
+@pytest.mark.gpu
+def test_device_alinet_builders_match_reference(g, kgs):
+    """oea_build_unweighted_adj / oea_build_2hop == alinet.py:155-181, 250-287 (reference fixtures)."""
+    from openea_amd.approaches import alinet
+    sup1 = [a for a, _ in kgs.train_links]
+    sup2 = [b for _, b in kgs.train_links]
+    kg1, kg2 = alinet.AKG(kgs.kg1.relation_triples_set), alinet.AKG(kgs.kg2.relation_triples_set)
+    en1, en2 = quiet(alinet.enhance_triples, kg1, kg2, sup1, sup2)
+    half = len(kgs.test_entities1) // 2
+    linked = set(sup1 + sup2 + kgs.valid_entities1 + kgs.valid_entities2 + kgs.test_entities1[:half] + kgs.test_entities2[:half])
+    for name, kg in (("kg1", kg1), ("kg2", kg2)):
+        assert np.array_equal(triples_sorted(quiet(alinet.generate_2hop_triples_device, kg, linked)), g["alinet_2hop_" + name])
+        assert np.array_equal(triples_sorted(quiet(alinet.generate_2hop_triples_device, kg)), g["alinet_2hop_all_" + name])
+    triples = list(kg1.triples | kg2.triples | en1 | en2)
+    one = alinet.no_weighted_adj_device(kgs.entities_num, triples)
+    assert_coo(coo_sorted(one.row, one.col, one.data), g["alinet_one_adj"])
+    host = alinet.no_weighted_adj(kgs.entities_num, triples)
+    assert np.array_equal(host.row, one.row) and np.array_equal(host.col, one.col)      # the order the 'runs' grouping sees
+    np.testing.assert_allclose(one.data, host.data, rtol=1e-14)
+
+
+@pytest.mark.gpu
+def test_device_rdgcn_structures_match_reference(g, kgs):
+    """oea_build_primal_adj / oea_build_dual_adj == rdgcn.py:45-72, 268-277."""
+    from openea_amd import ops
+    from openea_amd.approaches import rdgcn
+    triples = kgs.kg1.relation_triples_list + kgs.kg2.relation_triples_list
+    n_ent, n_rel = kgs.entities_num, kgs.relations_num
+    rows, cols, vals = ops.build_primal_adj(triples, n_ent)
+    assert_coo(coo_sorted(rows, cols, vals), g["rdgcn_primal"], tol=1e-7)
+    h_rows, h_cols, h_vals = rdgcn.get_sparse_tensor(triples, n_ent)
+    assert np.array_equal(h_vals[np.lexsort((h_cols, h_rows))], vals[np.lexsort((cols, rows))])      # bit-identical fp32 values
+    head, tail, _, _ = rdgcn.rfunc(triples, n_ent, n_rel)
+    count_r = len(head)
+    dual = ops.build_dual_adj(triples, count_r).cpu().numpy()
+    assert np.array_equal(dual, rdgcn.dual_adjacency(head, tail, count_r))
+
+
+@pytest.mark.gpu
+def test_device_builders_equal_host_builders_15k():
+    """the device builders on the EN-FR-15K-shaped synthetic pair: same entries as the numpy restatements (which equal the
+    reference's functions on the fixtures above), values to 1e-13, 2-hop triples identical."""
+    from openea_amd import ops
+    from openea_amd.approaches import alinet, rdgcn
+    from openea_amd.approaches.gcn_align import GCN_Utils
+    from openea_amd.modules.load.synth import make_kgs
+    kgs15 = make_kgs("EN-FR-15K-V1", mode="mapping", seed=0)
+    triples = kgs15.kg1.relation_triples_list + kgs15.kg2.relation_triples_list
+    n_ent, n_rel = kgs15.entities_num, kgs15.relations_num
+    u = GCN_Utils(types.SimpleNamespace(), kgs15)
+    sup = u.preprocess_adj(u.get_weighted_adj(n_ent, triples)).tocoo()
+    b = ops.build_weighted_adj(triples, n_ent, n_rel)
+    assert np.array_equal(sup.row, b["support"][0]) and np.array_equal(sup.col, b["support"][1])
+    np.testing.assert_allclose(b["support"][2], sup.data, rtol=1e-13)
+    kg1 = alinet.AKG(kgs15.kg1.relation_triples_set)
+    linked = set(kgs15.train_entities1 + kgs15.valid_entities1 + kgs15.test_entities1)
+    for le in (None, linked):
+        a = quiet(alinet.generate_2hop_triples, kg1, le, as_array=True)
+        d = quiet(alinet.generate_2hop_triples_device, kg1, le)
+        assert a.shape == d.shape and np.array_equal(a, d)
+    one_h, one_d = alinet.no_weighted_adj(n_ent, triples), alinet.no_weighted_adj_device(n_ent, triples)
+    assert np.array_equal(one_h.row, one_d.row) and np.array_equal(one_h.col, one_d.col)
+    np.testing.assert_allclose(one_d.data, one_h.data, rtol=1e-14)
+    hr, hc, hv = rdgcn.get_sparse_tensor(triples, n_ent)
+    dr, dc, dv = ops.build_primal_adj(triples, n_ent)
+    assert np.array_equal(coo_sorted(hr, hc, hv), coo_sorted(dr, dc, dv))
+    head, tail, _, _ = rdgcn.rfunc(triples, n_ent, n_rel)
+    assert np.array_equal(ops.build_dual_adj(triples, len(head)).cpu().numpy(), rdgcn.dual_adjacency(head, tail, len(head)))
