@@ -88,12 +88,15 @@ struct Row {
     float v[IT];
 };
 
-template <int G, int IT>
+// TIGHT (G == 32 only): the dispatch gives ld > (IT - 1) * 32, so only the last fragment needs the bound.  Used by the
+// grouped scoring kernel (18.8 vs 19.2 us at the 15K shape, 64 vs 75 us at the 100K shape); apply_rows is SLOWER with it
+// (13.2 vs 11.3 us, 83 vs 64 us: the optimiser's three row streams schedule worse as unconditional loads) and keeps the bound.
+template <int G, int IT, bool TIGHT = false>
 __device__ __forceinline__ void load_row(const float *__restrict__ base, int ld, int lane, Row<G, IT> &r) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int c = it * G + lane;
-        r.v[it] = c < ld ? base[c] : 0.f;
+        r.v[it] = ((TIGHT && G == 32 && it < IT - 1) || c < ld) ? base[c] : 0.f;
     }
 }
 template <int G, int IT>
@@ -131,13 +134,15 @@ __device__ __forceinline__ void dscore(const Row<G, IT> &delta, float coef, int 
 #pragma unroll
     for (int it = 0; it < IT; ++it) g.v[it] = l1 ? coef * sgn(delta.v[it]) : 2.f * coef * delta.v[it];
 }
-template <int G, int IT>
+// SKIPZERO: elements whose gradient is exactly 0 issue no atomic (L1 norm: sgn(0); a per-element branch) -- the grouped
+// kernel's L2 paths turn it off (a zero there is a measure-zero event and the branches cost more than the atomics)
+template <int G, int IT, bool SKIPZERO = true>
 __device__ __forceinline__ void atomic_row(float *__restrict__ dst, int ld, int lane, const Row<G, IT> &g, float sign) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int c = it * G + lane;
         const float v = sign * g.v[it];
-        if (c < ld && v != 0.f) oea::atomic_add_f32(dst + c, v);
+        if (((G == 32 && it < IT - 1) || c < ld) && (!SKIPZERO || v != 0.f)) oea::atomic_add_f32(dst + c, v);
     }
 }
 
@@ -276,6 +281,10 @@ __device__ __forceinline__ double score_independent(const float *__restrict__ en
 // Occupancy: a batch of 5,000 positives is 2,500 waves; at 2 waves/SIMD the chip holds 2,048, and the 452
 // late-comers doubled the kernel's critical path (25.9 us).  Capping the registers at 3 waves/SIMD (a few
 // spilled dwords for IT >= 2) lets every wave start at once: 19.4 us.
+// Measured and dropped (gpurun_out r02f, same binary, env-selected): 4 waves / SIMD (<= 128 VGPRs, ~40 spill accesses)
+// 20.1 vs 17.8 us at the 15K shape and 90 vs 65 us at the 100K shape; no per-element zero test in front of the atomics
+// (100 fewer VALU instructions) 19.4 vs 17.8 us -- the test skips WHOLE rows often (a positive inside its margin with only
+// tail-corrupted negatives active leaves gt all zero).
 template <int G, int IT, int LOSS, int L1>
 __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
@@ -297,9 +306,9 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
         int nid = lane < 3 * min(KC, k) ? ng[lane] : 0;
         const int h = __shfl(pid, 0, G), r = __shfl(pid, 1, G), t = __shfl(pid, 2, G);
         Row<G, IT> yh, yr, yt, delta, g, gh, gr, gt;
-        load_row<G, IT>(ent + (int64_t)h * ld, ld, lane, yh);
-        load_row<G, IT>(rel + (int64_t)r * ld, ld, lane, yr);
-        load_row<G, IT>(ent + (int64_t)t * ld, ld, lane, yt);
+        load_row<G, IT, true>(ent + (int64_t)h * ld, ld, lane, yh);
+        load_row<G, IT, true>(rel + (int64_t)r * ld, ld, lane, yr);
+        load_row<G, IT, true>(ent + (int64_t)t * ld, ld, lane, yt);
         double lsum = 0.0;
         bool any = false;
         for (int base = 0; base < k; base += KC) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
                 okm |= ok ? 1u << j : 0u;
                 slow |= (valid && !ok) ? 1u << j : 0u;                 // entries that are not corruptions of this positive
                 ce[j] = valid ? (tl ? ct : ch) : h;
-                load_row<G, IT>(ent + (int64_t)ce[j] * ld, ld, lane, yc[j]);
+                load_row<G, IT, true>(ent + (int64_t)ce[j] * ld, ld, lane, yc[j]);
             }
             if (base == 0) {
                 normalize<G, IT>(yh, cfg.ent_l2_norm);
