@@ -436,6 +436,12 @@ typedef struct oea_csr_split {
     const int32_t *chunk_e1;    /* [n_chunks] one past the last nonzero */
     const int32_t *rows;        /* [n_rows]   the split rows */
     int32_t n_chunks, n_rows, threshold;
+    /* optional (NULL / 0: the chunks are added to y with atomics after a zeroing launch): with a buffer of
+     * partials_floats >= n_chunks * ldy floats and the chunk range of every split row, the chunks are computed inside
+     * the row kernel's launch and summed in chunk order by the epilogue -- two launches, deterministic */
+    const int32_t *row_chunk0;  /* [n_rows + 1] first chunk of each split row */
+    float *partials;
+    int64_t partials_floats;
 } oea_csr_split;
 int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                  const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from,

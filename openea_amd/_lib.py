@@ -35,7 +35,8 @@ class SamplerSide(C.Structure):
 class CsrSplit(C.Structure):
     """mirror of `oea_csr_split` (include/openea_hip.h)."""
     _fields_ = [("chunk_row", C.c_void_p), ("chunk_e0", C.c_void_p), ("chunk_e1", C.c_void_p), ("rows", C.c_void_p),
-                ("n_chunks", C.c_int32), ("n_rows", C.c_int32), ("threshold", C.c_int32)]
+                ("n_chunks", C.c_int32), ("n_rows", C.c_int32), ("threshold", C.c_int32),
+                ("row_chunk0", C.c_void_p), ("partials", C.c_void_p), ("partials_floats", C.c_int64)]
 
 
 class AttnGraph(C.Structure):

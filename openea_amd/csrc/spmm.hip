@@ -94,15 +94,45 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
                                                        const float *__restrict__ vals, int64_t n_rows,
                                                        const float *__restrict__ x, int dim, int ldx, int act,
                                                        const float *__restrict__ mask_from, float *__restrict__ y,
-                                                       int ldy, int huge) {
+                                                       int ldy, int huge, oea_csr_split split, int n_chunk_blocks) {
     constexpr int NG = 256 / G;
     extern __shared__ __attribute__((aligned(16))) float s_part[];      // [NG][ldy] partial rows
     const int lane = threadIdx.x % G, gid = threadIdx.x / G;
-    // rows are dealt out CYCLICALLY: group gid of block b takes rows b + gridDim.x * (gid + NG * i).  Ids are
+    // the first n_chunk_blocks workgroups take one chunk of a hub row each (the heaviest items start first) and leave its
+    // partial sum in split.partials[chunk]: no atomics, no zeroing; spmm_rows_epilogue_kernel adds a row's chunks in order
+    if ((int)blockIdx.x < n_chunk_blocks) {
+        const int ch = blockIdx.x;
+        float4 acc[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        row_accumulate<G, IT>(colidx, vals, x, ldx, lane, split.chunk_e0[ch] + gid, split.chunk_e1[ch], NG, acc);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * G + lane) * 4;
+            if (c < ldy) oea::st4(s_part + gid * ldy + c, acc[it]);
+        }
+        __syncthreads();
+        if (gid == 0) {
+            float *o = split.partials + (int64_t)ch * ldy;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = (it * G + lane) * 4;
+                if (c < ldy) {
+                    for (int g2 = 1; g2 < NG; ++g2) {
+                        const float4 p = oea::ld4(s_part + g2 * ldy + c);
+                        acc[it].x += p.x; acc[it].y += p.y; acc[it].z += p.z; acc[it].w += p.w;
+                    }
+                    oea::st4(o + c, acc[it]);
+                }
+            }
+        }
+        return;
+    }
+    // rows are dealt out CYCLICALLY: group gid of block b takes rows b + nb * (gid + NG * i).  Ids are
     // frequency-ordered, so consecutive rows would hand all hubs to the first few workgroups.
-    const int64_t nb = gridDim.x;
+    const int64_t nb = gridDim.x - n_chunk_blocks, bid = blockIdx.x - n_chunk_blocks;
     for (int64_t base = 0; base < n_rows; base += nb * NG) {
-        const int64_t row = base + (int64_t)gid * nb + blockIdx.x;
+        const int64_t row = base + (int64_t)gid * nb + bid;
         int e0 = 0, e1 = 0;
         if (row < n_rows) { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
         if (row < n_rows && e1 - e0 <= kLongRow) {
@@ -114,7 +144,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
         }
         // long rows of this batch: workgroup-cooperative (block-uniform control flow)
         for (int r = 0; r < NG; ++r) {
-            const int64_t lrow = base + (int64_t)r * nb + blockIdx.x;
+            const int64_t lrow = base + (int64_t)r * nb + bid;
             if (lrow >= n_rows) break;
             const int l0 = rowptr[lrow], l1 = rowptr[lrow + 1];
             if (l1 - l0 <= kLongRow || l1 - l0 > huge) continue;     // huge rows: split across workgroups below
@@ -196,18 +226,35 @@ __global__ __launch_bounds__(256) void spmm_chunk_kernel(const int32_t *__restri
     }
 }
 
+// partials == NULL: y holds the atomically summed row (legacy path); else the row's chunks are added in chunk order
 template <int G, int IT>
 __global__ __launch_bounds__(256) void spmm_rows_epilogue_kernel(const int32_t *__restrict__ rows, int n, int dim, int act,
-                                                                 const float *__restrict__ mask_from, float *__restrict__ y, int ldy) {
+                                                                 const float *__restrict__ mask_from, float *__restrict__ y, int ldy,
+                                                                 const float *__restrict__ partials, const int32_t *__restrict__ row_chunk0) {
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (grp >= n) return;
     const int64_t row = rows[grp];
     float4 acc[IT];
+    if (partials) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int c = (it * G + lane) * 4;
-        acc[it] = c < ldy ? oea::ld4(y + row * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ch = row_chunk0[grp]; ch < row_chunk0[grp + 1]; ++ch) {
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int c = (it * G + lane) * 4;
+                if (c < ldy) {
+                    const float4 p = oea::ld4(partials + (int64_t)ch * ldy + c);
+                    acc[it].x += p.x; acc[it].y += p.y; acc[it].z += p.z; acc[it].w += p.w;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * G + lane) * 4;
+            acc[it] = c < ldy ? oea::ld4(y + row * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     row_store<G, IT>(acc, row, lane, dim, act, mask_from, y, ldy);
 }
@@ -386,17 +433,27 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
     hipStream_t st = oea::as_stream(stream);
     const bool use_split = split && split->n_chunks > 0;
     const int huge = use_split ? split->threshold : 0x7fffffff;
+    // hub chunks inside the row kernel when the split carries a partial-sum buffer (1 + 1 launches, fixed summation order);
+    // else the legacy path: zero the hub rows, chunk kernel with atomics, epilogue (1 + 3 launches)
+    const bool fused = use_split && split->partials && split->row_chunk0 &&
+                       split->partials_floats >= (int64_t)split->n_chunks * ldy;
+    oea_csr_split sp{};
+    if (use_split) sp = *split;
 #define CALL(G, IT)                                                                                                    \
     do {                                                                                                               \
         const size_t lds = sizeof(float) * (256 / G) * (size_t)ldy;                                                    \
-        spmm_csr_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20), 256, lds, st>>>( \
-            rowptr, colidx, vals, n_rows, x, dim, ldx, act, mask_from, y, ldy, huge);                                  \
+        const int ncb = fused ? split->n_chunks : 0;                                                                   \
+        spmm_csr_kernel<G, IT><<<(unsigned)(ncb + std::min<int64_t>(oea::ceil_div(n_rows, 256 / G), 1 << 20)), 256, lds, st>>>( \
+            rowptr, colidx, vals, n_rows, x, dim, ldx, act, mask_from, y, ldy, huge, sp, ncb);                         \
         if (use_split) {                                                                                               \
             const unsigned gr = (unsigned)oea::ceil_div(split->n_rows, 256 / G);                                       \
-            spmm_zero_rows_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, y, ldy);                      \
-            spmm_chunk_kernel<G, IT><<<(unsigned)split->n_chunks, 256, lds, st>>>(split->chunk_row, split->chunk_e0,   \
-                                                                                  split->chunk_e1, colidx, vals, x, ldx, y, ldy); \
-            spmm_rows_epilogue_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, dim, act, mask_from, y, ldy); \
+            if (!fused) {                                                                                              \
+                spmm_zero_rows_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, y, ldy);                  \
+                spmm_chunk_kernel<G, IT><<<(unsigned)split->n_chunks, 256, lds, st>>>(split->chunk_row, split->chunk_e0, \
+                                                                                      split->chunk_e1, colidx, vals, x, ldx, y, ldy); \
+            }                                                                                                          \
+            spmm_rows_epilogue_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, dim, act, mask_from, y, ldy, \
+                                                                 fused ? split->partials : nullptr, split->row_chunk0); \
         }                                                                                                              \
     } while (0)
     OEA_DISPATCH_LD(ldx, CALL);

@@ -566,22 +566,37 @@ def csr_split(indptr, threshold=768, chunk=512, dev=None, row_range=None):
     rows = np.flatnonzero(lens[lo:hi] > threshold)
     if len(rows) == 0:
         return None
-    c_row, c_e0, c_e1 = [], [], []
+    c_row, c_e0, c_e1, first = [], [], [], []
     for r in rows:
+        first.append(len(c_row))
         for e0 in range(int(indptr[lo + r]), int(indptr[lo + r + 1]), chunk):
             c_row.append(r)
             c_e0.append(e0)
             c_e1.append(min(e0 + chunk, int(indptr[lo + r + 1])))
-    t = [to_ids(np.asarray(a, np.int32), dev) for a in (c_row, c_e0, c_e1, rows)]
-    sp_ = _lib.CsrSplit(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), len(c_row), len(rows), int(threshold))
+    first.append(len(c_row))
+    t = [to_ids(np.asarray(a, np.int32), dev) for a in (c_row, c_e0, c_e1, rows, first)]
+    sp_ = _lib.CsrSplit(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), len(c_row), len(rows), int(threshold),
+                        t[4].data_ptr(), None, 0)
     sp_._keep = t
     return sp_
+
+
+def _split_partials(split, ld, dev):
+    """grow-only buffer for the hub chunks' partial sums (stream-ordered reuse by the calls on this operand)"""
+    need = int(split.n_chunks) * int(ld)
+    if split.partials_floats < need:
+        buf = torch.empty(need, dtype=torch.float32, device=dev)
+        split._partials = buf
+        split.partials, split.partials_floats = buf.data_ptr(), need
+    return split
 
 
 def spmm_csr(rowptr, colidx, vals, x, dim, act=0, mask_from=None, out=None, split=None):
     n_rows = rowptr.numel() - 1
     if out is None:
         out = torch.empty((n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    if split is not None:
+        _split_partials(split, out.shape[1], x.device)
     check(lib().oea_spmm_csr(_p(rowptr), _p(colidx), _p(vals), n_rows, _p(x), dim, x.shape[1], int(act),
                              _p(mask_from), _p(out), out.shape[1], C.byref(split) if split is not None else None,
                              _stream()))
