@@ -164,3 +164,23 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         assert np.array_equal(r0[key], r1[key])
         assert np.linalg.norm(r0[key] - single[key]) <= 1e-3 * np.linalg.norm(single[key])
     assert single["rotate"].dtype == np.float64
+
+
+def test_bench_two_ranks_like_the_driver(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` (the driver's launch line) with both
+    ranks on GPU 0 and gloo collectives (OEA_BENCH_ONE_GPU / OEA_BENCH_BACKEND, bench.py's test hooks): the partitioned
+    step runs through the timed regions and rank 0 prints one well-formed line."""
+    import json
+    env = dict(os.environ, OEA_BENCH_ONE_GPU="1", OEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+           "--repeats", "3"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["roofline"]["launches_timed"] > 0 and j["roofline"]["avg_kernel_us"] > 0 and j["roofline"]["apply_rows_avg_us"] > 0
+    assert j["extra"]["exchange_bytes_per_step_per_rank"] > 0
+    assert j["config"]["parallelism"] == "dp2"
