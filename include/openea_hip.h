@@ -354,6 +354,10 @@ int oea_pair_dots(const float *e1, int32_t ld1, const float *e2, int32_t ld2, in
  * query rows in chunks that fit `ws_bytes`; minimum one 128-row strip).
  * ------------------------------------------------------------------------------------- */
 size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc);
+/* queries == candidates (q == c, the truncated-sampling refresh of one KG's entities against themselves): with a
+ * workspace of this many bytes (0: shape not covered) oea_topk_inner computes only the tiles on and above the diagonal of
+ * S = E E^T and feeds rows and columns from them (bit-identical result: S_ij == S_ji in the k-ordered fmaf chain). */
+size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k);
 int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int64_t nc, int32_t ldc,
                    int32_t dim, int32_t k, const int32_t *id_map, int32_t *out_idx, void *workspace,
                    size_t ws_bytes, void *stream);

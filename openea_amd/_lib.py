@@ -120,6 +120,7 @@ PROTOTYPES = {
     "oea_perm_index": (_u32, [_u32, _u32, _u32]),
     "oea_sample_link_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _u64,
                                             _u64, _u32, _vp, _vp, _vp, _vp, _u64, _vp]),
+    "oea_topk_sym_workspace_bytes": (_sz, [_i64, _i32]),
     "oea_topk_workspace_bytes": (_sz, [_i64, _i64]),
     "oea_topk_inner": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "oea_topk_rows": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),

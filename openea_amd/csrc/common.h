@@ -51,6 +51,10 @@ void gather_packed_rows(const float *qp, int kp, const int32_t *rows, const int3
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
                         int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st);
 
+void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const float *thr, const void *items, int n_items, int nseg,
+                            int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
+                            uint8_t *ccounts, hipStream_t st);
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

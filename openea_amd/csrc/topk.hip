@@ -24,6 +24,8 @@
 
 #include <cmath>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
 //     recomputed with the same k-ordered fmaf chain as the matrix cores and selected by the three-read path.
 // Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
 constexpr int kSample = 2048;          // 2,048 sampled candidates: survivors ~ r N / S +- 1/sqrt(r) (r ~ 71 at k/N = 2 %)
-constexpr int kMaxSeg = 256;
+constexpr int kMaxSeg = 256;              // query-side segments per row
+constexpr int kMaxSegAll = 2304;          // + two candidate-side segments per query tile (symmetric search: T <= 1,100 tiles)
 
 __device__ __forceinline__ float ord2f(uint32_t key) {
     return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
@@ -589,11 +592,14 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    const int32_t *__restrict__ counts,
                                                                    const float *__restrict__ thr, int nseg, int cap, int64_t nc,
                                                                    int k, const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
-                                                                   int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
+                                                                   int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail,
+                                                                   const uint2 *__restrict__ clists, const uint8_t *__restrict__ ccounts,
+                                                                   int T, int ccap) {
+    // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
     __shared__ int hist[kBins];
     __shared__ uint32_t c_key[kCandCap];
     __shared__ int c_col[kCandCap];
-    __shared__ int s_off[kMaxSeg + 1];
+    __shared__ int s_off[kMaxSegAll + 1];
     extern __shared__ uint32_t bitmap[];      // ceil(nc / 32) words (dynamic: 12.5 KB at nc = 100,000 keeps 5 workgroups per CU)
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
@@ -603,23 +609,39 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_bad = 0; s_ncand = 0; }
     __syncthreads();
-    for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
-        const int c = counts[row * nseg + sg];
-        s_off[sg + 1] = c;
-        if (c > cap) s_bad = 1;
+    // segment lengths -> exclusive offsets (block scan: the symmetric search has hundreds of segments per row)
+    const int nst = nseg + T;
+    constexpr int kSegPer = (kMaxSegAll + SEL_THREADS - 1) / SEL_THREADS;
+    int seg_c[kSegPer];
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < kSegPer; ++u) {
+        const int sg = tid * kSegPer + u;
+        int c = 0;
+        if (sg < nseg) {
+            c = counts[row * nseg + sg];
+            if (c > cap) s_bad = 1;
+        } else if (sg < nst) {
+            c = ccounts[row * T + (sg - nseg)];
+            if (c > ccap) s_bad = 1;
+        }
+        seg_c[u] = c;
+        mine += c;
     }
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        s_off[0] = 0;
-        for (int sg = 0; sg < nseg; ++sg) { acc += s_off[sg + 1]; s_off[sg + 1] = acc; }
-        if (acc < k || acc > kPerThread * SEL_THREADS) s_bad = 1;
+    int total_all;
+    int run = block_excl_scan(mine, s_wave, &total_all);
+#pragma unroll
+    for (int u = 0; u < kSegPer; ++u) {
+        const int sg = tid * kSegPer + u;
+        if (sg <= nst) s_off[sg] = run;
+        run += seg_c[u];
     }
+    if (tid == 0 && (total_all < k || total_all > kPerThread * SEL_THREADS)) s_bad = 1;
     const int words = (int)((nc + 31) / 32);
     for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
     for (int w = tid; w < words; w += SEL_THREADS) bitmap[w] = 0u;
     __syncthreads();
-    const int total = s_off[nseg];
+    const int total = s_off[nst];
     bool fail = s_bad != 0;                                      // block-uniform from here on
     if (!fail) {
         float val[kPerThread];
@@ -633,14 +655,20 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
             val[e] = -INFINITY;
             col[e] = -1;
             if (i < total) {
-                int lo_s = 0, hi_s = nseg;                       // s_off[lo_s] <= i < s_off[hi_s]
+                int lo_s = 0, hi_s = nst;                        // s_off[lo_s] <= i < s_off[hi_s]
                 while (hi_s - lo_s > 1) {
                     const int mid = (lo_s + hi_s) >> 1;
                     if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
                 }
-                const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
-                val[e] = vb[at];
-                col[e] = cb[at];
+                if (lo_s < nseg) {
+                    const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
+                    val[e] = vb[at];
+                    col[e] = cb[at];
+                } else {
+                    const uint2 pr = clists[((int64_t)row * T + (lo_s - nseg)) * ccap + (i - s_off[lo_s])];
+                    val[e] = __uint_as_float(pr.x);
+                    col[e] = (int)pr.y;
+                }
                 mx = fmaxf(mx, val[e]);
             }
         }
@@ -854,6 +882,60 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     return p;
 }
 
+// ---- symmetric search (queries == candidates): the tiles on and above the diagonal serve rows AND columns ---------------
+struct SymPlan {
+    bool ok = false;
+    int r = 0, T = 0, L = 0, groups = 0, nseg = 0, cap = 0, ccap = 0, n_items = 0;
+    int64_t stride = 0, ld = 0;
+    size_t off_thr = 0, off_counts = 0, off_ccounts = 0, off_fail = 0, off_nfail = 0, off_items = 0, off_vals = 0, off_cols = 0,
+           off_clists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, total = 0;
+};
+
+static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
+    SymPlan p;
+    if (n < 32768) return p;
+    const double e = (double)k * kSample / (double)n;
+    p.r = (int)(e + 3.5 * std::sqrt(e) + 8.0);
+    const double frac = (double)p.r / kSample;                  // expected survivor fraction of a row
+    const double m_total = frac * (double)n;
+    if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || n > (int64_t)kBitWords * 32) return p;
+    p.T = (int)oea::ceil_div(n, 128);
+    p.groups = 16;                                              // work items per (full) query tile row: L tiles each
+    p.L = std::max(8, (int)oea::ceil_div(p.T, p.groups));
+    p.groups = (int)oea::ceil_div(p.T, p.L);
+    p.nseg = 4 * p.groups;
+    if (p.nseg > kMaxSeg || p.nseg + 2 * p.T >= kMaxSegAll) return p;
+    const double m = frac * p.L * 128.0 / 4.0;                  // per query-side segment (2 wave rows x 2 half-waves share an item)
+    p.cap = ((int)(m * (1.0 + 4.0 / std::sqrt((double)p.r)) + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
+    const double mc = frac * 64.0;                              // per candidate-side segment (the 64 queries of one wave column)
+    p.ccap = ((int)(mc * (1.0 + 4.0 / std::sqrt((double)p.r)) + 6.0 * std::sqrt(mc) + 4.0) + 3) / 4 * 4;
+    if (p.ccap > 248 || (size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
+    int64_t items = 0;
+    for (int qt = 0; qt < p.T; ++qt) items += oea::ceil_div(p.T - qt, p.L);
+    p.n_items = (int)items;
+    p.stride = n / kSample;
+    p.ld = (n + 31) / 32 * 32;
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += a256(bytes); return o; };
+    p.off_thr = take(sizeof(float) * (size_t)n);
+    p.off_counts = take(sizeof(int32_t) * (size_t)n * p.nseg);
+    p.off_ccounts = take((size_t)n * p.T * 2);
+    p.off_fail = take(sizeof(int32_t) * (size_t)n);
+    p.off_nfail = take(256);
+    p.off_items = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
+    p.off_vals = take(sizeof(float) * (size_t)n * p.nseg * p.cap);
+    p.off_cols = take(sizeof(int32_t) * (size_t)n * p.nseg * p.cap);
+    p.off_clists = take(8 * (size_t)n * p.T * 2 * p.ccap);
+    p.off_strip = take(sizeof(float) * (size_t)n * kSample);
+    p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
+    p.off_fbstrip = take(sizeof(float) * (size_t)kFbRows * p.ld);
+    p.off_fbq = take(sizeof(float) * kFbRows * 4096);
+    p.total = off;
+    p.ok = off <= ws_bytes;
+    return p;
+}
+
 // long rows with k well inside the LDS candidate lists take the one-read kernel
 static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int k, const int32_t *id_map, int32_t *out,
                           hipStream_t st) {
@@ -885,6 +967,11 @@ extern "C" {
 size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
     const int64_t ld = (nc + 31) / 32 * 32;
     return (size_t)nq * (size_t)ld * sizeof(float);
+}
+
+size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k) {
+    const SymPlan p = plan_sym(n, k, ~(size_t)0);
+    return p.ok ? p.total : 0;
 }
 
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
@@ -922,6 +1009,62 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         if (rc != OEA_OK) return rc;
     }
     static const bool lists_on = [] { const char *e = getenv("OEA_TOPK_LISTS"); return !(e && e[0] == '0'); }();
+    static const bool sym_on = [] { const char *e = getenv("OEA_TOPK_SYM"); return !(e && e[0] == '0'); }();
+    const bool same = q == c && nq == nc && ldq == ldc;
+    const SymPlan sy = (same && packed && lists_on && sym_on && dim <= 2048) ? plan_sym(nc, k, ws_bytes) : SymPlan();
+    if (sy.ok) {                                    // queries == candidates: the upper triangle's tiles feed rows and columns
+        char *w = static_cast<char *>(workspace);
+        float *thr = reinterpret_cast<float *>(w + sy.off_thr);
+        int32_t *counts = reinterpret_cast<int32_t *>(w + sy.off_counts);
+        uint8_t *ccounts = reinterpret_cast<uint8_t *>(w + sy.off_ccounts);
+        int32_t *fail_rows = reinterpret_cast<int32_t *>(w + sy.off_fail);
+        int32_t *n_fail = reinterpret_cast<int32_t *>(w + sy.off_nfail);
+        int32_t *items_dev = reinterpret_cast<int32_t *>(w + sy.off_items);
+        float *list_vals = reinterpret_cast<float *>(w + sy.off_vals);
+        int32_t *list_cols = reinterpret_cast<int32_t *>(w + sy.off_cols);
+        void *clists = w + sy.off_clists;
+        float *sstrip = reinterpret_cast<float *>(w + sy.off_strip);
+        float *scratch = reinterpret_cast<float *>(w + sy.off_scratch);
+        float *fbstrip = reinterpret_cast<float *>(w + sy.off_fbstrip);
+        float *fbq = reinterpret_cast<float *>(w + sy.off_fbq);
+        OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
+        // work items, longest sweeps first: (query tile, first candidate tile, one past the last, segment group)
+        std::vector<int32_t> items;
+        items.reserve(4 * (size_t)sy.n_items);
+        for (int g = 0; g < sy.groups; ++g)
+            for (int qt = 0; qt < sy.T; ++qt) {
+                const int b = qt + g * sy.L;
+                if (b >= sy.T) break;
+                items.push_back(qt); items.push_back(b); items.push_back(std::min(sy.T, b + sy.L)); items.push_back(g);
+            }
+        OEA_REQUIRE((int)(items.size() / 4) == sy.n_items, "item count");
+        OEA_CHECK_HIP(hipMemcpyAsync(items_dev, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        OEA_CHECK_HIP(hipStreamSynchronize(st));         // `items` lives on this stack frame
+        float *sp = nullptr;
+        int kps = 0;
+        int rc = oea::pack_rows(2, c, kSample, ldc * (int)sy.stride, dim, st, &sp, &kps);
+        if (rc != OEA_OK) return rc;
+        oea::sim_inner_store_packed(qp, nq, sp, kSample, kp, dim, sstrip, kSample, st);
+        kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(nq, 4), 256, 0, st>>>(sstrip, nq, kSample, sy.r, thr);
+        OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
+        // segments no work item writes (the lower triangle's) must read as empty
+        OEA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)nq * sy.nseg, st));
+        OEA_CHECK_HIP(hipMemsetAsync(ccounts, 0, (size_t)nq * sy.T * 2, st));
+        oea::topk_append_sym_packed(qp, nq, kp, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
+                                    sy.ccap, clists, ccounts, st);
+        list_select_kernel<<<(unsigned)nq, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
+            list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
+            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap);
+        gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp, kp, fail_rows, n_fail, fbq);
+        oea::sim_inner_store_packed_gated(fbq, kFbRows, cp, nc, kp, dim, fbstrip, sy.ld, n_fail, st);
+        row_select_indirect_kernel<<<kFbRows, SEL_THREADS, 0, st>>>(fbstrip, nc, sy.ld, k, id_map, out_idx, fail_rows, n_fail);
+        fallback_rows_kernel<<<kFallbackBlocks, SEL_THREADS, 0, st>>>(q, ldq, c, nc, ldc, dim, k, id_map, out_idx, fail_rows, n_fail,
+                                                                    scratch, sy.ld);
+        rc = oea::release_packed_rows(st);
+        if (rc != OEA_OK) return rc;
+        OEA_CHECK_HIP(hipGetLastError());
+        return OEA_OK;
+    }
     const ListPlan lp = (packed && lists_on && dim <= 2048) ? plan_lists(nq, nc, k, ws_bytes) : ListPlan();
     if (lp.ok) {                                    // strip-free path (see above)
         char *w = static_cast<char *>(workspace);
@@ -949,7 +1092,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, st);
             list_select_kernel<<<(unsigned)rows, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
-                                                                      k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail);
+                                                                      k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0);
             // fallback: bulk for the first kFbRows failed rows (gather -> gated tile sweep -> select), slow kernel for the rest
             gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp + r0 * kp, kp, fail_rows, n_fail, fbq);
             oea::sim_inner_store_packed_gated(fbq, kFbRows, cp, nc, kp, dim, fbstrip, lp.ld, n_fail, st);

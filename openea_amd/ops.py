@@ -373,6 +373,12 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     # query row (sample strip + survivor lists); 8 GB covers 100,000 queries in one pass.
     big = nc >= 32768 and nq >= 4096
     ws_bytes = min(full, max((8 << 30) if big else (2 << 30), 128 * ((nc + 31) // 32 * 32) * 4)) if ws_bytes is None else min(full, ws_bytes)
+    if big and q.data_ptr() == c.data_ptr() and nq == nc:
+        # one KG's entities against themselves: the symmetric search (upper-triangle tiles only) wants its lists for ALL rows
+        # at once (~0.3 MB per row at k / n = 2 %); taken when it fits in a third of the free memory
+        need = int(lib().oea_topk_sym_workspace_bytes(nq, k))
+        if need and need <= torch.cuda.mem_get_info(q.device)[0] // 3:
+            ws_bytes = max(ws_bytes, need)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     out = torch.empty((nq, k), dtype=torch.int32, device=q.device)
     check(lib().oea_topk_inner(_p(q), nq, q.shape[1], _p(c), nc, c.shape[1], dim, k, _p(id_map), _p(out),

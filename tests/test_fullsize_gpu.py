@@ -172,3 +172,22 @@ def test_graph_operators_100k_shape(ops):
         a = np.exp(lg - lg.max())
         a /= a.sum()
         np.testing.assert_allclose(o1h[r], a @ xh[ec[e]], rtol=1e-4, atol=2e-5)
+
+
+def test_symmetric_neighbour_search_equals_general_path(ops):
+    """queries == candidates (q is c): only the tiles on and above the diagonal are computed and feed rows and columns
+    (topk_append_sym_kernel); the result equals the general list path's (a copy of the table as candidates) bit for bit,
+    at a size with several work items per query tile and a ragged last tile, and equals the oracle on sampled rows."""
+    from oracle import cport
+    rng = np.random.RandomState(7)
+    n, d, k = 40100, 64, 800
+    assert ops.lib().oea_topk_sym_workspace_bytes(n, k) > 0
+    emb = _unit_rows(rng, n, d)
+    emb[5] = emb[4]                                                  # duplicate rows: ties across the diagonal
+    emb[n - 1] = emb[0]
+    t = ops.to_table(emb)
+    sym = ops.topk_inner(t, t, d, k).cpu().numpy()
+    gen = ops.topk_inner(t, t.clone(), d, k).cpu().numpy()
+    assert np.array_equal(sym, gen)
+    rows = np.concatenate([[0, 4, 5, n - 1], rng.choice(n, 12, replace=False)])
+    assert np.array_equal(sym[rows], cport.topk_inner(emb[rows], emb, k))
