@@ -23,8 +23,12 @@ KNN="python $R/tools/_exp/knn_time.py"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/knn_stats -- $KNN > $OUT/knn_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/knn_fetch -- $KNN > $OUT/knn_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knn_write -- $KNN > $OUT/knn_write.log 2>&1
-OEA_TOPK_LISTS=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/knnstrip_fetch -- $KNN > $OUT/knnstrip_fetch.log 2>&1
-OEA_TOPK_LISTS=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knnstrip_write -- $KNN > $OUT/knnstrip_write.log 2>&1
+# the general (queries != candidates) list path: OEA_TOPK_SYM=0; the strip path's traffic is in profiles/r02_pmc_hbm_traffic_knn_strip.csv
+OEA_TOPK_SYM=0 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/knngen_fetch -- $KNN > $OUT/knngen_fetch.log 2>&1
+OEA_TOPK_SYM=0 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/knngen_write -- $KNN > $OUT/knngen_write.log 2>&1
+# evaluation sweep at 70,000^2 x 100: traffic of the rank kernel
+LEGS=eval70k timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/eval70k_fetch -- python $R/tools/profile_legs.py > $OUT/eval70k_fetch.log 2>&1
+LEGS=eval70k timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/eval70k_write -- python $R/tools/profile_legs.py > $OUT/eval70k_write.log 2>&1
 # evaluation (with / without CSLS at 10,500^2 and 70,000^2), GNN legs
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/csls -- python $R/tools/_exp/csls_time.py > $OUT/csls.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs -- python $R/tools/profile_legs.py > $OUT/legs.log 2>&1

@@ -63,7 +63,8 @@ def main():
             open(os.path.join(prof, "%s_%s" % (name, log.replace(".log", "_stdout.txt"))), "w").writelines([note] + lines[-40:])
     workloads = {"": ("EN-FR-15K-V1", 75, 5000, 10), "100k": ("EN-FR-100K-V1", 100, 20000, 10)}
     for suffix, tag in (("", "pmc_hbm_traffic"), ("100k", "pmc_hbm_traffic_100k"), ("knn", "pmc_hbm_traffic_knn_lists"),
-                        ("knnstrip", "pmc_hbm_traffic_knn_strip")):
+                        ("knnstrip", "pmc_hbm_traffic_knn_strip"), ("knngen", "pmc_hbm_traffic_knn_general"),
+                        ("eval70k", "pmc_hbm_traffic_eval70k")):
         fdir = os.path.join(src, "pmc_fetch" + suffix if suffix in ("", "100k") else suffix + "_fetch")
         wdir = os.path.join(src, "pmc_write" + suffix if suffix in ("", "100k") else suffix + "_write")
         if not os.path.isdir(fdir):
