@@ -49,11 +49,12 @@ int topk_append_chunks(int64_t nq, int64_t nc);
 int kth_value(const float *strip, int64_t rows, int sample, int r, float *thr, hipStream_t st);          // topk.hip
 void gather_packed_rows(const float *qp, int kp, const int32_t *rows, const int32_t *n_rows, float *dst, hipStream_t st);   // <= 128 rows
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
-                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st);
+                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill, int sp_cap,
+                        hipStream_t st);
 
 void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const float *thr, const void *items, int n_items, int nseg,
                             int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
-                            uint8_t *ccounts, hipStream_t st);
+                            uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

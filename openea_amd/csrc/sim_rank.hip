@@ -404,13 +404,13 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
 // list segment PRIVATE to the lane: a query's survivors of chunk y come from the two wave rows (wm) and the two half-waves
 // that share it, hence 4 * gridDim.y segments of `cap` entries per query, each in ascending column order.  No atomics, no
 // N x N strip in HBM.  Values and columns go to two arrays (one dword store each from the register that holds them) at a
-// 32-bit byte offset from a wave-uniform base.  counts[q * nseg + seg] may exceed cap: the entries past cap were dropped
-// and the selection falls back for that query.
+// 32-bit byte offset from a wave-uniform base.  counts[q * nseg + seg] may exceed cap: the entries past cap went to the
+// query's spill list (one global atomic each; rare unless the neighbours of a row crowd into one candidate range).
 template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr, int tiles_per_chunk, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols,
-    int32_t *__restrict__ counts) {
+    int32_t *__restrict__ counts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -444,9 +444,16 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
                 for (int tn = 0; tn < 2; ++tn) {
                     const float v = acc[tm][tn][r];
                     if (v >= th[tn] && j < j_end) {
+                        // the store path stays branch-free: entries from index cap - 1 on land in the segment's LAST slot
+                        // (scratch: the select reads min(count, cap - 1) entries) and go to the row's spill list, one global
+                        // atomic each -- rare unless the neighbours of a row crowd into one candidate range
                         const uint32_t at = min(boff[tn], blast[tn]);
                         *reinterpret_cast<float *>(vbase + at) = v;
                         *reinterpret_cast<int32_t *>(cbase + at) = j;
+                        if (boff[tn] >= blast[tn]) {
+                            const int pos = atomicAdd(spill_cnt + qi[tn], 1);
+                            if (pos < sp_cap) spill[qi[tn] * sp_cap + pos] = make_uint2(__float_as_uint(v), (uint32_t)j);
+                        }
                         boff[tn] += 4u;
                     }
                 }
@@ -481,7 +488,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
     const float *__restrict__ e, int64_t n, int ld, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     int nseg, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols, int32_t *__restrict__ counts, int T, int ccap,
-    uint2 *__restrict__ clists, uint8_t *__restrict__ ccounts) {
+    uint2 *__restrict__ clists, uint8_t *__restrict__ ccounts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
@@ -533,22 +540,30 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
                     for (int tn = 0; tn < 2; ++tn) {
                         const float v = acc[tm][tn][r];
                         if (v >= th[tn] && jin) {
-                            const uint32_t at = min(boff[tn], blast[tn]);
+                            const uint32_t at = min(boff[tn], blast[tn]);           // last slot = scratch, see topk_append_kernel
                             *reinterpret_cast<float *>(vbase + at) = v;
                             *reinterpret_cast<int32_t *>(cbase + at) = j;
+                            if (boff[tn] >= blast[tn]) {
+                                const int pos = atomicAdd(spill_cnt + qi[tn], 1);
+                                if (pos < sp_cap) spill[qi[tn] * sp_cap + pos] = make_uint2(__float_as_uint(v), (uint32_t)j);
+                            }
                             boff[tn] += 4u;
                         }
                         const bool pc = v >= tc && qi[tn] < n;       // tc = +inf on the diagonal and past the last row
                         const unsigned long long bal = __ballot(pc);
                         const uint32_t bh = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                         const int slot = cnt + __popc(bh & below);
-                        if (pc && slot < ccap) seg[slot] = make_uint2(__float_as_uint(v), (uint32_t)qi[tn]);
+                        if (pc) seg[min(slot, ccap - 1)] = make_uint2(__float_as_uint(v), (uint32_t)qi[tn]);
+                        if (pc && slot >= ccap - 1) {                 // last slot = scratch; row j's spill list
+                            const int pos = atomicAdd(spill_cnt + j, 1);
+                            if (pos < sp_cap) spill[(int64_t)j * sp_cap + pos] = make_uint2(__float_as_uint(v), (uint32_t)qi[tn]);
+                        }
                         cnt += __popc(bh);
                     }
                     if (l32 == tm * 16 + r) my_cnt = cnt;
                 }
             }
-            // lengths above ccap saturate at 255: the select sees count > ccap and sends the row to the fallback
+            // lengths saturate at 255; the select reads min(length, ccap - 1) entries, the rest sits in the row's spill list
             if (offdiag && my_j < n) ccounts[(my_j * T + qt) * 2 + wn] = (uint8_t)min(my_cnt, 255);
         });
 #pragma unroll
@@ -1299,16 +1314,18 @@ int topk_append_chunks(int64_t nq, int64_t nc) {
 }
 void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const float *thr, const void *items, int n_items, int nseg,
                             int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
-                            uint8_t *ccounts, hipStream_t st) {
+                            uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st) {
     topk_append_sym_kernel<true><<<(unsigned)n_items, 256, 0, st>>>(ep, n, kp, dim, thr, static_cast<const int4 *>(items), nseg, cap,
                                                                     list_vals, list_cols, counts, T, ccap,
-                                                                    static_cast<uint2 *>(clists), ccounts);
+                                                                    static_cast<uint2 *>(clists), ccounts, spill_cnt,
+                                                                    static_cast<uint2 *>(spill), sp_cap);
 }
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
-                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, hipStream_t st) {
+                        int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill, int sp_cap,
+                        hipStream_t st) {
     const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);       // chunks planned by topk_append_chunks
     topk_append_kernel<true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
-        qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts);
+        qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, static_cast<uint2 *>(spill), sp_cap);
 }
 }  // namespace oea
 

@@ -549,6 +549,7 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
 // Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
 constexpr int kSample = 2048;          // 2,048 sampled candidates: survivors ~ r N / S +- 1/sqrt(r) (r ~ 71 at k/N = 2 %)
 constexpr int kMaxSeg = 256;              // query-side segments per row
+constexpr int kSpillCap = 512;             // entries of a row's spill list (appends that found their segment full)
 constexpr int kMaxSegAll = 2304;          // + two candidate-side segments per query tile (symmetric search: T <= 1,100 tiles)
 
 __device__ __forceinline__ float ord2f(uint32_t key) {
@@ -594,7 +595,8 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    int k, const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
                                                                    int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail,
                                                                    const uint2 *__restrict__ clists, const uint8_t *__restrict__ ccounts,
-                                                                   int T, int ccap) {
+                                                                   int T, int ccap, const int32_t *__restrict__ spill_cnt,
+                                                                   const uint2 *__restrict__ spill) {
     // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
     __shared__ int hist[kBins];
     __shared__ uint32_t c_key[kCandCap];
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     if (tid == 0) { s_bad = 0; s_ncand = 0; }
     __syncthreads();
     // segment lengths -> exclusive offsets (block scan: the symmetric search has hundreds of segments per row)
-    const int nst = nseg + T;
+    // + the row's spill list as the last segment (entries whose own segment was full)
+    const int nst = nseg + T + 1;
     constexpr int kSegPer = (kMaxSegAll + SEL_THREADS - 1) / SEL_THREADS;
     int seg_c[kSegPer];
     int mine = 0;
@@ -619,11 +622,12 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         const int sg = tid * kSegPer + u;
         int c = 0;
         if (sg < nseg) {
-            c = counts[row * nseg + sg];
-            if (c > cap) s_bad = 1;
+            c = min(counts[row * nseg + sg], cap - 1);             // the last slot of a segment is scratch (topk_append_kernel)
+        } else if (sg < nseg + T) {
+            c = min((int)ccounts[row * T + (sg - nseg)], ccap - 1);
         } else if (sg < nst) {
-            c = ccounts[row * T + (sg - nseg)];
-            if (c > ccap) s_bad = 1;
+            c = spill_cnt[row];
+            if (c > kSpillCap) s_bad = 1;                        // the spill list overflowed as well: strip path
         }
         seg_c[u] = c;
         mine += c;
@@ -664,6 +668,10 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                     const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
                     val[e] = vb[at];
                     col[e] = cb[at];
+                } else if (lo_s == nst - 1) {
+                    const uint2 pr = spill[row * kSpillCap + (i - s_off[lo_s])];
+                    val[e] = __uint_as_float(pr.x);
+                    col[e] = (int)pr.y;
                 } else {
                     const uint2 pr = clists[((int64_t)row * T + (lo_s - nseg)) * ccap + (i - s_off[lo_s])];
                     val[e] = __uint_as_float(pr.x);
@@ -830,7 +838,8 @@ struct ListPlan {
     bool ok = false;
     int r = 0, cap = 0, chunks = 0, nseg = 0;
     int64_t rows_per = 0, stride = 0, ld = 0;
-    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, cols_off = 0;
+    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, cols_off = 0,
+           off_spcnt = 0, off_spill = 0;
 };
 
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
@@ -856,7 +865,7 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
         if (nseg > kMaxSeg) return p;
         const double m = m_total / nseg;
         const int cap = ((int)(m + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
-        const size_t per_row = sizeof(float) * kSample + (size_t)nseg * cap * 8 + (size_t)nseg * 4 + 4 + 4 + 16;
+        const size_t per_row = sizeof(float) * kSample + (size_t)nseg * cap * 8 + (size_t)nseg * 4 + 4 + 4 + 16 + 4 + 8 * (size_t)kSpillCap;
         if ((size_t)128 * nseg * cap * 4 >= ((size_t)1 << 31)) return p;          // 32-bit byte offsets inside a query tile
         int64_t fit = (int64_t)((ws_bytes - fixed) / per_row) / 128 * 128;
         if (fit >= nq) fit = nq;
@@ -872,6 +881,8 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     p.off_counts = take(sizeof(int32_t) * (size_t)p.rows_per * p.nseg);
     p.off_fail = take(sizeof(int32_t) * (size_t)p.rows_per);
     p.off_nfail = take(256);
+    p.off_spcnt = take(sizeof(int32_t) * (size_t)p.rows_per);
+    p.off_spill = take(8 * (size_t)p.rows_per * kSpillCap);
     p.cols_off = a256((size_t)p.rows_per * p.nseg * p.cap * 4);
     p.off_lists = take(2 * p.cols_off);
     p.off_strip = take(sizeof(float) * (size_t)p.rows_per * kSample);
@@ -888,7 +899,7 @@ struct SymPlan {
     int r = 0, T = 0, L = 0, groups = 0, nseg = 0, cap = 0, ccap = 0, n_items = 0;
     int64_t stride = 0, ld = 0;
     size_t off_thr = 0, off_counts = 0, off_ccounts = 0, off_fail = 0, off_nfail = 0, off_items = 0, off_vals = 0, off_cols = 0,
-           off_clists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, total = 0;
+           off_clists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, off_spcnt = 0, off_spill = 0, total = 0;
 };
 
 static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
@@ -904,7 +915,7 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     p.L = std::max(8, (int)oea::ceil_div(p.T, p.groups));
     p.groups = (int)oea::ceil_div(p.T, p.L);
     p.nseg = 4 * p.groups;
-    if (p.nseg > kMaxSeg || p.nseg + 2 * p.T >= kMaxSegAll) return p;
+    if (p.nseg > kMaxSeg || p.nseg + 2 * p.T + 1 >= kMaxSegAll) return p;
     const double m = frac * p.L * 128.0 / 4.0;                  // per query-side segment (2 wave rows x 2 half-waves share an item)
     p.cap = ((int)(m * (1.0 + 4.0 / std::sqrt((double)p.r)) + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
     const double mc = frac * 64.0;                              // per candidate-side segment (the 64 queries of one wave column)
@@ -924,6 +935,8 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     p.off_fail = take(sizeof(int32_t) * (size_t)n);
     p.off_nfail = take(256);
     p.off_items = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
+    p.off_spcnt = take(sizeof(int32_t) * (size_t)n);
+    p.off_spill = take(8 * (size_t)n * kSpillCap);
     p.off_vals = take(sizeof(float) * (size_t)n * p.nseg * p.cap);
     p.off_cols = take(sizeof(int32_t) * (size_t)n * p.nseg * p.cap);
     p.off_clists = take(8 * (size_t)n * p.T * 2 * p.ccap);
@@ -943,6 +956,78 @@ static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld
         row_select_sampled_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
     else
         row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+}
+
+// item (g, qt) = candidate tiles [qt + g L, min(T, qt + (g + 1) L)) of query tile qt; group g holds the items of the query
+// tiles with qt + g L < T, numbered after the groups before it
+__global__ void sym_items_kernel(int T, int L, int groups, int4 *__restrict__ items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * T) return;
+    const int g = i / T, qt = i - g * T;
+    const int b = qt + g * L;
+    if (b >= T) return;
+    int base = 0;
+    for (int h = 0; h < g; ++h) base += max(0, T - h * L);
+    items[base + qt] = make_int4(qt, b, min(T, b + L), g);
+}
+
+// ---- rows the list select gave up on: redone through the strip path, in batches -------------------------------------------
+// (overflowed segments -- trained embeddings cluster: a row's neighbours crowd into a few candidate ranges -- fewer than k
+// survivors, tie-heavy rows.)  The survivor lists are dead once list_select_kernel has run, so their storage holds the
+// gathered packed query rows, the similarity strip of a batch and its selected columns.  One host read of the failure
+// count (the only synchronisation of the search); the work is proportional to the failed rows: 0.4 us per row at 100,000
+// candidates, against ~80 us per row of the per-row kernel this replaces.
+__global__ void gather_rows_list_kernel(const float *__restrict__ qp, int kp, const int32_t *__restrict__ rows, int n, int n_pad,
+                                        float *__restrict__ dst) {
+    const int cpr = kp / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n_pad * cpr; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / cpr), c = (int)(i - (int64_t)f * cpr);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < n) v = oea::ld4(qp + (int64_t)rows[f] * kp + 4 * c);
+        oea::st4(dst + (int64_t)f * kp + 4 * c, v);
+    }
+}
+__global__ void scatter_selected_kernel(const int32_t *__restrict__ sel, int k, const int32_t *__restrict__ rows, int n,
+                                        int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)n * k; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i / k);
+        out[(int64_t)rows[f] * k + (i - (int64_t)f * k)] = sel[i];
+    }
+}
+
+static int redo_failed_rows(const float *qp, int kp, const float *cp, int64_t nc, int dim, int k, const int32_t *id_map, int32_t *out,
+                            const int32_t *fail_rows, const int32_t *n_fail_dev, void *region, size_t region_bytes, int64_t ld,
+                            hipStream_t st) {
+    int32_t nf = 0;
+    OEA_CHECK_HIP(hipMemcpyAsync(&nf, n_fail_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    OEA_CHECK_HIP(hipStreamSynchronize(st));
+    static const bool dbg = getenv("OEA_TOPK_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[oea_topk_inner] rows redone through the strip path: %d\n", nf);
+    if (nf <= 0) return OEA_OK;
+    const size_t per_row = sizeof(float) * ((size_t)kp + (size_t)ld) + sizeof(int32_t) * (size_t)k;
+    int64_t batch = (int64_t)(region_bytes / per_row) / 128 * 128;
+    batch = std::min<int64_t>(batch, 16384);
+    OEA_REQUIRE(batch >= 128, "list storage smaller than one 128-row fallback batch");
+    char *w = static_cast<char *>(region);
+    float *gq = reinterpret_cast<float *>(w);
+    int32_t *sel = reinterpret_cast<int32_t *>(w + sizeof(float) * (size_t)batch * kp);
+    float *strip = reinterpret_cast<float *>(w + sizeof(float) * (size_t)batch * kp + (sizeof(int32_t) * (size_t)batch * k + 255) / 256 * 256);
+    // (the three areas fit: batch * per_row <= region_bytes, the 256-byte round-up is inside the slack of the /128*128)
+    if (sizeof(float) * (size_t)batch * kp + (sizeof(int32_t) * (size_t)batch * k + 255) / 256 * 256 + sizeof(float) * (size_t)batch * ld > region_bytes)
+        batch -= 128;
+    OEA_REQUIRE(batch >= 128, "list storage smaller than one 128-row fallback batch");
+    for (int64_t b0 = 0; b0 < nf; b0 += batch) {
+        const int cnt = (int)std::min<int64_t>(batch, nf - b0);
+        const int cnt_pad = (cnt + 127) / 128 * 128;
+        gather_rows_list_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div((int64_t)cnt_pad * (kp / 4), 256), 4096), 256, 0, st>>>(
+            qp, kp, fail_rows + b0, cnt, cnt_pad, gq);
+        oea::sim_inner_store_packed(gq, cnt, cp, nc, kp, dim, strip, ld, st);
+        launch_select(strip, cnt, nc, ld, k, id_map, sel, st);
+        scatter_selected_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div((int64_t)cnt * k, 256), 8192), 256, 0, st>>>(
+            sel, k, fail_rows + b0, cnt, out);
+    }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
 }
 
 }  // namespace
@@ -1023,23 +1108,16 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         float *list_vals = reinterpret_cast<float *>(w + sy.off_vals);
         int32_t *list_cols = reinterpret_cast<int32_t *>(w + sy.off_cols);
         void *clists = w + sy.off_clists;
+        int32_t *spill_cnt = reinterpret_cast<int32_t *>(w + sy.off_spcnt);
+        void *spill = w + sy.off_spill;
         float *sstrip = reinterpret_cast<float *>(w + sy.off_strip);
         float *scratch = reinterpret_cast<float *>(w + sy.off_scratch);
         float *fbstrip = reinterpret_cast<float *>(w + sy.off_fbstrip);
         float *fbq = reinterpret_cast<float *>(w + sy.off_fbq);
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
-        // work items, longest sweeps first: (query tile, first candidate tile, one past the last, segment group)
-        std::vector<int32_t> items;
-        items.reserve(4 * (size_t)sy.n_items);
-        for (int g = 0; g < sy.groups; ++g)
-            for (int qt = 0; qt < sy.T; ++qt) {
-                const int b = qt + g * sy.L;
-                if (b >= sy.T) break;
-                items.push_back(qt); items.push_back(b); items.push_back(std::min(sy.T, b + sy.L)); items.push_back(g);
-            }
-        OEA_REQUIRE((int)(items.size() / 4) == sy.n_items, "item count");
-        OEA_CHECK_HIP(hipMemcpyAsync(items_dev, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        OEA_CHECK_HIP(hipStreamSynchronize(st));         // `items` lives on this stack frame
+        // work items, full-length sweeps first: (query tile, first candidate tile, one past the last, segment group)
+        sym_items_kernel<<<(unsigned)oea::ceil_div((int64_t)sy.groups * sy.T, 256), 256, 0, st>>>(sy.T, sy.L, sy.groups,
+                                                                                              reinterpret_cast<int4 *>(items_dev));
         float *sp = nullptr;
         int kps = 0;
         int rc = oea::pack_rows(2, c, kSample, ldc * (int)sy.stride, dim, st, &sp, &kps);
@@ -1050,16 +1128,16 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         // segments no work item writes (the lower triangle's) must read as empty
         OEA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)nq * sy.nseg, st));
         OEA_CHECK_HIP(hipMemsetAsync(ccounts, 0, (size_t)nq * sy.T * 2, st));
+        OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)nq, st));
         oea::topk_append_sym_packed(qp, nq, kp, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
-                                    sy.ccap, clists, ccounts, st);
+                                    sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, st);
         list_select_kernel<<<(unsigned)nq, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
             list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
-            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap);
-        gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp, kp, fail_rows, n_fail, fbq);
-        oea::sim_inner_store_packed_gated(fbq, kFbRows, cp, nc, kp, dim, fbstrip, sy.ld, n_fail, st);
-        row_select_indirect_kernel<<<kFbRows, SEL_THREADS, 0, st>>>(fbstrip, nc, sy.ld, k, id_map, out_idx, fail_rows, n_fail);
-        fallback_rows_kernel<<<kFallbackBlocks, SEL_THREADS, 0, st>>>(q, ldq, c, nc, ldc, dim, k, id_map, out_idx, fail_rows, n_fail,
-                                                                    scratch, sy.ld);
+            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill));
+        rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
+                              8 * (size_t)nq * sy.T * 2 * sy.ccap, sy.ld, st);
+        if (rc != OEA_OK) return rc;
+        (void)scratch; (void)fbstrip; (void)fbq;
         rc = oea::release_packed_rows(st);
         if (rc != OEA_OK) return rc;
         OEA_CHECK_HIP(hipGetLastError());
@@ -1075,9 +1153,8 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         float *list_vals = reinterpret_cast<float *>(w + lp.off_lists);
         int32_t *list_cols = reinterpret_cast<int32_t *>(w + lp.off_lists + lp.cols_off);
         float *sstrip = reinterpret_cast<float *>(w + lp.off_strip);
-        float *scratch = reinterpret_cast<float *>(w + lp.off_scratch);
-        float *fbstrip = reinterpret_cast<float *>(w + lp.off_fbstrip);
-        float *fbq = reinterpret_cast<float *>(w + lp.off_fbq);
+        int32_t *spill_cnt = reinterpret_cast<int32_t *>(w + lp.off_spcnt);
+        void *spill = w + lp.off_spill;
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
         float *sp = nullptr;
         int kps = 0;
@@ -1089,17 +1166,17 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
-            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, st);
+            OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)rows, st));
+            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, spill_cnt,
+                                    spill, kSpillCap, st);
             list_select_kernel<<<(unsigned)rows, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
-                                                                      k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0);
-            // fallback: bulk for the first kFbRows failed rows (gather -> gated tile sweep -> select), slow kernel for the rest
-            gather_fail_rows_kernel<<<32, 256, 0, st>>>(qp + r0 * kp, kp, fail_rows, n_fail, fbq);
-            oea::sim_inner_store_packed_gated(fbq, kFbRows, cp, nc, kp, dim, fbstrip, lp.ld, n_fail, st);
-            row_select_indirect_kernel<<<kFbRows, SEL_THREADS, 0, st>>>(fbstrip, nc, lp.ld, k, id_map, out_idx + r0 * (int64_t)k,
-                                                                       fail_rows, n_fail);
-            fallback_rows_kernel<<<kFallbackBlocks, SEL_THREADS, 0, st>>>(q + r0 * ldq, ldq, c, nc, ldc, dim, k, id_map,
-                                                                        out_idx + r0 * (int64_t)k, fail_rows, n_fail, scratch, lp.ld);
+                                                                      k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
+                                                                      spill_cnt, static_cast<const uint2 *>(spill));
+            // rows the select gave up on: through the strip path, in batches, inside the (now dead) list storage
+            rc = redo_failed_rows(qp + r0 * kp, kp, cp, nc, dim, k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, list_vals,
+                                  2 * lp.cols_off, lp.ld, st);
+            if (rc != OEA_OK) return rc;
         }
         rc = oea::release_packed_rows(st);
         if (rc != OEA_OK) return rc;
