@@ -974,36 +974,42 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
-    __shared__ int ccnt_l[TILE];                                   // survivors of the current candidate tile, per candidate
-    const int nqt = (int)gridDim.x, qt = (int)blockIdx.x;          // candidate j owns nqt segments of ccap: one per query tile
+    // candidate j owns 2 * nqt segments of ccap values: one per (query tile, wave column) -- written by ONE wave, whose
+    // half-waves hold the same candidate for 32 queries each: slots = prefix counts of a wave ballot (no atomics, no barrier;
+    // the first version took a returning LDS atomic per survivor between two barriers per tile)
+    const int nqt = (int)gridDim.x, qt = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
     const int64_t q0 = (int64_t)blockIdx.x * TILE;
     const int64_t nct = (nc + TILE - 1) / TILE;
     const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
     const int nseg = 4 * (int)gridDim.y;
-    const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + (lane >> 5);
+    const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + half;
     float th[2];
     uint32_t boff[2], bbeg[2], blast[2];
     int64_t qi[2];
     char *__restrict__ vbase = reinterpret_cast<char *>(qlists + q0 * nseg * (int64_t)cap);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
-        const int ql = wn * 64 + tn * 32 + (lane & 31);
+        const int ql = wn * 64 + tn * 32 + l32;
         qi[tn] = q0 + ql;
         th[tn] = qi[tn] < nq ? thr_q[qi[tn]] : INFINITY;
         bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
         blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);
     }
+    const int jl0 = wm * 64 + 4 * half;
+    const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);     // lane l32 = tm * 16 + r looks after that candidate
+    const uint32_t below = (1u << l32) - 1u;
     run_tiles<PACKED>(
         c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
         [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
         [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * TILE;
-            const int jl0 = wm * 64 + 4 * (lane >> 5);
-            if (tid < TILE) ccnt_l[tid] = 0;
-            __syncthreads();                                     // the epilogue is reached by the whole workgroup together
+            const int64_t my_j = c0 + my_jl;
+            const float my_tc = my_j < nc ? thr_c[my_j] : INFINITY;
+            int my_cnt = 0;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -1011,7 +1017,9 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
                     const int jl = jl0 + tm * 32 + (r & 3) + 8 * (r >> 2);
                     const int j = (int)c0 + jl;
                     const bool jin = j < nc;
-                    const float tc = jin ? thr_c[j] : INFINITY;
+                    const float tc = __shfl(my_tc, (lane & 32) + tm * 16 + r, 64);
+                    float *__restrict__ seg = clists + (((int64_t)j * nqt + qt) * 2 + wn) * ccap;
+                    int cnt = 0;
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         const float v = acc[tm][tn][r];
@@ -1019,15 +1027,17 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
                             *reinterpret_cast<float *>(vbase + min(boff[tn], blast[tn])) = v;
                             boff[tn] += 4u;
                         }
-                        if (v >= tc && qi[tn] < nq) {             // an LDS counter hands out the slot: no global round trip
-                            const int pos = atomicAdd(&ccnt_l[jl], 1);
-                            if (pos < ccap) clists[((int64_t)j * nqt + qt) * ccap + pos] = v;
-                        }
+                        const bool pc = v >= tc && qi[tn] < nq;      // tc = +inf past the last candidate
+                        const unsigned long long bal = __ballot(pc);
+                        const uint32_t bh = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                        const int slot = cnt + __popc(bh & below);
+                        if (pc && slot < ccap) seg[slot] = v;
+                        cnt += __popc(bh);
                     }
+                    if (l32 == tm * 16 + r) my_cnt = cnt;
                 }
             }
-            __syncthreads();
-            if (tid < TILE && c0 + tid < nc) ccounts[(c0 + tid) * nqt + qt] = ccnt_l[tid];
+            if (my_j < nc) ccounts[(my_j * nqt + qt) * 2 + wn] = my_cnt;
         });
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -1035,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
 }
 
 constexpr int kMeanRegs = 16;                 // list values per lane: lists of up to 1,024 survivors
-constexpr int kMeanSeg = 1024;               // segments per list (rows: 4 * chunks; columns: one per query tile)
+constexpr int kMeanSeg = 2048;               // segments per list (rows: 4 * chunks; columns: two per query tile)
 
 // mean of the k largest of `cnt` values held kMeanRegs per lane (-inf padded): k rounds of wave-wide maximum, summed in
 // descending order -- the arithmetic of row_topk_mean_kernel
@@ -1077,10 +1087,25 @@ __global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__rest
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    if (lane == 0) {
-        int acc = 0;
-        off[0] = 0;
-        for (int sg = 0; sg < nseg; ++sg) { acc += off[sg + 1]; off[sg + 1] = acc; }
+    {   // lengths -> offsets: every lane scans a contiguous run of segments, the runs are chained by a wave scan
+        const int per = (nseg + 63) >> 6;
+        int mine = 0;
+        for (int u = 0; u < per; ++u) {
+            const int sg = lane * per + u;
+            if (sg < nseg) mine += off[sg + 1];
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int run = incl - mine;
+        for (int u = 0; u < per; ++u) {
+            const int sg = lane * per + u;
+            if (sg < nseg) { run += off[sg + 1]; off[sg + 1] = run; }
+        }
+        if (lane == 0) off[0] = 0;
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -1260,8 +1285,8 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     // the threshold is the r-th of a sample: the survivor count of a row scales with a factor of relative spread 1 / sqrt(r)
     // COMMON to its segments, on top of each segment's own sqrt(m) noise
     p.nqt = (int)oea::ceil_div(n1, TILE);
-    if (p.nqt > kMeanSeg) return p;
-    const double ms = m1 / p.nseg, mc = m2 / p.nqt;
+    if (2 * p.nqt > kMeanSeg) return p;
+    const double ms = m1 / p.nseg, mc = m2 / (2 * p.nqt);        // column lists: one segment per (query tile, wave column)
     p.cap = ((int)(ms * (1.0 + 5.0 / std::sqrt((double)p.r1)) + 8.0 * std::sqrt(ms) + 16.0) + 7) / 8 * 8;
     p.ccap = ((int)(mc * (1.0 + 5.0 / std::sqrt((double)p.r2)) + 8.0 * std::sqrt(mc) + 8.0) + 3) / 4 * 4;
     if ((size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
@@ -1270,10 +1295,10 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     p.off_thr1 = take(4 * (size_t)n1); p.off_thr2 = take(4 * (size_t)n2);
-    p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2 * p.nqt);
+    p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2 * 2 * p.nqt);
     p.off_fail1 = take(4 * (size_t)n1); p.off_fail2 = take(4 * (size_t)n2); p.off_nfail = take(256);
     p.off_qlists = take(4 * (size_t)n1 * p.nseg * p.cap);
-    p.off_clists = take(4 * (size_t)n2 * p.nqt * p.ccap);
+    p.off_clists = take(4 * (size_t)n2 * 2 * p.nqt * p.ccap);
     // sample strips; the fallback strip [kCslsFb, max ld] reuses the space after the thresholds are taken
     p.off_strip = take(4 * std::max<size_t>((size_t)std::max(n1, n2) * p.sample, (size_t)kCslsFb * std::max(p.ld1, p.ld2)));
     p.off_fbq = take(4 * (size_t)kCslsFb * 4096);
@@ -1495,7 +1520,7 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     csls_append_kernel<true><<<dim3((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks), 256, 0, st>>>(
         p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt);
     list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail);
-    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, p.nqt, p.ccap, n2, k, c_out, fail2, nfail + 1);
+    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2, nfail + 1);
     // fallbacks (normally empty): bulk for the first kCslsFb failed rows / columns, slow kernel for the rest
     oea::gather_packed_rows(p1.p, kp, fail1, nfail, fbq, st);
     sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), 1), 256, 0, st>>>(fbq, kCslsFb, kp, p2.p, n2, kp, dim, strip, p.ld2, nfail);

@@ -544,9 +544,10 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_sampled_kernel(const f
 //     the nq x nc strip is never written (it was 2 x 40 GB of traffic at 100,000 x 100,000);
 // (3) list_select_kernel picks the exact top-k by (value desc, column asc) among a query's survivors in LDS and writes
 //     them in ascending column order (bitonic sort of the k selected columns);
-// (4) queries whose lists overflowed, fell short of k or are tie-heavy are redone by fallback_rows_kernel: the row is
-//     recomputed with the same k-ordered fmaf chain as the matrix cores and selected by the three-read path.
-// Everything is enqueued without a host round trip; the result equals the strip path's bit for bit.
+// (4) an append that finds its segment full goes to the row's spill list (kSpillCap entries, one global atomic each);
+// (5) queries the select still gives up on (spill list full, fewer than k survivors, tie-heavy) are redone through the strip
+//     path in batches inside the dead list storage (redo_failed_rows: one host read of their count).
+// The result equals the strip path's bit for bit.
 constexpr int kSample = 2048;          // 2,048 sampled candidates: survivors ~ r N / S +- 1/sqrt(r) (r ~ 71 at k/N = 2 %)
 constexpr int kMaxSeg = 256;              // query-side segments per row
 constexpr int kSpillCap = 512;             // entries of a row's spill list (appends that found their segment full)
@@ -768,10 +769,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     if (tid == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
 }
 
-// ---- the rows list_select_kernel gave up on ----------------------------------------------------------------------------
-// The first kFbRows of them are redone in bulk: their packed query rows are gathered into one tile row, the tile kernel
-// writes their similarity strip (a 128-row sweep: tens of microseconds), the three-read select runs on it.  Any further
-// rows (adversarial inputs only) take the slow per-row kernel: the k-ordered fmaf chain of one thread per candidate.
+// ---- gather of <= kFbRows failed rows (the CSLS means' bulk fallback, sim_rank.hip) ---------------------------------------
 constexpr int kFbRows = 128;
 
 __global__ void gather_fail_rows_kernel(const float *__restrict__ qp, int kp, const int32_t *__restrict__ fail_rows,
@@ -786,60 +784,12 @@ __global__ void gather_fail_rows_kernel(const float *__restrict__ qp, int kp, co
     }
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void row_select_indirect_kernel(const float *__restrict__ s, int64_t nc, int64_t ld, int k,
-                                                                          const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
-                                                                          const int32_t *__restrict__ fail_rows,
-                                                                          const int32_t *__restrict__ n_fail) {
-    __shared__ int hist[kBins];
-    __shared__ uint32_t c_key[kCandCap];
-    __shared__ int c_col[kCandCap];
-    if ((int)blockIdx.x >= min(*n_fail, kFbRows)) return;
-    select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)fail_rows[blockIdx.x] * k, hist, c_key, c_col);
-}
-
-__global__ __launch_bounds__(SEL_THREADS) void fallback_rows_kernel(const float *__restrict__ q, int ldq, const float *__restrict__ c,
-                                                                     int64_t nc, int ldc, int dim, int k,
-                                                                     const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
-                                                                     const int32_t *__restrict__ fail_rows,
-                                                                     const int32_t *__restrict__ n_fail, float *__restrict__ scratch,
-                                                                     int64_t ld) {
-    __shared__ int hist[kBins];
-    __shared__ uint32_t c_key[kCandCap];
-    __shared__ int c_col[kCandCap];
-    __shared__ float qs[2048];
-    const int nf = *n_fail;
-    float *srow = scratch + (int64_t)blockIdx.x * ld;
-    for (int f = kFbRows + blockIdx.x; f < nf; f += gridDim.x) {       // rows past the bulk path
-        const int64_t row = fail_rows[f];
-        for (int i = threadIdx.x; i < dim; i += SEL_THREADS) qs[i] = q[row * ldq + i];
-        __syncthreads();
-        for (int64_t j = threadIdx.x; j < nc; j += SEL_THREADS) {
-            const float *b = c + j * ldc;
-            float acc = 0.f;
-            int kk = 0;
-            for (; kk + 4 <= dim; kk += 4) {
-                const float4 y = oea::ld4(b + kk);
-                acc = fmaf(qs[kk], y.x, acc); acc = fmaf(qs[kk + 1], y.y, acc);
-                acc = fmaf(qs[kk + 2], y.z, acc); acc = fmaf(qs[kk + 3], y.w, acc);
-            }
-            for (; kk < dim; ++kk) acc = fmaf(qs[kk], b[kk], acc);
-            srow[j] = acc;
-        }
-        __threadfence_block();
-        __syncthreads();
-        select_row_3pass(srow, nc, k, id_map, out + row * (int64_t)k, hist, c_key, c_col);
-        __syncthreads();
-    }
-}
-
-constexpr int kFallbackBlocks = 256;
 
 struct ListPlan {
     bool ok = false;
     int r = 0, cap = 0, chunks = 0, nseg = 0;
     int64_t rows_per = 0, stride = 0, ld = 0;
-    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, cols_off = 0,
-           off_spcnt = 0, off_spill = 0;
+    size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, cols_off = 0, off_spcnt = 0, off_spill = 0;
 };
 
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
@@ -856,7 +806,7 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     p.stride = nc / kSample;
     p.ld = (nc + 31) / 32 * 32;
     auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t fixed = a256(sizeof(float) * (size_t)(kFallbackBlocks + kFbRows) * p.ld) + a256(sizeof(float) * kFbRows * 4096) + 4096;
+    const size_t fixed = 4096;
     if (ws_bytes <= fixed) return p;
     int64_t rows = nq;
     for (int iter = 0; iter < 8; ++iter) {
@@ -886,10 +836,8 @@ static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     p.cols_off = a256((size_t)p.rows_per * p.nseg * p.cap * 4);
     p.off_lists = take(2 * p.cols_off);
     p.off_strip = take(sizeof(float) * (size_t)p.rows_per * kSample);
-    p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
-    p.off_fbstrip = take(sizeof(float) * (size_t)kFbRows * p.ld);
-    p.off_fbq = take(sizeof(float) * kFbRows * 4096);
-    p.ok = off <= ws_bytes;
+    // the batched strip fallback lives in the list storage: at least one 128-row batch must fit there
+    p.ok = off <= ws_bytes && 2 * p.cols_off >= 128 * (sizeof(float) * ((size_t)4096 + (size_t)p.ld) + sizeof(int32_t) * (size_t)k) + 256;
     return p;
 }
 
@@ -899,7 +847,7 @@ struct SymPlan {
     int r = 0, T = 0, L = 0, groups = 0, nseg = 0, cap = 0, ccap = 0, n_items = 0;
     int64_t stride = 0, ld = 0;
     size_t off_thr = 0, off_counts = 0, off_ccounts = 0, off_fail = 0, off_nfail = 0, off_items = 0, off_vals = 0, off_cols = 0,
-           off_clists = 0, off_strip = 0, off_scratch = 0, off_fbstrip = 0, off_fbq = 0, off_spcnt = 0, off_spill = 0, total = 0;
+           off_clists = 0, off_strip = 0, off_spcnt = 0, off_spill = 0, total = 0;
 };
 
 static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
@@ -941,9 +889,6 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     p.off_cols = take(sizeof(int32_t) * (size_t)n * p.nseg * p.cap);
     p.off_clists = take(8 * (size_t)n * p.T * 2 * p.ccap);
     p.off_strip = take(sizeof(float) * (size_t)n * kSample);
-    p.off_scratch = take(sizeof(float) * (size_t)kFallbackBlocks * p.ld);
-    p.off_fbstrip = take(sizeof(float) * (size_t)kFbRows * p.ld);
-    p.off_fbq = take(sizeof(float) * kFbRows * 4096);
     p.total = off;
     p.ok = off <= ws_bytes;
     return p;
@@ -1111,9 +1056,6 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         int32_t *spill_cnt = reinterpret_cast<int32_t *>(w + sy.off_spcnt);
         void *spill = w + sy.off_spill;
         float *sstrip = reinterpret_cast<float *>(w + sy.off_strip);
-        float *scratch = reinterpret_cast<float *>(w + sy.off_scratch);
-        float *fbstrip = reinterpret_cast<float *>(w + sy.off_fbstrip);
-        float *fbq = reinterpret_cast<float *>(w + sy.off_fbq);
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
         // work items, full-length sweeps first: (query tile, first candidate tile, one past the last, segment group)
         sym_items_kernel<<<(unsigned)oea::ceil_div((int64_t)sy.groups * sy.T, 256), 256, 0, st>>>(sy.T, sy.L, sy.groups,
@@ -1137,7 +1079,6 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
                               8 * (size_t)nq * sy.T * 2 * sy.ccap, sy.ld, st);
         if (rc != OEA_OK) return rc;
-        (void)scratch; (void)fbstrip; (void)fbq;
         rc = oea::release_packed_rows(st);
         if (rc != OEA_OK) return rc;
         OEA_CHECK_HIP(hipGetLastError());
