@@ -868,6 +868,8 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     p.cap = ((int)(m * (1.0 + 4.0 / std::sqrt((double)p.r)) + 8.0 * std::sqrt(m) + 32.0) + 7) / 8 * 8;
     const double mc = frac * 64.0;                              // per candidate-side segment (the 64 queries of one wave column)
     p.ccap = ((int)(mc * (1.0 + 4.0 / std::sqrt((double)p.r)) + 6.0 * std::sqrt(mc) + 4.0) + 3) / 4 * 4;
+    static const int env_ccap = [] { const char *e = getenv("OEA_TOPK_CCAP"); return e ? atoi(e) : 0; }();       // experiments
+    if (env_ccap >= 4) p.ccap = env_ccap;
     if (p.ccap > 248 || (size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
     int64_t items = 0;
     for (int qt = 0; qt < p.T; ++qt) items += oea::ceil_div(p.T - qt, p.L);
