@@ -1216,6 +1216,24 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             // and the dependent round trip costs more than the rows it saves; off by default.
             static const int flag_first = [] { const char *e = getenv("OEA_APPLY_FLAG_FIRST"); return e ? atoi(e) : 0; }();
             auto nb = [&](int r) { return (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + oea::ceil_div(n_ent, r), gpb), 1), 16384); };
+            // 16-lane groups (4 rows per wave, ceil(ld / 16) fragments per lane) when the tables do not fit the caches: the
+            // kernel is then bound by HBM and the narrower groups waste fewer lanes on the row's tail -- 100K shape 64.5 ->
+            // 54.9 us (step 0.139 -> 0.125 ms); at the 15K shape (latency-bound, cache-resident) they LOSE, 11.0 -> 16.3 us
+            // (gpurun_out r02p).  OEA_APPLY_G16 = 0 / 1 overrides the size rule.
+            static const int env_g16 = [] { const char *e = getenv("OEA_APPLY_G16"); return e ? atoi(e) : -1; }();
+            const bool g16 = env_g16 >= 0 ? env_g16 != 0 : (n_ent + n_rel) * (int64_t)ld * 12 > (int64_t)128 << 20;   // 3 arrays > 128 MB
+            if (g16 && G == 32 && R == 1) {
+                const int it16 = (ld + 15) / 16;
+                const int nbg = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + n_ent, 16), 1), 16384);
+#define OEA_APPLY16(ITX) oea::launch_timed(apply_rows<16, ITX, 1>, nbg, block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first)
+                if (it16 <= 2) OEA_APPLY16(2);
+                else if (it16 <= 4) OEA_APPLY16(4);
+                else if (it16 == 5) OEA_APPLY16(5);
+                else if (it16 == 6) OEA_APPLY16(6);
+                else if (it16 == 7) OEA_APPLY16(7);
+                else OEA_APPLY16(8);
+#undef OEA_APPLY16
+            } else
             if (R >= 4 && IT <= 4)
                 oea::launch_timed(apply_rows<G, IT, 4>, nb(4), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
             else if (R >= 2 && IT <= 8)
