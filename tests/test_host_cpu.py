@@ -33,6 +33,27 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.StepCfg) == 88            # 12 x 4-byte fields + 2 pointers (8-byte aligned) + 2 x int32 + 3 floats + int32 of oea_step_cfg
     assert C.sizeof(_lib.SamplerSide) == 48        # 5 pointers/u64 + 2 int32
     assert C.sizeof(_lib.RotateCfg) == 72          # 6 doubles + int64 + 4 x int32 of oea_rotate_cfg
+    assert C.sizeof(_lib.CsrSplit) == 72           # 4 pointers + 3 int32 (+ pad) + 2 pointers + int64 of oea_csr_split
+
+
+def test_host_side_planners_of_the_library():
+    """pure host entry points (no device): workspace planners answer without a GPU and follow their documented domains."""
+    from openea_amd import _lib
+    lib = _lib.load(require_device=False)
+    # symmetric neighbour search: covered from 32,768 rows up to the select's segment table (~140,000 rows)
+    assert lib.oea_topk_sym_workspace_bytes(20000, 400) == 0
+    need = lib.oea_topk_sym_workspace_bytes(100000, 2000)
+    assert 20 << 30 < need < 48 << 30               # ~30 GB: mostly the candidate-side segments
+    assert lib.oea_topk_sym_workspace_bytes(400000, 8000) == 0
+    assert lib.oea_topk_workspace_bytes(1000, 100000) == 1000 * 100000 * 4
+    # one-sweep CSLS means: from 4,096 x 4,096 on, k <= 32
+    assert lib.oea_csls_means_workspace_bytes(1000, 1000, 10) == 0
+    assert lib.oea_csls_means_workspace_bytes(10500, 10500, 10) > 0
+    assert lib.oea_csls_means_workspace_bytes(70000, 70000, 10) > 0
+    assert lib.oea_csls_means_workspace_bytes(10500, 10500, 64) == 0
+    # entity-id partition arithmetic
+    assert lib.oea_part_rows_per_rank(30000, 8) == 3750 and lib.oea_part_rows_per_rank(30001, 8) == 3751
+    assert lib.oea_part_send_floats(30000, 76, 8) == 8 * 3750 * 77
 
 
 def test_product_path_fails_loudly_without_gpu():
