@@ -143,6 +143,7 @@ class Workload:
         apply_s = m["apply_ms"] / 1e3 / launches
         achieved = alg_bytes / fwd_s / 1e9 if fwd_s > 0 else 0.0
         traffic = _traffic(self.shape, d, self.batch, neg, self.world)
+        rec = _profile_record(self.shape, d, self.batch, neg, self.world)
         # whole step: scoring + Adagrad (20*d B per touched row; touched rows <= unique ids of the batch, estimated
         # by the table rows here: at both shapes a batch touches most of the table)
         touched = min(self.kgs.entities_num + self.kgs.relations_num, scored_per_launch * 2)
@@ -154,6 +155,12 @@ class Workload:
                     "step_frac": round(step_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
                     "avg_kernel_us": round(fwd_s * 1e6, 2), "apply_rows_avg_us": round(apply_s * 1e6, 2),
                     "gap_between_kernels_us": round(m["gap_ms"] * 1e3 / launches, 2),
+                    # the same kernels in the committed rocprofv3 kernel trace of this command (pipelined dispatches; a dispatch
+                    # that carries HIP events starts behind a drained queue and measures 1-3 us longer)
+                    "rocprof_avg_kernel_us": rec.get("rocprof_avg_kernel_us"),
+                    "rocprof_apply_rows_avg_us": rec.get("rocprof_apply_rows_avg_us"),
+                    "frac_rocprof": round(alg_bytes / (rec["rocprof_avg_kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    if rec.get("rocprof_avg_kernel_us") else None,
                     "timing": "HIP start/stop events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on every "
                               "%d-th step of %d further K-step regions run right after the throughput regions (events on a "
                               "dispatch stop it from being pipelined behind its predecessor, so they stay out of `value`): the "
@@ -167,18 +174,24 @@ class Workload:
         return value, ms_per_step, roofline
 
 
-def _traffic(shape, d, batch, neg, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this very workload, else None"""
+def _profile_record(shape, d, batch, neg, world):
+    """the committed rocprofv3 record of this very workload (profiles/traffic_<shape>.json, written by
+    tools/summarize_profiles.py from the kernel-trace and FETCH_SIZE / WRITE_SIZE passes of the same command), else {}"""
     p = os.path.join(ROOT, "profiles", "traffic_%s.json" % shape)
     if world != 1 or not os.path.exists(p):
-        return None
+        return {}
     try:
         tj = json.load(open(p))
         if tj.get("workload") == [shape, d, batch, neg]:
-            return tj.get("hbm_bytes_per_launch")
+            return tj
     except Exception:
         pass
-    return None
+    return {}
+
+
+def _traffic(shape, d, batch, neg, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this very workload, else None"""
+    return _profile_record(shape, d, batch, neg, world).get("hbm_bytes_per_launch")
 
 
 def main():

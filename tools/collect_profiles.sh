@@ -18,6 +18,9 @@ PMC100="python $R/bench.py --shape EN-FR-100K-V1 --dim 100 --batch 20000 --eps 0
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats100k -- $PMC100 > $OUT/bench100k_stats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch100k -- $PMC100 > $OUT/bench100k_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write100k -- $PMC100 > $OUT/bench100k_write.log 2>&1
+python $R/bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+python $R/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_like.json 2> $OUT/bench_driver_like.err
+if [ "${COLLECT:-all}" = "bench" ]; then exit 0; fi     # COLLECT=bench: the step kernels' passes only
 # neighbour search at 100,000 x 100,000, k = 2,000: kernel stats + traffic of the strip-free path and of the strip path
 KNN="python $R/tools/_exp/knn_time.py"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/knn_stats -- $KNN > $OUT/knn_stats.log 2>&1
@@ -34,7 +37,5 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/csls --
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/legs -- python $R/tools/profile_legs.py > $OUT/legs.log 2>&1
 # matrix-core utilisation of the evaluation sweep (70,000^2 x 100), counters in their own pass
 LEGS=eval70k timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python $R/tools/profile_legs.py > $OUT/legs_mfma.log 2>&1
-python $R/bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
-python $R/bench.py --steps 20 --warmup 5 > $OUT/bench_driver_like.json 2> $OUT/bench_driver_like.err
 grep -h kNN $OUT/knn_stats.log | head -4
 tail -3 $OUT/csls.log

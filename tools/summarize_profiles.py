@@ -83,7 +83,19 @@ def main():
             if dom:
                 r = dom[0]
                 shape = workloads[suffix][0]
-                json.dump({"kernel": r[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
+                # average durations of the two step kernels in the kernel trace of the same bench command
+                dur = {}
+                leg = "stats" if suffix == "" else "stats100k"
+                for fcsv in glob.glob(os.path.join(src, leg, "*", "*_kernel_stats.csv")):
+                    for row in csv.DictReader(open(fcsv)):
+                        nm = row["Name"]
+                        if r[0][:60] in nm:
+                            dur["rocprof_avg_kernel_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+                            dur["rocprof_launches"] = int(row["Calls"])
+                        want = "apply_rows<32, 3" if suffix == "" else "apply_rows<"
+                        if want in nm and ("apply_rows<32, 3" in nm) == (suffix == ""):
+                            dur["rocprof_apply_rows_avg_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+                json.dump({**dur, "kernel": r[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
                            "workload": list(workloads[suffix]),
                            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/%s_%s.csv" % (name, tag),
                            "FETCH_SIZE_KB": r[2], "WRITE_SIZE_KB": r[3],
