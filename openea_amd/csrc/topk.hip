@@ -872,7 +872,7 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     if (env_ccap >= 4) p.ccap = env_ccap;
     if (p.ccap > 248 || (size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
     int64_t items = 0;
-    for (int qt = 0; qt < p.T; ++qt) items += oea::ceil_div(p.T - qt, p.L);
+    for (int c = 0; c < p.groups; ++c) items += std::min(p.T, (c + 1) * p.L);
     p.n_items = (int)items;
     p.stride = n / kSample;
     p.ld = (n + 31) / 32 * 32;
@@ -905,17 +905,19 @@ static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld
         row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
 }
 
-// item (g, qt) = candidate tiles [qt + g L, min(T, qt + (g + 1) L)) of query tile qt; group g holds the items of the query
-// tiles with qt + g L < T, numbered after the groups before it
-__global__ void sym_items_kernel(int T, int L, int groups, int4 *__restrict__ items) {
+// Work items of the symmetric sweep on an ABSOLUTE grid of candidate chunks: item (c, qt) = candidate tiles
+// [max(qt, c L), min(T, (c + 1) L)) of query tile qt, for every chunk c that reaches past the diagonal (qt < (c + 1) L).
+// Items are numbered chunk-major, so the workgroups in flight at one time walk the SAME candidate tiles in step and share
+// them in their XCD's L2 (windows that start at each query tile's own diagonal put 64 different panels per XCD in flight:
+// 21 % L2 hits against 68 % in the plain rank sweep).  Segment group of an item = c - qt / L.
+__global__ void sym_items_kernel(int T, int L, int chunks, int4 *__restrict__ items) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * T) return;
-    const int g = i / T, qt = i - g * T;
-    const int b = qt + g * L;
-    if (b >= T) return;
+    if (i >= chunks * T) return;
+    const int c = i / T, qt = i - c * T;
+    if (qt >= min(T, (c + 1) * L)) return;
     int base = 0;
-    for (int h = 0; h < g; ++h) base += max(0, T - h * L);
-    items[base + qt] = make_int4(qt, b, min(T, b + L), g);
+    for (int h = 0; h < c; ++h) base += min(T, (h + 1) * L);
+    items[base + qt] = make_int4(qt, max(qt, c * L), min(T, (c + 1) * L), c - qt / L);
 }
 
 // ---- rows the list select gave up on: redone through the strip path, in batches -------------------------------------------
@@ -1059,7 +1061,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         void *spill = w + sy.off_spill;
         float *sstrip = reinterpret_cast<float *>(w + sy.off_strip);
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
-        // work items, full-length sweeps first: (query tile, first candidate tile, one past the last, segment group)
+        // work items, chunk-major: (query tile, first candidate tile, one past the last, segment group)
         sym_items_kernel<<<(unsigned)oea::ceil_div((int64_t)sy.groups * sy.T, 256), 256, 0, st>>>(sy.T, sy.L, sy.groups,
                                                                                               reinterpret_cast<int4 *>(items_dev));
         float *sp = nullptr;

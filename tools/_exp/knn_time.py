@@ -12,7 +12,8 @@ from openea_amd import ops  # noqa: E402
 
 ops.lib()
 rng = np.random.RandomState(0)
-for n, d, k, reps in ((100000, 100, 2000, 5), (15000, 100, 1499, 20)):
+cases = ((100000, 100, 2000, 2),) if os.environ.get("KNN_QUICK") else ((100000, 100, 2000, 5), (15000, 100, 1499, 20))
+for n, d, k, reps in cases:
     x = rng.standard_normal((n, d)).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     t = ops.to_table(x)
