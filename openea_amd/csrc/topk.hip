@@ -792,15 +792,24 @@ struct ListPlan {
     size_t off_thr = 0, off_counts = 0, off_fail = 0, off_nfail = 0, off_lists = 0, off_strip = 0, cols_off = 0, off_spcnt = 0, off_spill = 0;
 };
 
+// sample rank of the threshold = e + sigma * sqrt(e) + slack (e = k S / N).  A row with fewer than k survivors costs 0.4 us in
+// the batched strip fallback, so the margin is modest: 2.5 sigma + 4 (r = 61 at k / N = 2 %, ~3.0 % of a row survives, ~0.6 % of
+// the rows come up short) measured 20.0 / 23.3 ms (random / trained tables, 100,000^2, k = 2,000) against 20.6 / 24.1 ms at
+// 3.5 sigma + 8 and 20.7 / 25.1 ms at 1.5 sigma + 2.  OEA_TOPK_SIGMA / OEA_TOPK_SLACK override.
+static int threshold_rank(double e) {
+    static const double sigma = [] { const char *v = getenv("OEA_TOPK_SIGMA"); return v ? atof(v) : 2.5; }();
+    static const double slack = [] { const char *v = getenv("OEA_TOPK_SLACK"); return v ? atof(v) : 4.0; }();
+    return (int)(e + sigma * std::sqrt(e) + slack);
+}
+
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
 static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     ListPlan p;
     if (nq < 4096 || nc < 32768) return p;
     const double e = (double)k * kSample / (double)nc;
     // sample rank of the threshold: the row then holds N * Beta(r, S - r + 1) survivors, i.e. about r N / S +- a relative
-    // 1 / sqrt(r); 3.5 sigma above k * S / N leaves "fewer than k survivors" at ~2e-4 per row -- those rows go through the
-    // bulk fallback (one gated 128-row tile sweep), which costs less than longer lists for every row would
-    p.r = (int)(e + 3.5 * std::sqrt(e) + 8.0);
+    // 1 / sqrt(r); rows left with fewer than k survivors go through the batched strip fallback (threshold_rank)
+    p.r = threshold_rank(e);
     const double m_total = (double)p.r * (double)nc / kSample;
     if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || nc > (int64_t)kBitWords * 32) return p;
     p.stride = nc / kSample;
@@ -854,7 +863,7 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     SymPlan p;
     if (n < 32768) return p;
     const double e = (double)k * kSample / (double)n;
-    p.r = (int)(e + 3.5 * std::sqrt(e) + 8.0);
+    p.r = threshold_rank(e);
     const double frac = (double)p.r / kSample;                  // expected survivor fraction of a row
     const double m_total = frac * (double)n;
     if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || n > (int64_t)kBitWords * 32) return p;
