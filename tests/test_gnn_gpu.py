@@ -46,10 +46,13 @@ def test_sparse_attention_matches_oracle(ops, grouping, d):
     seg_ptr, seg_row, col = g.seg_ptr_host, g.seg_row_host, g.e_colidx.cpu().numpy()
     out_ref, alpha = orc.sparse_attn_forward(z_h, v_h, seg_ptr, seg_row, col, n)
     dz_ref, dv_ref = orc.sparse_attn_backward(z_h, v_h, alpha, w_h, seg_ptr, seg_row, col)
-    # fp32 kernels vs fp64 oracle
-    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref, rtol=1e-5, atol=2e-5)
-    np.testing.assert_allclose(z.grad.cpu().numpy(), dz_ref, rtol=0, atol=3e-5 * max(1.0, np.abs(dz_ref).max()))
-    np.testing.assert_allclose(v.grad.cpu().numpy(), dv_ref, rtol=0, atol=2e-5 * max(1.0, np.abs(dv_ref).max()))
+    # fp32 kernels vs fp64 oracle.  Sub-segments and split columns are combined with fp32 atomics: the order of those sums
+    # changes from run to run, and dz is a difference of d-term dot products (d = 400: |terms| ~ 20) -- the tolerances sit a
+    # few times above the resulting run-to-run spread (2e-5 / 3e-5 / 2e-5 held in four of five runs) and four orders of
+    # magnitude below the effect of a wrong weight or a dropped edge
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref, rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), dz_ref, rtol=0, atol=1e-4 * max(1.0, np.abs(dz_ref).max()))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), dv_ref, rtol=0, atol=6e-5 * max(1.0, np.abs(dv_ref).max()))
     # rows sum to one per segment
     a = orc.segment_softmax(np.where(z_h > 0, z_h, 0.2 * z_h), seg_ptr)
     assert np.allclose(np.add.reduceat(a, seg_ptr[:-1][np.diff(seg_ptr) > 0]), 1.0)
