@@ -191,3 +191,23 @@ def test_symmetric_neighbour_search_equals_general_path(ops):
     assert np.array_equal(sym, gen)
     rows = np.concatenate([[0, 4, 5, n - 1], rng.choice(n, 12, replace=False)])
     assert np.array_equal(sym[rows], cport.topk_inner(emb[rows], emb, k))
+
+
+def test_neighbour_search_on_clustered_rows_spills_and_stays_exact(ops):
+    """clustered embeddings (blocks of ~600 consecutive near-duplicate rows, as trained tables have them): a row's neighbours
+    crowd into a few candidate tiles, its list segments overflow into the spill list (and some rows into the strip
+    fallback); both list paths must still equal the oracle."""
+    from oracle import cport
+    rng = np.random.RandomState(11)
+    n, d, k = 40100, 64, 800
+    centres = rng.standard_normal((n // 600 + 1, d)).astype(np.float32)
+    emb = centres[np.arange(n) // 600] + 0.15 * rng.standard_normal((n, d)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    t = ops.to_table(emb)
+    sym = ops.topk_inner(t, t, d, k).cpu().numpy()
+    gen = ops.topk_inner(t, t.clone(), d, k).cpu().numpy()
+    assert np.array_equal(sym, gen)
+    rows = np.concatenate([[0, 599, 600, n - 1], rng.choice(n, 20, replace=False)])
+    assert np.array_equal(sym[rows], cport.topk_inner(emb[rows], emb, k))
+    own = (sym // 600 == (np.arange(n) // 600)[:, None]).sum(1)           # the own cluster's ~600 rows lead every list
+    assert own.min() >= 500
