@@ -469,24 +469,38 @@ typedef struct oea_attn_graph {
     const int32_t *seg_row;      /* [n_seg]   output row of each segment */
     const int32_t *colidx;       /* [nnz]     value row (column) of each edge */
     int64_t n_sub, n_seg;
-    /* transposed edge list in column chunks, for dV */
-    const int32_t *t_sub_ptr;    /* [n_tsub+1] incoming-edge range of each column chunk */
-    const int32_t *t_sub_col;    /* [n_tsub]   column of each chunk */
-    const int32_t *t_row;        /* [nnz] output row of the incoming edge */
-    const int32_t *t_edge;       /* [nnz] its edge id (index into z / alpha) */
-    int64_t n_tsub;
-    int32_t unique_rows;         /* every output row has exactly one segment */
-    int32_t t_any_split;         /* some column owns more than one chunk (dV then accumulates atomically) */
+    /* the aggregate out = P . v as a CSR over the OUTPUT rows (fixed summation order: slot order inside a row) */
+    const int32_t *agg_rowptr;   /* [agg_rows+1] slot range of each output row */
+    const int32_t *agg_colidx;   /* [nnz] value row of each slot */
+    const int32_t *agg_edge;     /* [nnz] edge id of each slot (index into alpha); NULL: slot == edge (canonical order) */
+    int64_t agg_rows;
+    const oea_csr_split *agg_split;   /* hub rows of the aggregate (relative to agg_row0), or NULL */
+    /* the transposed CSR for dv = P^T . dout */
+    const int32_t *t_rowptr;     /* [t_rows+1] incoming-slot range of each value row (column) */
+    const int32_t *t_row;        /* [nnz] output row of the incoming edge (row of dout) */
+    const int32_t *t_edge;       /* [nnz] its edge id (index into alpha) */
+    int64_t t_rows;
+    const oea_csr_split *t_split;     /* hub columns (relative to t_row0), or NULL */
+    /* the ranges a call works on (whole graph: [0, n)); a rank of a row-sharded job passes the whole graph with ITS
+     * ranges: a block of segments (sub-segment range [sub0, sub1) = segments [seg0, seg1)), a block of output rows
+     * [agg_row0, agg_row1) with slots [agg_slot0, agg_slot1) = agg_rowptr[agg_row0 / agg_row1], a block of columns */
+    int64_t sub0, sub1, seg0, seg1;
+    int64_t agg_row0, agg_row1, agg_slot0, agg_slot1;
+    int64_t t_row0, t_row1, t_slot0, t_slot1;
 } oea_attn_graph;
-size_t oea_sparse_attn_workspace_floats(int64_t n_sub, int64_t n_seg);
-/* out [n_rows, ld] and (backward) dv [n_cols, ld] must be ZERO on entry.
- * Partial graphs are allowed (row-sharded jobs, one process per GPU): n_tsub == 0 -> the backward only produces dz of
- * the graph's own segments; n_sub == 0 -> it only produces the dv rows of the listed column chunks. */
+#define OEA_ATTN_ALPHA 1       /* forward: softmax statistics + alpha[e] of the segments [seg0, seg1) */
+#define OEA_ATTN_AGGREGATE 2   /* forward: out rows [agg_row0, agg_row1) from alpha of ALL their edges */
+#define OEA_ATTN_DZ 1          /* backward: dz[e] of the segments [seg0, seg1) */
+#define OEA_ATTN_DV 2          /* backward: dv rows [t_row0, t_row1) */
+size_t oea_sparse_attn_workspace_floats(const oea_attn_graph *g);
+/* No atomics: results are bit-reproducible.  z, alpha, dz are indexed by edge id; out [agg_rows, ld], dv [t_rows, ld]:
+ * every row of the call's range is written (rows without edges get zeros).  `phases` selects what runs (a single
+ * process passes both bits; between the phases a sharded job all-gathers alpha / dz). */
 int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v, int32_t dim, int32_t ld,
-                        float lrelu_slope, float *out, float *alpha, float *workspace, void *stream);
+                        float lrelu_slope, float *out, float *alpha, float *workspace, int32_t phases, void *stream);
 int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v, const float *alpha,
                         const float *dout, int32_t dim, int32_t ld, float lrelu_slope, float *dz, float *dv,
-                        float *workspace, void *stream);
+                        float *workspace, int32_t phases, void *stream);
 
 /* Dense Adam step with tf.train.AdamOptimizer semantics (alinet.py:871, rdgcn.py:332); t = 1-based
  * step count. */

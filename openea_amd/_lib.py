@@ -42,9 +42,14 @@ class CsrSplit(C.Structure):
 class AttnGraph(C.Structure):
     """mirror of `oea_attn_graph` (include/openea_hip.h)."""
     _fields_ = [("sub_ptr", C.c_void_p), ("sub_seg", C.c_void_p), ("seg_sub_ptr", C.c_void_p), ("seg_row", C.c_void_p),
-                ("colidx", C.c_void_p), ("n_sub", C.c_int64), ("n_seg", C.c_int64), ("t_sub_ptr", C.c_void_p),
-                ("t_sub_col", C.c_void_p), ("t_row", C.c_void_p), ("t_edge", C.c_void_p), ("n_tsub", C.c_int64),
-                ("unique_rows", C.c_int32), ("t_any_split", C.c_int32)]
+                ("colidx", C.c_void_p), ("n_sub", C.c_int64), ("n_seg", C.c_int64),
+                ("agg_rowptr", C.c_void_p), ("agg_colidx", C.c_void_p), ("agg_edge", C.c_void_p), ("agg_rows", C.c_int64),
+                ("agg_split", C.POINTER(CsrSplit)),
+                ("t_rowptr", C.c_void_p), ("t_row", C.c_void_p), ("t_edge", C.c_void_p), ("t_rows", C.c_int64),
+                ("t_split", C.POINTER(CsrSplit)),
+                ("sub0", C.c_int64), ("sub1", C.c_int64), ("seg0", C.c_int64), ("seg1", C.c_int64),
+                ("agg_row0", C.c_int64), ("agg_row1", C.c_int64), ("agg_slot0", C.c_int64), ("agg_slot1", C.c_int64),
+                ("t_row0", C.c_int64), ("t_row1", C.c_int64), ("t_slot0", C.c_int64), ("t_slot1", C.c_int64)]
 
 
 class RotateCfg(C.Structure):
@@ -134,9 +139,9 @@ PROTOTYPES = {
     "oea_csls_means": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "oea_csls_apply": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "oea_spmm_csr": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _i32, C.POINTER(CsrSplit), _vp]),
-    "oea_sparse_attn_workspace_floats": (_sz, [_i64, _i64]),
-    "oea_sparse_attn_fwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
-    "oea_sparse_attn_bwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "oea_sparse_attn_workspace_floats": (_sz, [C.POINTER(AttnGraph)]),
+    "oea_sparse_attn_fwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "oea_sparse_attn_bwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "oea_adam_dense": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _vp]),
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),

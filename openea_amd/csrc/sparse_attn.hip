@@ -14,14 +14,24 @@
 // Degrees are power-law (hubs with 10^3..10^5 two-hop neighbours), so a segment is cut into
 // SUB-SEGMENTS of at most kSubEdges edges on the host and every kernel works wave-per-sub-segment
 // (bounded, balanced work); segment-wide quantities are combined by tiny per-segment kernels:
-//   forward : K1 sub (max, sum exp)  ->  K2 segment (M, L)  ->  K3 sub: alpha = exp(e-M)/L,
-//             partial aggregate with the 64 lanes across the feature columns (coalesced 256-B
-//             gathers of V rows, alpha broadcast by __shfl), added to the output row (plain store
-//             when the row has a single sub-segment, hardware fp32 atomics otherwise)
+//   forward : K1 sub (max, sum exp; a segment that is ONE sub-segment gets its alphas right here)
+//             ->  K2 segment (M, L)  ->  K3 sub: alpha = exp(e-M)/L (both only when some segment has
+//             several sub-segments)  ->  out = P . V with P = the alphas as a CSR over the OUTPUT
+//             rows (slots in edge order inside a row; the edge order itself when it is canonical):
+//             csrc/spmm.hip's aggregate -- short rows serially in slot order, long rows by the
+//             workgroup's groups combined in group order, hub rows in chunks whose partial sums are
+//             added in chunk order.  NO atomics anywhere: two runs give identical bits, whatever
+//             the grouping (round 3; the round-2 kernels added sub-segment / split-column partials
+//             with fp32 atomics and differed from run to run).
 //   backward: B1 sub: d alpha_e = dOut_row . V_col (one wave reduction per edge), partial
 //             c = sum alpha d alpha -> B2 segment c -> B3 sub: d z_e = alpha_e (d alpha_e - c) lrelu'(z_e);
-//             B4: dV = transposed aggregate over column chunks with the stored alphas.
-// Bytes per launch (forward K3): nnz*(12 + 4*d) + 4*N*d  (SpMM bytes + nnz*4 logits).
+//             B4: dV = P^T . dOut, the same aggregate over the transposed CSR with the stored alphas.
+// Bytes per launch (forward aggregate): nnz*(12 + 4*d) + 4*N*d  (SpMM bytes + nnz*4 logits).
+//
+// Row-sharded jobs (one process per GPU): every rank holds the whole graph and runs the PHASES on its
+// own ranges -- softmax statistics / alphas / d z for a block of segments (a contiguous edge range in
+// either grouping), the aggregate for a block of output rows, dV for a block of columns -- with one
+// all-gather between the phases (models/graph_ops.py).
 #include "common.h"
 
 namespace {
@@ -40,13 +50,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ float lrelu(float x, float a) { return x > 0.f ? x : a * x; }
 
-// K1: per sub-segment softmax statistics
-__global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__restrict__ sub_ptr, int64_t n_sub,
-                                                             const float *__restrict__ z, float slope,
-                                                             float *__restrict__ sub_m, float *__restrict__ sub_l) {
+// K1: per sub-segment softmax statistics.  A segment that consists of this one sub-segment is finished here:
+// its (M, L) and its alphas are written, K2 / K3 never look at it.
+__global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__restrict__ sub_ptr,
+                                                             const int32_t *__restrict__ sub_seg,
+                                                             const int32_t *__restrict__ seg_sub_ptr, int64_t sub0,
+                                                             int64_t sub1, const float *__restrict__ z, float slope,
+                                                             float *__restrict__ sub_m, float *__restrict__ sub_l,
+                                                             float *__restrict__ seg_m, float *__restrict__ seg_l,
+                                                             float *__restrict__ alpha) {
     const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_sub) return;
+    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= sub1) return;
     const int e0 = sub_ptr[s], e1 = sub_ptr[s + 1];
     float m = -INFINITY;
     for (int e = e0 + lane; e < e1; e += W) m = fmaxf(m, lrelu(z[e], slope));
@@ -54,19 +69,29 @@ __global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__re
     float l = 0.f;
     for (int e = e0 + lane; e < e1; e += W) l += expf(lrelu(z[e], slope) - m);
     l = wave_sum(l);
-    if (lane == 0) { sub_m[s] = m; sub_l[s] = l; }
+    const int g = sub_seg[s];
+    const bool single = seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1;
+    if (lane == 0) {
+        sub_m[s] = m; sub_l[s] = l;
+        if (single) { seg_m[g] = m; seg_l[g] = l; }
+    }
+    if (single) {
+        const float inv_l = 1.0f / l;
+        for (int e = e0 + lane; e < e1; e += W) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
+    }
 }
 
 // K2: per segment (M, L) from its consecutive sub-segments.  One lane per segment for the usual few sub-segments; a hub
 // segment (power-law degrees: hundreds of sub-segments) is combined by the WHOLE wave, lanes striding over its
 // sub-segments (it was one thread's serial loop: 270 us of a 1.7 ms attention on the hub graph).
 constexpr int kSerialSubs = 8;
-__global__ __launch_bounds__(256) void attn_seg_combine_kernel(const int32_t *__restrict__ seg_sub_ptr, int64_t n_seg,
-                                                               const float *__restrict__ sub_m, const float *__restrict__ sub_l,
-                                                               float *__restrict__ seg_m, float *__restrict__ seg_l) {
+__global__ __launch_bounds__(256) void attn_seg_combine_kernel(const int32_t *__restrict__ seg_sub_ptr, int64_t seg0,
+                                                               int64_t seg1, const float *__restrict__ sub_m,
+                                                               const float *__restrict__ sub_l, float *__restrict__ seg_m,
+                                                               float *__restrict__ seg_l) {
     const int lane = threadIdx.x & 63;
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = g < n_seg;
+    const int64_t g = seg0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = g < seg1;
     const int s0 = valid ? seg_sub_ptr[g] : 0, s1 = valid ? seg_sub_ptr[g + 1] : 0;
     const bool hub = s1 - s0 > kSerialSubs;
     if (valid && !hub) {
@@ -92,74 +117,51 @@ __global__ __launch_bounds__(256) void attn_seg_combine_kernel(const int32_t *__
     }
 }
 
-// K3: alpha + partial aggregate of one sub-segment
-template <int IT>
-__global__ __launch_bounds__(256) void attn_aggregate_kernel(const int32_t *__restrict__ sub_ptr,
-                                                             const int32_t *__restrict__ sub_seg,
-                                                             const int32_t *__restrict__ seg_sub_ptr,
-                                                             const int32_t *__restrict__ seg_row, int64_t n_sub,
-                                                             const int32_t *__restrict__ colidx, const float *__restrict__ z,
-                                                             const float *__restrict__ v, int dim, int ld, float slope,
-                                                             const float *__restrict__ seg_m, const float *__restrict__ seg_l,
-                                                             float *__restrict__ out, float *__restrict__ alpha,
-                                                             int unique_rows) {
+// K3: alphas of the sub-segments of segments with SEVERAL sub-segments (the others were finished by K1)
+__global__ __launch_bounds__(256) void attn_alpha_kernel(const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_seg,
+                                                         const int32_t *__restrict__ seg_sub_ptr, int64_t sub0, int64_t sub1,
+                                                         const float *__restrict__ z, float slope,
+                                                         const float *__restrict__ seg_m, const float *__restrict__ seg_l,
+                                                         float *__restrict__ alpha) {
     const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_sub) return;
-    const int e0 = sub_ptr[s], e1 = sub_ptr[s + 1];
-    if (e1 <= e0) return;
+    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= sub1) return;
     const int g = sub_seg[s];
+    if (seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1) return;
     const float m = seg_m[g], inv_l = 1.0f / seg_l[g];
-    float acc[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) acc[it] = 0.f;
-    for (int base = e0; base < e1; base += W) {
-        const int e = base + lane;
-        float a = 0.f;
-        int c = 0;
-        if (e < e1) {
-            a = expf(lrelu(z[e], slope) - m) * inv_l;
-            c = colidx[e];
-            alpha[e] = a;
-        }
-        const int cnt = min(W, e1 - base);
-        for (int j = 0; j < cnt; ++j) {
-            const float aj = __shfl(a, j, 64);
-            const int cj = __shfl(c, j, 64);
-            const float *vr = v + (int64_t)cj * ld;
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int col = it * W + lane;
-                if (col < dim) acc[it] = fmaf(aj, vr[col], acc[it]);
-            }
-        }
-    }
-    const bool single = unique_rows && (seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1);
-    float *o = out + (int64_t)seg_row[g] * ld;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int col = it * W + lane;
-        if (col < dim) {
-            if (single) o[col] = acc[it];
-            else oea::atomic_add_f32(o + col, acc[it]);
-        }
-    }
+    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += W) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
+}
+
+// values of the aggregate's CSR slots [slot0, slot1): dst[slot] = alpha[edge_of_slot[slot]]
+__global__ __launch_bounds__(256) void attn_slot_values_kernel(const int32_t *__restrict__ edge_of_slot, int64_t slot0,
+                                                               int64_t slot1, const float *__restrict__ alpha,
+                                                               float *__restrict__ dst) {
+    const int64_t i = slot0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slot1) dst[i] = alpha[edge_of_slot[i]];
 }
 
 // B1: d alpha_e (stored in dz) and the sub-segment's partial c = sum alpha_e d alpha_e
 template <int IT>
 __global__ __launch_bounds__(256) void attn_bwd_dalpha_kernel(const int32_t *__restrict__ sub_ptr,
                                                               const int32_t *__restrict__ sub_seg,
-                                                              const int32_t *__restrict__ seg_row, int64_t n_sub,
-                                                              const int32_t *__restrict__ colidx, const float *__restrict__ v,
-                                                              const float *__restrict__ alpha, const float *__restrict__ dout,
-                                                              int dim, int ld, float *__restrict__ dz,
-                                                              float *__restrict__ sub_c) {
+                                                              const int32_t *__restrict__ seg_sub_ptr,
+                                                              const int32_t *__restrict__ seg_row, int64_t sub0,
+                                                              int64_t sub1, const int32_t *__restrict__ colidx,
+                                                              const float *__restrict__ v, const float *__restrict__ alpha,
+                                                              const float *__restrict__ dout, int dim, int ld,
+                                                              float *__restrict__ dz, float *__restrict__ sub_c) {
     const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_sub) return;
+    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= sub1) return;
     const int e0 = sub_ptr[s], e1 = sub_ptr[s + 1];
-    const float *dor = dout + (int64_t)seg_row[sub_seg[s]] * ld;
+    const int g = sub_seg[s];
+    // a segment of ONE edge: alpha = 1 exactly, c = alpha * d alpha = d alpha, d z = alpha (d alpha - c) = 0 exactly --
+    // no need for the dot product (AliNet's column-major 2-hop adjacency under the 'runs' grouping is all such segments)
+    if (e1 - e0 == 1 && seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1) {
+        if (lane == 0) { dz[e0] = 0.f; sub_c[s] = 0.f; }
+        return;
+    }
+    const float *dor = dout + (int64_t)seg_row[g] * ld;
     float d[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -195,13 +197,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dalpha_kernel(const int32_t *__r
 
 // B2 + B3: segment c (fixed order over its sub-segments), then d z of this sub-segment
 __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_seg,
-                                                          const int32_t *__restrict__ seg_sub_ptr, int64_t n_sub,
-                                                          const float *__restrict__ z, const float *__restrict__ alpha,
-                                                          const float *__restrict__ sub_c, float slope,
-                                                          float *__restrict__ dz) {
+                                                          const int32_t *__restrict__ seg_sub_ptr, int64_t sub0,
+                                                          int64_t sub1, const float *__restrict__ z,
+                                                          const float *__restrict__ alpha, const float *__restrict__ sub_c,
+                                                          float slope, float *__restrict__ dz) {
     const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_sub) return;
+    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= sub1) return;
     const int g = sub_seg[s];
     const int q0 = seg_sub_ptr[g], q1 = seg_sub_ptr[g + 1];
     float c = 0.f;
@@ -217,49 +219,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restr
     }
 }
 
-// B4: dV[col] += sum over the column chunk's incoming edges of alpha_e * dOut[row_e]
-template <int IT>
-__global__ __launch_bounds__(256) void attn_bwd_v_kernel(const int32_t *__restrict__ t_sub_ptr,
-                                                         const int32_t *__restrict__ t_sub_col, int64_t n_tsub,
-                                                         const int32_t *__restrict__ t_row, const int32_t *__restrict__ t_edge,
-                                                         const float *__restrict__ alpha, const float *__restrict__ dout,
-                                                         int dim, int ld, float *__restrict__ dv, int any_split) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_tsub) return;
-    const int e0 = t_sub_ptr[s], e1 = t_sub_ptr[s + 1];
-    if (e1 <= e0) return;
-    float acc[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) acc[it] = 0.f;
-    for (int base = e0; base < e1; base += W) {
-        const int e = base + lane;
-        float a = 0.f;
-        int r = 0;
-        if (e < e1) { a = alpha[t_edge[e]]; r = t_row[e]; }
-        const int cnt = min(W, e1 - base);
-        for (int q = 0; q < cnt; ++q) {
-            const float aq = __shfl(a, q, 64);
-            const int rq = __shfl(r, q, 64);
-            const float *dr = dout + (int64_t)rq * ld;
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int col = it * W + lane;
-                if (col < dim) acc[it] = fmaf(aq, dr[col], acc[it]);
-            }
-        }
-    }
-    float *o = dv + (int64_t)t_sub_col[s] * ld;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int col = it * W + lane;
-        if (col < dim) {
-            if (any_split) oea::atomic_add_f32(o + col, acc[it]);
-            else o[col] = acc[it];
-        }
-    }
-}
-
 #define OEA_ATTN_DISPATCH(ld, CALL)                                      \
     do {                                                                 \
         if ((ld) <= 128) { CALL(2); }                                    \
@@ -270,9 +229,16 @@ __global__ __launch_bounds__(256) void attn_bwd_v_kernel(const int32_t *__restri
     } while (0)
 
 static int check_graph(const oea_attn_graph *g) {
-    OEA_REQUIRE(g && (g->n_sub == 0 || (g->sub_ptr && g->sub_seg && g->seg_sub_ptr && g->seg_row && g->colidx)),
-                "attention graph: null pointer");
+    OEA_REQUIRE(g, "attention graph: null pointer");
     OEA_REQUIRE(g->n_sub >= 0 && g->n_seg >= 0 && g->n_sub >= g->n_seg, "n_sub >= n_seg >= 0");
+    OEA_REQUIRE(g->n_sub == 0 || (g->sub_ptr && g->sub_seg && g->seg_sub_ptr && g->seg_row && g->colidx),
+                "attention graph: null pointer");
+    OEA_REQUIRE(0 <= g->sub0 && g->sub0 <= g->sub1 && g->sub1 <= g->n_sub && 0 <= g->seg0 && g->seg0 <= g->seg1 &&
+                g->seg1 <= g->n_seg, "segment / sub-segment range");
+    OEA_REQUIRE(0 <= g->agg_row0 && g->agg_row0 <= g->agg_row1 && g->agg_row1 <= g->agg_rows && 0 <= g->agg_slot0 &&
+                g->agg_slot0 <= g->agg_slot1, "aggregate row / slot range");
+    OEA_REQUIRE(0 <= g->t_row0 && g->t_row0 <= g->t_row1 && g->t_row1 <= g->t_rows && 0 <= g->t_slot0 &&
+                g->t_slot0 <= g->t_slot1, "transposed row / slot range");
     return OEA_OK;
 }
 
@@ -280,61 +246,82 @@ static int check_graph(const oea_attn_graph *g) {
 
 extern "C" {
 
-size_t oea_sparse_attn_workspace_floats(int64_t n_sub, int64_t n_seg) { return (size_t)(2 * n_sub + 2 * n_seg + 256); }
+size_t oea_sparse_attn_workspace_floats(const oea_attn_graph *g) {
+    if (!g) return 0;
+    const int64_t slots = g->agg_slot1 > g->t_slot1 ? g->agg_slot1 : g->t_slot1;
+    return (size_t)(2 * g->n_sub + 2 * g->n_seg + slots + 256);
+}
 
 int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v, int32_t dim, int32_t ld,
-                        float lrelu_slope, float *out, float *alpha, float *workspace, void *stream) {
+                        float lrelu_slope, float *out, float *alpha, float *workspace, int32_t phases, void *stream) {
     const int rc = check_graph(g);
     if (rc != OEA_OK) return rc;
-    OEA_REQUIRE(z && v && out && alpha && workspace, "null pointer");
+    OEA_REQUIRE(alpha && workspace, "null pointer");
     OEA_REQUIRE(dim > 0 && dim <= ld && ld % 4 == 0, "dim <= ld, ld % 4 == 0");
-    if (g->n_sub == 0) return OEA_OK;
+    OEA_REQUIRE(phases & (OEA_ATTN_ALPHA | OEA_ATTN_AGGREGATE), "phases: OEA_ATTN_ALPHA | OEA_ATTN_AGGREGATE");
     hipStream_t st = oea::as_stream(stream);
     float *sub_m = workspace, *sub_l = sub_m + g->n_sub, *seg_m = sub_l + g->n_sub, *seg_l = seg_m + g->n_seg;
-    const unsigned grid = (unsigned)oea::ceil_div(g->n_sub, 4);
-    attn_sub_stats_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->n_sub, z, lrelu_slope, sub_m, sub_l);
-    attn_seg_combine_kernel<<<(unsigned)oea::ceil_div(g->n_seg, 256), 256, 0, st>>>(g->seg_sub_ptr, g->n_seg, sub_m, sub_l,
-                                                                                   seg_m, seg_l);
-#define CALL(IT)                                                                                                     \
-    attn_aggregate_kernel<IT><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->seg_row, g->n_sub,    \
-                                                    g->colidx, z, v, dim, ld, lrelu_slope, seg_m, seg_l, out, alpha, \
-                                                    g->unique_rows)
-    OEA_ATTN_DISPATCH(ld, CALL);
-#undef CALL
-    OEA_CHECK_HIP(hipGetLastError());
+    float *slot_vals = seg_l + g->n_seg;
+    if ((phases & OEA_ATTN_ALPHA) && g->sub1 > g->sub0) {
+        OEA_REQUIRE(z, "null pointer");
+        const unsigned grid = (unsigned)oea::ceil_div(g->sub1 - g->sub0, 4);
+        attn_sub_stats_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, lrelu_slope,
+                                                    sub_m, sub_l, seg_m, seg_l, alpha);
+        if (g->n_sub > g->n_seg) {          // some segment has several sub-segments
+            attn_seg_combine_kernel<<<(unsigned)oea::ceil_div(g->seg1 - g->seg0, 256), 256, 0, st>>>(
+                g->seg_sub_ptr, g->seg0, g->seg1, sub_m, sub_l, seg_m, seg_l);
+            attn_alpha_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, lrelu_slope,
+                                                    seg_m, seg_l, alpha);
+        }
+        OEA_CHECK_HIP(hipGetLastError());
+    }
+    if ((phases & OEA_ATTN_AGGREGATE) && g->agg_row1 > g->agg_row0) {
+        OEA_REQUIRE(v && out && g->agg_rowptr && g->agg_colidx, "null pointer");
+        const float *vals = alpha;
+        if (g->agg_edge) {
+            const int64_t n = g->agg_slot1 - g->agg_slot0;
+            if (n > 0)
+                attn_slot_values_kernel<<<(unsigned)oea::ceil_div(n, 256), 256, 0, st>>>(g->agg_edge, g->agg_slot0, g->agg_slot1,
+                                                                                       alpha, slot_vals);
+            vals = slot_vals;
+        }
+        return oea_spmm_csr(g->agg_rowptr + g->agg_row0, g->agg_colidx, vals, g->agg_row1 - g->agg_row0, v, dim, ld, 0, nullptr,
+                            out + g->agg_row0 * (int64_t)ld, ld, g->agg_split, stream);
+    }
     return OEA_OK;
 }
 
 int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v, const float *alpha, const float *dout,
                         int32_t dim, int32_t ld, float lrelu_slope, float *dz, float *dv, float *workspace,
-                        void *stream) {
+                        int32_t phases, void *stream) {
     const int rc = check_graph(g);
     if (rc != OEA_OK) return rc;
-    // a rank of a row-sharded job passes two partial graphs: its segments only (n_tsub = 0 -> dz of its edges) and
-    // the transposed lists of its column block only (n_sub = 0 -> dv rows of that block, alpha / dout of ALL edges)
-    OEA_REQUIRE(g->n_tsub == 0 || (g->t_sub_ptr && g->t_sub_col && g->t_row && g->t_edge), "attention graph: transposed lists missing");
-    OEA_REQUIRE(v && alpha && dout && dv && workspace && (g->n_sub == 0 || (z && dz)), "null pointer");
+    OEA_REQUIRE(alpha && dout && workspace, "null pointer");
     OEA_REQUIRE(dim > 0 && dim <= ld && ld % 4 == 0, "dim <= ld, ld % 4 == 0");
+    OEA_REQUIRE(phases & (OEA_ATTN_DZ | OEA_ATTN_DV), "phases: OEA_ATTN_DZ | OEA_ATTN_DV");
     hipStream_t st = oea::as_stream(stream);
-    if (g->n_sub > 0) {
-        float *sub_c = workspace;
-        const unsigned grid = (unsigned)oea::ceil_div(g->n_sub, 4);
-#define CALL(IT)                                                                                                    \
-    attn_bwd_dalpha_kernel<IT><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_row, g->n_sub, g->colidx, v, alpha, \
+    float *sub_c = workspace, *slot_vals = workspace + 2 * g->n_sub + 2 * g->n_seg;
+    if ((phases & OEA_ATTN_DZ) && g->sub1 > g->sub0) {
+        OEA_REQUIRE(z && v && dz, "null pointer");
+        const unsigned grid = (unsigned)oea::ceil_div(g->sub1 - g->sub0, 4);
+#define CALL(IT)                                                                                                      \
+    attn_bwd_dalpha_kernel<IT><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->seg_row, g->sub0, g->sub1, g->colidx, v, alpha, \
                                                      dout, dim, ld, dz, sub_c)
         OEA_ATTN_DISPATCH(ld, CALL);
 #undef CALL
-        attn_bwd_dz_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->n_sub, z, alpha, sub_c, lrelu_slope, dz);
+        attn_bwd_dz_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c,
+                                                 lrelu_slope, dz);
+        OEA_CHECK_HIP(hipGetLastError());
     }
-    if (g->n_tsub > 0) {
-        const unsigned grid = (unsigned)oea::ceil_div(g->n_tsub, 4);
-#define CALL(IT)                                                                                                  \
-    attn_bwd_v_kernel<IT><<<grid, 256, 0, st>>>(g->t_sub_ptr, g->t_sub_col, g->n_tsub, g->t_row, g->t_edge, alpha, \
-                                                dout, dim, ld, dv, g->t_any_split)
-        OEA_ATTN_DISPATCH(ld, CALL);
-#undef CALL
+    if ((phases & OEA_ATTN_DV) && g->t_row1 > g->t_row0) {
+        OEA_REQUIRE(dv && g->t_rowptr && g->t_row && g->t_edge, "attention graph: transposed lists missing");
+        const int64_t n = g->t_slot1 - g->t_slot0;
+        if (n > 0)
+            attn_slot_values_kernel<<<(unsigned)oea::ceil_div(n, 256), 256, 0, st>>>(g->t_edge, g->t_slot0, g->t_slot1, alpha,
+                                                                                   slot_vals);
+        return oea_spmm_csr(g->t_rowptr + g->t_row0, g->t_row, slot_vals, g->t_row1 - g->t_row0, dout, dim, ld, 0, nullptr,
+                            dv + g->t_row0 * (int64_t)ld, ld, g->t_split, stream);
     }
-    OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
 

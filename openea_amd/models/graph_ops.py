@@ -68,7 +68,8 @@ class EdgeGraph:
     * the transposed edge list (per column: output row + edge id) for the attention backward.
     """
 
-    SUB = 256          # edges per sub-segment / column chunk
+    SUB = 256          # edges per softmax sub-segment
+    HUB, CHUNK = 768, 512      # aggregate rows / columns with more than HUB slots are summed in chunks of CHUNK (oea_csr_split)
 
     def __init__(self, rows, cols, vals, shape, dev, grouping='row'):
         rows = np.asarray(rows, np.int64)
@@ -83,7 +84,7 @@ class EdgeGraph:
         at = sp.csr_matrix(a.T)
         at.sort_indices()
         self.fwd, self.bwd = CsrOperand(a, dev), CsrOperand(at, dev)      # A and A^T (row-sharded under torch.distributed)
-        # ---- attention structures over the ordered edge list ------------------------------------
+        # ---- attention structures over the ordered edge list: built on first use (most graphs only aggregate) ----
         if grouping == 'row':
             order = np.lexsort((cols, rows))                       # canonical row-major order
             rows_o, cols_o, vals_o = rows[order], cols[order], vals[order]
@@ -94,56 +95,69 @@ class EdgeGraph:
         self.grouping = grouping
         if grouping == 'reorder':
             self._init_reorder(rows, cols, dev)
+        self._rows_o, self._cols_o = rows_o, cols_o
         change = np.flatnonzero(np.diff(rows_o)) + 1 if self.nnz else np.zeros(0, np.int64)
         seg_start = np.concatenate([[0], change]).astype(np.int64) if self.nnz else np.zeros(0, np.int64)
-        seg_ptr = np.concatenate([seg_start, [self.nnz]]).astype(np.int64)
-        seg_row = rows_o[seg_start] if self.nnz else np.zeros(0, np.int64)
-        self.seg_ptr_host, self.seg_row_host = seg_ptr, seg_row
-        self.unique_rows = len(np.unique(seg_row)) == len(seg_row) if self.nnz else True
+        self.seg_ptr_host = np.concatenate([seg_start, [self.nnz]]).astype(np.int64)
+        self.seg_row_host = rows_o[seg_start] if self.nnz else np.zeros(0, np.int64)
+        self.unique_rows = len(np.unique(self.seg_row_host)) == len(self.seg_row_host) if self.nnz else True
         self.e_rows = torch.from_numpy(rows_o).to(dev)             # int64: torch index ops on edge vectors
         self.e_cols = torch.from_numpy(cols_o).to(dev)
         self.e_colidx = ops.to_ids(cols_o, dev)
         self.e_vals = ops.to_vec(vals_o, dev)
-        # sub-segments of at most SUB edges (balanced work on power-law degrees)
-        sub_ptr, sub_seg, seg_sub_ptr = split_ranges(seg_ptr, self.SUB)
-        t_order = np.lexsort((rows_o, cols_o))                     # edges grouped by column
-        counts = np.bincount(cols_o, minlength=shape[1]) if self.nnz else np.zeros(shape[1], np.int64)
-        t_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        t_sub_ptr, t_sub_col, _ = split_ranges(t_ptr, self.SUB, drop_empty=True)
-        self.attn = ops.attn_graph(ops.to_ids(sub_ptr, dev), ops.to_ids(sub_seg, dev), ops.to_ids(seg_sub_ptr, dev),
-                                   ops.to_ids(seg_row, dev), self.e_colidx, ops.to_ids(t_sub_ptr, dev),
-                                   ops.to_ids(t_sub_col, dev), ops.to_ids(rows_o[t_order], dev), ops.to_ids(t_order, dev),
-                                   self.unique_rows, len(t_sub_col) > int((counts > 0).sum()))
-        # ---- row-sharded attention under torch.distributed (one exchange per operator output) --------
-        # rank r owns a block of SEGMENTS (= output rows, balanced by edges; canonical order makes its edges one
-        # contiguous range) for out / alpha / dz, and a block of COLUMNS (balanced by incoming edges) for dv.
+        self._attn = None
+        self._shard = None
+        self._cut = (self.SUB, self.HUB, self.CHUNK)           # as set when the graph was made (the build is lazy)
+
+    @property
+    def attn(self):
+        if self._attn is None:
+            self._build_attn()
+        return self._attn
+
+    @property
+    def shard(self):
+        """the bounds of this rank's blocks when the job is row-sharded (torch.distributed, world > 1), else None"""
+        if self._attn is None:
+            self._build_attn()
+        return self._shard
+
+    def _build_attn(self):
+        """softmax segments cut into sub-segments + the aggregate as a CSR over the OUTPUT rows (slots in edge order inside
+        a row: the fixed summation order) + the transposed CSR for dv -> oea_attn_graph.
+        Row-sharded attention under torch.distributed (one exchange per operator output), BOTH groupings:
+        rank r owns a block of SEGMENTS (balanced by edges: a contiguous edge range in either order) for the softmax
+        statistics, alpha and dz; a block of OUTPUT ROWS (balanced by nonzeros) for the aggregate; a block of COLUMNS
+        (balanced by incoming edges) for dv.  Every rank holds the whole graph, the C call gets its ranges."""
         from . import dist as mdist
+        dev, nnz, shape = self.dev, self.nnz, self.shape
+        rows_o, cols_o, seg_ptr, seg_row = self._rows_o, self._cols_o, self.seg_ptr_host, self.seg_row_host
+        sub_ptr, sub_seg, seg_sub_ptr = split_ranges(seg_ptr, self._cut[0])
+        canonical = nnz == 0 or bool(np.all(np.diff(rows_o) >= 0))
+        agg_order = np.arange(nnz, dtype=np.int64) if canonical else np.argsort(rows_o, kind="stable")
+        agg_rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows_o, minlength=shape[0]))]).astype(np.int64)
+        t_order = np.argsort(cols_o, kind="stable")                # edges grouped by column, edge order inside a column
+        t_rowptr = np.concatenate([[0], np.cumsum(np.bincount(cols_o, minlength=shape[1]))]).astype(np.int64)
         rank, ws = mdist.world()
-        self.shard = None
-        if ws > 1 and self.unique_rows and grouping == 'row' and self.nnz > 0:
+        kw = {}
+        a_rng = t_rng = None
+        if ws > 1 and nnz > 0:
             sb = mdist.balanced_bounds(seg_ptr, ws)
-            s_lo, s_hi = sb[rank], sb[rank + 1]
-            e_lo, e_hi = int(seg_ptr[s_lo]), int(seg_ptr[s_hi])
-            l_sub_ptr, l_sub_seg, l_seg_sub_ptr = split_ranges(seg_ptr[s_lo: s_hi + 1] - e_lo, self.SUB)
-            if s_hi == s_lo:
-                l_sub_ptr, l_sub_seg, l_seg_sub_ptr = np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64)
-            row_bounds = [0] + [int(seg_row[sb[r]]) if sb[r] < len(seg_row) else shape[0] for r in range(1, ws)] + [shape[0]]
-            edge_bounds = [int(seg_ptr[b]) for b in sb]
-            cb = mdist.balanced_bounds(t_ptr, ws)
-            c_lo, c_hi = cb[rank], cb[rank + 1]
-            t_lo, t_hi = int(t_ptr[c_lo]), int(t_ptr[c_hi])
-            lt_sub_ptr, lt_sub_col, _ = split_ranges(t_ptr[c_lo: c_hi + 1] - t_lo, self.SUB, drop_empty=True)
-            empty = ops.to_ids(np.zeros(0, np.int32), dev)
-            one0 = ops.to_ids(np.zeros(1, np.int32), dev)
-            seg_part = ops.attn_graph(ops.to_ids(l_sub_ptr, dev), ops.to_ids(l_sub_seg, dev), ops.to_ids(l_seg_sub_ptr, dev),
-                                      ops.to_ids(seg_row[s_lo:s_hi], dev), ops.to_ids(cols_o[e_lo:e_hi], dev),
-                                      one0, empty, empty, empty, True, False)
-            lcounts = counts[c_lo:c_hi]
-            t_part = ops.attn_graph(one0, empty, one0, empty, empty, ops.to_ids(lt_sub_ptr, dev),
-                                    ops.to_ids(lt_sub_col + c_lo, dev), ops.to_ids(rows_o[t_order][t_lo:t_hi], dev),
-                                    ops.to_ids(t_order[t_lo:t_hi], dev), True, len(lt_sub_col) > int((lcounts > 0).sum()))
-            self.shard = dict(seg=seg_part, t=t_part, e_lo=e_lo, e_hi=e_hi, row_bounds=row_bounds, edge_bounds=edge_bounds,
-                              col_bounds=cb)
+            ab = mdist.balanced_bounds(agg_rowptr, ws)
+            cb = mdist.balanced_bounds(t_rowptr, ws)
+            a_rng, t_rng = (ab[rank], ab[rank + 1]), (cb[rank], cb[rank + 1])
+            kw = dict(seg_range=(sb[rank], sb[rank + 1]), sub_range=(int(seg_sub_ptr[sb[rank]]), int(seg_sub_ptr[sb[rank + 1]])),
+                      agg_rows=a_rng, agg_slots=(int(agg_rowptr[a_rng[0]]), int(agg_rowptr[a_rng[1]])),
+                      t_rows=t_rng, t_slots=(int(t_rowptr[t_rng[0]]), int(t_rowptr[t_rng[1]])))
+            self._shard = dict(edge_bounds=[int(seg_ptr[b]) for b in sb], row_bounds=ab, col_bounds=cb)
+        self._attn = ops.attn_graph(
+            ops.to_ids(sub_ptr, dev), ops.to_ids(sub_seg, dev), ops.to_ids(seg_sub_ptr, dev), ops.to_ids(seg_row, dev), self.e_colidx,
+            ops.to_ids(agg_rowptr, dev), self.e_colidx if canonical else ops.to_ids(cols_o[agg_order], dev),
+            None if canonical else ops.to_ids(agg_order, dev),
+            ops.to_ids(t_rowptr, dev), ops.to_ids(rows_o[t_order], dev), ops.to_ids(t_order, dev),
+            agg_split=ops.csr_split(agg_rowptr, self._cut[1], self._cut[2], dev=dev, row_range=a_rng),
+            t_split=ops.csr_split(t_rowptr, self._cut[1], self._cut[2], dev=dev, row_range=t_rng),
+            **kw)
 
 
 def _pattern_csr(major, minor, n_major, dev):
@@ -219,7 +233,9 @@ class SpmmFn(torch.autograd.Function):
 
 
 class SparseAttnFn(torch.autograd.Function):
-    """out = sparse_softmax(leaky_relu(z)) . v over the graph's segments (oea_sparse_attn_fwd/bwd)."""
+    """out = sparse_softmax(leaky_relu(z)) . v over the graph's segments (oea_sparse_attn_fwd/bwd; no atomics: two runs
+    give identical bits).  Row-sharded job: statistics / alpha / dz on this rank's block of segments, the aggregate on
+    its block of output rows, dv on its block of columns; one all-gather per output."""
 
     @staticmethod
     def forward(ctx, z, v, graph, slope):
@@ -228,13 +244,14 @@ class SparseAttnFn(torch.autograd.Function):
         sh = graph.shard
         if sh is None:
             out, alpha = ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0])
-        else:       # own segments only, then one all-gather of the output rows (and of alpha, for the dv half of the backward)
+        else:
             from . import dist as mdist
-            out, a_loc = ops.sparse_attn_fwd(sh['seg'], z[sh['e_lo']: sh['e_hi']].contiguous(), v, v.shape[1], slope, graph.shape[0])
-            out = mdist.allgather_blocks(out, sh['row_bounds'])
+            out = torch.empty((graph.shape[0], v.shape[1]), dtype=torch.float32, device=v.device)
             alpha = torch.empty_like(z)
-            alpha[sh['e_lo']: sh['e_hi']] = a_loc
+            ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0], out=out, alpha=alpha, phases=ops.ATTN_ALPHA)
             mdist.allgather_blocks(alpha, sh['edge_bounds'])
+            ops.sparse_attn_fwd(graph.attn, z, v, v.shape[1], slope, graph.shape[0], out=out, alpha=alpha, phases=ops.ATTN_AGGREGATE)
+            mdist.allgather_blocks(out, sh['row_bounds'])
         ctx.graph, ctx.slope = graph, slope
         ctx.save_for_backward(z, v, alpha)
         return out
@@ -249,12 +266,10 @@ class SparseAttnFn(torch.autograd.Function):
             dz, dv = ops.sparse_attn_bwd(g.attn, z, v, alpha, dout, v.shape[1], ctx.slope)
             return dz, dv, None, None
         from . import dist as mdist
-        lo, hi = sh['e_lo'], sh['e_hi']
-        dz_loc, _ = ops.sparse_attn_bwd(sh['seg'], z[lo:hi].contiguous(), v, alpha[lo:hi].contiguous(), dout, v.shape[1], ctx.slope)
-        dz = torch.empty_like(z)
-        dz[lo:hi] = dz_loc
+        dz, dv = torch.empty_like(z), torch.empty_like(v)
+        ops.sparse_attn_bwd(g.attn, z, v, alpha, dout, v.shape[1], ctx.slope, dz=dz, dv=dv, phases=ops.ATTN_DZ)
         mdist.allgather_blocks(dz, sh['edge_bounds'])
-        _, dv = ops.sparse_attn_bwd(sh['t'], z, v, alpha, dout, v.shape[1], ctx.slope)      # dv rows of this rank's column block
+        ops.sparse_attn_bwd(g.attn, z, v, alpha, dout, v.shape[1], ctx.slope, dz=dz, dv=dv, phases=ops.ATTN_DV)
         mdist.allgather_blocks(dv, sh['col_bounds'])
         return dz, dv, None, None
 

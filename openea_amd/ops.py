@@ -625,33 +625,65 @@ def sgd_rows_(w, grad_t, dim, normalize, lr):
 # -------------------------------------------------------------------------------------------
 
 
-def attn_graph(sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, t_sub_ptr, t_sub_col, t_row, t_edge, unique_rows,
-               t_any_split):
-    """pack the device arrays of an attention graph (keeps them alive)."""
-    g = _lib.AttnGraph(sub_ptr.data_ptr(), sub_seg.data_ptr(), seg_sub_ptr.data_ptr(), seg_row.data_ptr(),
-                       colidx.data_ptr(), sub_seg.numel(), seg_row.numel(), t_sub_ptr.data_ptr(), t_sub_col.data_ptr(),
-                       t_row.data_ptr(), t_edge.data_ptr(), t_sub_col.numel(), int(bool(unique_rows)), int(bool(t_any_split)))
-    g._keep = (sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, t_sub_ptr, t_sub_col, t_row, t_edge)
+ATTN_ALPHA, ATTN_AGGREGATE, ATTN_DZ, ATTN_DV = 1, 2, 1, 2
+
+
+def attn_graph(sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, agg_rowptr, agg_colidx, agg_edge, t_rowptr, t_row, t_edge,
+               agg_split=None, t_split=None, seg_range=None, sub_range=None, agg_rows=None, agg_slots=None, t_rows=None,
+               t_slots=None):
+    """pack the device arrays of an attention graph (keeps them alive).  agg_edge None: the edge order is the
+    aggregate's CSR order.  The *_range / *_rows / *_slots arguments restrict the ranges a call works on (a rank's blocks
+    of a row-sharded job); default: the whole graph."""
+    n_sub, n_seg = sub_seg.numel(), seg_row.numel()
+    n_agg, n_t, nnz = agg_rowptr.numel() - 1, t_rowptr.numel() - 1, colidx.numel()
+    s0, s1 = sub_range if sub_range is not None else (0, n_sub)
+    g0, g1 = seg_range if seg_range is not None else (0, n_seg)
+    a0, a1 = agg_rows if agg_rows is not None else (0, n_agg)
+    as0, as1 = agg_slots if agg_slots is not None else (0, nnz)
+    t0, t1 = t_rows if t_rows is not None else (0, n_t)
+    ts0, ts1 = t_slots if t_slots is not None else (0, nnz)
+    g = _lib.AttnGraph(sub_ptr.data_ptr(), sub_seg.data_ptr(), seg_sub_ptr.data_ptr(), seg_row.data_ptr(), colidx.data_ptr(),
+                       n_sub, n_seg, agg_rowptr.data_ptr(), agg_colidx.data_ptr(),
+                       agg_edge.data_ptr() if agg_edge is not None else None, n_agg,
+                       C.pointer(agg_split) if agg_split is not None else None,
+                       t_rowptr.data_ptr(), t_row.data_ptr(), t_edge.data_ptr(), n_t,
+                       C.pointer(t_split) if t_split is not None else None,
+                       int(s0), int(s1), int(g0), int(g1), int(a0), int(a1), int(as0), int(as1), int(t0), int(t1), int(ts0), int(ts1))
+    g._keep = (sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, agg_rowptr, agg_colidx, agg_edge, t_rowptr, t_row, t_edge,
+               agg_split, t_split)
+    g._splits = (agg_split, t_split)
     return g
 
 
-def sparse_attn_fwd(g, z, v, dim, slope, n_rows):
-    """-> (out [n_rows, ld], alpha [nnz])."""
-    out = torch.zeros((n_rows, v.shape[1]), dtype=torch.float32, device=v.device)
-    alpha = torch.empty_like(z)
-    ws = torch.empty(lib().oea_sparse_attn_workspace_floats(g.n_sub, g.n_seg), dtype=torch.float32, device=v.device)
+def _attn_ws(g, ld, dev):
+    for sp_ in g._splits:
+        if sp_ is not None:
+            _split_partials(sp_, ld, dev)
+    return torch.empty(lib().oea_sparse_attn_workspace_floats(C.byref(g)), dtype=torch.float32, device=dev)
+
+
+def sparse_attn_fwd(g, z, v, dim, slope, n_rows, out=None, alpha=None, phases=ATTN_ALPHA | ATTN_AGGREGATE):
+    """-> (out [n_rows, ld], alpha [nnz]); every row / edge of the graph's ranges is written (no zero-fill needed for a
+    whole-graph call; a sharded caller passes its own out / alpha)."""
+    if out is None:
+        out = torch.empty((n_rows, v.shape[1]), dtype=torch.float32, device=v.device)
+    if alpha is None:
+        alpha = torch.empty_like(z)
+    ws = _attn_ws(g, v.shape[1], v.device)
     check(lib().oea_sparse_attn_fwd(C.byref(g), _p(z), _p(v), dim, v.shape[1], float(slope), _p(out), _p(alpha), _p(ws),
-                                    _stream()))
+                                    int(phases), _stream()))
     return out, alpha
 
 
-def sparse_attn_bwd(g, z, v, alpha, dout, dim, slope):
+def sparse_attn_bwd(g, z, v, alpha, dout, dim, slope, dz=None, dv=None, phases=ATTN_DZ | ATTN_DV):
     """-> (dz [nnz], dv [n_cols, ld])."""
-    dz = torch.empty_like(z)
-    dv = torch.zeros_like(v)
-    ws = torch.empty(lib().oea_sparse_attn_workspace_floats(g.n_sub, g.n_seg), dtype=torch.float32, device=v.device)
+    if dz is None:
+        dz = torch.empty_like(z)
+    if dv is None:
+        dv = torch.empty_like(v)
+    ws = _attn_ws(g, v.shape[1], v.device)
     check(lib().oea_sparse_attn_bwd(C.byref(g), _p(z), _p(v), _p(alpha), _p(dout), dim, v.shape[1], float(slope), _p(dz),
-                                    _p(dv), _p(ws), _stream()))
+                                    _p(dv), _p(ws), int(phases), _stream()))
     return dz, dv
 
 

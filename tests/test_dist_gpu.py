@@ -72,6 +72,14 @@ with contextlib.redirect_stdout(buf):
     (att * up).sum().backward()
     attn_res = [att.detach().cpu().numpy(), z.grad.cpu().numpy(), v.grad.cpu().numpy()]
     assert (graph.shard is not None) == (world > 1)
+    # the same in the AS-FED edge order with TF1's run grouping (AliNet's default): several segments per output row
+    graph_r = EdgeGraph(er, rng.randint(0, n, nnz), rng.rand(nnz).astype(np.float32), (n, n), ops.device(), grouping="runs")
+    zr = torch.from_numpy(rng.standard_normal(graph_r.nnz).astype(np.float32)).cuda().requires_grad_(True)
+    vr = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda().requires_grad_(True)
+    att_r = sparse_attention(graph_r, zr, vr)
+    (att_r * up).sum().backward()
+    attn_res += [att_r.detach().cpu().numpy(), zr.grad.cpu().numpy(), vr.grad.cpu().numpy()]
+    assert (graph_r.shard is not None) == (world > 1) and not graph_r.unique_rows
     # AliNet end to end: sharded aggregates + sharded attention inside the autograd graph, device negative sampler
     a = AliNet()
     a.set_args(get_args("AliNet", output=os.environ["OEA_OUT"] + "/out/", training_data="synthetic/small/", dataset_division="f/",
@@ -96,7 +104,7 @@ with contextlib.redirect_stdout(buf):
         extra[nm] = b.ent_embeds.raw() if hasattr(b.ent_embeds, "raw") else b.ent_embeds.var.cpu().numpy()
 rank = int(os.environ.get("RANK", "0"))
 np.savez(os.environ["OEA_OUT"] + "/result_w%d_r%d.npz" % (world, rank), ent=m.ent_embeds.raw(), rel=m.rel_embeds.raw(),
-         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], alinet=alinet_out, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
+         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], att_r=attn_res[3], att_r_dz=attn_res[4], att_r_dv=attn_res[5], alinet=alinet_out, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
          rotate=extra["BootEA_RotatE"])
 if world > 1:
     dist.barrier()
@@ -153,11 +161,11 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     # sharded GCN aggregates: same rows computed by the same code; only hub-row atomics may reorder
     assert np.array_equal(r0["gcn_out"], r1["gcn_out"])
     np.testing.assert_allclose(r0["gcn_out"], single["gcn_out"], rtol=1e-4, atol=1e-5)
-    # sharded sparse attention: the same per-segment / per-column code on the same data; hub rows and hub columns are
-    # combined from their sub-segments with fp32 atomics, so agreement is to rounding, not bitwise
-    for key in ("att", "att_dz", "att_dv"):
+    # sharded sparse attention ('row' and 'runs' grouping): the same per-segment / per-row / per-column code on the same
+    # data in the same fixed summation order (no atomics since round 3) -> the SAME BITS as the single-process operator
+    for key in ("att", "att_dz", "att_dv", "att_r", "att_r_dz", "att_r_dv"):
         assert np.array_equal(r0[key], r1[key])                       # all-gathered results: identical on every rank
-        np.testing.assert_allclose(r0[key], single[key], rtol=5e-5, atol=5e-5)      # fp32 atomic sums in another order
+        assert np.array_equal(r0[key], single[key]), key
     assert np.array_equal(r0["alinet"], r1["alinet"])                  # replicas stay in lock-step through 4 Adam epochs
     assert np.linalg.norm(r0["alinet"] - single["alinet"]) <= 5e-3 * np.linalg.norm(single["alinet"])   # Adam amplifies the rounding
     for key in ("mtranse", "bootea", "transd", "rotate"):
@@ -166,15 +174,21 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     assert single["rotate"].dtype == np.float64
 
 
-def test_bench_two_ranks_like_the_driver(tmp_path):
-    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` (the driver's launch line) with both
-    ranks on GPU 0 and gloo collectives (OEA_BENCH_ONE_GPU / OEA_BENCH_BACKEND, bench.py's test hooks): the partitioned
-    step runs through the timed regions and rank 0 prints one well-formed line."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
+    """`python bench.py --gpus 2` (bench.py starts its own ranks) and `python -m torch.distributed.run --nproc-per-node 2
+    bench.py --gpus 2 ...` (the driver's documented launch line), both ranks on GPU 0 with gloo collectives
+    (OEA_BENCH_ONE_GPU / OEA_BENCH_BACKEND, bench.py's test hooks): the partitioned step and the row-sharded eval /
+    neighbour legs run through the timed regions and rank 0 prints one well-formed line."""
     import json
     env = dict(os.environ, OEA_BENCH_ONE_GPU="1", OEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
-           "--repeats", "3"]
+    env.pop("WORLD_SIZE", None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--repeats", "3"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -182,5 +196,7 @@ def test_bench_two_ranks_like_the_driver(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "weak" and j["value"] > 0
     assert j["roofline"]["launches_timed"] > 0 and j["roofline"]["avg_kernel_us"] > 0 and j["roofline"]["apply_rows_avg_us"] > 0
-    assert j["extra"]["exchange_bytes_per_step_per_rank"] > 0
-    assert j["config"]["parallelism"] == "dp2"
+    assert 0 < j["roofline"]["frac"] <= 1 and 0 < j["roofline"]["frac_sec8d"] <= 1
+    assert j["extra"]["exchange_bytes_per_step_per_rank"] > 0 and j["extra"]["collective_world_size"] == 2
+    assert j["extra"]["eval_pairs_per_s_inner"] > 0 and j["extra"]["neighbour_rows_per_s"] > 0
+    assert j["config"]["parallelism"].startswith("dp2") and j["config"]["global_batch"] == 10000

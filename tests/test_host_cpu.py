@@ -34,6 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.SamplerSide) == 48        # 5 pointers/u64 + 2 int32
     assert C.sizeof(_lib.RotateCfg) == 72          # 6 doubles + int64 + 4 x int32 of oea_rotate_cfg
     assert C.sizeof(_lib.CsrSplit) == 72           # 4 pointers + 3 int32 (+ pad) + 2 pointers + int64 of oea_csr_split
+    assert C.sizeof(_lib.AttnGraph) == 29 * 8      # 13 pointers + 16 int64 of oea_attn_graph
 
 
 def test_host_side_planners_of_the_library():
@@ -51,6 +52,10 @@ def test_host_side_planners_of_the_library():
     assert lib.oea_csls_means_workspace_bytes(10500, 10500, 10) > 0
     assert lib.oea_csls_means_workspace_bytes(70000, 70000, 10) > 0
     assert lib.oea_csls_means_workspace_bytes(10500, 10500, 64) == 0
+    # sparse attention: statistics of every sub-segment / segment + one value per CSR slot of the call's ranges
+    g = _lib.AttnGraph()
+    g.n_sub, g.n_seg, g.agg_slot1, g.t_slot1 = 1000, 600, 5000, 7000
+    assert lib.oea_sparse_attn_workspace_floats(g) >= 2 * 1000 + 2 * 600 + 7000
     # entity-id partition arithmetic
     assert lib.oea_part_rows_per_rank(30000, 8) == 3750 and lib.oea_part_rows_per_rank(30001, 8) == 3751
     assert lib.oea_part_send_floats(30000, 76, 8) == 8 * 3750 * 77
@@ -287,3 +292,26 @@ def test_native_greedy_matching_equals_python():
         w = np.round(rng.rand(len(pairs)), 1).astype(np.float32)
         m = ops.greedy_matching([p[0] for p in pairs], [p[1] for p in pairs], w)
         assert {p for p, keep in zip(pairs, m) if keep} == greedy_weight_matching(pairs, w)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE: one torch.distributed.run with N ranks on 127.0.0.1 and the same flags"""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
