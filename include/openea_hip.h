@@ -468,7 +468,7 @@ typedef struct oea_attn_graph {
     const int32_t *seg_sub_ptr;  /* [n_seg+1] sub-segment range of each segment */
     const int32_t *seg_row;      /* [n_seg]   output row of each segment */
     const int32_t *colidx;       /* [nnz]     value row (column) of each edge */
-    int64_t n_sub, n_seg;
+    int64_t n_sub, n_seg, nnz;   /* nnz = sub_ptr[n_sub]: the number of edges */
     /* the aggregate out = P . v as a CSR over the OUTPUT rows (fixed summation order: slot order inside a row) */
     const int32_t *agg_rowptr;   /* [agg_rows+1] slot range of each output row */
     const int32_t *agg_colidx;   /* [nnz] value row of each slot */

@@ -42,7 +42,7 @@ class CsrSplit(C.Structure):
 class AttnGraph(C.Structure):
     """mirror of `oea_attn_graph` (include/openea_hip.h)."""
     _fields_ = [("sub_ptr", C.c_void_p), ("sub_seg", C.c_void_p), ("seg_sub_ptr", C.c_void_p), ("seg_row", C.c_void_p),
-                ("colidx", C.c_void_p), ("n_sub", C.c_int64), ("n_seg", C.c_int64),
+                ("colidx", C.c_void_p), ("n_sub", C.c_int64), ("n_seg", C.c_int64), ("nnz", C.c_int64),
                 ("agg_rowptr", C.c_void_p), ("agg_colidx", C.c_void_p), ("agg_edge", C.c_void_p), ("agg_rows", C.c_int64),
                 ("agg_split", C.POINTER(CsrSplit)),
                 ("t_rowptr", C.c_void_p), ("t_row", C.c_void_p), ("t_edge", C.c_void_p), ("t_rows", C.c_int64),

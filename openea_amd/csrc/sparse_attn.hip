@@ -49,9 +49,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float lrelu(float x, float a) { return x > 0.f ? x : a * x; }
+// reductions over the G consecutive lanes that share a sub-segment (G = 1: one thread per sub-segment -- graphs whose
+// softmax groups are a handful of edges, e.g. TF1's run grouping on a column-major adjacency; G = 64: one wave)
+template <int G>
+__device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 
 // K1: per sub-segment softmax statistics.  A segment that consists of this one sub-segment is finished here:
 // its (M, L) and its alphas are written, K2 / K3 never look at it.
+template <int G>
 __global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__restrict__ sub_ptr,
                                                              const int32_t *__restrict__ sub_seg,
                                                              const int32_t *__restrict__ seg_sub_ptr, int64_t sub0,
@@ -59,16 +74,16 @@ __global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__re
                                                              float *__restrict__ sub_m, float *__restrict__ sub_l,
                                                              float *__restrict__ seg_m, float *__restrict__ seg_l,
                                                              float *__restrict__ alpha) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= sub1) return;
+    const int lane = threadIdx.x % G;
+    const int64_t s = sub0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (s >= sub1) return;                                      // whole groups leave together (256 % G == 0)
     const int e0 = sub_ptr[s], e1 = sub_ptr[s + 1];
     float m = -INFINITY;
-    for (int e = e0 + lane; e < e1; e += W) m = fmaxf(m, lrelu(z[e], slope));
-    m = wave_max(m);
+    for (int e = e0 + lane; e < e1; e += G) m = fmaxf(m, lrelu(z[e], slope));
+    m = grp_max<G>(m);
     float l = 0.f;
-    for (int e = e0 + lane; e < e1; e += W) l += expf(lrelu(z[e], slope) - m);
-    l = wave_sum(l);
+    for (int e = e0 + lane; e < e1; e += G) l += expf(lrelu(z[e], slope) - m);
+    l = grp_sum<G>(l);
     const int g = sub_seg[s];
     const bool single = seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1;
     if (lane == 0) {
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_sub_stats_kernel(const int32_t *__re
     }
     if (single) {
         const float inv_l = 1.0f / l;
-        for (int e = e0 + lane; e < e1; e += W) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
+        for (int e = e0 + lane; e < e1; e += G) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
     }
 }
 
@@ -118,18 +133,24 @@ __global__ __launch_bounds__(256) void attn_seg_combine_kernel(const int32_t *__
 }
 
 // K3: alphas of the sub-segments of segments with SEVERAL sub-segments (the others were finished by K1)
+template <int G>
 __global__ __launch_bounds__(256) void attn_alpha_kernel(const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_seg,
                                                          const int32_t *__restrict__ seg_sub_ptr, int64_t sub0, int64_t sub1,
                                                          const float *__restrict__ z, float slope,
                                                          const float *__restrict__ seg_m, const float *__restrict__ seg_l,
                                                          float *__restrict__ alpha) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % G;
+    const int64_t s = sub0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (s >= sub1) return;
     const int g = sub_seg[s];
     if (seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1) return;
     const float m = seg_m[g], inv_l = 1.0f / seg_l[g];
-    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += W) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
+    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += G) alpha[e] = expf(lrelu(z[e], slope) - m) * inv_l;
+}
+
+__global__ __launch_bounds__(256) void attn_fill_kernel(float *__restrict__ dst, int64_t i0, int64_t i1, float v) {
+    const int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < i1) dst[i] = v;
 }
 
 // values of the aggregate's CSR slots [slot0, slot1): dst[slot] = alpha[edge_of_slot[slot]]
@@ -196,24 +217,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dalpha_kernel(const int32_t *__r
 }
 
 // B2 + B3: segment c (fixed order over its sub-segments), then d z of this sub-segment
+template <int G>
 __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_seg,
                                                           const int32_t *__restrict__ seg_sub_ptr, int64_t sub0,
                                                           int64_t sub1, const float *__restrict__ z,
                                                           const float *__restrict__ alpha, const float *__restrict__ sub_c,
                                                           float slope, float *__restrict__ dz) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x % G;
+    const int64_t s = sub0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (s >= sub1) return;
     const int g = sub_seg[s];
     const int q0 = seg_sub_ptr[g], q1 = seg_sub_ptr[g + 1];
     float c = 0.f;
     if (q1 - q0 <= kSerialSubs) {
         for (int q = q0; q < q1; ++q) c += sub_c[q];
-    } else {                                                     // hub segment: lanes stride over its sub-segments
-        for (int q = q0 + lane; q < q1; q += W) c += sub_c[q];
-        c = wave_sum(c);
+    } else {                                                     // hub segment: the group's lanes stride over its sub-segments
+        for (int q = q0 + lane; q < q1; q += G) c += sub_c[q];
+        c = grp_sum<G>(c);
     }
-    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += W) {
+    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += G) {
         const float de = alpha[e] * (dz[e] - c);
         dz[e] = de * (z[e] > 0.f ? 1.f : slope);
     }
@@ -228,9 +250,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restr
         else { oea::set_error("ld %d > 1280 unsupported", (int)(ld)); return OEA_EUNSUPPORTED; } \
     } while (0)
 
+// lanes per sub-segment of the element-wise kernels, from the average sub-segment length (a property of the graph: the
+// same on every rank of a sharded job and in every call, so the summation order -- and the bits -- never change)
+static int group_width(const oea_attn_graph *g) {
+    const double avg = g->n_sub > 0 ? (double)g->nnz / (double)g->n_sub : 0.0;
+    return avg <= 3.0 ? 1 : (avg <= 24.0 ? 8 : 64);
+}
+
 static int check_graph(const oea_attn_graph *g) {
     OEA_REQUIRE(g, "attention graph: null pointer");
-    OEA_REQUIRE(g->n_sub >= 0 && g->n_seg >= 0 && g->n_sub >= g->n_seg, "n_sub >= n_seg >= 0");
+    OEA_REQUIRE(g->n_sub >= 0 && g->n_seg >= 0 && g->n_sub >= g->n_seg && g->nnz >= g->n_seg, "nnz >= n_sub >= n_seg >= 0");
     OEA_REQUIRE(g->n_sub == 0 || (g->sub_ptr && g->sub_seg && g->seg_sub_ptr && g->seg_row && g->colidx),
                 "attention graph: null pointer");
     OEA_REQUIRE(0 <= g->sub0 && g->sub0 <= g->sub1 && g->sub1 <= g->n_sub && 0 <= g->seg0 && g->seg0 <= g->seg1 &&
@@ -264,14 +293,26 @@ int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v,
     float *slot_vals = seg_l + g->n_seg;
     if ((phases & OEA_ATTN_ALPHA) && g->sub1 > g->sub0) {
         OEA_REQUIRE(z, "null pointer");
-        const unsigned grid = (unsigned)oea::ceil_div(g->sub1 - g->sub0, 4);
-        attn_sub_stats_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, lrelu_slope,
-                                                    sub_m, sub_l, seg_m, seg_l, alpha);
-        if (g->n_sub > g->n_seg) {          // some segment has several sub-segments
-            attn_seg_combine_kernel<<<(unsigned)oea::ceil_div(g->seg1 - g->seg0, 256), 256, 0, st>>>(
-                g->seg_sub_ptr, g->seg0, g->seg1, sub_m, sub_l, seg_m, seg_l);
-            attn_alpha_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, lrelu_slope,
-                                                    seg_m, seg_l, alpha);
+        const int64_t ns = g->sub1 - g->sub0;
+        if (g->n_seg == g->nnz) {           // every softmax group is ONE edge: alpha = exp(0) / 1 = 1, nothing to compute
+            OEA_REQUIRE(g->sub_ptr, "null pointer");
+            attn_fill_kernel<<<(unsigned)oea::ceil_div(ns, 256), 256, 0, st>>>(alpha, g->sub0, g->sub1, 1.0f);   // sub-segment id == edge id
+        } else {
+            const int G = group_width(g);
+#define CALL(GW)                                                                                                        \
+    do {                                                                                                                \
+        const unsigned grid = (unsigned)oea::ceil_div(ns * GW, 256);                                                    \
+        attn_sub_stats_kernel<GW><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z,    \
+                                                        lrelu_slope, sub_m, sub_l, seg_m, seg_l, alpha);               \
+        if (g->n_sub > g->n_seg) { /* some segment has several sub-segments */                                         \
+            attn_seg_combine_kernel<<<(unsigned)oea::ceil_div(g->seg1 - g->seg0, 256), 256, 0, st>>>(                   \
+                g->seg_sub_ptr, g->seg0, g->seg1, sub_m, sub_l, seg_m, seg_l);                                          \
+            attn_alpha_kernel<GW><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z,    \
+                                                        lrelu_slope, seg_m, seg_l, alpha);                              \
+        }                                                                                                               \
+    } while (0)
+            if (G == 1) CALL(1); else if (G == 8) CALL(8); else CALL(64);
+#undef CALL
         }
         OEA_CHECK_HIP(hipGetLastError());
     }
@@ -301,7 +342,12 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
     OEA_REQUIRE(phases & (OEA_ATTN_DZ | OEA_ATTN_DV), "phases: OEA_ATTN_DZ | OEA_ATTN_DV");
     hipStream_t st = oea::as_stream(stream);
     float *sub_c = workspace, *slot_vals = workspace + 2 * g->n_sub + 2 * g->n_seg;
-    if ((phases & OEA_ATTN_DZ) && g->sub1 > g->sub0) {
+    if ((phases & OEA_ATTN_DZ) && g->sub1 > g->sub0 && g->n_seg == g->nnz) {
+        // every softmax group is ONE edge: d z = alpha (d alpha - alpha d alpha) = 0 exactly
+        OEA_REQUIRE(dz, "null pointer");
+        attn_fill_kernel<<<(unsigned)oea::ceil_div(g->sub1 - g->sub0, 256), 256, 0, st>>>(dz, g->sub0, g->sub1, 0.0f);
+        OEA_CHECK_HIP(hipGetLastError());
+    } else if ((phases & OEA_ATTN_DZ) && g->sub1 > g->sub0) {
         OEA_REQUIRE(z && v && dz, "null pointer");
         const unsigned grid = (unsigned)oea::ceil_div(g->sub1 - g->sub0, 4);
 #define CALL(IT)                                                                                                      \
@@ -309,8 +355,11 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
                                                      dout, dim, ld, dz, sub_c)
         OEA_ATTN_DISPATCH(ld, CALL);
 #undef CALL
-        attn_bwd_dz_kernel<<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c,
-                                                 lrelu_slope, dz);
+        const int G = group_width(g);
+        const unsigned gz = (unsigned)oea::ceil_div((g->sub1 - g->sub0) * G, 256);
+        if (G == 1) attn_bwd_dz_kernel<1><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c, lrelu_slope, dz);
+        else if (G == 8) attn_bwd_dz_kernel<8><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c, lrelu_slope, dz);
+        else attn_bwd_dz_kernel<64><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c, lrelu_slope, dz);
         OEA_CHECK_HIP(hipGetLastError());
     }
     if ((phases & OEA_ATTN_DV) && g->t_row1 > g->t_row0) {

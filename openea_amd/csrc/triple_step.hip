@@ -944,6 +944,10 @@ __global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent,
         float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
         const int on = is_rel ? cfg.rel_l2_norm : cfg.ent_l2_norm;
         const float flag = touched[row];
+        // Adadelta WITHOUT the l2_normalize in front of the lookup: TF's gradient is IndexedSlices and SparseApplyAdadelta
+        // only visits the gathered rows -- the accumulators of untouched rows do not decay.  (With the normalisation the
+        // gradient is dense; TF1's sparse Adam decays every row either way: optimizer._apply_sparse_shared.)
+        if (cfg.opt_kind == OEA_OPT_ADADELTA && !on && flag == 0.f) continue;
         Row<G, IT> rv, rg, r0, r1;
         load_row<G, IT>(v, ld, lane, rv);
         load_row<G, IT>(g, ld, lane, rg);

@@ -95,6 +95,10 @@ class BasicModel:
         cfg = generate_optimizer(loss_cfg, self.args.learning_rate, opt=self.args.optimizer)
         nv = na = None
         if normal is not None:
+            if cfg['optimizer'] not in ('Adagrad', 'SGD'):
+                # oea_triple_step's TransH score trains the normal vectors with Adagrad or SGD (apply_normal_rows)
+                raise NotImplementedError("TransH scoring with optimizer=%s: the normal-vector table is trained with Adagrad "
+                                          "(the shipped args files) or SGD" % cfg['optimizer'])
             nv = normal.var
             na = torch.full_like(nv, 0.1) if cfg['optimizer'] == 'Adagrad' else None
         return ops.make_step_cfg(ent_l2_norm=self.ent_embeds.is_l2_norm, rel_l2_norm=self.rel_embeds.is_l2_norm,
@@ -118,7 +122,12 @@ class BasicModel:
 
     def _define_mapping_graph(self):
         self.mapping_loss = "alpha * (sum||e2 - e1 M||^2 + sum (M M^T - I)^2)"     # mapping.py:17, losses.py:76-80
-        self.mapping_optimizer = dict(optimizer=self.args.optimizer, lr=self.args.learning_rate)
+        from ..modules.base.optimizers import get_optimizer
+        self.mapping_optimizer = get_optimizer(self.args.optimizer, self.args.learning_rate)
+        if self.mapping_optimizer['optimizer'] not in ('Adagrad', 'SGD'):
+            # oea_mapping_step updates M with Adagrad or SGD; reject here instead of failing in the first mapping epoch
+            raise NotImplementedError("mapping matrix with optimizer=%s: the fused mapping step (csrc/mapping.hip) implements "
+                                      "Adagrad (the shipped mtranse_args_*.json) and SGD" % self.args.optimizer)
         # a second optimizer instance in the reference (mapping.py:18) = its own Adagrad accumulators
         cfg, opt = self._step_cfg(dict(loss='positive', loss_norm='L2'), 0)
         self._mapping_trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group(),

@@ -307,8 +307,11 @@ class TFAdam:
 
 
 class DenseSGD:
-    """tf.train.GradientDescentOptimizer over dense device parameters (p -= lr * grad; oea_sgd_rows without the
-    normalisation pull-back)."""
+    """tf.train.GradientDescentOptimizer over dense device parameters: p -= lr * grad (oea_sgd_rows without the
+    normalisation pull-back).  Any shape: the parameter is viewed as rows of 256 floats (the tail, if any, as one more
+    zero-padded row), so 1-D biases and widths that are not a multiple of 4 take the same kernel."""
+
+    ROW = 256
 
     def __init__(self, params, lr):
         self.params, self.lr = list(params), lr
@@ -320,10 +323,18 @@ class DenseSGD:
                 continue
             g = p.grad.contiguous()
             mdist.sync_replicated_(g)
-            w = p.data.view(-1, p.shape[-1]) if p.dim() > 1 else p.data.view(1, -1)
-            gg = g.view_as(w)
-            if w.shape[1] % 4 == 0:
-                ops.sgd_rows_(w, gg, w.shape[1], False, self.lr)
-            else:                                   # oea_sgd_rows wants 16-byte rows: flatten to one padded row is not
-                p.data.add_(g, alpha=-self.lr)      # possible in place; tiny parameters take the element-wise add
+            w = p.data if p.data.is_contiguous() else p.data.contiguous()
+            n, row = w.numel(), self.ROW
+            full = n // row * row
+            if full:
+                ops.sgd_rows_(w.view(-1)[:full].view(-1, row), g.view(-1)[:full].view(-1, row), row, False, self.lr)
+            if n > full:
+                tail_w = torch.zeros(row, dtype=w.dtype, device=w.device)
+                tail_g = torch.zeros(row, dtype=w.dtype, device=w.device)
+                tail_w[: n - full] = w.view(-1)[full:]
+                tail_g[: n - full] = g.view(-1)[full:]
+                ops.sgd_rows_(tail_w.view(1, row), tail_g.view(1, row), row, False, self.lr)
+                w.view(-1)[full:] = tail_w[: n - full]
+            if w.data_ptr() != p.data.data_ptr():
+                p.data.copy_(w)
             p.grad = None

@@ -141,6 +141,7 @@ class TripleTrainer:
     def apply_entity_row_grads(self, ids, grads):
         """optimiser step for gradients w.r.t. the normalised entity rows `ids` computed outside the
         fused kernel (device [n, ld] fp32): scatter into the scratch, then the apply phase."""
+        self._no_partition("apply_entity_row_grads")
         ops.step_scatter_ent_rows(self.ws, self.ent.rows, self.rel.rows, self.ent.ld, ids, grads)
         self.count_steps()
         if self.dist is not None:
@@ -154,6 +155,7 @@ class TripleTrainer:
     def apply_scratch(self):
         """optimiser step for whatever a kernel outside the fused step has added to the gradient scratch
         (oea_mapping_step): the exchange (if any), then the apply phase."""
+        self._no_partition("apply_scratch")
         self.count_steps()
         if self.dist is not None:
             import torch.distributed as dist
@@ -162,6 +164,22 @@ class TripleTrainer:
                 self.xchg /= dist.get_world_size(self.dist)
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
+
+    def _no_partition(self, what):
+        """the replicated side entries (gradients computed outside the fused step) go through the dense exchange and the
+        full optimiser state; a trainer partitioned by entity id keeps 1 / G of the state (ent_acc is None) -- the small
+        steps that use them (MTransE's mapping step, BootEA's alignment step) build their own replicated trainer"""
+        if self.part is not None:
+            raise RuntimeError("TripleTrainer.%s on a trainer partitioned by entity id: build the trainer with "
+                               "replicated=True (its optimiser state is then whole on every rank)" % what)
+
+    def exchange_description(self):
+        if self.dist is None:
+            return None
+        if self.part is not None:
+            return ("owner = id mod G: reduce-scatter of the packed gradient rows + touched flags ([G][rows/G][ld+1] fp32), "
+                    "all-reduce of the relation rows, all-gather of the updated owned rows ([G][rows/G][ld])")
+        return "dense all-reduce of the gradient scratch + touched flags, every rank applies every row"
 
     def exchange_bytes_per_step(self):
         """bytes this rank sends (= receives) per optimiser step in the data-parallel exchange: a ring all-reduce of the

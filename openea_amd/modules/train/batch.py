@@ -169,18 +169,30 @@ class EpochBatches:
 _sampler_cache = {}
 
 
+def _fingerprint(all_triples_set, entities_list):
+    """cheap content fingerprint: sizes + a strided sample of ~256 triples (itertools.islice: the walk over the set is a
+    C loop, no sort, no per-element python work) + the ends of the entity list"""
+    from itertools import islice
+    n, m = len(all_triples_set), len(entities_list)
+    sample = tuple(islice(all_triples_set, 0, None, max(1, n // 256)))
+    return (n, hash(sample), m, entities_list[0] if m else -1, entities_list[-1] if m else -1)
+
+
 def _cached_sampler(all_triples_set, entities_list):
-    """one device sampler per (triple set, entity list) CONTENT: the key is a hash of the sorted triples and of the
-    list, so a set mutated in place (or a recycled id()) never returns a stale table."""
+    """one device sampler per (triple set, entity list).  The key is (id, id): O(1) per call; the stored fingerprint
+    (sizes + a strided sample of the set) is compared on every hit, so a set mutated in place or a
+    recycled id() never returns a stale table.  The sorted [n, 3] array is only built on a miss."""
+    key = (id(all_triples_set), id(entities_list))
+    fp = _fingerprint(all_triples_set, entities_list)
+    hit = _sampler_cache.get(key)
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    if len(_sampler_cache) > 8:
+        _sampler_cache.clear()
     tri = np.asarray(sorted(all_triples_set), dtype=np.int32).reshape(-1, 3)
     ents = np.asarray(entities_list, dtype=np.int32)
-    key = (hash(tri.tobytes()), hash(ents.tobytes()), len(tri), len(ents))
-    s = _sampler_cache.get(key)
-    if s is None:
-        if len(_sampler_cache) > 8:
-            _sampler_cache.clear()
-        s = TripleSampler(tri, ents)
-        _sampler_cache[key] = s
+    s = TripleSampler(tri, ents)
+    _sampler_cache[key] = (fp, s)
     return s
 
 

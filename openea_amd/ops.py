@@ -643,7 +643,7 @@ def attn_graph(sub_ptr, sub_seg, seg_sub_ptr, seg_row, colidx, agg_rowptr, agg_c
     t0, t1 = t_rows if t_rows is not None else (0, n_t)
     ts0, ts1 = t_slots if t_slots is not None else (0, nnz)
     g = _lib.AttnGraph(sub_ptr.data_ptr(), sub_seg.data_ptr(), seg_sub_ptr.data_ptr(), seg_row.data_ptr(), colidx.data_ptr(),
-                       n_sub, n_seg, agg_rowptr.data_ptr(), agg_colidx.data_ptr(),
+                       n_sub, n_seg, nnz, agg_rowptr.data_ptr(), agg_colidx.data_ptr(),
                        agg_edge.data_ptr() if agg_edge is not None else None, n_agg,
                        C.pointer(agg_split) if agg_split is not None else None,
                        t_rowptr.data_ptr(), t_row.data_ptr(), t_edge.data_ptr(), n_t,

@@ -33,6 +33,7 @@ def test_sparse_attention_matches_oracle(ops, grouping, d):
     rows, cols, vals = _graph(rng, n, 6)
     if d == 100:                                                    # exercise multi-sub-segment rows and hub rows / columns in chunks
         EdgeGraph.SUB, EdgeGraph.HUB, EdgeGraph.CHUNK = 64, 96, 64
+        cols[100:400] = 7                                           # a hub column: dV of row 7 is summed in chunks
     g = EdgeGraph(rows, cols, vals, (n, n), ops.device(), grouping=grouping)
     EdgeGraph.SUB, EdgeGraph.HUB, EdgeGraph.CHUNK = 256, 768, 512
     if grouping == "runs":

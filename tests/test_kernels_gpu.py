@@ -823,6 +823,53 @@ def test_triple_step_dense_optimisers_vs_oracle(ops, opt, capsys):
     assert not bool((ws[: ws.numel() - 8 * 4096] != 0).any().item())
 
 
+def test_adadelta_without_normalisation_is_sparse(ops):
+    """ent_l2_norm / rel_l2_norm off: TF's gradient of the lookups is IndexedSlices and SparseApplyAdadelta visits the
+    gathered rows only -- rows no triple of the batch touches keep their variable AND their accumulators."""
+    rng = np.random.RandomState(12)
+    n_ent, n_rel, n_pos, k, d = 400, 9, 50, 2, 32
+    ent = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32)
+    rel = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32)
+    pos, neg = _kg(rng, 200, n_rel, n_pos, k)                   # entity ids < 200: rows 200.. are never gathered
+    cfg = ops.make_step_cfg(neg_group_k=k, optimizer="Adadelta", lr=0.5, loss="limited", loss_norm="L2", pos_margin=0.01,
+                            neg_margin=2.0, balance=0.2, ent_l2_norm=False, rel_l2_norm=False)
+    d_ent, d_rel = ops.to_table(ent), ops.to_table(rel)
+    st_e = torch.full((2,) + tuple(d_ent.shape), 0.25, device=d_ent.device)      # non-zero state: a dense pass would decay it
+    st_r = torch.full((2,) + tuple(d_rel.shape), 0.25, device=d_ent.device)
+    ws = ops.step_workspace(n_ent, n_rel, ops.pad4(d))
+    loss_acc = torch.zeros(1, dtype=torch.float64, device=d_ent.device)
+    for t in range(1, 3):
+        cfg.opt_t = t
+        ops.triple_step(d_ent, st_e, d_rel, st_r, d, ops.to_ids(pos), ops.to_ids(neg), cfg, ws, loss_acc)
+    touched = np.zeros(n_ent, bool)
+    touched[np.unique(np.concatenate([pos[:, [0, 2]].ravel(), neg[:, [0, 2]].ravel()]))] = True
+    e_now, s_now = d_ent.cpu().numpy()[:, :d], st_e.cpu().numpy()[:, :, :d]
+    assert np.array_equal(e_now[~touched], ent[~touched]) and np.all(s_now[:, ~touched] == 0.25)
+    assert np.abs(e_now[touched] - ent[touched]).max() > 1e-4 and np.any(s_now[0][touched] != 0.25)
+
+
+def test_dense_sgd_any_shape(ops):
+    """DenseSGD (tf.train.GradientDescentOptimizer over dense parameters): 1-D biases, widths that are not a multiple of
+    4 and non-contiguous views all take oea_sgd_rows."""
+    from openea_amd.models.graph_ops import DenseSGD
+    dev = ops.device()
+    rng = np.random.RandomState(3)
+    shapes = [(1000,), (37, 50), (300, 256), (5,)]
+    params = [torch.tensor(rng.standard_normal(sh).astype(np.float32), device=dev, requires_grad=True) for sh in shapes]
+    base = torch.tensor(rng.standard_normal((64, 48)).astype(np.float32), device=dev)
+    view = base.t()                                         # non-contiguous parameter
+    view.requires_grad_(True)
+    params.append(view)
+    before = [p.detach().cpu().numpy().copy() for p in params]
+    grads = [rng.standard_normal(tuple(p.shape)).astype(np.float32) for p in params]
+    for p, g in zip(params, grads):
+        p.grad = torch.tensor(g, device=dev)
+    DenseSGD(params, 0.3).step()
+    for p, b, g in zip(params, before, grads):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), b - np.float32(0.3) * g, rtol=1e-6, atol=1e-7)
+        assert p.grad is None
+
+
 @pytest.mark.parametrize("case", ["random", "clusters", "ties"])
 def test_topk_strip_free_path_bit_exact(ops, case, monkeypatch):
     """nc >= 32,768 and nq >= 4,096 take the threshold-append sweep + list select (no similarity strip in HBM); rows whose
