@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--neg", type=int, default=10)
     ap.add_argument("--eps", type=float, default=0.9, help="truncated_epsilon")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--exchange", choices=("epoch", "step", "allreduce"), default="epoch",
+                    help="N > 1: how the ranks exchange (models/trainer.py:TripleTrainer).  epoch (default; BASELINE.json north_star): "
+                         "local steps on each rank's share of the batch, one exchange per epoch; step: per-step reduce-scatter / "
+                         "all-gather, the G-rank job equals the single-GPU job.  The other mode is measured too (extra.other_exchange)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour / 100K-shape legs")
     ap.add_argument("--no-gnn", action="store_true", help="skip the GNN legs (BASELINE configs 3-5)")
@@ -122,7 +126,7 @@ def cached_kgs(shape, mode):
 class Workload:
     """tables + samplers + trainer of one shape, and the timed K-step regions on it"""
 
-    def __init__(self, torch, ops, shape, dim, batch, neg, eps, dev, rank=0, world=1, group=None, scaling="weak"):
+    def __init__(self, torch, ops, shape, dim, batch, neg, eps, dev, rank=0, world=1, group=None, scaling="weak", exchange=None):
         from openea_amd.models.trainer import EmbeddingTable, RelationTripleEpochs, TripleTrainer, refresh_neighbours
         from openea_amd.modules.base.initializers import truncated_normal_host
         self.torch, self.ops, self.shape, self.d, self.batch, self.neg, self.eps = torch, ops, shape, dim, batch, neg, eps
@@ -135,7 +139,7 @@ class Workload:
         self.rel = EmbeddingTable(truncated_normal_host(rng, (kgs.relations_num, dim), 1.0 / np.sqrt(dim)), True, "rel_embeds", dev)
         cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2,
                                 ent_l2_norm=True, rel_l2_norm=True, optimizer="Adagrad", lr=0.01, neg_group_k=neg)
-        self.trainer = TripleTrainer(self.ent, self.rel, cfg, "Adagrad", dist_group=group)
+        self.trainer = TripleTrainer(self.ent, self.rel, cfg, "Adagrad", dist_group=group, exchange=exchange)
         self.epochs = RelationTripleEpochs(kgs, self.global_batch, neg, seed=2, dev=dev, rank=rank, world=world)
         self.k1 = int((1 - eps) * kgs.kg1.entities_num)      # basic_model.py:270-271 (1499 at eps=0.9, N=15000)
         self.k2 = int((1 - eps) * kgs.kg2.entities_num)
@@ -339,11 +343,15 @@ def main():
             cached_kgs(args.shape, "swapping")     # one rank builds the synthetic KGs, the others read the pickle
         dist.barrier()
 
-    wl = Workload(torch, ops, args.shape, args.dim, args.batch, args.neg, args.eps, dev, rank, world, group, args.scaling)
+    wl = Workload(torch, ops, args.shape, args.dim, args.batch, args.neg, args.eps, dev, rank, world, group, args.scaling,
+                  args.exchange)
     m = wl.measure(args.steps, args.warmup, args.repeats)
     extra = {}
     if not args.no_extra:                   # eval / neighbour legs: row-sharded over the ranks (every rank takes part)
         extra.update(extra_legs(torch, ops, wl.ent, wl.kgs, args.dim, wl.k1))
+    multi = None
+    if world > 1:
+        multi = multi_gpu_legs(torch, ops, dev, args, rank, world, group, wl)      # every rank takes part
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -361,10 +369,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         xb = wl.trainer.exchange_bytes_per_step()
+        ep_b = wl.trainer.epoch_exchange_bytes()
+        if wl.trainer.local_epochs:
+            xb = int(ep_b / max(wl.steps_per_epoch, 1))
+        extra["exchange_mode"] = wl.trainer.exchange
         extra["exchange_bytes_per_step_per_rank"] = xb
-        extra["exchange"] = wl.trainer.exchange_description() if hasattr(wl.trainer, "exchange_description") else None
+        extra["exchange_bytes_per_epoch_per_rank"] = ep_b if wl.trainer.local_epochs else xb * wl.steps_per_epoch
+        extra["exchange"] = wl.trainer.exchange_description()
         # what the exchange alone would cost on the ring: per-link xGMI 153 GB/s, 7 links, realistic RCCL bus bandwidth ~350 GB/s
         extra["exchange_predicted_us_per_step_at_350GBs"] = round(xb / 350e9 * 1e6, 1)
+        extra.update(multi or {})
         extra["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
         extra["collective_world_size"] = dist.get_world_size()
     cpu = None
@@ -397,8 +411,8 @@ def main():
                                   args.neg, args.eps),
                    "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
                    "entities": extra_entities(args.shape),
-                   "parallelism": ("dp%d, entity tables partitioned by id (owner = id mod %d): reduce-scatter of gradients + "
-                                   "all-gather of updated rows per step" % (world, world)) if world > 1 else "single",
+                   "parallelism": ("dp%d, exchange = %s: %s" % (world, extra.get("exchange_mode"), extra.get("exchange")))
+                   if world > 1 else "single",
                    "timing": "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (args.repeats, args.steps),
                    "parity_note": "TF1 op semantics / optimiser arithmetic are restated, not executed (no TensorFlow "
                                   "here): SURVEY H1/H3/H4, DESIGN.md section 5"},
@@ -408,6 +422,36 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+
+
+def multi_gpu_legs(torch, ops, dev, args, rank, world, group, main_wl):
+    """N > 1 only, every rank: the OTHER exchange mode on the same shape (fewer regions) and the EN-FR-100K-V1 shape in the
+    main mode -- BASELINE.json asks for both shapes at 1 / 2 / 4 / 8 GPUs."""
+    import torch.distributed as dist
+    out = {}
+
+    def run(shape, dim, batch, eps, exchange, steps, warmup, repeats):
+        if rank == 0:
+            cached_kgs(shape, "swapping")
+        dist.barrier()
+        wl = Workload(torch, ops, shape, dim, batch, args.neg, eps, dev, rank, world, group, args.scaling, exchange)
+        m = wl.measure(steps, warmup, repeats)
+        value, ms, _ = wl.summarize(m, steps)
+        ep_b = wl.trainer.epoch_exchange_bytes()
+        xb = int(ep_b / max(wl.steps_per_epoch, 1)) if wl.trainer.local_epochs else wl.trainer.exchange_bytes_per_step()
+        res = {"shape": shape, "exchange_mode": wl.trainer.exchange, "value": round(value, 1), "unit": "triples/s",
+               "ms_per_step": round(ms, 4), "steps": steps, "repeats": repeats, "global_batch": wl.global_batch,
+               "triple_steps_per_epoch": wl.steps_per_epoch, "exchange_bytes_per_step_per_rank": xb}
+        del wl
+        torch.cuda.empty_cache()
+        return res
+    other = "step" if main_wl.trainer.exchange == "epoch" else "epoch"
+    out["other_exchange"] = run(args.shape, args.dim, args.batch, args.eps, other, args.steps, min(args.warmup, 5), 5)
+    if not args.no_extra and args.shape == "EN-FR-15K-V1":
+        steps = min(args.steps, 58)
+        out["shape_100k"] = run("EN-FR-100K-V1", 100, 20000, 0.98, main_wl.trainer.exchange, steps, min(args.warmup, 5), 5)
+        out["shape_100k_other_exchange"] = run("EN-FR-100K-V1", 100, 20000, 0.98, other, steps, min(args.warmup, 5), 3)
+    return out
 
 
 def extra_entities(shape):

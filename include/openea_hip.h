@@ -316,6 +316,19 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                            void *stream);
 
+/* The same for ONE RANK of a job whose ranks take contiguous shares of every batch (rows [n rank / world, n (rank + 1) / world)
+ * of the batch's n rows, as models/dist.py:shard_batch) and train on LOCAL copies of the tables between two exchanges
+ * (`dp_exchange = 'epoch'`: no collective inside the epoch; the caller reconciles the copies at the epoch's end).  The
+ * negatives keep the single-process Philox streams (position inside the batch), so the union of the ranks' draws is the
+ * single-process draw.  rank = 0, world = 1: oea_triple_epoch_range. */
+int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                                 int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                 const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                 const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                                 uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                                 void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                                 int32_t rank, int32_t world, void *stream);
+
 /* Negative LINKS of AliNet.generate_input_batch (approaches/alinet.py:988-1006), drawn on the device.
  *   uniform   (nbr1 == NULL): pair q = round * n_pos + i, round < k:  (ents1[pi1_round(i)], ents2[pi2_round(i)])
  *             -- zip(random.sample(ents1, n_pos), random.sample(ents2, n_pos)) per round; needs n_pos <= n1, n2;

@@ -27,4 +27,4 @@ class BootEA_TransH(BootEA):
                                         balance=self.args.neg_margin_balance)
         cfg, opt = self._step_cfg(self.triple_loss, self.args.neg_triple_num, normal=self.normal_vector)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group())
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, **self._dist_kw())

@@ -30,7 +30,7 @@ class MTransE(BasicModel):
         self.triple_loss = positive_loss('L2')
         cfg, opt = self._step_cfg(self.triple_loss, 0)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group())
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, **self._dist_kw())
 
     def launch_training_1epo(self, epoch, triple_steps, steps_tasks, training_batch_queue, neighbors1, neighbors2):
         self.launch_triple_training_1epo(epoch, triple_steps, steps_tasks, training_batch_queue, neighbors1, neighbors2)

@@ -1428,10 +1428,23 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
                            uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                            void *stream) {
+    return oea_triple_epoch_range_shard(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos_all, offsets_host, splits_host,
+                                        steps, step_begin, step_end, k, side0, side1, seed, step_base, neg_buf, err_flag, cfg,
+                                        workspace, loss_accum, offsets_dev, splits_dev, 0, 1, stream);
+}
+
+int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                                 int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                 const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                 const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                                 uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                                 void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                                 int32_t rank, int32_t world, void *stream) {
     OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
     OEA_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= steps, "0 <= step_begin <= step_end <= steps");
     OEA_REQUIRE((offsets_dev == nullptr) == (splits_dev == nullptr), "offsets_dev and splits_dev go together");
+    OEA_REQUIRE(world >= 1 && rank >= 0 && rank < world, "0 <= rank < world");
     // side0 == NULL with the device layout given: neg_buf already holds the epoch's negatives (the caller drew them
     // with oea_sample_negatives_epoch, e.g. on another stream while the previous epoch was running)
     const bool presampled = k > 0 && side0 == nullptr && side1 == nullptr && offsets_dev != nullptr;
@@ -1439,7 +1452,8 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
     const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;      // neg_buf covers the whole epoch
     // the sampler does not read the tables: a range that starts the epoch draws ALL its negatives in one launch
     // (later ranges of the same epoch find them in neg_buf: pass side0 = side1 = NULL, or let them be drawn again
-    // step by step -- the Philox streams are the same either way)
+    // step by step -- the Philox streams are the same either way).  A rank of a sharded job draws the WHOLE epoch as
+    // well (same streams on every rank: the union of the ranks' slices is the single-process draw) and uses its rows.
     const bool sample_all = ahead && !presampled && step_begin == 0;
     if (sample_all) {
         const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0,
@@ -1448,19 +1462,26 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
     }
     oea_step_cfg step_cfg = *cfg;             // Adam: opt_t counts the steps actually run (cfg->opt_t = count of the first)
     for (int32_t s = step_begin; s < step_end; ++s) {
-        const int64_t lo = offsets_host[s], n = offsets_host[s + 1] - lo;
-        if (n <= 0) continue;
+        const int64_t b0 = offsets_host[s], nb = offsets_host[s + 1] - b0;
+        if (nb <= 0) continue;
+        // this rank's contiguous share of the batch rows (models/dist.py:shard_batch; the whole batch when world == 1)
+        const int64_t r_lo = nb * rank / world, r_hi = nb * (rank + 1) / world;
+        const int64_t lo = b0 + r_lo, n = r_hi - r_lo;
+        int64_t split = splits_host[s] - r_lo;
+        split = split < 0 ? 0 : (split > n ? n : split);
         const int32_t *pos = pos_all + 3 * lo;
         int32_t *negs = ahead ? neg_buf + 3 * lo * (int64_t)k : neg_buf;
-        if (k > 0 && !presampled && !sample_all) {
-            const int rc = oea_sample_negatives_pair(pos, n, splits_host[s], k, side0, side1, seed, step_base + (uint32_t)s,
-                                                     0u, 10, negs, err_flag, stream);
+        if (n > 0 && k > 0 && !presampled && !sample_all) {
+            const int rc = oea_sample_negatives_pair(pos, n, split, k, side0, side1, seed, step_base + (uint32_t)s,
+                                                     (uint32_t)r_lo, 10, negs, err_flag, stream);
             if (rc != OEA_OK) return rc;
         }
-        const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
-                                             k > 0 ? negs : nullptr, n * (int64_t)k, &step_cfg, workspace, loss_accum,
-                                             OEA_PHASE_BOTH, stream);
-        if (rc != OEA_OK) return rc;
+        if (n > 0) {
+            const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
+                                                 k > 0 ? negs : nullptr, n * (int64_t)k, &step_cfg, workspace, loss_accum,
+                                                 OEA_PHASE_BOTH, stream);
+            if (rc != OEA_OK) return rc;
+        }
         ++step_cfg.opt_t;
     }
     return OEA_OK;

@@ -89,6 +89,12 @@ class BasicModel:
         import torch.distributed as tdist
         return tdist.group.WORLD if mdist.world()[1] > 1 else None
 
+    def _dist_kw(self):
+        """keyword arguments of the MAIN step's trainer: the process group + how the ranks exchange (args.dp_exchange:
+        'step' -- the G-rank job equals the single-GPU job --, 'allreduce', or 'epoch' -- BASELINE.json north_star: local
+        steps, one exchange per epoch; models/trainer.py:TripleTrainer)"""
+        return dict(dist_group=self._dist_group(), exchange=getattr(self.args, 'dp_exchange', None))
+
     def _step_cfg(self, loss_cfg, neg_group_k, normal=None):
         """normal: EmbeddingTable of TransH normal vectors -> the step scores projected rows and trains it
         (its own Adagrad accumulator, created here: one per generate_optimizer call)."""
@@ -110,7 +116,7 @@ class BasicModel:
         k = self.args.neg_triple_num if self.args.loss != 'margin-based' else 0
         cfg, opt = self._step_cfg(self.triple_loss, k)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group())
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, **self._dist_kw())
 
     def _define_mapping_variables(self):
         """mapping.py:22-25: orthogonal d x d matrix + identity."""
@@ -266,6 +272,8 @@ class BasicModel:
                                                                        epochs.s1.nbr is not neighbors1):
             epochs.set_neighbours(neighbors1, neighbors2)
         trained_samples_num = epochs.run_epoch(self._trainer)
+        if epochs.world > 1:                      # pop_loss sums the ranks' losses: divide by the whole job's positives
+            trained_samples_num = int(epochs.batches.offsets[-1])
         epoch_loss = self._trainer.pop_loss() / max(trained_samples_num, 1)
         print('epoch {}, avg. triple loss: {:.4f}, cost time: {:.4f}s'.format(epoch, epoch_loss, time.time() - start))
 

@@ -50,12 +50,34 @@ class EmbeddingTable:
 
 
 class TripleTrainer:
-    def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None, replicated=False):
+    def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None, replicated=False, exchange=None):
         """replicated=True (with a dist_group): every rank feeds the SAME full batch (small steps that are not worth
         sharding: MTransE's mapping step, BootEA's alignment step); the gradient scratch is then averaged instead of
-        summed -- its only purpose is to give every replica the same bits (fp32 atomics reorder per process)."""
+        summed -- its only purpose is to give every replica the same bits (fp32 atomics reorder per process).
+
+        exchange (with a dist_group, not replicated; default: OEA_DP_EXCHANGE or 'step'):
+          'step'      the G-rank job EQUALS the single-GPU job: per step, gradients reduce-scattered to the owners of the
+                      entity rows (owner = id mod G), owners run the optimiser, updated rows all-gathered;
+          'allreduce' the same with one dense all-reduce and a replicated update (round 1);
+          'epoch'     BASELINE.json north_star: "RCCL all-gather of boundary embeddings ... each epoch" -- every rank trains
+                      its share of every batch on its LOCAL copy of the tables with the fused single-GPU epoch call (no
+                      collective, no host work per step); at the epoch's end the copies are reconciled: the changes of
+                      tables and optimiser state since the last exchange are summed over the ranks (reduce-scatter to
+                      the owner of each row + all-gather of the owned rows = one all-reduce of the deltas).  Inside an
+                      epoch a rank reads rows other ranks are training with a delay of at most one epoch (local SGD): NOT
+                      equal to the single-GPU job -- drift measured in tests/test_dist_gpu.py, DESIGN.md section 6."""
         self.ent, self.rel, self.cfg = ent, rel, cfg
         self.replicated = bool(replicated)
+        import os as _os
+        self.exchange = exchange or {"partition": "step"}.get(_os.environ.get("OEA_DP_EXCHANGE", "step"),
+                                                               _os.environ.get("OEA_DP_EXCHANGE", "step"))
+        if self.exchange not in ("step", "allreduce", "epoch"):
+            raise ValueError("dp_exchange: 'step', 'allreduce' or 'epoch'")
+        if dist_group is None or self.replicated:
+            self.exchange = "step"
+        if self.exchange == "epoch" and cfg.score_kind not in (ops.SCORE_TRANSE, ops.SCORE_TRANSD):
+            self.exchange = "step"        # TransH keeps a third trained table outside (ent, rel): per-step exchange only
+        self._snap = None
         dev = ent.var.device
         self.dev = dev
         if optimizer == 'Adagrad':        # tf.train.AdagradOptimizer: initial_accumulator_value = 0.1
@@ -77,8 +99,51 @@ class TripleTrainer:
         self.part = None
         import os
         if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD') and cfg.score_kind == ops.SCORE_TRANSE
-                and os.environ.get("OEA_DP_EXCHANGE", "partition") == "partition"):
+                and self.exchange == "step"):
             self._init_partition(optimizer)
+
+    # ---- dp_exchange = 'epoch': local steps, one exchange per epoch ----------------------------------------------
+    @property
+    def local_epochs(self):
+        return self.dist is not None and not self.replicated and self.exchange == "epoch"
+
+    def _state_tensors(self):
+        return [t for t in (self.ent.var, self.rel.var, self.ent_acc, self.rel_acc) if t is not None]
+
+    def epoch_begin(self):
+        """remember tables + optimiser state as every rank holds them now (identical on all ranks; taken afresh every
+        epoch: other trainers -- BootEA's alignment step, MTransE's mapping step -- move the same tables in between)"""
+        cur = self._state_tensors()
+        if self._snap is None:
+            self._snap = [torch.empty_like(t) for t in cur]
+        for t, snap in zip(cur, self._snap):
+            snap.copy_(t)
+
+    def epoch_sync(self):
+        """reconcile the ranks' local copies: state = snapshot + sum over ranks of (local state - snapshot).  The sum is
+        one all-reduce per tensor (RCCL: reduce-scatter to the owners + all-gather of the owned rows); every rank ends
+        with the same bits and takes them as the next snapshot."""
+        import torch.distributed as dist
+        if self._snap is None:
+            return
+        from . import dist as mdist
+        for cur, snap in zip(self._state_tensors(), self._snap):
+            cur.sub_(snap)
+            if mdist._staged(cur, self.dist):          # gloo (one-GPU wiring tests): stage on the host
+                h = cur.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.dist)
+                cur.copy_(h)
+            else:
+                dist.all_reduce(cur, op=dist.ReduceOp.SUM, group=self.dist)
+            cur.add_(snap)
+
+    def epoch_exchange_bytes(self):
+        """bytes this rank sends (= receives) per epoch-end exchange (ring all-reduce of every state tensor)"""
+        if not self.local_epochs:
+            return 0
+        import torch.distributed as dist
+        g = dist.get_world_size(self.dist)
+        return int(sum(t.numel() for t in self._state_tensors()) * 4 * 2 * (g - 1) / g)
 
     def _init_partition(self, optimizer):
         import torch.distributed as dist
@@ -176,6 +241,10 @@ class TripleTrainer:
     def exchange_description(self):
         if self.dist is None:
             return None
+        if self.local_epochs:
+            return ("dp_exchange = 'epoch': local steps on this rank's share of every batch (fused epoch call, no collective); "
+                    "per epoch one all-reduce of the changes of tables + optimiser state (= reduce-scatter to the row owners + "
+                    "all-gather of the owned rows)")
         if self.part is not None:
             return ("owner = id mod G: reduce-scatter of the packed gradient rows + touched flags ([G][rows/G][ld+1] fp32), "
                     "all-reduce of the relation rows, all-gather of the updated owned rows ([G][rows/G][ld])")
@@ -285,7 +354,10 @@ class RelationTripleEpochs:
     def _run_range(self, trainer, lo, hi):
         S = len(self.batches.splits)
         b = self.batches
-        if self.world == 1 and getattr(trainer, "fused_epoch", True):
+        local = self.world > 1 and getattr(trainer, "local_epochs", False)
+        if local and lo == 0:
+            trainer.epoch_begin()
+        if (self.world == 1 or local) and getattr(trainer, "fused_epoch", True):
             if self._sides is None:
                 self._sides = (self.s1.side(), self.s2.side())
             main = torch.cuda.current_stream()
@@ -306,15 +378,21 @@ class RelationTripleEpochs:
                              None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
                              self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
                              trainer.ws, trainer.loss, self._off_dev if self.k else None,
-                             self._spl_dev if self.k else None, step_range=(lo, hi))
+                             self._spl_dev if self.k else None, step_range=(lo, hi),
+                             shard=(self.rank, self.world) if local else (0, 1))
             if lo == 0 and self.k:
                 self._epoch_negs_ready = True             # a range that starts the epoch draws all its negatives
             self.global_step += hi - lo
             n = int(b.offsets[hi] - b.offsets[lo])
+            if local:                                     # this rank's share of those batches
+                nb = np.diff(b.offsets[lo:hi + 1])
+                n = int((nb * (self.rank + 1) // self.world - nb * self.rank // self.world).sum())
             if ev_start is not None:
                 self._prefetch_next(ev_start)             # next epoch's shuffle + negatives on the side stream
             if hi == S:
                 self._epoch_base = self.global_step
+                if local:
+                    trainer.epoch_sync()                  # the one exchange of the epoch
             return n
         n = 0
         for step in range(lo, hi):

@@ -55,5 +55,4 @@ class TransD(TransE):
                                 neg_group_k=0, transfer_bases=(self.ent_embeds.visible_rows, self.rel_embeds.visible_rows),
                                 **merged)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, merged['optimizer'],
-                                      dist_group=self._dist_group())
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, merged['optimizer'], **self._dist_kw())

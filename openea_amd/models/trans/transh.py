@@ -20,4 +20,4 @@ class TransH(TransE):
         self.triple_loss = margin_loss(self.args.margin, self.args.loss_norm)
         cfg, opt = self._step_cfg(self.triple_loss, 0, normal=self.normal_vector)
         self.triple_optimizer = cfg
-        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, dist_group=self._dist_group())
+        self._trainer = TripleTrainer(self.ent_embeds, self.rel_embeds, cfg, opt, **self._dist_kw())

@@ -301,19 +301,20 @@ def sample_negatives_epoch(pos_all, offsets_dev, splits_dev, steps, k, side0, si
 
 
 def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
-                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None, step_range=None):
+                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None, step_range=None, shard=(0, 1)):
     """Enqueue every step of an epoch (or steps [lo, hi) of it: step_range) with one call (offsets / splits: host int64
     numpy arrays; their device copies enable sampling the whole epoch ahead in one launch -- neg_buf then covers the
-    epoch).  step_base: Philox step of the epoch's step 0."""
+    epoch).  step_base: Philox step of the epoch's step 0.  shard = (rank, world): this rank's contiguous share of every
+    batch, trained on the local tables (dp_exchange = 'epoch')."""
     steps = len(splits)
     lo, hi = (0, steps) if step_range is None else step_range
-    check(lib().oea_triple_epoch_range(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+    check(lib().oea_triple_epoch_range_shard(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
                                        ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
                                        splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
                                        C.byref(side0) if side0 is not None else None,
                                        C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
                                        _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
-                                       _p(offsets_dev), _p(splits_dev), _stream()))
+                                       _p(offsets_dev), _p(splits_dev), int(shard[0]), int(shard[1]), _stream()))
 
 
 def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None, row2=None,

@@ -52,8 +52,8 @@ def test_sparse_attention_matches_oracle(ops, grouping, d):
     for a, b in zip(*runs):
         assert np.array_equal(a, b)
     out_h, dz_h, dv_h = runs[0]
-    if d == 100:
-        assert g.attn.agg_split and g.attn.t_split and g.attn.n_sub > g.attn.n_seg
+    if d == 100:                                                    # hub rows / the hub column in chunks; rows cut into sub-segments
+        assert g.attn.agg_split and g.attn.t_split and (grouping == "runs" or g.attn.n_sub > g.attn.n_seg)
     seg_ptr, seg_row, col = g.seg_ptr_host, g.seg_row_host, g.e_colidx.cpu().numpy()
     out_ref, alpha = orc.sparse_attn_forward(z_h, v_h, seg_ptr, seg_row, col, n)
     dz_ref, dv_ref = orc.sparse_attn_backward(z_h, v_h, alpha, w_h, seg_ptr, seg_row, col)
