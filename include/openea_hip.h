@@ -515,6 +515,39 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
                         const float *dout, int32_t dim, int32_t ld, float lrelu_slope, float *dz, float *dv,
                         float *workspace, int32_t phases, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Row-wise glue of the GNN approaches, fused (csrc/gnn_fused.hip): one pass forward, one pass backward, one wave per
+ * row, no atomics.  All tensors fp32 row-major.
+ *
+ * oea_concat_l2n_*: emb = l2n(concat(l2n(x_0), ..., l2n(x_{k-1}))), k <= 4 blocks [n, lds[i]] with dims[i] columns
+ *   (approaches/alinet.py:835-840 / 932-943); out [n, ld_out], ld_out >= sum dims (pad columns get zeros);
+ *   inv_blk [n, 4] / inv_all [n]: the inverse norms, kept for the backward.  bwd: dz [n, ld_out] -> dx[i] [n, lds[i]].
+ * oea_pair_loss_l2_*: alinet.py:828-850 (compute_loss).  pairs int32 [m, 2], the first n_pos of them positive links:
+ *   term_p = ||e_i - e_j||^2 (positive) | balance * weight * relu(margin - ||e_i - e_j||^2) (negative; weight [m - n_pos]
+ *   or NULL = 1); the loss is the sum of terms [m] (the caller adds them: fixed order); coef [m] = d term / d ||.||^2.
+ *   bwd: rowptr [n + 1] / other [2 m] / slot_pair [2 m] = the pairs' endpoints grouped by embedding row (slot order =
+ *   the summation order), gscale = device scalar d L / d loss; grad [n, ld]: every row written.
+ * oea_highway_*: gate = relu(tanh(p)), out = tanh(b' (1 - gate) + a' gate), a' = a gamma + beta, b' = b gamma + beta
+ *   (alinet.py:597-622; gamma / beta = the layer's BatchNormalization affine, gamma already divided by sqrt(1 + eps));
+ *   bwd: da, db, dp [n, d] and partials [oea_colsum_blocks(n), 2, d] whose sums over dim 0 are d gamma, d beta.
+ * oea_bias_tanh_*: y = tanh(x + bias) (alinet.py:583-590); bwd: gx [n, d], partials [oea_colsum_blocks(n), d] -> d bias.
+ * ------------------------------------------------------------------------------------- */
+int oea_concat_l2n_fwd(const float *const *x, const int32_t *dims, const int32_t *lds, int32_t k, int64_t n, float *out,
+                       int32_t ld_out, float *inv_blk, float *inv_all, void *stream);
+int oea_concat_l2n_bwd(float *const *dx, const int32_t *dims, const int32_t *lds, int32_t k, int64_t n, const float *z,
+                       const float *dz, int32_t ld_out, const float *inv_blk, const float *inv_all, void *stream);
+int oea_pair_loss_l2_fwd(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *pairs, int64_t m, int64_t n_pos,
+                         const float *weight, float margin, float balance, float *coef, float *terms, void *stream);
+int oea_pair_loss_l2_bwd(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
+                         const int32_t *slot_pair, const float *coef, const float *gscale, float *grad, void *stream);
+int32_t oea_colsum_blocks(int64_t n);
+int oea_highway_fwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, int64_t n, int32_t d,
+                    float *out, void *stream);
+int oea_highway_bwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, const float *out,
+                    const float *gout, int64_t n, int32_t d, float *da, float *db, float *dp, float *partials, void *stream);
+int oea_bias_tanh_fwd(const float *x, const float *bias, int64_t n, int32_t d, float *y, void *stream);
+int oea_bias_tanh_bwd(const float *y, const float *gy, int64_t n, int32_t d, float *gx, float *partials, void *stream);
+
 /* Dense Adam step with tf.train.AdamOptimizer semantics (alinet.py:871, rdgcn.py:332); t = 1-based
  * step count. */
 int oea_adam_dense(float *param, const float *grad, float *m, float *v, int64_t n, float lr, float beta1,

@@ -27,7 +27,7 @@ import torch
 from .. import ops
 from ..models.basic_model import BasicModel
 from ..modules.base.optimizers import generate_optimizer
-from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
+from ..models.graph_ops import EdgeGraph, TFAdam, bias_tanh, concat_l2n, highway_gate, pair_loss, sparse_attention, spmm
 from ..modules.finding.evaluation import early_stop
 from ..modules.load import read as rd
 
@@ -322,7 +322,15 @@ class BatchNormAffine:
         self.beta = torch.zeros(dim, device=dev, requires_grad=True)
 
     def __call__(self, x):
-        return x * (self.gamma / math.sqrt(1.0 + BN_EPS)) + self.beta
+        return torch.addcmul(self.beta, x, self.scale())          # one pass: x * gamma' + beta
+
+    def scale(self):
+        return self.gamma / math.sqrt(1.0 + BN_EPS)
+
+    def fold(self, weight):
+        """BN(x) @ W = x @ (gamma'[:, None] * W) + beta @ W: the affine map folded into the [d_in, d_out] weight and a bias
+        row -- two small tensors (autograd reaches gamma / beta through them) instead of two passes over [E, d_in]."""
+        return self.scale()[:, None] * weight, self.beta @ weight
 
     def params(self):
         return [self.gamma, self.beta]
@@ -338,8 +346,8 @@ class GraphConvolution:
         self.bias = torch.zeros(output_dim, device=dev, requires_grad=True)
 
     def call(self, inputs):
-        x = self.bn(inputs)
-        return torch.tanh(spmm(self.graph, x @ self.kernel) + self.bias)
+        wf, bw = self.bn.fold(self.kernel)
+        return bias_tanh(spmm(self.graph, torch.addmm(bw, inputs, wf)), self.bias)      # csrc/gnn_fused.hip
 
     def params(self):
         return self.bn.params() + [self.kernel, self.bias]
@@ -376,9 +384,9 @@ class HighwayLayer:
         self.bn = BatchNormAffine(input_dim, dev)
 
     def call(self, input1, input2):
-        input1, input2 = self.bn(input1), self.bn(input2)
-        gate = torch.relu(torch.tanh(input1 @ self.weight))
-        return torch.tanh(input2 * (1 - gate) + input1 * gate)
+        wf, bw = self.bn.fold(self.weight)
+        p = torch.addmm(bw, input1, wf)                              # BN(input1) @ W
+        return highway_gate(input1, input2, p, self.bn.scale(), self.bn.beta)      # csrc/gnn_fused.hip, one pass each way
 
     def params(self):
         return self.bn.params() + [self.weight]
@@ -476,17 +484,13 @@ class AliNet(BasicModel):
 
     def _concat_train(self, outs):
         """alinet.py:835-840: l2n(concat(l2n(out_0), ..., l2n(init)))."""
-        return l2n(torch.cat([l2n(o) for o in outs + [self.init_embedding]], dim=1))
+        return concat_l2n(outs + [self.init_embedding])              # csrc/gnn_fused.hip: one pass each way
 
     def compute_loss(self, emb, pos_links, neg_links, neg_valid=None):
         """alinet.py:828-850.  neg_valid: 0/1 weights of the drawn pairs (device sampler: duplicates and
         supervised pairs carry 0 instead of being removed from the list)."""
-        e1, e2 = emb[pos_links[:, 0]], emb[pos_links[:, 1]]
-        pos_loss = ((e1 - e2) ** 2).sum()
-        n1, n2 = emb[neg_links[:, 0]], emb[neg_links[:, 1]]
-        hinge = torch.relu(self.args.neg_margin - ((n1 - n2) ** 2).sum(1))
-        neg_loss = hinge.sum() if neg_valid is None else (hinge * neg_valid).sum()
-        return pos_loss + self.args.neg_margin_balance * neg_loss
+        dim = sum(self.args.layer_dims)
+        return pair_loss(emb, dim, pos_links, neg_links, neg_valid, self.args.neg_margin, self.args.neg_margin_balance)
 
     def compute_rel_loss(self, emb, hs, ts):
         """alinet.py:852-866."""

@@ -274,6 +274,100 @@ class SparseAttnFn(torch.autograd.Function):
         return dz, dv, None, None
 
 
+class ConcatL2NormFn(torch.autograd.Function):
+    """l2n(concat(l2n(x_0), ..., l2n(x_{k-1}))) in one pass each way (oea_concat_l2n_fwd / bwd); output [n, pad4(sum d)]."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [x.contiguous() for x in xs]
+        out, inv_blk, inv_all = ops.concat_l2n_fwd(xs)
+        ctx.dims = [x.shape[1] for x in xs]
+        ctx.save_for_backward(out, inv_blk, inv_all)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        out, inv_blk, inv_all = ctx.saved_tensors
+        return tuple(ops.concat_l2n_bwd(ctx.dims, out, dz.contiguous(), inv_blk, inv_all))
+
+
+class PairLossFn(torch.autograd.Function):
+    """sum ||e_i - e_j||^2 over the positive links + balance * sum w relu(margin - ||e_i - e_j||^2) over the negative ones
+    (alinet.py:828-850) -> scalar.  Forward: one wave per pair; backward: the pairs' endpoints grouped by embedding row
+    (one stable device sort per batch), one wave per row adds its active pairs in slot order -- no atomics."""
+
+    @staticmethod
+    def forward(ctx, emb, dim, pos, neg, weight, margin, balance):
+        emb = emb.contiguous()
+        pairs = torch.cat([pos, neg]).to(torch.int32).contiguous()
+        terms, coef = ops.pair_loss_l2_fwd(emb, dim, pairs, pos.shape[0], weight, margin, balance)
+        ctx.dim = dim
+        ctx.save_for_backward(emb, pairs, coef)
+        return terms.sum()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        emb, pairs, coef = ctx.saved_tensors
+        m = pairs.shape[0]
+        ends = torch.cat([pairs[:, 0], pairs[:, 1]]).to(torch.int64)
+        order = torch.argsort(ends, stable=True)
+        rowptr = torch.zeros(emb.shape[0] + 1, dtype=torch.int64, device=emb.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(ends, minlength=emb.shape[0]), 0)
+        other = torch.cat([pairs[:, 1], pairs[:, 0]])[order].contiguous()
+        slot_pair = (order % m).to(torch.int32).contiguous()
+        g = gloss.to(torch.float32).reshape(1).contiguous()
+        grad = ops.pair_loss_l2_bwd(emb, ctx.dim, rowptr.to(torch.int32), other, slot_pair, coef, g)
+        return grad, None, None, None, None, None, None
+
+
+class HighwayFn(torch.autograd.Function):
+    """out = tanh(b' (1 - gate) + a' gate), gate = relu(tanh(p)), a' / b' = a / b through the layer's BatchNorm affine
+    (alinet.py:597-622), one pass each way (oea_highway_fwd / bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, b, p, gamma, beta):
+        a, b, p = a.contiguous(), b.contiguous(), p.contiguous()
+        out = ops.highway_fwd(a, b, p, gamma.contiguous(), beta.contiguous())
+        ctx.save_for_backward(a, b, p, gamma, beta, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b, p, gamma, beta, out = ctx.saved_tensors
+        return ops.highway_bwd(a, b, p, gamma.contiguous(), beta.contiguous(), out, gout.contiguous())
+
+
+class BiasTanhFn(torch.autograd.Function):
+    """tanh(x + bias) (alinet.py:583-590), one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        y = ops.bias_tanh_fwd(x.contiguous(), bias.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.bias_tanh_bwd(y, gy.contiguous())
+
+
+def concat_l2n(xs):
+    return ConcatL2NormFn.apply(*xs)
+
+
+def pair_loss(emb, dim, pos, neg, weight, margin, balance):
+    return PairLossFn.apply(emb, dim, pos, neg, weight, margin, balance)
+
+
+def highway_gate(a, b, p, gamma, beta):
+    return HighwayFn.apply(a, b, p, gamma, beta)
+
+
+def bias_tanh(x, bias):
+    return BiasTanhFn.apply(x, bias)
+
+
 def spmm(graph, x):
     return SpmmFn.apply(x, graph)
 

@@ -692,3 +692,84 @@ def adam_dense_(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     check(lib().oea_adam_dense(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr), float(beta1), float(beta2),
                                float(eps), int(t), _stream()))
     return param
+
+
+# -------------------------------------------------------------------------------------------
+# fused row-wise glue of the GNN approaches (csrc/gnn_fused.hip)
+# -------------------------------------------------------------------------------------------
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def _i32_array(vals):
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def concat_l2n_fwd(xs):
+    """xs: list of <= 4 contiguous [n, d_i] fp32 tensors -> (emb [n, pad4(sum d)], inv_blk [n, 4], inv_all [n])."""
+    n = xs[0].shape[0]
+    dims = [x.shape[1] for x in xs]
+    out = torch.empty((n, pad4(sum(dims))), dtype=torch.float32, device=xs[0].device)
+    inv_blk = torch.empty((n, 4), dtype=torch.float32, device=out.device)
+    inv_all = torch.empty(n, dtype=torch.float32, device=out.device)
+    check(lib().oea_concat_l2n_fwd(_ptr_array(xs), _i32_array(dims), _i32_array(dims), len(xs), n, _p(out), out.shape[1],
+                                   _p(inv_blk), _p(inv_all), _stream()))
+    return out, inv_blk, inv_all
+
+
+def concat_l2n_bwd(dims, z, dz, inv_blk, inv_all):
+    n = z.shape[0]
+    dxs = [torch.empty((n, d), dtype=torch.float32, device=z.device) for d in dims]
+    check(lib().oea_concat_l2n_bwd(_ptr_array(dxs), _i32_array(dims), _i32_array(dims), len(dims), n, _p(z), _p(dz), z.shape[1],
+                                   _p(inv_blk), _p(inv_all), _stream()))
+    return dxs
+
+
+def pair_loss_l2_fwd(emb, dim, pairs, n_pos, weight, margin, balance):
+    """pairs int32 [m, 2] (the first n_pos positive) -> (terms [m], coef [m])."""
+    m = pairs.shape[0]
+    coef = torch.empty(m, dtype=torch.float32, device=emb.device)
+    terms = torch.empty(m, dtype=torch.float32, device=emb.device)
+    check(lib().oea_pair_loss_l2_fwd(_p(emb), emb.shape[0], dim, emb.shape[1], _p(pairs), m, int(n_pos), _p(weight), float(margin),
+                                     float(balance), _p(coef), _p(terms), _stream()))
+    return terms, coef
+
+
+def pair_loss_l2_bwd(emb, dim, rowptr, other, slot_pair, coef, gscale):
+    grad = torch.empty_like(emb)
+    check(lib().oea_pair_loss_l2_bwd(_p(emb), emb.shape[0], dim, emb.shape[1], _p(rowptr), _p(other), _p(slot_pair), _p(coef),
+                                     _p(gscale), _p(grad), _stream()))
+    return grad
+
+
+def highway_fwd(a, b, p, gamma, beta):
+    out = torch.empty_like(a)
+    check(lib().oea_highway_fwd(_p(a), _p(b), _p(p), _p(gamma), _p(beta), a.shape[0], a.shape[1], _p(out), _stream()))
+    return out
+
+
+def highway_bwd(a, b, p, gamma, beta, out, gout):
+    n, d = a.shape
+    da, db, dp = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    parts = torch.empty((lib().oea_colsum_blocks(n), 2, d), dtype=torch.float32, device=a.device)
+    check(lib().oea_highway_bwd(_p(a), _p(b), _p(p), _p(gamma), _p(beta), _p(out), _p(gout), n, d, _p(da), _p(db), _p(dp), _p(parts),
+                                _stream()))
+    sums = parts.sum(0)
+    return da, db, dp, sums[0], sums[1]
+
+
+def bias_tanh_fwd(x, bias):
+    y = torch.empty_like(x)
+    check(lib().oea_bias_tanh_fwd(_p(x), _p(bias), x.shape[0], x.shape[1], _p(y), _stream()))
+    return y
+
+
+def bias_tanh_bwd(y, gy):
+    n, d = y.shape
+    gx = torch.empty_like(y)
+    parts = torch.empty((lib().oea_colsum_blocks(n), d), dtype=torch.float32, device=y.device)
+    check(lib().oea_bias_tanh_bwd(_p(y), _p(gy), n, d, _p(gx), _p(parts), _stream()))
+    return gx, parts.sum(0)

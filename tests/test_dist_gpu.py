@@ -143,7 +143,8 @@ def _launch(tmp_path, world, prefix="result", **extra_env):
         outs.append(out.decode(errors="replace"))
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    return [np.load(os.path.join(str(tmp_path), "%s_w%d_r%d.npz" % (prefix, world, r))) for r in range(world)]
+    # read eagerly: a later launch with the same world size overwrites the files
+    return [dict(np.load(os.path.join(str(tmp_path), "%s_w%d_r%d.npz" % (prefix, world, r))).items()) for r in range(world)]
 
 
 def test_two_ranks_reproduce_single_process(tmp_path):

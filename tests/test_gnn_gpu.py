@@ -90,6 +90,104 @@ def test_sparse_attention_single_edge_runs(ops):
     assert not z.grad.cpu().numpy().any()
 
 
+def _l2n(x):
+    return x * torch.rsqrt(torch.clamp((x * x).sum(1, keepdim=True), min=1e-12))
+
+
+@pytest.mark.parametrize("dims", [[8, 4, 8], [400, 300, 500], [75], [130, 62]])
+def test_fused_concat_l2n_equals_torch(ops, dims):
+    """csrc/gnn_fused.hip: l2n(concat(l2n(x_k))) forward + backward against the plain torch fp32 composition
+    (alinet.py:835-840), including an all-zero row (the 1e-12 clamp)."""
+    from openea_amd.models.graph_ops import concat_l2n
+    dev = ops.device()
+    rng = np.random.RandomState(sum(dims))
+    n = 301
+    host = [rng.standard_normal((n, d)).astype(np.float32) * (0.1 + i) for i, d in enumerate(dims)]
+    host[0][7] = 0.0
+    xs = [torch.tensor(h, device=dev, requires_grad=True) for h in host]
+    xr = [torch.tensor(h, device=dev, requires_grad=True) for h in host]
+    w = torch.tensor(rng.standard_normal((n, sum(dims))).astype(np.float32), device=dev)
+    out = concat_l2n(xs)
+    ref = _l2n(torch.cat([_l2n(x) for x in xr], dim=1))
+    assert out.shape[1] == ops.pad4(sum(dims)) and not out[:, sum(dims):].any()
+    np.testing.assert_allclose(out[:, :sum(dims)].detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    (out[:, :sum(dims)] * w).sum().backward()
+    (ref * w).sum().backward()
+    for a, b in zip(xs, xr):
+        keep = np.ones(n, bool)
+        if a is xs[0]:
+            keep[7] = False              # torch differentiates the clamp of the zero row as a constant: both are "some" subgradient
+        np.testing.assert_allclose(a.grad.cpu().numpy()[keep], b.grad.cpu().numpy()[keep], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("d", [20, 1200])
+def test_fused_pair_loss_equals_torch(ops, d):
+    """alinet.py:828-850: loss and gradient w.r.t. the embedding rows against the torch composition; two runs identical
+    (the backward sums a row's pairs in slot order, no atomics)."""
+    from openea_amd.models.graph_ops import pair_loss
+    dev = ops.device()
+    rng = np.random.RandomState(d)
+    n, n_pos, n_neg = 500, 120, 900
+    e = rng.standard_normal((n, d)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    pos = torch.tensor(rng.randint(0, n, (n_pos, 2)), device=dev)
+    neg = torch.tensor(rng.randint(0, 40, (n_neg, 2)), device=dev)            # few rows: long per-row slot lists, equal pairs
+    valid = torch.tensor((rng.rand(n_neg) < 0.8).astype(np.float32), device=dev)
+    grads = []
+    for _ in range(2):
+        emb = torch.tensor(e, device=dev, requires_grad=True)
+        loss = pair_loss(emb, d, pos, neg, valid, 1.5, 0.1)
+        (loss * 0.7).backward()
+        grads.append(emb.grad.cpu().numpy())
+    assert np.array_equal(grads[0], grads[1])
+    er = torch.tensor(e, device=dev, requires_grad=True)
+    hinge = torch.relu(1.5 - ((er[neg[:, 0]] - er[neg[:, 1]]) ** 2).sum(1))
+    ref = ((er[pos[:, 0]] - er[pos[:, 1]]) ** 2).sum() + 0.1 * (hinge * valid).sum()
+    (ref * 0.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    np.testing.assert_allclose(grads[0], er.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert float((hinge > 0).float().mean()) > 0.05 and float((hinge == 0).float().mean()) > 0.05
+
+
+def test_fused_highway_and_bias_tanh_equal_torch(ops):
+    """alinet.py:597-622 / :583-590: gate + output and bias + tanh, forward and every gradient (incl. the BatchNorm affine's
+    column sums) against the torch composition."""
+    import math
+    from openea_amd.models.graph_ops import bias_tanh, highway_gate
+    dev = ops.device()
+    rng = np.random.RandomState(9)
+    n, d = 1500, 400
+
+    def mk(*shape, s=1.0):
+        return rng.standard_normal(shape).astype(np.float32) * s
+    h = dict(a=mk(n, d), b=mk(n, d), p=mk(n, d), g=1.0 + mk(d, s=0.1), be=mk(d, s=0.1))
+    w = torch.tensor(mk(n, d), device=dev)
+    t1 = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in h.items()}
+    t2 = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in h.items()}
+    out = highway_gate(t1["a"], t1["b"], t1["p"], t1["g"], t1["be"])
+    av, bv = t2["a"] * t2["g"] + t2["be"], t2["b"] * t2["g"] + t2["be"]
+    gate = torch.relu(torch.tanh(t2["p"]))
+    ref = torch.tanh(bv * (1 - gate) + av * gate)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    for k in h:
+        a, b = t1[k].grad.cpu().numpy(), t2[k].grad.cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), k
+    x1 = torch.tensor(h["a"], device=dev, requires_grad=True)
+    x2 = torch.tensor(h["a"], device=dev, requires_grad=True)
+    b1 = torch.tensor(h["be"], device=dev, requires_grad=True)
+    b2 = torch.tensor(h["be"], device=dev, requires_grad=True)
+    y = bias_tanh(x1, b1)
+    yr = torch.tanh(x2 + b2)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    (y * w).sum().backward()
+    (yr * w).sum().backward()
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert np.abs(b1.grad.cpu().numpy() - b2.grad.cpu().numpy()).max() <= 2e-4 * np.abs(b2.grad.cpu().numpy()).max()
+    assert math.isfinite(float(y.sum()))
+
+
 def test_spmm_autograd(ops):
     from openea_amd.models.graph_ops import EdgeGraph, spmm
     rng = np.random.RandomState(1)
