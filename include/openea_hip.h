@@ -405,6 +405,16 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
                   int32_t *rank, int32_t *argmax, void *workspace, void *stream);
 /* integer reductions of rank[]: hits[i] = #{rank < top_k[i]}, rank_sum = sum(rank+1) (int64),
  * rr_sum = sum 1/(rank+1) (double, fixed summation order).  alignment.py:163-168. */
+/* The inner-product evaluation in TWO launches (the 10,500^2 call spent a third of its time in eight small
+ * launches around the 0.20 ms sweep): a prologue that packs both operands, computes the gold similarities and clears the
+ * merge buffers, and the tile sweep, whose last workgroup extracts argmax and reduces the metrics in a fixed order.
+ * hits_and_rank_sum_dev: int64 [nk + 1] (Hits@top_k[i] counts, then sum(rank + 1)); rr_sum_dev: double sum 1 / (rank + 1).
+ * workspace: oea_rank_eval_metrics_workspace_bytes(n1).  Same ranks / argmax as oea_rank_eval + oea_rank_metrics. */
+size_t oea_rank_eval_metrics_workspace_bytes(int64_t n1);
+int oea_rank_eval_metrics(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                          const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
+                          int32_t *rank, int32_t *argmax, int64_t *hits_and_rank_sum_dev, double *rr_sum_dev, void *workspace,
+                          void *stream);
 int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, int32_t nk,
                      int64_t *hits_dev, int64_t *rank_sum_dev, double *rr_sum_dev, void *stream);
 

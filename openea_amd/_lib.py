@@ -136,6 +136,8 @@ PROTOTYPES = {
     "oea_rank_workspace_bytes": (_sz, [_i64]),
     "oea_rank_eval": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "oea_rank_eval_metrics_workspace_bytes": (_sz, [_i64]),
+    "oea_rank_eval_metrics": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oea_sim_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "oea_row_topk_mean": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "oea_csls_means_workspace_bytes": (_sz, [_i64, _i64, _i32]),

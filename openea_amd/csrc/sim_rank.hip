@@ -305,6 +305,103 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
     gold[i] = acc;
 }
 
+// ---- fused evaluation: ONE prologue launch + the sweep (oea_rank_eval_metrics) -------------------------------------------------
+// The 10,500^2 evaluation of BASELINE configs[1] is a 0.20 ms tile sweep; with its operands packed by two launches, the gold
+// similarities by a third, two memsets, the argmax extraction and the metric reduction by two more, and a zero-fill of the
+// result buffer, the call took 0.28 ms.  Prologue: both packs + golds + zeroing in one grid-stride
+// kernel.  Epilogue: the sweep's workgroups take a ticket after their integer atomics; the last one reads the merged ranks /
+// keys back (device-coherent loads), writes argmax and reduces Hits@k / sum(rank + 1) / sum 1 / (rank + 1) in a fixed order.
+struct EvalTail {
+    unsigned *done;            // NULL: plain oea_rank_eval (argmax / metrics by separate launches)
+    int32_t *argmax;
+    long long *hits;           // [nk], then rank_sum at hits[nk]
+    double *rr_sum;
+    int tk[8];
+    int nk;
+};
+
+__device__ __forceinline__ void eval_tail(const EvalTail &t, const int32_t *rank, const unsigned long long *best_key, int64_t n1,
+                                          long long *s_i, double *s_d) {
+    long long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double rr = 0.0;
+    for (int64_t i = threadIdx.x; i < n1; i += blockDim.x) {
+        const int r = __hip_atomic_load(rank + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // other XCDs' atomics
+        const unsigned long long key = __hip_atomic_load(best_key + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t.argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] += (k < t.nk && r < t.tk[k]);
+        h[8] += r + 1;
+        rr += 1.0 / (double)(r + 1);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) h[k] += __shfl_xor(h[k], off, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+    __syncthreads();                 // the tile buffers are free: every wave is past its last MFMA chunk
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_i[wave * 9 + k] = h[k];
+        s_d[wave] = rr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        long long v = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_i[w * 9 + threadIdx.x];
+        if ((int)threadIdx.x < t.nk) t.hits[threadIdx.x] = v;
+        else if (threadIdx.x == 8) t.hits[t.nk] = v;
+    } else if (threadIdx.x == 9) {
+        double v = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_d[w];
+        *t.rr_sum = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void eval_prologue_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
+                                                            const float *__restrict__ e2, int64_t n2, int ld2, int dim,
+                                                            float *__restrict__ p1, int64_t n1_pad, float *__restrict__ p2,
+                                                            int64_t n2_pad, int kp, const float *__restrict__ csls_r,
+                                                            const float *__restrict__ csls_c, int64_t gold_off,
+                                                            float *__restrict__ gold, unsigned long long *__restrict__ keys,
+                                                            int32_t *__restrict__ rank, unsigned *__restrict__ done) {
+    const int cpr = kp / 4;
+    const int64_t t1 = n1_pad * cpr, t2 = n2_pad * cpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = gid; i < t1 + t2; i += stride) {                 // pack_rows_kernel for both operands
+        const bool second = i >= t1;
+        const int64_t ii = second ? i - t1 : i;
+        const int64_t row = ii / cpr;
+        const int c = (int)(ii - row * cpr);
+        const int k = 8 * (c >> 1) + (c & 1);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < (second ? n2 : n1)) {
+            const float *r = second ? e2 + row * ld2 : e1 + row * ld1;
+            if (k < dim) v.x = r[k];
+            if (k + 2 < dim) v.y = r[k + 2];
+            if (k + 4 < dim) v.z = r[k + 4];
+            if (k + 6 < dim) v.w = r[k + 6];
+        }
+        oea::st4((second ? p2 : p1) + row * kp + 4 * c, v);
+    }
+    for (int64_t i = gid; i < n1; i += stride) {                      // gold_inner_kernel + the two memsets
+        const float *a = e1 + i * ld1, *b = e2 + (gold_off + i) * ld2;
+        float acc = 0.f;
+        int k = 0;
+        for (; k + 4 <= dim; k += 4) {
+            const float4 x = oea::ld4(a + k), y = oea::ld4(b + k);
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+        for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+        if (csls_r) acc = (2.0f * acc - csls_r[i]) - csls_c[gold_off + i];
+        gold[i] = acc;
+        keys[i] = 0ull;
+        rank[i] = 0;
+    }
+    if (gid == 0) *done = 0u;
+}
+
 // ---- fused rank epilogue: M = candidates (e2 rows), N = queries (e1 rows) -----------------------
 // grid.x = query tiles, grid.y = candidate chunks.  Per lane: one query (MFMA column) and 16
 // candidates per MFMA tile, so the per-query reductions stay in registers across the whole
@@ -313,7 +410,8 @@ template <bool CSLS, bool PACKED>
 __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
     const float *__restrict__ e1, int64_t n1, int ld1, const float *__restrict__ e2, int64_t n2, int ld2,
     int dim, const float *__restrict__ gold, const float *__restrict__ csls_r, const float *__restrict__ csls_c,
-    int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key) {
+    int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key,
+    EvalTail tail) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,6 +492,17 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
             if (cnt[tn]) atomicAdd(rank + qi[tn], cnt[tn]);
             const unsigned long long key = ((unsigned long long)f2ord(best[tn]) << 32) | (0xFFFFFFFFu - (uint32_t)bidx[tn]);
             atomicMax(best_key + qi[tn], key);
+        }
+    }
+    if (tail.done) {                 // fused evaluation (oea_rank_eval_metrics): the workgroup that arrives LAST finishes the job
+        __shared__ int s_last;
+        __threadfence();             // this thread's atomics are performed before the ticket below can be seen
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(tail.done, 1u) == gridDim.x * gridDim.y - 1u;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            eval_tail(tail, rank, best_key, n1, reinterpret_cast<long long *>(As), reinterpret_cast<double *>(Bs));
         }
     }
 }
@@ -1223,9 +1332,23 @@ struct PackSlot {
 };
 static PackSlot g_slot[4];       // 0 = queries, 1 = candidates, 2 / 3 = column / row samples (neighbour search, CSLS means)
 
+static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedOp *out, int64_t *n_pad_out);
+
 static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
+    int64_t n_pad = 0;
+    const int rc = reserve_operand(slot, n, dim, st, out, &n_pad);
+    if (rc != OEA_OK) return rc;
+    const int64_t total = n_pad * (out->kp / 4);
+    pack_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 16384), 256, 0, st>>>(src, n, ld, dim, out->p, n_pad,
+                                                                                                   out->kp);
+    return OEA_OK;
+}
+
+// the slot's buffer for an [n, dim] operand (grown if needed, ordered behind its previous use), without the pack launch
+static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedOp *out, int64_t *n_pad_out) {
     PackSlot &sl = g_slot[slot];
     const int64_t n_pad = (n + TILE - 1) / TILE * TILE;
+    *n_pad_out = n_pad;
     out->kp = (dim + BK - 1) / BK * BK;
     const size_t need = sizeof(float) * (size_t)n_pad * out->kp;
     if (!sl.used) OEA_CHECK_HIP(hipEventCreateWithFlags(&sl.used, hipEventDisableTiming));
@@ -1241,9 +1364,6 @@ static int pack_operand(int slot, const float *src, int64_t n, int ld, int dim, 
     }
     sl.last = st;
     out->p = sl.p;
-    const int64_t total = n_pad * (out->kp / 4);
-    pack_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 16384), 256, 0, st>>>(src, n, ld, dim, out->p, n_pad,
-                                                                                                   out->kp);
     return OEA_OK;
 }
 // after the kernels that read the packed operands have been enqueued
@@ -1389,18 +1509,18 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
             if (rc != OEA_OK) return rc;
             if (csls_r)
                 rank_inner_kernel<true, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
-                                                                    gold_offset, rank, keys);
+                                                                    gold_offset, rank, keys, EvalTail{});
             else
                 rank_inner_kernel<false, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
-                                                                     gold_offset, rank, keys);
+                                                                     gold_offset, rank, keys, EvalTail{});
             rc = release_packed(st);
             if (rc != OEA_OK) return rc;
         } else if (csls_r) {
             rank_inner_kernel<true, false><<<grid, 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset,
-                                                                 rank, keys);
+                                                                 rank, keys, EvalTail{});
         } else {
             rank_inner_kernel<false, false><<<grid, 256, 0, st>>>(e1, n1, ld1, e2, n2, ld2, dim, gold, csls_r, csls_c, tpc, gold_offset,
-                                                                  rank, keys);
+                                                                  rank, keys, EvalTail{});
         }
     } else if (metric == OEA_METRIC_MANHATTAN || metric == OEA_METRIC_EUCLIDEAN) {
         const int64_t qt = oea::ceil_div(n1, VT), ctiles = oea::ceil_div(n2, VT);
@@ -1432,6 +1552,53 @@ int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, 
     rank_metrics_kernel<<<1, 1024, 0, oea::as_stream(stream)>>>(rank, n, make_int4(t[0], t[1], t[2], t[3]),
                                                                make_int4(t[4], t[5], t[6], t[7]), nk,
                                                                (long long *)hits_dev, (long long *)rank_sum_dev, rr_sum_dev);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+size_t oea_rank_eval_metrics_workspace_bytes(int64_t n1) { return oea_rank_workspace_bytes(n1) + 256; }
+
+int oea_rank_eval_metrics(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                          const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
+                          int32_t *rank, int32_t *argmax, int64_t *hits_and_rank_sum_dev, double *rr_sum_dev, void *workspace,
+                          void *stream) {
+    OEA_REQUIRE(e1 && e2 && rank && argmax && workspace && top_k_host && hits_and_rank_sum_dev && rr_sum_dev, "null pointer");
+    OEA_REQUIRE(n1 > 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
+    OEA_REQUIRE((csls_r == nullptr) == (csls_c == nullptr), "csls_r and csls_c go together");
+    OEA_REQUIRE(n2 < 0x7fffffff && nk >= 1 && nk <= 8, "n2 < 2^31, 1 <= len(top_k) <= 8");
+    if (!use_glds()) { oea::set_error("oea_rank_eval_metrics needs the packed-operand tiles (OEA_TILE_GLDS=0 is set)"); return OEA_EUNSUPPORTED; }
+    hipStream_t st = oea::as_stream(stream);
+    unsigned long long *keys = static_cast<unsigned long long *>(workspace);
+    float *gold = reinterpret_cast<float *>(keys + n1);
+    unsigned *done = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + ((oea_rank_workspace_bytes(n1) + 15) / 16) * 16);
+    PackedOp p1, p2;
+    int64_t n1_pad = 0, n2_pad = 0;
+    int rc = reserve_operand(0, n1, dim, st, &p1, &n1_pad);
+    if (rc == OEA_OK) rc = reserve_operand(1, n2, dim, st, &p2, &n2_pad);
+    if (rc != OEA_OK) return rc;
+    const int64_t work = (n1_pad + n2_pad) * (p1.kp / 4);
+    eval_prologue_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(work, 256), 16384), 256, 0, st>>>(
+        e1, n1, ld1, e2, n2, ld2, dim, p1.p, n1_pad, p2.p, n2_pad, p1.kp, csls_r, csls_c, gold_offset, gold, keys, rank, done);
+    EvalTail tail{};
+    tail.done = done;
+    tail.argmax = argmax;
+    tail.hits = reinterpret_cast<long long *>(hits_and_rank_sum_dev);
+    tail.rr_sum = rr_sum_dev;
+    tail.nk = nk;
+    for (int i = 0; i < nk; ++i) tail.tk[i] = top_k_host[i];
+    int tpc = 1;
+    const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
+    const int chunks = pick_chunks(qt, ctiles, &tpc);
+    const dim3 grid((unsigned)qt, (unsigned)chunks);
+    if (csls_r)
+        rank_inner_kernel<true, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
+                                                            gold_offset, rank, keys, tail);
+    else
+        rank_inner_kernel<false, true><<<grid, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, p2.kp, dim, gold, csls_r, csls_c, tpc,
+                                                             gold_offset, rank, keys, tail);
+    rc = release_packed(st);
+    if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -28,6 +28,8 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
     r = c = None
     if csls_k > 0:
         r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
+    if kmetric == 'inner' and 1 <= len(top_k) <= 8 and ops.tile_glds():
+        return ops.rank_eval_metrics(t1, t2, dim, top_k, r, c)             # prologue + sweep: two launches, one copy back
     rank, argmax = ops.rank_eval(t1, t2, dim, kmetric, r, c)
     hits, rank_sum, rr_sum = ops.rank_metrics(rank, top_k)
     return rank, argmax, hits, rank_sum, rr_sum

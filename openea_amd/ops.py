@@ -408,6 +408,31 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     return rank, argmax
 
 
+def tile_glds():
+    """the similarity tiles run on packed operands staged by LDS-DMA (default; OEA_TILE_GLDS=0 selects the register-staged
+    pipeline, kept for the bit-exactness test between the two)"""
+    import os
+    return os.environ.get("OEA_TILE_GLDS", "1")[:1] != "0"
+
+
+def rank_eval_metrics(e1, e2, dim, top_k, csls_r=None, csls_c=None, gold_offset=0):
+    """inner-product evaluation in two launches (oea_rank_eval_metrics) + ONE device->host copy ->
+    (rank int32 [n1] device, argmax int32 [n1] device, hits counts list[int], rank_sum int, rr_sum float)."""
+    n1, n2 = e1.shape[0], e2.shape[0]
+    assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
+    nk = len(top_k)
+    ws = torch.empty(lib().oea_rank_eval_metrics_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
+    rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    buf = torch.empty(nk + 2, dtype=torch.int64, device=e1.device)     # hits[nk], rank_sum, rr bits: all written by the kernel
+    tk = (C.c_int32 * nk)(*[int(k) for k in top_k])
+    check(lib().oea_rank_eval_metrics(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, _p(csls_r), _p(csls_c),
+                                      int(gold_offset), tk, nk, _p(rank), _p(argmax), C.c_void_p(buf.data_ptr()),
+                                      C.c_void_p(buf.data_ptr() + 8 * (nk + 1)), _p(ws), _stream()))
+    host = buf.cpu().numpy()
+    return rank, argmax, [int(x) for x in host[:nk]], int(host[nk]), float(host[nk + 1:nk + 2].view(np.float64)[0])
+
+
 def rank_rows(s, gold_idx):
     """rank of column gold_idx[i] in row i of a device similarity block + row argmax -> (int32[n], int32[n])."""
     n = s.shape[0]

@@ -103,6 +103,31 @@ def test_rank_metrics(ops):
     assert abs(rr / len(rank) - mrr) < 1e-12
 
 
+@pytest.mark.parametrize("n1,n2,d,csls", [(300, 420, 40, False), (1000, 1500, 100, True), (129, 129, 75, False), (1, 1, 8, False),
+                                          (10500, 10500, 75, False), (2500, 7000, 100, True)])
+def test_rank_eval_metrics_two_launches_equal_the_separate_calls(ops, n1, n2, d, csls):
+    """oea_rank_eval_metrics (prologue + sweep whose last workgroup extracts argmax and reduces the metrics) == oea_rank_eval
+    + oea_rank_metrics == the oracle, bit for bit -- also called twice in a row (the ticket counter is reset by the prologue)."""
+    from oracle import cport
+    rng = np.random.RandomState(n1 + d)
+    e1, e2 = _embeds(rng, n1, n2, d)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    r = c = None
+    if csls:
+        s = ops.sim_matrix(t1, t2, d, "inner")
+        r, c = ops.row_topk_mean(s, 10), ops.row_topk_mean(ops.sim_matrix(t2, t1, d, "inner"), 10)
+    top_k = [1, 5, 10, 50]
+    rank0, am0 = ops.rank_eval(t1, t2, d, "inner", csls_r=r, csls_c=c)
+    hits0, rs0, rr0 = ops.rank_metrics(rank0, top_k)
+    for _ in range(2):
+        rank, am, hits, rs, rr = ops.rank_eval_metrics(t1, t2, d, top_k, r, c)
+        assert np.array_equal(rank.cpu().numpy(), rank0.cpu().numpy()) and np.array_equal(am.cpu().numpy(), am0.cpu().numpy())
+        assert hits == hits0 and rs == rs0 and abs(rr - rr0) <= 1e-9 * max(rr0, 1.0)
+    if n1 <= 1000:
+        r_ref, a_ref = cport.rank_eval(e1, e2, "inner", None if r is None else r.cpu().numpy(), None if c is None else c.cpu().numpy())
+        assert np.array_equal(rank.cpu().numpy(), r_ref) and np.array_equal(am.cpu().numpy(), a_ref)
+
+
 @pytest.mark.parametrize("n2,k", [(1031, 10), (12, 10), (64, 1), (5000, 32), (257, 16)])
 def test_row_topk_mean_edge_cases(ops, n2, k):
     """calculate_nearest_k (similarity.py:80-83): ties, constant rows (more than 256 entries at the threshold ->
