@@ -364,11 +364,21 @@ class AliNetGraphAttentionLayer:
         self.kernel2 = glorot_uniform(rng, (input_dim, input_dim), dev)
 
     def call(self, inputs):
+        g = self.graph
+        if g.single_edge_groups:
+            # every softmax group of the graph is ONE edge (TF1's run grouping on the column-major adjacency preprocess_adj
+            # hands over): alpha = softmax of a single logit = 1 EXACTLY, whatever the logits are, and
+            # d loss / d logit = 0 EXACTLY -- kernel1 / kernel2 neither influence the output nor receive a gradient (Adam
+            # leaves them where they are: m = v = 0).  The two [E, d] x [d, d] products, the row-wise quadratic forms and
+            # their backward passes are therefore skipped; outputs and every gradient are bit-identical with computing them.
+            wf, bw = self.bn.fold(self.kernel)
+            mapped = torch.addmm(bw, inputs, wf)                     # BN(inputs) @ kernel
+            z = torch.zeros(g.nnz, dtype=torch.float32, device=mapped.device)
+            return torch.tanh(sparse_attention(g, z, mapped, slope=0.2))
         x = self.bn(inputs)
         mapped = x @ self.kernel
         s1 = torch.tanh(((x @ self.kernel1) * x).sum(1))
         s2 = torch.tanh(((x @ self.kernel2) * x).sum(1))
-        g = self.graph
         z = g.e_vals * s1[g.e_rows] + g.e_vals * s2[g.e_cols]        # sparse_add of the two products (:667-669)
         return torch.tanh(sparse_attention(g, z, mapped, slope=0.2))
 

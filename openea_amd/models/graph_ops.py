@@ -110,6 +110,11 @@ class EdgeGraph:
         self._cut = (self.SUB, self.HUB, self.CHUNK)           # as set when the graph was made (the build is lazy)
 
     @property
+    def single_edge_groups(self):
+        """every softmax group is one edge (alpha = 1, d z = 0 exactly: csrc/sparse_attn.hip runs no softmax kernel then)"""
+        return self.grouping != 'reorder' and self.nnz > 0 and len(self.seg_row_host) == self.nnz
+
+    @property
     def attn(self):
         if self._attn is None:
             self._build_attn()
@@ -299,7 +304,7 @@ class PairLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb, dim, pos, neg, weight, margin, balance):
         emb = emb.contiguous()
-        pairs = torch.cat([pos, neg]).to(torch.int32).contiguous()
+        pairs = torch.cat([pos[:, :2], neg[:, :2]]).to(torch.int32).contiguous()
         terms, coef = ops.pair_loss_l2_fwd(emb, dim, pairs, pos.shape[0], weight, margin, balance)
         ctx.dim = dim
         ctx.save_for_backward(emb, pairs, coef)

@@ -147,7 +147,7 @@ def _launch(tmp_path, world, prefix="result", **extra_env):
     return [dict(np.load(os.path.join(str(tmp_path), "%s_w%d_r%d.npz" % (prefix, world, r))).items()) for r in range(world)]
 
 
-def test_two_ranks_reproduce_single_process(tmp_path):
+def test_two_ranks_reproduce_single_process(tmp_path, capsys):
     import json
     single = _launch(tmp_path, 1)[0]
     r0, r1 = _launch(tmp_path, 2)
@@ -175,7 +175,11 @@ def test_two_ranks_reproduce_single_process(tmp_path):
         assert np.array_equal(r0[key], r1[key])                       # all-gathered results: identical on every rank
         assert np.array_equal(r0[key], single[key]), key
     assert np.array_equal(r0["alinet"], r1["alinet"])                  # replicas stay in lock-step through 4 Adam epochs
-    assert np.linalg.norm(r0["alinet"] - single["alinet"]) <= 5e-3 * np.linalg.norm(single["alinet"])   # Adam amplifies the rounding
+    d_alinet = np.linalg.norm(r0["alinet"] - single["alinet"]) / np.linalg.norm(single["alinet"])
+    with capsys.disabled():
+        print("\nAliNet two ranks vs single process after 4 Adam epochs: relative L2 %.2e; GCN-Align outputs max abs %.2e"
+              % (d_alinet, float(np.abs(r0["gcn_out"] - single["gcn_out"]).max())))
+    assert d_alinet <= float(os.environ.get("OEA_ALINET_2RANK_TOL", "5e-3"))
     for key in ("mtranse", "bootea", "transd", "rotate"):
         assert np.array_equal(r0[key], r1[key])
         assert np.linalg.norm(r0[key] - single[key]) <= 1e-3 * np.linalg.norm(single[key])

@@ -128,7 +128,7 @@ def test_fused_pair_loss_equals_torch(ops, d):
     dev = ops.device()
     rng = np.random.RandomState(d)
     n, n_pos, n_neg = 500, 120, 900
-    e = rng.standard_normal((n, d)).astype(np.float32)
+    e = (rng.rand(n, 1) * 1.5 * rng.standard_normal((1, d)) + rng.standard_normal((n, d))).astype(np.float32)    # a common component of varying weight: distances straddle the margin
     e /= np.linalg.norm(e, axis=1, keepdims=True)
     pos = torch.tensor(rng.randint(0, n, (n_pos, 2)), device=dev)
     neg = torch.tensor(rng.randint(0, 40, (n_neg, 2)), device=dev)            # few rows: long per-row slot lists, equal pairs

@@ -314,7 +314,9 @@ def test_alinet_model_on_device_equals_reference_graph(grouping):
     loss.backward()
     for name, p in by_name.items():
         ref = t[tag + "_grad_" + name]
-        got = p.grad.detach().cpu().numpy().reshape(ref.shape)
+        # a parameter without a gradient: the attention logits' kernels when every softmax group is one edge (their
+        # gradient is exactly zero -- the reference's finite differences say the same)
+        got = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy().reshape(ref.shape)
         assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 0.05), name
 
 

@@ -210,6 +210,121 @@ def test_rdgcn_layers_100k_shape(tmp_path, capsys):
               % (kgs.entities_num, L.count_r, len(er), ", ".join("%s %.2e" % r for r in report)))
 
 
+def _segment_attention_f64(er, ec, z, v, n_rows, grouping, slope=0.2):
+    """tf.sparse_softmax + sparse_tensor_dense_matmul over the WHOLE graph in float64, vectorised: softmax groups = rows
+    ('row': edges sorted by row first) or maximal runs of consecutive equal rows in the fed order ('runs')."""
+    import scipy.sparse as sp
+    if grouping == 'row':
+        order = np.lexsort((ec, er))
+        er, ec, z = er[order], ec[order], z[order]
+    starts = np.concatenate([[0], np.flatnonzero(np.diff(er)) + 1])
+    lg = np.where(z > 0, z, slope * z)
+    seg_of = np.repeat(np.arange(len(starts)), np.diff(np.concatenate([starts, [len(er)]])))
+    e = np.exp(lg - np.maximum.reduceat(lg, starts)[seg_of])
+    alpha = e / np.add.reduceat(e, starts)[seg_of]
+    return sp.csr_matrix((alpha, (er, ec)), shape=(n_rows, v.shape[0])) @ v      # duplicates are summed: several groups per row
+
+
+def test_alinet_end_to_end_forward_100k_shape(tmp_path, capsys):
+    """the WHOLE AliNet forward at the EN-DE-100K shape (500-400-300), not layer by layer on the device's
+    own intermediate inputs -- a float64 numpy / scipy restatement of alinet.py:574-677,784-826 from the initial embedding
+    to both layer outputs, every row."""
+    import scipy.sparse as sp
+    from openea_amd.approaches import AliNet
+    from openea_amd.modules.load.synth import make_kgs
+    kgs = make_kgs("EN-DE-100K-V1", mode="mapping", seed=0)
+    m = AliNet()
+    m.set_args(_args("AliNet", tmp_path, "EN-DE-100K-V1", max_epoch=1, start_valid=1000))
+    m.set_kgs(kgs)
+    m.init()
+    rng = np.random.RandomState(3)
+    with torch.no_grad():                      # move the BatchNorm affines and biases off their initial (1, 0) so that they matter
+        for p in m._params[1:]:
+            if p.dim() == 1:
+                p.add_(torch.from_numpy(rng.standard_normal(p.shape[0]).astype(np.float32) * 0.05).to(p.device))
+        outs = [_h(o) for o in m._forward()]
+    n = kgs.entities_num
+
+    def csr(op):
+        return sp.csr_matrix((op.vals.cpu().numpy().astype(np.float64), op.colidx.cpu().numpy(), op.rowptr.cpu().numpy()), shape=op.shape)
+
+    def bn(x, b):
+        return x * (_h(b.gamma) * BN_SCALE) + _h(b.beta)
+    x = _h(m.init_embedding)
+    g0, g1, at, hw = m.one_hop_layers[0], m.one_hop_layers[1], m.two_hop_layers[0], m.highways[0]
+    a1 = csr(g0.graph.fwd)
+    one = np.tanh(a1 @ (bn(x, g0.bn) @ _h(g0.kernel)) + _h(g0.bias))
+    xb = bn(x, at.bn)
+    s1 = np.tanh(((xb @ _h(at.kernel1)) * xb).sum(1))
+    s2 = np.tanh(((xb @ _h(at.kernel2)) * xb).sum(1))
+    er, ec, ev = _edges(at.graph)
+    two = np.tanh(_segment_attention_f64(er, ec, ev * s1[er] + ev * s2[ec], xb @ _h(at.kernel), n, at.graph.grouping))
+    i1, i2 = bn(two, hw.bn), bn(one, hw.bn)
+    gate = np.maximum(np.tanh(i1 @ _h(hw.weight)), 0.0)
+    x1 = np.tanh(i2 * (1 - gate) + i1 * gate)
+    x2 = np.tanh(csr(g1.graph.fwd) @ (bn(x1, g1.bn) @ _h(g1.kernel)) + _h(g1.bias))
+    d1, d2 = float(np.abs(outs[0] - x1).max()), float(np.abs(outs[1] - x2).max())
+    with capsys.disabled():
+        print("\nAliNet end-to-end forward at the EN-DE-100K shape (%d entities, grouping %r, %d of %d softmax groups single-edge): "
+              "max abs deviation from the float64 forward over ALL rows: layer-1 output %.2e, layer-2 output %.2e"
+              % (n, at.graph.grouping, int((np.diff(at.graph.seg_ptr_host) == 1).sum()), len(at.graph.seg_row_host), d1, d2))
+    assert d1 <= 1e-4 and d2 <= 1e-4
+
+
+def test_rdgcn_end_to_end_forward_100k_shape(tmp_path, capsys):
+    """the WHOLE RDGCN forward (rdgcn.py:184-338) at the EN-FR-100K shape, d = 300, in float64 numpy / scipy from the input
+    layer to the output embedding, every row -- against Layer.forward() on the device."""
+    import scipy.sparse as sp
+    from openea_amd.approaches import RDGCN
+    from openea_amd.modules.load.synth import make_kgs
+    kgs = make_kgs("EN-FR-100K-V1", mode="mapping", seed=0)
+    m = RDGCN()
+    m.set_args(_args("RDGCN", tmp_path, "EN-FR-100K-V1", max_epoch=1, start_valid=1000, random_name_init=True))
+    m.set_kgs(kgs)
+    m.init()
+    L = m.gcn_model
+    with torch.no_grad():
+        out = _h(L.forward())
+    p = {k: _h(v) for k, v in L.p.items()}
+    n = kgs.entities_num
+
+    def csr(op):
+        return sp.csr_matrix((op.vals.cpu().numpy().astype(np.float64), op.colidx.cpu().numpy(), op.rowptr.cpu().numpy()), shape=op.shape)
+    hm, tm, M = csr(L.head_mean.fwd), csr(L.tail_mean.fwd), csr(L.M.fwd)
+    A, bias = _h(L.dual_A), _h(L.dual_bias)
+    er, ec, _ = _edges(L.r_graph)
+    edge_rel = L.edge_rel.cpu().numpy()
+
+    def compute_r(x):
+        return np.concatenate([hm @ x, tm @ x], axis=1)
+
+    def dense_att(in_fts, f1, b1, f2, b2, values):
+        logits = A * ((in_fts @ f1 + b1) + (in_fts @ f2 + b2).T)
+        lg = np.where(logits > 0, logits, 0.2 * logits) + bias
+        e = np.exp(lg - lg.max(1, keepdims=True))
+        return np.maximum((e / e.sum(1, keepdims=True)) @ values, 0.0)
+
+    def sparse_att(x, dual, w, b):
+        z = (dual @ w + b).reshape(-1)[edge_rel]
+        return np.maximum(_segment_attention_f64(er, ec, z, x, n, L.r_graph.grouping), 0.0)
+    x0 = _h(L.primal_X_0)
+    r0 = compute_r(x0)
+    d1 = dense_att(r0 @ p['sa_w'], p['sa_f1'], p['sa_b1'], p['sa_f2'], p['sa_b2'], r0)
+    x1 = x0 + L.alpha * sparse_att(x0, d1, p['pa1_w'], p['pa1_b'])
+    d2 = dense_att(compute_r(x1) @ p['da_w'] + p['da_b'], p['da_f1'], p['da_b1'], p['da_f2'], p['da_b2'], d1)
+    cur = x0 + L.beta * sparse_att(x1, d2, p['pa2_w'], p['pa2_b'])
+    for tag in ("1", "2"):
+        diag = np.maximum(M @ (cur * p['diag' + tag]), 0.0)
+        gate = 1.0 / (1.0 + np.exp(-(cur @ p['hw%s_w' % tag] + p['hw%s_b' % tag])))
+        cur = gate * diag + (1.0 - gate) * cur
+    dev = float(np.abs(out - cur).max())
+    with capsys.disabled():
+        print("\nRDGCN end-to-end forward at the EN-FR-100K shape (%d entities, %d relations, %d attention edges, grouping %r): "
+              "max abs deviation of the output embedding from the float64 forward over ALL rows %.2e (|out| max %.2f)"
+              % (n, L.count_r, len(er), L.r_graph.grouping, dev, float(np.abs(cur).max())))
+    assert dev <= 1e-4 * max(1.0, float(np.abs(cur).max()))
+
+
 def test_gcn_align_epoch_100k_shape(tmp_path, capsys):
     """gcn_align.py:498-539, 204-267, 737-785: two full-batch epochs of the structure unit at the EN-FR-100K shape against
     the oracle's epoch (fp64, scipy, whole graph), adjacency from the oracle's own restatement of :610-664."""
