@@ -469,6 +469,9 @@ typedef struct oea_csr_split {
     const int32_t *row_chunk0;  /* [n_rows + 1] first chunk of each split row */
     float *partials;
     int64_t partials_floats;
+    /* optional, with `partials`: [n_rows] zero-initialised tickets -- the last chunk of a row to finish adds the row's
+     * chunks in chunk order and stores the row inside the SAME launch (no epilogue launch; the tickets reset themselves) */
+    uint32_t *tickets;
 } oea_csr_split;
 int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                  const float *x, int32_t dim, int32_t ldx, int32_t act, const float *mask_from,
@@ -535,8 +538,9 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
  * oea_pair_loss_l2_*: alinet.py:828-850 (compute_loss).  pairs int32 [m, 2], the first n_pos of them positive links:
  *   term_p = ||e_i - e_j||^2 (positive) | balance * weight * relu(margin - ||e_i - e_j||^2) (negative; weight [m - n_pos]
  *   or NULL = 1); the loss is the sum of terms [m] (the caller adds them: fixed order); coef [m] = d term / d ||.||^2.
- *   bwd: rowptr [n + 1] / other [2 m] / slot_pair [2 m] = the pairs' endpoints grouped by embedding row (slot order =
- *   the summation order), gscale = device scalar d L / d loss; grad [n, ld]: every row written.
+ *   bwd = oea_pair_grad_rows(norm = 2): rowptr [n + 1] / other [2 m] / slot_pair [2 m] = the pairs' endpoints grouped by
+ *   embedding row (slot order = the summation order), gscale = device scalar d L / d loss (NULL = 1); grad [n, ld]: every
+ *   row written.  norm = 1: grad[r] = sum coef sign(e_r - e_other) -- the L1 hinge of GCN-Align (oea_align_loss_l1_coef).
  * oea_highway_*: gate = relu(tanh(p)), out = tanh(b' (1 - gate) + a' gate), a' = a gamma + beta, b' = b gamma + beta
  *   (alinet.py:597-622; gamma / beta = the layer's BatchNormalization affine, gamma already divided by sqrt(1 + eps));
  *   bwd: da, db, dp [n, d] and partials [oea_colsum_blocks(n), 2, d] whose sums over dim 0 are d gamma, d beta.
@@ -548,8 +552,8 @@ int oea_concat_l2n_bwd(float *const *dx, const int32_t *dims, const int32_t *lds
                        const float *dz, int32_t ld_out, const float *inv_blk, const float *inv_all, void *stream);
 int oea_pair_loss_l2_fwd(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *pairs, int64_t m, int64_t n_pos,
                          const float *weight, float margin, float balance, float *coef, float *terms, void *stream);
-int oea_pair_loss_l2_bwd(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
-                         const int32_t *slot_pair, const float *coef, const float *gscale, float *grad, void *stream);
+int oea_pair_grad_rows(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
+                       const int32_t *slot_pair, const float *coef, const float *gscale, int32_t norm, float *grad, void *stream);
 int32_t oea_colsum_blocks(int64_t n);
 int oea_highway_fwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, int64_t n, int32_t d,
                     float *out, void *stream);
@@ -571,6 +575,16 @@ int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, 
                       int64_t t, int32_t k, float gamma, const int32_t *neg_left,
                       const int32_t *neg_right, const int32_t *neg2_left, const int32_t *neg2_right,
                       float *grad, double *loss_accum, void *stream);
+
+/* The same hinge WITHOUT the gradient: coef_out [t + 2 t k] gets the signed coefficient of every pair -- [0, t): the links,
+ * + #active hinges / (2 k t); [t + a 2k + i]: negative i of link a (i < k: (neg_left, neg_right), else (neg2_left,
+ * neg2_right)), - 1 / (2 k t) if its hinge is active, else 0 -- and oea_pair_grad_rows(norm = 1) over the pairs' endpoints
+ * grouped by row gives the gradient without atomics (reproducible; the choice when the negatives stay for several epochs
+ * and k is small: GCN-Align).  grad may be NULL then. */
+int oea_align_loss_l1_coef(const float *out_emb, int64_t n, int32_t dim, int32_t ld, const int32_t *ill,
+                           int64_t t, int32_t k, float gamma, const int32_t *neg_left,
+                           const int32_t *neg_right, const int32_t *neg2_left, const int32_t *neg2_right,
+                           float *grad, double *loss_accum, float *coef_out, void *stream);
 
 /* W -= lr * dW where dW is the gradient w.r.t. T = l2_normalize(W) pulled back through the
  * normalisation (gcn_align.py:52-56 + GradientDescentOptimizer, gcn_align.py:511).

@@ -36,7 +36,7 @@ class CsrSplit(C.Structure):
     """mirror of `oea_csr_split` (include/openea_hip.h)."""
     _fields_ = [("chunk_row", C.c_void_p), ("chunk_e0", C.c_void_p), ("chunk_e1", C.c_void_p), ("rows", C.c_void_p),
                 ("n_chunks", C.c_int32), ("n_rows", C.c_int32), ("threshold", C.c_int32),
-                ("row_chunk0", C.c_void_p), ("partials", C.c_void_p), ("partials_floats", C.c_int64)]
+                ("row_chunk0", C.c_void_p), ("partials", C.c_void_p), ("partials_floats", C.c_int64), ("tickets", C.c_void_p)]
 
 
 class AttnGraph(C.Structure):
@@ -150,7 +150,8 @@ PROTOTYPES = {
     "oea_concat_l2n_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
     "oea_concat_l2n_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "oea_pair_loss_l2_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp]),
-    "oea_pair_loss_l2_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "oea_pair_grad_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "oea_align_loss_l1_coef": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oea_colsum_blocks": (_i32, [_i64]),
     "oea_highway_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_highway_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),

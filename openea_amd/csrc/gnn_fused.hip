@@ -140,9 +140,12 @@ __global__ __launch_bounds__(256) void pair_loss_fwd_kernel(const float *__restr
     }
 }
 
-// one wave per embedding row r: grad[r] = gscale * sum over the row's pair slots (in slot order) of 2 coef (e_r - e_other);
-// slots with coef == 0 (hinge inactive) are skipped; rows without slots get zeros.  No atomics.
-template <int IT>
+// one wave per embedding row r: grad[r] = gscale * sum over the row's pair slots (in slot order) of
+//   L2: 2 coef (e_r - e_other)        (d / d e_r of coef ||e_r - e_other||^2)
+//   L1: coef sign(e_r - e_other)      (d / d e_r of coef |e_r - e_other|_1; sign(0) = 0)
+// -- the same expression whichever end of the pair r is.  Slots with coef == 0 (hinge inactive) are skipped; rows without
+// slots get zeros.  No atomics.
+template <int IT, bool L1>
 __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float *__restrict__ emb, int64_t n, int dim, int ld,
                                                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ other,
                                                             const int32_t *__restrict__ slot_pair, const float *__restrict__ coef,
@@ -174,17 +177,21 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float *__restr
             while (live) {                                          // the active slots of this batch of 64, in slot order
                 const int q = __ffsll((long long)live) - 1;
                 live &= live - 1;
-                const float cq = 2.f * __shfl(c, q, 64);
+                const float cq = (L1 ? 1.f : 2.f) * __shfl(c, q, 64);
                 const float *orow = emb + (int64_t)__shfl(o, q, 64) * ld;
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
                     const int col = it * W + lane;
-                    if (col < dim) acc[it] = fmaf(cq, me[it] - orow[col], acc[it]);
+                    if (col < dim) {
+                        const float df = me[it] - orow[col];
+                        if (L1) acc[it] += df > 0.f ? cq : (df < 0.f ? -cq : 0.f);
+                        else acc[it] = fmaf(cq, df, acc[it]);
+                    }
                 }
             }
         }
     }
-    const float gs = *gscale;
+    const float gs = gscale ? *gscale : 1.f;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int col = it * W + lane;
@@ -345,11 +352,16 @@ int oea_pair_loss_l2_fwd(const float *emb, int64_t n, int32_t dim, int32_t ld, c
     return OEA_OK;
 }
 
-int oea_pair_loss_l2_bwd(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
-                         const int32_t *slot_pair, const float *coef, const float *gscale, float *grad, void *stream) {
-    OEA_REQUIRE(emb && rowptr && other && slot_pair && coef && gscale && grad && n > 0 && dim > 0 && dim <= ld, "arguments");
+int oea_pair_grad_rows(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
+                       const int32_t *slot_pair, const float *coef, const float *gscale, int32_t norm, float *grad, void *stream) {
+    OEA_REQUIRE(emb && rowptr && other && slot_pair && coef && grad && n > 0 && dim > 0 && dim <= ld, "arguments");
+    OEA_REQUIRE(norm == 1 || norm == 2, "norm: 1 (L1) or 2 (squared L2)");
     hipStream_t st = oea::as_stream(stream);
-#define CALL(IT) pair_loss_bwd_kernel<IT><<<(unsigned)oea::ceil_div(n, 4), 256, 0, st>>>(emb, n, dim, ld, rowptr, other, slot_pair, coef, gscale, grad)
+#define CALL(IT)                                                                                                                  \
+    do {                                                                                                                          \
+        if (norm == 1) pair_loss_bwd_kernel<IT, true><<<(unsigned)oea::ceil_div(n, 4), 256, 0, st>>>(emb, n, dim, ld, rowptr, other, slot_pair, coef, gscale, grad); \
+        else pair_loss_bwd_kernel<IT, false><<<(unsigned)oea::ceil_div(n, 4), 256, 0, st>>>(emb, n, dim, ld, rowptr, other, slot_pair, coef, gscale, grad); \
+    } while (0)
     OEA_ROW_DISPATCH(ld, CALL);
 #undef CALL
     OEA_CHECK_HIP(hipGetLastError());

@@ -312,49 +312,93 @@ __global__ void gold_inner_kernel(const float *__restrict__ e1, int64_t n1, int 
 // kernel.  Epilogue: the sweep's workgroups take a ticket after their integer atomics; the last one reads the merged ranks /
 // keys back (device-coherent loads), writes argmax and reduces Hits@k / sum(rank + 1) / sum 1 / (rank + 1) in a fixed order.
 struct EvalTail {
-    unsigned *done;            // NULL: plain oea_rank_eval (argmax / metrics by separate launches)
+    unsigned *done;            // NULL: plain oea_rank_eval (argmax / metrics by separate launches); else [1 + query tiles] tickets
     int32_t *argmax;
     long long *hits;           // [nk], then rank_sum at hits[nk]
     double *rr_sum;
+    long long *tile_part;      // [query tiles][10]: Hits@k x 8, sum(rank + 1), bits of the tile's sum 1 / (rank + 1)
     int tk[8];
     int nk;
 };
 
+// Two levels, so that nobody walks all n1 rows alone (a first version let the globally last workgroup read every rank with
+// device-coherent loads: 41 dependent round trips per thread at n1 = 10,500 -- slower than the launches it replaced):
+//  (1) the last of the gridDim.y workgroups of a QUERY TILE finalises the tile's 128 rows -- one coherent load per thread --
+//      and leaves the tile's partial sums (integers; the reciprocal ranks added in a fixed order);
+//  (2) the last tile to do so adds the partials in tile order.
 __device__ __forceinline__ void eval_tail(const EvalTail &t, const int32_t *rank, const unsigned long long *best_key, int64_t n1,
-                                          long long *s_i, double *s_d) {
+                                          long long *s_i, double *s_d, int *s_flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __threadfence();                 // this thread's atomics are performed before the ticket below can be seen
+    __syncthreads();
+    if (tid == 0) *s_flag = atomicAdd(t.done + 1 + blockIdx.x, 1u) == gridDim.y - 1u;
+    __syncthreads();
+    if (!*s_flag) return;
+    __threadfence();
     long long h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double rr = 0.0;
-    for (int64_t i = threadIdx.x; i < n1; i += blockDim.x) {
+    const int64_t i = (int64_t)blockIdx.x * TILE + tid;
+    if (tid < TILE && i < n1) {
         const int r = __hip_atomic_load(rank + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // other XCDs' atomics
         const unsigned long long key = __hip_atomic_load(best_key + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t.argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
 #pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] += (k < t.nk && r < t.tk[k]);
-        h[8] += r + 1;
-        rr += 1.0 / (double)(r + 1);
+        for (int k = 0; k < 8; ++k) h[k] = (k < t.nk && r < t.tk[k]);
+        h[8] = r + 1;
+        rr = 1.0 / (double)(r + 1);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) h[k] += __shfl_xor(h[k], off, 64);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
-    __syncthreads();                 // the tile buffers are free: every wave is past its last MFMA chunk
-    if (lane == 0) {
+    if (lane == 0) {                 // the tile buffers are free: every wave is past its last MFMA chunk (barriers above)
 #pragma unroll
         for (int k = 0; k < 9; ++k) s_i[wave * 9 + k] = h[k];
         s_d[wave] = rr;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
+    if (tid < 10) {
         long long v = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_i[w * 9 + threadIdx.x];
-        if ((int)threadIdx.x < t.nk) t.hits[threadIdx.x] = v;
-        else if (threadIdx.x == 8) t.hits[t.nk] = v;
-    } else if (threadIdx.x == 9) {
+        if (tid < 9) { for (int w = 0; w < 4; ++w) v += s_i[w * 9 + tid]; }
+        else { double d = 0.0; for (int w = 0; w < 4; ++w) d += s_d[w]; v = __double_as_longlong(d); }
+        __hip_atomic_store(t.tile_part + (int64_t)blockIdx.x * 10 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) *s_flag = atomicAdd(t.done, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (!*s_flag) return;
+    __threadfence();
+    long long g[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double grr = 0.0;
+    for (int q = tid; q < (int)gridDim.x; q += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] += __hip_atomic_load(t.tile_part + (int64_t)q * 10 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        grr += __longlong_as_double(__hip_atomic_load(t.tile_part + (int64_t)q * 10 + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) g[k] += __shfl_xor(g[k], off, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) grr += __shfl_xor(grr, off, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_i[wave * 9 + k] = g[k];
+        s_d[wave] = grr;
+    }
+    __syncthreads();
+    if (tid < 9) {
+        long long v = 0;
+        for (int w = 0; w < 4; ++w) v += s_i[w * 9 + tid];
+        if (tid < t.nk) t.hits[tid] = v;
+        else if (tid == 8) t.hits[t.nk] = v;
+    } else if (tid == 9) {
         double v = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += s_d[w];
+        for (int w = 0; w < 4; ++w) v += s_d[w];
         *t.rr_sum = v;
     }
 }
@@ -365,7 +409,7 @@ __global__ __launch_bounds__(256) void eval_prologue_kernel(const float *__restr
                                                             int64_t n2_pad, int kp, const float *__restrict__ csls_r,
                                                             const float *__restrict__ csls_c, int64_t gold_off,
                                                             float *__restrict__ gold, unsigned long long *__restrict__ keys,
-                                                            int32_t *__restrict__ rank, unsigned *__restrict__ done) {
+                                                            int32_t *__restrict__ rank, unsigned *__restrict__ done, int n_done) {
     const int cpr = kp / 4;
     const int64_t t1 = n1_pad * cpr, t2 = n2_pad * cpr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,7 +443,7 @@ __global__ __launch_bounds__(256) void eval_prologue_kernel(const float *__restr
         keys[i] = 0ull;
         rank[i] = 0;
     }
-    if (gid == 0) *done = 0u;
+    for (int64_t i = gid; i < n_done; i += stride) done[i] = 0u;
 }
 
 // ---- fused rank epilogue: M = candidates (e2 rows), N = queries (e1 rows) -----------------------
@@ -494,16 +538,9 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
             atomicMax(best_key + qi[tn], key);
         }
     }
-    if (tail.done) {                 // fused evaluation (oea_rank_eval_metrics): the workgroup that arrives LAST finishes the job
-        __shared__ int s_last;
-        __threadfence();             // this thread's atomics are performed before the ticket below can be seen
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(tail.done, 1u) == gridDim.x * gridDim.y - 1u;
-        __syncthreads();
-        if (s_last) {
-            __threadfence();
-            eval_tail(tail, rank, best_key, n1, reinterpret_cast<long long *>(As), reinterpret_cast<double *>(Bs));
-        }
+    if (tail.done) {                 // fused evaluation (oea_rank_eval_metrics): the last workgroups to arrive finish the job
+        __shared__ int s_flag;
+        eval_tail(tail, rank, best_key, n1, reinterpret_cast<long long *>(As), reinterpret_cast<double *>(Bs), &s_flag);
     }
 }
 
@@ -1556,7 +1593,10 @@ int oea_rank_metrics(const int32_t *rank, int64_t n, const int32_t *top_k_host, 
     return OEA_OK;
 }
 
-size_t oea_rank_eval_metrics_workspace_bytes(int64_t n1) { return oea_rank_workspace_bytes(n1) + 256; }
+size_t oea_rank_eval_metrics_workspace_bytes(int64_t n1) {
+    const size_t tiles = (size_t)((n1 + TILE - 1) / TILE);
+    return oea_rank_workspace_bytes(n1) + 256 + tiles * (10 * sizeof(long long) + sizeof(unsigned)) + 64;
+}
 
 int oea_rank_eval_metrics(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
                           const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
@@ -1571,7 +1611,10 @@ int oea_rank_eval_metrics(const float *e1, int64_t n1, int32_t ld1, const float 
     hipStream_t st = oea::as_stream(stream);
     unsigned long long *keys = static_cast<unsigned long long *>(workspace);
     float *gold = reinterpret_cast<float *>(keys + n1);
-    unsigned *done = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + ((oea_rank_workspace_bytes(n1) + 15) / 16) * 16);
+    const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
+    char *extra = reinterpret_cast<char *>(workspace) + ((oea_rank_workspace_bytes(n1) + 15) / 16) * 16;
+    long long *tile_part = reinterpret_cast<long long *>(extra);
+    unsigned *done = reinterpret_cast<unsigned *>(extra + (size_t)qt * 10 * sizeof(long long));
     PackedOp p1, p2;
     int64_t n1_pad = 0, n2_pad = 0;
     int rc = reserve_operand(0, n1, dim, st, &p1, &n1_pad);
@@ -1579,16 +1622,17 @@ int oea_rank_eval_metrics(const float *e1, int64_t n1, int32_t ld1, const float 
     if (rc != OEA_OK) return rc;
     const int64_t work = (n1_pad + n2_pad) * (p1.kp / 4);
     eval_prologue_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(work, 256), 16384), 256, 0, st>>>(
-        e1, n1, ld1, e2, n2, ld2, dim, p1.p, n1_pad, p2.p, n2_pad, p1.kp, csls_r, csls_c, gold_offset, gold, keys, rank, done);
+        e1, n1, ld1, e2, n2, ld2, dim, p1.p, n1_pad, p2.p, n2_pad, p1.kp, csls_r, csls_c, gold_offset, gold, keys, rank, done,
+        (int)qt + 1);
     EvalTail tail{};
     tail.done = done;
+    tail.tile_part = tile_part;
     tail.argmax = argmax;
     tail.hits = reinterpret_cast<long long *>(hits_and_rank_sum_dev);
     tail.rr_sum = rr_sum_dev;
     tail.nk = nk;
     for (int i = 0; i < nk; ++i) tail.tk[i] = top_k_host[i];
     int tpc = 1;
-    const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
     const int chunks = pick_chunks(qt, ctiles, &tpc);
     const dim3 grid((unsigned)qt, (unsigned)chunks);
     if (csls_r)

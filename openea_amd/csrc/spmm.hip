@@ -126,6 +126,46 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
                 }
             }
         }
+        if (split.tickets) {
+            // the row's LAST chunk to finish adds the row's chunks in chunk order and stores the row (round 3: the separate
+            // epilogue launch -- ~5 us behind every aggregate with hub rows -- is gone; the order of the sum, and with it
+            // the bits, do not depend on which chunk arrives last)
+            __shared__ int s_sr, s_last;
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int lo = 0, hi = split.n_rows;                       // split row sr: row_chunk0[sr] <= ch < row_chunk0[sr + 1]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (split.row_chunk0[mid] <= ch) lo = mid; else hi = mid;
+                }
+                const unsigned n = (unsigned)(split.row_chunk0[lo + 1] - split.row_chunk0[lo]);
+                s_sr = lo;
+                s_last = atomicAdd(split.tickets + lo, 1u) == n - 1u;
+                if (s_last) split.tickets[lo] = 0u;                  // ready for the next launch on this operand
+            }
+            __syncthreads();
+            if (s_last && gid == 0) {
+                __threadfence();
+                float4 sum[IT];
+#pragma unroll
+                for (int it = 0; it < IT; ++it) sum[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c2 = split.row_chunk0[s_sr]; c2 < split.row_chunk0[s_sr + 1]; ++c2) {
+                    const unsigned *pp = reinterpret_cast<const unsigned *>(split.partials + (int64_t)c2 * ldy);
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int c = (it * G + lane) * 4;
+                        if (c < ldy) {               // device-coherent loads: the other chunks were written through other XCDs' L2
+                            sum[it].x += __uint_as_float(__hip_atomic_load(pp + c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            sum[it].y += __uint_as_float(__hip_atomic_load(pp + c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            sum[it].z += __uint_as_float(__hip_atomic_load(pp + c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            sum[it].w += __uint_as_float(__hip_atomic_load(pp + c + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        }
+                    }
+                }
+                row_store<G, IT>(sum, (int64_t)split.rows[s_sr], lane, dim, act, mask_from, y, ldy);
+            }
+        }
         return;
     }
     // rows are dealt out CYCLICALLY: group gid of block b takes rows b + nb * (gid + NG * i).  Ids are
@@ -275,7 +315,11 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                                                             const int32_t *__restrict__ neg_right,
                                                             const int32_t *__restrict__ neg2_left,
                                                             const int32_t *__restrict__ neg2_right,
-                                                            float *__restrict__ grad, double *__restrict__ loss_accum) {
+                                                            float *__restrict__ grad, double *__restrict__ loss_accum,
+                                                            float *__restrict__ coef_out) {
+    // coef_out != NULL: no gradient here -- the signed coefficient of every pair ([0, t): the links, + scale * #active
+    // hinges; [t + a 2k + i]: negative i of link a, - scale if its hinge is active) goes out and oea_pair_grad_rows sums
+    // each row's pairs in a fixed order (no atomics, reproducible bits)
     constexpr int NG = 256 / G;
     __shared__ int s_active;
     __shared__ double s_loss[4];
@@ -316,6 +360,14 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
             }
             B = group_sum<G>(B);
             const float L = D - B;
+            if (coef_out) {
+                if (lane == 0) coef_out[t + a * 2 * k + i] = L > 0.f ? -scale : 0.f;
+                if (L > 0.f) {
+                    ++active;
+                    if (lane == 0) loss_local += (double)L;
+                }
+                continue;
+            }
             if (L > 0.f) {
                 ++active;
                 if (lane == 0) loss_local += (double)L;
@@ -334,7 +386,7 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
                 }
             }
         }
-        if (active) {
+        if (active && !coef_out) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = it * G + lane;
@@ -345,7 +397,8 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
         if (lane == 0 && active) atomicAdd(&s_active, active);
         __syncthreads();
         const int total = s_active;
-        if (gid == 0 && total) {
+        if (coef_out && threadIdx.x == 0) coef_out[a] = scale * (float)total;
+        if (gid == 0 && total && !coef_out) {
             const float ca = scale * (float)total;
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
@@ -452,8 +505,9 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
                 spmm_chunk_kernel<G, IT><<<(unsigned)split->n_chunks, 256, lds, st>>>(split->chunk_row, split->chunk_e0, \
                                                                                       split->chunk_e1, colidx, vals, x, ldx, y, ldy); \
             }                                                                                                          \
-            spmm_rows_epilogue_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, dim, act, mask_from, y, ldy, \
-                                                                 fused ? split->partials : nullptr, split->row_chunk0); \
+            if (!(fused && split->tickets))                                                                            \
+                spmm_rows_epilogue_kernel<G, IT><<<gr, 256, 0, st>>>(split->rows, split->n_rows, dim, act, mask_from, y, ldy, \
+                                                                     fused ? split->partials : nullptr, split->row_chunk0); \
         }                                                                                                              \
     } while (0)
     OEA_DISPATCH_LD(ldx, CALL);
@@ -466,13 +520,21 @@ int oea_align_loss_l1(const float *out_emb, int64_t n, int32_t dim, int32_t ld, 
                       int32_t k, float gamma, const int32_t *neg_left, const int32_t *neg_right,
                       const int32_t *neg2_left, const int32_t *neg2_right, float *grad, double *loss_accum,
                       void *stream) {
-    OEA_REQUIRE(out_emb && ill && neg_left && neg_right && neg2_left && neg2_right && grad && loss_accum, "null pointer");
+    return oea_align_loss_l1_coef(out_emb, n, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum,
+                                  nullptr, stream);
+}
+
+int oea_align_loss_l1_coef(const float *out_emb, int64_t n, int32_t dim, int32_t ld, const int32_t *ill, int64_t t,
+                           int32_t k, float gamma, const int32_t *neg_left, const int32_t *neg_right,
+                           const int32_t *neg2_left, const int32_t *neg2_right, float *grad, double *loss_accum,
+                           float *coef_out, void *stream) {
+    OEA_REQUIRE(out_emb && ill && neg_left && neg_right && neg2_left && neg2_right && (grad || coef_out) && loss_accum, "null pointer");
     OEA_REQUIRE(ld % 4 == 0 && dim > 0 && dim <= ld && k >= 1 && n > 0, "shapes");
     if (t == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
 #define CALL(G, IT)                                                                                             \
     align_loss_l1_kernel<G, IT><<<(unsigned)std::min<int64_t>(t, 65535), 256, 0, st>>>(                           \
-        out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum)
+        out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum, coef_out)
     if (ld <= 32) CALL(32, 1);          // lane-strided rows: G * IT >= ld
     else if (ld <= 64) CALL(32, 2);
     else if (ld <= 96) CALL(32, 3);

@@ -313,15 +313,9 @@ class PairLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         emb, pairs, coef = ctx.saved_tensors
-        m = pairs.shape[0]
-        ends = torch.cat([pairs[:, 0], pairs[:, 1]]).to(torch.int64)
-        order = torch.argsort(ends, stable=True)
-        rowptr = torch.zeros(emb.shape[0] + 1, dtype=torch.int64, device=emb.device)
-        rowptr[1:] = torch.cumsum(torch.bincount(ends, minlength=emb.shape[0]), 0)
-        other = torch.cat([pairs[:, 1], pairs[:, 0]])[order].contiguous()
-        slot_pair = (order % m).to(torch.int32).contiguous()
+        rowptr, other, slot_pair = ops.pair_rows_csr(pairs, emb.shape[0])
         g = gloss.to(torch.float32).reshape(1).contiguous()
-        grad = ops.pair_loss_l2_bwd(emb, ctx.dim, rowptr.to(torch.int32), other, slot_pair, coef, g)
+        grad = ops.pair_grad_rows(emb, ctx.dim, rowptr, other, slot_pair, coef, g, norm=2)
         return grad, None, None, None, None, None, None
 
 

@@ -607,9 +607,10 @@ def csr_split(indptr, threshold=768, chunk=512, dev=None, row_range=None):
             c_e1.append(min(e0 + chunk, int(indptr[lo + r + 1])))
     first.append(len(c_row))
     t = [to_ids(np.asarray(a, np.int32), dev) for a in (c_row, c_e0, c_e1, rows, first)]
+    tickets = torch.zeros(len(rows), dtype=torch.int32, device=t[0].device)      # last-arriver tickets of the hub rows (self-resetting)
     sp_ = _lib.CsrSplit(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), len(c_row), len(rows), int(threshold),
-                        t[4].data_ptr(), None, 0)
-    sp_._keep = t
+                        t[4].data_ptr(), None, 0, tickets.data_ptr())
+    sp_._keep = t + [tickets]
     return sp_
 
 
@@ -763,11 +764,35 @@ def pair_loss_l2_fwd(emb, dim, pairs, n_pos, weight, margin, balance):
     return terms, coef
 
 
-def pair_loss_l2_bwd(emb, dim, rowptr, other, slot_pair, coef, gscale):
-    grad = torch.empty_like(emb)
-    check(lib().oea_pair_loss_l2_bwd(_p(emb), emb.shape[0], dim, emb.shape[1], _p(rowptr), _p(other), _p(slot_pair), _p(coef),
-                                     _p(gscale), _p(grad), _stream()))
+def pair_rows_csr(pairs, n_rows):
+    """the endpoints of `pairs` (device int [m, 2]) grouped by row, slots in pair order (one stable device sort) ->
+    (rowptr int32 [n_rows + 1], other int32 [2 m], slot_pair int32 [2 m]) for pair_grad_rows."""
+    m = pairs.shape[0]
+    ends = torch.cat([pairs[:, 0], pairs[:, 1]]).to(torch.int64)
+    order = torch.argsort(ends, stable=True)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=pairs.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n_rows), 0)
+    other = torch.cat([pairs[:, 1], pairs[:, 0]])[order].to(torch.int32).contiguous()
+    return rowptr.to(torch.int32), other, (order % m).to(torch.int32).contiguous()
+
+
+def pair_grad_rows(emb, dim, rowptr, other, slot_pair, coef, gscale=None, norm=2, out=None):
+    """grad[r] = gscale * sum over row r's pair slots of 2 coef (e_r - e_other) (norm 2) | coef sign(e_r - e_other) (norm 1)."""
+    grad = torch.empty_like(emb) if out is None else out
+    check(lib().oea_pair_grad_rows(_p(emb), emb.shape[0], dim, emb.shape[1], _p(rowptr), _p(other), _p(slot_pair), _p(coef),
+                                   _p(gscale), int(norm), _p(grad), _stream()))
     return grad
+
+
+def align_loss_l1_coef(out_emb, dim, ill, k, gamma, neg_left, neg_right, neg2_left, neg2_right, loss_accum, coef=None):
+    """the L1 hinge without its gradient -> coef [t + 2 t k] (signed pair coefficients for pair_grad_rows(norm=1))."""
+    t = ill.shape[0]
+    if coef is None:
+        coef = torch.empty(t + 2 * t * k, dtype=torch.float32, device=out_emb.device)
+    check(lib().oea_align_loss_l1_coef(_p(out_emb), out_emb.shape[0], dim, out_emb.shape[1], _p(ill), t, k, float(gamma),
+                                       _p(neg_left), _p(neg_right), _p(neg2_left), _p(neg2_right), None, _p(loss_accum), _p(coef),
+                                       _stream()))
+    return coef
 
 
 def highway_fwd(a, b, p, gamma, beta):
