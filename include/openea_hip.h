@@ -592,6 +592,32 @@ int oea_align_loss_l1_coef(const float *out_emb, int64_t n, int32_t dim, int32_t
 int oea_sgd_rows(float *w, const float *grad_t, int64_t rows, int32_t dim, int32_t ld,
                  int32_t normalize, float lr, void *stream);
 
+/* One full-batch epoch of a GCN_Align_Unit (approaches/gcn_align.py:498-539: GraphConvolution(relu, trunc_normal weight) ->
+ * GraphConvolution(identity, no weight) + align_loss + GradientDescentOptimizer; the loop of :737-785) enqueued by ONE call:
+ *   T = l2_normalize(W);  X = T (featureless) | F . T;  H1 = relu(A X);  out = A H1;  hinge -> d out;
+ *   d H1 = A^T d out (gated by H1 > 0);  d X = A^T d H1;  d T = d X | F^T d X;  W -= lr * (d T through the normalisation).
+ * A / A^T / F / F^T: CSR operands (+ optional hub-row splits); pair_*: the hinge's pair endpoints grouped by row
+ * (oea_align_loss_l1_coef + oea_pair_grad_rows(norm 1): no atomics) or NULL (oea_align_loss_l1 with atomics).
+ * Buffers [n, ld] (t: [w_rows, ld]; x, g_t only with features; coef [t + 2 t k] only with pair lists) are the caller's
+ * and hold the forward / backward intermediates afterwards (out = the unit's output embedding). */
+typedef struct oea_gcn_unit {
+    const int32_t *a_rowptr, *a_colidx; const float *a_vals; const oea_csr_split *a_split;
+    const int32_t *at_rowptr, *at_colidx; const float *at_vals; const oea_csr_split *at_split;
+    const int32_t *f_rowptr, *f_colidx; const float *f_vals; const oea_csr_split *f_split;       /* NULL: featureless */
+    const int32_t *ft_rowptr, *ft_colidx; const float *ft_vals; const oea_csr_split *ft_split;
+    const int32_t *row_ids;          /* [w_rows] = 0 .. w_rows - 1 */
+    const int32_t *ill;              /* [t, 2] seed links */
+    const int32_t *neg_left, *neg_right, *neg2_left, *neg2_right;      /* [t k] */
+    const int32_t *pair_rowptr, *pair_other, *pair_slot;               /* [n + 1], [2 (t + 2 t k)] x 2, or NULL */
+    int64_t n, w_rows, t;
+    int32_t dim, ld, k;
+    float gamma, lr;
+} oea_gcn_unit;
+typedef struct oea_gcn_unit_buffers {
+    float *t, *x, *h1, *out, *g_out, *g_pre1, *g_x, *g_t, *coef;
+} oea_gcn_unit_buffers;
+int oea_gcn_unit_epoch(const oea_gcn_unit *u, float *w, const oea_gcn_unit_buffers *b, double *loss_accum, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Graph builders on the device (csrc/graph_build.hip) -- the per-init adjacency construction of the GNN approaches.
  * Inputs: triples int32 [n, 3] (device).  Outputs are sorted by (row, col); their sizes are data dependent: the caller

@@ -52,6 +52,21 @@ class AttnGraph(C.Structure):
                 ("t_row0", C.c_int64), ("t_row1", C.c_int64), ("t_slot0", C.c_int64), ("t_slot1", C.c_int64)]
 
 
+class GcnUnit(C.Structure):
+    """mirror of `oea_gcn_unit` (include/openea_hip.h)."""
+    _fields_ = ([(pre + suf, t) for pre in ("a_", "at_", "f_", "ft_")
+                 for suf, t in (("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p), ("split", C.POINTER(CsrSplit)))]
+                + [(nm, C.c_void_p) for nm in ("row_ids", "ill", "neg_left", "neg_right", "neg2_left", "neg2_right", "pair_rowptr",
+                                               "pair_other", "pair_slot")]
+                + [("n", C.c_int64), ("w_rows", C.c_int64), ("t", C.c_int64), ("dim", C.c_int32), ("ld", C.c_int32), ("k", C.c_int32),
+                   ("gamma", C.c_float), ("lr", C.c_float)])
+
+
+class GcnUnitBuffers(C.Structure):
+    """mirror of `oea_gcn_unit_buffers`."""
+    _fields_ = [(nm, C.c_void_p) for nm in ("t", "x", "h1", "out", "g_out", "g_pre1", "g_x", "g_t", "coef")]
+
+
 class RotateCfg(C.Structure):
     """mirror of `oea_rotate_cfg` (include/openea_hip.h)."""
     _fields_ = [("gamma", C.c_double), ("phase_scale", C.c_double), ("lr", C.c_double), ("beta1", C.c_double),
@@ -161,6 +176,7 @@ PROTOTYPES = {
     "oea_align_loss_l1": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
     "oea_sgd_rows": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "oea_gcn_unit_epoch": (C.c_int, [C.POINTER(GcnUnit), _vp, C.POINTER(GcnUnitBuffers), _vp, _vp]),
     "oea_build_unweighted_adj": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "oea_build_weighted_adj": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "oea_build_primal_adj": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),

@@ -174,34 +174,87 @@ class GCN_Align_Unit:
         return T, H1, out
 
     def train_step(self, negs):
-        """one full-batch epoch: forward, L1 hinge, backward, SGD.  Returns nothing; loss accumulates."""
+        """one full-batch epoch: forward, L1 hinge, backward, SGD.  Returns nothing; loss accumulates.
+        Single process: ONE C call enqueues the epoch's kernels (oea_gcn_unit_epoch) -- driven op by op from Python the
+        epoch was bound by the host at the 15K shapes.  Under torch.distributed the aggregates are row-sharded with an
+        all-gather per layer (models/graph_ops.py:CsrOperand), op by op."""
+        from ..models import dist as mdist
+        if mdist.world()[1] == 1:
+            return self._train_step_fused(negs)
         d = self.dim
         T, H1, out = self.forward()
         nl, nr, n2l, n2r = negs
         k = self.args.neg_triple_num
-        if k <= 16:
-            # the negatives stay for 10 epochs (gcn_align.py:740-755): their endpoints are grouped by row once, every epoch
-            # the hinge kernel only writes the pairs' coefficients and each row sums its pairs in a fixed order -- no
-            # atomics (67 -> ~35 us at the D-W-15K shape, reproducible bits)
-            if getattr(self, "_pairs_of", None) is not negs:
-                t = self.ILL.shape[0]
-                neg_pairs = torch.stack([torch.stack([nl.view(t, k), n2l.view(t, k)], 1).reshape(-1),
-                                         torch.stack([nr.view(t, k), n2r.view(t, k)], 1).reshape(-1)], 1)     # [t, 2, k] order = a 2k + i
-                self._pair_csr = ops.pair_rows_csr(torch.cat([self.ILL.to(neg_pairs.dtype), neg_pairs]), out.shape[0])
-                self._pairs_of = negs
-                self._coef = None
-            self._coef = ops.align_loss_l1_coef(out, d, self.ILL, k, self.args.gamma, nl, nr, n2l, n2r, self.loss, self._coef)
-            g_out = ops.pair_grad_rows(out, d, *self._pair_csr, self._coef, norm=1)
+        pairs = self._pair_lists(negs, out.shape[0])
+        if pairs is not None:
+            self._coef = ops.align_loss_l1_coef(out, d, self.ILL, k, self.args.gamma, nl, nr, n2l, n2r, self.loss, getattr(self, "_coef", None))
+            g_out = ops.pair_grad_rows(out, d, *pairs, self._coef, norm=1)
         else:
             g_out = torch.zeros_like(out)
             ops.align_loss_l1(out, d, self.ILL, k, self.args.gamma, nl, nr, n2l, n2r, g_out, self.loss)
         g_pre1 = self.adj.tmm(g_out, d, mask_from=H1)           # relu gate fused
         g_x = self.adj.tmm(g_pre1, d)
         g_T = g_x if self.features is None else self.features.tmm(g_x, d)
-        from ..models import dist as mdist
-        mdist.sync_replicated_(g_T)                     # torch.distributed: the hinge's atomics reorder per process
+        mdist.sync_replicated_(g_T)                     # torch.distributed: keep the replicas on the same bits
         ops.sgd_rows_(self.W, g_T, d, True, self.args.learning_rate)
         self.outputs = out
+
+    def _pair_lists(self, negs, n_rows):
+        """k <= 16 (GCN-Align's 5): the negatives stay for 10 epochs (gcn_align.py:740-755), so the endpoints of the hinge's
+        pairs are grouped by row once per redraw; every epoch the hinge kernel only writes the pairs' coefficients and each
+        row adds its pairs in a fixed order -- no atomics, reproducible bits.  Larger k (RDGCN's 125): the atomic kernel."""
+        k = self.args.neg_triple_num
+        if k > 16:
+            return None
+        key = tuple(x.data_ptr() for x in negs)
+        if getattr(self, "_pairs_key", None) != key or getattr(self, "_pairs_ver", None) != tuple(x._version for x in negs):
+            nl, nr, n2l, n2r = negs
+            t = self.ILL.shape[0]
+            neg_pairs = torch.stack([torch.stack([nl.view(t, k), n2l.view(t, k)], 1).reshape(-1),
+                                     torch.stack([nr.view(t, k), n2r.view(t, k)], 1).reshape(-1)], 1)     # [t, 2, k]: index a 2k + i
+            self._pair_csr = ops.pair_rows_csr(torch.cat([self.ILL.to(neg_pairs.dtype), neg_pairs]), n_rows)
+            self._pairs_key, self._pairs_ver = key, tuple(x._version for x in negs)
+            self._pairs_keep = negs                              # the device pointers in the key stay valid
+        return self._pair_csr
+
+    def _train_step_fused(self, negs):
+        import ctypes as C
+        from .. import _lib
+        d, dev = self.dim, self.W.device
+        ld = self.W.shape[1]
+        n = self.adj.shape[0]
+        k = self.args.neg_triple_num
+        if getattr(self, "_bufs", None) is None:
+            def buf(rows):
+                return torch.empty((rows, ld), dtype=torch.float32, device=dev)
+            feat = self.features is not None
+            self._bufs = dict(t=buf(self.W.shape[0]), x=buf(n) if feat else None, h1=buf(n), out=buf(n), g_out=buf(n), g_pre1=buf(n),
+                              g_x=buf(n), g_t=buf(self.W.shape[0]) if feat else None,
+                              coef=torch.empty(self.ILL.shape[0] * (1 + 2 * k), dtype=torch.float32, device=dev))
+            self._cb = _lib.GcnUnitBuffers(*[None if self._bufs[nm] is None else self._bufs[nm].data_ptr()
+                                             for nm in ("t", "x", "h1", "out", "g_out", "g_pre1", "g_x", "g_t", "coef")])
+        pairs = self._pair_lists(negs, n)
+        u = _lib.GcnUnit()
+        ops_list = [("a_", self.adj.fwd), ("at_", self.adj.bwd)]
+        if self.features is not None:
+            ops_list += [("f_", self.features.fwd), ("ft_", self.features.bwd)]
+        for pre, op in ops_list:
+            setattr(u, pre + "rowptr", op.rowptr.data_ptr())
+            setattr(u, pre + "colidx", op.colidx.data_ptr())
+            setattr(u, pre + "vals", op.vals.data_ptr())
+            if op.split is not None:
+                ops._split_partials(op.split, ld, dev)
+                setattr(u, pre + "split", C.pointer(op.split))
+        nl, nr, n2l, n2r = negs
+        u.row_ids, u.ill = self.row_ids.data_ptr(), self.ILL.data_ptr()
+        u.neg_left, u.neg_right, u.neg2_left, u.neg2_right = nl.data_ptr(), nr.data_ptr(), n2l.data_ptr(), n2r.data_ptr()
+        if pairs is not None:
+            u.pair_rowptr, u.pair_other, u.pair_slot = (x.data_ptr() for x in pairs)
+        u.n, u.w_rows, u.t = n, self.W.shape[0], self.ILL.shape[0]
+        u.dim, u.ld, u.k = d, ld, k
+        u.gamma, u.lr = float(self.args.gamma), float(self.args.learning_rate)
+        ops.check(ops.lib().oea_gcn_unit_epoch(C.byref(u), self.W.data_ptr(), C.byref(self._cb), self.loss.data_ptr(), ops._stream()))
+        self.outputs = self._bufs["out"]
 
     def pop_loss(self):
         v = float(self.loss.item())

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
             // epilogue launch -- ~5 us behind every aggregate with hub rows -- is gone; the order of the sum, and with it
             // the bits, do not depend on which chunk arrives last)
             __shared__ int s_sr, s_last;
-            __threadfence();
+            // the partial row was written with plain stores: release at device scope = write it back from this XCD's L2
+            // (no invalidate -- the reader below uses device-coherent loads); only the few chunk workgroups pay for it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
             if (threadIdx.x == 0) {
                 int lo = 0, hi = split.n_rows;                       // split row sr: row_chunk0[sr] <= ch < row_chunk0[sr + 1]
@@ -146,7 +148,6 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t *__restrict
             }
             __syncthreads();
             if (s_last && gid == 0) {
-                __threadfence();
                 float4 sum[IT];
 #pragma unroll
                 for (int it = 0; it < IT; ++it) sum[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,6 +561,52 @@ int oea_sgd_rows(float *w, const float *grad_t, int64_t rows, int32_t dim, int32
     OEA_DISPATCH_LD(ld, CALL);
 #undef CALL
     OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+// ---- one full-batch epoch of a GCN_Align_Unit (gcn_align.py:498-539, 737-785) enqueued by ONE call -------------------------
+// At the 15K shapes the epoch is ~10 kernels of 5-40 us: driven op by op from Python it was bound by the host (0.245 ms per
+// epoch whatever the kernels took, gpurun_out r03f); the call below enqueues the same kernels back to back.
+int oea_gcn_unit_epoch(const oea_gcn_unit *u, float *w, const oea_gcn_unit_buffers *b, double *loss_accum, void *stream) {
+    OEA_REQUIRE(u && w && b && loss_accum, "null pointer");
+    OEA_REQUIRE(u->a_rowptr && u->a_colidx && u->a_vals && u->at_rowptr && u->at_colidx && u->at_vals && u->row_ids && u->ill &&
+                u->neg_left && u->neg_right && u->neg2_left && u->neg2_right, "gcn unit: null pointer");
+    OEA_REQUIRE(b->t && b->h1 && b->out && b->g_out && b->g_pre1 && b->g_x, "gcn unit buffers: null pointer");
+    OEA_REQUIRE(u->n > 0 && u->w_rows > 0 && u->dim > 0 && u->dim <= u->ld && u->ld % 4 == 0, "shapes");
+    const bool feat = u->f_rowptr != nullptr;
+    OEA_REQUIRE(!feat || (u->f_colidx && u->f_vals && u->ft_rowptr && u->ft_colidx && u->ft_vals && b->x && b->g_t), "gcn unit: feature operand");
+    OEA_REQUIRE(feat || u->w_rows == u->n, "featureless unit: the weight IS the [n, dim] table");
+    const int d = u->dim, ld = u->ld;
+    int rc;
+#define OEA_TRY(call) do { rc = (call); if (rc != OEA_OK) return rc; } while (0)
+    // T = l2_normalize(W) (trunc_normal returns the normalised tensor, gcn_align.py:52-56); X = T | F . T
+    OEA_TRY(oea_gather_rows(w, d, ld, u->row_ids, u->w_rows, 1, b->t, ld, stream));
+    const float *x = b->t;
+    if (feat) {
+        OEA_TRY(oea_spmm_csr(u->f_rowptr, u->f_colidx, u->f_vals, u->n, b->t, d, ld, 0, nullptr, b->x, ld, u->f_split, stream));
+        x = b->x;
+    }
+    OEA_TRY(oea_spmm_csr(u->a_rowptr, u->a_colidx, u->a_vals, u->n, x, d, ld, 1, nullptr, b->h1, ld, u->a_split, stream));        // relu(A X)
+    OEA_TRY(oea_spmm_csr(u->a_rowptr, u->a_colidx, u->a_vals, u->n, b->h1, d, ld, 0, nullptr, b->out, ld, u->a_split, stream));   // A H1
+    if (u->pair_rowptr) {        // hinge coefficients, then every row adds its pairs in a fixed order (no atomics)
+        OEA_REQUIRE(u->pair_other && u->pair_slot && b->coef, "gcn unit: pair lists");
+        OEA_TRY(oea_align_loss_l1_coef(b->out, u->n, d, ld, u->ill, u->t, u->k, u->gamma, u->neg_left, u->neg_right, u->neg2_left,
+                                       u->neg2_right, nullptr, loss_accum, b->coef, stream));
+        OEA_TRY(oea_pair_grad_rows(b->out, u->n, d, ld, u->pair_rowptr, u->pair_other, u->pair_slot, b->coef, nullptr, 1, b->g_out, stream));
+    } else {
+        OEA_CHECK_HIP(hipMemsetAsync(b->g_out, 0, sizeof(float) * (size_t)u->n * ld, oea::as_stream(stream)));
+        OEA_TRY(oea_align_loss_l1(b->out, u->n, d, ld, u->ill, u->t, u->k, u->gamma, u->neg_left, u->neg_right, u->neg2_left,
+                                  u->neg2_right, b->g_out, loss_accum, stream));
+    }
+    OEA_TRY(oea_spmm_csr(u->at_rowptr, u->at_colidx, u->at_vals, u->n, b->g_out, d, ld, 0, b->h1, b->g_pre1, ld, u->at_split, stream));   // relu gate fused
+    OEA_TRY(oea_spmm_csr(u->at_rowptr, u->at_colidx, u->at_vals, u->n, b->g_pre1, d, ld, 0, nullptr, b->g_x, ld, u->at_split, stream));
+    const float *g_t = b->g_x;
+    if (feat) {
+        OEA_TRY(oea_spmm_csr(u->ft_rowptr, u->ft_colidx, u->ft_vals, u->w_rows, b->g_x, d, ld, 0, nullptr, b->g_t, ld, u->ft_split, stream));
+        g_t = b->g_t;
+    }
+    OEA_TRY(oea_sgd_rows(w, g_t, u->w_rows, d, ld, 1, u->lr, stream));       // through the row normalisation
+#undef OEA_TRY
     return OEA_OK;
 }
 

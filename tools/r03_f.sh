@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box: suite without the multi-process tests + determinism probe + bench.
 set -u
-TAG=${1:-r03f}
+TAG=${1:-r03g}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
