@@ -554,6 +554,9 @@ int oea_pair_loss_l2_fwd(const float *emb, int64_t n, int32_t dim, int32_t ld, c
                          const float *weight, float margin, float balance, float *coef, float *terms, void *stream);
 int oea_pair_grad_rows(const float *emb, int64_t n, int32_t dim, int32_t ld, const int32_t *rowptr, const int32_t *other,
                        const int32_t *slot_pair, const float *coef, const float *gscale, int32_t norm, float *grad, void *stream);
+/* out[s] = sum of vals[order[e]] (order NULL: vals[e]) over e in [seg_ptr[s], seg_ptr[s + 1]) -- one wave per segment, fixed
+ * order: the gradient of a gather from few distinct rows (rdgcn.py:202-215: per-relation logits gathered per attention edge) */
+int oea_segment_sum_f32(const float *vals, const int32_t *order, const int32_t *seg_ptr, int64_t n_seg, float *out, void *stream);
 int32_t oea_colsum_blocks(int64_t n);
 int oea_highway_fwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, int64_t n, int32_t d,
                     float *out, void *stream);

@@ -219,6 +219,16 @@ class GCN_Align_Unit:
 
     def _train_step_fused(self, negs):
         import ctypes as C
+        key = tuple(x.data_ptr() for x in negs)
+        if getattr(self, "_unit_key", None) != key or self._pairs_ver != tuple(x._version for x in negs):
+            self._build_unit(negs)                                   # once per redraw of the negatives (every 10 epochs)
+            self._unit_key = key
+        ops.check(self._epoch_fn(C.byref(self._unit), self.W.data_ptr(), C.byref(self._cb), self.loss.data_ptr(), ops._stream()))
+        self.outputs = self._bufs["out"]
+
+    def _build_unit(self, negs):
+        """the argument block of oea_gcn_unit_epoch: operands, negatives, pair lists, buffers (allocated once)"""
+        import ctypes as C
         from .. import _lib
         d, dev = self.dim, self.W.device
         ld = self.W.shape[1]
@@ -233,6 +243,7 @@ class GCN_Align_Unit:
                               coef=torch.empty(self.ILL.shape[0] * (1 + 2 * k), dtype=torch.float32, device=dev))
             self._cb = _lib.GcnUnitBuffers(*[None if self._bufs[nm] is None else self._bufs[nm].data_ptr()
                                              for nm in ("t", "x", "h1", "out", "g_out", "g_pre1", "g_x", "g_t", "coef")])
+            self._epoch_fn = ops.lib().oea_gcn_unit_epoch
         pairs = self._pair_lists(negs, n)
         u = _lib.GcnUnit()
         ops_list = [("a_", self.adj.fwd), ("at_", self.adj.bwd)]
@@ -253,8 +264,10 @@ class GCN_Align_Unit:
         u.n, u.w_rows, u.t = n, self.W.shape[0], self.ILL.shape[0]
         u.dim, u.ld, u.k = d, ld, k
         u.gamma, u.lr = float(self.args.gamma), float(self.args.learning_rate)
-        ops.check(ops.lib().oea_gcn_unit_epoch(C.byref(u), self.W.data_ptr(), C.byref(self._cb), self.loss.data_ptr(), ops._stream()))
-        self.outputs = self._bufs["out"]
+        self._unit = u
+        self._unit_keep = negs
+        if pairs is None:
+            self._pairs_ver = tuple(x._version for x in negs)
 
     def pop_loss(self):
         v = float(self.loss.item())

@@ -28,7 +28,7 @@ import torch
 from .. import ops
 from ..models.basic_model import BasicModel
 from ..modules.base.optimizers import generate_optimizer
-from ..models.graph_ops import EdgeGraph, TFAdam, sparse_attention, spmm
+from ..models.graph_ops import gather_few, gather_few_plan, EdgeGraph, TFAdam, sparse_attention, spmm
 from ..modules.finding.evaluation import early_stop, test, valid
 from ..modules.load import read as rd
 
@@ -218,7 +218,9 @@ class Layer:
     def add_sparse_att_layer(self, inlayer, dual_layer, w, b):
         """rdgcn.py:202-215: logit of an edge = conv1d(dual feature of its relation)."""
         dual_transform = (dual_layer @ w + b).reshape(-1)
-        z = dual_transform[self.edge_rel]
+        if getattr(self, "_rel_plan", None) is None:
+            self._rel_plan = gather_few_plan(self.edge_rel, dual_transform.shape[0])
+        z = gather_few(dual_transform, self.edge_rel, self._rel_plan)      # backward: one wave per relation (fixed order)
         return torch.relu(sparse_attention(self.r_graph, z, inlayer, slope=0.2))
 
     def add_diag_layer(self, inlayer, w0):

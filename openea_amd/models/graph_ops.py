@@ -351,6 +351,35 @@ class BiasTanhFn(torch.autograd.Function):
         return ops.bias_tanh_bwd(y, gy.contiguous())
 
 
+class GatherFewFn(torch.autograd.Function):
+    """z = src[idx] for a 1-D src with FEW rows and many gathers (RDGCN: one logit per relation, gathered per attention
+    edge); backward = one wave per source row adds its edges' gradients in a fixed order (oea_segment_sum_f32) instead of
+    torch's sorted index_put walk over ~800 duplicates per row."""
+
+    @staticmethod
+    def forward(ctx, src, idx, plan):
+        ctx.plan, ctx.n = plan, src.shape[0]
+        return src[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        order, seg_ptr = ctx.plan
+        return ops.segment_sum(g.contiguous(), order, seg_ptr), None, None
+
+
+def gather_few_plan(idx, n_rows):
+    """(order int32 [len(idx)], seg_ptr int32 [n_rows + 1]): the gather positions grouped by source row, position order kept"""
+    idx64 = idx.to(torch.int64)
+    order = torch.argsort(idx64, stable=True).to(torch.int32).contiguous()
+    seg_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=idx.device)
+    seg_ptr[1:] = torch.cumsum(torch.bincount(idx64, minlength=n_rows), 0)
+    return order, seg_ptr.to(torch.int32)
+
+
+def gather_few(src, idx, plan):
+    return GatherFewFn.apply(src, idx, plan)
+
+
 def concat_l2n(xs):
     return ConcatL2NormFn.apply(*xs)
 

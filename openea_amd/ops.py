@@ -823,3 +823,11 @@ def bias_tanh_bwd(y, gy):
     parts = torch.empty((lib().oea_colsum_blocks(n), d), dtype=torch.float32, device=y.device)
     check(lib().oea_bias_tanh_bwd(_p(y), _p(gy), n, d, _p(gx), _p(parts), _stream()))
     return gx, parts.sum(0)
+
+
+def segment_sum(vals, order, seg_ptr):
+    """out[s] = sum of vals[order[e]] over e in [seg_ptr[s], seg_ptr[s + 1]) (order may be None) -> fp32 [n_seg]."""
+    n_seg = seg_ptr.numel() - 1
+    out = torch.empty(n_seg, dtype=torch.float32, device=vals.device)
+    check(lib().oea_segment_sum_f32(_p(vals), _p(order), _p(seg_ptr), n_seg, _p(out), _stream()))
+    return out

@@ -188,6 +188,28 @@ def test_fused_highway_and_bias_tanh_equal_torch(ops):
     assert math.isfinite(float(y.sum()))
 
 
+def test_gather_few_backward_is_a_segment_sum(ops):
+    """rdgcn.py:202-215: one logit per relation gathered per attention edge; the backward adds each relation's edges in a
+    fixed order (one wave per relation) -- equal to torch's index backward to rounding, identical between runs."""
+    from openea_amd.models.graph_ops import gather_few, gather_few_plan
+    dev = ops.device()
+    rng = np.random.RandomState(4)
+    n_src, n_idx = 700, 60000
+    idx = torch.tensor(np.minimum(rng.zipf(1.3, n_idx) - 1, n_src - 1), device=dev)
+    plan = gather_few_plan(idx, n_src)
+    w = torch.tensor(rng.standard_normal(n_idx).astype(np.float32), device=dev)
+    grads = []
+    for _ in range(2):
+        src = torch.tensor(rng.standard_normal(n_src).astype(np.float32) * 0 + 1.0, device=dev, requires_grad=True)
+        (gather_few(src, idx, plan) * w).sum().backward()
+        grads.append(src.grad.cpu().numpy())
+    assert np.array_equal(grads[0], grads[1])
+    ref = np.zeros(n_src)
+    np.add.at(ref, idx.cpu().numpy(), w.cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(grads[0], ref, rtol=1e-5, atol=1e-4)
+    assert (ref == 0).any()                                        # relations without edges get a zero gradient
+
+
 def test_spmm_autograd(ops):
     from openea_amd.models.graph_ops import EdgeGraph, spmm
     rng = np.random.RandomState(1)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box: full suite + bench + kNN segment-capacity experiment.
 set -u
-TAG=${1:-r03e}
+TAG=${1:-r03h}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -9,7 +9,7 @@ cd $R
 timeout 1800 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 grep -E "passed|failed|FAILED|ERROR|per-epoch exchange|AliNet two|end-to-end forward" $OUT/pytest_gpu.log | tail -30
-for C in 16 8 6; do
+for C in ; do
   OEA_TOPK_CCAP=$C timeout 300 python tools/_exp/knn_time.py > $OUT/knn_ccap$C.log 2>&1
   echo "ccap $C: $(grep -h -i "knn\|ms" $OUT/knn_ccap$C.log | tail -3 | tr '\n' ' ')"
 done
