@@ -95,6 +95,21 @@ with contextlib.redirect_stdout(buf):
     a.init()
     with torch.no_grad():
         alinet_fwd0 = a._forward()[-1].detach().cpu().numpy()           # before any step: the forward alone, sharded vs not
+    # one backward on the initial parameters (the sampler state is put back afterwards): gradient by gradient, sharded vs not
+    import random as _random
+    _st, _pst = a._rng.get_state(), _random.getstate()
+    _pos, _neg, _valid = a.device_input_batch(a.args.batch_size)
+    _hs, _, _ts = a.generate_rel_batch()
+    _outs = a._forward()
+    _emb = a._concat_train(_outs)
+    _loss = a.compute_loss(_emb, _pos, _neg, _valid) + a.compute_rel_loss(_emb, torch.as_tensor(_hs, device=a.dev), torch.as_tensor(_ts, device=a.dev))
+    _loss.backward()
+    alinet_grads = {"alinet_g%02d" % i: (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().numpy() for i, p in enumerate(a._params)}
+    for p in a._params:
+        p.grad = None
+    a._rng.set_state(_st)
+    _random.setstate(_pst)
+    a._neg_step -= 1
     a.args.max_epoch = 1
     a.run()
     alinet_ep1 = a._forward()[-1].detach().cpu().numpy()
@@ -117,7 +132,7 @@ with contextlib.redirect_stdout(buf):
         extra[nm] = b.ent_embeds.raw() if hasattr(b.ent_embeds, "raw") else b.ent_embeds.var.cpu().numpy()
 rank = int(os.environ.get("RANK", "0"))
 np.savez(os.environ["OEA_OUT"] + "/result_w%d_r%d.npz" % (world, rank), ent=m.ent_embeds.raw(), rel=m.rel_embeds.raw(),
-         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], att_r=attn_res[3], att_r_dz=attn_res[4], att_r_dv=attn_res[5], alinet=alinet_out, alinet_fwd0=alinet_fwd0, alinet_ep1=alinet_ep1, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
+         nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], att_r=attn_res[3], att_r_dz=attn_res[4], att_r_dv=attn_res[5], alinet=alinet_out, alinet_fwd0=alinet_fwd0, alinet_ep1=alinet_ep1, **alinet_grads, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
          rotate=extra["BootEA_RotatE"])
 if world > 1:
     dist.barrier()
@@ -188,6 +203,11 @@ def test_two_ranks_reproduce_single_process(tmp_path, capsys):
         print("\nAliNet two ranks vs single process: forward before training %.2e, after 1 Adam epoch %.2e, after 4 epochs %.2e "
               "(relative L2); GCN-Align outputs max abs %.2e"
               % (rel("alinet_fwd0"), rel("alinet_ep1"), d_alinet, float(np.abs(r0["gcn_out"] - single["gcn_out"]).max())))
+        for key in sorted(k for k in single if k.startswith("alinet_g")):
+            if not np.array_equal(r0[key], single[key]):
+                print("   gradient %s %s: sharded vs single max abs %.2e (|g| max %.2e), differing entries %d"
+                      % (key, single[key].shape, float(np.abs(r0[key] - single[key]).max()), float(np.abs(single[key]).max()),
+                         int((r0[key] != single[key]).sum())))
     assert d_alinet <= float(os.environ.get("OEA_ALINET_2RANK_TOL", "5e-3"))
     for key in ("mtranse", "bootea", "transd", "rotate"):
         assert np.array_equal(r0[key], r1[key])
