@@ -219,3 +219,52 @@ def test_predict_and_predict_entities(kgs_small, tmp_path):
     for (_, _, conf), a, b in zip(res, uris1, uris2):
         assert abs(conf - ref[row_of[a[1]], col_of[b[1]]]) < 1e-5
     assert os.path.exists(m.out_folder + "conf.tsv")
+
+
+@pytest.mark.parametrize("name", ["AliNet", "GCN_Align", "RDGCN", "AlignE"])
+def test_no_kernel_reads_unwritten_memory(name, tmp_path, monkeypatch):
+    """every buffer the host layer hands to the kernels comes from torch.empty / empty_like: poisoned with NaN here, a kernel
+    that read a byte nobody wrote would spread NaNs into the trained tables (found this way in round 3: nothing -- kept as a
+    guard; world-dependent results would be the symptom)."""
+    import torch as _torch
+    from openea_amd import approaches
+    from openea_amd.modules.load.synth import make_kgs
+    from openea_amd.run.default_args import get_args
+    real_empty, real_empty_like = _torch.empty, _torch.empty_like
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_floating_point() and t.is_cuda:
+            t.fill_(float("nan"))
+        elif t.is_cuda and t.dtype in (_torch.int32, _torch.int64):
+            t.fill_(-(1 << 30))
+        return t
+
+    def poisoned_like(x, **k):
+        t = real_empty_like(x, **k)
+        if t.is_floating_point() and t.is_cuda:
+            t.fill_(float("nan"))
+        return t
+    kw = dict(AliNet=dict(layer_dims=[48, 32, 24], batch_size=600, truncated_epsilon=0.9),
+              GCN_Align=dict(se_dim=32, ae_dim=16), RDGCN=dict(dim=32, neg_triple_num=8, random_name_init=True),
+              AlignE=dict(dim=32, batch_size=2000, neg_triple_num=5, truncated_freq=2, truncated_epsilon=0.9))[name]
+    mode = "swapping" if name == "AlignE" else "mapping"
+    m = getattr(approaches, name)()
+    m.set_args(get_args(name, output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/", max_epoch=3,
+                        start_valid=100, eval_freq=100, **kw))
+    m.set_kgs(make_kgs("small", mode=mode, seed=0))
+    m.init()
+    monkeypatch.setattr(_torch, "empty", poisoned)
+    monkeypatch.setattr(_torch, "empty_like", poisoned_like)
+    m.run()
+    monkeypatch.undo()
+    if name == "AliNet":
+        outs = [o.detach() for o in m._forward()] + [p.detach() for p in m._params]
+    elif name == "GCN_Align":
+        outs = [m.model_se.forward()[2], m.model_se.W] + ([m.model_ae.forward()[2]] if m.model_ae is not None else [])
+    elif name == "RDGCN":
+        outs = [m.gcn_model.forward().detach()] + [p.detach() for p in m.gcn_model.params()]
+    else:
+        outs = [m.ent_embeds.var, m.rel_embeds.var]
+    for o in outs:
+        assert bool(_torch.isfinite(o).all()), name
