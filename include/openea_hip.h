@@ -557,6 +557,11 @@ int oea_pair_grad_rows(const float *emb, int64_t n, int32_t dim, int32_t ld, con
 /* out[s] = sum of vals[order[e]] (order NULL: vals[e]) over e in [seg_ptr[s], seg_ptr[s + 1]) -- one wave per segment, fixed
  * order: the gradient of a gather from few distinct rows (rdgcn.py:202-215: per-relation logits gathered per attention edge) */
 int oea_segment_sum_f32(const float *vals, const int32_t *order, const int32_t *seg_ptr, int64_t n_seg, float *out, void *stream);
+/* the row-grouped endpoint lists of a pair list for oea_pair_grad_rows: pairs int32 [m, 2] with rows in [0, n_rows) ->
+ * rowptr [n_rows + 1], other [2 m] (the partner row of every slot), slot_pair [2 m] (its pair); inside a row the slots keep
+ * pair order.  One call, stream-ordered, no host synchronisation (csrc/graph_build.hip: rocPRIM stable sort + scan). */
+int oea_pair_rows_build(const int32_t *pairs, int64_t m, int64_t n_rows, int32_t *rowptr, int32_t *other, int32_t *slot_pair,
+                        void *stream);
 int32_t oea_colsum_blocks(int64_t n);
 int oea_highway_fwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, int64_t n, int32_t d,
                     float *out, void *stream);

@@ -168,6 +168,7 @@ PROTOTYPES = {
     "oea_pair_grad_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "oea_align_loss_l1_coef": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oea_segment_sum_f32": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "oea_pair_rows_build": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "oea_colsum_blocks": (_i32, [_i64]),
     "oea_highway_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_highway_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -12,6 +12,7 @@
 // kernel on the transposed CSR with the relu gate fused in.
 // Bytes per launch: nnz*(8 + 4*d) + 4*N*d.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -511,7 +512,13 @@ int oea_spmm_csr(const int32_t *rowptr, const int32_t *colidx, const float *vals
                                                                      fused ? split->partials : nullptr, split->row_chunk0); \
         }                                                                                                              \
     } while (0)
-    OEA_DISPATCH_LD(ldx, CALL);
+    // 64 < ld <= 128 (the d = 100 tables of GCN-Align / the translational models): 16-lane groups with two float4 per lane --
+    // 16 rows per workgroup instead of 8, half the waves for the same rows: 40.8 -> 36.1 us per aggregate at the D-W-15K shape
+    // (gpurun_out r03k).  OEA_SPMM_G = 8 / 16 / 32 overrides (experiments).
+    static const int env_g = [] { const char *e = getenv("OEA_SPMM_G"); return e ? atoi(e) : 16; }();
+    if (ldx > 64 && ldx <= 128 && env_g == 16) { CALL(16, 2); }
+    else if (ldx > 64 && ldx <= 128 && env_g == 8) { CALL(8, 4); }
+    else OEA_DISPATCH_LD(ldx, CALL);
 #undef CALL
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;

@@ -765,15 +765,16 @@ def pair_loss_l2_fwd(emb, dim, pairs, n_pos, weight, margin, balance):
 
 
 def pair_rows_csr(pairs, n_rows):
-    """the endpoints of `pairs` (device int [m, 2]) grouped by row, slots in pair order (one stable device sort) ->
-    (rowptr int32 [n_rows + 1], other int32 [2 m], slot_pair int32 [2 m]) for pair_grad_rows."""
+    """the endpoints of `pairs` (device int [m, 2]) grouped by row, slots in pair order (oea_pair_rows_build: one stable
+    device sort + a scan, no host synchronisation) -> (rowptr int32 [n_rows + 1], other int32 [2 m], slot_pair int32 [2 m])
+    for pair_grad_rows."""
+    pairs = pairs.to(torch.int32).contiguous()
     m = pairs.shape[0]
-    ends = torch.cat([pairs[:, 0], pairs[:, 1]]).to(torch.int64)
-    order = torch.argsort(ends, stable=True)
-    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=pairs.device)
-    rowptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n_rows), 0)
-    other = torch.cat([pairs[:, 1], pairs[:, 0]])[order].to(torch.int32).contiguous()
-    return rowptr.to(torch.int32), other, (order % m).to(torch.int32).contiguous()
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=pairs.device)
+    other = torch.empty(2 * m, dtype=torch.int32, device=pairs.device)
+    slot_pair = torch.empty(2 * m, dtype=torch.int32, device=pairs.device)
+    check(lib().oea_pair_rows_build(_p(pairs), m, int(n_rows), _p(rowptr), _p(other), _p(slot_pair), _stream()))
+    return rowptr, other, slot_pair
 
 
 def pair_grad_rows(emb, dim, rowptr, other, slot_pair, coef, gscale=None, norm=2, out=None):
