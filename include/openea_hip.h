@@ -398,7 +398,8 @@ int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_
  * DESIGN.md "Packed similarity operands"); reuse is ordered by `stream` (a call on another stream waits for
  * the previous use).  OEA_TILE_GLDS=0 in the environment selects the register-staged tiles (same bits, no scratch).
  * ------------------------------------------------------------------------------------- */
-enum { OEA_METRIC_INNER = 0, OEA_METRIC_MANHATTAN = 1, OEA_METRIC_EUCLIDEAN = 2 };
+enum { OEA_METRIC_INNER = 0, OEA_METRIC_MANHATTAN = 1, OEA_METRIC_EUCLIDEAN = 2,
+       OEA_METRIC_MANHATTAN_F32 = 3 /* oea_sim_matrix only: 1 - sum |a - b| accumulated in fp32 -- a ranking pre-filter, not scipy's bits */ };
 size_t oea_rank_workspace_bytes(int64_t n1);
 int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2,
                   int32_t dim, int32_t metric, const float *csls_r, const float *csls_c, int64_t gold_offset,
@@ -430,6 +431,12 @@ int oea_rank_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, const 
 int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2,
                    int32_t ld2, int32_t dim, int32_t metric, float *out, int64_t ld_out,
                    void *stream);
+/* exact fp64 L1 distances of a candidate list: out[i, j] = sum_k |q[i, k] - table[cand[i, j], k]| (fixed summation order).
+ * With OEA_METRIC_MANHATTAN_F32 + oea_topk_rows this is RDGCN's hard-negative mining (approaches/rdgcn.py:75-87) without the
+ * fp64 distance of every (seed, entity) pair: fp32 ranks k + margin candidates, these are re-ranked exactly. */
+int oea_pair_l1_f64(const float *q, int64_t nq, int32_t ldq, const float *table, int64_t n, int32_t ldt, int32_t dim,
+                    const int32_t *cand, int32_t c, double *out, void *stream);
+
 /* out[i] = mean of the k largest of S[i, 0:n2] (calculate_nearest_k, similarity.py:80-83),
  * summed in descending order in fp32.  k <= 64. */
 int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_t k, float *out,

@@ -76,7 +76,7 @@ class RotateCfg(C.Structure):
 
 LOSS_KIND = {"margin-based": 0, "limited": 1, "logistic": 2, "positive": 3, "align": 4}
 OPT_KIND = {"SGD": 0, "Adagrad": 1, "Adam": 2, "Adadelta": 3}
-METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2}
+METRIC = {"inner": 0, "manhattan": 1, "euclidean": 2, "manhattan_f32": 3}
 
 _vp, _i32, _i64, _u32, _u64, _f32, _sz = (C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64,
                                           C.c_float, C.c_size_t)
@@ -150,6 +150,7 @@ PROTOTYPES = {
     "oea_rank_rows": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "oea_rank_workspace_bytes": (_sz, [_i64]),
     "oea_rank_eval": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "oea_pair_l1_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "oea_rank_eval_metrics_workspace_bytes": (_sz, [_i64]),
     "oea_rank_eval_metrics": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

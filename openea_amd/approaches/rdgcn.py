@@ -248,12 +248,27 @@ class Layer:
         return AlignLossL1.apply(out, self.ill_dev, self.k, float(self.gamma), negs)
 
 
-def get_neg(ill_ids, output_layer, dim, k):
+def get_neg(ill_ids, output_layer, dim, k, exact_strip=False, margin=32):
     """rdgcn.py:75-87: the k L1-nearest entities of every seed entity among ALL entities (the seed
-    itself included, as in the reference) -> device int32 [t*k]."""
+    itself included, as in the reference) -> device int32 [t*k], ascending ids per seed.
+
+    The reference ranks fp64 `cdist` values.  Default here (round 3): fp32 L1 distances of every (seed, entity) pair rank
+    k + margin candidates per seed (4x the fp64 rate), their EXACT fp64 distances pick the k nearest (ties: smaller id) --
+    the selection the reference makes, as long as the fp32 ranking keeps the true k nearest among its first k + margin
+    (fp32 accumulation error ~1e-5 of a distance; the gap between the k-th and the (k + 32)-th neighbour is orders larger).
+    exact_strip=True: every pair in fp64 (sim_valu_store_kernel, the bits of scipy's cdist), rounded to fp32 for the select."""
     q = ops.gather_rows(output_layer, dim, ill_ids)
-    s = ops.sim_matrix(q, output_layer, dim, 'manhattan', pad=True)        # 1 - cityblock distance, fp64 inside
-    return ops.topk_rows(s, k, nc=output_layer.shape[0]).reshape(-1)
+    n = output_layer.shape[0]
+    if exact_strip or k + margin >= n:
+        s = ops.sim_matrix(q, output_layer, dim, 'manhattan', pad=True)        # 1 - cityblock distance, fp64 inside
+        return ops.topk_rows(s, k, nc=n).reshape(-1)
+    s = ops.sim_matrix(q, output_layer, dim, 'manhattan_f32', pad=True)
+    cand = ops.topk_rows(s, k + margin, nc=n)                                    # ascending ids
+    del s
+    d64 = ops.pair_l1_f64(q, output_layer, dim, cand)
+    order = torch.argsort(d64, dim=1, stable=True)[:, :k]                        # k smallest distances, ties -> smaller id
+    sel = torch.sort(torch.gather(cand.to(torch.int64), 1, order), dim=1).values
+    return sel.to(torch.int32).reshape(-1).contiguous()
 
 
 def read_word_vectors(file_path):

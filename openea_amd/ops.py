@@ -466,6 +466,15 @@ def sim_matrix(e1, e2, dim, metric='inner', pad=False):
     return out
 
 
+def pair_l1_f64(q, table, dim, cand):
+    """exact fp64 L1 distances of the candidate lists cand int32 [nq, c] -> fp64 [nq, c]."""
+    nq, c = cand.shape
+    out = torch.empty((nq, c), dtype=torch.float64, device=q.device)
+    check(lib().oea_pair_l1_f64(_p(q), nq, q.shape[1], _p(table), table.shape[0], table.shape[1], dim, _p(cand), c, _p(out),
+                                _stream()))
+    return out
+
+
 def row_topk_mean(s, k):
     out = torch.empty(s.shape[0], dtype=torch.float32, device=s.device)
     check(lib().oea_row_topk_mean(_p(s), s.shape[0], s.shape[1], s.stride(0), k, _p(out), _stream()))

@@ -360,13 +360,24 @@ def test_rdgcn_word_vector_initialisation(ops, tmp_path):
     assert np.abs(m.gcn_model.primal_X_0.detach().cpu().numpy() - x0).max() > 0      # the input layer is trained
 
 
-def test_rdgcn_hard_negative_mining(ops):
-    """get_neg (rdgcn.py:75-87): k L1-nearest entities of each seed entity, as a set, vs scipy."""
+@pytest.mark.parametrize("exact_strip", [False, True])
+def test_rdgcn_hard_negative_mining(ops, exact_strip):
+    """get_neg (rdgcn.py:75-87): k L1-nearest entities of each seed entity, as a set, vs scipy -- the default path (fp32
+    pre-filter of k + 32 candidates, exact fp64 re-rank) and the all-pairs fp64 strip; clustered rows (near-equal distances)
+    and exact duplicates included."""
     from scipy.spatial.distance import cdist
     from openea_amd.approaches.rdgcn import get_neg
     rng = np.random.RandomState(4)
-    emb = rng.standard_normal((700, 32)).astype(np.float32)
-    seeds = rng.choice(700, 50, replace=False).astype(np.int32)
-    out = get_neg(ops.to_ids(seeds), ops.to_table(emb), 32, 7).cpu().numpy().reshape(50, 7)
-    ref = cdist(emb[seeds], emb, metric="cityblock").argsort(1)[:, :7]
-    assert all(set(out[i]) == set(ref[i]) for i in range(50))
+    emb = rng.standard_normal((3000, 40)).astype(np.float32)
+    emb[1000:1400] = emb[1000] + 1e-3 * rng.standard_normal((400, 40)).astype(np.float32)     # a tight cluster
+    emb[2000:2004] = emb[7]                                                                     # exact duplicates of row 7
+    seeds = np.concatenate([rng.choice(3000, 60, replace=False), [7, 1000, 1100, 2001]]).astype(np.int32)
+    k = 25
+    out = get_neg(ops.to_ids(seeds), ops.to_table(emb), 40, k, exact_strip=exact_strip).cpu().numpy().reshape(len(seeds), k)
+    d = cdist(emb[seeds].astype(np.float64), emb.astype(np.float64), metric="cityblock")
+    for i in range(len(seeds)):
+        kth = np.sort(d[i])[k - 1]
+        sure = set(np.flatnonzero(d[i] < kth - 1e-4 * max(kth, 1.0)).tolist())          # everything clearly inside the k nearest
+        allowed = set(np.flatnonzero(d[i] <= kth + (1e-4 * max(kth, 1.0) if exact_strip else 0.0)).tolist())
+        got = set(out[i].tolist())
+        assert len(got) == k and sure <= got <= allowed, (i, exact_strip)

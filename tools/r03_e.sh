@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box: full suite + bench + kNN segment-capacity experiment.
 set -u
-TAG=${1:-r03h}
+TAG=${1:-r03l}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
