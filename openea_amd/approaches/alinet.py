@@ -379,6 +379,9 @@ class AliNetGraphAttentionLayer:
         mapped = x @ self.kernel
         s1 = torch.tanh(((x @ self.kernel1) * x).sum(1))
         s2 = torch.tanh(((x @ self.kernel2) * x).sum(1))
+        if getattr(self, "keep_prob", 0.0) > 0.0:                    # tf.nn.dropout(con_sa, keep_prob) (:665-667)
+            s1 = _tf_dropout(s1, self.keep_prob)
+            s2 = _tf_dropout(s2, self.keep_prob)
         z = g.e_vals * s1[g.e_rows] + g.e_vals * s2[g.e_cols]        # sparse_add of the two products (:667-669)
         return torch.tanh(sparse_attention(g, z, mapped, slope=0.2))
 
@@ -394,12 +397,22 @@ class HighwayLayer:
         self.bn = BatchNormAffine(input_dim, dev)
 
     def call(self, input1, input2):
+        if getattr(self, "keep_prob", 0.0) > 0.0:                    # dropout between tanh and relu of the gate (:618-620): op by op
+            a, b = self.bn(input1), self.bn(input2)
+            gate = torch.relu(_tf_dropout(torch.tanh(a @ self.weight), self.keep_prob))
+            return torch.tanh(b * (1 - gate) + a * gate)
         wf, bw = self.bn.fold(self.weight)
         p = torch.addmm(bw, input1, wf)                              # BN(input1) @ W
         return highway_gate(input1, input2, p, self.bn.scale(), self.bn.beta)      # csrc/gnn_fused.hip, one pass each way
 
     def params(self):
         return self.bn.params() + [self.weight]
+
+
+def _tf_dropout(x, keep_prob):
+    """tf.nn.dropout(x, keep_prob): keep with probability keep_prob, scale the kept by 1 / keep_prob (torch's Philox stream,
+    not TF's: the draws differ, the distribution is the same)."""
+    return torch.nn.functional.dropout(x, p=1.0 - keep_prob, training=True)
 
 
 def l2n(x):
@@ -427,8 +440,11 @@ class AliNet(BasicModel):
         """alinet.py:692-747."""
         dev = ops.device()
         self.dev = dev
-        if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0:
-            raise NotImplementedError("dropout > 0 is not built (every shipped args file uses 0)")
+        # args.dropout > 0 (no shipped args file): the reference passes it to the attention layer and the highway gate only
+        # (alinet.py:806,817; the GraphConvolution layers are built with dropout_rate = 0.0, :796) and calls
+        # tf.nn.dropout(x, self.dropout_rate) -- TF1's second positional argument is KEEP_prob, so `dropout` is the keep
+        # probability there (:619,666-667); the op sits in the graph, i.e. evaluation embeddings are dropped out as well.
+        self.keep_prob = float(getattr(self.args, "dropout", 0.0) or 0.0)
         self.ref_ent1 = self.kgs.test_entities1 + self.kgs.valid_entities1
         self.attn_grouping = getattr(self.args, 'attn_grouping', self.attn_grouping)      # 'row' | 'runs' (SURVEY H3)
         self.ref_ent2 = self.kgs.test_entities2 + self.kgs.valid_entities2
@@ -474,6 +490,7 @@ class AliNet(BasicModel):
             if i < layer_num - 1:
                 self.two_hop_layers.append(AliNetGraphAttentionLayer(self._rng, dims[i], dims[i + 1], self.adj[1], self.dev))
                 self.highways.append(HighwayLayer(self._rng, dims[i + 1], dims[i + 1], self.dev))
+                self.two_hop_layers[-1].keep_prob = self.highways[-1].keep_prob = getattr(self, "keep_prob", 0.0)
         self._params = [self.init_embedding]
         for layer in self.one_hop_layers + self.two_hop_layers + self.highways:
             self._params += layer.params()

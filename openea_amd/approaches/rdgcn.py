@@ -224,7 +224,10 @@ class Layer:
         return torch.relu(sparse_attention(self.r_graph, z, inlayer, slope=0.2))
 
     def add_diag_layer(self, inlayer, w0):
-        """rdgcn.py:184-191."""
+        """rdgcn.py:184-191; tf.nn.dropout(inlayer, 1 - dropout) in front (in the graph: also when evaluating)."""
+        rate = float(getattr(self.args, "dropout", 0.0) or 0.0)
+        if rate > 0.0:
+            inlayer = torch.nn.functional.dropout(inlayer, p=rate, training=True)
         return torch.relu(spmm(self.M, inlayer * w0))
 
     @staticmethod
@@ -316,8 +319,6 @@ class RDGCN(BasicModel):
 
     def init(self):
         self.dev = ops.device()
-        if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0:
-            raise NotImplementedError("dropout > 0 is not built (every shipped args file uses 0)")
         if self.local_name_vectors is None:
             # rdgcn.py:358,424: the name vectors ARE the model's input (accuracy rests on them); the reference raises
             # FileNotFoundError when the word-vector file is missing.  Random initialisation must be asked for.

@@ -381,3 +381,28 @@ def test_rdgcn_hard_negative_mining(ops, exact_strip):
         allowed = set(np.flatnonzero(d[i] <= kth + (1e-4 * max(kth, 1.0) if exact_strip else 0.0)).tolist())
         got = set(out[i].tolist())
         assert len(got) == k and sure <= got <= allowed, (i, exact_strip)
+
+
+@pytest.mark.parametrize("name,kw", [("AliNet", dict(layer_dims=[48, 32, 24], batch_size=600, truncated_epsilon=0.9, dropout=0.8, attn_grouping="row")),
+                                     ("RDGCN", dict(dim=32, neg_triple_num=8, random_name_init=True, dropout=0.2))])
+def test_gnn_dropout_paths(ops, tmp_path, name, kw):
+    """args.dropout > 0 (no shipped args file; alinet.py:619,665-667: tf.nn.dropout(x, dropout) -- the value is TF1's KEEP
+    probability there; rdgcn.py:185: tf.nn.dropout(x, 1 - dropout)): the models train, stay finite, and a forward pass is
+    random (the op sits in the reference's graph, evaluation included) with the right scale."""
+    from openea_amd import approaches
+    from openea_amd.approaches.alinet import _tf_dropout
+    from openea_amd.modules.load.synth import make_kgs
+    from openea_amd.run.default_args import get_args
+    m = getattr(approaches, name)()
+    m.set_args(get_args(name, output=str(tmp_path) + "/out/", training_data="synthetic/small/", dataset_division="f/", max_epoch=3,
+                        start_valid=100, eval_freq=100, **kw))
+    m.set_kgs(make_kgs("small", mode="mapping", seed=0))
+    m.init()
+    m.run()
+    with torch.no_grad():
+        a = (m._forward()[-1] if name == "AliNet" else m.gcn_model.forward()).detach()
+        b = (m._forward()[-1] if name == "AliNet" else m.gcn_model.forward()).detach()
+    assert bool(torch.isfinite(a).all()) and not torch.equal(a, b)
+    x = torch.ones(200000, device=ops.device())
+    y = _tf_dropout(x, 0.8)
+    assert abs(float(y.mean()) - 1.0) < 0.01 and abs(float((y > 0).float().mean()) - 0.8) < 0.01
