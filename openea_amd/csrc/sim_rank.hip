@@ -895,49 +895,72 @@ __global__ __launch_bounds__(256) void rank_valu_kernel(
 // 1 - sum |a - b| with fp32 accumulation: NOT the bits of scipy's cdist (that is sim_valu_store_kernel's fp64 chain, 92 ms for
 // 20,000 x 200,000 x 300 at 0.68 of the fp64 vector peak); it only has to rank the candidates well enough that the true k
 // nearest are among the k + margin it keeps -- those are then re-ranked with exact fp64 distances (oea_pair_l1_f64).
-// 64 x 64 tile per workgroup, float operand tiles in LDS, 4 x 4 outputs per thread; |.| is a free source modifier of the add.
+// 128 x 128 tile per workgroup, 8 x 8 outputs per thread: per k a thread reads its 8 + 8 operands with FOUR ds_read_b128
+// (rows / columns t*4..+4 and 64 + t*4..+4: a 16-lane group reads 256 contiguous bytes, no bank conflict) for 128 vector
+// operations -- the first version (64 x 64 tile, 4 x 4 outputs, 8 ds_read_b32 per 32 operations) spent as many LDS cycles as
+// VALU cycles and was no faster than the fp64 kernel (88 vs 93 ms).  |.| is a free source modifier of the add.
+constexpr int LT = 128, LK = 32;
 __global__ __launch_bounds__(256) void sim_l1_f32_store_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
                                                                const float *__restrict__ e2, int64_t n2, int ld2, int dim,
                                                                float *__restrict__ out, int64_t ld_out) {
-    __shared__ float Qs[VK * (VT + 1)];
-    __shared__ float Cs[VK * (VT + 1)];
+    __shared__ __attribute__((aligned(16))) float Qs[LK * LT];
+    __shared__ __attribute__((aligned(16))) float Cs[LK * LT];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int64_t q0 = (int64_t)blockIdx.y * VT, c0 = (int64_t)blockIdx.x * VT;
-    float acc[4][4];
+    const int64_t q0 = (int64_t)blockIdx.y * LT, c0 = (int64_t)blockIdx.x * LT;
+    float acc[8][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    const int r = tid >> 2, kq = (tid & 3) * 8;
-    for (int k0 = 0; k0 < dim; k0 += VK) {
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.f;
+    // staging: thread -> (row = tid / 2, 16 k values starting at (tid % 2) * 16), stored k-major: [k][row]
+    const int r = tid >> 1, kq = (tid & 1) * 16;
+    for (int k0 = 0; k0 < dim; k0 += LK) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 16; e += 4) {
             const int k = k0 + kq + e;
-            Qs[(kq + e) * (VT + 1) + r] = (q0 + r < n1 && k < dim) ? e1[(q0 + r) * ld1 + k] : 0.f;
-            Cs[(kq + e) * (VT + 1) + r] = (c0 + r < n2 && k < dim) ? e2[(c0 + r) * ld2 + k] : 0.f;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), cv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + r < n1 && k < ld1) qv = oea::ld4(e1 + (q0 + r) * ld1 + k);          // ld % 4 == 0; pad columns are zero
+            if (c0 + r < n2 && k < ld2) cv = oea::ld4(e2 + (c0 + r) * ld2 + k);
+            if (k + 0 >= dim) { qv.x = 0.f; cv.x = 0.f; }
+            if (k + 1 >= dim) { qv.y = 0.f; cv.y = 0.f; }
+            if (k + 2 >= dim) { qv.z = 0.f; cv.z = 0.f; }
+            if (k + 3 >= dim) { qv.w = 0.f; cv.w = 0.f; }
+            Qs[(kq + e + 0) * LT + r] = qv.x; Qs[(kq + e + 1) * LT + r] = qv.y; Qs[(kq + e + 2) * LT + r] = qv.z; Qs[(kq + e + 3) * LT + r] = qv.w;
+            Cs[(kq + e + 0) * LT + r] = cv.x; Cs[(kq + e + 1) * LT + r] = cv.y; Cs[(kq + e + 2) * LT + r] = cv.z; Cs[(kq + e + 3) * LT + r] = cv.w;
         }
         __syncthreads();
-        const int kk = min(VK, dim - k0);
+        const int kk = min(LK, dim - k0);
         for (int k = 0; k < kk; ++k) {
-            float qv[4], cv[4];
+            const float4 qa = *reinterpret_cast<const float4 *>(Qs + k * LT + ty * 4);
+            const float4 qb = *reinterpret_cast<const float4 *>(Qs + k * LT + 64 + ty * 4);
+            const float4 ca = *reinterpret_cast<const float4 *>(Cs + k * LT + tx * 4);
+            const float4 cb = *reinterpret_cast<const float4 *>(Cs + k * LT + 64 + tx * 4);
+            const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
-            for (int a = 0; a < 4; ++a) qv[a] = Qs[k * (VT + 1) + ty * 4 + a];
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) cv[b] = Cs[k * (VT + 1) + tx + 16 * b];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += fabsf(qv[a] - cv[b]);
+                for (int b = 0; b < 8; ++b) acc[a][b] += fabsf(qv[a] - cv[b]);
         }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 8; ++a) {
+        const int64_t i = q0 + (a < 4 ? ty * 4 + a : 64 + ty * 4 + (a - 4));
+        if (i >= n1) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int64_t i = q0 + ty * 4 + a, j = c0 + tx + 16 * b;
-            if (i < n1 && j < n2) out[i * ld_out + j] = 1.0f - acc[a][b];
+        for (int h = 0; h < 2; ++h) {
+            const int64_t j = c0 + h * 64 + tx * 4;
+            float *o = out + i * ld_out + j;
+            if (j + 3 < n2 && (ld_out & 3) == 0) {
+                oea::st4(o, make_float4(1.0f - acc[a][h * 4 + 0], 1.0f - acc[a][h * 4 + 1], 1.0f - acc[a][h * 4 + 2], 1.0f - acc[a][h * 4 + 3]));
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (j + b < n2) o[b] = 1.0f - acc[a][h * 4 + b];
+            }
         }
+    }
 }
 
 // exact fp64 L1 distance of every (query row, candidate) pair of a candidate list: one 16-lane group per pair, lane-strided
@@ -1167,7 +1190,9 @@ __global__ void csls_apply_kernel(float *__restrict__ s, int64_t n1, int64_t n2,
 
 static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
     // enough workgroups to fill 256 CUs several times over, without splitting finer than a tile
-    int64_t want = std::max<int64_t>(1, (2048 + q_tiles - 1) / q_tiles);
+    // (OEA_RANK_WGS overrides the target count: experiments)
+    static const int64_t target = [] { const char *e = getenv("OEA_RANK_WGS"); return e ? (int64_t)atoi(e) : (int64_t)3072; }();
+    int64_t want = std::max<int64_t>(1, (target + q_tiles - 1) / q_tiles);
     int64_t chunks = std::min<int64_t>(want, c_tiles);
     *tiles_per_chunk = (int)((c_tiles + chunks - 1) / chunks);
     return (int)((c_tiles + *tiles_per_chunk - 1) / *tiles_per_chunk);
@@ -1739,7 +1764,7 @@ int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         sim_valu_store_kernel<OEA_METRIC_EUCLIDEAN><<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(
             e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
     } else if (metric == OEA_METRIC_MANHATTAN_F32) {
-        sim_l1_f32_store_kernel<<<dim3((unsigned)oea::ceil_div(n2, VT), (unsigned)oea::ceil_div(n1, VT)), 256, 0, st>>>(
+        sim_l1_f32_store_kernel<<<dim3((unsigned)oea::ceil_div(n2, LT), (unsigned)oea::ceil_div(n1, LT)), 256, 0, st>>>(
             e1, n1, ld1, e2, n2, ld2, dim, out, ld_out);
     } else {
         oea::set_error("unknown metric %d", metric);
