@@ -856,7 +856,10 @@ static int threshold_rank(double e) {
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
 static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     ListPlan p;
-    if (nq < 4096 || nc < 32768) return p;
+    // from 16,384 candidates on (round 3; 32,768 before): 30,000^2 x 100, k = 600: 2.84 ms against 3.39 ms through strips; at
+    // 15,000 candidates the two paths are even (k = 300: 1.93 / 2.09 ms, k = 1,499: 1.47 / 1.42 ms) -- gpurun_out r03q
+    static const int64_t min_nc = [] { const char *e = getenv("OEA_TOPK_LISTS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    if (nq < 4096 || nc < min_nc) return p;
     const double e = (double)k * kSample / (double)nc;
     // sample rank of the threshold: the row then holds N * Beta(r, S - r + 1) survivors, i.e. about r N / S +- a relative
     // 1 / sqrt(r); rows left with fewer than k survivors go through the batched strip fallback (threshold_rank)
@@ -912,7 +915,10 @@ struct SymPlan {
 
 static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     SymPlan p;
-    if (n < 32768) return p;
+    // from 8,192 rows on (round 3; 32,768 before): at 15,000 rows, k = 1,499 the upper-triangle sweep + list select take 1.10 ms
+    // against 1.39 ms for the N x N strip + three-read row select, at 30,000 rows, k = 600 2.29 against 3.39 ms (gpurun_out r03p)
+    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    if (n < min_n) return p;
     const double e = (double)k * kSample / (double)n;
     p.r = threshold_rank(e);
     const double frac = (double)p.r / kSample;                  // expected survivor fraction of a row
