@@ -705,17 +705,25 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         float mx = -INFINITY;
         const float *vb = list_vals + row * nseg * (int64_t)cap;
         const int32_t *cb = list_cols + row * nseg * (int64_t)cap;
+        // a thread takes `per` CONSECUTIVE list positions: one binary search for the segment of its first position, then a
+        // forward walk (round 3; a strided assignment cost a binary search -- 11 LDS reads -- for each of its 24 positions)
+        const int per = (total + SEL_THREADS - 1) / SEL_THREADS;                 // <= kPerThread (checked above)
+        const int i0 = tid * per;
+        int lo_s = 0;
+        {
+            int hi_s = nst;                                                  // s_off[lo_s] <= i0 < s_off[hi_s]
+            while (hi_s - lo_s > 1) {
+                const int mid = (lo_s + hi_s) >> 1;
+                if (s_off[mid] <= i0) lo_s = mid; else hi_s = mid;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < kPerThread; ++e) {
-            const int i = tid + e * SEL_THREADS;
+            const int i = i0 + e;
             val[e] = -INFINITY;
             col[e] = -1;
-            if (i < total) {
-                int lo_s = 0, hi_s = nst;                        // s_off[lo_s] <= i < s_off[hi_s]
-                while (hi_s - lo_s > 1) {
-                    const int mid = (lo_s + hi_s) >> 1;
-                    if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
-                }
+            if (e < per && i < total) {
+                while (s_off[lo_s + 1] <= i) ++lo_s;                         // skips empty segments; i < total = s_off[nst]
                 if (lo_s < nseg) {
                     const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
                     val[e] = vb[at];
@@ -856,9 +864,9 @@ static int threshold_rank(double e) {
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
 static ListPlan plan_lists(int64_t nq, int64_t nc, int k, size_t ws_bytes) {
     ListPlan p;
-    // from 16,384 candidates on (round 3; 32,768 before): 30,000^2 x 100, k = 600: 2.84 ms against 3.39 ms through strips; at
-    // 15,000 candidates the two paths are even (k = 300: 1.93 / 2.09 ms, k = 1,499: 1.47 / 1.42 ms) -- gpurun_out r03q
-    static const int64_t min_nc = [] { const char *e = getenv("OEA_TOPK_LISTS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    // OEA_TOPK_LISTS_MIN = 8192 / 16384 measured on random rows (gpurun_out r03q): 30,000^2 x 100, k = 600 2.84 vs 3.39 ms through
+    // strips, 15,000^2 even; not enabled: trained tables overflow the lists at these sizes (see plan_sym)
+    static const int64_t min_nc = [] { const char *e = getenv("OEA_TOPK_LISTS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
     if (nq < 4096 || nc < min_nc) return p;
     const double e = (double)k * kSample / (double)nc;
     // sample rank of the threshold: the row then holds N * Beta(r, S - r + 1) survivors, i.e. about r N / S +- a relative
@@ -915,9 +923,12 @@ struct SymPlan {
 
 static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     SymPlan p;
-    // from 8,192 rows on (round 3; 32,768 before): at 15,000 rows, k = 1,499 the upper-triangle sweep + list select take 1.10 ms
-    // against 1.39 ms for the N x N strip + three-read row select, at 30,000 rows, k = 600 2.29 against 3.39 ms (gpurun_out r03p)
-    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();
+    // Measured in round 3 (OEA_TOPK_SYM_MIN = 8192): on RANDOM unit rows the upper-triangle sweep + list select beat the N x N
+    // strip + three-read row select below 32,768 rows too (15,000 rows, k = 1,499: 1.10 vs 1.39 ms; 30,000 rows, k = 600: 2.29 vs
+    // 3.39 ms, gpurun_out r03p) -- but on TRAINED tables, which is what a refresh sees, the neighbours crowd into few candidate
+    // ranges, list segments overflow and the failed rows are redone through the strip: 1.74 vs 1.41 ms at 15,000 rows in the
+    // bench line (gpurun_out r03r).  The limit stays at 32,768.
+    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
     if (n < min_n) return p;
     const double e = (double)k * kSample / (double)n;
     p.r = threshold_rank(e);

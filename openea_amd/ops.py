@@ -373,7 +373,7 @@ def topk_inner(q, c, dim, k, id_map=None, ws_bytes=None):
     # for both kernels, few launch tails) matter more than keeping the strip in the 256 MB cache.
     # Long candidate lists (nc >= 32,768, nq >= 4,096) take the strip-free path (csrc/topk.hip): ~55 KB of workspace per
     # query row (sample strip + survivor lists); 8 GB covers 100,000 queries in one pass.
-    big = nc >= int(os.environ.get("OEA_TOPK_LISTS_MIN", "16384")) and nq >= 4096
+    big = nc >= int(os.environ.get("OEA_TOPK_LISTS_MIN", "32768")) and nq >= 4096
     ws_bytes = min(full, max((8 << 30) if big else (2 << 30), 128 * ((nc + 31) // 32 * 32) * 4)) if ws_bytes is None else min(full, ws_bytes)
     if q.data_ptr() == c.data_ptr() and nq == nc:
         # one KG's entities against themselves: the symmetric search (upper-triangle tiles only) wants its lists for ALL rows
