@@ -705,25 +705,20 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         float mx = -INFINITY;
         const float *vb = list_vals + row * nseg * (int64_t)cap;
         const int32_t *cb = list_cols + row * nseg * (int64_t)cap;
-        // a thread takes `per` CONSECUTIVE list positions: one binary search for the segment of its first position, then a
-        // forward walk (round 3; a strided assignment cost a binary search -- 11 LDS reads -- for each of its 24 positions)
-        const int per = (total + SEL_THREADS - 1) / SEL_THREADS;                 // <= kPerThread (checked above)
-        const int i0 = tid * per;
-        int lo_s = 0;
-        {
-            int hi_s = nst;                                                  // s_off[lo_s] <= i0 < s_off[hi_s]
-            while (hi_s - lo_s > 1) {
-                const int mid = (lo_s + hi_s) >> 1;
-                if (s_off[mid] <= i0) lo_s = mid; else hi_s = mid;
-            }
-        }
 #pragma unroll
         for (int e = 0; e < kPerThread; ++e) {
-            const int i = i0 + e;
+            const int i = tid + e * SEL_THREADS;
             val[e] = -INFINITY;
             col[e] = -1;
-            if (e < per && i < total) {
-                while (s_off[lo_s + 1] <= i) ++lo_s;                         // skips empty segments; i < total = s_off[nst]
+            if (i < total) {
+                // (round 3, measured and dropped: consecutive positions per thread with one binary search + a forward walk
+                //  instead of a binary search per position -- 4.41 -> 5.02 ms: the strided assignment keeps a wave's loads in
+                //  neighbouring entries of the same segments)
+                int lo_s = 0, hi_s = nst;                        // s_off[lo_s] <= i < s_off[hi_s]
+                while (hi_s - lo_s > 1) {
+                    const int mid = (lo_s + hi_s) >> 1;
+                    if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
+                }
                 if (lo_s < nseg) {
                     const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
                     val[e] = vb[at];
