@@ -236,6 +236,13 @@ size_t oea_mapping_workspace_floats(int64_t n_links, int32_t ld, int32_t dim);
 int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_norm, const int32_t *ids1,
                      const int32_t *ids2, int64_t n, float *M, float *M_acc, float alpha, float lr, int32_t opt_kind,
                      float *ent_grad, float *ent_touched, float *work, double *loss_accum, void *stream);
+/* A whole mapping epoch (approaches/mtranse.py:84-96) enqueued by ONE call: `steps` x (oea_mapping_step on the step's n links +
+ * the apply phase of the step engine with `cfg`).  batches: device int32 [steps, 2, n].  Single process only (a data-parallel
+ * job exchanges the scratch between the two halves of every step). */
+int oea_mapping_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t dim,
+                      int32_t ld, int32_t ent_l2_norm, const int32_t *batches, int32_t steps, int64_t n, float *M, float *M_acc,
+                      float alpha, float lr, int32_t opt_kind, const oea_step_cfg *cfg, void *workspace, float *work,
+                      double *mapping_loss_accum, double *step_loss_accum, void *stream);
 /* addresses of the entity gradient scratch and its touched flags inside a step workspace */
 int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, float **ent_grad,
                             float **ent_touched);

@@ -137,6 +137,8 @@ PROTOTYPES = {
     "oea_mapping_workspace_floats": (_sz, [_i64, _i32, _i32]),
     "oea_mapping_step": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp,
                                    _vp, _vp, _vp]),
+    "oea_mapping_epoch": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _f32, _f32, _i32,
+                                    C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp]),
     "oea_step_entity_scratch": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "oea_greedy_matching": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "oea_pair_dots": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),

@@ -129,4 +129,31 @@ int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_n
     return OEA_OK;
 }
 
+// A whole mapping epoch of MTransE (approaches/mtranse.py:84-96: `steps` steps on n random seed links each) enqueued by ONE
+// call: per step the fused mapping step above + the apply phase of the step engine (the optimiser on the entity rows the
+// links touched).  batches: device int32 [steps, 2, n] (ids1 row, ids2 row per step).  Driven step by step from Python the
+// epoch was bound by the host (two library calls + their argument marshalling per 50 us of kernels).
+int oea_mapping_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t dim,
+                      int32_t ld, int32_t ent_l2_norm, const int32_t *batches, int32_t steps, int64_t n, float *M, float *M_acc,
+                      float alpha, float lr, int32_t opt_kind, const oea_step_cfg *cfg, void *workspace, float *work,
+                      double *mapping_loss_accum, double *step_loss_accum, void *stream) {
+    OEA_REQUIRE(ent && rel && batches && M && cfg && workspace && work && mapping_loss_accum && step_loss_accum, "null pointer");
+    OEA_REQUIRE(steps >= 0 && n >= 0, "steps, n >= 0");
+    float *eg = nullptr, *et = nullptr;
+    int rc = oea_step_entity_scratch(workspace, n_ent, n_rel, ld, &eg, &et);
+    if (rc != OEA_OK) return rc;
+    oea_step_cfg step_cfg = *cfg;
+    for (int32_t s = 0; s < steps; ++s) {
+        const int32_t *ids1 = batches + (int64_t)s * 2 * n, *ids2 = ids1 + n;
+        rc = oea_mapping_step(ent, ld, dim, ent_l2_norm, ids1, ids2, n, M, M_acc, alpha, lr, opt_kind, eg, et, work,
+                              mapping_loss_accum, stream);
+        if (rc != OEA_OK) return rc;
+        rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, nullptr, 0, nullptr, 0, &step_cfg, workspace,
+                                   step_loss_accum, OEA_PHASE_APPLY, stream);
+        if (rc != OEA_OK) return rc;
+        ++step_cfg.opt_t;
+    }
+    return OEA_OK;
+}
+
 }  // extern "C"

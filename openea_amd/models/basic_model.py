@@ -291,7 +291,14 @@ class BasicModel:
         t = self._mapping_trainer
         loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
         opt = self.mapping_optimizer['optimizer']
-        for s in range(triple_steps):
+        if t.dist is None:            # single process: ONE C call enqueues the epoch's steps (oea_mapping_epoch)
+            t.count_steps(triple_steps)
+            self._mapping_work = ops.mapping_epoch(self.ent_embeds.var, t.ent_acc, self.rel_embeds.var, t.rel_acc, self.args.dim,
+                                                   self.ent_embeds.is_l2_norm, batches.contiguous(), self.mapping_mat,
+                                                   self._mapping_acc if opt == 'Adagrad' else None, float(self.args.alpha),
+                                                   float(self.args.learning_rate), opt, t.cfg, t.ws, loss_dev, t.loss,
+                                                   getattr(self, "_mapping_work", None))
+        for s in range(triple_steps if t.dist is not None else 0):
             self._mapping_work = ops.mapping_step(self.ent_embeds.var, self.args.dim, self.ent_embeds.is_l2_norm,
                                                   batches[s, 0], batches[s, 1], self.mapping_mat,
                                                   self._mapping_acc if opt == 'Adagrad' else None, float(self.args.alpha),

@@ -206,6 +206,20 @@ def mapping_step(ent, dim, ent_l2_norm, ids1, ids2, mapping, mapping_acc, alpha,
     return work
 
 
+def mapping_epoch(ent, ent_acc, rel, rel_acc, dim, ent_l2_norm, batches, mapping, mapping_acc, alpha, lr, optimizer, cfg, workspace,
+                  mapping_loss, step_loss, work=None):
+    """a whole MTransE mapping epoch with one call (oea_mapping_epoch): batches device int32 [steps, 2, n]."""
+    steps, _, n = batches.shape
+    need = lib().oea_mapping_workspace_floats(n, ent.shape[1], dim)
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.float32, device=ent.device)
+    check(lib().oea_mapping_epoch(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim, ent.shape[1],
+                                  int(bool(ent_l2_norm)), _p(batches), int(steps), int(n), _p(mapping), _p(mapping_acc), float(alpha),
+                                  float(lr), OPT_KIND[optimizer], C.byref(cfg), _p(workspace), _p(work), _p(mapping_loss),
+                                  _p(step_loss), _stream()))
+    return work
+
+
 def part_rows_per_rank(n_ent, world):
     return int(lib().oea_part_rows_per_rank(int(n_ent), int(world)))
 

@@ -101,6 +101,43 @@ def test_translational_models_end_to_end(kgs_small, tmp_path, name, mode, kw, ca
         assert out.count("stable alignment precision = ") == 2
 
 
+def test_mapping_epoch_call_equals_the_step_loop(kgs_small, tmp_path):
+    """oea_mapping_epoch (one call per MTransE mapping epoch) == the loop of oea_mapping_step + apply phase it replaces: same
+    mapping matrix, entity table and accumulators."""
+    from openea_amd import ops
+    from openea_amd.approaches import MTransE
+    from openea_amd.modules.base import initializers
+    res = []
+    for fused in (True, False):
+        initializers.seed(99)
+        m = MTransE()
+        m.set_args(_args("MTransE", tmp_path, dim=32, batch_size=2000, max_epoch=1))
+        m.set_kgs(kgs_small["mapping"])
+        m.init()
+        t = m._mapping_trainer
+        links = np.asarray(m.kgs.train_links, np.int32)
+        steps, n = 5, len(links) // 5
+        rng = np.random.RandomState(3)
+        picks = np.stack([rng.choice(len(links), n, replace=False) for _ in range(steps)])
+        batches = ops.to_ids(np.ascontiguousarray(links[picks].transpose(0, 2, 1)), m.mapping_mat.device)
+        loss = torch.zeros(1, dtype=torch.float64, device=m.mapping_mat.device)
+        if fused:
+            t.count_steps(steps)
+            ops.mapping_epoch(m.ent_embeds.var, t.ent_acc, m.rel_embeds.var, t.rel_acc, 32, True, batches, m.mapping_mat, m._mapping_acc,
+                              float(m.args.alpha), float(m.args.learning_rate), "Adagrad", t.cfg, t.ws, loss, t.loss)
+        else:
+            work = None
+            for s_ in range(steps):
+                work = ops.mapping_step(m.ent_embeds.var, 32, True, batches[s_, 0], batches[s_, 1], m.mapping_mat, m._mapping_acc,
+                                        float(m.args.alpha), float(m.args.learning_rate), "Adagrad", t.ws, m.ent_embeds.rows,
+                                        m.rel_embeds.rows, loss, work)
+                t.apply_scratch()
+        res.append((m.mapping_mat.cpu().numpy(), m.ent_embeds.raw(), t.ent_acc.cpu().numpy(), float(loss.item())))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)          # the entity-row gradients are fp32 atomic sums
+    assert abs(res[0][3] - res[1][3]) <= 1e-6 * abs(res[1][3])
+
+
 def test_gcn_align_epoch_matches_oracle(kgs_small, tmp_path):
     from openea_amd.approaches import GCN_Align
     from oracle import np_oracle as orc
