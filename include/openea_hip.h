@@ -438,6 +438,16 @@ int oea_rank_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, const 
 int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2,
                    int32_t ld2, int32_t dim, int32_t metric, float *out, int64_t ld_out,
                    void *stream);
+/* Fixed-point L1 pre-filter (RDGCN's hard-negative mining, approaches/rdgcn.py:75-87; scipy cdist 'cityblock' in the reference).
+ * oea_quantize_rows_u16: dst[i, k] = clamp(round((src[i, k] - lo) * inv_step), 0, 65535) for k < dim, 0 for dim <= k < ldq
+ * (ldq: a multiple of 8).  oea_l1_u16_strip: out[i, j] = -(float) sum_k |q[i, k] - c[j, k]| (integer sums; larger = nearer, the
+ * order oea_topk_rows selects; sums >= 2^24 are rounded to float).  step * sum is within dim * step of the true L1 distance when
+ * [lo, lo + 65535 step] covers the table: the caller certifies its candidate lists with that bound and re-ranks them with
+ * oea_pair_l1_f64. */
+int oea_quantize_rows_u16(const float *src, int64_t n, int32_t ld, int32_t dim, float lo, float inv_step, uint16_t *dst,
+                          int32_t ldq, void *stream);
+int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t nc, int32_t ldq, float *out, int64_t ld_out,
+                     void *stream);
 /* exact fp64 L1 distances of a candidate list: out[i, j] = sum_k |q[i, k] - table[cand[i, j], k]| (fixed summation order).
  * With OEA_METRIC_MANHATTAN_F32 + oea_topk_rows this is RDGCN's hard-negative mining (approaches/rdgcn.py:75-87) without the
  * fp64 distance of every (seed, entity) pair: fp32 ranks k + margin candidates, these are re-ranked exactly. */
@@ -581,6 +591,19 @@ int oea_highway_fwd(const float *a, const float *b, const float *p, const float 
                     float *out, void *stream);
 int oea_highway_bwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, const float *out,
                     const float *gout, int64_t n, int32_t d, float *da, float *db, float *dp, float *partials, void *stream);
+/* RDGCN's dense glue between its sparse operators, one pass each way (rdgcn.py:184-191, 250-256, 330-333):
+ * oea_sigmoid_mix_*: gate = sigmoid(p + bias), out = gate b + (1 - gate) a (highway; p = a W from a library GEMM);
+ *   bwd: da, db, dp [n, d] and partials [oea_colsum_blocks(n), d] -> d bias (summed in block order by the caller); b_relu != 0:
+ *   b is a relu's output and db is gated by b > 0 (the gradient of the relu's input).
+ * oea_relu_axpy_*: out = x + alpha relu(y); bwd: dy = alpha gout where y > 0 (dx = gout).
+ * oea_colsum_prod: partials [oea_colsum_blocks(n), d] of the column sums of x * y (d w0 of the diagonal layer). */
+int oea_sigmoid_mix_fwd(const float *a, const float *b, const float *p, const float *bias, int64_t n, int32_t d, float *out,
+                        void *stream);
+int oea_sigmoid_mix_bwd(const float *a, const float *b, const float *p, const float *bias, const float *gout, int64_t n, int32_t d,
+                        int32_t b_relu, float *da, float *db, float *dp, float *partials, void *stream);
+int oea_relu_axpy_fwd(const float *x, const float *y, float alpha, int64_t total, float *out, void *stream);
+int oea_relu_axpy_bwd(const float *y, const float *gout, float alpha, int64_t total, float *dy, void *stream);
+int oea_colsum_prod(const float *x, const float *y, int64_t n, int32_t d, float *partials, void *stream);
 int oea_bias_tanh_fwd(const float *x, const float *bias, int64_t n, int32_t d, float *y, void *stream);
 int oea_bias_tanh_bwd(const float *y, const float *gy, int64_t n, int32_t d, float *gx, float *partials, void *stream);
 

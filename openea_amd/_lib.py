@@ -152,6 +152,8 @@ PROTOTYPES = {
     "oea_rank_rows": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "oea_rank_workspace_bytes": (_sz, [_i64]),
     "oea_rank_eval": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "oea_quantize_rows_u16": (C.c_int, [_vp, _i64, _i32, _i32, C.c_float, C.c_float, _vp, _i32, _vp]),
+    "oea_l1_u16_strip": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "oea_pair_l1_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "oea_rank_eval_metrics_workspace_bytes": (_sz, [_i64]),
@@ -175,6 +177,11 @@ PROTOTYPES = {
     "oea_colsum_blocks": (_i32, [_i64]),
     "oea_highway_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_highway_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "oea_sigmoid_mix_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "oea_sigmoid_mix_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "oea_relu_axpy_fwd": (C.c_int, [_vp, _vp, C.c_float, _i64, _vp, _vp]),
+    "oea_relu_axpy_bwd": (C.c_int, [_vp, _vp, C.c_float, _i64, _vp, _vp]),
+    "oea_colsum_prod": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_bias_tanh_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_bias_tanh_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "oea_adam_dense": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _vp]),

@@ -28,7 +28,8 @@ import torch
 from .. import ops
 from ..models.basic_model import BasicModel
 from ..modules.base.optimizers import generate_optimizer
-from ..models.graph_ops import gather_few, gather_few_plan, EdgeGraph, TFAdam, sparse_attention, spmm
+from ..models.graph_ops import (diag_highway, gather_few, gather_few_plan, relu_axpy, EdgeGraph, TFAdam, sparse_attention,
+                                spmm)
 from ..modules.finding.evaluation import early_stop, test, valid
 from ..modules.load import read as rd
 
@@ -215,13 +216,14 @@ class Layer:
         p = self.p
         return self._dense_att(inlayer2 @ p['da_w'] + p['da_b'], p['da_f1'], p['da_b1'], p['da_f2'], p['da_b2'], inlayer)
 
-    def add_sparse_att_layer(self, inlayer, dual_layer, w, b):
-        """rdgcn.py:202-215: logit of an edge = conv1d(dual feature of its relation)."""
+    def add_sparse_att_layer(self, inlayer, dual_layer, w, b, relu=True):
+        """rdgcn.py:202-215: logit of an edge = conv1d(dual feature of its relation).  relu=False: the caller applies it."""
         dual_transform = (dual_layer @ w + b).reshape(-1)
         if getattr(self, "_rel_plan", None) is None:
             self._rel_plan = gather_few_plan(self.edge_rel, dual_transform.shape[0])
-        z = gather_few(dual_transform, self.edge_rel, self._rel_plan)      # backward: one wave per relation (fixed order)
-        return torch.relu(sparse_attention(self.r_graph, z, inlayer, slope=0.2))
+        z = gather_few(dual_transform, self.edge_rel, self._rel_plan)      # backward: chunked wave sums per relation (fixed order)
+        out = sparse_attention(self.r_graph, z, inlayer, slope=0.2)
+        return torch.relu(out) if relu else out
 
     def add_diag_layer(self, inlayer, w0):
         """rdgcn.py:184-191; tf.nn.dropout(inlayer, 1 - dropout) in front (in the graph: also when evaluating)."""
@@ -236,42 +238,83 @@ class Layer:
         gate = torch.sigmoid(layer1 @ kernel_gate + bias_gate)
         return gate * layer2 + (1.0 - gate) * layer1
 
+    def gcn_block(self, x, w0, kernel_gate, bias_gate):
+        """highway(x, add_diag_layer(x)) (rdgcn.py:334-337): fused (models/graph_ops.py:DiagHighwayFn) unless dropout is on"""
+        if float(getattr(self.args, "dropout", 0.0) or 0.0) > 0.0 or os.environ.get("OEA_RDGCN_FUSED", "1") == "0":
+            return self.highway(x, self.add_diag_layer(x, w0), kernel_gate, bias_gate)
+        return diag_highway(x, w0, kernel_gate, bias_gate, self.M)
+
     def forward(self):
         """rdgcn.py:317-337."""
         p = self.p
         x0 = self.primal_X_0
+        fused = os.environ.get("OEA_RDGCN_FUSED", "1") != "0"
         dual_H_1 = self.add_self_att_layer(self.compute_r(x0))
-        x1 = x0 + self.alpha * self.add_sparse_att_layer(x0, dual_H_1, p['pa1_w'], p['pa1_b'])
+        if fused:
+            x1 = relu_axpy(x0, self.add_sparse_att_layer(x0, dual_H_1, p['pa1_w'], p['pa1_b'], relu=False), self.alpha)
+        else:
+            x1 = x0 + self.alpha * self.add_sparse_att_layer(x0, dual_H_1, p['pa1_w'], p['pa1_b'])
         dual_H_2 = self.add_dual_att_layer(dual_H_1, self.compute_r(x1))
-        x2 = x0 + self.beta * self.add_sparse_att_layer(x1, dual_H_2, p['pa2_w'], p['pa2_b'])
-        g1 = self.highway(x2, self.add_diag_layer(x2, p['diag1']), p['hw1_w'], p['hw1_b'])
-        return self.highway(g1, self.add_diag_layer(g1, p['diag2']), p['hw2_w'], p['hw2_b'])
+        if fused:
+            x2 = relu_axpy(x0, self.add_sparse_att_layer(x1, dual_H_2, p['pa2_w'], p['pa2_b'], relu=False), self.beta)
+        else:
+            x2 = x0 + self.beta * self.add_sparse_att_layer(x1, dual_H_2, p['pa2_w'], p['pa2_b'])
+        g1 = self.gcn_block(x2, p['diag1'], p['hw1_w'], p['hw1_b'])
+        return self.gcn_block(g1, p['diag2'], p['hw2_w'], p['hw2_b'])
 
     def loss(self, out, negs):
         return AlignLossL1.apply(out, self.ill_dev, self.k, float(self.gamma), negs)
 
 
-def get_neg(ill_ids, output_layer, dim, k, exact_strip=False, margin=32):
+def get_neg(ill_ids, output_layer, dim, k, exact_strip=False, margin=32, prefilter=None, stats=None):
     """rdgcn.py:75-87: the k L1-nearest entities of every seed entity among ALL entities (the seed
     itself included, as in the reference) -> device int32 [t*k], ascending ids per seed.
 
-    The reference ranks fp64 `cdist` values.  Default here (round 3): fp32 L1 distances of every (seed, entity) pair rank
-    k + margin candidates per seed (4x the fp64 rate), their EXACT fp64 distances pick the k nearest (ties: smaller id) --
-    the selection the reference makes, as long as the fp32 ranking keeps the true k nearest among its first k + margin
-    (fp32 accumulation error ~1e-5 of a distance; the gap between the k-th and the (k + 32)-th neighbour is orders larger).
-    exact_strip=True: every pair in fp64 (sim_valu_store_kernel, the bits of scipy's cdist), rounded to fp32 for the select."""
+    The reference ranks fp64 `cdist` values.  Here a cheap distance of every (seed, entity) pair ranks k + margin candidates
+    per seed and their EXACT fp64 distances pick the k nearest (ties: smaller id) -- the selection the reference makes as long
+    as the cheap ranking keeps the true k nearest among its first k + margin.
+    prefilter='u16' (default, `OEA_L1_PREFILTER`): the rows on a common 16-bit grid over the table's range, integer L1
+      distances (`oea_l1_u16_strip`: a quarter of the fp32 kernel's vector instructions).  grid distance and true distance
+      differ by at most dim * step, so every list is CERTIFIED: it is accepted only if the worst candidate's lower bound lies
+      above the k-th exact distance; the seeds that fail (none on the shapes tested) go through the all-pairs fp64 path.
+    prefilter='f32': fp32 L1 distances (accumulation error ~1e-5 of a distance, not certified).
+    exact_strip=True: every pair in fp64 (sim_valu_store_kernel, the bits of scipy's cdist), rounded to fp32 for the select.
+    stats: optional dict, receives 'uncertified' (number of seeds redone)."""
     q = ops.gather_rows(output_layer, dim, ill_ids)
     n = output_layer.shape[0]
     if exact_strip or k + margin >= n:
         s = ops.sim_matrix(q, output_layer, dim, 'manhattan', pad=True)        # 1 - cityblock distance, fp64 inside
         return ops.topk_rows(s, k, nc=n).reshape(-1)
-    s = ops.sim_matrix(q, output_layer, dim, 'manhattan_f32', pad=True)
+    prefilter = prefilter or os.environ.get('OEA_L1_PREFILTER', 'u16')
+    bound = None
+    if prefilter == 'u16':
+        lo, hi = torch.aminmax(output_layer[:, :dim])
+        lo, hi = float(lo), float(hi)
+        step = max(hi - lo, 1e-30) / 65535.0
+        qt = ops.quantize_rows_u16(output_layer, dim, lo, 1.0 / step)
+        s = ops.l1_u16_strip(qt.index_select(0, ill_ids.to(torch.int64)), qt)      # minus the grid distance in steps
+        del qt
+    else:
+        s = ops.sim_matrix(q, output_layer, dim, 'manhattan_f32', pad=True)
     cand = ops.topk_rows(s, k + margin, nc=n)                                    # ascending ids
+    if prefilter == 'u16':
+        # no entity outside the list is nearer on the grid than the list's farthest member; (dim + 4) steps cover both
+        # quantisations per column (0.5 step each, + the fp32 rounding of the grid map) and the float rounding of large sums
+        worst = -torch.gather(s, 1, cand.to(torch.int64)).amin(dim=1).to(torch.float64)
+        bound = worst * step - (dim * 1.02 + 4.0) * step
     del s
     d64 = ops.pair_l1_f64(q, output_layer, dim, cand)
     order = torch.argsort(d64, dim=1, stable=True)[:, :k]                        # k smallest distances, ties -> smaller id
-    sel = torch.sort(torch.gather(cand.to(torch.int64), 1, order), dim=1).values
-    return sel.to(torch.int32).reshape(-1).contiguous()
+    sel = torch.sort(torch.gather(cand.to(torch.int64), 1, order), dim=1).values.to(torch.int32)
+    if bound is not None:
+        kth = torch.gather(d64, 1, order[:, k - 1:k]).reshape(-1)
+        redo = torch.nonzero(~(bound > kth)).reshape(-1)
+        if stats is not None:
+            stats['uncertified'] = int(redo.numel())
+        if redo.numel():
+            s = ops.sim_matrix(q.index_select(0, redo).contiguous(), output_layer, dim, 'manhattan', pad=True)
+            sel[redo] = ops.topk_rows(s, k, nc=n)
+    return sel.reshape(-1).contiguous()
 
 
 def read_word_vectors(file_path):

@@ -273,6 +273,70 @@ __global__ __launch_bounds__(256) void bias_tanh_bwd_kernel(const float *__restr
     }
 }
 
+// ---- RDGCN's highway (rdgcn.py:250-256) and residual (rdgcn.py:330-333) ------------------------------------------------
+// gate = sigmoid(p + bias), out = gate b + (1 - gate) a.  b_relu != 0: b is the output of a relu (the diagonal GCN layer,
+// rdgcn.py:184-191) and db comes out already gated by b > 0, i.e. as the gradient of the relu's INPUT.
+__global__ __launch_bounds__(256) void sigmoid_mix_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                              const float *__restrict__ p, const float *__restrict__ bias,
+                                                              int64_t n, int d, float *__restrict__ out) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gate = 1.f / (1.f + __expf(-(p[i] + bias[(int)(i % d)])));
+        out[i] = gate * b[i] + (1.f - gate) * a[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_mix_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                              const float *__restrict__ p, const float *__restrict__ bias,
+                                                              const float *__restrict__ go, int64_t n, int d, int rows_per_block,
+                                                              int b_relu, float *__restrict__ da, float *__restrict__ db,
+                                                              float *__restrict__ dp, float *__restrict__ partials) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {           // a thread owns its columns: the bias sums need no reduction
+        const float bb = bias[c];
+        float sb = 0.f;
+#pragma unroll 4
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t i = r * d + c;
+            const float gate = 1.f / (1.f + __expf(-(p[i] + bb)));
+            const float g = go[i], av = a[i], bv = b[i];
+            da[i] = g * (1.f - gate);
+            db[i] = (b_relu && !(bv > 0.f)) ? 0.f : g * gate;
+            const float dpv = g * (bv - av) * gate * (1.f - gate);
+            dp[i] = dpv;
+            sb += dpv;
+        }
+        partials[(int64_t)blockIdx.x * d + c] = sb;
+    }
+}
+
+// out = x + alpha relu(y);  backward: dy = alpha go where y > 0 (dx = go needs no kernel)
+__global__ __launch_bounds__(256) void relu_axpy_fwd_kernel(const float *__restrict__ x, const float *__restrict__ y, float alpha,
+                                                            int64_t total, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = x[i] + alpha * fmaxf(y[i], 0.f);
+}
+
+__global__ __launch_bounds__(256) void relu_axpy_bwd_kernel(const float *__restrict__ y, const float *__restrict__ go, float alpha,
+                                                            int64_t total, float *__restrict__ dy) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        dy[i] = y[i] > 0.f ? alpha * go[i] : 0.f;
+}
+
+// column sums of x * y over row blocks (d w0 of the diagonal layer: sum_rows dxs * x): partials [blocks, d]
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const float *__restrict__ x, const float *__restrict__ y, int64_t n, int d,
+                                                          int rows_per_block, float *__restrict__ partials) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int64_t r = r0; r < r1; ++r) s = fmaf(x[r * d + c], y[r * d + c], s);
+        partials[(int64_t)blockIdx.x * d + c] = s;
+    }
+}
+
 // ---- segment sums -------------------------------------------------------------------------------------------------------
 // out[s] = sum of vals[order[e]] over e in [seg_ptr[s], seg_ptr[s + 1]): one wave per segment, lanes stride over it, butterfly
 // sum -- the gradient of a gather z = src[idx] with FEW distinct indices (RDGCN: the logit of an attention edge is a
@@ -413,6 +477,55 @@ int oea_highway_bwd(const float *a, const float *b, const float *p, const float 
     const int nb = oea_colsum_blocks(n);
     const int rpb = (int)oea::ceil_div(n, nb);
     highway_bwd_kernel<<<nb, 256, 0, oea::as_stream(stream)>>>(a, b, p, gamma, beta, out, gout, n, d, rpb, da, db, dp, partials);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_sigmoid_mix_fwd(const float *a, const float *b, const float *p, const float *bias, int64_t n, int32_t d, float *out,
+                        void *stream) {
+    OEA_REQUIRE(a && b && p && bias && out && d > 0, "arguments");
+    if (n == 0) return OEA_OK;
+    sigmoid_mix_fwd_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n * d, 256), 1 << 16), 256, 0, oea::as_stream(stream)>>>(
+        a, b, p, bias, n, d, out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_sigmoid_mix_bwd(const float *a, const float *b, const float *p, const float *bias, const float *gout, int64_t n, int32_t d,
+                        int32_t b_relu, float *da, float *db, float *dp, float *partials, void *stream) {
+    OEA_REQUIRE(a && b && p && bias && gout && da && db && dp && partials && d > 0, "arguments");
+    if (n == 0) return OEA_OK;
+    const int nb = oea_colsum_blocks(n);
+    const int rpb = (int)oea::ceil_div(n, nb);
+    sigmoid_mix_bwd_kernel<<<nb, 256, 0, oea::as_stream(stream)>>>(a, b, p, bias, gout, n, d, rpb, b_relu, da, db, dp, partials);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_relu_axpy_fwd(const float *x, const float *y, float alpha, int64_t total, float *out, void *stream) {
+    OEA_REQUIRE(x && y && out && total >= 0, "arguments");
+    if (total == 0) return OEA_OK;
+    relu_axpy_fwd_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 1 << 16), 256, 0, oea::as_stream(stream)>>>(
+        x, y, alpha, total, out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_relu_axpy_bwd(const float *y, const float *gout, float alpha, int64_t total, float *dy, void *stream) {
+    OEA_REQUIRE(y && gout && dy && total >= 0, "arguments");
+    if (total == 0) return OEA_OK;
+    relu_axpy_bwd_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 1 << 16), 256, 0, oea::as_stream(stream)>>>(
+        y, gout, alpha, total, dy);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_colsum_prod(const float *x, const float *y, int64_t n, int32_t d, float *partials, void *stream) {
+    OEA_REQUIRE(x && y && partials && d > 0, "arguments");
+    if (n == 0) return OEA_OK;
+    const int nb = oea_colsum_blocks(n);
+    const int rpb = (int)oea::ceil_div(n, nb);
+    colsum_prod_kernel<<<nb, 256, 0, oea::as_stream(stream)>>>(x, y, n, d, rpb, partials);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -37,23 +37,55 @@ __global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restr
         for (int c = lane; c < dim; c += 64) y1[c] = r1[c] * i1;
         __builtin_amdgcn_wave_barrier();
         float sq = 0.f;
-        for (int c = lane; c < dim; c += 64) {           // p[c] = sum_k y1[k] M[k][c]: M rows read coalesced across lanes
-            float p = 0.f;
-            for (int k = 0; k < dim; ++k) p = fmaf(y1[k], M[(int64_t)k * dim + c], p);
-            const float d = r2[c] * i2 - p;
-            df[c] = d;
-            sq += d * d;
-            diff_out[i * ld + c] = d;
-            e1_out[i * ld + c] = y1[c];
-            oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c, 2.f * alpha * d);
+        // p[c] = sum_k y1[k] M[k][c]: M rows read coalesced across lanes, two columns per lane and eight rows per trip so
+        // that 16 loads are in flight (one load per fma was L2-latency bound: 78 us for 166 links at d = 100).
+        for (int c0 = lane; c0 < dim; c0 += 128) {
+            const int c1 = c0 + 64;
+            const bool two = c1 < dim;
+            const float *m0 = M + c0, *m1 = M + (two ? c1 : c0);
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < dim; ++k) {
+                const float y = y1[k];
+                p0 = fmaf(y, m0[(int64_t)k * dim], p0);
+                p1 = fmaf(y, m1[(int64_t)k * dim], p1);
+            }
+            const float d0 = r2[c0] * i2 - p0;
+            df[c0] = d0;
+            sq += d0 * d0;
+            diff_out[i * ld + c0] = d0;
+            e1_out[i * ld + c0] = y1[c0];
+            oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c0, 2.f * alpha * d0);
+            if (two) {
+                const float d1 = r2[c1] * i2 - p1;
+                df[c1] = d1;
+                sq += d1 * d1;
+                diff_out[i * ld + c1] = d1;
+                e1_out[i * ld + c1] = y1[c1];
+                oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c1, 2.f * alpha * d1);
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < dim; k += 64) {           // g1[k] = -2a sum_c diff[c] M[k][c]
-            const float *mr = M + (int64_t)k * dim;
-            float g = 0.f;
-            for (int c = 0; c < dim; ++c) g = fmaf(df[c], mr[c], g);
-            oea::atomic_add_f32(ent_grad + (int64_t)a * ld + k, -2.f * alpha * g);
+        // g1[k] = -2a sum_c diff[c] M[k][c]: lanes across the columns of row k (coalesced), one wave sum per row, eight rows
+        // per trip; the sums land in y1 (its values are already stored) and the atomics go out one row element per lane.
+        for (int k0 = 0; k0 < dim; k0 += 8) {
+            float part[8];
+            const float *mr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { part[u] = 0.f; mr[u] = M + (int64_t)min(k0 + u, dim - 1) * dim; }
+            for (int c = lane; c < dim; c += 64) {
+                const float d = df[c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) part[u] = fmaf(d, mr[u][c], part[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float g = oea::group_sum<64>(part[u]);
+                if (lane == 0 && k0 + u < dim) y1[k0 + u] = g;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < dim; k += 64) oea::atomic_add_f32(ent_grad + (int64_t)a * ld + k, -2.f * alpha * y1[k]);
         if (lane == 0) { ent_touched[a] = 1.f; ent_touched[b] = 1.f; }
         sq = oea::group_sum<64>(sq);
         if (lane == 0) loss_local += (double)sq;
@@ -70,6 +102,7 @@ __global__ __launch_bounds__(256) void mapping_orth_kernel(const float *__restri
         const int k = idx / dim, j = idx % dim;
         const float *a = M + (int64_t)k * dim, *b = M + (int64_t)j * dim;
         float s = 0.f;
+#pragma unroll 8
         for (int c = 0; c < dim; ++c) s = fmaf(a[c], b[c], s);
         s -= (k == j) ? 1.f : 0.f;
         orth[idx] = s;
@@ -86,9 +119,11 @@ __global__ __launch_bounds__(256) void mapping_update_kernel(const float *__rest
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= dim * dim) return;
     const int k = idx / dim, c = idx % dim;
-    float ed = 0.f;
+    float ed = 0.f;                                      // loads eight links ahead of the fma chain (was latency bound)
+#pragma unroll 8
     for (int64_t i = 0; i < n; ++i) ed = fmaf(e1[i * ld + k], diff[i * ld + c], ed);      // (E1^T Diff)[k][c]
     float om = 0.f;
+#pragma unroll 8
     for (int j = 0; j < dim; ++j) om = fmaf(orth[k * dim + j], M[(int64_t)j * dim + c], om);
     const float g = alpha * (-2.f * ed + 4.f * om);
     const float m = M[idx];

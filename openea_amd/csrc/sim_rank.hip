@@ -963,6 +963,100 @@ __global__ __launch_bounds__(256) void sim_l1_f32_store_kernel(const float *__re
     }
 }
 
+// ---- fixed-point L1 pre-filter: rows on a common u16 grid, v_sad_u16 (two columns per instruction) -----------------------
+// q = round((x - lo) * inv_step) in 0..65535 with lo / step from the table's own range: |x - (lo + q step)| <= step / 2, so
+// the grid distance  step * sum_k |qa_k - qb_k|  is within dim * step of the true L1 distance -- a bound the caller turns
+// into a certificate (approaches/rdgcn.py:get_neg): a candidate list is accepted only if no row outside it can beat its
+// k-th exact distance.  The fp32 kernel above issues 2 vector instructions per (pair, column) and runs at the full
+// unpacked issue rate (61 ms for 20,000 x 200,000 x 300); this one issues 1/2.
+__global__ __launch_bounds__(256) void quantize_rows_u16_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, float lo,
+                                                                float inv_step, uint16_t *__restrict__ dst, int ldq) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per 8 columns (one 16-byte store)
+    const int per_row = ldq >> 3;
+    if (idx >= n * per_row) return;
+    const int64_t row = idx / per_row;
+    const int k0 = (int)(idx % per_row) * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        uint32_t h[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + 2 * e + u;
+            float v = 0.f;                                                   // pad columns: the same grid point in every row
+            if (k < dim) v = fminf(fmaxf(rintf((src[row * ld + k] - lo) * inv_step), 0.f), 65535.f);
+            h[u] = (uint32_t)v;
+        }
+        w[e] = h[0] | (h[1] << 16);
+    }
+    *reinterpret_cast<uint4 *>(dst + row * ldq + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// out[i, j] = -(float) sum_k |q[i, k] - c[j, k]|  (larger = nearer, what oea_topk_rows selects).  Same tiling as
+// sim_l1_f32_store_kernel: 128 x 128 per workgroup, 8 x 8 per thread, operands k-major in LDS as dwords of two columns.
+constexpr int UK = 32;                                                       // dwords (64 columns) per staged chunk
+__global__ __launch_bounds__(256) void l1_u16_strip_kernel(const uint16_t *__restrict__ q, int64_t nq,
+                                                           const uint16_t *__restrict__ c, int64_t nc, int ldq,
+                                                           float *__restrict__ out, int64_t ld_out) {
+    __shared__ __attribute__((aligned(16))) uint32_t Qs[UK * LT];
+    __shared__ __attribute__((aligned(16))) uint32_t Cs[UK * LT];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t q0 = (int64_t)blockIdx.y * LT, c0 = (int64_t)blockIdx.x * LT;
+    uint32_t acc[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0u;
+    const int r = tid >> 1, wq = (tid & 1) * 16;                              // staging: thread -> (row, 16 dwords of the chunk)
+    const int ldw = ldq >> 1;                                                // dwords per row, a multiple of 4
+    const uint32_t *qrow = reinterpret_cast<const uint32_t *>(q) + (q0 + r) * ldw;
+    const uint32_t *crow = reinterpret_cast<const uint32_t *>(c) + (c0 + r) * ldw;
+    const bool q_in = q0 + r < nq, c_in = c0 + r < nc;
+    for (int w0 = 0; w0 < ldw; w0 += UK) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const int w = w0 + wq + e;
+            uint4 qv = make_uint4(0u, 0u, 0u, 0u), cv = make_uint4(0u, 0u, 0u, 0u);
+            if (q_in && w < ldw) qv = *reinterpret_cast<const uint4 *>(qrow + w);
+            if (c_in && w < ldw) cv = *reinterpret_cast<const uint4 *>(crow + w);
+            Qs[(wq + e + 0) * LT + r] = qv.x; Qs[(wq + e + 1) * LT + r] = qv.y; Qs[(wq + e + 2) * LT + r] = qv.z; Qs[(wq + e + 3) * LT + r] = qv.w;
+            Cs[(wq + e + 0) * LT + r] = cv.x; Cs[(wq + e + 1) * LT + r] = cv.y; Cs[(wq + e + 2) * LT + r] = cv.z; Cs[(wq + e + 3) * LT + r] = cv.w;
+        }
+        __syncthreads();
+        const int kk = min(UK, ldw - w0);
+        for (int k = 0; k < kk; ++k) {
+            const uint4 qa = *reinterpret_cast<const uint4 *>(Qs + k * LT + ty * 4);
+            const uint4 qb = *reinterpret_cast<const uint4 *>(Qs + k * LT + 64 + ty * 4);
+            const uint4 ca = *reinterpret_cast<const uint4 *>(Cs + k * LT + tx * 4);
+            const uint4 cb = *reinterpret_cast<const uint4 *>(Cs + k * LT + 64 + tx * 4);
+            const uint32_t qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const uint32_t cv[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_sad_u16(qv[a], cv[b], acc[a][b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int64_t i = q0 + (a < 4 ? ty * 4 + a : 64 + ty * 4 + (a - 4));
+        if (i >= nq) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t j = c0 + h * 64 + tx * 4;
+            float *o = out + i * ld_out + j;
+            if (j + 3 < nc && (ld_out & 3) == 0) {
+                oea::st4(o, make_float4(-(float)acc[a][h * 4 + 0], -(float)acc[a][h * 4 + 1], -(float)acc[a][h * 4 + 2], -(float)acc[a][h * 4 + 3]));
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (j + b < nc) o[b] = -(float)acc[a][h * 4 + b];
+            }
+        }
+    }
+}
+
 // exact fp64 L1 distance of every (query row, candidate) pair of a candidate list: one 16-lane group per pair, lane-strided
 // columns, butterfly sum (a fixed order: equal rows give equal sums)
 __global__ __launch_bounds__(256) void pair_l1_f64_kernel(const float *__restrict__ q, int64_t nq, int ldq,
@@ -1770,6 +1864,28 @@ int oea_sim_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         oea::set_error("unknown metric %d", metric);
         return OEA_EINVAL;
     }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_quantize_rows_u16(const float *src, int64_t n, int32_t ld, int32_t dim, float lo, float inv_step, uint16_t *dst,
+                          int32_t ldq, void *stream) {
+    OEA_REQUIRE(src && dst && dim > 0 && dim <= ld && ldq % 8 == 0 && dim <= ldq && n >= 0, "ldq: a multiple of 8 >= dim");
+    if (n == 0) return OEA_OK;
+    const int64_t items = n * (ldq / 8);
+    quantize_rows_u16_kernel<<<(unsigned)oea::ceil_div(items, 256), 256, 0, oea::as_stream(stream)>>>(src, n, ld, dim, lo, inv_step,
+                                                                                                 dst, ldq);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t nc, int32_t ldq, float *out, int64_t ld_out,
+                     void *stream) {
+    OEA_REQUIRE(q && c && out && ldq > 0 && ldq % 8 == 0 && ld_out >= nc, "ldq: a multiple of 8; ld_out >= nc");
+    OEA_REQUIRE(ldq <= 32768, "at most 32768 columns (u32 sums)");   // sums >= 2^24 round to float: <= 2^-24 relative
+    if (nq == 0 || nc == 0) return OEA_OK;
+    l1_u16_strip_kernel<<<dim3((unsigned)oea::ceil_div(nc, LT), (unsigned)oea::ceil_div(nq, LT)), 256, 0, oea::as_stream(stream)>>>(
+        q, nq, c, nc, ldq, out, ld_out);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

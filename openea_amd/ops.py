@@ -481,6 +481,24 @@ def sim_matrix(e1, e2, dim, metric='inner', pad=False):
     return out
 
 
+def quantize_rows_u16(table, dim, lo, inv_step):
+    """-> int16-typed device tensor [n, ldq] holding u16 grid points (ldq = dim rounded up to 8; pad columns 0)."""
+    n = table.shape[0]
+    ldq = (dim + 7) // 8 * 8
+    out = torch.empty((n, ldq), dtype=torch.int16, device=table.device)
+    check(lib().oea_quantize_rows_u16(_p(table), n, table.shape[1], dim, float(lo), float(inv_step), _p(out), ldq, _stream()))
+    return out
+
+
+def l1_u16_strip(qq, qc, pad=True):
+    """-> device fp32 [nq, ld]: minus the integer L1 distance of every (query, candidate) pair of two u16 row sets."""
+    nq, nc = qq.shape[0], qc.shape[0]
+    ld = (nc + 31) // 32 * 32 if pad else nc
+    out = torch.empty((nq, ld), dtype=torch.float32, device=qq.device)
+    check(lib().oea_l1_u16_strip(_p(qq), nq, _p(qc), nc, qq.shape[1], _p(out), ld, _stream()))
+    return out
+
+
 def pair_l1_f64(q, table, dim, cand):
     """exact fp64 L1 distances of the candidate lists cand int32 [nq, c] -> fp64 [nq, c]."""
     nq, c = cand.shape
@@ -834,6 +852,42 @@ def highway_bwd(a, b, p, gamma, beta, out, gout):
                                 _stream()))
     sums = parts.sum(0)
     return da, db, dp, sums[0], sums[1]
+
+
+def sigmoid_mix_fwd(a, b, p, bias):
+    out = torch.empty_like(a)
+    check(lib().oea_sigmoid_mix_fwd(_p(a), _p(b), _p(p), _p(bias), a.shape[0], a.shape[1], _p(out), _stream()))
+    return out
+
+
+def sigmoid_mix_bwd(a, b, p, bias, gout, b_relu=False):
+    """-> da, db, dp, dbias (db gated by b > 0 when b is a relu's output)"""
+    n, d = a.shape
+    da, db, dp = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    parts = torch.empty((lib().oea_colsum_blocks(n), d), dtype=torch.float32, device=a.device)
+    check(lib().oea_sigmoid_mix_bwd(_p(a), _p(b), _p(p), _p(bias), _p(gout), n, d, int(bool(b_relu)), _p(da), _p(db), _p(dp),
+                                    _p(parts), _stream()))
+    return da, db, dp, parts.sum(0)
+
+
+def relu_axpy_fwd(x, y, alpha):
+    out = torch.empty_like(x)
+    check(lib().oea_relu_axpy_fwd(_p(x), _p(y), float(alpha), x.numel(), _p(out), _stream()))
+    return out
+
+
+def relu_axpy_bwd(y, gout, alpha):
+    dy = torch.empty_like(y)
+    check(lib().oea_relu_axpy_bwd(_p(y), _p(gout), float(alpha), y.numel(), _p(dy), _stream()))
+    return dy
+
+
+def colsum_prod(x, y):
+    """column sums of x * y -> fp32 [d] (fixed order: row blocks, then blocks)"""
+    n, d = x.shape
+    parts = torch.empty((lib().oea_colsum_blocks(n), d), dtype=torch.float32, device=x.device)
+    check(lib().oea_colsum_prod(_p(x), _p(y), n, d, _p(parts), _stream()))
+    return parts.sum(0)
 
 
 def bias_tanh_fwd(x, bias):

@@ -224,6 +224,38 @@ def test_spmm_autograd(ops):
     np.testing.assert_allclose(x.grad.cpu().numpy(), a.T @ w.cpu().numpy().astype(np.float64), rtol=0, atol=1e-4)
 
 
+def test_rdgcn_fused_block_and_residual_match_the_torch_composition(ops):
+    """rdgcn.py:184-191, 250-256, 330-337: highway(x, relu(M (x * w0))) and x + alpha relu(y) as fused Functions
+    (models/graph_ops.py:DiagHighwayFn / ReluAxpyFn) against the op-by-op torch fp32 composition: outputs and the gradients
+    of every input (x enters the block three ways; the relu's gradient is folded into the mix kernel)."""
+    from openea_amd.models.graph_ops import EdgeGraph, diag_highway, relu_axpy, spmm
+    rng = np.random.RandomState(7)
+    n, d = 1300, 300
+    rows, cols, vals = _graph(rng, n, 6)
+    g = EdgeGraph(rows, cols, vals, (n, n), ops.device())
+
+    def leaf(a):
+        return torch.tensor(np.asarray(a, np.float32), device=g.dev, requires_grad=True)
+    x_h = rng.standard_normal((n, d)) * 0.5
+    w0_h, k_h, b_h = 1.0 + 0.2 * rng.standard_normal((1, d)), rng.standard_normal((d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(d)
+    y_h, wgt = rng.standard_normal((n, d)), torch.tensor(rng.standard_normal((n, d)).astype(np.float32), device=g.dev)
+    res = []
+    for fused in (True, False):
+        x, w0, k, b, y = leaf(x_h), leaf(w0_h), leaf(k_h), leaf(b_h), leaf(y_h)
+        if fused:
+            x1 = relu_axpy(x, y, 0.1)
+            out = diag_highway(x1, w0, k, b, g)
+        else:
+            x1 = x + 0.1 * torch.relu(y)
+            gate = torch.sigmoid(x1 @ k + b)
+            out = gate * torch.relu(spmm(g, x1 * w0)) + (1.0 - gate) * x1
+        (out * wgt).sum().backward()
+        res.append([t.detach().cpu().numpy() for t in (out, x.grad, w0.grad, k.grad, b.grad, y.grad)])
+    for name, a, r in zip(("out", "dx", "dw0", "dW", "dbias", "dy"), *res):
+        assert a.shape == r.shape, name
+        assert np.abs(a - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0) * (30 if name in ("dw0", "dW", "dbias") else 1), (name, np.abs(a - r).max())
+
+
 def test_tf_adam(ops):
     from openea_amd.models.graph_ops import TFAdam
     from oracle import np_oracle as orc
@@ -360,11 +392,12 @@ def test_rdgcn_word_vector_initialisation(ops, tmp_path):
     assert np.abs(m.gcn_model.primal_X_0.detach().cpu().numpy() - x0).max() > 0      # the input layer is trained
 
 
-@pytest.mark.parametrize("exact_strip", [False, True])
-def test_rdgcn_hard_negative_mining(ops, exact_strip):
-    """get_neg (rdgcn.py:75-87): k L1-nearest entities of each seed entity, as a set, vs scipy -- the default path (fp32
-    pre-filter of k + 32 candidates, exact fp64 re-rank) and the all-pairs fp64 strip; clustered rows (near-equal distances)
-    and exact duplicates included."""
+@pytest.mark.parametrize("prefilter,exact_strip", [("u16", False), ("f32", False), (None, True)])
+def test_rdgcn_hard_negative_mining(ops, prefilter, exact_strip):
+    """get_neg (rdgcn.py:75-87): k L1-nearest entities of each seed entity, as a set, vs scipy -- the default path (16-bit
+    grid pre-filter of k + 32 candidates with its certificate, exact fp64 re-rank; the seeds inside the tight cluster cannot be
+    certified and take the all-pairs path), the fp32 pre-filter, and the all-pairs fp64 strip; clustered rows (near-equal
+    distances) and exact duplicates included."""
     from scipy.spatial.distance import cdist
     from openea_amd.approaches.rdgcn import get_neg
     rng = np.random.RandomState(4)
@@ -373,14 +406,19 @@ def test_rdgcn_hard_negative_mining(ops, exact_strip):
     emb[2000:2004] = emb[7]                                                                     # exact duplicates of row 7
     seeds = np.concatenate([rng.choice(3000, 60, replace=False), [7, 1000, 1100, 2001]]).astype(np.int32)
     k = 25
-    out = get_neg(ops.to_ids(seeds), ops.to_table(emb), 40, k, exact_strip=exact_strip).cpu().numpy().reshape(len(seeds), k)
+    stats = {}
+    out = get_neg(ops.to_ids(seeds), ops.to_table(emb), 40, k, exact_strip=exact_strip, prefilter=prefilter, stats=stats)
+    out = out.cpu().numpy().reshape(len(seeds), k)
+    if prefilter == "u16":
+        n_cluster = int(((seeds >= 1000) & (seeds < 1400)).sum())
+        assert n_cluster <= stats["uncertified"] < len(seeds) // 2, stats      # the cluster seeds fail, most others pass
     d = cdist(emb[seeds].astype(np.float64), emb.astype(np.float64), metric="cityblock")
     for i in range(len(seeds)):
         kth = np.sort(d[i])[k - 1]
         sure = set(np.flatnonzero(d[i] < kth - 1e-4 * max(kth, 1.0)).tolist())          # everything clearly inside the k nearest
         allowed = set(np.flatnonzero(d[i] <= kth + (1e-4 * max(kth, 1.0) if exact_strip else 0.0)).tolist())
         got = set(out[i].tolist())
-        assert len(got) == k and sure <= got <= allowed, (i, exact_strip)
+        assert len(got) == k and sure <= got <= allowed, (i, prefilter, exact_strip)
 
 
 @pytest.mark.parametrize("name,kw", [("AliNet", dict(layer_dims=[48, 32, 24], batch_size=600, truncated_epsilon=0.9, dropout=0.8, attn_grouping="row")),
