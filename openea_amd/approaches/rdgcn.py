@@ -125,6 +125,37 @@ class AlignLossL1(torch.autograd.Function):
         return grad * dloss, None, None, None, None
 
 
+class AlignLossL1Rows(torch.autograd.Function):
+    """get_loss without atomics: the hinge kernel writes one signed coefficient per pair, every output row then adds its own
+    pairs in a fixed order (oea_align_loss_l1_coef + oea_pair_grad_rows; the row lists are built once per redraw of the
+    negatives, every 10 epochs) -- reproducible bits."""
+
+    @staticmethod
+    def forward(ctx, out, ill, k, gamma, negs, pairs):
+        out = out.contiguous()
+        loss = torch.zeros(1, dtype=torch.float64, device=out.device)
+        coef = ops.align_loss_l1_coef(out, out.shape[1], ill, k, gamma, negs[0], negs[1], negs[2], negs[3], loss)
+        ctx.pairs = pairs
+        ctx.save_for_backward(out, coef)
+        return loss.to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        out, coef = ctx.saved_tensors
+        grad = ops.pair_grad_rows(out, out.shape[1], *ctx.pairs, coef, gscale=dloss.reshape(1).contiguous(), norm=1)
+        return grad, None, None, None, None, None
+
+
+def align_pair_rows(ill, k, negs, n_rows):
+    """the endpoints of the hinge's pairs grouped by row: pair a < t = link a, pair t + a 2k + i = negative i of link a
+    (i < k: (neg_left, neg_right), i >= k: (neg2_left, neg2_right)) -- the coefficient layout of oea_align_loss_l1_coef"""
+    nl, nr, n2l, n2r = negs
+    t = ill.shape[0]
+    neg_pairs = torch.stack([torch.stack([nl.view(t, k), n2l.view(t, k)], 1).reshape(-1),
+                             torch.stack([nr.view(t, k), n2r.view(t, k)], 1).reshape(-1)], 1)
+    return ops.pair_rows_csr(torch.cat([ill.to(neg_pairs.dtype), neg_pairs]), n_rows)
+
+
 class Layer:
     """rdgcn.py:162-338."""
 
@@ -263,7 +294,15 @@ class Layer:
         return self.gcn_block(g1, p['diag2'], p['hw2_w'], p['hw2_b'])
 
     def loss(self, out, negs):
-        return AlignLossL1.apply(out, self.ill_dev, self.k, float(self.gamma), negs)
+        """get_loss (rdgcn.py:293-315).  Default: row-grouped gradient (no atomics); `OEA_RDGCN_LOSS=atomic`: one kernel with
+        fp32 atomics (bits depend on the arrival order)."""
+        if os.environ.get("OEA_RDGCN_LOSS", "rows") == "atomic":
+            return AlignLossL1.apply(out, self.ill_dev, self.k, float(self.gamma), negs)
+        key = tuple((x.data_ptr(), x._version) for x in negs)
+        if getattr(self, "_pairs_key", None) != key:
+            self._pairs = align_pair_rows(self.ill_dev, self.k, negs, out.shape[0])
+            self._pairs_key, self._pairs_keep = key, negs
+        return AlignLossL1Rows.apply(out, self.ill_dev, self.k, float(self.gamma), negs, self._pairs)
 
 
 def get_neg(ill_ids, output_layer, dim, k, exact_strip=False, margin=32, prefilter=None, stats=None):

@@ -16,15 +16,26 @@
 namespace {
 
 // workspace: [e1: n x ld][diff: n x ld][orth: d x d][m_new: d x d]
+// M_LDS: the workgroup first copies M into LDS (d <= 120: 57.6 KB + the per-wave rows; every element is then read 2 x 4 times
+// at LDS latency instead of L2 latency -- 166 links at d = 100: 78 us with one global load per fma, 23.5 us with 16 loads in
+// flight, M_LDS below that)
+template <bool M_LDS>
 __global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restrict__ ent, int ld, int dim, int l2norm,
                                                             const int32_t *__restrict__ ids1, const int32_t *__restrict__ ids2,
-                                                            int64_t n, const float *__restrict__ M, float alpha,
+                                                            int64_t n, const float *__restrict__ Mg, float alpha,
                                                             float *__restrict__ ent_grad, float *__restrict__ ent_touched,
                                                             float *__restrict__ e1_out, float *__restrict__ diff_out,
                                                             double *__restrict__ loss_accum) {
-    extern __shared__ float lds[];                       // per wave: y1 [dim], diff [dim]
+    extern __shared__ float lds[];                       // per wave: y1 [dim], diff [dim]; then M [dim x dim] if M_LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *y1 = lds + wave * 2 * dim, *df = y1 + dim;
+    const float *M = Mg;
+    if (M_LDS) {
+        float *Ms = lds + 8 * dim;
+        for (int i = threadIdx.x; i < dim * dim; i += 256) Ms[i] = Mg[i];
+        __syncthreads();
+        M = Ms;
+    }
     double loss_local = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
         const int a = ids1[i], b = ids2[i];
@@ -153,8 +164,11 @@ int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_n
     OEA_REQUIRE(dim <= 2000, "dim <= 2000 (per-wave rows live in the default 64 KB of LDS)");
     hipStream_t st = oea::as_stream(stream);
     float *e1 = work, *diff = e1 + n * ld, *orth = diff + n * ld, *m_new = orth + (int64_t)dim * dim;
-    if (n > 0)
-        mapping_links_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n, 4), 4096), 256, sizeof(float) * 8 * dim, st>>>(
+    if (n > 0 && dim <= 120)
+        mapping_links_kernel<true><<<(unsigned)std::min<int64_t>(oea::ceil_div(n, 4), 1024), 256, sizeof(float) * (8 * dim + dim * dim), st>>>(
+            ent, ld, dim, ent_l2_norm, ids1, ids2, n, M, alpha, ent_grad, ent_touched, e1, diff, loss_accum);
+    else if (n > 0)
+        mapping_links_kernel<false><<<(unsigned)std::min<int64_t>(oea::ceil_div(n, 4), 4096), 256, sizeof(float) * 8 * dim, st>>>(
             ent, ld, dim, ent_l2_norm, ids1, ids2, n, M, alpha, ent_grad, ent_touched, e1, diff, loss_accum);
     const unsigned nb = (unsigned)oea::ceil_div((int64_t)dim * dim, 256);
     mapping_orth_kernel<<<nb, 256, 0, st>>>(M, dim, alpha, orth, loss_accum);
