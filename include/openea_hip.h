@@ -591,6 +591,15 @@ int oea_highway_fwd(const float *a, const float *b, const float *p, const float 
                     float *out, void *stream);
 int oea_highway_bwd(const float *a, const float *b, const float *p, const float *gamma, const float *beta, const float *out,
                     const float *gout, int64_t n, int32_t d, float *da, float *db, float *dp, float *partials, void *stream);
+/* out [k1, ld_out] = A^T B for row-major A [m, lda] (k1 columns used) and B [m, ldb] (k2 columns): the weight gradient
+ * dW = X^T dY of the GNN approaches' dense layers (alinet.py:574-582, rdgcn.py:250-256: m = #entities, k <= 500) on
+ * v_mfma_f32_32x32x2_f32 (exact fp32 products, fixed summation order: slab order inside a row chunk, then chunk order).
+ * k1, k2, lda, ldb multiples of 4, operands 16-byte aligned.  workspace: oea_gemm_tn_workspace_floats(m, k1, k2) floats
+ * (partial tiles of the row chunks; 0 when one chunk suffices). */
+size_t oea_gemm_tn_workspace_floats(int64_t m, int32_t k1, int32_t k2);
+int oea_gemm_tn_f32(const float *a, int32_t lda, int32_t k1, const float *b, int32_t ldb, int32_t k2, int64_t m, float *out,
+                    int32_t ld_out, float *workspace, void *stream);
+
 /* RDGCN's dense glue between its sparse operators, one pass each way (rdgcn.py:184-191, 250-256, 330-333):
  * oea_sigmoid_mix_*: gate = sigmoid(p + bias), out = gate b + (1 - gate) a (highway; p = a W from a library GEMM);
  *   bwd: da, db, dp [n, d] and partials [oea_colsum_blocks(n), d] -> d bias (summed in block order by the caller); b_relu != 0:

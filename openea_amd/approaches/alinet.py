@@ -27,7 +27,7 @@ import torch
 from .. import ops
 from ..models.basic_model import BasicModel
 from ..modules.base.optimizers import generate_optimizer
-from ..models.graph_ops import EdgeGraph, TFAdam, bias_tanh, concat_l2n, highway_gate, pair_loss, sparse_attention, spmm
+from ..models.graph_ops import EdgeGraph, TFAdam, bias_tanh, concat_l2n, dense, highway_gate, pair_loss, sparse_attention, spmm
 from ..modules.finding.evaluation import early_stop
 from ..modules.load import read as rd
 
@@ -347,7 +347,7 @@ class GraphConvolution:
 
     def call(self, inputs):
         wf, bw = self.bn.fold(self.kernel)
-        return bias_tanh(spmm(self.graph, torch.addmm(bw, inputs, wf)), self.bias)      # csrc/gnn_fused.hip
+        return bias_tanh(spmm(self.graph, dense(inputs, wf, bw)), self.bias)      # csrc/gnn_fused.hip
 
     def params(self):
         return self.bn.params() + [self.kernel, self.bias]
@@ -372,7 +372,7 @@ class AliNetGraphAttentionLayer:
             # leaves them where they are: m = v = 0).  The two [E, d] x [d, d] products, the row-wise quadratic forms and
             # their backward passes are therefore skipped; outputs and every gradient are bit-identical with computing them.
             wf, bw = self.bn.fold(self.kernel)
-            mapped = torch.addmm(bw, inputs, wf)                     # BN(inputs) @ kernel
+            mapped = dense(inputs, wf, bw)                     # BN(inputs) @ kernel
             z = torch.zeros(g.nnz, dtype=torch.float32, device=mapped.device)
             return torch.tanh(sparse_attention(g, z, mapped, slope=0.2))
         x = self.bn(inputs)
@@ -402,7 +402,7 @@ class HighwayLayer:
             gate = torch.relu(_tf_dropout(torch.tanh(a @ self.weight), self.keep_prob))
             return torch.tanh(b * (1 - gate) + a * gate)
         wf, bw = self.bn.fold(self.weight)
-        p = torch.addmm(bw, input1, wf)                              # BN(input1) @ W
+        p = dense(input1, wf, bw)                              # BN(input1) @ W
         return highway_gate(input1, input2, p, self.bn.scale(), self.bn.beta)      # csrc/gnn_fused.hip, one pass each way
 
     def params(self):
@@ -513,18 +513,20 @@ class AliNet(BasicModel):
         """alinet.py:835-840: l2n(concat(l2n(out_0), ..., l2n(init)))."""
         return concat_l2n(outs + [self.init_embedding])              # csrc/gnn_fused.hip: one pass each way
 
-    def compute_loss(self, emb, pos_links, neg_links, neg_valid=None):
+    def compute_loss(self, emb, pos_links, neg_links, neg_valid=None, side=None):
         """alinet.py:828-850.  neg_valid: 0/1 weights of the drawn pairs (device sampler: duplicates and
         supervised pairs carry 0 instead of being removed from the list)."""
         dim = sum(self.args.layer_dims)
-        return pair_loss(emb, dim, pos_links, neg_links, neg_valid, self.args.neg_margin, self.args.neg_margin_balance)
+        return pair_loss(emb, dim, pos_links, neg_links, neg_valid, self.args.neg_margin, self.args.neg_margin_balance, side=side)
+
+    def _rel_loss_rows(self, h, t):
+        d = h.shape[1]
+        r = (h - t).reshape(-1, self.rel_win_size, d).mean(1, keepdim=True).repeat(1, self.rel_win_size, 1).reshape(-1, d)
+        return ((h - t - l2n(r)) ** 2).sum() * self.args.rel_param
 
     def compute_rel_loss(self, emb, hs, ts):
         """alinet.py:852-866."""
-        h, t = emb[hs], emb[ts]
-        d = emb.shape[1]
-        r = (h - t).reshape(-1, self.rel_win_size, d).mean(1, keepdim=True).repeat(1, self.rel_win_size, 1).reshape(-1, d)
-        return ((h - t - l2n(r)) ** 2).sum() * self.args.rel_param
+        return self._rel_loss_rows(emb[hs], emb[ts])
 
     # ---- batches (alinet.py:983-1017) ---------------------------------------------------------------
     def generate_input_batch(self, batch_size, neighbors1=None, neighbors2=None):
@@ -695,9 +697,12 @@ class AliNet(BasicModel):
         outs = self._forward()
         emb = self._concat_train(outs)
         dev = self.dev
-        loss = self.compute_loss(emb, torch.as_tensor(pos_links, device=dev), torch.as_tensor(neg_links, device=dev), neg_valid)
-        if hs is not None:
-            loss = loss + self.compute_rel_loss(emb, torch.as_tensor(hs, device=dev), torch.as_tensor(ts, device=dev))
+        side = None
+        if hs is not None:                                            # relation loss on the gathered head / tail rows
+            n_h = len(hs)
+            idx = torch.cat([torch.as_tensor(hs, device=dev), torch.as_tensor(ts, device=dev)]).to(torch.int64)
+            side = (idx, lambda rows: self._rel_loss_rows(rows[:n_h], rows[n_h:]))
+        loss = self.compute_loss(emb, torch.as_tensor(pos_links, device=dev), torch.as_tensor(neg_links, device=dev), neg_valid, side=side)
         loss.backward()
         self.optimizer.step()
         return loss

@@ -174,20 +174,39 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float *__restr
                 }
                 loaded = true;
             }
-            while (live) {                                          // the active slots of this batch of 64, in slot order
-                const int q = __ffsll((long long)live) - 1;
-                live &= live - 1;
-                const float cq = (L1 ? 1.f : 2.f) * __shfl(c, q, 64);
-                const float *orow = emb + (int64_t)__shfl(o, q, 64) * ld;
+            // the active slots of this batch of 64, in slot order, FOUR per trip: all their rows are requested before the
+            // first is used (one slot per trip waited a full L2 round trip per pair: a seed row of RDGCN has 251 pairs --
+            // 11.6 ms for the 100K loss); an empty place points at the row itself with coefficient 0, which adds exact zeros
+            while (live) {
+                float cq[4];
+                const float *orow[4];
 #pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const int col = it * W + lane;
-                    if (col < dim) {
-                        const float df = me[it] - orow[col];
-                        if (L1) acc[it] += df > 0.f ? cq : (df < 0.f ? -cq : 0.f);
-                        else acc[it] = fmaf(cq, df, acc[it]);
+                for (int u = 0; u < 4; ++u) {
+                    cq[u] = 0.f;
+                    orow[u] = emb + row * ld;
+                    if (live) {
+                        const int q = __ffsll((long long)live) - 1;
+                        live &= live - 1;
+                        cq[u] = (L1 ? 1.f : 2.f) * __shfl(c, q, 64);
+                        orow[u] = emb + (int64_t)__shfl(o, q, 64) * ld;
                     }
                 }
+                float ov[4][IT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int col = it * W + lane;
+                        ov[u][it] = col < dim ? orow[u][col] : 0.f;
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const float df = me[it] - ov[u][it];
+                        if (L1) acc[it] += df > 0.f ? cq[u] : (df < 0.f ? -cq[u] : 0.f);
+                        else acc[it] = fmaf(cq[u], df, acc[it]);
+                    }
             }
         }
     }
@@ -358,6 +377,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restric
     do {                                                                 \
         if ((cols) <= 128) { CALL(2); }                                  \
         else if ((cols) <= 256) { CALL(4); }                             \
+        else if ((cols) <= 320) { CALL(5); }                             \
         else if ((cols) <= 512) { CALL(8); }                             \
         else if ((cols) <= 1280) { CALL(20); }                           \
         else { oea::set_error("%d columns > 1280 unsupported", (int)(cols)); return OEA_EUNSUPPORTED; } \

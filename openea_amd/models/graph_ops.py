@@ -302,13 +302,25 @@ class PairLossFn(torch.autograd.Function):
     (one stable device sort per batch), one wave per row adds its active pairs in slot order -- no atomics."""
 
     @staticmethod
-    def forward(ctx, emb, dim, pos, neg, weight, margin, balance):
+    def forward(ctx, emb, dim, pos, neg, weight, margin, balance, side=None):
         emb = emb.contiguous()
         pairs = torch.cat([pos[:, :2], neg[:, :2]]).to(torch.int32).contiguous()
         terms, coef = ops.pair_loss_l2_fwd(emb, dim, pairs, pos.shape[0], weight, margin, balance)
         ctx.dim = dim
         ctx.save_for_backward(emb, pairs, coef)
-        return terms.sum()
+        loss = terms.sum()
+        ctx.side = None
+        if side is not None:
+            # a second loss on FEW rows of emb (AliNet's relation loss, alinet.py:852-866: 2 x 20,000 of 200,000 rows of width
+            # 1,200): evaluated on a gathered copy, its row gradients are added into the dense gradient this Function returns
+            # anyway -- as two more autograd branches each cost a zero-filled [E, d] tensor, a scatter and a full-size add
+            idx, fn = side
+            rows = emb.index_select(0, idx).detach().requires_grad_(True)
+            with torch.enable_grad():
+                side_loss = fn(rows)
+            ctx.side = (idx, rows, side_loss)
+            loss = loss + side_loss.detach()
+        return loss
 
     @staticmethod
     def backward(ctx, gloss):
@@ -316,7 +328,12 @@ class PairLossFn(torch.autograd.Function):
         rowptr, other, slot_pair = ops.pair_rows_csr(pairs, emb.shape[0])
         g = gloss.to(torch.float32).reshape(1).contiguous()
         grad = ops.pair_grad_rows(emb, ctx.dim, rowptr, other, slot_pair, coef, g, norm=2)
-        return grad, None, None, None, None, None, None
+        if ctx.side is not None:
+            idx, rows, side_loss = ctx.side
+            (g_rows,) = torch.autograd.grad(side_loss, rows)
+            grad.index_put_((idx,), g_rows * g, accumulate=True)      # duplicates summed in sorted order (deterministic)
+            ctx.side = None
+        return grad, None, None, None, None, None, None, None
 
 
 class HighwayFn(torch.autograd.Function):
@@ -351,6 +368,29 @@ class BiasTanhFn(torch.autograd.Function):
         return ops.bias_tanh_bwd(y, gy.contiguous())
 
 
+class DenseFn(torch.autograd.Function):
+    """y = x W (+ bias row) for a tall x [E, d_in]: forward and dx on the library's NN / NT kernels (85-105 TFLOP/s at these
+    shapes), the weight gradient dW = x^T dy on oea_gemm_tn_f32 (the library's TN kernels run it at 44-57)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, w) if bias is not None else x @ w
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+        dw = ops.gemm_tn(x.contiguous(), dy) if ctx.needs_input_grad[1] else None
+        return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
+def dense(x, w, bias=None):
+    return DenseFn.apply(x, w, bias)
+
+
 class DiagHighwayFn(torch.autograd.Function):
     """One GCN block of RDGCN (rdgcn.py:184-191, 250-256, 334-337):  h = relu(M (x * w0)),  gate = sigmoid(x W + b),
     out = gate h + (1 - gate) x.  The aggregate carries the relu, the gate / mix and their gradients are one kernel each way
@@ -373,7 +413,7 @@ class DiagHighwayFn(torch.autograd.Function):
         dxs = ctx.graph.bwd.apply(dh_pre, x.shape[1])
         dx = torch.addmm(da, dp, kernel_gate.t())
         dx.addcmul_(dxs, w0)
-        return dx, ops.colsum_prod(dxs, x).reshape(w0.shape), x.t() @ dp, dbias, None
+        return dx, ops.colsum_prod(dxs, x).reshape(w0.shape), ops.gemm_tn(x, dp), dbias, None
 
 
 class ReluAxpyFn(torch.autograd.Function):
@@ -445,8 +485,9 @@ def concat_l2n(xs):
     return ConcatL2NormFn.apply(*xs)
 
 
-def pair_loss(emb, dim, pos, neg, weight, margin, balance):
-    return PairLossFn.apply(emb, dim, pos, neg, weight, margin, balance)
+def pair_loss(emb, dim, pos, neg, weight, margin, balance, side=None):
+    """side = (idx int64 [m], fn): + fn(emb[idx]), a loss on few rows whose gradient joins the pair loss's dense one"""
+    return PairLossFn.apply(emb, dim, pos, neg, weight, margin, balance, side)
 
 
 def highway_gate(a, b, p, gamma, beta):

@@ -854,6 +854,20 @@ def highway_bwd(a, b, p, gamma, beta, out, gout):
     return da, db, dp, sums[0], sums[1]
 
 
+def gemm_tn(a, b):
+    """a^T @ b for two tall row-major fp32 matrices with the same number of rows -> [a.shape[1], b.shape[1]]
+    (oea_gemm_tn_f32; shapes it does not take -- widths not multiples of 4 -- go to the library)."""
+    m, k1 = a.shape
+    k2 = b.shape[1]
+    if k1 % 4 or k2 % 4 or not (a.is_contiguous() and b.is_contiguous()) or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return a.t() @ b
+    out = torch.empty((k1, k2), dtype=torch.float32, device=a.device)
+    n_ws = lib().oea_gemm_tn_workspace_floats(m, k1, k2)
+    ws = torch.empty(n_ws, dtype=torch.float32, device=a.device) if n_ws else None
+    check(lib().oea_gemm_tn_f32(_p(a), k1, k1, _p(b), k2, k2, m, _p(out), k2, _p(ws), _stream()))
+    return out
+
+
 def sigmoid_mix_fwd(a, b, p, bias):
     out = torch.empty_like(a)
     check(lib().oea_sigmoid_mix_fwd(_p(a), _p(b), _p(p), _p(bias), a.shape[0], a.shape[1], _p(out), _stream()))

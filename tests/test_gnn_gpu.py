@@ -149,6 +149,39 @@ def test_fused_pair_loss_equals_torch(ops, d):
     assert float((hinge > 0).float().mean()) > 0.05 and float((hinge == 0).float().mean()) > 0.05
 
 
+def test_pair_loss_with_a_side_loss_on_few_rows_equals_two_autograd_branches(ops):
+    """alinet.py:852-866 + :1055-1062: the relation loss reads few rows of the training embedding; evaluated on a gathered
+    copy inside PairLossFn (its row gradients join the dense gradient of the pair loss) it gives the loss and gradient of
+    `pair loss + rel loss` taken as two autograd branches; duplicates among the gathered rows included; two runs identical."""
+    from openea_amd.models.graph_ops import pair_loss
+    dev = ops.device()
+    rng = np.random.RandomState(3)
+    n, d, n_h, win = 800, 96, 150, 3
+    e = rng.standard_normal((n, d)).astype(np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    pos = torch.tensor(rng.randint(0, n, (100, 2)), device=dev)
+    neg = torch.tensor(rng.randint(0, n, (700, 2)), device=dev)
+    hs = torch.tensor(rng.randint(0, 60, n_h), device=dev)                     # few distinct rows: many duplicates
+    ts = torch.tensor(rng.randint(0, n, n_h), device=dev)
+
+    def rel(h, t):
+        r = (h - t).reshape(-1, win, d).mean(1, keepdim=True).repeat(1, win, 1).reshape(-1, d)
+        r = r * torch.rsqrt(torch.clamp((r * r).sum(1, keepdim=True), min=1e-12))
+        return ((h - t - r) ** 2).sum() * 0.01
+    out = []
+    for mode in ("side", "side", "branches"):
+        emb = torch.tensor(e, device=dev, requires_grad=True)
+        if mode == "side":
+            loss = pair_loss(emb, d, pos, neg, None, 1.5, 0.1, side=(torch.cat([hs, ts]), lambda rows: rel(rows[:n_h], rows[n_h:])))
+        else:
+            loss = pair_loss(emb, d, pos, neg, None, 1.5, 0.1) + rel(emb[hs], emb[ts])
+        (loss * 1.3).backward()
+        out.append((float(loss.detach()), emb.grad.cpu().numpy()))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert abs(out[0][0] - out[2][0]) <= 1e-6 * abs(out[2][0])
+    np.testing.assert_allclose(out[0][1], out[2][1], rtol=1e-5, atol=1e-6)
+
+
 def test_fused_highway_and_bias_tanh_equal_torch(ops):
     """alinet.py:597-622 / :583-590: gate + output and bias + tanh, forward and every gradient (incl. the BatchNorm affine's
     column sums) against the torch composition."""

@@ -943,3 +943,33 @@ def test_csls_means_one_sweep_bit_exact(ops, case):
     r_ref = ops.row_topk_mean(ops.sim_matrix(t1, t2, d, "inner"), k)
     c_ref = ops.row_topk_mean(ops.sim_matrix(t2, t1, d, "inner"), k)
     assert torch.equal(r, r_ref) and torch.equal(c, c_ref)
+
+
+@pytest.mark.parametrize("m,k1,k2", [(5000, 300, 300), (70001, 500, 400), (33, 8, 12), (4097, 400, 300), (20000, 128, 64), (1000, 6, 8)])
+def test_gemm_tn_matches_float64(ops, m, k1, k2):
+    """dW = X^T dY of the GNN dense layers (alinet.py:574-582, rdgcn.py:250-256) on the fp32 matrix cores with the row
+    reduction split into chunks: against a float64 product (fp32 accumulation error only), two runs bit-identical, and the
+    autograd wrapper's three gradients against torch's."""
+    import torch
+    from openea_amd.models.graph_ops import dense
+    dev = ops.device()
+    g = torch.Generator(device=dev).manual_seed(m)
+    a = torch.randn(m, k1, device=dev, generator=g)
+    b = torch.randn(m, k2, device=dev, generator=g)
+    got = ops.gemm_tn(a, b)
+    assert torch.equal(got, ops.gemm_tn(a, b))
+    ref = a.double().t() @ b.double()
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2e-6 * (m ** 0.5) * 4 + 1e-5, err
+    lib_err = ((a.t() @ b).double() - ref).abs().max().item()
+    assert err <= 10 * lib_err + 1e-4, (err, lib_err)                   # the same order as the library's own rounding
+    x = a.clone().requires_grad_(True)
+    w = (torch.randn(k1, k2, device=dev, generator=g) * 0.1).requires_grad_(True)
+    bias = torch.randn(k2, device=dev, generator=g).requires_grad_(True)
+    (dense(x, w, bias) * b).sum().backward()
+    x2, w2, bias2 = a.clone().requires_grad_(True), w.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    (torch.addmm(bias2, x2, w2) * b).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-5)
+    assert (w.grad - w2.grad).abs().max().item() <= 1e-5 * max(w2.grad.abs().max().item(), 1.0) * 8
+    assert torch.allclose(bias.grad, bias2.grad, rtol=1e-4, atol=1e-3)
