@@ -423,6 +423,71 @@ __global__ __launch_bounds__(256) void align_loss_l1_kernel(const float *__restr
     }
 }
 
+// The coefficient pass for SMALL k (GCN-Align's 5): one G-lane group per seed link instead of one workgroup -- at
+// t = 4,500 links x 10 negatives the workgroup-per-link kernel spent 43 us on two barriers and an LDS counter per link
+// (the whole GCN-Align epoch is 0.22 ms).  A group holds x_l - x_r, walks the link's 2k negatives (both rows of a negative
+// pair are requested before the first is used), writes their coefficients and the link's own; no LDS, no barrier inside
+// the loop; the loss leaves through one double atomic per workgroup.
+template <int G, int IT>
+__global__ __launch_bounds__(256) void align_coef_groups_kernel(const float *__restrict__ emb, int dim, int ld,
+                                                                const int32_t *__restrict__ ill, int64_t t, int k, float gamma,
+                                                                const int32_t *__restrict__ neg_left, const int32_t *__restrict__ neg_right,
+                                                                const int32_t *__restrict__ neg2_left, const int32_t *__restrict__ neg2_right,
+                                                                double *__restrict__ loss_accum, float *__restrict__ coef_out) {
+    constexpr int NG = 256 / G;
+    __shared__ double s_loss[4];
+    const int lane = threadIdx.x % G, gid = threadIdx.x / G;
+    const float scale = 1.0f / (2.0f * (float)k * (float)t);
+    double loss_local = 0.0;
+    for (int64_t a = (int64_t)blockIdx.x * NG + gid; a < t; a += (int64_t)gridDim.x * NG) {
+        const int l = ill[2 * a], r = ill[2 * a + 1];
+        float A = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * G + lane;
+            A += c < ld ? fabsf(emb[(int64_t)l * ld + c] - emb[(int64_t)r * ld + c]) : 0.f;
+        }
+        A = group_sum<G>(A);
+        const float D = A + gamma;
+        int active = 0;
+        for (int i = 0; i < 2 * k; i += 2) {                       // two negatives per trip: four rows in flight
+            float B[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int iu = min(i + u, 2 * k - 1);
+                const int side = iu >= k, b = side ? iu - k : iu;
+                const int nl = (side ? neg2_left : neg_left)[a * k + b], nr = (side ? neg2_right : neg_right)[a * k + b];
+                float acc = 0.f;
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int c = it * G + lane;
+                    acc += c < ld ? fabsf(emb[(int64_t)nl * ld + c] - emb[(int64_t)nr * ld + c]) : 0.f;
+                }
+                B[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float L = D - group_sum<G>(B[u]);
+                if (i + u < 2 * k) {
+                    if (lane == 0) coef_out[t + a * 2 * k + i + u] = L > 0.f ? -scale : 0.f;
+                    if (L > 0.f) {
+                        ++active;
+                        if (lane == 0) loss_local += (double)L;
+                    }
+                }
+            }
+        }
+        if (lane == 0) coef_out[a] = scale * (float)active;
+    }
+    const double w = oea::wave_sum_d(loss_local);
+    if ((threadIdx.x & 63) == 0) s_loss[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        if (tot != 0.0) atomicAdd(loss_accum, tot * (double)scale);
+    }
+}
+
 template <int G, int IT>
 __global__ __launch_bounds__(256) void sgd_rows_kernel(float *__restrict__ w, const float *__restrict__ grad, int64_t rows,
                                                        int dim, int ld, int normalize, float lr) {
@@ -540,6 +605,18 @@ int oea_align_loss_l1_coef(const float *out_emb, int64_t n, int32_t dim, int32_t
     OEA_REQUIRE(ld % 4 == 0 && dim > 0 && dim <= ld && k >= 1 && n > 0, "shapes");
     if (t == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
+    if (coef_out && !grad && k <= 16 && ld <= 128) {                 // small k: a lane group per link (GCN-Align)
+#define CALLG(IT)                                                                                                          \
+    align_coef_groups_kernel<32, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(t, 8), 4096), 256, 0, st>>>(                 \
+        out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, loss_accum, coef_out)
+        if (ld <= 32) CALLG(1);
+        else if (ld <= 64) CALLG(2);
+        else if (ld <= 96) CALLG(3);
+        else CALLG(4);
+#undef CALLG
+        OEA_CHECK_HIP(hipGetLastError());
+        return OEA_OK;
+    }
 #define CALL(G, IT)                                                                                             \
     align_loss_l1_kernel<G, IT><<<(unsigned)std::min<int64_t>(t, 65535), 256, 0, st>>>(                           \
         out_emb, dim, ld, ill, t, k, gamma, neg_left, neg_right, neg2_left, neg2_right, grad, loss_accum, coef_out)
