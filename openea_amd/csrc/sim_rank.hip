@@ -1057,6 +1057,127 @@ __global__ __launch_bounds__(256) void l1_u16_strip_kernel(const uint16_t *__res
     }
 }
 
+// ---- manhattan evaluation from the grid distances (RDGCN's metric, similarity.py:46-48 + alignment.py:146-168) -------------
+// The reference ranks float32(1 - cdist(e1, e2, 'cityblock')): fp64 distances of EVERY pair (rank_valu_kernel: 125 ms at
+// 70,000^2 x 300, the fp64 vector rate).  Here every pair only gets its 16-bit grid distance G (l1_u16_strip_kernel); the
+// true distance lies within `err` of G step, so against the gold distance d_g a candidate is
+//     certainly nearer   G step + err < d_g      -> counted,
+//     certainly farther  G step - err > d_g      -> ignored,
+//     in between                                  -> its EXACT similarity decides (sequential fp64 chain, the bits of
+//                                                    rank_valu_kernel / scipy), tie rule included;
+// the nearest candidate is the best exact similarity among the candidates within 2 err of the smallest grid distance.
+// One workgroup per query row over its strip row [nc] of -G (two reads, the second out of L2); the few exact distances
+// are one thread each.  A row whose candidate lists overflow (cannot happen unless thousands of candidates sit within
+// `err` of the gold distance) evaluates every pair exactly.
+constexpr int kGridAmb = 2048, kGridTop = 512;
+
+__device__ __forceinline__ float exact_l1_sim(const double *__restrict__ qs, const float *__restrict__ c, int dim) {
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < dim; ++k) acc += fabs(qs[k] - (double)c[k]);       // k ascending: valu_tile's order
+    return (float)(1.0 - acc);
+}
+
+__global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__restrict__ strip, int64_t rows, int64_t row0, int64_t nc,
+                                                                int64_t ld, const float *__restrict__ e1, int ld1,
+                                                                const float *__restrict__ e2, int ld2, int dim, int64_t gold_off,
+                                                                float step, float err, int32_t *__restrict__ rank,
+                                                                int32_t *__restrict__ argmax) {
+    extern __shared__ double lds_d[];                              // qs [dim] (padded to even), then the lists
+    double *qs = lds_d;
+    int32_t *amb = reinterpret_cast<int32_t *>(qs + ((dim + 1) & ~1));
+    int32_t *top = amb + kGridAmb;
+    __shared__ int s_namb, s_ntop, s_cnt;
+    __shared__ float s_gold, s_gmin;
+    __shared__ unsigned long long s_best;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    if (r >= rows) return;
+    const int64_t i = row0 + r, g = i + gold_off;
+    for (int k = tid; k < dim; k += 256) qs[k] = (double)e1[i * ld1 + k];
+    if (tid == 0) { s_namb = 0; s_ntop = 0; s_cnt = 0; s_best = 0ull; s_gmin = INFINITY; }
+    __syncthreads();
+    if (tid == 0) s_gold = exact_l1_sim(qs, e2 + g * ld2, dim);
+    __syncthreads();
+    const float sg = s_gold;
+    // slack: the float rounding of the similarities around the gold one and of grid sums >= 2^24
+    const float tol = err + 4.0e-7f * fmaxf(fabsf(sg), 1.0f) + 4.0f * step;
+    const float dg = (float)(1.0 - (double)sg);
+    const float g_lo = (dg - tol) / step, g_hi = (dg + tol) / step;          // in grid units; strip holds -G
+    const float *srow = strip + r * ld;
+    int cnt = 0;
+    float gmin = INFINITY;
+    for (int64_t j = tid; j < nc; j += 256) {
+        const float G = -srow[j];
+        gmin = fminf(gmin, G);
+        if (j == g) continue;
+        if (G < g_lo) ++cnt;
+        else if (G <= g_hi) {
+            const int at = atomicAdd(&s_namb, 1);
+            if (at < kGridAmb) amb[at] = (int32_t)j;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_cnt, cnt);
+        atomicMin(reinterpret_cast<int *>(&s_gmin), __float_as_int(gmin));     // G >= 0: the int order is the float order
+    }
+    __syncthreads();
+    const float top_hi = s_gmin + 2.0f * tol / step;
+    for (int64_t j = tid; j < nc; j += 256) {
+        if (-srow[j] <= top_hi) {
+            const int at = atomicAdd(&s_ntop, 1);
+            if (at < kGridTop) top[at] = (int32_t)j;
+        }
+    }
+    __syncthreads();
+    const int namb = s_namb, ntop = s_ntop;
+    int extra = 0;
+    unsigned long long best = 0ull;
+    if (namb > kGridAmb || ntop > kGridTop) {
+        // every pair exactly (the lists overflowed)
+        for (int64_t j = tid; j < nc; j += 256) {
+            const float v = exact_l1_sim(qs, e2 + j * ld2, dim);
+            extra += (j != g) && (v > sg || (v == sg && j < g));
+            const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+            best = key > best ? key : best;
+        }
+        if (tid == 0) s_cnt = 0;                                    // the grid count is replaced, not extended
+        __syncthreads();
+    } else {
+        for (int a = tid; a < namb; a += 256) {
+            const int64_t j = amb[a];
+            const float v = exact_l1_sim(qs, e2 + j * ld2, dim);
+            extra += v > sg || (v == sg && j < g);
+        }
+        for (int a = tid; a < ntop; a += 256) {
+            const int64_t j = top[a];
+            const float v = exact_l1_sim(qs, e2 + j * ld2, dim);
+            const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        extra += __shfl_xor(extra, off, 64);
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((tid & 63) == 0) {
+        if (extra) atomicAdd(&s_cnt, extra);
+        atomicMax(&s_best, best);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rank[i] = s_cnt;
+        argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(s_best & 0xFFFFFFFFull));
+    }
+}
+
 // exact fp64 L1 distance of every (query row, candidate) pair of a candidate list: one 16-lane group per pair, lane-strided
 // columns, butterfly sum (a fixed order: equal rows give equal sums)
 __global__ __launch_bounds__(256) void pair_l1_f64_kernel(const float *__restrict__ q, int64_t nq, int ldq,
@@ -1886,6 +2007,20 @@ int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t n
     if (nq == 0 || nc == 0) return OEA_OK;
     l1_u16_strip_kernel<<<dim3((unsigned)oea::ceil_div(nc, LT), (unsigned)oea::ceil_div(nq, LT)), 256, 0, oea::as_stream(stream)>>>(
         q, nq, c, nc, ldq, out, ld_out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
+                          const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err, int32_t *rank,
+                          int32_t *argmax, void *stream) {
+    OEA_REQUIRE(strip && e1 && e2 && rank && argmax && rows >= 0 && row0 >= 0 && nc > 0 && ld >= nc, "arguments");
+    OEA_REQUIRE(dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 4096 && step > 0.f && err >= 0.f, "dim <= 4096, step > 0");
+    OEA_REQUIRE(row0 + rows + gold_offset <= nc && gold_offset >= 0, "gold of row i is column gold_offset + i < nc");
+    if (rows == 0) return OEA_OK;
+    const size_t lds = sizeof(double) * (size_t)((dim + 1) & ~1) + sizeof(int32_t) * (kGridAmb + kGridTop);
+    rank_l1_grid_rows_kernel<<<(unsigned)rows, 256, lds, oea::as_stream(stream)>>>(strip, rows, row0, nc, ld, e1, ld1, e2, ld2, dim,
+                                                                                   gold_offset, step, err, rank, argmax);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -415,11 +415,38 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]
     assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
+    if metric == 'manhattan' and csls_r is None and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
+        return rank_eval_l1_grid(e1, e2, dim, gold_offset)
     ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
     check(lib().oea_rank_eval(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC[metric],
                               _p(csls_r), _p(csls_c), int(gold_offset), _p(rank), _p(argmax), _p(ws), _stream()))
+    return rank, argmax
+
+
+def rank_eval_l1_grid(e1, e2, dim, gold_offset=0, block_bytes=2 << 30):
+    """rank_eval(metric='manhattan') without the fp64 distance of every pair: 16-bit grid distances of all pairs
+    (oea_l1_u16_strip, blocks of query rows), then oea_rank_l1_grid_rows -- exact similarities only where the grid leaves a
+    doubt.  Same ranks and nearest candidates as the all-pairs fp64 kernel (tested)."""
+    n1, n2 = e1.shape[0], e2.shape[0]
+    lo1, hi1 = torch.aminmax(e1[:, :dim])
+    lo2, hi2 = torch.aminmax(e2[:, :dim])
+    lo, hi = min(float(lo1), float(lo2)), max(float(hi1), float(hi2))
+    step = max(hi - lo, 1e-30) / 65535.0
+    q1 = quantize_rows_u16(e1, dim, lo, 1.0 / step)
+    q2 = quantize_rows_u16(e2, dim, lo, 1.0 / step)
+    err = (dim * 1.02 + 1.0) * step                      # half a step per operand and column, + the fp32 rounding of the grid map
+    ld = (n2 + 31) // 32 * 32
+    rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    rows_per = int(max(128, min(n1, block_bytes // (4 * ld))))
+    for r0 in range(0, n1, rows_per):
+        rows = min(rows_per, n1 - r0)
+        strip = l1_u16_strip(q1[r0: r0 + rows], q2)
+        check(lib().oea_rank_l1_grid_rows(_p(strip), rows, r0, n2, ld, _p(e1), e1.shape[1], _p(e2), e2.shape[1], dim, int(gold_offset),
+                                          float(step), float(err), _p(rank), _p(argmax), _stream()))
+        del strip
     return rank, argmax
 
 

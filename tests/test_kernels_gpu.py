@@ -973,3 +973,41 @@ def test_gemm_tn_matches_float64(ops, m, k1, k2):
     assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-5)
     assert (w.grad - w2.grad).abs().max().item() <= 1e-5 * max(w2.grad.abs().max().item(), 1.0) * 8
     assert torch.allclose(bias.grad, bias2.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", ["random", "trained", "clustered", "ties", "degenerate"])
+def test_manhattan_evaluation_from_grid_distances_equals_all_pairs_fp64(ops, case, monkeypatch):
+    """RDGCN's evaluation metric (similarity.py:46-48, alignment.py:146-168): ranks and nearest candidates from 16-bit grid
+    distances + exact similarities where the grid leaves a doubt == the all-pairs fp64 kernel (itself bit-exact with scipy's
+    cdist, tests above), on random rows, rows whose gold is the nearest ('trained'), tight clusters (hundreds of candidates
+    within the grid's error of the gold distance), exact duplicates of gold columns (the tie rule) and a table of identical
+    rows (every list overflows: the in-kernel all-pairs path); a second block size exercises row0 > 0 and a gold offset."""
+    import torch
+    rng = np.random.RandomState(11)
+    n1, n2, d = 1500, 4000, 75
+    e2 = rng.standard_normal((n2, d)).astype(np.float32) * 0.3
+    off = 700
+    if case == "random":
+        e1 = rng.standard_normal((n1, d)).astype(np.float32) * 0.3
+    elif case == "trained":
+        e1 = e2[off:off + n1] + 0.05 * rng.standard_normal((n1, d)).astype(np.float32)
+    elif case == "clustered":
+        e2[1000:3000] = e2[1000] + 2e-4 * rng.standard_normal((2000, d)).astype(np.float32)
+        e1 = e2[off:off + n1] + 1e-4 * rng.standard_normal((n1, d)).astype(np.float32)
+    elif case == "ties":
+        e1 = e2[off:off + n1] + 0.02 * rng.standard_normal((n1, d)).astype(np.float32)
+        e2[3000:3400] = e2[off:off + 400]                          # exact copies of gold columns behind them
+        e2[0:300] = e2[off + 500:off + 800]                        # ... and in front of them
+    else:
+        e2[:] = e2[0]
+        e1 = np.repeat(e2[:1], n1, axis=0)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    monkeypatch.setenv("OEA_L1_EVAL", "f64")
+    ref_rank, ref_arg = ops.rank_eval(t1, t2, d, "manhattan", gold_offset=off)
+    monkeypatch.setenv("OEA_L1_EVAL", "grid")
+    rank, arg = ops.rank_eval(t1, t2, d, "manhattan", gold_offset=off)
+    assert torch.equal(rank, ref_rank) and torch.equal(arg, ref_arg)
+    rank, arg = ops.rank_eval_l1_grid(t1, t2, d, gold_offset=off, block_bytes=4 * 4000 * 600)     # three blocks of rows
+    assert torch.equal(rank, ref_rank) and torch.equal(arg, ref_arg)
+    if case == "trained":
+        assert int((rank == 0).sum()) > n1 // 2
