@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void l1_u16_strip_kernel(const uint16_t *__res
 // One workgroup per query row over its strip row [nc] of -G (two reads, the second out of L2); the few exact distances
 // are one thread each.  A row whose candidate lists overflow (cannot happen unless thousands of candidates sit within
 // `err` of the gold distance) evaluates every pair exactly.
-constexpr int kGridAmb = 2048, kGridTop = 512;
+constexpr int kGridAmb = 2048, kGridTop = 4096;
 
 __device__ __forceinline__ float exact_l1_sim(const double *__restrict__ qs, const float *__restrict__ c, int dim) {
     double acc = 0.0;
@@ -1105,16 +1105,31 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
     const float dg = (float)(1.0 - (double)sg);
     const float g_lo = (dg - tol) / step, g_hi = (dg + tol) / step;          // in grid units; strip holds -G
     const float *srow = strip + r * ld;
+    const float band = 2.0f * tol / step;
     int cnt = 0;
     float gmin = INFINITY;
-    for (int64_t j = tid; j < nc; j += 256) {
-        const float G = -srow[j];
-        gmin = fminf(gmin, G);
-        if (j == g) continue;
-        if (G < g_lo) ++cnt;
-        else if (G <= g_hi) {
-            const int at = atomicAdd(&s_namb, 1);
-            if (at < kGridAmb) amb[at] = (int32_t)j;
+    // ONE read of the strip row: the candidates for the nearest are collected against the thread's RUNNING minimum (a
+    // superset of those within `band` of the row's minimum: ~ln(n / 256) records per thread on unordered data) and filtered
+    // once the row minimum is known; only if that list overflows (candidates ordered by falling distance) the row is read again
+    for (int64_t j4 = (int64_t)tid * 4; j4 < nc; j4 += 1024) {       // ld % 4 == 0: 16-byte reads; columns >= nc are unwritten
+        const float4 v4 = oea::ld4(srow + j4);
+        const float Gs[4] = {-v4.x, -v4.y, -v4.z, -v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j4 + u;
+            const float G = Gs[u];
+            if (j >= nc) continue;
+            if (G <= gmin + band) {
+                const int at = atomicAdd(&s_ntop, 1);
+                if (at < kGridTop) top[at] = (int32_t)j;
+            }
+            gmin = fminf(gmin, G);
+            if (j == g) continue;
+            if (G < g_lo) ++cnt;
+            else if (G <= g_hi) {
+                const int at = atomicAdd(&s_namb, 1);
+                if (at < kGridAmb) amb[at] = (int32_t)j;
+            }
         }
     }
 #pragma unroll
@@ -1127,14 +1142,19 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
         atomicMin(reinterpret_cast<int *>(&s_gmin), __float_as_int(gmin));     // G >= 0: the int order is the float order
     }
     __syncthreads();
-    const float top_hi = s_gmin + 2.0f * tol / step;
-    for (int64_t j = tid; j < nc; j += 256) {
-        if (-srow[j] <= top_hi) {
-            const int at = atomicAdd(&s_ntop, 1);
-            if (at < kGridTop) top[at] = (int32_t)j;
+    const float top_hi = s_gmin + band;
+    if (s_ntop > kGridTop) {                                        // workgroup-uniform
+        __syncthreads();
+        if (tid == 0) s_ntop = 0;
+        __syncthreads();
+        for (int64_t j = tid; j < nc; j += 256) {
+            if (-srow[j] <= top_hi) {
+                const int at = atomicAdd(&s_ntop, 1);
+                if (at < kGridTop) top[at] = (int32_t)j;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     const int namb = s_namb, ntop = s_ntop;
     int extra = 0;
     unsigned long long best = 0ull;
@@ -1146,6 +1166,7 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
             const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
             best = key > best ? key : best;
         }
+        __syncthreads();
         if (tid == 0) s_cnt = 0;                                    // the grid count is replaced, not extended
         __syncthreads();
     } else {
@@ -1156,6 +1177,7 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
         }
         for (int a = tid; a < ntop; a += 256) {
             const int64_t j = top[a];
+            if (-srow[j] > top_hi) continue;                        // a record of the running minimum only
             const float v = exact_l1_sim(qs, e2 + j * ld2, dim);
             const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
             best = key > best ? key : best;
@@ -2015,6 +2037,7 @@ int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_
                           const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err, int32_t *rank,
                           int32_t *argmax, void *stream) {
     OEA_REQUIRE(strip && e1 && e2 && rank && argmax && rows >= 0 && row0 >= 0 && nc > 0 && ld >= nc, "arguments");
+    OEA_REQUIRE(ld % 4 == 0 && ((uintptr_t)strip & 15) == 0, "strip rows: 16-byte aligned (ld % 4 == 0)");
     OEA_REQUIRE(dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 4096 && step > 0.f && err >= 0.f, "dim <= 4096, step > 0");
     OEA_REQUIRE(row0 + rows + gold_offset <= nc && gold_offset >= 0, "gold of row i is column gold_offset + i < nc");
     if (rows == 0) return OEA_OK;
