@@ -1380,7 +1380,8 @@ int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float 
     OEA_REQUIRE(ent && rel && own && rel_x && upd && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(world >= 1 && rank >= 0 && rank < world && ld % 4 == 0, "world / rank / ld");
     OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (cfg->opt_kind == OEA_OPT_ADAGRAD && acc_own && rel_acc), "SGD or Adagrad (+ state)");
-    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE, "the partitioned step covers the TransE score");
+    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE || cfg->score_kind == OEA_SCORE_TRANSD,
+                "the partitioned step covers the TransE and TransD scores (TransD: both stacked tables are ordinary rows)");
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     const int64_t rpr = oea_part_rows_per_rank(n_ent, world);

@@ -98,8 +98,8 @@ class TripleTrainer:
         # translational models.  OEA_DP_EXCHANGE=allreduce keeps the replicated update with one dense all-reduce.
         self.part = None
         import os
-        if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD') and cfg.score_kind == ops.SCORE_TRANSE
-                and self.exchange == "step"):
+        if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD')
+                and cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSD) and self.exchange == "step"):
             self._init_partition(optimizer)
 
     # ---- dp_exchange = 'epoch': local steps, one exchange per epoch ----------------------------------------------
