@@ -1486,10 +1486,19 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
             const int64_t my_j = c0 + my_jl;
             const float my_tc = my_j < nc ? thr_c[my_j] : INFINITY;
             int my_cnt = 0;
+            // k ~ 10: ~0.05 % of the values survive either threshold, so most accumulator registers hold none.  One bound per
+            // lane -- the smaller of its own query thresholds and the smallest candidate threshold of this tile's wave --
+            // lets a register be skipped with two compares and a ballot instead of the slot arithmetic below (which cost the
+            // means sweep 12.3 ms against 9.5 ms for the plain rank sweep at 70,000^2)
+            float tc_min = my_tc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tc_min = fminf(tc_min, __shfl_xor(tc_min, off, 64));
+            const float lo0 = fminf(th[0], tc_min), lo1 = fminf(th[1], tc_min);
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if (__ballot(acc[tm][0][r] >= lo0 || acc[tm][1][r] >= lo1) == 0ull) continue;
                     const int jl = jl0 + tm * 32 + (r & 3) + 8 * (r >> 2);
                     const int j = (int)c0 + jl;
                     const bool jin = j < nc;

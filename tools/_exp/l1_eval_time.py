@@ -6,7 +6,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from openea_amd import ops  # noqa: E402
 
 n, d = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (70000, 300)
