@@ -648,7 +648,9 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail,
                                                                    const uint2 *__restrict__ clists, const uint8_t *__restrict__ ccounts,
                                                                    int T, int ccap, const int32_t *__restrict__ spill_cnt,
-                                                                   const uint2 *__restrict__ spill) {
+                                                                   const uint2 *__restrict__ spill, int stop_after) {
+    // stop_after (experiments, OEA_TOPK_SELECT_STOP): leave after phase 1 (lengths + scan), 2 (gather), 3 (histogram + bucket),
+    // 4 (threshold bucket ranked), 5 (bitmap set); 0 = run to the end.  Results are garbage when it is set.
     // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
     __shared__ int hist[kBins];
     __shared__ uint32_t c_key[kCandCap];
@@ -699,6 +701,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     __syncthreads();
     const int total = s_off[nst];
     bool fail = s_bad != 0;                                      // block-uniform from here on
+    if (stop_after == 1) return;
     if (!fail) {
         float val[kPerThread];
         int col[kPerThread];
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         if (lane == 0) s_red[wave] = mx;
         __syncthreads();
+        if (stop_after == 2) { if (mx == 12345.f) out[row] = col[0] + col[kPerThread - 1]; return; }
         const float lo = thr[row];                               // every survivor is >= thr
         const float hi = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
@@ -769,6 +773,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         }
         __syncthreads();
         const int bstar = s_bstar, need = s_need;
+        if (stop_after == 3) return;
         fail = hist[bstar] > kCandCap;                          // tie-heavy row: the fallback's radix path handles it
         if (!fail) {
 #pragma unroll
@@ -793,6 +798,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
             __syncthreads();
             const uint32_t tkey = s_tkey;
             const int tcol = s_tcol;
+            if (stop_after == 4) return;
 #pragma unroll
             for (int e = 0; e < kPerThread; ++e) {
                 if (col[e] < 0) continue;
@@ -800,6 +806,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                 if (key > tkey || (key == tkey && col[e] <= tcol)) atomicOr(&bitmap[col[e] >> 5], 1u << (col[e] & 31));   // exactly k bits
             }
             __syncthreads();
+            if (stop_after == 5) return;
             // enumerate the set bits in ascending column order: contiguous word ranges per thread + block scan
             const int wpt = (words + SEL_THREADS - 1) / SEL_THREADS;
             const int w0 = tid * wpt, w1 = min(words, w0 + wpt);
@@ -854,6 +861,11 @@ static int threshold_rank(double e) {
     static const double sigma = [] { const char *v = getenv("OEA_TOPK_SIGMA"); return v ? atof(v) : 2.5; }();
     static const double slack = [] { const char *v = getenv("OEA_TOPK_SLACK"); return v ? atof(v) : 4.0; }();
     return (int)(e + sigma * std::sqrt(e) + slack);
+}
+
+static int select_stop() {
+    static const int v = [] { const char *e = getenv("OEA_TOPK_SELECT_STOP"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 // workspace layout of one pass of `rows` queries; ok = false when the strip path should run instead
@@ -1151,7 +1163,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
                                     sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, st);
         list_select_kernel<<<(unsigned)nq, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
             list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
-            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill));
+            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill), select_stop());
         rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
                               8 * (size_t)nq * sy.T * 2 * sy.ccap, sy.ld, st);
         if (rc != OEA_OK) return rc;
@@ -1189,7 +1201,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             list_select_kernel<<<(unsigned)rows, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
-                                                                      spill_cnt, static_cast<const uint2 *>(spill));
+                                                                      spill_cnt, static_cast<const uint2 *>(spill), select_stop());
             // rows the select gave up on: through the strip path, in batches, inside the (now dead) list storage
             rc = redo_failed_rows(qp + r0 * kp, kp, cp, nc, dim, k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, list_vals,
                                   2 * lp.cols_off, lp.ld, st);
