@@ -697,7 +697,20 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     if (tid == 0 && (total_all < k || total_all > kPerThread * SEL_THREADS)) s_bad = 1;
     const int words = (int)((nc + 31) / 32);
     for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
-    for (int w = tid; w < words; w += SEL_THREADS) bitmap[w] = 0u;
+    // owner[i] = the segment of list position i, written by the thread that counted the segment: the gather below finds an
+    // entry with two LDS reads instead of a binary search over ~1,600 segment offsets (11 dependent reads per entry: the
+    // gather was 2.3 ms of the select's 4.7 at 100,000 rows).  The table lives in the bitmap's storage, which is zeroed after
+    // the gather.
+    uint16_t *owner = reinterpret_cast<uint16_t *>(bitmap);
+    if (total_all <= kPerThread * SEL_THREADS) {
+        int at = run;                                            // == s_off[tid * kSegPer + kSegPer] after the loop above
+#pragma unroll
+        for (int u = kSegPer - 1; u >= 0; --u) {
+            at -= seg_c[u];
+            const int sg = tid * kSegPer + u;
+            for (int e = 0; e < seg_c[u]; ++e) owner[at + e] = (uint16_t)sg;
+        }
+    }
     __syncthreads();
     const int total = s_off[nst];
     bool fail = s_bad != 0;                                      // block-uniform from here on
@@ -717,11 +730,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                 // (round 3, measured and dropped: consecutive positions per thread with one binary search + a forward walk
                 //  instead of a binary search per position -- 4.41 -> 5.02 ms: the strided assignment keeps a wave's loads in
                 //  neighbouring entries of the same segments)
-                int lo_s = 0, hi_s = nst;                        // s_off[lo_s] <= i < s_off[hi_s]
-                while (hi_s - lo_s > 1) {
-                    const int mid = (lo_s + hi_s) >> 1;
-                    if (s_off[mid] <= i) lo_s = mid; else hi_s = mid;
-                }
+                const int lo_s = owner[i];                       // s_off[lo_s] <= i < s_off[lo_s + 1]
                 if (lo_s < nseg) {
                     const int64_t at = (int64_t)lo_s * cap + (i - s_off[lo_s]);
                     val[e] = vb[at];
@@ -742,6 +751,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         if (lane == 0) s_red[wave] = mx;
         __syncthreads();
+        for (int w = tid; w < words; w += SEL_THREADS) bitmap[w] = 0u;       // the owner table is dead: its storage becomes the bitmap
         if (stop_after == 2) { if (mx == 12345.f) out[row] = col[0] + col[kPerThread - 1]; return; }
         const float lo = thr[row];                               // every survivor is >= thr
         const float hi = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
@@ -815,6 +825,25 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
             int tot;
             int pos = block_excl_scan(cnt, s_wave, &tot);
             int32_t *o = out + row * (int64_t)k;
+            if (k <= kBins) {
+                // the k columns are staged in LDS (the histogram is dead) and leave coalesced, their id_map look-ups
+                // independent of each other: a thread writing its own ~8 columns one by one issued 64 partial-line stores
+                // per instruction and waited for every look-up (1.0 ms of the select at 100,000 rows without id_map)
+                for (int w = w0; w < w1; ++w) {
+                    uint32_t bits = bitmap[w];
+                    while (bits) {
+                        const int b = __ffs((int)bits) - 1;
+                        bits &= bits - 1;
+                        hist[pos++] = 32 * w + b;
+                    }
+                }
+                __syncthreads();
+                for (int i = tid; i < k; i += SEL_THREADS) {
+                    const int c = hist[i];
+                    o[i] = id_map ? id_map[c] : c;
+                }
+                return;
+            }
             for (int w = w0; w < w1; ++w) {
                 uint32_t bits = bitmap[w];
                 while (bits) {
@@ -861,6 +890,11 @@ static int threshold_rank(double e) {
     static const double sigma = [] { const char *v = getenv("OEA_TOPK_SIGMA"); return v ? atof(v) : 2.5; }();
     static const double slack = [] { const char *v = getenv("OEA_TOPK_SLACK"); return v ? atof(v) : 4.0; }();
     return (int)(e + sigma * std::sqrt(e) + slack);
+}
+
+// dynamic LDS of list_select_kernel: the bitmap of selected columns, or the owner table of the gather that precedes it
+static size_t select_lds_bytes(int64_t nc) {
+    return std::max(sizeof(uint32_t) * (size_t)((nc + 31) / 32), sizeof(uint16_t) * (size_t)kPerThread * SEL_THREADS);
 }
 
 static int select_stop() {
@@ -1161,7 +1195,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)nq, st));
         oea::topk_append_sym_packed(qp, nq, kp, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
                                     sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, st);
-        list_select_kernel<<<(unsigned)nq, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
+        list_select_kernel<<<(unsigned)nq, SEL_THREADS, select_lds_bytes(nc), st>>>(
             list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
             static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill), select_stop());
         rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
@@ -1198,7 +1232,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)rows, st));
             oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, spill_cnt,
                                     spill, kSpillCap, st);
-            list_select_kernel<<<(unsigned)rows, SEL_THREADS, sizeof(uint32_t) * (size_t)((nc + 31) / 32), st>>>(
+            list_select_kernel<<<(unsigned)rows, SEL_THREADS, select_lds_bytes(nc), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
                                                                       spill_cnt, static_cast<const uint2 *>(spill), select_stop());
