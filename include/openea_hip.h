@@ -180,6 +180,13 @@ int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float 
                    int32_t world, int32_t rank, float *own, float *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
                    int64_t n_items, double *loss_accum, void *stream);
 int oea_part_unpack(float *ent, int64_t n_ent, int32_t ld, int32_t world, int32_t rank, const float *all, void *stream);
+/* TransH under the entity-id partition (approaches/bootea_transh.py:58-96): the normal-vector table is relation-sized and
+ * replicated.  After the GRAD phase its gradient scratch (copy 0) and touched flags -- [n_rel, ld] and [n_rel] floats at the
+ * byte offsets oea_step_normal_scratch reports inside the step workspace -- are summed over the ranks (two small all-reduces),
+ * then every rank runs oea_step_apply_normals (the optimiser on the touched rows of cfg->normal, state cfg->normal_acc). */
+int oea_step_normal_scratch(int64_t n_ent, int64_t n_rel, int32_t ld, int64_t *grad_offset_bytes, int64_t *touched_offset_bytes);
+int oea_step_apply_normals(int64_t n_ent, int64_t n_rel, int32_t ld, const oea_step_cfg *cfg, void *workspace, void *stream);
+
 
 /* Add externally computed gradients w.r.t. the (normalised) entity rows `ids` into the step's
  * gradient scratch: grad[ids[i]] += src[i].  Followed by oea_triple_step_phase(...,

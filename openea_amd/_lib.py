@@ -110,6 +110,8 @@ PROTOTYPES = {
     "oea_part_pack": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "oea_part_apply": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, C.POINTER(StepCfg), _vp, _i64,
                                  _vp, _vp]),
+    "oea_step_normal_scratch": (C.c_int, [_i64, _i64, _i32, _vp, _vp]),
+    "oea_step_apply_normals": (C.c_int, [_i64, _i64, _i32, _vp, _vp, _vp]),
     "oea_part_unpack": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "oea_step_scatter_ent_rows": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "oea_tripleset_capacity": (_u64, [_i64]),

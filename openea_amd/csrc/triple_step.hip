@@ -1358,6 +1358,34 @@ size_t oea_part_send_floats(int64_t n_ent, int32_t ld, int32_t world) {
     else if (ld <= 1280) { CALL(64, 20); }                              \
     else { oea::set_error("ld %d > 1280 unsupported", ld); return OEA_EUNSUPPORTED; }
 
+/* TransH under the entity-id partition: the normal-vector table is relation-sized and replicated, so its gradient scratch
+ * (copy 0 after the GRAD phase folded the copies) and touched flags are summed over the ranks with two small all-reduces
+ * and every rank applies the same update.  oea_step_normal_scratch: where the two regions sit in the workspace (byte
+ * offsets + float counts); oea_step_apply_normals: the optimiser on the touched normal rows (cfg->normal / normal_acc). */
+int oea_step_normal_scratch(int64_t n_ent, int64_t n_rel, int32_t ld, int64_t *grad_offset_bytes, int64_t *touched_offset_bytes) {
+    OEA_REQUIRE(grad_offset_bytes && touched_offset_bytes, "null pointer");
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, reinterpret_cast<void *>(256), &ws);           // fake base: only offsets matter
+    *grad_offset_bytes = reinterpret_cast<char *>(ws.nrm_grad) - reinterpret_cast<char *>(256);
+    *touched_offset_bytes = reinterpret_cast<char *>(ws.nrm_touched) - reinterpret_cast<char *>(256);
+    return OEA_OK;
+}
+
+int oea_step_apply_normals(int64_t n_ent, int64_t n_rel, int32_t ld, const oea_step_cfg *cfg, void *workspace, void *stream) {
+    OEA_REQUIRE(cfg && workspace && ld % 4 == 0, "arguments");
+    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSH && cfg->normal, "TransH score with its normal-vector table");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (cfg->opt_kind == OEA_OPT_ADAGRAD && cfg->normal_acc), "SGD or Adagrad (+ state)");
+    if (n_rel == 0) return OEA_OK;
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    hipStream_t st = oea::as_stream(stream);
+#define OEA_CALL(G, IT) apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, 256 / G), 1), 256, 0, st>>>(n_rel, ld, *cfg, ws, 1);
+    OEA_PART_DISPATCH(OEA_CALL)
+#undef OEA_CALL
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
 int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, float *send, float *rel_x,
                   void *stream) {
     OEA_REQUIRE(workspace && send && rel_x && world >= 1 && ld % 4 == 0, "arguments");
@@ -1380,8 +1408,8 @@ int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float 
     OEA_REQUIRE(ent && rel && own && rel_x && upd && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(world >= 1 && rank >= 0 && rank < world && ld % 4 == 0, "world / rank / ld");
     OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (cfg->opt_kind == OEA_OPT_ADAGRAD && acc_own && rel_acc), "SGD or Adagrad (+ state)");
-    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE || cfg->score_kind == OEA_SCORE_TRANSD,
-                "the partitioned step covers the TransE and TransD scores (TransD: both stacked tables are ordinary rows)");
+    // TransD: both stacked tables are ordinary rows; TransH: the normal-vector table goes through oea_step_apply_normals
+    OEA_REQUIRE(cfg->score_kind >= OEA_SCORE_TRANSE && cfg->score_kind <= OEA_SCORE_TRANSD, "score_kind");
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     const int64_t rpr = oea_part_rows_per_rank(n_ent, world);

@@ -282,12 +282,18 @@ class BasicModel:
         (random.sample); Adagrad on the entity rows (through the normalisation) and on M.  One step = the fused
         oea_mapping_step (3 kernels) + the apply phase of the step engine; the epoch's batches go up in one copy."""
         start = time.time()
-        links = np.asarray(self.kgs.train_links, np.int32)
-        n_batch = len(links) // triple_steps
-        rng = np.random.RandomState(self._seed + 1000 + epoch)
-        picks = np.stack([rng.choice(len(links), n_batch, replace=False) for _ in range(triple_steps)])
         dev = self.mapping_mat.device
-        batches = ops.to_ids(np.ascontiguousarray(links[picks].transpose(0, 2, 1)), dev)      # [steps, 2, n_batch]
+        if getattr(self, "_train_links_dev", None) is None:
+            self._train_links_dev = ops.to_ids(np.asarray(self.kgs.train_links, np.int32), dev)           # [L, 2]
+        links = self._train_links_dev
+        n_batch = links.shape[0] // triple_steps
+        # random.sample per step = the first n_batch of a random permutation of the links; drawn for all steps at once on the
+        # device (keys + row-wise argsort; same seed -> same draws on every rank).  On the host this was the epoch: numpy
+        # permutes all L links per rng.choice(..., replace=False) call -- 2 ms of a 4.2 ms epoch at 15K, 13 ms at 100K
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(self._seed + 1000 + epoch)
+        picks = torch.rand((triple_steps, links.shape[0]), device=dev, generator=gen).argsort(dim=1)[:, :n_batch]
+        batches = links[picks.reshape(-1)].reshape(triple_steps, n_batch, 2).permute(0, 2, 1).contiguous()   # [steps, 2, n_batch]
         t = self._mapping_trainer
         loss_dev = torch.zeros(1, dtype=torch.float64, device=dev)
         opt = self.mapping_optimizer['optimizer']

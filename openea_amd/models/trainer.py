@@ -99,7 +99,7 @@ class TripleTrainer:
         self.part = None
         import os
         if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD')
-                and cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSD) and self.exchange == "step"):
+                and cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD) and self.exchange == "step"):
             self._init_partition(optimizer)
 
     # ---- dp_exchange = 'epoch': local steps, one exchange per epoch ----------------------------------------------
@@ -173,10 +173,18 @@ class TripleTrainer:
         ops.part_pack(self.ws, self.ent.rows, self.rel.rows, self.ent.ld, p['world'], p['send'], p['rel_x'])
         mdist.reduce_scatter_(p['own'], p['send'], self.dist)
         mdist.allreduce_sum_(p['rel_x'], self.dist)
+        transh = self.cfg.score_kind == ops.SCORE_TRANSH
+        if transh:                     # the normal-vector table is relation-sized and replicated: its scratch is summed too
+            if 'nrm' not in p:
+                p['nrm'] = ops.step_normal_views(self.ws, self.ent.rows, self.rel.rows, self.ent.ld)
+            mdist.allreduce_sum_(p['nrm'][0], self.dist)
+            mdist.allreduce_sum_(p['nrm'][1], self.dist)
         grouped = self.cfg.neg_group_k > 0 or self.cfg.loss_kind == 0
         n_items = pos.shape[0] if grouped else pos.shape[0] + (0 if neg is None else neg.shape[0])
         ops.part_apply(self.ent.var, p['acc_own'], self.rel.var, self.rel_acc, p['world'], p['rank'], p['own'], p['rel_x'],
                        p['upd'], self.cfg, self.ws, n_items, self.loss)
+        if transh:
+            ops.step_apply_normals(self.ent.rows, self.rel.rows, self.ent.ld, self.cfg, self.ws)
         mdist.all_gather_into_(p['all'], p['upd'], self.dist)
         ops.part_unpack(self.ent.var, p['world'], p['rank'], p['all'])
 

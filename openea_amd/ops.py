@@ -244,6 +244,20 @@ def step_exchange_view(workspace, n_ent, n_rel, ld):
     return workspace[: 4 * n].view(torch.float32)
 
 
+def step_normal_views(workspace, n_ent, n_rel, ld):
+    """TransH under the entity-id partition: fp32 views of the normal-vector gradient scratch [n_rel * ld] and its touched
+    flags [n_rel] inside the step workspace (summed over the ranks after the GRAD phase, include/openea_hip.h)."""
+    g_off, t_off = C.c_int64(0), C.c_int64(0)
+    check(lib().oea_step_normal_scratch(int(n_ent), int(n_rel), int(ld), C.byref(g_off), C.byref(t_off)))
+    grad = workspace[g_off.value: g_off.value + 4 * n_rel * ld].view(torch.float32)
+    touched = workspace[t_off.value: t_off.value + 4 * n_rel].view(torch.float32)
+    return grad, touched
+
+
+def step_apply_normals(n_ent, n_rel, ld, cfg, workspace):
+    check(lib().oea_step_apply_normals(int(n_ent), int(n_rel), int(ld), C.byref(cfg), _p(workspace), _stream()))
+
+
 def profile_begin(stride=1):
     check(lib().oea_profile_begin(int(stride)))
 

@@ -27,8 +27,8 @@ if world > 1:
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["OEA_PORT"],
                             rank=int(os.environ["RANK"]), world_size=world)
 torch.cuda.set_device(0)
-from openea_amd.approaches import AlignE, AliNet, BootEA, BootEA_RotatE, GCN_Align, MTransE
-from openea_amd.models.trans import TransD
+from openea_amd.approaches import AlignE, AliNet, BootEA, BootEA_RotatE, BootEA_TransH, GCN_Align, MTransE
+from openea_amd.models.trans import TransD, TransH
 from openea_amd.modules.load.synth import make_kgs
 from openea_amd.run.default_args import get_args
 from openea_amd.modules.finding.alignment import greedy_alignment
@@ -121,6 +121,8 @@ with contextlib.redirect_stdout(buf):
     for cls, nm, mode, kw in ((MTransE, "MTransE", "mapping", dict(max_epoch=4, start_valid=100, eval_freq=100)),
                               (BootEA, "BootEA", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, sim_th=0.3)),
                               (TransD, "TransD", "sharing", dict(max_epoch=4, start_valid=100, eval_freq=100)),
+                              (TransH, "TransH", "sharing", dict(max_epoch=4, start_valid=100, eval_freq=100)),
+                              (BootEA_TransH, "BootEA_TransH", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, sim_th=0.3)),
                               (BootEA_RotatE, "BootEA_RotatE", "swapping", dict(max_epoch=4, sub_epoch=2, start_valid=100, start_bp=2,
                                                                                 sim_th=0.3, gamma=6.0, neg_triple_num=4))):
         b = cls()
@@ -133,7 +135,7 @@ with contextlib.redirect_stdout(buf):
 rank = int(os.environ.get("RANK", "0"))
 np.savez(os.environ["OEA_OUT"] + "/result_w%d_r%d.npz" % (world, rank), ent=m.ent_embeds.raw(), rel=m.rel_embeds.raw(),
          nbr=nbr, res=json.dumps(res), gcn_out=gcn_out, att=attn_res[0], att_dz=attn_res[1], att_dv=attn_res[2], att_r=attn_res[3], att_r_dz=attn_res[4], att_r_dv=attn_res[5], alinet=alinet_out, alinet_fwd0=alinet_fwd0, alinet_ep1=alinet_ep1, **alinet_grads, mtranse=extra["MTransE"], bootea=extra["BootEA"], transd=extra["TransD"],
-         rotate=extra["BootEA_RotatE"])
+         rotate=extra["BootEA_RotatE"], transh=extra["TransH"], bootea_transh=extra["BootEA_TransH"])
 if world > 1:
     dist.barrier()
 '''
@@ -209,13 +211,14 @@ def test_two_ranks_reproduce_single_process(tmp_path, capsys):
                       % (key, single[key].shape, float(np.abs(r0[key] - single[key]).max()), float(np.abs(single[key]).max()),
                          int((r0[key] != single[key]).sum())))
     assert d_alinet <= float(os.environ.get("OEA_ALINET_2RANK_TOL", "5e-3"))
-    for key in ("mtranse", "bootea", "transd", "rotate"):
+    for key in ("mtranse", "bootea", "transd", "rotate", "transh", "bootea_transh"):
         assert np.array_equal(r0[key], r1[key])
         assert np.linalg.norm(r0[key] - single[key]) <= 1e-3 * np.linalg.norm(single[key])
     with capsys.disabled():
         print("two ranks vs single process, relative L2 of the entity tables: " + ", ".join(
             "%s %.2e" % (key, float(np.linalg.norm(r0[key] - single[key]) / np.linalg.norm(single[key])))
-            for key in ("mtranse", "bootea", "transd", "rotate")) + "  (TransD: stacked tables partitioned by row id, round 3)")
+            for key in ("mtranse", "bootea", "transd", "rotate", "transh", "bootea_transh"))
+              + "  (round 3: TransD's stacked tables and TransH's entity / relation tables partitioned by row id, the normal vectors replicated)")
     assert single["rotate"].dtype == np.float64
 
 

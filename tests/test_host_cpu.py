@@ -61,6 +61,36 @@ def test_host_side_planners_of_the_library():
     assert lib.oea_part_send_floats(30000, 76, 8) == 8 * 3750 * 77
 
 
+def test_host_side_plans_of_round_3():
+    """Planners that run without a device: the row chunks of the X^T dY kernel (workspace = chunks x k1 x k2 partial tiles, none
+    when one chunk covers the rows), and the chunked per-row sums behind RDGCN's per-relation logit gradient (every gather
+    position in exactly one chunk of <= 2,048, chunks grouped by source row)."""
+    import torch
+    from openea_amd import _lib
+    from openea_amd.models.graph_ops import gather_few_plan
+    lib = _lib.load(require_device=False)
+    assert lib.oea_gemm_tn_workspace_floats(100, 8, 12) == 0                      # one chunk: written in place
+    for m, k1, k2 in ((200000, 500, 400), (200000, 300, 300), (5000, 300, 300), (70001, 500, 400)):
+        n = lib.oea_gemm_tn_workspace_floats(m, k1, k2)
+        assert n % (k1 * k2) == 0
+        chunks = n // (k1 * k2)
+        tiles = -(-k1 // 128) * -(-k2 // 128)
+        assert 2 <= chunks <= -(-m // 256) and chunks * tiles <= 2048 + tiles, (m, k1, k2, chunks)
+    assert lib.oea_colsum_blocks(0) == 0 and lib.oea_colsum_blocks(500) == 1 and lib.oea_colsum_blocks(200000) == 3125
+    assert lib.oea_colsum_blocks(10 ** 7) == 4096
+    rng = np.random.RandomState(4)
+    n_src, n_idx = 50, 30000
+    idx = torch.tensor(np.minimum(rng.zipf(1.3, n_idx) - 1, n_src - 1))
+    order, chunk_ptr, row_chunk_ptr = gather_few_plan(idx, n_src)
+    cp, rcp = chunk_ptr.numpy(), row_chunk_ptr.numpy()
+    assert cp[0] == 0 and cp[-1] == n_idx and (np.diff(cp) > 0).all() and np.diff(cp).max() <= 2048
+    assert sorted(order.tolist()) == list(range(n_idx))
+    for r in range(n_src):
+        pos = order[cp[rcp[r]]: cp[rcp[r + 1]]].long()
+        assert (idx[pos] == r).all() and len(pos) == int((idx == r).sum())
+        assert (np.diff(pos.numpy()) > 0).all()                                    # position order kept inside a row
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -56,11 +56,26 @@ for name, dst, hdr in (("/tmp/r03n.out", "r03_eval_workgroup_target.txt", "greed
                        ("/tmp/r03k2.out", "r03_spmm_group_width.txt", "bench.gnn_legs with OEA_SPMM_G = lanes per row of the aggregate at 64 < ld <= 128")):
     if os.path.exists(name):
         text([l for l in open(name) if l.startswith(("WGS=", "G="))], dst, hdr)
-f = os.path.join(G, "r03m2", "rdgcn_epochs.txt")
+f = os.path.join(G, "r03u", "rdgcn_epochs.txt")
 if os.path.exists(f):
     text([l for l in open(f) if "epochs:" in l or "get_neg" in l or "negative set" in l], "r03_rdgcn_mining.txt",
-         "RDGCN: ms per epoch over 20 epochs, and one hard-negative mining call (20,000 x 200,000 x 300 at the 100K shape) through the all-pairs "
-         "fp64 strip (exact_strip=True) and through the fp32 pre-filter + exact fp64 re-rank (default)")
+         "RDGCN: ms per epoch over 20 epochs (fused GCN block on / off), and one hard-negative mining call (20,000 x 200,000 x 300 at the "
+         "100K shape) through the all-pairs fp64 strip, the fp32 pre-filter and the certified 16-bit grid pre-filter (default), each "
+         "followed by the exact fp64 re-rank; 'uncertified' = seeds the certificate sent to the all-pairs path")
+for src, dst, hdr, keep in (
+        ("r03y3/gemm_tn.txt", "r03_gemm_tn.txt", "tools/_exp/gemm_tn_time.py: dW = X^T dY at E = 200,000, library (torch.mm) vs oea_gemm_tn_f32", "M="),
+        ("r03ab/l1_eval.txt", "r03_l1_grid_eval.txt", "tools/_exp/l1_eval_time.py: manhattan evaluation 70,000^2 x 300, all-pairs fp64 vs 16-bit grid distances + "
+         "exact decisions (ranks and nearest candidates compared)", ""),
+        ("r03af/select_phases.txt", "r03_select_phases.txt", "tools/r03_af.sh: symmetric neighbour search 100,000^2, k = 2,000, ms per call UNDER the tracer with "
+         "list_select_kernel leaving after phase N (OEA_TOPK_SELECT_STOP; 0 = complete)", "STOP"),
+        ("r03ag2/knn.txt", "r03_knn_times.txt", "tools/_exp/knn_time.py (random unit rows) and knn_trained.py (tables after 400 training steps)", ""),
+        ("r03ae/csls_time.txt", "r03_csls_eval.txt", "tools/_exp/csls_time.py: greedy alignment with and without CSLS", "eval")):
+    f = os.path.join(G, src)
+    if os.path.exists(f):
+        text([l for l in open(f) if keep in l], dst, hdr)
+copy(os.path.join(G, "r03w", "MTransE_15k_kernel_stats.csv"), "r03_MTransE_15k_kernel_stats.csv")
+copy(os.path.join(G, "r03ad", "l1_eval_kernel_stats.csv"), "r03_l1_grid_eval_kernel_stats.csv")
+copy(os.path.join(G, "r03ad", "csls70k_kernel_stats.csv"), "r03_csls70k_kernel_stats.csv")
 f = os.path.join(G, "r03g", "determinism.txt")
 if os.path.exists(f):
     text(open(f).readlines(), "r03_determinism.txt", "tools/_exp/alinet_determinism.py: two single-process runs from the same seeds")
