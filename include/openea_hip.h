@@ -459,10 +459,12 @@ int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t n
  * row0 .. row0 + rows of e1 against all nc rows of e2; step = the grid's step, err = the bound on |distance - G step|):
  * rank[row0 + r] / argmax[row0 + r] as oea_rank_eval(OEA_METRIC_MANHATTAN) gives them -- candidates whose grid distance
  * leaves no doubt are counted from the strip, the others by their exact similarity (sequential fp64 chain).
- * gold of row i = column gold_offset + i. */
+ * gold of row i = column gold_offset + i.  n_exact_rows (may be NULL): incremented for every row whose candidate lists
+ * overflowed and which therefore evaluated every pair exactly inside the kernel -- many of them mean the table's range makes
+ * the grid's error bound useless and the all-pairs kernel (oea_rank_eval) is the faster path. */
 int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
                           const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err, int32_t *rank,
-                          int32_t *argmax, void *stream);
+                          int32_t *argmax, int32_t *n_exact_rows, void *stream);
 /* exact fp64 L1 distances of a candidate list: out[i, j] = sum_k |q[i, k] - table[cand[i, j], k]| (fixed summation order).
  * With OEA_METRIC_MANHATTAN_F32 + oea_topk_rows this is RDGCN's hard-negative mining (approaches/rdgcn.py:75-87) without the
  * fp64 distance of every (seed, entity) pair: fp32 ranks k + margin candidates, these are re-ranked exactly. */

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
                                                                 int64_t ld, const float *__restrict__ e1, int ld1,
                                                                 const float *__restrict__ e2, int ld2, int dim, int64_t gold_off,
                                                                 float step, float err, int32_t *__restrict__ rank,
-                                                                int32_t *__restrict__ argmax) {
+                                                                int32_t *__restrict__ argmax, int32_t *__restrict__ n_exact_rows) {
     extern __shared__ double lds_d[];                              // qs [dim] (padded to even), then the lists
     double *qs = lds_d;
     int32_t *amb = reinterpret_cast<int32_t *>(qs + ((dim + 1) & ~1));
@@ -1159,7 +1159,9 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
     int extra = 0;
     unsigned long long best = 0ull;
     if (namb > kGridAmb || ntop > kGridTop) {
-        // every pair exactly (the lists overflowed)
+        // every pair exactly (the lists overflowed); counted, so that the caller can leave the grid path when a table's
+        // range makes its error bound useless (a few outliers stretch the grid: most candidates become doubtful)
+        if (tid == 0 && n_exact_rows) atomicAdd(n_exact_rows, 1);
         for (int64_t j = tid; j < nc; j += 256) {
             const float v = exact_l1_sim(qs, e2 + j * ld2, dim);
             extra += (j != g) && (v > sg || (v == sg && j < g));
@@ -2044,7 +2046,7 @@ int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t n
 
 int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
                           const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err, int32_t *rank,
-                          int32_t *argmax, void *stream) {
+                          int32_t *argmax, int32_t *n_exact_rows, void *stream) {
     OEA_REQUIRE(strip && e1 && e2 && rank && argmax && rows >= 0 && row0 >= 0 && nc > 0 && ld >= nc, "arguments");
     OEA_REQUIRE(ld % 4 == 0 && ((uintptr_t)strip & 15) == 0, "strip rows: 16-byte aligned (ld % 4 == 0)");
     OEA_REQUIRE(dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 4096 && step > 0.f && err >= 0.f, "dim <= 4096, step > 0");
@@ -2052,7 +2054,7 @@ int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_
     if (rows == 0) return OEA_OK;
     const size_t lds = sizeof(double) * (size_t)((dim + 1) & ~1) + sizeof(int32_t) * (kGridAmb + kGridTop);
     rank_l1_grid_rows_kernel<<<(unsigned)rows, 256, lds, oea::as_stream(stream)>>>(strip, rows, row0, nc, ld, e1, ld1, e2, ld2, dim,
-                                                                                   gold_offset, step, err, rank, argmax);
+                                                                                   gold_offset, step, err, rank, argmax, n_exact_rows);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

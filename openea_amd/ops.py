@@ -455,12 +455,25 @@ def rank_eval_l1_grid(e1, e2, dim, gold_offset=0, block_bytes=2 << 30):
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
     rows_per = int(max(128, min(n1, block_bytes // (4 * ld))))
-    for r0 in range(0, n1, rows_per):
+    n_exact = torch.zeros(1, dtype=torch.int32, device=e1.device)
+    r0 = 0
+    while r0 < n1:
         rows = min(rows_per, n1 - r0)
         strip = l1_u16_strip(q1[r0: r0 + rows], q2)
         check(lib().oea_rank_l1_grid_rows(_p(strip), rows, r0, n2, ld, _p(e1), e1.shape[1], _p(e2), e2.shape[1], dim, int(gold_offset),
-                                          float(step), float(err), _p(rank), _p(argmax), _stream()))
+                                          float(step), float(err), _p(rank), _p(argmax), _p(n_exact), _stream()))
         del strip
+        r0 += rows
+        if r0 == rows and r0 < n1 and int(n_exact.item()) > rows // 64:
+            # the grid is useless for this table (outliers stretch its range: most candidates are within the error bound of
+            # the gold distance and whole rows fall back to exact pairs): the rest through the all-pairs fp64 kernel
+            rest = n1 - r0
+            ws = torch.empty(lib().oea_rank_workspace_bytes(rest), dtype=torch.uint8, device=e1.device)
+            rk, am = torch.empty(rest, dtype=torch.int32, device=e1.device), torch.empty(rest, dtype=torch.int32, device=e1.device)
+            check(lib().oea_rank_eval(_p(e1[r0:]), rest, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC['manhattan'], None, None,
+                                      int(gold_offset) + r0, _p(rk), _p(am), _p(ws), _stream()))
+            rank[r0:], argmax[r0:] = rk, am
+            break
     return rank, argmax
 
 

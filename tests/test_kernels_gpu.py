@@ -975,13 +975,15 @@ def test_gemm_tn_matches_float64(ops, m, k1, k2):
     assert torch.allclose(bias.grad, bias2.grad, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("case", ["random", "trained", "clustered", "ties", "degenerate"])
+@pytest.mark.parametrize("case", ["random", "trained", "clustered", "ties", "degenerate", "outliers"])
 def test_manhattan_evaluation_from_grid_distances_equals_all_pairs_fp64(ops, case, monkeypatch):
     """RDGCN's evaluation metric (similarity.py:46-48, alignment.py:146-168): ranks and nearest candidates from 16-bit grid
     distances + exact similarities where the grid leaves a doubt == the all-pairs fp64 kernel (itself bit-exact with scipy's
     cdist, tests above), on random rows, rows whose gold is the nearest ('trained'), tight clusters (hundreds of candidates
-    within the grid's error of the gold distance), exact duplicates of gold columns (the tie rule) and a table of identical
-    rows (every list overflows: the in-kernel all-pairs path); a second block size exercises row0 > 0 and a gold offset."""
+    within the grid's error of the gold distance), exact duplicates of gold columns (the tie rule), a table of identical
+    rows (every list overflows: the in-kernel all-pairs path) and a table with two huge outliers (the grid is useless: the
+    first block goes exact in the kernel, the rest through the all-pairs kernel); a second block size exercises row0 > 0
+    and a gold offset."""
     import torch
     rng = np.random.RandomState(11)
     n1, n2, d = 1500, 4000, 75
@@ -998,6 +1000,9 @@ def test_manhattan_evaluation_from_grid_distances_equals_all_pairs_fp64(ops, cas
         e1 = e2[off:off + n1] + 0.02 * rng.standard_normal((n1, d)).astype(np.float32)
         e2[3000:3400] = e2[off:off + 400]                          # exact copies of gold columns behind them
         e2[0:300] = e2[off + 500:off + 800]                        # ... and in front of them
+    elif case == "outliers":                                       # two huge entries stretch the grid: its error bound exceeds every
+        e1 = e2[off:off + n1] + 0.05 * rng.standard_normal((n1, d)).astype(np.float32)     # distance, whole rows go exact and the
+        e2[5, 3], e2[3999, 70] = 4000.0, -4000.0                   # caller leaves the grid after the first block of rows
     else:
         e2[:] = e2[0]
         e1 = np.repeat(e2[:1], n1, axis=0)
