@@ -323,6 +323,23 @@ __global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__
     select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col);
 }
 
+// The same select with the row held in LDS: ONE read of the strip instead of three (rows of up to ~32,000 columns fit the
+// 160 KB of a CU; 15,000 columns = 60 KB + 16 KB of tables -> two workgroups per CU).  An experiment (see launch_select):
+// the 15,000^2, k = 1,499 search spends 0.85 of its 1.36 ms in the three-read select, but NOT on the re-reads.
+__global__ __launch_bounds__(SEL_THREADS) void row_select_cached_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                        int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                        int32_t *__restrict__ out /* [n_rows, k] */) {
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];          // nc rounded up to 4 floats
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    const float *src = s + (int64_t)blockIdx.x * ld;
+    for (int64_t c = (int64_t)threadIdx.x * 4; c < nc; c += SEL_THREADS * 4)     // ld % 4 == 0: the last 16 B stay inside the row
+        *reinterpret_cast<float4 *>(row_lds + c) = *reinterpret_cast<const float4 *>(src + c);
+    __syncthreads();
+    select_row_3pass(row_lds, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col);
+}
+
 // ---- one-read select for long rows -------------------------------------------------------------------------------
 // A SAMPLE of the row (64 contiguous runs of 128 entries spread over it) gives a bucket threshold that the true
 // k-th largest value clears with ~3 sigma; ONE pass over the row then keeps, per wave and in column order, the
@@ -1017,8 +1034,21 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
 // long rows with k well inside the LDS candidate lists take the one-read kernel
 static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int k, const int32_t *id_map, int32_t *out,
                           hipStream_t st) {
+    // rows that fit the LDS beside the select's tables (<= 128 KB of row: 32,768 columns) CAN be selected from one read
+    // instead of three (OEA_TOPK_SELECT_CACHED=1).  Measured (round 3, gpurun_out r03ag3): 15,000^2, k = 1,499 1.39 -> 1.66 ms --
+    // the re-reads come out of L2 and were not the bound; the histogram / candidate passes are LDS work either way and two
+    // workgroups per CU (76 KB each) hide less of it than the eight of the three-read kernel.  Off by default.
+    static const bool cached_ok = [] {
+        const char *e = getenv("OEA_TOPK_SELECT_CACHED");
+        if (!(e && e[0] == '1')) return false;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(row_select_cached_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   128 * 1024) == hipSuccess;
+    }();
+    const size_t row_bytes = sizeof(float) * (size_t)((nc + 3) / 4 * 4);
     if (nc >= 16384 && (int64_t)k * 5 <= (int64_t)kWaveCap * 4 * 3)        // expected candidates ~1.3 k <= 3/4 of the lists
         row_select_sampled_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+    else if (cached_ok && nc >= 2048 && row_bytes <= 128 * 1024 && (((uintptr_t)s | (uintptr_t)(ld * 4)) & 15) == 0)
+        row_select_cached_kernel<<<(unsigned)n_rows, SEL_THREADS, row_bytes, st>>>(s, n_rows, nc, ld, k, id_map, out);
     else
         row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
 }

@@ -227,10 +227,11 @@ def test_topk_rows_ties_and_ragged(ops, nc, k):
     assert np.array_equal(got, _select_ref(s, k))
 
 
-@pytest.mark.parametrize("nc,k", [(20000, 1500), (16384, 64), (33333, 3000)])
+@pytest.mark.parametrize("nc,k", [(20000, 1500), (16384, 64), (33333, 3000), (12000, 1100), (2052, 700)])
 def test_topk_rows_sampled_path(ops, nc, k):
-    """rows long enough for the one-read (sampled threshold) select, including rows built to defeat the sample:
-    whatever path a row takes, the (value desc, column asc) selection is the oracle's."""
+    """rows long enough for the one-read (sampled threshold) select, including rows built to defeat the sample, and rows of
+    2,048 .. 32,768 columns that the select holds in LDS (one read of the strip; tie-heavy rows take its radix path on the
+    LDS copy): whatever path a row takes, the (value desc, column asc) selection is the oracle's."""
     import torch
     rng = np.random.RandomState(nc + k)
     ld = (nc + 31) // 32 * 32
