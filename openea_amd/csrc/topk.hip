@@ -145,7 +145,7 @@ __device__ __forceinline__ int lin_bin(float v, float lo, float scale) {
 // the three-read select of one row (every thread of the workgroup calls it)
 __device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int k, const int32_t *__restrict__ id_map,
                                  int32_t *__restrict__ o, int *hist /*[kBins]*/, uint32_t *c_key /*[kCandCap]*/,
-                                 int *c_col /*[kCandCap]*/) {
+                                 int *c_col /*[kCandCap]*/, int stop_after = 0 /* experiments: leave after phase N */) {
     __shared__ float s_red[8];
     __shared__ int s_bstar, s_need, s_ncand, s_gt[4], s_cbefore[4], s_tcol;
     __shared__ uint32_t s_tkey;
@@ -224,6 +224,7 @@ __device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int 
     }
     __syncthreads();
     const int bstar = s_bstar, need = s_need;
+    if (stop_after == 1) return;
     if (hist[bstar] > kCandCap) {                       // block-uniform
         __syncthreads();
         radix_select_row(src, nc, k, id_map, o, hist);
@@ -261,6 +262,7 @@ __device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int 
     for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off, 64);
     if (lane == 0) s_gt[wave] = gt;
     __syncthreads();
+    if (stop_after == 2) return;
     // exact rank of every candidate by (value desc, column asc)
     const int ncand = s_ncand;
     for (int i = tid; i < ncand; i += SEL_THREADS) {
@@ -280,6 +282,7 @@ __device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int 
     __syncthreads();
     const uint32_t tkey = s_tkey;
     const int tcol = s_tcol;
+    if (stop_after == 3) return;
     int running = s_cbefore[wave];
     for (int w = 0; w < wave; ++w) running += s_gt[w];
 
@@ -314,13 +317,172 @@ __device__ void select_row_3pass(const float *__restrict__ src, int64_t nc, int 
     }
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
-                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
-                                                                 int32_t *__restrict__ out /* [n_rows, k] */) {
+// The same select for rows of <= 1024 * TPW columns with the row held in REGISTERS: every wave loads its contiguous quarter
+// of the row once (TPW float4 per lane, all requests in flight together) and the three passes of select_row_3pass run on
+// the registers.  The three-read kernel exposed the L2 latency twelve times per row (3 passes x 4 trips of 4 tiles); at
+// 15,000 columns the select was 0.85 ms of the 1.36 ms search (read 1 + histogram 0.32, read 2 0.12, read 3 0.38).
+// The bucket range is the row's exact [min, max] here (it was a 1,024-entry sample); the selection is exact either way.
+template <int TPW>
+__device__ void select_row_regs(const float *__restrict__ src, int64_t nc, int k, const int32_t *__restrict__ id_map,
+                                int32_t *__restrict__ o, int *hist /*[kBins]*/, uint32_t *c_key /*[kCandCap]*/,
+                                int *c_col /*[kCandCap]*/) {
+    __shared__ float s_red[8];
+    __shared__ int s_bstar, s_need, s_ncand, s_gt[4], s_cbefore[4], s_tcol;
+    __shared__ uint32_t s_tkey;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tiles = (nc + 255) / 256;
+    const int64_t tiles_per_wave = (tiles + 3) / 4;                // <= TPW (checked by the launcher)
+    const int64_t seg0 = wave * tiles_per_wave * 256;
+    const int64_t seg1 = seg0 + tiles_per_wave * 256 < nc ? seg0 + tiles_per_wave * 256 : nc;
+    float4 v[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {                                // ld % 4 == 0: a 16 B load at c0 < nc stays inside the row
+        const int64_t c0 = seg0 + u * 256 + lane * 4;
+        v[u] = c0 < seg1 ? *reinterpret_cast<const float4 *>(src + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int b = tid; b < kBins; b += SEL_THREADS) hist[b] = 0;
+    if (tid < 4) { s_gt[tid] = 0; s_cbefore[tid] = 0; }
+    if (tid == 0) s_ncand = 0;
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int64_t c0 = seg0 + u * 256 + lane * 4;
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c0 + i < seg1) { mn = fminf(mn, vv[i]); mx = fmaxf(mx, vv[i]); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) { s_red[wave] = mn; s_red[4 + wave] = mx; }
+    __syncthreads();
+    const float lo = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+    const float hi = fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7]));
+    const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
+    // ---- pass 1: histogram ----------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int64_t c0 = seg0 + u * 256 + lane * 4;
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (c0 + i < seg1) atomicAdd(&hist[lin_bin(vv[i], lo, scale)], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {          // the bucket (from the top) where the cumulative count reaches k
+        constexpr int per = kBins / 64;
+        const int top = kBins - 1 - tid * per;
+        int sum = 0;
+        for (int b = 0; b < per; ++b) sum += hist[top - b];
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += t;
+        }
+        const int before = incl - sum;
+        if (before < k && incl >= k) {
+            int acc = before;
+            for (int b = 0; b < per; ++b) {
+                const int c = hist[top - b];
+                if (acc + c >= k) { s_bstar = top - b; s_need = k - acc; break; }
+                acc += c;
+            }
+        }
+    }
+    __syncthreads();
+    const int bstar = s_bstar, need = s_need;
+    if (hist[bstar] > kCandCap) {                       // block-uniform: tie-heavy row, the radix path re-reads it
+        __syncthreads();
+        radix_select_row(src, nc, k, id_map, o, hist);
+        return;
+    }
+    // ---- pass 2: candidates of bucket b*, per-wave count above it ----------------------------------------
+    int gt = 0;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int64_t c0 = seg0 + u * 256 + lane * 4;
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c0 + i < seg1) {
+                const int b = lin_bin(vv[i], lo, scale);
+                gt += b > bstar;
+                if (b == bstar) {
+                    const int p = atomicAdd(&s_ncand, 1);
+                    c_key[p] = f2ord(vv[i]);
+                    c_col[p] = (int)(c0 + i);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) gt += __shfl_xor(gt, off, 64);
+    if (lane == 0) s_gt[wave] = gt;
+    __syncthreads();
+    const int ncand = s_ncand;
+    for (int i = tid; i < ncand; i += SEL_THREADS) {     // exact rank of every candidate by (value desc, column asc)
+        const uint32_t ki = c_key[i];
+        const int ci = c_col[i];
+        int rank = 0;
+        for (int j = 0; j < ncand; ++j) {
+            const uint32_t kj = c_key[j];
+            rank += (kj > ki) || (kj == ki && c_col[j] < ci);
+        }
+        if (rank == need - 1) { s_tkey = ki; s_tcol = ci; }
+        if (rank < need) {
+            for (int w = 1; w < 4; ++w)
+                if (ci < w * tiles_per_wave * 256) atomicAdd(&s_cbefore[w], 1);
+        }
+    }
+    __syncthreads();
+    const uint32_t tkey = s_tkey;
+    const int tcol = s_tcol;
+    int running = s_cbefore[wave];
+    for (int w = 0; w < wave; ++w) running += s_gt[w];
+    // ---- pass 3: ordered compaction (tiles in column order) ------------------------------------------------
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int64_t c0 = seg0 + u * 256 + lane * 4;
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        bool sel[4];
+        uint64_t bal[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t key = f2ord(vv[i]);
+            sel[i] = (c0 + i < seg1) && (key > tkey || (key == tkey && (int)(c0 + i) <= tcol));
+            bal[i] = __ballot(sel[i]);
+        }
+        if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;
+        int p = running + __popcll(bal[0] & lt) + __popcll(bal[1] & lt) + __popcll(bal[2] & lt) + __popcll(bal[3] & lt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (sel[i]) o[p++] = id_map ? id_map[c0 + i] : (int32_t)(c0 + i);
+        running += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+    }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(SEL_THREADS) void row_select_regs_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                      int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                      int32_t *__restrict__ out /* [n_rows, k] */) {
     __shared__ int hist[kBins];
     __shared__ uint32_t c_key[kCandCap];
     __shared__ int c_col[kCandCap];
-    select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col);
+    select_row_regs<TPW>(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void row_select_kernel(const float *__restrict__ s, int64_t n_rows, int64_t nc,
+                                                                 int64_t ld, int k, const int32_t *__restrict__ id_map,
+                                                                 int32_t *__restrict__ out /* [n_rows, k] */, int stop_after) {
+    __shared__ int hist[kBins];
+    __shared__ uint32_t c_key[kCandCap];
+    __shared__ int c_col[kCandCap];
+    select_row_3pass(s + (int64_t)blockIdx.x * ld, nc, k, id_map, out + (int64_t)blockIdx.x * k, hist, c_key, c_col, stop_after);
 }
 
 // The same select with the row held in LDS: ONE read of the strip instead of three (rows of up to ~32,000 columns fit the
@@ -1045,12 +1207,21 @@ static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld
                                    128 * 1024) == hipSuccess;
     }();
     const size_t row_bytes = sizeof(float) * (size_t)((nc + 3) / 4 * 4);
+    // rows of <= 16,384 columns: the row in registers, one read (OEA_TOPK_SELECT_REGS=0: the three-read kernel)
+    static const bool regs_on = [] { const char *e = getenv("OEA_TOPK_SELECT_REGS"); return !(e && e[0] == '0'); }();
+    const bool aligned16 = (((uintptr_t)s | (uintptr_t)(ld * 4)) & 15) == 0;
     if (nc >= 16384 && (int64_t)k * 5 <= (int64_t)kWaveCap * 4 * 3)        // expected candidates ~1.3 k <= 3/4 of the lists
         row_select_sampled_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
     else if (cached_ok && nc >= 2048 && row_bytes <= 128 * 1024 && (((uintptr_t)s | (uintptr_t)(ld * 4)) & 15) == 0)
         row_select_cached_kernel<<<(unsigned)n_rows, SEL_THREADS, row_bytes, st>>>(s, n_rows, nc, ld, k, id_map, out);
+    else if (regs_on && nc <= 4096 && aligned16)
+        row_select_regs_kernel<4><<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+    else if (regs_on && nc <= 8192 && aligned16)
+        row_select_regs_kernel<8><<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+    else if (regs_on && nc <= 16384 && aligned16)
+        row_select_regs_kernel<16><<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
     else
-        row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out);
+        row_select_kernel<<<(unsigned)n_rows, SEL_THREADS, 0, st>>>(s, n_rows, nc, ld, k, id_map, out, select_stop());
 }
 
 // Work items of the symmetric sweep on an ABSOLUTE grid of candidate chunks: item (c, qt) = candidate tiles
