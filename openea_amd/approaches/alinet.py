@@ -69,7 +69,7 @@ def no_weighted_adj(total_ent_num, triple_list):
 
 def remove_unlinked_triples(triples, linked_ents):
     """alinet.py:240-247."""
-    return list({(h, r, t) for h, r, t in triples if h in linked_ents and t in linked_ents})
+    return sorted({(h, r, t) for h, r, t in triples if h in linked_ents and t in linked_ents})      # sorted: see AKG
 
 
 def generate_rel_ht(triples):
@@ -297,7 +297,12 @@ class AKG:
 
     def __init__(self, triples):
         self.triples = set(triples)
-        self.triple_list = list(self.triples)
+        # SORTED, like every list of modules/load/kg.py: the reference takes list(set) (alinet.py:463), whose order changes with
+        # PYTHONHASHSEED through the insertion order of the set it is built from.  Everything derived from this list by
+        # position -- the relation batches (generate_rel_batch indexes rel_ht_dict's lists), the ties of the 2-hop pattern
+        # ranking -- must be the same in every process of a data-parallel job and from run to run (round 3: a two-rank job
+        # differed from the single-process job by 4e-4 after one epoch in three runs of four, and by 0 in the fourth)
+        self.triple_list = sorted(self.triples)
         self.triples_num = len(self.triples)
         self.heads = {t[0] for t in self.triple_list}
         self.tails = {t[2] for t in self.triple_list}

@@ -105,6 +105,9 @@ with contextlib.redirect_stdout(buf):
     _loss = a.compute_loss(_emb, _pos, _neg, _valid) + a.compute_rel_loss(_emb, torch.as_tensor(_hs, device=a.dev), torch.as_tensor(_ts, device=a.dev))
     _loss.backward()
     alinet_grads = {"alinet_g%02d" % i: (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().numpy() for i, p in enumerate(a._params)}
+    alinet_grads.update(alinet_in_neg=_neg.cpu().numpy(), alinet_in_valid=_valid.cpu().numpy(), alinet_in_pos=np.asarray(_pos.cpu() if hasattr(_pos, "cpu") else _pos),
+                        alinet_in_hs=np.asarray(_hs), alinet_in_ts=np.asarray(_ts), alinet_in_loss=np.asarray(float(_loss.detach())),
+                        alinet_in_emb=_emb.detach().cpu().numpy())
     for p in a._params:
         p.grad = None
     a._rng.set_state(_st)
@@ -205,12 +208,17 @@ def test_two_ranks_reproduce_single_process(tmp_path, capsys):
         print("\nAliNet two ranks vs single process: forward before training %.2e, after 1 Adam epoch %.2e, after 4 epochs %.2e "
               "(relative L2); GCN-Align outputs max abs %.2e"
               % (rel("alinet_fwd0"), rel("alinet_ep1"), d_alinet, float(np.abs(r0["gcn_out"] - single["gcn_out"]).max())))
+        for key in sorted(k for k in single if k.startswith("alinet_in_")):
+            if not np.array_equal(r0[key], single[key]):
+                print("   first batch %s: sharded vs single DIFFER (%d entries)" % (key, int((r0[key] != single[key]).sum())))
         for key in sorted(k for k in single if k.startswith("alinet_g")):
             if not np.array_equal(r0[key], single[key]):
                 print("   gradient %s %s: sharded vs single max abs %.2e (|g| max %.2e), differing entries %d"
                       % (key, single[key].shape, float(np.abs(r0[key] - single[key]).max()), float(np.abs(single[key]).max()),
                          int((r0[key] != single[key]).sum())))
-    assert d_alinet <= float(os.environ.get("OEA_ALINET_2RANK_TOL", "5e-3"))
+    # round 3: bit-identical (0.00e+00) since the sparse operators have no atomics, the weight gradients a fixed summation order
+    # and AliNet's triple list a canonical order (it was list(set): the relation batches followed PYTHONHASHSEED)
+    assert d_alinet <= float(os.environ.get("OEA_ALINET_2RANK_TOL", "1e-6"))
     for key in ("mtranse", "bootea", "transd", "rotate", "transh", "bootea_transh"):
         assert np.array_equal(r0[key], r1[key])
         assert np.linalg.norm(r0[key] - single[key]) <= 1e-3 * np.linalg.norm(single[key])
