@@ -68,12 +68,26 @@ for src, dst, hdr, keep in (
          "exact decisions (ranks and nearest candidates compared)", ""),
         ("r03af/select_phases.txt", "r03_select_phases.txt", "tools/r03_af.sh: symmetric neighbour search 100,000^2, k = 2,000, ms per call UNDER the tracer with "
          "list_select_kernel leaving after phase N (OEA_TOPK_SELECT_STOP; 0 = complete)", "STOP"),
-        ("r03ag2/knn.txt", "r03_knn_times.txt", "tools/_exp/knn_time.py (random unit rows) and knn_trained.py (tables after 400 training steps)", ""),
+        ("r03ag4/knn.txt", "r03_knn_times.txt", "tools/_exp/knn_time.py (random unit rows) and knn_trained.py (tables after 400 training steps)", ""),
         ("r03ae/csls_time.txt", "r03_csls_eval.txt", "tools/_exp/csls_time.py: greedy alignment with and without CSLS", "eval")):
     f = os.path.join(G, src)
     if os.path.exists(f):
         text([l for l in open(f) if keep in l], dst, hdr)
 copy(os.path.join(G, "r03w", "MTransE_15k_kernel_stats.csv"), "r03_MTransE_15k_kernel_stats.csv")
+copy(os.path.join(G, "r03ak", "knn15_kernel_stats.csv"), "r03_knn15k_kernel_stats.csv")
+f = os.path.join(G, "r03al", "row_select_phases.txt")
+if os.path.exists(f):
+    text(open(f).readlines(), "r03_row_select_phases.txt", "15,000^2, k = 1,499 neighbour search, ms per call with row_select_kernel leaving after "
+         "phase N (OEA_TOPK_SELECT_STOP: 1 = histogram + bucket, 2 = candidate pass, 3 = ranking; 0 = complete)")
+lines = []
+for i in (1, 2, 3, 4):
+    for tag in ("r03an", "r03an2"):
+        f = os.path.join(G, tag, "pytest_%d.log" % i)
+        if os.path.exists(f):
+            lines += ["%s run %d: %s" % ("list(set) order" if tag == "r03an" else "sorted order  ", i, l) for l in open(f) if "AliNet two ranks" in l or "first batch" in l]
+if lines:
+    text(lines, "r03_alinet_two_ranks.txt", "tests/test_dist_gpu.py::test_two_ranks_reproduce_single_process, four runs each with AliNet's triple list as "
+         "list(set) (hash-seed dependent) and sorted")
 copy(os.path.join(G, "r03ad", "l1_eval_kernel_stats.csv"), "r03_l1_grid_eval_kernel_stats.csv")
 copy(os.path.join(G, "r03ad", "csls70k_kernel_stats.csv"), "r03_csls70k_kernel_stats.csv")
 f = os.path.join(G, "r03g", "determinism.txt")
