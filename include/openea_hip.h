@@ -343,6 +343,22 @@ int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, floa
                                  void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                                  int32_t rank, int32_t world, void *stream);
 
+/* The steps [step_begin, step_end) of a data-parallel epoch under the partition from ONE call, over the C ABI's own
+ * communicator (oea_comm_*, declared below): per step GRAD on this rank's share of the batch (rows nb*rank/world ..
+ * nb*(rank+1)/world of batch s, as oea_triple_epoch_range_shard) -> oea_part_pack -> reduce-scatter + relation all-reduce ->
+ * oea_part_apply (+ oea_step_apply_normals for TransH) -> all-gather -> oea_part_unpack, all enqueued on `stream` with no host
+ * work in between.  Buffers as above: send [world * rpr * (ld + 1)], own [rpr * (ld + 1)], rel_x [n_rel * (ld + 1)], upd
+ * [rpr, ld], all [world, rpr, ld]; acc_own [rpr, ld] (Adagrad).  The other arguments as oea_triple_epoch_range. */
+struct oea_comm;
+int oea_triple_epoch_range_comm(struct oea_comm *comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
+                                int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
+                                int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, float *send, float *own, float *rel_x,
+                                float *upd, float *all, void *stream);
+
+
 /* Negative LINKS of AliNet.generate_input_batch (approaches/alinet.py:988-1006), drawn on the device.
  *   uniform   (nbr1 == NULL): pair q = round * n_pos + i, round < k:  (ents1[pi1_round(i)], ents2[pi2_round(i)])
  *             -- zip(random.sample(ents1, n_pos), random.sample(ents2, n_pos)) per round; needs n_pos <= n1, n2;

@@ -131,6 +131,9 @@ PROTOTYPES = {
     "oea_triple_epoch_range_shard": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                          C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
                                          C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "oea_triple_epoch_range_comm": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                        C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
+                                        C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oea_rotate_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oea_rotate_exchange_doubles": (_sz, [_i64, _i64, _i32]),
     "oea_rotate_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _i32,

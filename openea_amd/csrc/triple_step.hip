@@ -1516,4 +1516,81 @@ int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, floa
     return OEA_OK;
 }
 
+// The steps [step_begin, step_end) of a data-parallel epoch under the entity-id partition, enqueued by ONE call: per step
+// GRAD on this rank's share of the batch -> pack -> reduce-scatter (RCCL) + all-reduce of the relation rows -> optimiser on
+// the owned rows -> all-gather -> unpack; everything on `stream`, no host work between the steps (driven from Python the
+// exchange costs six library calls and three torch.distributed calls per step).  The communicator is the C ABI's own
+// (oea_comm_*: RCCL through dlopen), so a non-Python host runs the same job.  Buffers as in the step-by-step protocol
+// (include/openea_hip.h): send [world * rpr * (ld + 1)], own [rpr * (ld + 1)], rel_x [n_rel * (ld + 1)], upd [rpr, ld],
+// all [world, rpr, ld]; acc_own = the optimiser state of the owned rows.  TransH: the normal vectors' scratch is all-reduced
+// and applied on every rank.  Same Philox streams as the single-GPU epoch; result = the step-by-step partitioned job.
+int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
+                                int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
+                                int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, float *send, float *own, float *rel_x,
+                                float *upd, float *all, void *stream) {
+    OEA_REQUIRE(comm && pos_all && offsets_host && splits_host && cfg && send && own && rel_x && upd && all, "null pointer");
+    OEA_REQUIRE(steps >= 0 && k >= 0 && 0 <= step_begin && step_begin <= step_end && step_end <= steps, "step range");
+    OEA_REQUIRE((offsets_dev == nullptr) == (splits_dev == nullptr), "offsets_dev and splits_dev go together");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || cfg->opt_kind == OEA_OPT_ADAGRAD, "the partition runs SGD / Adagrad");
+    const int32_t world = oea_comm_size(comm), rank = oea_comm_rank(comm);
+    const bool presampled = k > 0 && side0 == nullptr && side1 == nullptr && offsets_dev != nullptr;
+    OEA_REQUIRE(k == 0 || (neg_buf && (presampled || (err_flag && side0 && side1))), "sampling needs neg_buf, err_flag and both sides");
+    const bool ahead = k > 0 && offsets_dev != nullptr && steps > 0;
+    const bool sample_all = ahead && !presampled && step_begin == 0;
+    if (sample_all) {
+        const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0, side1, seed,
+                                                  step_base, 10, neg_buf, err_flag, stream);
+        if (rc != OEA_OK) return rc;
+    }
+    const int64_t rpr = oea_part_rows_per_rank(n_ent, world);
+    const int64_t chunk = rpr * (ld + 1);
+    const bool transh = cfg->score_kind == OEA_SCORE_TRANSH;
+    float *nrm_grad = nullptr, *nrm_touched = nullptr;
+    if (transh) {
+        int64_t g_off = 0, t_off = 0;
+        int rc = oea_step_normal_scratch(n_ent, n_rel, ld, &g_off, &t_off);
+        if (rc != OEA_OK) return rc;
+        nrm_grad = reinterpret_cast<float *>(static_cast<char *>(workspace) + g_off);
+        nrm_touched = reinterpret_cast<float *>(static_cast<char *>(workspace) + t_off);
+    }
+    oea_step_cfg step_cfg = *cfg;
+#define OEA_TRY_RC(call) do { const int _rc = (call); if (_rc != OEA_OK) return _rc; } while (0)
+    for (int32_t s = step_begin; s < step_end; ++s) {
+        const int64_t b0 = offsets_host[s], nb = offsets_host[s + 1] - b0;
+        if (nb <= 0) continue;
+        const int64_t r_lo = nb * rank / world, r_hi = nb * (rank + 1) / world;
+        const int64_t lo = b0 + r_lo, n = r_hi - r_lo;
+        int64_t split = splits_host[s] - r_lo;
+        split = split < 0 ? 0 : (split > n ? n : split);
+        const int32_t *pos = pos_all + 3 * lo;
+        int32_t *negs = ahead ? neg_buf + 3 * lo * (int64_t)k : neg_buf;
+        if (n > 0 && k > 0 && !presampled && !sample_all)
+            OEA_TRY_RC(oea_sample_negatives_pair(pos, n, split, k, side0, side1, seed, step_base + (uint32_t)s, (uint32_t)r_lo, 10, negs,
+                                                 err_flag, stream));
+        // every rank takes part in every exchange, also with an empty share of the batch (n == 0: nothing scored)
+        OEA_TRY_RC(oea_triple_step_phase(ent, nullptr, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n, k > 0 ? negs : nullptr, n * (int64_t)k,
+                                         &step_cfg, workspace, loss_accum, OEA_PHASE_GRAD, stream));
+        OEA_TRY_RC(oea_part_pack(workspace, n_ent, n_rel, ld, world, send, rel_x, stream));
+        OEA_TRY_RC(oea_comm_reduce_scatter_f32(comm, send, own, chunk, stream));
+        OEA_TRY_RC(oea_allreduce_f32(comm, rel_x, n_rel * (int64_t)(ld + 1), stream));
+        if (transh) {
+            OEA_TRY_RC(oea_allreduce_f32(comm, nrm_grad, n_rel * (int64_t)ld, stream));
+            OEA_TRY_RC(oea_allreduce_f32(comm, nrm_touched, n_rel, stream));
+        }
+        const bool grouped = step_cfg.neg_group_k > 0 || step_cfg.loss_kind == OEA_LOSS_MARGIN;
+        const int64_t n_items = grouped ? n : n + n * (int64_t)k;
+        OEA_TRY_RC(oea_part_apply(ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, own, rel_x, upd, &step_cfg, workspace, n_items,
+                                  loss_accum, stream));
+        if (transh) OEA_TRY_RC(oea_step_apply_normals(n_ent, n_rel, ld, &step_cfg, workspace, stream));
+        OEA_TRY_RC(oea_allgather_rows(comm, upd, all, rpr, ld, stream));
+        OEA_TRY_RC(oea_part_unpack(ent, n_ent, ld, world, rank, all, stream));
+        ++step_cfg.opt_t;
+    }
+#undef OEA_TRY_RC
+    return OEA_OK;
+}
+
 }  // extern "C"

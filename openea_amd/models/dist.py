@@ -109,6 +109,27 @@ def allgather_blocks(full, bounds, group=None):
     return full
 
 
+def c_abi_comm(group=None):
+    """The C ABI's own communicator (oea_comm_*: RCCL through dlopen, one GPU per rank) over the ranks of `group`; rank 0's
+    128-byte id travels through torch.distributed.  Used by the one-call partitioned epoch (oea_triple_epoch_range_comm)."""
+    import ctypes as C
+    from .. import ops
+    from .._lib import check
+    rank, ws = world(group)
+    lib = ops.lib()
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        check(lib.oea_comm_unique_id(uid))
+    box = [bytes(uid.raw) if rank == 0 else None]
+    if ws > 1:
+        src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+    buf = (C.c_char * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    check(lib.oea_comm_init(buf, rank, ws, C.byref(comm)))
+    return comm
+
+
 def allreduce_sum_(t, group=None):
     _, ws = world(group)
     if ws > 1:

@@ -49,6 +49,11 @@ class EmbeddingTable:
         return self.var[:self.visible_rows, :self.dim].cpu().numpy()
 
 
+def cfg_allows_c_epoch(cfg):
+    """the one-call partitioned epoch covers what the partition covers (SGD / Adagrad, TransE / TransH / TransD scores)"""
+    return cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD)
+
+
 class TripleTrainer:
     def __init__(self, ent, rel, cfg, optimizer='Adagrad', dist_group=None, replicated=False, exchange=None):
         """replicated=True (with a dist_group): every rank feeds the SAME full batch (small steps that are not worth
@@ -163,6 +168,15 @@ class TripleTrainer:
         else:
             p['acc_own'] = None
         self.part = p
+        # OEA_DP_C_EPOCH=1: the epoch's partitioned steps from ONE C call over the C ABI's own RCCL communicator
+        # (oea_triple_epoch_range_comm) instead of six library calls + three torch.distributed calls per step.  Opt-in: RCCL
+        # wants one GPU per rank, so the build pool (one GPU) could only run it with a single rank
+        # (tests/test_partition_gpu.py::test_partitioned_epoch_from_one_c_call_single_rank).
+        self.comm = None
+        import os as _os
+        if _os.environ.get("OEA_DP_C_EPOCH") == "1" and cfg_allows_c_epoch(self.cfg):
+            from . import dist as mdist
+            self.comm = mdist.c_abi_comm(self.dist)
 
     def _step_partitioned(self, pos, neg):
         """GRAD | pack | reduce-scatter + relation all-reduce | apply owned rows | all-gather | unpack"""
@@ -363,9 +377,10 @@ class RelationTripleEpochs:
         S = len(self.batches.splits)
         b = self.batches
         local = self.world > 1 and getattr(trainer, "local_epochs", False)
+        c_part = getattr(trainer, "comm", None) is not None and getattr(trainer, "part", None) is not None   # one C call, RCCL inside
         if local and lo == 0:
             trainer.epoch_begin()
-        if (self.world == 1 or local) and getattr(trainer, "fused_epoch", True):
+        if (self.world == 1 or local or c_part) and getattr(trainer, "fused_epoch", True):
             if self._sides is None:
                 self._sides = (self.s1.side(), self.s2.side())
             main = torch.cuda.current_stream()
@@ -380,19 +395,28 @@ class RelationTripleEpochs:
             have = self.k and self._epoch_negs_ready
             if hasattr(trainer, "count_steps"):
                 trainer.count_steps(int((np.diff(b.offsets[lo:hi + 1]) > 0).sum()))
-            ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
-                             b.dall, b.offsets, b.splits, self.k,
-                             None if (have or not self.k) else self._sides[0],
-                             None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
-                             self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
-                             trainer.ws, trainer.loss, self._off_dev if self.k else None,
-                             self._spl_dev if self.k else None, step_range=(lo, hi),
-                             shard=(self.rank, self.world) if local else (0, 1))
+            if c_part:
+                ops.triple_epoch_comm(trainer.comm, trainer.ent.var, trainer.part['acc_own'], trainer.rel.var, trainer.rel_acc,
+                                      trainer.ent.dim, b.dall, b.offsets, b.splits, self.k,
+                                      None if (have or not self.k) else self._sides[0],
+                                      None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
+                                      self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
+                                      trainer.ws, trainer.loss, self._off_dev if self.k else None,
+                                      self._spl_dev if self.k else None, trainer.part, step_range=(lo, hi))
+            else:
+                ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
+                                 b.dall, b.offsets, b.splits, self.k,
+                                 None if (have or not self.k) else self._sides[0],
+                                 None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
+                                 self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
+                                 trainer.ws, trainer.loss, self._off_dev if self.k else None,
+                                 self._spl_dev if self.k else None, step_range=(lo, hi),
+                                 shard=(self.rank, self.world) if local else (0, 1))
             if lo == 0 and self.k:
                 self._epoch_negs_ready = True             # a range that starts the epoch draws all its negatives
             self.global_step += hi - lo
             n = int(b.offsets[hi] - b.offsets[lo])
-            if local:                                     # this rank's share of those batches
+            if local or (c_part and self.world > 1):      # this rank's share of those batches
                 nb = np.diff(b.offsets[lo:hi + 1])
                 n = int((nb * (self.rank + 1) // self.world - nb * self.rank // self.world).sum())
             if ev_start is not None:

@@ -346,6 +346,41 @@ def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, s
                                        _p(offsets_dev), _p(splits_dev), int(shard[0]), int(shard[1]), _stream()))
 
 
+def comm_single_or_none():
+    """a one-rank communicator of the C ABI (tests): (handle, destroy)"""
+    uid = (C.c_char * 128)()
+    check(lib().oea_comm_unique_id(uid))
+    comm = C.c_void_p()
+    check(lib().oea_comm_init(uid, 0, 1, C.byref(comm)))
+    return comm
+
+
+def part_buffers(n_ent, n_rel, ld, world, dev, adagrad=True):
+    """the exchange buffers of the partitioned step (include/openea_hip.h) + the optimiser state of the owned rows"""
+    rpr = lib().oea_part_rows_per_rank(int(n_ent), int(world))
+    chunk = rpr * (ld + 1)
+    f = dict(dtype=torch.float32, device=dev)
+    return dict(rpr=rpr, chunk=chunk, send=torch.empty(world * chunk, **f), own=torch.empty(chunk, **f),
+                rel_x=torch.empty(n_rel * (ld + 1), **f), upd=torch.empty((rpr, ld), **f), all=torch.empty((world, rpr, ld), **f),
+                acc_own=torch.full((rpr, ld), 0.1, **f) if adagrad else None)
+
+
+def triple_epoch_comm(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base, neg_buf,
+                      err_flag, cfg, workspace, loss_accum, offsets_dev, splits_dev, bufs, step_range=None):
+    """steps [lo, hi) of a data-parallel epoch under the entity-id partition from ONE C call over the C ABI's communicator
+    (oea_triple_epoch_range_comm); bufs = part_buffers(...)."""
+    steps = len(splits)
+    lo, hi = (0, steps) if step_range is None else step_range
+    check(lib().oea_triple_epoch_range_comm(comm, _p(ent), _p(acc_own), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+                                            ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
+                                            splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
+                                            C.byref(side0) if side0 is not None else None,
+                                            C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
+                                            _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
+                                            _p(offsets_dev), _p(splits_dev), _p(bufs['send']), _p(bufs['own']), _p(bufs['rel_x']),
+                                            _p(bufs['upd']), _p(bufs['all']), _stream()))
+
+
 def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None, row2=None,
                           exclude=None, seed=0, step=0, scratch=None):
     """AliNet.generate_input_batch negatives on the device -> (pairs int32 [m, 2], valid fp32 [m]).

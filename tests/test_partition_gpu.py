@@ -142,3 +142,122 @@ def test_comm_group_of_the_c_abi_single_rank():
                        stderr=subprocess.STDOUT, timeout=180)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "COMM_OK" in out, out[-3000:]
+
+
+EPOCH_COMM_WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["OEA_ROOT"])
+from openea_amd import ops
+from openea_amd.models.trainer import EmbeddingTable, TripleTrainer
+torch.cuda.set_device(0)
+rng = np.random.RandomState(7)
+n_ent, n_rel, d, B, k, steps = 1003, 19, 40, 900, 3, 5
+ent_h = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32)
+rel_h = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32)
+pos = np.stack([rng.randint(0, n_ent, steps * B), rng.randint(0, n_rel, steps * B), rng.randint(0, n_ent, steps * B)], 1).astype(np.int32)
+neg = np.repeat(pos, k, 0)
+neg[:, 2] = rng.randint(0, n_ent, len(neg))
+offsets = (np.arange(steps + 1) * B).astype(np.int64)
+offsets[3] -= 37                                                  # ragged batches
+splits = np.full(steps, B // 2, np.int64)
+dev = torch.device("cuda:0")
+pos_d, neg_d = ops.to_ids(pos), ops.to_ids(neg)
+off_d, spl_d = torch.from_numpy(offsets).to(dev), torch.from_numpy(splits).to(dev)
+res = {}
+for mode in ("plain", "comm"):
+    for opt in ("Adagrad", "SGD"):
+        cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer=opt, lr=0.02,
+                                neg_group_k=k)
+        ent, rel = EmbeddingTable(ent_h, True, "e"), EmbeddingTable(rel_h, True, "r")
+        tr = TripleTrainer(ent, rel, cfg, opt)
+        tr.count_steps(steps)
+        if mode == "plain":
+            ops.triple_epoch(ent.var, tr.ent_acc, rel.var, tr.rel_acc, d, pos_d, offsets, splits, k, None, None, 1, 0, neg_d, None, tr.cfg,
+                             tr.ws, tr.loss, off_d, spl_d)
+            acc = tr.ent_acc
+        else:
+            comm = ops.comm_single_or_none()
+            bufs = ops.part_buffers(n_ent, n_rel, ent.ld, 1, dev, adagrad=opt == "Adagrad")
+            ops.triple_epoch_comm(comm, ent.var, bufs["acc_own"], rel.var, tr.rel_acc, d, pos_d, offsets, splits, k, None, None, 1, 0, neg_d,
+                                  None, tr.cfg, tr.ws, tr.loss, off_d, spl_d, bufs)
+            torch.cuda.synchronize()
+            ops.check(ops.lib().oea_comm_destroy(comm))
+            acc = bufs["acc_own"]
+        torch.cuda.synchronize()
+        res[mode + opt] = (ent.raw(), rel.raw(), None if acc is None else acc.cpu().numpy(), float(tr.loss.item()))
+for opt in ("Adagrad", "SGD"):
+    a, b = res["plain" + opt], res["comm" + opt]
+    for x, y, name in ((a[0], b[0], "entity table"), (a[1], b[1], "relation table"), (a[2], b[2], "accumulator")):
+        if x is None:
+            continue
+        err = float(np.abs(x - y).max() / max(np.abs(x).max(), 1e-30))
+        assert err <= 2e-6, (opt, name, err)
+    assert abs(a[3] - b[3]) <= 1e-6 * abs(a[3]), (opt, a[3], b[3])
+    assert float(np.abs(a[0] - ent_h).max()) > 1e-3               # the epoch did move the tables
+print("EPOCH_COMM_OK")
+'''
+
+
+def test_partitioned_epoch_from_one_c_call_single_rank():
+    """oea_triple_epoch_range_comm: the steps of an epoch under the entity-id partition (GRAD -> pack -> RCCL reduce-scatter +
+    all-reduce -> owned apply -> all-gather -> unpack) enqueued by ONE call over the C ABI's own communicator.  With the one
+    rank this box can give RCCL every collective is the identity and the result must be the single-GPU epoch call's (tables,
+    Adagrad state, loss; ragged batches); more ranks need more GPUs (the step-by-step protocol it strings together is covered
+    with 2 and 4 ranks through torch.distributed above)."""
+    p = subprocess.run([sys.executable, "-c", EPOCH_COMM_WORKER], env=dict(os.environ, OEA_ROOT=ROOT), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "EPOCH_COMM_OK" in out, out[-3000:]
+
+
+TRAINER_COMM_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["OEA_ROOT"])
+torch.cuda.set_device(0)
+from openea_amd import ops
+from openea_amd.models.trainer import EmbeddingTable, RelationTripleEpochs, TripleTrainer
+from openea_amd.modules.load.synth import make_kgs
+kgs = make_kgs("small", mode="swapping", seed=0)
+rng = np.random.RandomState(2)
+d, k = 32, 4
+ent_h = (rng.standard_normal((kgs.entities_num, d)) / np.sqrt(d)).astype(np.float32)
+rel_h = (rng.standard_normal((kgs.relations_num, d)) / np.sqrt(d)).astype(np.float32)
+out = {}
+for mode in ("plain", "c_epoch"):
+    group = None
+    if mode == "c_epoch":
+        os.environ["OEA_DP_C_EPOCH"] = "1"
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["OEA_PORT"], rank=0, world_size=1)
+        group = dist.group.WORLD
+    cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.02,
+                            neg_group_k=k)
+    ent, rel = EmbeddingTable(ent_h, True, "e"), EmbeddingTable(rel_h, True, "r")
+    tr = TripleTrainer(ent, rel, cfg, "Adagrad", dist_group=group)
+    assert (tr.part is not None and tr.comm is not None) == (mode == "c_epoch")
+    ep = RelationTripleEpochs(kgs, 700, k, seed=3)
+    n = sum(ep.run_epoch(tr) for _ in range(3))
+    torch.cuda.synchronize()
+    out[mode] = (ent.raw(), rel.raw(), tr.pop_loss(), n)
+a, b = out["plain"], out["c_epoch"]
+assert a[3] == b[3] and a[3] > 0
+for x, y in ((a[0], b[0]), (a[1], b[1])):
+    assert float(np.abs(x - y).max() / np.abs(x).max()) <= 1e-5, float(np.abs(x - y).max())
+assert abs(a[2] - b[2]) <= 1e-5 * abs(a[2])
+assert float(np.abs(a[0] - ent_h).max()) > 1e-3
+print("TRAINER_COMM_OK")
+'''
+
+
+def test_trainer_runs_the_partitioned_epoch_from_one_c_call():
+    """OEA_DP_C_EPOCH=1: TripleTrainer builds the C ABI's communicator over its process group and RelationTripleEpochs hands the
+    epoch to oea_triple_epoch_range_comm (sampler ahead on the side stream, device shuffle, ranges, loss read-back as in the
+    single-GPU path).  One rank (what RCCL can get on this box): three epochs equal the plain single-GPU trainer's."""
+    p = subprocess.run([sys.executable, "-c", TRAINER_COMM_WORKER], env=dict(os.environ, OEA_ROOT=ROOT, OEA_PORT=str(_free_port())),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0 and "TRAINER_COMM_OK" in out, out[-3000:]
