@@ -10,12 +10,17 @@ A "step" = the negatives of one batch drawn on the device + one fused optimiser 
 does it (RelationTripleEpochs.run_steps -> oea_triple_epoch_range: ONE C call per epoch touched, next epoch's shuffle
 and negatives on a side stream).  value = positives (training triples) consumed per second, whole job.
 
-  python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
+  python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong] [--exchange step|epoch|allreduce]
 
 N > 1: `python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1, one process per GPU,
-RCCL); started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  --scaling weak (default): every GPU
-keeps --batch positives per step (the global batch grows with N -- named in config.workload); strong: the global batch
-stays --batch.
+RCCL); started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  The N > 1 headline is BASELINE.json's
+sharded configuration: the EN-FR-100K-V1 shape (dim 100, GLOBAL batch 20,000 = bootea_args_100K.json, eps 0.98) under STRONG
+scaling (every rank scores 20,000 / N positives of every batch) with the PARITY-PRESERVING exchange (--exchange step: entity
+rows owned by id mod N, reduce-scatter of the gradients, optimiser on the owned rows, all-gather of the updated rows -- the
+N-rank job equals the single-GPU job), one C call per epoch over the C ABI's RCCL communicator
+(oea_triple_epoch_range_comm), with HIP-event phase times.  The same configuration on ONE GPU is timed in the same run
+(extra.single_gpu_same_config), so the speed-up does not depend on another line.  --exchange epoch (local SGD, one exchange
+per epoch: drifts from the single-GPU job, tests/test_dist_gpu.py) and --scaling weak are named side legs in `extra`.
 
 Timing: W untimed warm-up steps, then the K-step region -- barrier + synchronize on both sides, MAX over ranks --
 is timed --repeats times (default 50) and the MEDIAN region is reported (a single region is ~1 ms at this shape: one
@@ -62,21 +67,40 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=50, help="timed K-step regions (median reported)")
-    ap.add_argument("--dim", type=int, default=75)
-    ap.add_argument("--shape", default="EN-FR-15K-V1")
-    ap.add_argument("--batch", type=int, default=5000, help="positives per GPU per step (weak) / per job (strong)")
+    ap.add_argument("--dim", type=int, default=None, help="default: 75 (15K shapes, BASELINE config 2) / 100 (100K shapes)")
+    ap.add_argument("--shape", default=None, help="default: EN-FR-15K-V1 at N = 1, EN-FR-100K-V1 at N > 1")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="positives per GPU per step (weak) / per job (strong); default 5,000 (15K shapes) / 20,000 (100K shapes)")
     ap.add_argument("--neg", type=int, default=10)
-    ap.add_argument("--eps", type=float, default=0.9, help="truncated_epsilon")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--exchange", choices=("epoch", "step", "allreduce"), default="epoch",
-                    help="N > 1: how the ranks exchange (models/trainer.py:TripleTrainer).  epoch (default; BASELINE.json north_star): "
-                         "local steps on each rank's share of the batch, one exchange per epoch; step: per-step reduce-scatter / "
-                         "all-gather, the G-rank job equals the single-GPU job.  The other mode is measured too (extra.other_exchange)")
+    ap.add_argument("--eps", type=float, default=None, help="truncated_epsilon; default 0.9 (15K) / 0.98 (100K)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong at N > 1 (the BASELINE batch)")
+    ap.add_argument("--exchange", choices=("epoch", "step", "allreduce"), default="step",
+                    help="N > 1: how the ranks exchange (models/trainer.py:TripleTrainer).  step (default): per-step reduce-scatter / "
+                         "all-gather under the entity-id partition, the N-rank job EQUALS the single-GPU job; epoch: local steps on "
+                         "each rank's share of the batch, one exchange per epoch (local SGD: drifts).  The other mode is measured too "
+                         "(extra.other_exchange)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour / 100K-shape legs")
     ap.add_argument("--no-gnn", action="store_true", help="skip the GNN legs (BASELINE configs 3-5)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE / WRITE_SIZE passes")
     return ap.parse_args()
+
+
+def resolve_defaults(args, world):
+    """N = 1: BASELINE config 2 (EN-FR-15K-V1, dim 75, batch 5,000).  N > 1: the sharded configuration of BASELINE.json's
+    north_star -- EN-FR-100K-V1, dim 100, the shipped batch of 20,000 (bootea_args_100K.json) kept GLOBAL (strong scaling)."""
+    if args.shape is None:
+        args.shape = "EN-FR-100K-V1" if world > 1 else "EN-FR-15K-V1"
+    big = "100K" in args.shape
+    if args.dim is None:
+        args.dim = 100 if big else 75
+    if args.batch is None:
+        args.batch = 20000 if big else 5000
+    if args.eps is None:
+        args.eps = 0.98 if big else 0.9
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
+    return args
 
 
 def _free_port():
@@ -100,26 +124,47 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+KGS_CACHE_VERSION = 2        # bump when modules/load/synth.py:make_kgs changes what it generates
+
+
+def _cache_dir():
+    """a directory only this user can write (0700, owned by us, not a symlink): the synthetic-KG cache is a pickle, and a
+    pickle from a path another user could have pre-created is code execution"""
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "oea_bench_cache_%d" % os.getuid())
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.lstat(d)
+        import stat
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None
+        return d
+    except OSError:
+        return None
+
+
 def cached_kgs(shape, mode):
-    """synthetic KG pair of a BASELINE shape (seed 0); pickled under /tmp so that the child runs of this bench (the
-    rocprofv3 counter passes) and the other ranks do not rebuild it"""
+    """synthetic KG pair of a BASELINE shape (seed 0); pickled in a private directory so that the child runs of this bench
+    (the rocprofv3 counter passes) and the other ranks do not rebuild it"""
     import pickle
     from openea_amd.modules.load.synth import make_kgs
-    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "oea_bench_kgs_%s_%s_%d.pkl" % (shape, mode, os.getuid()))
-    if os.path.exists(p):
+    d = _cache_dir()
+    p = os.path.join(d, "kgs_v%d_%s_%s.pkl" % (KGS_CACHE_VERSION, shape, mode)) if d else None
+    if p and os.path.exists(p):
         try:
-            with open(p, "rb") as f:
-                return pickle.load(f)
+            if os.lstat(p).st_uid == os.getuid():
+                with open(p, "rb") as f:
+                    return pickle.load(f)
         except Exception:
             pass
     kgs = make_kgs(shape, mode=mode, seed=0)
-    try:
-        tmp = p + ".%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            pickle.dump(kgs, f, protocol=pickle.HIGHEST_PROTOCOL)
-        os.replace(tmp, p)
-    except Exception:
-        pass
+    if p:
+        try:
+            tmp = p + ".%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                pickle.dump(kgs, f, protocol=pickle.HIGHEST_PROTOCOL)
+            os.replace(tmp, p)
+        except Exception:
+            pass
     return kgs
 
 
@@ -191,6 +236,23 @@ class Workload:
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(times=t.cpu().numpy(), pos=c.cpu().numpy(), pos_local=np.asarray(pos, np.float64),
                     fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss)
+
+    def phase_times(self, steps):
+        """N > 1, one C call per epoch (oea_triple_epoch_range_comm): HIP events at the phase boundaries of `steps` further
+        steps -> microseconds per step and phase on this rank (the collectives' events include the wait for the slowest rank)"""
+        comm = getattr(self.trainer, "comm", None)
+        if comm is None or self.trainer.part is None:
+            return {"note": "exchange mode '%s' is not driven by the one-call partitioned epoch: no phase events" % self.trainer.exchange}
+        comm.profile_begin()
+        self.epochs.run_steps(self.trainer, steps)
+        self.barrier()
+        ms, n = comm.profile_end()
+        out = {"%s_us" % k: round(v / max(n, 1) * 1e3, 2) for k, v in ms.items()}
+        out.update({"steps_timed": n, "sum_us": round(sum(ms.values()) / max(n, 1) * 1e3, 2), "communicator": comm.description(),
+                    "note": "HIP events on the launch stream at the phase boundaries of oea_triple_epoch_range_comm, rank 0; "
+                            "reduce_scatter includes the small all-reduce of the relation rows; events between the phases stop "
+                            "the kernels from pipelining, so sum_us is a little above ms_per_step"})
+        return out
 
     def summarize(self, m, steps, traffic=None):
         """median region -> (value, ms_per_step, roofline dict)"""
@@ -324,6 +386,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    resolve_defaults(args, world)
     if os.environ.get("OEA_BENCH_ONE_GPU"):       # test hook: all ranks share GPU 0 (with OEA_BENCH_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -347,6 +410,8 @@ def main():
                   args.exchange)
     m = wl.measure(args.steps, args.warmup, args.repeats)
     extra = {}
+    if world > 1:
+        extra["exchange_phases"] = wl.phase_times(args.steps)                      # every rank takes part
     if not args.no_extra:                   # eval / neighbour legs: row-sharded over the ranks (every rank takes part)
         extra.update(extra_legs(torch, ops, wl.ent, wl.kgs, args.dim, wl.k1))
     multi = None
@@ -381,10 +446,13 @@ def main():
         extra.update(multi or {})
         extra["collective_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else backend
         extra["collective_world_size"] = dist.get_world_size()
+        one = (multi or {}).get("single_gpu_same_config")
+        if one:
+            extra["speedup_vs_single_gpu_same_config"] = round(value / one["value"], 4)
     cpu = None
     if not args.no_cpu and world == 1:
         cpu = cpu_baseline(wl.kgs, args.dim, args, wl.k1, wl.k2)
-    if not args.no_extra and world == 1 and args.shape == "EN-FR-15K-V1":
+    if not args.no_extra and world == 1 and args.shape == "EN-FR-15K-V1" and args.dim == 75:
         del wl
         torch.cuda.empty_cache()
         extra["shape_100k"] = shape_100k(torch, ops, dev, args)
@@ -402,13 +470,16 @@ def main():
         "repeats": args.repeats, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BootEA/AlignE translational step, %s shape (synthetic), dim=%d, GLOBAL batch=%d positives (%s "
-                               "scaling: %g per GPU x %d GPU%s%s), k=%d, truncated eps=%.2f; extra.shape_100k: EN-FR-100K-V1 "
-                               "shape, dim=100, batch=20000, eps=0.98"
+                               "scaling: %g per GPU x %d GPU%s%s), k=%d, truncated eps=%.2f%s"
                                % (args.shape, args.dim, args.batch * world if args.scaling == "weak" else args.batch, args.scaling,
                                   per_gpu, world, "s" if world > 1 else "",
                                   "; the shipped configuration is batch=%d: N>1 weak scaling trains with a LARGER global batch "
                                   "than any BASELINE configuration" % args.batch if (world > 1 and args.scaling == "weak") else "",
-                                  args.neg, args.eps),
+                                  args.neg, args.eps,
+                                  "; extra.shape_100k: EN-FR-100K-V1 shape, dim=100, batch=20000, eps=0.98" if world == 1 else
+                                  " = BASELINE.json's sharded configuration (bootea_args_100K.json: dim 100, batch 20,000) when the "
+                                  "shape is EN-FR-100K-V1; the N = 1 line of this bench is BASELINE config 2 (EN-FR-15K-V1, dim 75, "
+                                  "batch 5,000) -- the same configuration on one GPU is extra.single_gpu_same_config"),
                    "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
                    "entities": extra_entities(args.shape),
                    "parallelism": ("dp%d, exchange = %s: %s" % (world, extra.get("exchange_mode"), extra.get("exchange")))
@@ -425,32 +496,50 @@ def main():
 
 
 def multi_gpu_legs(torch, ops, dev, args, rank, world, group, main_wl):
-    """N > 1 only, every rank: the OTHER exchange mode on the same shape (fewer regions) and the EN-FR-100K-V1 shape in the
-    main mode -- BASELINE.json asks for both shapes at 1 / 2 / 4 / 8 GPUs."""
+    """N > 1 only, every rank.  (1) the SAME configuration on one GPU, timed in this run (every rank runs it on its own GPU,
+    no collective; rank 0's number is reported) -- the reference point of the speed-up; (2) the side legs: the other exchange
+    mode on the same shape, weak scaling, and the EN-FR-15K-V1 shape (BASELINE config 2's batch of 5,000 kept global)."""
     import torch.distributed as dist
     out = {}
 
-    def run(shape, dim, batch, eps, exchange, steps, warmup, repeats):
+    def run(shape, dim, batch, eps, exchange, scaling, steps, warmup, repeats, single=False):
         if rank == 0:
             cached_kgs(shape, "swapping")
         dist.barrier()
-        wl = Workload(torch, ops, shape, dim, batch, args.neg, eps, dev, rank, world, group, args.scaling, exchange)
+        if single:
+            wl = Workload(torch, ops, shape, dim, batch, args.neg, eps, dev)
+        else:
+            wl = Workload(torch, ops, shape, dim, batch, args.neg, eps, dev, rank, world, group, scaling, exchange)
         m = wl.measure(steps, warmup, repeats)
         value, ms, _ = wl.summarize(m, steps)
-        ep_b = wl.trainer.epoch_exchange_bytes()
-        xb = int(ep_b / max(wl.steps_per_epoch, 1)) if wl.trainer.local_epochs else wl.trainer.exchange_bytes_per_step()
-        res = {"shape": shape, "exchange_mode": wl.trainer.exchange, "value": round(value, 1), "unit": "triples/s",
-               "ms_per_step": round(ms, 4), "steps": steps, "repeats": repeats, "global_batch": wl.global_batch,
-               "triple_steps_per_epoch": wl.steps_per_epoch, "exchange_bytes_per_step_per_rank": xb}
+        res = {"shape": shape, "value": round(value, 1), "unit": "triples/s", "ms_per_step": round(ms, 4), "steps": steps,
+               "repeats": repeats, "global_batch": wl.global_batch, "triple_steps_per_epoch": wl.steps_per_epoch}
+        if not single:
+            ep_b = wl.trainer.epoch_exchange_bytes()
+            xb = int(ep_b / max(wl.steps_per_epoch, 1)) if wl.trainer.local_epochs else wl.trainer.exchange_bytes_per_step()
+            res.update({"exchange_mode": wl.trainer.exchange, "scaling": scaling, "exchange_bytes_per_step_per_rank": xb})
+            if wl.trainer.local_epochs:
+                res["parity"] = ("local SGD with one exchange per epoch: NOT the single-GPU job (2.9e-2 relative L2 drift of the "
+                                 "entity table after 6 epochs at 2 ranks, tests/test_dist_gpu.py); reported as a side leg only")
+        dist.barrier()
         del wl
         torch.cuda.empty_cache()
         return res
-    other = "step" if main_wl.trainer.exchange == "epoch" else "epoch"
-    out["other_exchange"] = run(args.shape, args.dim, args.batch, args.eps, other, args.steps, min(args.warmup, 5), 5)
-    if not args.no_extra and args.shape == "EN-FR-15K-V1":
-        steps = min(args.steps, 58)
-        out["shape_100k"] = run("EN-FR-100K-V1", 100, 20000, 0.98, main_wl.trainer.exchange, steps, min(args.warmup, 5), 5)
-        out["shape_100k_other_exchange"] = run("EN-FR-100K-V1", 100, 20000, 0.98, other, steps, min(args.warmup, 5), 3)
+    big = "100K" in args.shape
+    steps = min(args.steps, 58) if big else args.steps
+    wu = min(args.warmup, 5)
+    one = run(args.shape, args.dim, args.batch, args.eps, None, None, steps, wu, 5, single=True)
+    one["note"] = "the same shape / dim / batch / k on ONE GPU (rank 0's; every rank ran it on its own GPU at the same time)"
+    out["single_gpu_same_config"] = one
+    other = "epoch" if main_wl.trainer.exchange != "epoch" else "step"
+    out["other_exchange"] = run(args.shape, args.dim, args.batch, args.eps, other, args.scaling, steps, wu, 5)
+    if not args.no_extra and not os.environ.get("OEA_BENCH_ONE_GPU"):       # (the one-GPU wiring test stops here: host-staged collectives)
+        out["other_scaling"] = run(args.shape, args.dim, args.batch, args.eps, args.exchange, "weak" if args.scaling == "strong" else "strong",
+                                   steps, wu, 3)
+        o_shape = ("EN-FR-15K-V1", 75, 5000, 0.9) if big else ("EN-FR-100K-V1", 100, 20000, 0.98)
+        o_steps = min(args.steps, 58) if not big else args.steps
+        out["other_shape"] = run(*o_shape, args.exchange, args.scaling, o_steps, wu, 5)
+        out["other_shape_single_gpu"] = run(*o_shape, None, None, o_steps, wu, 5, single=True)
     return out
 
 

@@ -79,6 +79,9 @@ int oea_gather_rows(const float *table, int32_t dim, int32_t ld, const int32_t *
  * sk != 0: zero rows stay zero; TF semantics otherwise: x*rsqrt(max(ss,1e-12))) */
 int oea_normalize_rows(float *table, int64_t rows, int32_t dim, int32_t ld, int32_t sk, void *stream);
 int oea_fill_f32(float *p, int64_t n, float value, void *stream);
+/* device <-> host copies ordered on `stream`, complete on return (staging of oea_comm_init_callbacks hosts) */
+int oea_copy_to_host(const void *dev, void *host, size_t bytes, void *stream);
+int oea_copy_from_host(void *dev, const void *host, size_t bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Translational step -- replaces one session.run([triple_loss, triple_optimizer]) of
@@ -152,6 +155,13 @@ int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float
  * bit-identical.  n_pos / n_neg must be repeated unchanged in the APPLY call. */
 enum { OEA_PHASE_BOTH = 0, OEA_PHASE_GRAD = 1, OEA_PHASE_APPLY = 2 };
 size_t oea_step_exchange_floats(int64_t n_ent, int64_t n_rel, int32_t ld);
+/* Element type of the gradient scratch, the touched flags and every buffer of the partition protocol that carries them
+ * (`send`, `own`, `rel_x` below): 4 = fp32 accumulated with hardware fp32 atomics (libopenea_hip.so); 8 = int64 FIXED POINT
+ * with 32 fractional bits accumulated with 64-bit integer atomics (libopenea_hip_det.so, the same sources built with
+ * -DOEA_DET_SCRATCH): integer sums do not depend on the order of the atomics, so a job gives the same bits run to run and
+ * for any number of ranks (the collectives then sum int64: OEA_COMM_I64).  oea_step_exchange_floats counts ELEMENTS of this
+ * type. */
+int32_t oea_step_scratch_elem_bytes(void);
 int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
                           int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
@@ -174,10 +184,10 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
  * SGD / Adagrad, TransE score.  Result = the single-process step on the concatenated batch. */
 int64_t oea_part_rows_per_rank(int64_t n_ent, int32_t world);
 size_t oea_part_send_floats(int64_t n_ent, int32_t ld, int32_t world);
-int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, float *send, float *rel_x,
+int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, void *send, void *rel_x,
                   void *stream);
 int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t ld,
-                   int32_t world, int32_t rank, float *own, float *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
+                   int32_t world, int32_t rank, void *own, void *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
                    int64_t n_items, double *loss_accum, void *stream);
 int oea_part_unpack(float *ent, int64_t n_ent, int32_t ld, int32_t world, int32_t rank, const float *all, void *stream);
 /* TransH under the entity-id partition (approaches/bootea_transh.py:58-96): the normal-vector table is relation-sized and
@@ -242,7 +252,7 @@ int oea_rotate_lookup(const double *ent, int64_t n_ent, int32_t dim, int32_t ld,
 size_t oea_mapping_workspace_floats(int64_t n_links, int32_t ld, int32_t dim);
 int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_norm, const int32_t *ids1,
                      const int32_t *ids2, int64_t n, float *M, float *M_acc, float alpha, float lr, int32_t opt_kind,
-                     float *ent_grad, float *ent_touched, float *work, double *loss_accum, void *stream);
+                     void *ent_grad, void *ent_touched, float *work, double *loss_accum, void *stream);
 /* A whole mapping epoch (approaches/mtranse.py:84-96) enqueued by ONE call: `steps` x (oea_mapping_step on the step's n links +
  * the apply phase of the step engine with `cfg`).  batches: device int32 [steps, 2, n].  Single process only (a data-parallel
  * job exchanges the scratch between the two halves of every step). */
@@ -251,8 +261,8 @@ int oea_mapping_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, flo
                       float alpha, float lr, int32_t opt_kind, const oea_step_cfg *cfg, void *workspace, float *work,
                       double *mapping_loss_accum, double *step_loss_accum, void *stream);
 /* addresses of the entity gradient scratch and its touched flags inside a step workspace */
-int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, float **ent_grad,
-                            float **ent_touched);
+int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, void **ent_grad,
+                            void **ent_touched);
 
 /* ---------------------------------------------------------------------------------------
  * Negative sampling -- replaces generate_neg_triples_fast (modules/train/batch.py:89-119).
@@ -355,7 +365,7 @@ int oea_triple_epoch_range_comm(struct oea_comm *comm, float *ent, float *acc_ow
                                 const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
                                 const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
                                 int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
-                                const int64_t *offsets_dev, const int64_t *splits_dev, float *send, float *own, float *rel_x,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, void *send, void *own, void *rel_x,
                                 float *upd, float *all, void *stream);
 
 
@@ -750,6 +760,17 @@ int oea_build_2hop(const int32_t *tri, int64_t n_tri, const int32_t *full_tri, i
 typedef struct oea_comm *oea_comm_t;
 int oea_comm_unique_id(void *id_out_128);
 int oea_comm_init(const void *unique_id_128, int32_t rank, int32_t nranks, oea_comm_t *out);
+/* A communicator over HOST CALLBACKS instead of RCCL: every collective of the entry points below (and of
+ * oea_triple_epoch_range_comm) is handed to `fn`: op = OEA_COMM_*, send / recv = device pointers, count = elements PER RANK
+ * (all-gather: elements of every rank's send block; reduce-scatter: elements of every rank's recv block; all-reduce:
+ * elements of the buffer, send == recv), dtype = OEA_COMM_F32 / F64 / I64.  The callback must order itself after the work
+ * already enqueued on `stream` and leave the result visible to work enqueued after it returns; it returns 0 on success.
+ * RCCL needs one GPU per rank: with callbacks over torch.distributed's gloo group the build pool's ONE GPU runs the call path
+ * with 2 and 4 ranks (tests/test_partition_gpu.py). */
+enum { OEA_COMM_ALLREDUCE = 0, OEA_COMM_ALLGATHER = 1, OEA_COMM_REDUCE_SCATTER = 2 };
+enum { OEA_COMM_F32 = 0, OEA_COMM_F64 = 1, OEA_COMM_I64 = 2 };
+typedef int (*oea_comm_callback)(void *user, int32_t op, const void *send, void *recv, int64_t count, int32_t dtype, void *stream);
+int oea_comm_init_callbacks(int32_t rank, int32_t nranks, oea_comm_callback fn, void *user, oea_comm_t *out);
 int oea_comm_destroy(oea_comm_t c);
 int32_t oea_comm_rank(oea_comm_t c);
 int32_t oea_comm_size(oea_comm_t c);
@@ -760,6 +781,16 @@ int oea_comm_reduce_scatter_f32(oea_comm_t c, const float *send, float *recv, in
 int oea_allreduce_f32(oea_comm_t c, float *buf, int64_t n, void *stream);
 int oea_allreduce_f64(oea_comm_t c, double *buf, int64_t n, void *stream);
 int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream);
+/* the same three collectives for any of the dtypes (the deterministic build exchanges int64 fixed-point gradients) */
+int oea_comm_allgather(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream);
+int oea_comm_reduce_scatter(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream);
+int oea_comm_allreduce(oea_comm_t c, void *buf, int64_t n, int32_t dtype, void *stream);
+/* Phase times of oea_triple_epoch_range_comm: between _begin and _end every step records HIP events at its phase boundaries
+ * on the call's stream; _end waits for the last one and returns the summed milliseconds per phase
+ * (GRAD | pack | reduce-scatter + relation all-reduce | apply | all-gather | unpack) and the number of steps recorded. */
+enum { OEA_COMM_PHASES = 6 };
+int oea_comm_profile_begin(oea_comm_t c);
+int oea_comm_profile_end(oea_comm_t c, double *phase_ms /* [OEA_COMM_PHASES] */, int32_t *steps);
 
 #ifdef __cplusplus
 }

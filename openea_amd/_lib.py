@@ -7,8 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OPENEA_HIP_LIB: load another build of the same library (kernel experiments); default = the in-tree build
-LIB_PATH = os.environ.get("OPENEA_HIP_LIB") or os.path.join(_HERE, "csrc", "libopenea_hip.so")
+# OPENEA_HIP_LIB: load another build of the same library (kernel experiments); default = the in-tree build.
+# OEA_STEP_DETERMINISTIC=1: the build whose translational step accumulates its gradients in int64 fixed point
+# (libopenea_hip_det.so, csrc/common.h): the same bits run to run and for any number of ranks.
+DETERMINISTIC = os.environ.get("OEA_STEP_DETERMINISTIC", "0")[:1] == "1"
+LIB_PATH = os.environ.get("OPENEA_HIP_LIB") or os.path.join(_HERE, "csrc",
+                                                            "libopenea_hip_det.so" if DETERMINISTIC else "libopenea_hip.so")
 
 
 class OpenEAHipError(RuntimeError):
@@ -99,10 +103,13 @@ PROTOTYPES = {
     "oea_gather_rows": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _vp]),
     "oea_normalize_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp]),
     "oea_fill_f32": (C.c_int, [_vp, _i64, _f32, _vp]),
+    "oea_copy_to_host": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "oea_copy_from_host": (C.c_int, [_vp, _vp, _sz, _vp]),
     "oea_step_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oea_triple_step": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
                                   C.POINTER(StepCfg), _vp, _vp, _vp]),
     "oea_step_exchange_floats": (_sz, [_i64, _i64, _i32]),
+    "oea_step_scratch_elem_bytes": (_i32, []),
     "oea_triple_step_phase": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64,
                                         C.POINTER(StepCfg), _vp, _vp, _i32, _vp]),
     "oea_part_rows_per_rank": (_i64, [_i64, _i32]),
@@ -212,7 +219,19 @@ PROTOTYPES = {
     "oea_allreduce_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "oea_allreduce_f64": (C.c_int, [_vp, _vp, _i64, _vp]),
     "oea_allreduce_i64": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "oea_comm_init_callbacks": (C.c_int, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),
+    "oea_comm_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "oea_comm_reduce_scatter": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "oea_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "oea_comm_profile_begin": (C.c_int, [_vp]),
+    "oea_comm_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i32)]),
 }
+
+# oea_comm_callback: int (*)(void *user, int32 op, const void *send, void *recv, int64 count, int32 dtype, void *stream)
+COMM_CALLBACK = C.CFUNCTYPE(C.c_int, _vp, _i32, _vp, _vp, _i64, _i32, _vp)
+COMM_ALLREDUCE, COMM_ALLGATHER, COMM_REDUCE_SCATTER = 0, 1, 2
+COMM_F32, COMM_F64, COMM_I64 = 0, 1, 2
+COMM_PHASES = ("grad", "pack", "reduce_scatter", "apply", "all_gather", "unpack")
 
 def tile_glds():
     """the packed (LDS-DMA) tile path is on unless OEA_TILE_GLDS=0 (csrc/sim_rank.hip)"""

@@ -9,8 +9,15 @@
 //
 // RCCL is resolved with dlopen at oea_comm_init time: libopenea_hip.so has no link-time dependency on it, a single-GPU
 // process never loads it, and a process that already holds an RCCL (PyTorch's) shares that copy.
+//
+// A communicator can also be built over HOST CALLBACKS (oea_comm_init_callbacks): the same entry points then hand every
+// collective to the caller's function.  RCCL wants one GPU per rank; with the callbacks the one-call partitioned epoch
+// (oea_triple_epoch_range_comm) runs with 2 and 4 ranks sharing ONE GPU over torch.distributed's gloo group, which is how
+// the build pool (one GPU) tests the call path a multi-GPU node runs over RCCL.
 #include <dlfcn.h>
 #include <string.h>
+
+#include <vector>
 
 #include "common.h"
 
@@ -64,7 +71,16 @@ static Rccl *rccl() {
 struct oea_comm {
     ncclComm_t comm;
     int rank, nranks;
+    oea_comm_callback fn;           // non-null: every collective goes to the host callback instead of RCCL
+    void *user;
+    // phase profile of oea_triple_epoch_range_comm (oea_comm_profile_begin / _end): events at the phase boundaries
+    bool profiling;
+    std::vector<hipEvent_t> events;        // OEA_COMM_PHASES + 1 per step
 };
+
+namespace {
+int nccl_dtype(int32_t dtype) { return dtype == OEA_COMM_F32 ? ncclFloat32 : (dtype == OEA_COMM_F64 ? ncclFloat64 : ncclInt64); }
+}
 
 #define OEA_CHECK_RCCL(expr)                                                                       \
     do {                                                                                           \
@@ -93,13 +109,20 @@ int oea_comm_init(const void *unique_id_128, int32_t rank, int32_t nranks, oea_c
     memcpy(&id, unique_id_128, sizeof(id));
     ncclComm_t c = nullptr;
     OEA_CHECK_RCCL(r->CommInitRank(&c, nranks, id, rank));       // binds the calling thread's current HIP device
-    *out = new oea_comm{c, rank, nranks};
+    *out = new oea_comm{c, rank, nranks, nullptr, nullptr, false, {}};
+    return OEA_OK;
+}
+
+int oea_comm_init_callbacks(int32_t rank, int32_t nranks, oea_comm_callback fn, void *user, oea_comm_t *out) {
+    OEA_REQUIRE(fn && out && nranks >= 1 && rank >= 0 && rank < nranks, "arguments");
+    *out = new oea_comm{nullptr, rank, nranks, fn, user, false, {}};
     return OEA_OK;
 }
 
 int oea_comm_destroy(oea_comm_t c) {
     if (!c) return OEA_OK;
-    OEA_CHECK_RCCL(rccl()->CommDestroy(c->comm));
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (!c->fn) OEA_CHECK_RCCL(rccl()->CommDestroy(c->comm));
     delete c;
     return OEA_OK;
 }
@@ -107,34 +130,83 @@ int oea_comm_destroy(oea_comm_t c) {
 int32_t oea_comm_rank(oea_comm_t c) { return c ? c->rank : -1; }
 int32_t oea_comm_size(oea_comm_t c) { return c ? c->nranks : 0; }
 
+#define OEA_CALLBACK(op, send, recv, count, dtype)                                                                      \
+    if (c->fn) {                                                                                                        \
+        const int _rc = c->fn(c->user, op, send, recv, (int64_t)(count), dtype, stream);                                \
+        if (_rc != 0) { oea::set_error("%s:%d: the collective callback returned %d", __FILE__, __LINE__, _rc); return OEA_EHIP; } \
+        return OEA_OK;                                                                                                  \
+    }
+
+int oea_comm_allgather(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream) {
+    OEA_REQUIRE(c && send && recv && n_per_rank >= 0 && dtype >= OEA_COMM_F32 && dtype <= OEA_COMM_I64, "arguments");
+    OEA_CALLBACK(OEA_COMM_ALLGATHER, send, recv, n_per_rank, dtype)
+    OEA_CHECK_RCCL(rccl()->AllGather(send, recv, (size_t)n_per_rank, nccl_dtype(dtype), c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_comm_reduce_scatter(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream) {
+    OEA_REQUIRE(c && send && recv && n_per_rank >= 0 && dtype >= OEA_COMM_F32 && dtype <= OEA_COMM_I64, "arguments");
+    OEA_CALLBACK(OEA_COMM_REDUCE_SCATTER, send, recv, n_per_rank, dtype)
+    OEA_CHECK_RCCL(rccl()->ReduceScatter(send, recv, (size_t)n_per_rank, nccl_dtype(dtype), ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_comm_allreduce(oea_comm_t c, void *buf, int64_t n, int32_t dtype, void *stream) {
+    OEA_REQUIRE(c && buf && n >= 0 && dtype >= OEA_COMM_F32 && dtype <= OEA_COMM_I64, "arguments");
+    OEA_CALLBACK(OEA_COMM_ALLREDUCE, buf, buf, n, dtype)
+    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, nccl_dtype(dtype), ncclSum, c->comm, oea::as_stream(stream)));
+    return OEA_OK;
+}
+#undef OEA_CALLBACK
+
 int oea_allgather_rows(oea_comm_t c, const float *send, float *recv, int64_t rows_per_rank, int32_t ld, void *stream) {
-    OEA_REQUIRE(c && send && recv && rows_per_rank >= 0 && ld > 0, "arguments");
-    OEA_CHECK_RCCL(rccl()->AllGather(send, recv, (size_t)rows_per_rank * ld, ncclFloat32, c->comm, oea::as_stream(stream)));
-    return OEA_OK;
+    OEA_REQUIRE(ld > 0, "arguments");
+    return oea_comm_allgather(c, send, recv, rows_per_rank * ld, OEA_COMM_F32, stream);
 }
-
 int oea_comm_reduce_scatter_f32(oea_comm_t c, const float *send, float *recv, int64_t n_per_rank, void *stream) {
-    OEA_REQUIRE(c && send && recv && n_per_rank >= 0, "arguments");
-    OEA_CHECK_RCCL(rccl()->ReduceScatter(send, recv, (size_t)n_per_rank, ncclFloat32, ncclSum, c->comm, oea::as_stream(stream)));
+    return oea_comm_reduce_scatter(c, send, recv, n_per_rank, OEA_COMM_F32, stream);
+}
+int oea_allreduce_f32(oea_comm_t c, float *buf, int64_t n, void *stream) { return oea_comm_allreduce(c, buf, n, OEA_COMM_F32, stream); }
+int oea_allreduce_f64(oea_comm_t c, double *buf, int64_t n, void *stream) { return oea_comm_allreduce(c, buf, n, OEA_COMM_F64, stream); }
+int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream) { return oea_comm_allreduce(c, buf, n, OEA_COMM_I64, stream); }
+
+// ---- phase profile of the one-call partitioned epoch -----------------------------------------------------------------
+int oea_comm_profile_begin(oea_comm_t c) {
+    OEA_REQUIRE(c, "null communicator");
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->events.clear();
+    c->profiling = true;
     return OEA_OK;
 }
 
-int oea_allreduce_f32(oea_comm_t c, float *buf, int64_t n, void *stream) {
-    OEA_REQUIRE(c && buf && n >= 0, "arguments");
-    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, oea::as_stream(stream)));
-    return OEA_OK;
-}
-
-int oea_allreduce_f64(oea_comm_t c, double *buf, int64_t n, void *stream) {
-    OEA_REQUIRE(c && buf && n >= 0, "arguments");
-    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, c->comm, oea::as_stream(stream)));
-    return OEA_OK;
-}
-
-int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream) {
-    OEA_REQUIRE(c && buf && n >= 0, "arguments");
-    OEA_CHECK_RCCL(rccl()->AllReduce(buf, buf, (size_t)n, ncclInt64, ncclSum, c->comm, oea::as_stream(stream)));
+int oea_comm_profile_end(oea_comm_t c, double *phase_ms, int32_t *steps) {
+    OEA_REQUIRE(c && phase_ms && steps, "null pointer");
+    c->profiling = false;
+    const size_t per = OEA_COMM_PHASES + 1, n = c->events.size() / per;
+    for (int p = 0; p < OEA_COMM_PHASES; ++p) phase_ms[p] = 0.0;
+    if (n) OEA_CHECK_HIP(hipEventSynchronize(c->events[n * per - 1]));
+    for (size_t s_ = 0; s_ < n; ++s_)
+        for (int p = 0; p < OEA_COMM_PHASES; ++p) {
+            float ms = 0.f;
+            OEA_CHECK_HIP(hipEventElapsedTime(&ms, c->events[s_ * per + p], c->events[s_ * per + p + 1]));
+            phase_ms[p] += ms;
+        }
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    c->events.clear();
+    *steps = (int32_t)n;
     return OEA_OK;
 }
 
 }  // extern "C"
+
+// boundary `i` (0 .. OEA_COMM_PHASES) of the current step of oea_triple_epoch_range_comm (triple_step.hip)
+namespace oea {
+int comm_phase_mark(oea_comm_t c, hipStream_t st) {
+    if (!c || !c->profiling) return OEA_OK;
+    hipEvent_t e;
+    OEA_CHECK_HIP(hipEventCreate(&e));
+    OEA_CHECK_HIP(hipEventRecord(e, st));
+    c->events.push_back(e);
+    return OEA_OK;
+}
+}  // namespace oea

@@ -56,6 +56,8 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
                             int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
                             uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st);
 
+int comm_phase_mark(struct ::oea_comm *c, hipStream_t st);      // comm.hip: phase boundary of the one-call partitioned epoch
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -108,6 +110,41 @@ __device__ __forceinline__ double wave_sum_d(double v) { return group_sum_d<64>(
 
 // hardware fp32 atomic add (global_atomic_add_f32, no CAS loop); device scope.
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- gradient scratch of the translational step --------------------------------------------------------------------
+// Two builds of the library from the same sources (csrc/Makefile):
+//   libopenea_hip.so      grad_t = float: hardware fp32 atomics.  The sum of a row's contributions depends on the order the
+//                         atomics arrive in, so two runs of one job differ in the last bits.
+//   libopenea_hip_det.so  (-DOEA_DET_SCRATCH) grad_t = int64 FIXED POINT with 32 fractional bits, 64-bit integer atomics
+//                         (global_atomic_add_x2).  Integer addition is associative: the sum is the same whatever the order --
+//                         run to run, and whether one GPU or G ranks computed the contributions (the partition exchanges
+//                         the int64 sums).  Every contribution is rounded ONCE to the 2^-32 grid (|v| < 2^19; larger values
+//                         saturate), the row sum is exact and rounded once to fp32 when the optimiser reads it: closer to
+//                         the fp64 oracle than any fp32 summation order.  TF sums the duplicate rows of a gather's gradient
+//                         before the optimiser (optimizers.py:4-7): this is that sum, without an order.
+#ifdef OEA_DET_SCRATCH
+typedef long long grad_t;
+typedef long long flag_t;
+constexpr int kDetScratch = 1;
+// float -> round(v * 2^32) as int64: v + 1.5 * 2^20 in fp64 has ulp 2^-32 and keeps its exponent for |v| < 2^19, so the
+// difference of the two bit patterns IS the fixed-point value (one cvt, one fp64 add, one 32-bit subtract)
+__device__ __forceinline__ long long to_fixed(float v) {
+    const float c = __builtin_amdgcn_fmed3f(v, -524287.f, 524287.f);
+    const double d = (double)c + 1572864.0;                       // 1.5 * 2^20 = 0x4138000000000000
+    return __double_as_longlong(d) - 0x4138000000000000LL;
+}
+__device__ __forceinline__ float grad_val(long long q) { return (float)((double)q * 2.3283064365386963e-10); }   // 2^-32
+__device__ __forceinline__ void grad_add(long long *p, float v) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p), (unsigned long long)to_fixed(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+typedef float grad_t;
+typedef float flag_t;
+constexpr int kDetScratch = 0;
+__device__ __forceinline__ float grad_val(float q) { return q; }
+__device__ __forceinline__ void grad_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+#endif
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }

@@ -23,7 +23,7 @@ template <bool M_LDS>
 __global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restrict__ ent, int ld, int dim, int l2norm,
                                                             const int32_t *__restrict__ ids1, const int32_t *__restrict__ ids2,
                                                             int64_t n, const float *__restrict__ Mg, float alpha,
-                                                            float *__restrict__ ent_grad, float *__restrict__ ent_touched,
+                                                            oea::grad_t *__restrict__ ent_grad, oea::flag_t *__restrict__ ent_touched,
                                                             float *__restrict__ e1_out, float *__restrict__ diff_out,
                                                             double *__restrict__ loss_accum) {
     extern __shared__ float lds[];                       // per wave: y1 [dim], diff [dim]; then M [dim x dim] if M_LDS
@@ -66,14 +66,14 @@ __global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restr
             sq += d0 * d0;
             diff_out[i * ld + c0] = d0;
             e1_out[i * ld + c0] = y1[c0];
-            oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c0, 2.f * alpha * d0);
+            oea::grad_add(ent_grad + (int64_t)b * ld + c0, 2.f * alpha * d0);
             if (two) {
                 const float d1 = r2[c1] * i2 - p1;
                 df[c1] = d1;
                 sq += d1 * d1;
                 diff_out[i * ld + c1] = d1;
                 e1_out[i * ld + c1] = y1[c1];
-                oea::atomic_add_f32(ent_grad + (int64_t)b * ld + c1, 2.f * alpha * d1);
+                oea::grad_add(ent_grad + (int64_t)b * ld + c1, 2.f * alpha * d1);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void mapping_links_kernel(const float *__restr
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < dim; k += 64) oea::atomic_add_f32(ent_grad + (int64_t)a * ld + k, -2.f * alpha * y1[k]);
+        for (int k = lane; k < dim; k += 64) oea::grad_add(ent_grad + (int64_t)a * ld + k, -2.f * alpha * y1[k]);
         if (lane == 0) { ent_touched[a] = 1.f; ent_touched[b] = 1.f; }
         sq = oea::group_sum<64>(sq);
         if (lane == 0) loss_local += (double)sq;
@@ -157,7 +157,9 @@ size_t oea_mapping_workspace_floats(int64_t n_links, int32_t ld, int32_t dim) {
 
 int oea_mapping_step(const float *ent, int32_t ld, int32_t dim, int32_t ent_l2_norm, const int32_t *ids1,
                      const int32_t *ids2, int64_t n, float *M, float *M_acc, float alpha, float lr, int32_t opt_kind,
-                     float *ent_grad, float *ent_touched, float *work, double *loss_accum, void *stream) {
+                     void *ent_grad_, void *ent_touched_, float *work, double *loss_accum, void *stream) {
+    oea::grad_t *ent_grad = static_cast<oea::grad_t *>(ent_grad_);
+    oea::flag_t *ent_touched = static_cast<oea::flag_t *>(ent_touched_);
     OEA_REQUIRE(ent && ids1 && ids2 && M && ent_grad && ent_touched && work && loss_accum, "null pointer");
     OEA_REQUIRE(dim > 0 && dim <= ld && n >= 0, "dim <= ld");
     OEA_REQUIRE(opt_kind == OEA_OPT_SGD || (opt_kind == OEA_OPT_ADAGRAD && M_acc), "Adagrad needs the accumulator of M");
@@ -188,7 +190,7 @@ int oea_mapping_epoch(float *ent, float *ent_acc, int64_t n_ent, float *rel, flo
                       double *mapping_loss_accum, double *step_loss_accum, void *stream) {
     OEA_REQUIRE(ent && rel && batches && M && cfg && workspace && work && mapping_loss_accum && step_loss_accum, "null pointer");
     OEA_REQUIRE(steps >= 0 && n >= 0, "steps, n >= 0");
-    float *eg = nullptr, *et = nullptr;
+    void *eg = nullptr, *et = nullptr;
     int rc = oea_step_entity_scratch(workspace, n_ent, n_rel, ld, &eg, &et);
     if (rc != OEA_OK) return rc;
     oea_step_cfg step_cfg = *cfg;

@@ -334,6 +334,10 @@ __device__ __forceinline__ void eval_tail(const EvalTail &t, const int32_t *rank
     // outstanding memory operations to have completed (s_waitcnt), NOT a cache action.  A __threadfence() here costs every
     // workgroup an L2 write-back + invalidate: the operand panels its XCD neighbours share in L2 are thrown away 2,000 times
     // per sweep (measured: 0.283 -> 0.365 ms per 10,500^2 evaluation, gpurun_out r03e / r03f).
+    // The wait is spelled out: a workgroup-scope release need not lower to s_waitcnt vmcnt(0) when the
+    // workgroup's waves share one L2 anyway (no tgsplit), and this wave's no-return atomics go to other L2 channels than the
+    // ticket -- they must have been acknowledged before thread 0 takes it.  s_waitcnt 0 = vmcnt(0) expcnt(0) lgkmcnt(0).
+    __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) *s_flag = atomicAdd(t.done + 1 + blockIdx.x, 1u) == gridDim.y - 1u;
@@ -369,6 +373,7 @@ __device__ __forceinline__ void eval_tail(const EvalTail &t, const int32_t *rank
         else { double d = 0.0; for (int w = 0; w < 4; ++w) d += s_d[w]; v = __double_as_longlong(d); }
         __hip_atomic_store(t.tile_part + (int64_t)blockIdx.x * 10 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) *s_flag = atomicAdd(t.done, 1u) == gridDim.x - 1u;

@@ -281,4 +281,22 @@ int oea_fill_f32(float *p, int64_t n, float value, void *stream) {
     return OEA_OK;
 }
 
+// device <-> host copies ordered on `stream` and complete on return (the host side of a collective callback stages its
+// buffers with these: oea_comm_init_callbacks)
+int oea_copy_to_host(const void *dev, void *host, size_t bytes, void *stream) {
+    OEA_REQUIRE((dev && host) || bytes == 0, "null");
+    if (bytes == 0) return OEA_OK;
+    OEA_CHECK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, oea::as_stream(stream)));
+    OEA_CHECK_HIP(hipStreamSynchronize(oea::as_stream(stream)));
+    return OEA_OK;
+}
+
+int oea_copy_from_host(void *dev, const void *host, size_t bytes, void *stream) {
+    OEA_REQUIRE((dev && host) || bytes == 0, "null");
+    if (bytes == 0) return OEA_OK;
+    OEA_CHECK_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, oea::as_stream(stream)));
+    OEA_CHECK_HIP(hipStreamSynchronize(oea::as_stream(stream)));
+    return OEA_OK;
+}
+
 }  // extern "C"

@@ -35,21 +35,24 @@ namespace {
 
 using oea::group_sum;
 
+using oea::flag_t;
+using oea::grad_t;      // float, or int64 fixed point in the deterministic build (common.h)
+
 struct StepWs {
-    float *ent_grad, *rel_grad;         // rel_grad: copy 0 of the relation scratch [n_rel][ld]
-    float *rel_extra;                   // copies 1 .. kRelCopies-1, [kRelCopies-1][n_rel][ld]
+    grad_t *ent_grad, *rel_grad;        // rel_grad: copy 0 of the relation scratch [n_rel][ld]
+    grad_t *rel_extra;                  // copies 1 .. kRelCopies-1, [kRelCopies-1][n_rel][ld]
     int64_t rel_copy_stride;            // n_rel * ld
-    float *ent_touched, *rel_touched;   // 1.0f = row received gradient (float so one SUM all-reduce covers grads + flags)
-    float *nrm_grad, *nrm_extra;        // TransH normal vectors: copy 0 / copies 1.. (same shapes as the relation scratch)
-    float *nrm_touched;
+    flag_t *ent_touched, *rel_touched;  // 1 = row received gradient (same type as the gradients: one SUM all-reduce covers both)
+    grad_t *nrm_grad, *nrm_extra;       // TransH normal vectors: copy 0 / copies 1.. (same shapes as the relation scratch)
+    flag_t *nrm_touched;
     double *partials;                   // [kMaxBlocks]
     // layout: [ent_grad | rel_grad (copy 0) | nrm_grad (copy 0) | ent_touched | rel_touched | nrm_touched] is the
     // contiguous prefix that data-parallel ranks all-reduce (the extra copies are folded into copy 0 first);
     // [rel_extra | nrm_extra | partials] follow.
-    __device__ __forceinline__ float *rel_copy(int64_t c) const {
+    __device__ __forceinline__ grad_t *rel_copy(int64_t c) const {
         return c == 0 ? rel_grad : rel_extra + (c - 1) * rel_copy_stride;
     }
-    __device__ __forceinline__ float *nrm_copy(int64_t c) const {
+    __device__ __forceinline__ grad_t *nrm_copy(int64_t c) const {
         return c == 0 ? nrm_grad : nrm_extra + (c - 1) * rel_copy_stride;
     }
 };
@@ -66,14 +69,14 @@ static size_t ws_layout(int64_t n_ent, int64_t n_rel, int32_t ld, void *base, St
     size_t off = 0;
     char *b = static_cast<char *>(base);
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return b ? b + o : nullptr; };
-    float *eg = (float *)take(sizeof(float) * (size_t)n_ent * ld);
-    float *rg = (float *)take(sizeof(float) * (size_t)n_rel * ld);
-    float *ng = (float *)take(sizeof(float) * (size_t)n_rel * ld);
-    float *et = (float *)take(sizeof(float) * (size_t)n_ent);
-    float *rt = (float *)take(sizeof(float) * (size_t)n_rel);
-    float *nt = (float *)take(sizeof(float) * (size_t)n_rel);
-    float *rx = (float *)take(sizeof(float) * (size_t)n_rel * ld * (kRelCopies - 1));
-    float *nx = (float *)take(sizeof(float) * (size_t)n_rel * ld * (kRelCopies - 1));
+    grad_t *eg = (grad_t *)take(sizeof(grad_t) * (size_t)n_ent * ld);
+    grad_t *rg = (grad_t *)take(sizeof(grad_t) * (size_t)n_rel * ld);
+    grad_t *ng = (grad_t *)take(sizeof(grad_t) * (size_t)n_rel * ld);
+    flag_t *et = (flag_t *)take(sizeof(flag_t) * (size_t)n_ent);
+    flag_t *rt = (flag_t *)take(sizeof(flag_t) * (size_t)n_rel);
+    flag_t *nt = (flag_t *)take(sizeof(flag_t) * (size_t)n_rel);
+    grad_t *rx = (grad_t *)take(sizeof(grad_t) * (size_t)n_rel * ld * (kRelCopies - 1));
+    grad_t *nx = (grad_t *)take(sizeof(grad_t) * (size_t)n_rel * ld * (kRelCopies - 1));
     double *pp = (double *)take(sizeof(double) * kMaxBlocks);
     if (ws) {
         ws->rel_copy_stride = n_rel * (int64_t)ld; ws->ent_grad = eg; ws->rel_grad = rg; ws->rel_extra = rx;
@@ -97,6 +100,23 @@ __device__ __forceinline__ void load_row(const float *__restrict__ base, int ld,
     for (int it = 0; it < IT; ++it) {
         const int c = it * G + lane;
         r.v[it] = ((TIGHT && G == 32 && it < IT - 1) || c < ld) ? base[c] : 0.f;
+    }
+}
+// a row of the gradient scratch: raw elements (exact sums of the relation copies), then ONE conversion to fp32
+template <int G, int IT>
+__device__ __forceinline__ void load_grad_raw(const grad_t *__restrict__ base, int ld, int lane, grad_t (&q)[IT]) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = it * G + lane;
+        q[it] = c < ld ? base[c] : (grad_t)0;
+    }
+}
+template <int G, int IT>
+__device__ __forceinline__ void load_grad_row(const grad_t *__restrict__ base, int ld, int lane, Row<G, IT> &r) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = it * G + lane;
+        r.v[it] = c < ld ? oea::grad_val(base[c]) : 0.f;
     }
 }
 template <int G, int IT>
@@ -137,12 +157,12 @@ __device__ __forceinline__ void dscore(const Row<G, IT> &delta, float coef, int 
 // SKIPZERO: elements whose gradient is exactly 0 issue no atomic (L1 norm: sgn(0); a per-element branch) -- the grouped
 // kernel's L2 paths turn it off (a zero there is a measure-zero event and the branches cost more than the atomics)
 template <int G, int IT, bool SKIPZERO = true>
-__device__ __forceinline__ void atomic_row(float *__restrict__ dst, int ld, int lane, const Row<G, IT> &g, float sign) {
+__device__ __forceinline__ void atomic_row(grad_t *__restrict__ dst, int ld, int lane, const Row<G, IT> &g, float sign) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int c = it * G + lane;
         const float v = sign * g.v[it];
-        if (((G == 32 && it < IT - 1) || c < ld) && (!SKIPZERO || v != 0.f)) oea::atomic_add_f32(dst + c, v);
+        if (((G == 32 && it < IT - 1) || c < ld) && (!SKIPZERO || v != 0.f)) oea::grad_add(dst + c, v);
     }
 }
 
@@ -754,21 +774,24 @@ __global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, 
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
     for (int64_t row = grp; row < n_rel; row += ngrp) {
-        if (ws.nrm_touched[row] == 0.f) continue;
+        if (ws.nrm_touched[row] == 0) continue;
         float *v = cfg.normal + row * ld;
         Row<G, IT> rv, rg, y1, y2;
+        grad_t q[IT];
         load_row<G, IT>(v, ld, lane, rv);
-        load_row<G, IT>(ws.nrm_grad + row * ld, ld, lane, rg);
+        load_grad_raw<G, IT>(ws.nrm_grad + row * ld, ld, lane, q);
         for (int cp = 1; cp < kRelCopies && !copies_folded; ++cp) {
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = it * G + lane;
                 if (c < ld) {
-                    const float x = ws.nrm_copy(cp)[row * ld + c];
-                    if (x != 0.f) { rg.v[it] += x; ws.nrm_copy(cp)[row * ld + c] = 0.f; }
+                    const grad_t x = ws.nrm_copy(cp)[row * ld + c];
+                    if (x != 0) { q[it] += x; ws.nrm_copy(cp)[row * ld + c] = 0; }
                 }
             }
         }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) rg.v[it] = oea::grad_val(q[it]);
         const float ss1 = sumsq<G, IT>(rv);
         const float inv1 = rsqrtf(fmaxf(ss1, 1e-12f));
 #pragma unroll
@@ -793,18 +816,18 @@ __global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, 
                 } else {
                     v[c] = rv.v[it] - cfg.lr * gv;
                 }
-                ws.nrm_grad[row * ld + c] = 0.f;
+                ws.nrm_grad[row * ld + c] = 0;
             }
         }
-        if (lane == 0) ws.nrm_touched[row] = 0.f;
+        if (lane == 0) ws.nrm_touched[row] = 0;
     }
 }
 
 // ---- kernel 2: optimiser on touched rows (relation rows first, then entity rows) -------------------
 // pull the summed gradient of one row back through the normalisation, apply Adagrad / SGD, clear the scratch row
 template <int G, int IT>
-__device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__restrict__ acc, float *__restrict__ g,
-                                              float *__restrict__ touched_flag, int ld, int lane, int on,
+__device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__restrict__ acc, grad_t *__restrict__ g,
+                                              flag_t *__restrict__ touched_flag, int ld, int lane, int on,
                                               const oea_step_cfg &cfg, const Row<G, IT> &rv, Row<G, IT> &rg,
                                               const Row<G, IT> &ra) {
     float inv = 1.f, ydg = 0.f;
@@ -829,10 +852,10 @@ __device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__re
             } else {
                 v[c] = rv.v[it] - cfg.lr * gv;
             }
-            g[c] = 0.f;
+            g[c] = 0;
         }
     }
-    if (lane == 0) *touched_flag = 0.f;
+    if (lane == 0) *touched_flag = 0;
 }
 
 // Work item w of the grid: w < n_rel -> relation row w (sums its 16 scratch copies); else R consecutive entity rows.
@@ -856,15 +879,15 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             if (flag_first) {          // large tables: a batch leaves many rows untouched -- look before fetching 3 rows
                 bool any = false;
 #pragma unroll
-                for (int r = 0; r < R; ++r) any |= row0 + r < n_ent && ws.ent_touched[row0 + r] != 0.f;
+                for (int r = 0; r < R; ++r) any |= row0 + r < n_ent && ws.ent_touched[row0 + r] != 0;
                 if (!any) continue;
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int64_t row = row0 + r < n_ent ? row0 + r : n_ent - 1;
-                flag[r] = row0 + r < n_ent ? ws.ent_touched[row] : 0.f;
+                flag[r] = row0 + r < n_ent ? (float)ws.ent_touched[row] : 0.f;
                 load_row<G, IT>(ent + row * ld, ld, lane, rv[r]);
-                load_row<G, IT>(ws.ent_grad + row * ld, ld, lane, rg[r]);
+                load_grad_row<G, IT>(ws.ent_grad + row * ld, ld, lane, rg[r]);
                 if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(ent_acc + row * ld, ld, lane, ra[r]);
             }
 #pragma unroll
@@ -880,34 +903,37 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
         const int64_t row = w;
         float *v = rel + row * ld;
         float *acc = rel_acc + row * ld;
-        float *g = ws.rel_grad + row * ld;
-        const float flag = ws.rel_touched[row];
+        grad_t *g = ws.rel_grad + row * ld;
+        const float flag = (float)ws.rel_touched[row];
         Row<G, IT> rv, rg, ra;
+        grad_t q[IT];                       // raw scratch elements: the copies are summed exactly in the fixed-point build
         load_row<G, IT>(v, ld, lane, rv);
-        load_row<G, IT>(g, ld, lane, rg);
+        load_grad_raw<G, IT>(g, ld, lane, q);
         if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
         if (flag == 0.f) continue;
         if (!copies_folded) {               // sum (fixed order) and clear the other copies
             constexpr int CB = IT <= 4 ? 5 : 1;       // copies fetched together (all loads issued before use)
             for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
-                float tmp[CB][IT];
+                grad_t tmp[CB][IT];
 #pragma unroll
                 for (int u = 0; u < CB; ++u)
 #pragma unroll
                     for (int it = 0; it < IT; ++it) {
                         const int c = it * G + lane;
-                        tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? ws.rel_copy(cp0 + u)[row * ld + c] : 0.f;
+                        tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? ws.rel_copy(cp0 + u)[row * ld + c] : (grad_t)0;
                     }
 #pragma unroll
                 for (int u = 0; u < CB; ++u)
 #pragma unroll
                     for (int it = 0; it < IT; ++it) {
                         const int c = it * G + lane;
-                        rg.v[it] += tmp[u][it];
-                        if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0.f) ws.rel_copy(cp0 + u)[row * ld + c] = 0.f;
+                        q[it] += tmp[u][it];
+                        if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0) ws.rel_copy(cp0 + u)[row * ld + c] = 0;
                     }
             }
         }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) rg.v[it] = oea::grad_val(q[it]);
         apply_one_row<G, IT>(v, acc, g, ws.rel_touched + row, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
     }
     // fixed-order reduction of the loss partials by one wave of block 0
@@ -937,20 +963,20 @@ __global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent,
         const bool is_rel = row_all < n_rel;
         const int64_t row = is_rel ? row_all : row_all - n_rel;
         const int64_t rows = is_rel ? n_rel : n_ent;
-        float *touched = is_rel ? ws.rel_touched : ws.ent_touched;
+        flag_t *touched = is_rel ? ws.rel_touched : ws.ent_touched;
         float *v = (is_rel ? rel : ent) + row * ld;
         float *s0 = (is_rel ? rel_state : ent_state) + row * ld;
         float *s1 = s0 + rows * (int64_t)ld;
-        float *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
+        grad_t *g = (is_rel ? ws.rel_grad : ws.ent_grad) + row * ld;
         const int on = is_rel ? cfg.rel_l2_norm : cfg.ent_l2_norm;
-        const float flag = touched[row];
+        const float flag = (float)touched[row];
         // Adadelta WITHOUT the l2_normalize in front of the lookup: TF's gradient is IndexedSlices and SparseApplyAdadelta
         // only visits the gathered rows -- the accumulators of untouched rows do not decay.  (With the normalisation the
         // gradient is dense; TF1's sparse Adam decays every row either way: optimizer._apply_sparse_shared.)
         if (cfg.opt_kind == OEA_OPT_ADADELTA && !on && flag == 0.f) continue;
         Row<G, IT> rv, rg, r0, r1;
         load_row<G, IT>(v, ld, lane, rv);
-        load_row<G, IT>(g, ld, lane, rg);
+        load_grad_row<G, IT>(g, ld, lane, rg);
         load_row<G, IT>(s0, ld, lane, r0);
         load_row<G, IT>(s1, ld, lane, r1);
         float inv = 1.f, ydg = 0.f;
@@ -980,10 +1006,10 @@ __global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent,
                     s1[c] = r1.v[it] * cfg.beta1 + upd * upd * (1.f - cfg.beta1);
                     v[c] = rv.v[it] - cfg.lr * upd;
                 }
-                if (flag != 0.f) g[c] = 0.f;
+                if (flag != 0.f) g[c] = 0;
             }
         }
-        if (flag != 0.f && lane == 0) touched[row] = 0.f;
+        if (flag != 0.f && lane == 0) touched[row] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         double s = 0.0;
@@ -1010,7 +1036,7 @@ __global__ __launch_bounds__(256) void apply_rows_dense(float *__restrict__ ent,
 // but the optimiser runs on 1/G of the rows and its state is sharded.
 template <int G, int IT>
 __global__ __launch_bounds__(256) void part_pack_kernel(StepWs ws, int64_t n_ent, int64_t n_rel, int ld, int world, int64_t rpr,
-                                                        float *__restrict__ send, float *__restrict__ rel_x) {
+                                                        grad_t *__restrict__ send, grad_t *__restrict__ rel_x) {
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
@@ -1019,32 +1045,32 @@ __global__ __launch_bounds__(256) void part_pack_kernel(StepWs ws, int64_t n_ent
     for (int64_t w = grp; w < slots + n_rel; w += ngrp) {
         if (w >= slots) {                                          // relation row: grads (copies folded by the GRAD phase) + flag
             const int64_t r = w - slots;
-            const float f = ws.rel_touched[r];
+            const flag_t f = ws.rel_touched[r];
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int c = it * G + lane;
                 if (c < ld) {
-                    rel_x[r * ld + c] = f != 0.f ? ws.rel_grad[r * ld + c] : 0.f;
-                    if (f != 0.f) ws.rel_grad[r * ld + c] = 0.f;
+                    rel_x[r * ld + c] = f != 0 ? ws.rel_grad[r * ld + c] : (grad_t)0;
+                    if (f != 0) ws.rel_grad[r * ld + c] = 0;
                 }
             }
-            if (lane == 0) { rel_x[n_rel * ld + r] = f; ws.rel_touched[r] = 0.f; }
+            if (lane == 0) { rel_x[n_rel * ld + r] = f; ws.rel_touched[r] = 0; }
             continue;
         }
         const int64_t o = w / rpr, j = w - o * rpr, id = j * world + o;        // slot (o, j) holds entity id
-        const float f = id < n_ent ? ws.ent_touched[id] : 0.f;
-        float *dst = send + o * chunk + j * ld;
+        const flag_t f = id < n_ent ? ws.ent_touched[id] : (flag_t)0;
+        grad_t *dst = send + o * chunk + j * ld;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int c = it * G + lane;
             if (c < ld) {
-                dst[c] = f != 0.f ? ws.ent_grad[id * ld + c] : 0.f;
-                if (f != 0.f) ws.ent_grad[id * ld + c] = 0.f;
+                dst[c] = f != 0 ? ws.ent_grad[id * ld + c] : (grad_t)0;
+                if (f != 0) ws.ent_grad[id * ld + c] = 0;
             }
         }
         if (lane == 0) {
             send[o * chunk + rpr * ld + j] = f;
-            if (f != 0.f) ws.ent_touched[id] = 0.f;
+            if (f != 0) ws.ent_touched[id] = 0;
         }
     }
 }
@@ -1052,8 +1078,8 @@ __global__ __launch_bounds__(256) void part_pack_kernel(StepWs ws, int64_t n_ent
 template <int G, int IT>
 __global__ __launch_bounds__(256) void part_apply_kernel(float *__restrict__ ent, float *__restrict__ acc_own, int64_t n_ent,
                                                          float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel,
-                                                         int ld, int world, int rank, int64_t rpr, float *__restrict__ own /* [rpr*(ld+1)] */,
-                                                         float *__restrict__ rel_x, float *__restrict__ upd /* [rpr, ld] */,
+                                                         int ld, int world, int rank, int64_t rpr, grad_t *__restrict__ own /* [rpr*(ld+1)] */,
+                                                         grad_t *__restrict__ rel_x, float *__restrict__ upd /* [rpr, ld] */,
                                                          oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum) {
     const int lane = threadIdx.x % G;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -1062,11 +1088,11 @@ __global__ __launch_bounds__(256) void part_apply_kernel(float *__restrict__ ent
         Row<G, IT> rv, rg, ra;
         if (w >= rpr) {
             const int64_t r = w - rpr;
-            if (rel_x[n_rel * ld + r] == 0.f) continue;
+            if (rel_x[n_rel * ld + r] == 0) continue;
             load_row<G, IT>(rel + r * ld, ld, lane, rv);
-            load_row<G, IT>(rel_x + r * ld, ld, lane, rg);
+            load_grad_row<G, IT>(rel_x + r * ld, ld, lane, rg);
             if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(rel_acc + r * ld, ld, lane, ra);
-            float dummy;
+            flag_t dummy;
             apply_one_row<G, IT>(rel + r * ld, rel_acc + r * ld, rel_x + r * ld, &dummy, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
             continue;
         }
@@ -1078,10 +1104,10 @@ __global__ __launch_bounds__(256) void part_apply_kernel(float *__restrict__ ent
         }
         float *v = ent + id * ld;
         load_row<G, IT>(v, ld, lane, rv);
-        if (own[rpr * ld + j] != 0.f) {
-            load_row<G, IT>(own + j * ld, ld, lane, rg);
+        if (own[rpr * ld + j] != 0) {
+            load_grad_row<G, IT>(own + j * ld, ld, lane, rg);
             if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc_own + j * ld, ld, lane, ra);
-            float dummy;
+            flag_t dummy;
             apply_one_row<G, IT>(v, acc_own + j * ld, own + j * ld, &dummy, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
             load_row<G, IT>(v, ld, lane, rv);                      // the updated row (same lanes wrote it)
         }
@@ -1112,21 +1138,21 @@ __global__ void part_unpack_kernel(float *__restrict__ ent, int64_t n_ent, int l
 // data parallel: fold relation copies 1.. into copy 0 (and clear them) so that only copy 0 is exchanged
 __global__ void fold_rel_copies_kernel(StepWs ws, int64_t n, int with_normal) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float sum = 0.f;
+        grad_t sum = 0;
 #pragma unroll
         for (int c = 0; c < kRelCopies - 1; ++c) {
-            const float v = ws.rel_extra[c * ws.rel_copy_stride + i];
-            if (v != 0.f) { sum += v; ws.rel_extra[c * ws.rel_copy_stride + i] = 0.f; }
+            const grad_t v = ws.rel_extra[c * ws.rel_copy_stride + i];
+            if (v != 0) { sum += v; ws.rel_extra[c * ws.rel_copy_stride + i] = 0; }
         }
-        if (sum != 0.f) ws.rel_grad[i] += sum;
+        if (sum != 0) ws.rel_grad[i] += sum;
         if (with_normal) {
-            float sn = 0.f;
+            grad_t sn = 0;
 #pragma unroll
             for (int c = 0; c < kRelCopies - 1; ++c) {
-                const float v = ws.nrm_extra[c * ws.rel_copy_stride + i];
-                if (v != 0.f) { sn += v; ws.nrm_extra[c * ws.rel_copy_stride + i] = 0.f; }
+                const grad_t v = ws.nrm_extra[c * ws.rel_copy_stride + i];
+                if (v != 0) { sn += v; ws.nrm_extra[c * ws.rel_copy_stride + i] = 0; }
             }
-            if (sn != 0.f) ws.nrm_grad[i] += sn;
+            if (sn != 0) ws.nrm_grad[i] += sn;
         }
     }
 }
@@ -1134,7 +1160,7 @@ __global__ void fold_rel_copies_kernel(StepWs ws, int64_t n, int with_normal) {
 // grad[ids[i], c] += src[i, c]  (gradients w.r.t. NORMALISED rows produced outside the fused step,
 // e.g. MTransE's mapping loss, approaches/mtranse.py:84-96) + touched flags, so that apply_rows
 // pulls them through the normalisation and the optimiser like any other row gradient.
-__global__ void scatter_rows_kernel(float *__restrict__ grad, float *__restrict__ touched, int ld,
+__global__ void scatter_rows_kernel(grad_t *__restrict__ grad, flag_t *__restrict__ touched, int ld,
                                     const int32_t *__restrict__ ids, int64_t n, const float *__restrict__ src,
                                     int src_ld) {
     const int64_t total = n * ld;
@@ -1143,8 +1169,8 @@ __global__ void scatter_rows_kernel(float *__restrict__ grad, float *__restrict_
         const int c = (int)(i - row * ld);
         const float v = src[row * src_ld + c];
         const int32_t id = ids[row];
-        if (v != 0.f) oea::atomic_add_f32(grad + (int64_t)id * ld + c, v);
-        if (c == 0) touched[id] = 1.f;
+        if (v != 0.f) oea::grad_add(grad + (int64_t)id * ld + c, v);
+        if (c == 0) touched[id] = 1;
     }
 }
 
@@ -1162,6 +1188,14 @@ void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const f
     else if (cfg.loss_kind == OEA_LOSS_POSITIVE) { if (cfg.l1) OEA_GROUPED(OEA_LOSS_POSITIVE, 1); else OEA_GROUPED(OEA_LOSS_POSITIVE, 0); }
     else OEA_GROUPED(-1, -1);
 #undef OEA_GROUPED
+}
+
+// 16-lane groups for the optimiser kernels when the tables do not fit the caches (see launch_step).  ONE rule for apply_rows
+// and part_apply_kernel, on the size of the WHOLE table: the group width decides the order of the row reductions, and the
+// partitioned job must round like the single-GPU job (bit for bit in the fixed-point build).
+static bool apply_g16(int64_t n_ent, int64_t n_rel, int32_t ld) {
+    static const int env_g16 = [] { const char *e = getenv("OEA_APPLY_G16"); return e ? atoi(e) : -1; }();
+    return env_g16 >= 0 ? env_g16 != 0 : (n_ent + n_rel) * (int64_t)ld * 12 > (int64_t)128 << 20;   // 3 arrays > 128 MB
 }
 
 template <int G, int IT>
@@ -1224,8 +1258,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             // kernel is then bound by HBM and the narrower groups waste fewer lanes on the row's tail -- 100K shape 64.5 ->
             // 54.9 us (step 0.139 -> 0.125 ms); at the 15K shape (latency-bound, cache-resident) they LOSE, 11.0 -> 16.3 us
             // (gpurun_out r02p).  OEA_APPLY_G16 = 0 / 1 overrides the size rule.
-            static const int env_g16 = [] { const char *e = getenv("OEA_APPLY_G16"); return e ? atoi(e) : -1; }();
-            const bool g16 = env_g16 >= 0 ? env_g16 != 0 : (n_ent + n_rel) * (int64_t)ld * 12 > (int64_t)128 << 20;   // 3 arrays > 128 MB
+            const bool g16 = apply_g16(n_ent, n_rel, ld);
             if (g16 && G == 32 && R == 1) {
                 const int it16 = (ld + 15) / 16;
                 const int nbg = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + n_ent, 16), 1), 16384);
@@ -1263,8 +1296,10 @@ size_t oea_step_workspace_bytes(int64_t n_ent, int64_t n_rel, int32_t ld) {
 size_t oea_step_exchange_floats(int64_t n_ent, int64_t n_rel, int32_t ld) {
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, reinterpret_cast<void *>(256), &ws);   // fake base: only offsets matter
-    return (size_t)(reinterpret_cast<char *>(ws.rel_extra) - reinterpret_cast<char *>(256)) / sizeof(float);
+    return (size_t)(reinterpret_cast<char *>(ws.rel_extra) - reinterpret_cast<char *>(256)) / sizeof(grad_t);
 }
+
+int32_t oea_step_scratch_elem_bytes(void) { return (int32_t)sizeof(grad_t); }
 
 int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
                     int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
@@ -1321,7 +1356,7 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     return OEA_OK;
 }
 
-int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, float **ent_grad, float **ent_touched) {
+int oea_step_entity_scratch(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, void **ent_grad, void **ent_touched) {
     OEA_REQUIRE(workspace && ent_grad && ent_touched, "null pointer");
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
@@ -1386,8 +1421,9 @@ int oea_step_apply_normals(int64_t n_ent, int64_t n_rel, int32_t ld, const oea_s
     return OEA_OK;
 }
 
-int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, float *send, float *rel_x,
+int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, void *send_, void *rel_x_,
                   void *stream) {
+    grad_t *send = static_cast<grad_t *>(send_), *rel_x = static_cast<grad_t *>(rel_x_);
     OEA_REQUIRE(workspace && send && rel_x && world >= 1 && ld % 4 == 0, "arguments");
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
@@ -1403,8 +1439,9 @@ int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int
 }
 
 int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel, int32_t ld,
-                   int32_t world, int32_t rank, float *own, float *rel_x, float *upd, const oea_step_cfg *cfg, void *workspace,
+                   int32_t world, int32_t rank, void *own_, void *rel_x_, float *upd, const oea_step_cfg *cfg, void *workspace,
                    int64_t n_items, double *loss_accum, void *stream) {
+    grad_t *own = static_cast<grad_t *>(own_), *rel_x = static_cast<grad_t *>(rel_x_);
     OEA_REQUIRE(ent && rel && own && rel_x && upd && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(world >= 1 && rank >= 0 && rank < world && ld % 4 == 0, "world / rank / ld");
     OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || (cfg->opt_kind == OEA_OPT_ADAGRAD && acc_own && rel_acc), "SGD or Adagrad (+ state)");
@@ -1418,12 +1455,24 @@ int oea_part_apply(float *ent, float *acc_own, int64_t n_ent, float *rel, float 
 #define OEA_CALL(G, IT)                                                                                                       \
     {                                                                                                                         \
         const int gpb = 256 / G;                                                                                              \
-        const int n_part = n_items > 0 ? (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_items, gpb), 1), kMaxBlocks) : 0; \
+        /* one partial per workgroup of the GRAD kernel, whose groups are 32 lanes wide up to ld = 128 and 64 beyond */     \
+        const int grad_gpb = 256 / (ld <= 128 ? 32 : 64);                                                                     \
+        const int n_part = n_items > 0 ? (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_items, grad_gpb), 1), kMaxBlocks) : 0; \
         /* the second event pair of a sampled step (the GRAD call took the first): bench.py's apply timing under partitioning */ \
         oea::launch_timed(part_apply_kernel<G, IT>, (unsigned)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(rpr + n_rel, gpb), 1), 16384), 256, st, \
             ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, rpr, own, rel_x, upd, *cfg, ws, n_part, loss_accum);   \
     }
-    OEA_PART_DISPATCH(OEA_CALL)
+    if (ld <= 128 && apply_g16(n_ent, n_rel, ld)) {                 // the single-GPU job's group width at this table size
+        const int it16 = (ld + 15) / 16;
+        if (it16 <= 2) OEA_CALL(16, 2)
+        else if (it16 <= 4) OEA_CALL(16, 4)
+        else if (it16 == 5) OEA_CALL(16, 5)
+        else if (it16 == 6) OEA_CALL(16, 6)
+        else if (it16 == 7) OEA_CALL(16, 7)
+        else OEA_CALL(16, 8)
+    } else {
+        OEA_PART_DISPATCH(OEA_CALL)
+    }
 #undef OEA_CALL
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
@@ -1529,7 +1578,7 @@ int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int
                                 const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
                                 const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
                                 int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
-                                const int64_t *offsets_dev, const int64_t *splits_dev, float *send, float *own, float *rel_x,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, void *send, void *own, void *rel_x,
                                 float *upd, float *all, void *stream) {
     OEA_REQUIRE(comm && pos_all && offsets_host && splits_host && cfg && send && own && rel_x && upd && all, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0 && 0 <= step_begin && step_begin <= step_end && step_end <= steps, "step range");
@@ -1548,14 +1597,18 @@ int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int
     const int64_t rpr = oea_part_rows_per_rank(n_ent, world);
     const int64_t chunk = rpr * (ld + 1);
     const bool transh = cfg->score_kind == OEA_SCORE_TRANSH;
-    float *nrm_grad = nullptr, *nrm_touched = nullptr;
+    void *nrm_grad = nullptr, *nrm_touched = nullptr;
     if (transh) {
         int64_t g_off = 0, t_off = 0;
         int rc = oea_step_normal_scratch(n_ent, n_rel, ld, &g_off, &t_off);
         if (rc != OEA_OK) return rc;
-        nrm_grad = reinterpret_cast<float *>(static_cast<char *>(workspace) + g_off);
-        nrm_touched = reinterpret_cast<float *>(static_cast<char *>(workspace) + t_off);
+        nrm_grad = static_cast<char *>(workspace) + g_off;
+        nrm_touched = static_cast<char *>(workspace) + t_off;
     }
+    // the gradients travel in the scratch's own type: fp32, or int64 fixed point in the deterministic build (exact sums:
+    // the G-rank job then equals the single-GPU job bit for bit)
+    const int32_t gdt = oea::kDetScratch ? OEA_COMM_I64 : OEA_COMM_F32;
+    hipStream_t st = oea::as_stream(stream);
     oea_step_cfg step_cfg = *cfg;
 #define OEA_TRY_RC(call) do { const int _rc = (call); if (_rc != OEA_OK) return _rc; } while (0)
     for (int32_t s = step_begin; s < step_end; ++s) {
@@ -1571,22 +1624,29 @@ int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int
             OEA_TRY_RC(oea_sample_negatives_pair(pos, n, split, k, side0, side1, seed, step_base + (uint32_t)s, (uint32_t)r_lo, 10, negs,
                                                  err_flag, stream));
         // every rank takes part in every exchange, also with an empty share of the batch (n == 0: nothing scored)
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         OEA_TRY_RC(oea_triple_step_phase(ent, nullptr, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n, k > 0 ? negs : nullptr, n * (int64_t)k,
                                          &step_cfg, workspace, loss_accum, OEA_PHASE_GRAD, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         OEA_TRY_RC(oea_part_pack(workspace, n_ent, n_rel, ld, world, send, rel_x, stream));
-        OEA_TRY_RC(oea_comm_reduce_scatter_f32(comm, send, own, chunk, stream));
-        OEA_TRY_RC(oea_allreduce_f32(comm, rel_x, n_rel * (int64_t)(ld + 1), stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        OEA_TRY_RC(oea_comm_reduce_scatter(comm, send, own, chunk, gdt, stream));
+        OEA_TRY_RC(oea_comm_allreduce(comm, rel_x, n_rel * (int64_t)(ld + 1), gdt, stream));
         if (transh) {
-            OEA_TRY_RC(oea_allreduce_f32(comm, nrm_grad, n_rel * (int64_t)ld, stream));
-            OEA_TRY_RC(oea_allreduce_f32(comm, nrm_touched, n_rel, stream));
+            OEA_TRY_RC(oea_comm_allreduce(comm, nrm_grad, n_rel * (int64_t)ld, gdt, stream));
+            OEA_TRY_RC(oea_comm_allreduce(comm, nrm_touched, n_rel, gdt, stream));
         }
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         const bool grouped = step_cfg.neg_group_k > 0 || step_cfg.loss_kind == OEA_LOSS_MARGIN;
         const int64_t n_items = grouped ? n : n + n * (int64_t)k;
         OEA_TRY_RC(oea_part_apply(ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, own, rel_x, upd, &step_cfg, workspace, n_items,
                                   loss_accum, stream));
         if (transh) OEA_TRY_RC(oea_step_apply_normals(n_ent, n_rel, ld, &step_cfg, workspace, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         OEA_TRY_RC(oea_allgather_rows(comm, upd, all, rpr, ld, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         OEA_TRY_RC(oea_part_unpack(ent, n_ent, ld, world, rank, all, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
         ++step_cfg.opt_t;
     }
 #undef OEA_TRY_RC

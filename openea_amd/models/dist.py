@@ -109,25 +109,92 @@ def allgather_blocks(full, bounds, group=None):
     return full
 
 
+class CAbiComm:
+    """The C ABI's communicator (include/openea_hip.h: oea_comm_*) over the ranks of `group`, for the one-call partitioned
+    epoch (oea_triple_epoch_range_comm).
+
+    * backend "nccl" (one GPU per rank -- a multi-GPU node): RCCL through the library's own dlopen, rank 0's 128-byte id
+      travels through torch.distributed.
+    * any other backend (gloo: the CPU group, and N ranks sharing ONE GPU in the build pool's tests), or
+      OEA_COMM_CALLBACKS=1: oea_comm_init_callbacks -- every collective of the C call comes back to `_collective`, which
+      stages the device buffer through the host (oea_copy_to_host / _from_host, ordered on the call's stream) and runs the
+      torch.distributed collective on the host copy.  Same call path, same protocol, slower wire."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import os
+        from .. import _lib, ops
+        from .._lib import check
+        self.group = group
+        self.rank, self.world = world(group)
+        self.lib = lib = ops.lib()
+        self.handle = C.c_void_p()
+        backend = dist.get_backend(group) if self.world > 1 else "nccl"
+        self.callbacks = (self.world > 1 and backend != "nccl") or os.environ.get("OEA_COMM_CALLBACKS") == "1"
+        if self.callbacks:
+            self._fn = _lib.COMM_CALLBACK(self._collective)            # kept alive with the object
+            check(lib.oea_comm_init_callbacks(self.rank, self.world, C.cast(self._fn, C.c_void_p), None, C.byref(self.handle)))
+            return
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            check(lib.oea_comm_unique_id(uid))
+        box = [bytes(uid.raw) if self.rank == 0 else None]
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+        buf = (C.c_char * 128).from_buffer_copy(box[0])
+        check(lib.oea_comm_init(buf, self.rank, self.world, C.byref(self.handle)))
+
+    _NP = {0: np.float32, 1: np.float64, 2: np.int64}
+
+    def _collective(self, user, op, send, recv, count, dtype, stream):
+        """oea_comm_callback: returns 0 on success (an exception cannot cross the C frame: it is printed and reported as 1)"""
+        try:
+            from .._lib import COMM_ALLGATHER, COMM_ALLREDUCE, check
+            npdt = self._NP[int(dtype)]
+            n_in = int(count) * (self.world if op != COMM_ALLGATHER and op != COMM_ALLREDUCE else 1)
+            host = np.empty(n_in, npdt)
+            check(self.lib.oea_copy_to_host(send, host.ctypes.data, host.nbytes, stream))
+            t = torch.from_numpy(host)
+            if self.world == 1:
+                out = t
+            elif op == COMM_ALLREDUCE:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                out = t
+            elif op == COMM_ALLGATHER:
+                out = torch.empty(int(count) * self.world, dtype=t.dtype)
+                dist.all_gather_into_tensor(out, t, group=self.group)
+            else:
+                out = torch.empty(int(count), dtype=t.dtype)
+                dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
+            o = out.numpy()
+            check(self.lib.oea_copy_from_host(recv, o.ctypes.data, o.nbytes, stream))
+            return 0
+        except Exception:            # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def profile_begin(self):
+        from .._lib import check
+        check(self.lib.oea_comm_profile_begin(self.handle))
+
+    def profile_end(self):
+        """-> ({phase: ms summed over the recorded steps}, steps)"""
+        import ctypes as C
+        from .._lib import COMM_PHASES, check
+        ms = (C.c_double * len(COMM_PHASES))()
+        n = C.c_int32(0)
+        check(self.lib.oea_comm_profile_end(self.handle, ms, C.byref(n)))
+        return {k: float(v) for k, v in zip(COMM_PHASES, ms)}, int(n.value)
+
+    def description(self):
+        return ("host callbacks over torch.distributed '%s' (staged through the host)" % dist.get_backend(self.group)
+                if self.callbacks else "RCCL (the C ABI's own communicator, librccl through dlopen)")
+
+
 def c_abi_comm(group=None):
-    """The C ABI's own communicator (oea_comm_*: RCCL through dlopen, one GPU per rank) over the ranks of `group`; rank 0's
-    128-byte id travels through torch.distributed.  Used by the one-call partitioned epoch (oea_triple_epoch_range_comm)."""
-    import ctypes as C
-    from .. import ops
-    from .._lib import check
-    rank, ws = world(group)
-    lib = ops.lib()
-    uid = (C.c_char * 128)()
-    if rank == 0:
-        check(lib.oea_comm_unique_id(uid))
-    box = [bytes(uid.raw) if rank == 0 else None]
-    if ws > 1:
-        src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
-        dist.broadcast_object_list(box, src=src, group=group)
-    buf = (C.c_char * 128).from_buffer_copy(box[0])
-    comm = C.c_void_p()
-    check(lib.oea_comm_init(buf, rank, ws, C.byref(comm)))
-    return comm
+    return CAbiComm(group)
 
 
 def allreduce_sum_(t, group=None):

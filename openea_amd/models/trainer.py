@@ -51,7 +51,8 @@ class EmbeddingTable:
 
 def cfg_allows_c_epoch(cfg):
     """the one-call partitioned epoch covers what the partition covers (SGD / Adagrad, TransE / TransH / TransD scores)"""
-    return cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD)
+    return (cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD)
+            and cfg.opt_kind in (ops.OPT_KIND["SGD"], ops.OPT_KIND["Adagrad"]))
 
 
 class TripleTrainer:
@@ -82,6 +83,12 @@ class TripleTrainer:
             self.exchange = "step"
         if self.exchange == "epoch" and cfg.score_kind not in (ops.SCORE_TRANSE, ops.SCORE_TRANSD):
             self.exchange = "step"        # TransH keeps a third trained table outside (ent, rel): per-step exchange only
+        if self.exchange == "epoch" and optimizer not in ('Adagrad', 'SGD'):
+            # epoch_sync sums the ranks' CHANGES of tables + state: sound only when a rank leaves the rows it did not touch
+            # alone (SGD / Adagrad).  Adam and Adadelta (with l2_norm) move every row every step (m, v and the table decay
+            # where the gradient is zero), so the sum would count that decay G times (m flips sign, v goes negative):
+            # those optimisers keep the per-step exchange (dense all-reduce of the gradients, replicated update).
+            self.exchange = "step"
         self._snap = None
         dev = ent.var.device
         self.dev = dev
@@ -156,10 +163,11 @@ class TripleTrainer:
         ent, rel, dev = self.ent, self.rel, self.dev
         rpr = ops.part_rows_per_rank(ent.rows, g)
         chunk = rpr * (ent.ld + 1)
+        gdt = ops.scratch_dtype()                  # fp32, or int64 fixed point in the deterministic build: exact sums on the wire
         p = dict(world=g, rank=rk, rpr=rpr, chunk=chunk,
-                 send=torch.empty(g * chunk, dtype=torch.float32, device=dev),
-                 own=torch.empty(chunk, dtype=torch.float32, device=dev),
-                 rel_x=torch.empty(rel.rows * (rel.ld + 1), dtype=torch.float32, device=dev),
+                 send=torch.empty(g * chunk, dtype=gdt, device=dev),
+                 own=torch.empty(chunk, dtype=gdt, device=dev),
+                 rel_x=torch.empty(rel.rows * (rel.ld + 1), dtype=gdt, device=dev),
                  upd=torch.empty((rpr, ent.ld), dtype=torch.float32, device=dev),
                  all=torch.empty((g, rpr, ent.ld), dtype=torch.float32, device=dev))
         if optimizer == 'Adagrad':                 # the state of the owned rows only: row j <-> entity id j * G + rank
@@ -168,13 +176,13 @@ class TripleTrainer:
         else:
             p['acc_own'] = None
         self.part = p
-        # OEA_DP_C_EPOCH=1: the epoch's partitioned steps from ONE C call over the C ABI's own RCCL communicator
-        # (oea_triple_epoch_range_comm) instead of six library calls + three torch.distributed calls per step.  Opt-in: RCCL
-        # wants one GPU per rank, so the build pool (one GPU) could only run it with a single rank
-        # (tests/test_partition_gpu.py::test_partitioned_epoch_from_one_c_call_single_rank).
+        # The epoch's partitioned steps come from ONE C call over the C ABI's communicator (oea_triple_epoch_range_comm:
+        # RCCL on a multi-GPU node, host callbacks over the torch.distributed group otherwise -- models/dist.py:CAbiComm)
+        # instead of six library calls + three torch.distributed calls per step.  OEA_DP_C_EPOCH=0 keeps the per-step
+        # Python loop (the same protocol, _step_partitioned).
         self.comm = None
         import os as _os
-        if _os.environ.get("OEA_DP_C_EPOCH") == "1" and cfg_allows_c_epoch(self.cfg):
+        if _os.environ.get("OEA_DP_C_EPOCH", "1") != "0" and cfg_allows_c_epoch(self.cfg):
             from . import dist as mdist
             self.comm = mdist.c_abi_comm(self.dist)
 
@@ -202,6 +210,15 @@ class TripleTrainer:
         mdist.all_gather_into_(p['all'], p['upd'], self.dist)
         ops.part_unpack(self.ent.var, p['world'], p['rank'], p['all'])
 
+    def _average_xchg(self):
+        """replicated steps: every rank computed the same gradients from the same inputs; the average gives every replica
+        the same bits (fp32 atomics reorder per process).  The fixed-point build's sums are identical already: G x / G = x"""
+        g = torch.distributed.get_world_size(self.dist)
+        if self.xchg.dtype == torch.int64:
+            self.xchg.div_(g, rounding_mode="floor")
+        else:
+            self.xchg /= g
+
     def count_steps(self, n=1):
         """n more optimiser steps are about to run: cfg.opt_t = 1-based count of the first of them"""
         self.cfg.opt_t = self.t + 1
@@ -221,7 +238,7 @@ class TripleTrainer:
                             self.ws, self.loss, phase=ops.PHASE_GRAD)
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
             if self.replicated:
-                self.xchg /= dist.get_world_size(self.dist)
+                self._average_xchg()
             ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, pos, neg, self.cfg,
                             self.ws, self.loss, phase=ops.PHASE_APPLY)
 
@@ -235,7 +252,7 @@ class TripleTrainer:
             import torch.distributed as dist
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
             if self.replicated:
-                self.xchg /= dist.get_world_size(self.dist)
+                self._average_xchg()
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
 
@@ -248,7 +265,7 @@ class TripleTrainer:
             import torch.distributed as dist
             dist.all_reduce(self.xchg, op=dist.ReduceOp.SUM, group=self.dist)
             if self.replicated:
-                self.xchg /= dist.get_world_size(self.dist)
+                self._average_xchg()
         ops.triple_step(self.ent.var, self.ent_acc, self.rel.var, self.rel_acc, self.ent.dim, self._empty, None,
                         self.cfg, self.ws, self.loss, phase=ops.PHASE_APPLY)
 
@@ -280,9 +297,10 @@ class TripleTrainer:
         import torch.distributed as dist
         g = dist.get_world_size(self.dist)
         if self.part is not None:       # reduce-scatter of the packed gradients + all-gather of the updated rows + relation all-reduce
-            p = self.part
-            return int((p['send'].numel() + p['all'].numel()) * 4 * (g - 1) / g + p['rel_x'].numel() * 4 * 2 * (g - 1) / g)
-        return int(self.xchg.numel() * 4 * 2 * (g - 1) / g)
+            p = self.part            # the gradients travel as fp32 or (deterministic build) int64, the updated rows as fp32
+            nb = lambda t: t.numel() * t.element_size()
+            return int((nb(p['send']) + nb(p['all'])) * (g - 1) / g + nb(p['rel_x']) * 2 * (g - 1) / g)
+        return int(self.xchg.numel() * self.xchg.element_size() * 2 * (g - 1) / g)
 
     def pop_loss(self):
         """epoch loss (sum of batch losses) -> host float; resets the accumulator.  Under data
@@ -396,7 +414,7 @@ class RelationTripleEpochs:
             if hasattr(trainer, "count_steps"):
                 trainer.count_steps(int((np.diff(b.offsets[lo:hi + 1]) > 0).sum()))
             if c_part:
-                ops.triple_epoch_comm(trainer.comm, trainer.ent.var, trainer.part['acc_own'], trainer.rel.var, trainer.rel_acc,
+                ops.triple_epoch_comm(trainer.comm.handle, trainer.ent.var, trainer.part['acc_own'], trainer.rel.var, trainer.rel_acc,
                                       trainer.ent.dim, b.dall, b.offsets, b.splits, self.k,
                                       None if (have or not self.k) else self._sides[0],
                                       None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,

@@ -178,10 +178,19 @@ def _fingerprint(all_triples_set, entities_list):
     return (n, hash(sample), m, entities_list[0] if m else -1, entities_list[-1] if m else -1)
 
 
+def invalidate_sampler_cache():
+    """drop the cached device samplers: call after mutating a triple set or an entity list IN PLACE (see _cached_sampler)"""
+    _sampler_cache.clear()
+
+
 def _cached_sampler(all_triples_set, entities_list):
     """one device sampler per (triple set, entity list).  The key is (id, id): O(1) per call; the stored fingerprint
-    (sizes + a strided sample of the set) is compared on every hit, so a set mutated in place or a
-    recycled id() never returns a stale table.  The sorted [n, 3] array is only built on a miss."""
+    (sizes + a strided sample of ~256 triples + the ends of the entity list) is compared on every hit, which catches a
+    recycled id() and any mutation that changes a size.  It is NOT a content hash: a set mutated in place with its size
+    kept (one triple removed, another added) or an entity list edited in the middle almost always passes it and would get
+    the stale device table -- negatives filtered against the old set.  The reference never mutates these containers
+    (kgs.py builds them once); a caller that does must call invalidate_sampler_cache().  The sorted [n, 3] array is only
+    built on a miss."""
     key = (id(all_triples_set), id(entities_list))
     fp = _fingerprint(all_triples_set, entities_list)
     hit = _sampler_cache.get(key)

@@ -110,6 +110,16 @@ def make_step_cfg(loss='limited', loss_norm='L2', margin=0.0, pos_margin=0.0, ne
     return cfg
 
 
+def scratch_dtype():
+    """element type of the step's gradient scratch, its touched flags and the partition's exchange buffers: fp32, or int64
+    fixed point in the deterministic build (OEA_STEP_DETERMINISTIC=1 -> libopenea_hip_det.so, csrc/common.h)"""
+    return torch.int64 if lib().oea_step_scratch_elem_bytes() == 8 else torch.float32
+
+
+def deterministic():
+    return lib().oea_step_scratch_elem_bytes() == 8
+
+
 def step_workspace(n_ent, n_rel, ld, dev=None):
     nbytes = lib().oea_step_workspace_bytes(n_ent, n_rel, ld)
     return torch.zeros(nbytes, dtype=torch.uint8, device=dev or device())
@@ -238,10 +248,11 @@ def part_unpack(ent, world, rank, all_rows):
 
 
 def step_exchange_view(workspace, n_ent, n_rel, ld):
-    """fp32 view of the workspace region (gradient scratch + touched flags) that data-parallel
-    ranks sum with one all-reduce."""
+    """view (fp32, or int64 in the deterministic build) of the workspace region (gradient scratch + touched flags) that
+    data-parallel ranks sum with one all-reduce."""
     n = lib().oea_step_exchange_floats(n_ent, n_rel, ld)
-    return workspace[: 4 * n].view(torch.float32)
+    dt = scratch_dtype()
+    return workspace[: dt.itemsize * n].view(dt)
 
 
 def step_normal_views(workspace, n_ent, n_rel, ld):
@@ -249,8 +260,9 @@ def step_normal_views(workspace, n_ent, n_rel, ld):
     flags [n_rel] inside the step workspace (summed over the ranks after the GRAD phase, include/openea_hip.h)."""
     g_off, t_off = C.c_int64(0), C.c_int64(0)
     check(lib().oea_step_normal_scratch(int(n_ent), int(n_rel), int(ld), C.byref(g_off), C.byref(t_off)))
-    grad = workspace[g_off.value: g_off.value + 4 * n_rel * ld].view(torch.float32)
-    touched = workspace[t_off.value: t_off.value + 4 * n_rel].view(torch.float32)
+    dt = scratch_dtype()
+    grad = workspace[g_off.value: g_off.value + dt.itemsize * n_rel * ld].view(dt)
+    touched = workspace[t_off.value: t_off.value + dt.itemsize * n_rel].view(dt)
     return grad, touched
 
 
@@ -360,8 +372,9 @@ def part_buffers(n_ent, n_rel, ld, world, dev, adagrad=True):
     rpr = lib().oea_part_rows_per_rank(int(n_ent), int(world))
     chunk = rpr * (ld + 1)
     f = dict(dtype=torch.float32, device=dev)
-    return dict(rpr=rpr, chunk=chunk, send=torch.empty(world * chunk, **f), own=torch.empty(chunk, **f),
-                rel_x=torch.empty(n_rel * (ld + 1), **f), upd=torch.empty((rpr, ld), **f), all=torch.empty((world, rpr, ld), **f),
+    g = dict(dtype=scratch_dtype(), device=dev)         # the gradients travel in the scratch's own type
+    return dict(rpr=rpr, chunk=chunk, send=torch.empty(world * chunk, **g), own=torch.empty(chunk, **g),
+                rel_x=torch.empty(n_rel * (ld + 1), **g), upd=torch.empty((rpr, ld), **f), all=torch.empty((world, rpr, ld), **f),
                 acc_own=torch.full((rpr, ld), 0.1, **f) if adagrad else None)
 
 

@@ -266,20 +266,28 @@ def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
     import json
     env = dict(os.environ, OEA_BENCH_ONE_GPU="1", OEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--repeats", "3"]
+    # the N > 1 default is the EN-FR-100K-V1 shape; with both ranks on one GPU and the collectives staged through the host the
+    # test takes the 15K shape (same code path: strong scaling, per-step partition exchange from one C call per epoch)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--repeats", "3", "--shape", "EN-FR-15K-V1"]
     if launcher == "self":
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + tail
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "strong" and j["value"] > 0
     assert j["roofline"]["launches_timed"] > 0 and j["roofline"]["avg_kernel_us"] > 0 and j["roofline"]["apply_rows_avg_us"] > 0
     assert 0 < j["roofline"]["frac"] <= 1 and 0 < j["roofline"]["frac_sec8d"] <= 1
-    assert j["extra"]["exchange_bytes_per_step_per_rank"] > 0 and j["extra"]["collective_world_size"] == 2
-    assert j["extra"]["eval_pairs_per_s_inner"] > 0 and j["extra"]["neighbour_rows_per_s"] > 0
-    assert j["config"]["parallelism"].startswith("dp2") and j["config"]["global_batch"] == 10000
+    x = j["extra"]
+    assert x["exchange_bytes_per_step_per_rank"] > 0 and x["collective_world_size"] == 2 and x["exchange_mode"] == "step"
+    assert x["eval_pairs_per_s_inner"] > 0 and x["neighbour_rows_per_s"] > 0
+    assert j["config"]["parallelism"].startswith("dp2") and j["config"]["global_batch"] == 5000       # BASELINE config 2's batch, kept global
+    ph = x["exchange_phases"]                  # HIP events of the one-call partitioned epoch
+    assert ph["steps_timed"] == 10 and all(ph[k + "_us"] >= 0 for k in ("grad", "pack", "reduce_scatter", "apply", "all_gather", "unpack"))
+    assert ph["grad_us"] > 0 and ph["apply_us"] > 0
+    assert x["single_gpu_same_config"]["value"] > 0 and x["speedup_vs_single_gpu_same_config"] > 0
+    assert x["other_exchange"]["exchange_mode"] == "epoch" and "parity" in x["other_exchange"]

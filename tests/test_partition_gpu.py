@@ -261,3 +261,104 @@ def test_trainer_runs_the_partitioned_epoch_from_one_c_call():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "TRAINER_COMM_OK" in out, out[-3000:]
+
+
+EPOCH_RANKS_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["OEA_ROOT"])
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+group = None
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["OEA_PORT"], rank=rank, world_size=world)
+    group = dist.group.WORLD
+torch.cuda.set_device(0)
+from openea_amd import ops
+from openea_amd.models.trainer import EmbeddingTable, RelationTripleEpochs, TripleTrainer, refresh_neighbours
+from openea_amd.modules.load.synth import make_kgs
+kgs = make_kgs("small", mode="swapping", seed=0)
+rng = np.random.RandomState(2)
+d, k = 36, 4
+ent_h = (rng.standard_normal((kgs.entities_num, d)) / np.sqrt(d)).astype(np.float32)
+rel_h = (rng.standard_normal((kgs.relations_num, d)) / np.sqrt(d)).astype(np.float32)
+opt = os.environ["OEA_OPT"]
+cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer=opt, lr=0.02,
+                        neg_group_k=k)
+ent, rel = EmbeddingTable(ent_h, True, "e"), EmbeddingTable(rel_h, True, "r")
+tr = TripleTrainer(ent, rel, cfg, opt, dist_group=group)
+if world > 1:
+    assert tr.part is not None and tr.comm is not None and tr.comm.callbacks      # the one-call epoch is the default path
+    tr.comm.profile_begin()
+ep = RelationTripleEpochs(kgs, 700, k, seed=3, rank=rank, world=world)
+n = 0
+for e in range(5):
+    if e == 2:                        # a truncated-sampling refresh in between, as BootEA / AlignE do
+        nbr1 = refresh_neighbours(ent, kgs.kg1.entities_list, 40)
+        nbr2 = refresh_neighbours(ent, kgs.kg2.entities_list, 40)
+        ep.set_neighbours(nbr1, nbr2)
+    n += ep.run_epoch(tr)
+ep.check()
+torch.cuda.synchronize()
+phases = None
+if world > 1:
+    phases, steps = tr.comm.profile_end()
+    assert steps == 5 * len(ep.batches.splits) and all(v >= 0 for v in phases.values()) and phases["grad"] > 0, (phases, steps)
+loss = tr.pop_loss()
+np.savez(os.environ["OEA_OUT"] + "/ep_w%d_r%d.npz" % (world, rank), ent=ent.raw(), rel=rel.raw(), loss=loss, n=n,
+         det=int(ops.deterministic()))
+if world > 1:
+    dist.barrier()
+'''
+
+
+def _launch_epochs(tmp_path, world, opt, det):
+    env = dict(os.environ, OEA_ROOT=ROOT, OEA_OUT=str(tmp_path), OEA_PORT=str(_free_port()), WORLD_SIZE=str(world), OEA_OPT=opt,
+               OEA_STEP_DETERMINISTIC="1" if det else "0")
+    env.pop("OEA_DP_C_EPOCH", None)
+    procs = [subprocess.Popen([sys.executable, "-c", EPOCH_RANKS_WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(str(tmp_path), "ep_w%d_r%d.npz" % (world, r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("det", [False, True], ids=["fp32_atomics", "fixed_point"])
+@pytest.mark.parametrize("opt", ["Adagrad", "SGD"])
+def test_one_call_partitioned_epochs_with_2_and_4_ranks_equal_the_single_process_job(tmp_path, opt, det, capsys):
+    """The DEFAULT data-parallel path of the translational models: TripleTrainer + RelationTripleEpochs hand every epoch to
+    oea_triple_epoch_range_comm (GRAD -> pack -> reduce-scatter + relation all-reduce -> owned apply -> all-gather -> unpack,
+    one C call per epoch).  2 and 4 ranks share this box's GPU, so the communicator runs over host callbacks on the gloo group
+    (RCCL needs a GPU per rank; a multi-GPU node takes the RCCL branch of the same entry points).  Five epochs with a
+    neighbour refresh in between: replicas hold the same bits, the tables equal the single-process job's within the north-star
+    tolerance -- and BIT FOR BIT in the fixed-point build (libopenea_hip_det.so: integer sums have no order)."""
+    from _tol import assert_rows_close
+    single = _launch_epochs(tmp_path, 1, opt, det)[0]
+    assert int(single["det"]) == int(det)
+    again = _launch_epochs(tmp_path, 1, opt, det)[0]
+    if det:       # the single-GPU job itself: two runs, the same bits
+        assert np.array_equal(again["ent"], single["ent"]) and np.array_equal(again["rel"], single["rel"])
+        assert float(again["loss"]) == float(single["loss"])
+    for world in (2, 4):
+        ranks = _launch_epochs(tmp_path, world, opt, det)
+        for r in ranks[1:]:
+            assert np.array_equal(r["ent"], ranks[0]["ent"]) and np.array_equal(r["rel"], ranks[0]["rel"])
+        assert sum(int(r["n"]) for r in ranks) == int(single["n"])
+        with capsys.disabled():
+            assert_rows_close(ranks[0]["ent"], single["ent"], "%s%s, %d ranks (one C call per epoch) vs 1 process, entity table after 5 epochs"
+                              % (opt, " fixed point" if det else "", world))
+            assert_rows_close(ranks[0]["rel"], single["rel"], "relation table")
+        assert abs(float(ranks[0]["loss"]) - float(single["loss"])) <= 1e-5 * abs(float(single["loss"]))
+        if det:
+            assert np.array_equal(ranks[0]["ent"], single["ent"]) and np.array_equal(ranks[0]["rel"], single["rel"]), \
+                "fixed-point build: the %d-rank job must equal the single-process job bit for bit" % world
