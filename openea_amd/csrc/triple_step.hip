@@ -912,7 +912,13 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
         if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
         if (flag == 0.f) continue;
         if (!copies_folded) {               // sum (fixed order) and clear the other copies
-            constexpr int CB = IT <= 4 ? 5 : 1;       // copies fetched together (all loads issued before use)
+            // copies fetched together (all loads issued before use).  The fixed-point build keeps this loop rolled: unrolled, its
+            // int64 elements (two registers each) took the kernel from 120 to 172 VGPRs = from 4 to 2 waves per SIMD, and the
+            // latency-bound 15K shape paid double (11.3 -> 23.7 us, gpurun_out r04a)
+            constexpr int CB = IT <= 4 ? 5 : 1;
+#ifdef OEA_DET_SCRATCH
+#pragma unroll 1
+#endif
             for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
                 grad_t tmp[CB][IT];
 #pragma unroll

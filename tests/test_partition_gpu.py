@@ -330,7 +330,8 @@ def _launch_epochs(tmp_path, world, opt, det):
         outs.append(out.decode(errors="replace"))
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    return [np.load(os.path.join(str(tmp_path), "ep_w%d_r%d.npz" % (world, r))) for r in range(world)]
+    # read NOW: a later launch with the same world size writes the same file names (np.load is lazy)
+    return [dict(np.load(os.path.join(str(tmp_path), "ep_w%d_r%d.npz" % (world, r)))) for r in range(world)]
 
 
 @pytest.mark.parametrize("det", [False, True], ids=["fp32_atomics", "fixed_point"])
