@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour / 100K-shape legs")
     ap.add_argument("--no-gnn", action="store_true", help="skip the GNN legs (BASELINE configs 3-5)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 FETCH_SIZE / WRITE_SIZE passes")
+    ap.add_argument("--leg", default=None, help="internal: child mode of a rocprofv3 counter pass (pmc_gnn)")
     return ap.parse_args()
 
 
@@ -406,6 +407,9 @@ def main():
             cached_kgs(args.shape, "swapping")     # one rank builds the synthetic KGs, the others read the pickle
         dist.barrier()
 
+    if args.leg == "pmc_gnn":                   # child of measure_gnn_traffic's rocprofv3 passes: launches only, no line
+        pmc_child(torch, ops, dev)
+        return
     wl = Workload(torch, ops, args.shape, args.dim, args.batch, args.neg, args.eps, dev, rank, world, group, args.scaling,
                   args.exchange)
     m = wl.measure(args.steps, args.warmup, args.repeats)
@@ -458,11 +462,40 @@ def main():
         extra["shape_100k"] = shape_100k(torch, ops, dev, args)
     if not args.no_gnn and world == 1:
         torch.cuda.empty_cache()
+        gtraffic = None if args.no_traffic else measure_gnn_traffic()
         try:
-            extra["gnn"] = gnn_legs(torch, ops, dev)
+            extra["gnn"] = gnn_legs(torch, ops, dev, gtraffic)
         except Exception as e:      # noqa: BLE001 -- a failing side leg must not take the headline line down
             extra["gnn"] = {"error": repr(e)[:500]}
+        # counter traffic of the CSLS evaluation (70,000^2 x 100) and of the neighbour search (100,000^2, k = 2,000), priced
+        # with the wall times of extra.shape_100k
+        s100 = extra.get("shape_100k")
+        if gtraffic and s100 and "error" not in gtraffic:
+            for leg_name, key, rate_key, units in (("csls_eval_70k", "csls_eval_hbm", "eval_pairs_per_s_inner_csls10", 70000),
+                                                   ("knn_100k", "neighbour_search_hbm", "neighbour_rows_per_s", 100000)):
+                t = gtraffic.get(leg_name)
+                if t and s100.get(rate_key):
+                    ms = units / s100[rate_key] * 1e3
+                    s100[key] = {"hbm_bytes_per_call": t["hbm_bytes_per_call"], "ms_per_call": round(ms, 3),
+                                 "hbm_frac": round(t["hbm_bytes_per_call"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "kernels": t["kernels"], "traffic_source": gtraffic.get("source")}
+        elif gtraffic and s100:
+            s100["csls_eval_hbm"] = s100["neighbour_search_hbm"] = gtraffic
 
+    roofline_eval = None
+    if extra.get("eval_pairs_per_s_inner"):
+        n1 = extra["eval_pairs"]
+        tf = 2.0 * n1 * n1 * args.dim * extra["eval_pairs_per_s_inner"] / n1 / 1e12
+        roofline_eval = {"kernel": "rank_inner_kernel + prologue / tail (oea_rank_eval_metrics): greedy_alignment of the %d test pairs, "
+                                   "inner product, whole call incl. the copy of the metrics to the host" % n1,
+                         "bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                         "flops_per_call": 2.0 * n1 * n1 * args.dim, "pairs_per_s": extra["eval_pairs_per_s_inner"],
+                         "csls10_pairs_per_s": extra.get("eval_pairs_per_s_inner_csls10"),
+                         "csls10_frac_4N1N2d": round(4.0 * n1 * n1 * args.dim * extra["eval_pairs_per_s_inner_csls10"] / n1 / 157.3e12, 4)
+                         if extra.get("eval_pairs_per_s_inner_csls10") else None,
+                         "note": "second half of BASELINE.json's metric (alignment-eval pairs/s): exact fp32 MFMA (v_mfma_f32_32x32x2_f32, "
+                                 "157.3 TFLOP/s dense peak), 2*N1*N2*d flop / wall time of the whole call"}
+        roofline["eval"] = roofline_eval
     per_gpu = args.batch if args.scaling == "weak" else args.batch / world
     out = {
         "metric": "training triples/sec (positives consumed; truncated negative sampling k=%d + limited loss + Adagrad)" % args.neg,
@@ -487,7 +520,7 @@ def main():
                    "timing": "median of %d regions of %d steps, each bracketed by barrier + synchronize" % (args.repeats, args.steps),
                    "parity_note": "TF1 op semantics / optimiser arithmetic are restated, not executed (no TensorFlow "
                                   "here): SURVEY H1/H3/H4, DESIGN.md section 5"},
-        "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        "roofline": roofline, "roofline_eval": roofline_eval, "cpu_baseline": cpu, "extra": extra,
     }
     print(json.dumps(out), flush=True)
     if world > 1:
@@ -643,31 +676,241 @@ def _hbm_block(kernel, alg_bytes, ms, **kw):
                  "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}, **kw)
 
 
-def gnn_legs(torch, ops, dev):
+PMC_LEGS = ("gcn_spmm_15k", "alinet_1hop_100k", "attn_runs_fwd", "attn_runs_bwd", "attn_row_fwd", "attn_row_bwd", "csls_eval_70k",
+            "knn_100k")
+PMC_MARK0 = 1000        # marker launch of leg i: fill_kernel with (PMC_MARK0 + i) workgroups of 256
+
+
+def _quiet(fn):
     import contextlib
     import io
-    out = {}
-    rng = np.random.RandomState(0)
-    from openea_amd.run.default_args import get_args
-    # ---- config 3: GCN-Align 2-layer CSR aggregate, D-W-15K-V2 shape --------------------------------------------
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn()
+
+
+def _build_gcn(torch, ops, dev, rng):
     from openea_amd.approaches.gcn_align import GCN_Align
+    from openea_amd.run.default_args import get_args
     kgs = cached_kgs("D-W-15K-V2", "mapping")
-    buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
+
+    def mk():
         m = GCN_Align()
         m.set_args(get_args("GCN_Align", output="/tmp/oea_out/", training_data="synthetic/dw15k/", dataset_division="f/"))
         m.set_kgs(kgs)
         m.init()
+        return m
+    m = _quiet(mk)
     se = m.model_se
+    d = m.args.se_dim
+    x = ops.gather_rows(se.W, d, se.row_ids, normalize=True)
+    return m, kgs, se, d, x
+
+
+def _build_alinet(torch, ops, dev, grouping=None, epochs=0):
+    """AliNet at the EN-DE-100K-V1 shape -> (model, kgs, init seconds, ms per epoch or None)"""
+    from openea_amd.approaches import AliNet
+    from openea_amd.run.default_args import get_args
+    kgs = cached_kgs("EN-DE-100K-V1", "mapping")
+    kw = dict(scale="100K", output="/tmp/oea_out/", training_data="synthetic/EN-DE-100K-V1/", dataset_division="f/", max_epoch=1,
+              start_valid=10 ** 6, eval_freq=10 ** 6)
+    if grouping:
+        kw["attn_grouping"] = grouping
+    res = {}
+
+    def mk():
+        a = AliNet()
+        a.set_args(get_args("AliNet", **kw))
+        a.set_kgs(kgs)
+        t0 = time.perf_counter()
+        a.init()
+        torch.cuda.synchronize()
+        res["init_s"] = time.perf_counter() - t0
+        if epochs:
+            a.run()
+            torch.cuda.synchronize()
+            a.args.max_epoch = epochs
+            t0 = time.perf_counter()
+            a.run()
+            torch.cuda.synchronize()
+            res["ms_epoch"] = (time.perf_counter() - t0) / epochs * 1e3
+        return a
+    a = _quiet(mk)
+    return a, kgs, res["init_s"], res.get("ms_epoch")
+
+
+def _attn_closures(torch, ops, dev, g2, n, d):
+    z = torch.randn(g2.nnz, device=dev)
+    v = torch.randn(n, ops.pad4(d), device=dev)
+    dout = torch.randn(n, ops.pad4(d), device=dev)
+    res = {}
+
+    def fwd():
+        res["o"], res["a"] = ops.sparse_attn_fwd(g2.attn, z, v, d, 0.2, n)
+
+    def bwd():
+        ops.sparse_attn_bwd(g2.attn, z, v, res["a"], dout, d, 0.2)
+    return fwd, bwd
+
+
+def _row_grouped(g2, dev):
+    """the same ordered edge list under the per-row softmax grouping (SURVEY H3's other reading)"""
+    from openea_amd.models.graph_ops import EdgeGraph
+    return EdgeGraph(g2._rows_o, g2._cols_o, g2.e_vals.cpu().numpy(), g2.shape, dev, grouping="row")
+
+
+def _eval_tables(torch, ops, dev, n_e, d_e, rng):
+    e1 = rng.standard_normal((n_e, d_e)).astype(np.float32)
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    t1 = ops.to_table(e1, dev=dev)
+    t2 = ops.to_table((e1 + 0.4 * rng.standard_normal((n_e, d_e)).astype(np.float32) / np.sqrt(d_e)).astype(np.float32), dev=dev)
+    return t1, t2
+
+
+def pmc_child(torch, ops, dev):
+    """child of a rocprofv3 --pmc pass (--leg pmc_gnn): a few launches of every kernel whose HBM traffic the parent prices,
+    each group behind a MARKER launch (fill_kernel with PMC_MARK0 + i workgroups) so that the parent can tell the aggregate of
+    the 1-hop graph from the attention's (same kernel, same grid) in the counter file"""
+    from openea_amd.modules.finding.alignment import greedy_alignment_device
+    from openea_amd.models.trainer import EmbeddingTable, refresh_neighbours
+    from openea_amd.modules.base.initializers import truncated_normal_host
+    rng = np.random.RandomState(0)
+    mark_buf = torch.empty(256 * (PMC_MARK0 + len(PMC_LEGS) + 1), dtype=torch.float32, device=dev)
+
+    def leg(name, fn, reps):
+        i = PMC_LEGS.index(name)
+        torch.cuda.synchronize()
+        ops.check(ops.lib().oea_fill_f32(mark_buf.data_ptr(), 256 * (PMC_MARK0 + i), 0.0, torch.cuda.current_stream().cuda_stream))
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    m, kgs, se, d, x = _build_gcn(torch, ops, dev, rng)
+    se.adj.mm(x, d, act=1)
+    leg("gcn_spmm_15k", lambda: se.adj.mm(x, d, act=1), 3)
+    del m, se, x
+    a, kgs, _, _ = _build_alinet(torch, ops, dev)
+    g2, g1 = a.adj[1], a.adj[0]
+    n, d = kgs.entities_num, a.args.layer_dims[1]
+    x1 = torch.randn(n, ops.pad4(d), device=dev)
+    g1.fwd.apply(x1, d)
+    leg("alinet_1hop_100k", lambda: g1.fwd.apply(x1, d), 3)
+    for tag, g in (("runs", g2), ("row", _row_grouped(g2, dev))):
+        fwd, bwd = _attn_closures(torch, ops, dev, g, n, d)
+        fwd(), bwd()
+        leg("attn_%s_fwd" % tag, fwd, 2)
+        leg("attn_%s_bwd" % tag, bwd, 2)
+    del a, g1, g2, x1
+    torch.cuda.empty_cache()
+    t1, t2 = _eval_tables(torch, ops, dev, 70000, 100, rng)
+    greedy_alignment_device(t1, t2, 100, [1, 5, 10, 50], "inner", False, 10)
+    leg("csls_eval_70k", lambda: greedy_alignment_device(t1, t2, 100, [1, 5, 10, 50], "inner", False, 10), 2)
+    del t1, t2
+    torch.cuda.empty_cache()
+    kgs = cached_kgs("EN-FR-100K-V1", "swapping")
+    ent = EmbeddingTable(truncated_normal_host(np.random.RandomState(1), (kgs.entities_num, 100), 0.1), True, "ent_embeds", dev)
+    refresh_neighbours(ent, kgs.kg1.entities_list, 2000)
+    leg("knn_100k", lambda: refresh_neighbours(ent, kgs.kg1.entities_list, 2000), 1)
+
+
+def _pmc_pass_legs(counter, timeout_s):
+    """one rocprofv3 --pmc pass over `bench.py --leg pmc_gnn` -> {leg: {kernel name: (sum of the counter, launches)}}"""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    out = tempfile.mkdtemp(prefix="oea_pmc_", dir=tmp)
+    try:
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.abspath(__file__), "--leg", "pmc_gnn"]
+        p = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+        rows = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == counter:
+                    rows.append((int(r.get("Dispatch_Id") or 0), r["Kernel_Name"], int(r.get("Grid_Size") or 0), float(r["Counter_Value"])))
+        if not rows:
+            raise RuntimeError("no %s rows (rc %d): %s" % (counter, p.returncode, p.stderr.decode(errors="replace")[-300:]))
+        rows.sort()
+        legs = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+        cur = None
+        for _, name, grid, val in rows:
+            if "fill_kernel" in name and grid % 256 == 0 and PMC_MARK0 <= grid // 256 < PMC_MARK0 + len(PMC_LEGS):
+                cur = PMC_LEGS[grid // 256 - PMC_MARK0]
+                continue
+            if cur is not None:
+                legs[cur][name][0] += val
+                legs[cur][name][1] += 1
+        if not legs:
+            raise RuntimeError("no marker launches in the counter file (columns: Grid_Size / Dispatch_Id missing?)")
+        return legs
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+PMC_REPS = {"gcn_spmm_15k": 3, "alinet_1hop_100k": 3, "attn_runs_fwd": 2, "attn_runs_bwd": 2, "attn_row_fwd": 2, "attn_row_bwd": 2,
+            "csls_eval_70k": 2, "knn_100k": 1}
+
+
+def measure_gnn_traffic(timeout_s=300):
+    """FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 correction: bytes = (2 FETCH + WRITE) KB) of the GNN / CSLS / neighbour
+    kernels, per CALL of the operator -> {leg: {"hbm_bytes_per_call", "kernels": {name: bytes per launch}}} or {"error"}"""
+    try:
+        t0 = time.time()
+        fetch = _pmc_pass_legs("FETCH_SIZE", timeout_s)
+        write = _pmc_pass_legs("WRITE_SIZE", timeout_s)
+        out = {}
+        for leg_name in PMC_LEGS:
+            if leg_name not in fetch:
+                continue
+            ks = {}
+            total = 0.0
+            for name, (fv, n) in fetch[leg_name].items():
+                wv = write.get(leg_name, {}).get(name, [0.0, 0])[0]
+                b = (2.0 * fv + wv) * 1024
+                total += b
+                ks[name[:90]] = {"hbm_bytes_per_launch": int(b / max(n, 1)), "launches_per_call": round(n / PMC_REPS[leg_name], 2)}
+            out[leg_name] = {"hbm_bytes_per_call": int(total / PMC_REPS[leg_name]), "kernels": ks}
+        out["source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
+                         "`bench.py --leg pmc_gnn` (marker launches separate the operators), (2*FETCH + WRITE) KB, %.0f s" % (time.time() - t0))
+        return out
+    except Exception as e:          # noqa: BLE001 -- the profiler must not take the bench line down
+        return {"error": "unavailable (%s)" % str(e)[:300]}
+
+
+def _with_hbm(block, traffic, leg_name, ms, kernel_sub=None):
+    """attach the counter traffic of one operator call to its roofline block: hbm_frac = counter bytes / time / HBM peak --
+    a formula fraction above ~0.79 (6.3 TB/s achievable of 8) is served by L2 / MALL by definition"""
+    t = (traffic or {}).get(leg_name)
+    if not t:
+        block["traffic"] = None
+        block["traffic_source"] = (traffic or {}).get("error", "not collected")
+        return block
+    b = t["hbm_bytes_per_call"]
+    if kernel_sub:
+        b = sum(int(v["hbm_bytes_per_launch"] * v["launches_per_call"]) for k, v in t["kernels"].items() if kernel_sub in k)
+    block["traffic"] = int(b)
+    block["hbm_frac"] = round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    block["traffic_source"] = traffic.get("source")
+    return block
+
+
+def gnn_legs(torch, ops, dev, traffic=None):
+    out = {}
+    rng = np.random.RandomState(0)
+    # ---- config 3: GCN-Align 2-layer CSR aggregate, D-W-15K-V2 shape --------------------------------------------
+    m, kgs, se, d, x = _build_gcn(torch, ops, dev, rng)
     train = np.asarray(kgs.train_links, np.int32)
     k, t = m.args.neg_triple_num, len(train)
-    negs = tuple(ops.to_ids(x.astype(np.int32)) for x in (np.repeat(train[:, 0], k), rng.choice(kgs.entities_num, t * k),
-                                                           rng.choice(kgs.entities_num, t * k), np.repeat(train[:, 1], k)))
-    nnz, n, d = se.adj.nnz, kgs.entities_num, m.args.se_dim
+    negs = tuple(ops.to_ids(x_.astype(np.int32)) for x_ in (np.repeat(train[:, 0], k), rng.choice(kgs.entities_num, t * k),
+                                                             rng.choice(kgs.entities_num, t * k), np.repeat(train[:, 1], k)))
+    nnz, n = se.adj.nnz, kgs.entities_num
     ms_epoch = _wall(torch, lambda: se.train_step(negs), 50)
     spmm_bytes = nnz * (8 + 4 * d) + 4 * n * d
     epoch_bytes = 4 * spmm_bytes + 4 * (2 * t + 4 * t * k) * d + 12 * n * d
-    x = ops.gather_rows(se.W, d, se.row_ids, normalize=True)
     ms_spmm = _timed_events(torch, lambda: se.adj.mm(x, d, act=1), 50)
     out["gcn_align_se_epoch_DW15K"] = {
         "workload": "GCN-Align structure model, full-batch epoch (2 aggregates fwd, 2 bwd, L1 hinge over %d links x %d negatives, "
@@ -675,27 +918,29 @@ def gnn_legs(torch, ops, dev):
         "ms_per_epoch": round(ms_epoch, 4), "epochs_per_s": round(1e3 / ms_epoch, 1),
         "roofline_epoch": _hbm_block("whole epoch (wall, synchronised)", epoch_bytes, ms_epoch,
                                      formula="4*(nnz*(8+4d)+4Nd) + 4*(2t+4tk)*d + 12*N*d (SURVEY 8d)"),
-        "roofline": _hbm_block("spmm_csr_kernel (one aggregate, relu fused; HIP events on the launch stream, 50 launches)",
-                               spmm_bytes, ms_spmm, formula="nnz*(8+4d) + 4*N*d (SURVEY 8d)",
-                               note="E=30,000: X (12 MB) and the CSR (4 MB) are cache-resident")}
+        "roofline": _with_hbm(_hbm_block("spmm_csr_kernel (one aggregate, relu fused; HIP events on the launch stream, 50 launches)",
+                                         spmm_bytes, ms_spmm, formula="nnz*(8+4d) + 4*N*d (SURVEY 8d)",
+                                         perfect_reuse_bytes=int(nnz * 8 + 8 * n * d),
+                                         note="E=30,000: X (12 MB) and the CSR (4 MB) are cache-resident"),
+                              traffic, "gcn_spmm_15k", ms_spmm)}
     del m, se
     torch.cuda.empty_cache()
     # ---- config 5 (evaluation half): RDGCN's metric -- manhattan similarity + rank, d = 300, 70,000 test pairs ----
     from openea_amd.modules.finding.alignment import greedy_alignment_device
     n_e, d_e = 70000, 300
-    e1 = rng.standard_normal((n_e, d_e)).astype(np.float32)
-    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
-    t1 = ops.to_table(e1, dev=dev)
-    t2 = ops.to_table((e1 + 0.4 * rng.standard_normal((n_e, d_e)).astype(np.float32) / np.sqrt(d_e)).astype(np.float32), dev=dev)
+    t1, t2 = _eval_tables(torch, ops, dev, n_e, d_e, rng)
     os.environ["OEA_L1_EVAL"] = "f64"                                   # every pair in fp64 (round 2's path, kept beside the default)
     ms_l1_f64 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 0), 1)
     os.environ["OEA_L1_EVAL"] = "grid"
     ms_l1 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 0), 2)
+    ms_l1_csls = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 10), 1)
     ms_in = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "inner", False, 0), 2)
     sad_ops = float(n_e) * n_e * ((d_e + 7) // 8 * 8) / 2.0                # one v_sad_u16 per pair and two columns
     out["rdgcn_eval_70000x300"] = {
-        "workload": "greedy_alignment over 70,000 x 70,000 pairs at d = 300 (RDGCN's test(): eval_metric manhattan; inner beside it)",
+        "workload": "greedy_alignment over 70,000 x 70,000 pairs at d = 300 (RDGCN's test(): eval_metric manhattan, then the same "
+                    "with csls = 10 -- basic_model.py:132-135; inner beside it)",
         "manhattan_ms": round(ms_l1, 2), "manhattan_pairs_per_s": round(n_e / ms_l1 * 1e3, 1),
+        "manhattan_csls10_ms": round(ms_l1_csls, 2), "manhattan_csls10_pairs_per_s": round(n_e / ms_l1_csls * 1e3, 1),
         "manhattan_all_pairs_fp64_ms": round(ms_l1_f64, 2),
         "inner_ms": round(ms_in, 2), "inner_pairs_per_s": round(n_e / ms_in * 1e3, 1),
         "roofline": {"kernel": "l1_u16_strip_kernel (16-bit grid distances of every pair; exact fp64 similarities only where the "
@@ -712,59 +957,55 @@ def gnn_legs(torch, ops, dev):
                            "peak": 157.3, "unit": "TFLOP/s", "frac": round(2.0 * n_e * n_e * d_e / (ms_in * 1e-3) / 1e12 / 157.3, 4)}}
     del t1, t2
     torch.cuda.empty_cache()
-    # ---- config 4: AliNet at the EN-DE-100K-V1 shape --------------------------------------------------------------
-    from openea_amd.approaches import AliNet
-    kgs = cached_kgs("EN-DE-100K-V1", "mapping")
-    buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
-        a = AliNet()
-        a.set_args(get_args("AliNet", scale="100K", output="/tmp/oea_out/", training_data="synthetic/EN-DE-100K-V1/",
-                            dataset_division="f/", max_epoch=1, start_valid=10 ** 6, eval_freq=10 ** 6))
-        a.set_kgs(kgs)
-        t0 = time.perf_counter()
-        a.init()
-        torch.cuda.synchronize()
-        init_s = time.perf_counter() - t0
-        a.run()
-        torch.cuda.synchronize()
-        a.args.max_epoch = 3
-        t0 = time.perf_counter()
-        a.run()
-        torch.cuda.synchronize()
-        ms_epoch = (time.perf_counter() - t0) / 3 * 1e3
+    # ---- config 4: AliNet at the EN-DE-100K-V1 shape, under BOTH readings of tf.sparse_softmax -------------
+    a, kgs, init_s, ms_epoch = _build_alinet(torch, ops, dev, epochs=3)
     g2, g1 = a.adj[1], a.adj[0]
     n, d = kgs.entities_num, a.args.layer_dims[1]
-    z = torch.randn(g2.nnz, device=dev)
-    v = torch.randn(n, ops.pad4(d), device=dev)
-    dout = torch.randn(n, ops.pad4(d), device=dev)
-    res = {}
-
-    def attn_fwd():
-        res["o"], res["a"] = ops.sparse_attn_fwd(g2.attn, z, v, d, 0.2, n)
-
-    def attn_bwd():
-        ops.sparse_attn_bwd(g2.attn, z, v, res["a"], dout, d, 0.2)
-    ms_f = _timed_events(torch, attn_fwd, 10)
-    ms_b = _timed_events(torch, attn_bwd, 10)
     nnz2 = g2.nnz
-    single_edge = len(g2.seg_row_host) == nnz2
     agg = nnz2 * (8 + 4 * d) + 4 * n * d
-    fwd_bytes = agg + 4 * nnz2 + 8 * n
-    bwd_bytes = agg + (0 if single_edge else agg)        # dV = transposed aggregate; d alpha dots only for multi-edge segments
     x1 = torch.randn(n, ops.pad4(d), device=dev)
     ms_1hop = _timed_events(torch, lambda: g1.fwd.apply(x1, d), 10)
+    att = {}
+    for tag, g in (("runs", g2), ("row", _row_grouped(g2, dev))):
+        fwd, bwd = _attn_closures(torch, ops, dev, g, n, d)
+        ms_f = _timed_events(torch, fwd, 10)
+        ms_b = _timed_events(torch, bwd, 10)
+        single = len(g.seg_row_host) == nnz2
+        fwd_bytes = agg + 4 * nnz2 + 8 * n
+        bwd_bytes = agg + (0 if single else agg)       # dV = transposed aggregate; d alpha dots only for multi-edge segments
+        blk = _hbm_block("sparse attention operator fwd + bwd (softmax statistics, alpha, aggregate; d alpha, d z, d V) at d=%d, "
+                         "grouping '%s': %d softmax groups over %d edges%s; HIP events on the launch stream"
+                         % (d, tag, len(g.seg_row_host), nnz2, " (every group ONE edge: no softmax kernel runs, alpha = 1)" if single else ""),
+                         fwd_bytes + bwd_bytes, ms_f + ms_b,
+                         formula="fwd nnz*(12+4d)+4Nd+8N; bwd the transposed aggregate (+ one more pass of gathers for d alpha "
+                                 "when groups have several edges)", perfect_reuse_bytes=int(2 * (nnz2 * 8 + 8 * n * d)))
+        t_f, t_b = (traffic or {}).get("attn_%s_fwd" % tag), (traffic or {}).get("attn_%s_bwd" % tag)
+        if t_f and t_b:
+            tb = t_f["hbm_bytes_per_call"] + t_b["hbm_bytes_per_call"]
+            blk.update(traffic=int(tb), hbm_frac=round(tb / ((ms_f + ms_b) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic_source=traffic.get("source"))
+        else:
+            blk.update(traffic=None, traffic_source=(traffic or {}).get("error", "not collected"))
+        att[tag] = {"attention_fwd_ms": round(ms_f, 4), "attention_bwd_ms": round(ms_b, 4), "softmax_groups": int(len(g.seg_row_host)),
+                    "roofline": blk}
+    del a
+    torch.cuda.empty_cache()
+    a_row, _, _, ms_epoch_row = _build_alinet(torch, ops, dev, grouping="row", epochs=3)
+    del a_row
     out["alinet_EN-DE-100K"] = {
-        "workload": "AliNet, layer_dims %s, EN-DE-100K-V1 shape: E=%d, 1-hop nnz=%d, 2-hop nnz=%d, grouping '%s' (%d softmax "
-                    "segments); one epoch = one full-graph step (batch %d) + Adam" % (a.args.layer_dims, n, g1.nnz, nnz2, g2.grouping,
-                                                                                     len(g2.seg_row_host), a.args.batch_size),
-        "init_s": round(init_s, 2), "ms_per_epoch": round(ms_epoch, 2),
-        "attention_fwd_ms": round(ms_f, 4), "attention_bwd_ms": round(ms_b, 4),
-        "roofline": _hbm_block("sparse attention operator fwd + bwd (softmax statistics, alpha, aggregate; d alpha, d z, d V) at d=%d, "
-                               "HIP events on the launch stream" % d, fwd_bytes + bwd_bytes, ms_f + ms_b,
-                               formula="fwd nnz*(12+4d)+4Nd+8N; bwd the transposed aggregate (+ one more pass of gathers for d alpha "
-                                       "when segments have several edges)"),
-        "roofline_1hop_aggregate": _hbm_block("spmm_csr_kernel (1-hop aggregate, d=%d)" % d, g1.nnz * (8 + 4 * d) + 4 * n * d, ms_1hop,
-                                              formula="nnz*(8+4d) + 4*N*d")}
+        "workload": "AliNet, layer_dims [500, 400, 300], EN-DE-100K-V1 shape: E=%d, 1-hop nnz=%d, 2-hop nnz=%d; one epoch = one "
+                    "full-graph step + Adam; default attn_grouping 'runs' (TF1's run grouping on the column-major adjacency: %d "
+                    "groups), 'row' (per-row softmax: %d groups) beside it" % (n, g1.nnz, nnz2, att["runs"]["softmax_groups"],
+                                                                             att["row"]["softmax_groups"]),
+        "init_s": round(init_s, 2), "ms_per_epoch": round(ms_epoch, 2), "ms_per_epoch_grouping_row": round(ms_epoch_row, 2),
+        "attention_fwd_ms": att["runs"]["attention_fwd_ms"], "attention_bwd_ms": att["runs"]["attention_bwd_ms"],
+        "roofline": att["runs"]["roofline"], "grouping_row": att["row"],
+        "roofline_1hop_aggregate": _with_hbm(_hbm_block("spmm_csr_kernel (1-hop aggregate, d=%d)" % d, g1.nnz * (8 + 4 * d) + 4 * n * d,
+                                                        ms_1hop, formula="nnz*(8+4d) + 4*N*d",
+                                                        perfect_reuse_bytes=int(g1.nnz * 8 + 8 * n * d)),
+                                             traffic, "alinet_1hop_100k", ms_1hop)}
+    out["note"] = ("frac = SURVEY 8d's formula bytes (every gathered row counted once per nonzero) / time / 8 TB/s; hbm_frac = counter "
+                   "bytes / time / 8 TB/s.  A formula fraction above ~0.79 (6.3 TB/s achievable) means the gathered rows come out "
+                   "of L2 / MALL; perfect_reuse_bytes = nnz*8 + 8*N*d is the floor with every row read once")
     return out
 
 

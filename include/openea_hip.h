@@ -491,6 +491,18 @@ int oea_l1_u16_strip(const uint16_t *q, int64_t nq, const uint16_t *c, int64_t n
 int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
                           const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err, int32_t *rank,
                           int32_t *argmax, int32_t *n_exact_rows, void *stream);
+/* The same with CSLS (models/basic_model.py:132-135: test() evaluates a second time with csls = args.csls; GCN-Align and RDGCN
+ * do so under the manhattan metric): rank / argmax of v_ij = (2 s_ij - csls_r[i]) - csls_c[j] as oea_rank_eval gives them with
+ * the same means.  csls_r [n1], csls_c [nc]. */
+int oea_rank_l1_grid_rows_csls(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
+                               const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err,
+                               const float *csls_r, const float *csls_c, int32_t *rank, int32_t *argmax, int32_t *n_exact_rows,
+                               void *stream);
+/* exact manhattan SIMILARITIES of a candidate list: out[i, j] = float(1 - sum_k |q[i, k] - table[cand[i, j], k]|) with the
+ * sequential fp64 chain of oea_sim_matrix(OEA_METRIC_MANHATTAN) (k ascending: scipy cdist's bits) -- the values the CSLS means
+ * of the manhattan metric are sums of (modules/finding/similarity.py:46-48,57-83). */
+int oea_pair_l1_sim(const float *q, int64_t nq, int32_t ldq, const float *table, int64_t n, int32_t ldt, int32_t dim,
+                    const int32_t *cand, int32_t c, float *out, void *stream);
 /* exact fp64 L1 distances of a candidate list: out[i, j] = sum_k |q[i, k] - table[cand[i, j], k]| (fixed summation order).
  * With OEA_METRIC_MANHATTAN_F32 + oea_topk_rows this is RDGCN's hard-negative mining (approaches/rdgcn.py:75-87) without the
  * fp64 distance of every (seed, entity) pair: fp32 ranks k + margin candidates, these are re-ranked exactly. */

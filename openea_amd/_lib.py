@@ -168,6 +168,9 @@ PROTOTYPES = {
     "oea_l1_u16_strip": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "oea_rank_l1_grid_rows": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "oea_pair_l1_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "oea_rank_l1_grid_rows_csls": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp, _vp,
+                                             _vp, _vp, _vp, _vp]),
+    "oea_pair_l1_sim": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "oea_rank_eval_metrics_workspace_bytes": (_sz, [_i64]),
     "oea_rank_eval_metrics": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

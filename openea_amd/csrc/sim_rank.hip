@@ -1207,6 +1207,160 @@ __global__ __launch_bounds__(256) void rank_l1_grid_rows_kernel(const float *__r
     }
 }
 
+// ---- the same with CSLS (basic_model.py:132-135: test() runs greedy_alignment a second time with csls = args.csls; for
+// GCN-Align / RDGCN that is the manhattan metric) ------------------------------------------------------------------------------
+// v_ij = (2 s_ij - r_i) - c_j in fp32 (rank_valu_kernel's expression; s_ij = float(1 - d_ij)).  From the grid distance G the
+// similarity is known to +-err, so v~_ij = (2 (1 - G step) - r_i) - c_j is within tol_j = 2 err + rounding slack of v_ij:
+// candidates whose interval [v~ - tol, v~ + tol] does not contain the gold value are decided by the strip, the others -- and
+// the candidates whose upper bound reaches the row's best lower bound, for the nearest -- by their exact value.
+__device__ __forceinline__ float csls_tol(float s_approx, float r, float c, float err, float step) {
+    return 2.0f * err + 8.0f * step + 6.0e-7f * (2.0f * fabsf(s_approx) + fabsf(r) + fabsf(c) + 1.0f);
+}
+
+__global__ __launch_bounds__(256) void rank_l1_grid_rows_csls_kernel(const float *__restrict__ strip, int64_t rows, int64_t row0,
+                                                                     int64_t nc, int64_t ld, const float *__restrict__ e1, int ld1,
+                                                                     const float *__restrict__ e2, int ld2, int dim, int64_t gold_off,
+                                                                     float step, float err, const float *__restrict__ csls_r,
+                                                                     const float *__restrict__ csls_c, int32_t *__restrict__ rank,
+                                                                     int32_t *__restrict__ argmax, int32_t *__restrict__ n_exact_rows) {
+    extern __shared__ double lds_d[];
+    double *qs = lds_d;
+    int32_t *amb = reinterpret_cast<int32_t *>(qs + ((dim + 1) & ~1));
+    int32_t *top = amb + kGridAmb;
+    __shared__ int s_namb, s_ntop, s_cnt;
+    __shared__ float s_gold;
+    __shared__ unsigned s_lmax_ord;                                  // f2ord bits of the row's best lower bound
+    __shared__ unsigned long long s_best;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    if (r >= rows) return;
+    const int64_t i = row0 + r, g = i + gold_off;
+    const float ri = csls_r[i];
+    for (int k = tid; k < dim; k += 256) qs[k] = (double)e1[i * ld1 + k];
+    if (tid == 0) { s_namb = 0; s_ntop = 0; s_cnt = 0; s_best = 0ull; s_lmax_ord = 0u; }
+    __syncthreads();
+    if (tid == 0) s_gold = (2.0f * exact_l1_sim(qs, e2 + g * ld2, dim) - ri) - csls_c[g];
+    __syncthreads();
+    const float vg = s_gold;
+    const float *srow = strip + r * ld;
+    int cnt = 0;
+    float lmax = -INFINITY;                                          // running maximum of the lower bounds v~ - tol
+    for (int64_t j4 = (int64_t)tid * 4; j4 < nc; j4 += 1024) {       // ld % 4 == 0: 16-byte reads; columns >= nc are unwritten
+        const float4 v4 = oea::ld4(srow + j4);
+        const float Gs[4] = {-v4.x, -v4.y, -v4.z, -v4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j4 + u;
+            if (j >= nc) continue;
+            const float cj = csls_c[j];
+            const float sa = fmaf(-Gs[u], step, 1.0f);
+            const float va = (2.0f * sa - ri) - cj;
+            const float tol = csls_tol(sa, ri, cj, err, step);
+            if (va + tol >= lmax) {
+                const int at = atomicAdd(&s_ntop, 1);
+                if (at < kGridTop) top[at] = (int32_t)j;
+            }
+            lmax = fmaxf(lmax, va - tol);
+            if (j == g) continue;
+            if (va - tol > vg) ++cnt;
+            else if (va + tol >= vg) {
+                const int at = atomicAdd(&s_namb, 1);
+                if (at < kGridAmb) amb[at] = (int32_t)j;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_cnt, cnt);
+        atomicMax(&s_lmax_ord, f2ord(lmax));                         // order-preserving bits: the bound may be negative
+    }
+    __syncthreads();
+    float row_lmax;
+    {
+        const unsigned o = s_lmax_ord;
+        row_lmax = __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+    }
+    auto upper = [&](int64_t j) {
+        const float cj = csls_c[j];
+        const float sa = fmaf(srow[j], step, 1.0f);                   // srow holds -G
+        return ((2.0f * sa - ri) - cj) + csls_tol(sa, ri, cj, err, step);
+    };
+    if (s_ntop > kGridTop) {                                        // workgroup-uniform
+        __syncthreads();
+        if (tid == 0) s_ntop = 0;
+        __syncthreads();
+        for (int64_t j = tid; j < nc; j += 256) {
+            if (upper(j) >= row_lmax) {
+                const int at = atomicAdd(&s_ntop, 1);
+                if (at < kGridTop) top[at] = (int32_t)j;
+            }
+        }
+        __syncthreads();
+    }
+    const int namb = s_namb, ntop = s_ntop;
+    int extra = 0;
+    unsigned long long best = 0ull;
+    if (namb > kGridAmb || ntop > kGridTop) {                        // the lists overflowed: every pair exactly
+        if (tid == 0 && n_exact_rows) atomicAdd(n_exact_rows, 1);
+        for (int64_t j = tid; j < nc; j += 256) {
+            const float v = (2.0f * exact_l1_sim(qs, e2 + j * ld2, dim) - ri) - csls_c[j];
+            extra += (j != g) && (v > vg || (v == vg && j < g));
+            const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+            best = key > best ? key : best;
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+    } else {
+        for (int a = tid; a < namb; a += 256) {
+            const int64_t j = amb[a];
+            const float v = (2.0f * exact_l1_sim(qs, e2 + j * ld2, dim) - ri) - csls_c[j];
+            extra += v > vg || (v == vg && j < g);
+        }
+        for (int a = tid; a < ntop; a += 256) {
+            const int64_t j = top[a];
+            if (upper(j) < row_lmax) continue;                       // a record of the running bound only
+            const float v = (2.0f * exact_l1_sim(qs, e2 + j * ld2, dim) - ri) - csls_c[j];
+            const unsigned long long key = ((unsigned long long)f2ord(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        extra += __shfl_xor(extra, off, 64);
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((tid & 63) == 0) {
+        if (extra) atomicAdd(&s_cnt, extra);
+        atomicMax(&s_best, best);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rank[i] = s_cnt;
+        argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(s_best & 0xFFFFFFFFull));
+    }
+}
+
+// exact similarity float(1 - d) of every (query row, candidate) pair of a candidate list with the SEQUENTIAL fp64 chain
+// (k ascending: the bits of valu_tile / scipy's cdist): one thread per pair.  The CSLS means of the manhattan metric are
+// sums of these values, so the chain's order matters (pair_l1_f64_kernel below adds in a butterfly order).
+__global__ __launch_bounds__(256) void pair_l1_sim_seq_kernel(const float *__restrict__ q, int64_t nq, int ldq,
+                                                              const float *__restrict__ table, int ldt, int dim,
+                                                              const int32_t *__restrict__ cand, int c, float *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nq * c) return;
+    const float *a = q + (p / c) * ldq, *b = table + (int64_t)cand[p] * ldt;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < dim; ++k) acc += fabs((double)a[k] - (double)b[k]);
+    out[p] = (float)(1.0 - acc);
+}
+
 // exact fp64 L1 distance of every (query row, candidate) pair of a candidate list: one 16-lane group per pair, lane-strided
 // columns, butterfly sum (a fixed order: equal rows give equal sums)
 __global__ __launch_bounds__(256) void pair_l1_f64_kernel(const float *__restrict__ q, int64_t nq, int ldq,
@@ -2060,6 +2214,32 @@ int oea_rank_l1_grid_rows(const float *strip, int64_t rows, int64_t row0, int64_
     const size_t lds = sizeof(double) * (size_t)((dim + 1) & ~1) + sizeof(int32_t) * (kGridAmb + kGridTop);
     rank_l1_grid_rows_kernel<<<(unsigned)rows, 256, lds, oea::as_stream(stream)>>>(strip, rows, row0, nc, ld, e1, ld1, e2, ld2, dim,
                                                                                    gold_offset, step, err, rank, argmax, n_exact_rows);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_rank_l1_grid_rows_csls(const float *strip, int64_t rows, int64_t row0, int64_t nc, int64_t ld, const float *e1, int32_t ld1,
+                               const float *e2, int32_t ld2, int32_t dim, int64_t gold_offset, float step, float err,
+                               const float *csls_r, const float *csls_c, int32_t *rank, int32_t *argmax, int32_t *n_exact_rows,
+                               void *stream) {
+    OEA_REQUIRE(strip && e1 && e2 && rank && argmax && csls_r && csls_c && rows >= 0 && row0 >= 0 && nc > 0 && ld >= nc, "arguments");
+    OEA_REQUIRE(ld % 4 == 0 && ((uintptr_t)strip & 15) == 0, "strip rows: 16-byte aligned (ld % 4 == 0)");
+    OEA_REQUIRE(dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 4096 && step > 0.f && err >= 0.f, "dim <= 4096, step > 0");
+    OEA_REQUIRE(row0 + rows + gold_offset <= nc && gold_offset >= 0, "gold of row i is column gold_offset + i < nc");
+    if (rows == 0) return OEA_OK;
+    const size_t lds = sizeof(double) * (size_t)((dim + 1) & ~1) + sizeof(int32_t) * (kGridAmb + kGridTop);
+    rank_l1_grid_rows_csls_kernel<<<(unsigned)rows, 256, lds, oea::as_stream(stream)>>>(strip, rows, row0, nc, ld, e1, ld1, e2, ld2, dim,
+                                                                                        gold_offset, step, err, csls_r, csls_c, rank,
+                                                                                        argmax, n_exact_rows);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_pair_l1_sim(const float *q, int64_t nq, int32_t ldq, const float *table, int64_t n, int32_t ldt, int32_t dim,
+                    const int32_t *cand, int32_t c, float *out, void *stream) {
+    OEA_REQUIRE(q && table && cand && out && dim > 0 && dim <= ldq && dim <= ldt && c > 0 && n > 0, "arguments");
+    if (nq == 0) return OEA_OK;
+    pair_l1_sim_seq_kernel<<<(unsigned)oea::ceil_div(nq * c, 256), 256, 0, oea::as_stream(stream)>>>(q, nq, ldq, table, ldt, dim, cand, c, out);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

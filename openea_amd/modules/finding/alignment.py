@@ -30,7 +30,12 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
         r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
     if kmetric == 'inner' and 1 <= len(top_k) <= 8 and ops.tile_glds():
         return ops.rank_eval_metrics(t1, t2, dim, top_k, r, c)             # prologue + sweep: two launches, one copy back
-    rank, argmax = ops.rank_eval(t1, t2, dim, kmetric, r, c)
+    grid = getattr(csls_means_device, "last_grid", None) if (csls_k > 0 and kmetric == 'manhattan') else None
+    csls_means_device.last_grid = None
+    if grid is not None:       # manhattan + CSLS: the rank pass reads the strips the means pass left behind
+        rank, argmax = ops.rank_eval_l1_grid(t1, t2, dim, csls_r=r, csls_c=c, grid=grid)
+    else:
+        rank, argmax = ops.rank_eval(t1, t2, dim, kmetric, r, c)
     hits, rank_sum, rr_sum = ops.rank_metrics(rank, top_k)
     return rank, argmax, hits, rank_sum, rr_sum
 
@@ -49,6 +54,7 @@ def _greedy_alignment_sharded(t1, t2, dim, top_k, kmetric, csls_k, rk, ws):
         r_loc, _ = csls_means_device(t1[lo1:hi1], t2, dim, kmetric, csls_k, cols=False)
         c_loc, _ = csls_means_device(t2[lo2:hi2], t1, dim, kmetric, csls_k, cols=False)
         r, c = mdist.allgather_rows(r_loc, n1), mdist.allgather_rows(c_loc, n2)
+        csls_means_device.last_grid = None
 
     def rank_fn(block, cand, d, off):
         return ops.rank_eval(block, cand, d, kmetric, None if r is None else r[off: off + block.shape[0]].contiguous(),

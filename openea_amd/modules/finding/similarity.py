@@ -74,11 +74,19 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
     """Per-row and per-column top-k means WITHOUT holding the whole matrix: strips of rows of S
     and of S^T are produced and reduced one after the other (each strip <= max_bytes).
     cols=False: only the row means (second result None)."""
+    import os
     import torch
     if kmetric == 'inner' and cols:        # one sweep, no strips of S / S^T (n1, n2 >= 4096)
         rc = ops.csls_means(t1, t2, dim, k)
         if rc is not None:
             return rc
+    if (kmetric == 'manhattan' and min(t1.shape[0], t2.shape[0]) >= 2048 and k + 32 < min(t1.shape[0], t2.shape[0])
+            and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64'):
+        # 16-bit grid distances + exact similarities of the k + margin nearest (certified): the same means without the fp64
+        # distance of every pair, twice (ops.l1_grid_topk_means); the grid and the query strips go on to the rank pass
+        r, c, grid = ops.csls_means_l1_grid(t1, t2, dim, k, cols=cols)
+        csls_means_device.last_grid = grid
+        return r, c
 
     def strip_means(a, b):
         n, m = a.shape[0], b.shape[0]

@@ -477,8 +477,8 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]
     assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
-    if metric == 'manhattan' and csls_r is None and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
-        return rank_eval_l1_grid(e1, e2, dim, gold_offset)
+    if metric == 'manhattan' and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
+        return rank_eval_l1_grid(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
     ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
@@ -487,40 +487,133 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     return rank, argmax
 
 
-def rank_eval_l1_grid(e1, e2, dim, gold_offset=0, block_bytes=2 << 30):
+class L1Grid:
+    """both tables of a manhattan evaluation on ONE 16-bit grid over their common range (oea_quantize_rows_u16), the error
+    bound of a grid distance, and -- when they fit a third of the free memory -- the strips of grid distances of the query
+    blocks, kept so that the CSLS evaluation (row means, then ranks) computes them once."""
+
+    def __init__(self, e1, e2, dim, block_bytes=2 << 30):
+        self.e1, self.e2, self.dim = e1, e2, dim
+        lo1, hi1 = torch.aminmax(e1[:, :dim])
+        lo2, hi2 = torch.aminmax(e2[:, :dim])
+        lo, hi = min(float(lo1), float(lo2)), max(float(hi1), float(hi2))
+        self.step = max(hi - lo, 1e-30) / 65535.0
+        self.q1 = quantize_rows_u16(e1, dim, lo, 1.0 / self.step)
+        self.q2 = self.q1 if e2 is e1 else quantize_rows_u16(e2, dim, lo, 1.0 / self.step)
+        self.err = (dim * 1.02 + 1.0) * self.step      # half a step per operand and column, + the fp32 rounding of the grid map
+        self.ld = (e2.shape[0] + 31) // 32 * 32
+        self.rows_per = int(max(128, min(e1.shape[0], block_bytes // (4 * self.ld))))
+        self.strips = {}                               # r0 -> strip of query rows [r0, r0 + rows) against all of e2
+
+    def blocks(self):
+        n1 = self.e1.shape[0]
+        return [(r0, min(self.rows_per, n1 - r0)) for r0 in range(0, n1, self.rows_per)]
+
+    def strip(self, r0, rows, keep=False):
+        s = self.strips.get(r0)
+        if s is None:
+            s = l1_u16_strip(self.q1[r0: r0 + rows], self.q2)
+            if keep:
+                self.strips[r0] = s
+        return s
+
+    def can_keep(self):
+        need = 4 * self.ld * self.e1.shape[0]
+        return need <= torch.cuda.mem_get_info(self.e1.device)[0] // 3
+
+
+def pair_l1_sim(q, table, dim, cand):
+    """exact manhattan similarities float(1 - d) of the candidate lists cand int32 [nq, c] (sequential fp64 chain) -> fp32 [nq, c]"""
+    nq, c = cand.shape
+    out = torch.empty((nq, c), dtype=torch.float32, device=q.device)
+    check(lib().oea_pair_l1_sim(_p(q), nq, q.shape[1], _p(table), table.shape[0], table.shape[1], dim, _p(cand), c, _p(out), _stream()))
+    return out
+
+
+def l1_grid_topk_means(q_tab, c_tab, qq, qc, dim, k, step, err, margin=32, block_bytes=2 << 30, keep=None, stats=None):
+    """mean of the k largest manhattan similarities of every row of q_tab against c_tab (calculate_nearest_k,
+    similarity.py:80-83) WITHOUT the fp64 distance of every pair: the k + margin nearest on the 16-bit grid, their exact
+    similarities (sequential fp64 chain, rounded to fp32 like sim()), the mean by oea_row_topk_mean on that short list --
+    the same values summed in the same order as over the whole row.  Every list is CERTIFIED: no entity outside it can be
+    nearer than its farthest member's lower bound, which must not beat the k-th exact value; rows that fail take the
+    all-pairs fp64 strip.  keep: an L1Grid whose strips this pass should leave behind (q_tab = its e1)."""
+    n, nc = q_tab.shape[0], c_tab.shape[0]
+    ld = (nc + 31) // 32 * 32
+    rows_per = keep.rows_per if keep is not None else int(max(128, min(n, block_bytes // (4 * ld))))
+    out = torch.empty(n, dtype=torch.float32, device=q_tab.device)
+    c = min(k + margin, nc)
+    redone = 0
+    for r0 in range(0, n, rows_per):
+        rows = min(rows_per, n - r0)
+        strip = keep.strip(r0, rows, keep=True) if keep is not None else l1_u16_strip(qq[r0: r0 + rows], qc)
+        cand = topk_rows(strip, c, nc=nc)                                            # the c smallest grid distances
+        worst = -torch.gather(strip, 1, cand.to(torch.int64)).amin(dim=1).to(torch.float64)
+        qb = q_tab[r0: r0 + rows]
+        sims = pair_l1_sim(qb, c_tab, dim, cand)
+        means = row_topk_mean(sims, k)
+        kth = torch.topk(sims, k, dim=1).values[:, k - 1].to(torch.float64)
+        # a non-member's distance is at least worst * step - err (+ 4 steps: float rounding of large grid sums)
+        bound = 1.0 - (worst * step - (err + 4.0 * step))
+        redo = torch.nonzero(~(bound <= kth)).reshape(-1) if c < nc else torch.zeros(0, dtype=torch.int64, device=q_tab.device)
+        if redo.numel():
+            redone += int(redo.numel())
+            for b0 in range(0, redo.numel(), 4096):
+                idx = redo[b0: b0 + 4096]
+                s = sim_matrix(qb.index_select(0, idx).contiguous(), c_tab, dim, 'manhattan')
+                means[idx] = row_topk_mean(s, k)
+                del s
+        out[r0: r0 + rows] = means
+        del strip
+    if stats is not None:
+        stats['uncertified'] = stats.get('uncertified', 0) + redone
+    return out
+
+
+def csls_means_l1_grid(e1, e2, dim, k, cols=True):
+    """CSLS means of the manhattan metric from grid distances -> (r [n1], c [n2] or None, grid): the L1Grid keeps the query
+    strips (when they fit) for rank_eval_l1_grid(..., grid=grid)."""
+    grid = L1Grid(e1, e2, dim)
+    keep = grid if (cols and grid.can_keep()) else None        # the strips are kept for the single-process rank pass only
+    r = l1_grid_topk_means(e1, e2, grid.q1, grid.q2, dim, k, grid.step, grid.err, keep=keep)
+    c = l1_grid_topk_means(e2, e1, grid.q2, grid.q1, dim, k, grid.step, grid.err) if cols else None
+    return r, c, grid
+
+
+def rank_eval_l1_grid(e1, e2, dim, gold_offset=0, block_bytes=2 << 30, csls_r=None, csls_c=None, grid=None):
     """rank_eval(metric='manhattan') without the fp64 distance of every pair: 16-bit grid distances of all pairs
-    (oea_l1_u16_strip, blocks of query rows), then oea_rank_l1_grid_rows -- exact similarities only where the grid leaves a
-    doubt.  Same ranks and nearest candidates as the all-pairs fp64 kernel (tested)."""
+    (oea_l1_u16_strip, blocks of query rows), then oea_rank_l1_grid_rows[_csls] -- exact similarities only where the grid
+    leaves a doubt.  Same ranks and nearest candidates as the all-pairs fp64 kernel (tested), with or without CSLS means."""
     n1, n2 = e1.shape[0], e2.shape[0]
-    lo1, hi1 = torch.aminmax(e1[:, :dim])
-    lo2, hi2 = torch.aminmax(e2[:, :dim])
-    lo, hi = min(float(lo1), float(lo2)), max(float(hi1), float(hi2))
-    step = max(hi - lo, 1e-30) / 65535.0
-    q1 = quantize_rows_u16(e1, dim, lo, 1.0 / step)
-    q2 = quantize_rows_u16(e2, dim, lo, 1.0 / step)
-    err = (dim * 1.02 + 1.0) * step                      # half a step per operand and column, + the fp32 rounding of the grid map
-    ld = (n2 + 31) // 32 * 32
+    if grid is None or grid.e1.data_ptr() != e1.data_ptr() or grid.e2.data_ptr() != e2.data_ptr() or grid.e1.shape != e1.shape:
+        grid = L1Grid(e1, e2, dim, block_bytes)
+    step, err, ld = grid.step, grid.err, grid.ld
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
-    rows_per = int(max(128, min(n1, block_bytes // (4 * ld))))
     n_exact = torch.zeros(1, dtype=torch.int32, device=e1.device)
-    r0 = 0
-    while r0 < n1:
-        rows = min(rows_per, n1 - r0)
-        strip = l1_u16_strip(q1[r0: r0 + rows], q2)
-        check(lib().oea_rank_l1_grid_rows(_p(strip), rows, r0, n2, ld, _p(e1), e1.shape[1], _p(e2), e2.shape[1], dim, int(gold_offset),
-                                          float(step), float(err), _p(rank), _p(argmax), _p(n_exact), _stream()))
+    csls = csls_r is not None
+    for r0, rows in grid.blocks():
+        strip = grid.strip(r0, rows)
+        if csls:
+            check(lib().oea_rank_l1_grid_rows_csls(_p(strip), rows, r0, n2, ld, _p(e1), e1.shape[1], _p(e2), e2.shape[1], dim,
+                                                   int(gold_offset), float(step), float(err), _p(csls_r), _p(csls_c), _p(rank),
+                                                   _p(argmax), _p(n_exact), _stream()))
+        else:
+            check(lib().oea_rank_l1_grid_rows(_p(strip), rows, r0, n2, ld, _p(e1), e1.shape[1], _p(e2), e2.shape[1], dim,
+                                              int(gold_offset), float(step), float(err), _p(rank), _p(argmax), _p(n_exact), _stream()))
         del strip
-        r0 += rows
-        if r0 == rows and r0 < n1 and int(n_exact.item()) > rows // 64:
+        grid.strips.pop(r0, None)
+        r1 = r0 + rows
+        if r0 == 0 and r1 < n1 and int(n_exact.item()) > rows // 64:
             # the grid is useless for this table (outliers stretch its range: most candidates are within the error bound of
             # the gold distance and whole rows fall back to exact pairs): the rest through the all-pairs fp64 kernel
-            rest = n1 - r0
+            rest = n1 - r1
             ws = torch.empty(lib().oea_rank_workspace_bytes(rest), dtype=torch.uint8, device=e1.device)
             rk, am = torch.empty(rest, dtype=torch.int32, device=e1.device), torch.empty(rest, dtype=torch.int32, device=e1.device)
-            check(lib().oea_rank_eval(_p(e1[r0:]), rest, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC['manhattan'], None, None,
-                                      int(gold_offset) + r0, _p(rk), _p(am), _p(ws), _stream()))
-            rank[r0:], argmax[r0:] = rk, am
+            check(lib().oea_rank_eval(_p(e1[r1:]), rest, e1.shape[1], _p(e2), n2, e2.shape[1], dim, METRIC['manhattan'],
+                                      _p(csls_r[r1:].contiguous()) if csls else None, _p(csls_c), int(gold_offset) + r1, _p(rk), _p(am),
+                                      _p(ws), _stream()))
+            rank[r1:], argmax[r1:] = rk, am
+            grid.strips.clear()
             break
     return rank, argmax
 

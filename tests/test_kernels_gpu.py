@@ -1017,3 +1017,27 @@ def test_manhattan_evaluation_from_grid_distances_equals_all_pairs_fp64(ops, cas
     assert torch.equal(rank, ref_rank) and torch.equal(arg, ref_arg)
     if case == "trained":
         assert int((rank == 0).sum()) > n1 // 2
+    # ---- the same with CSLS (basic_model.py:132-135: test() evaluates a second time with csls = args.csls): the means from
+    # the k + margin nearest on the grid (certified lists, exact similarities in scipy's summation order) and the ranks of
+    # (2 s - r) - c from the strip + exact decisions == strips of every pair in fp64 + rank_valu_kernel
+    from openea_amd.modules.finding.similarity import csls_means_device
+    sq = e2[off:off + n1] + 0.05 * rng.standard_normal((n1, d)).astype(np.float32) if case in ("random",) else e1
+    s1, s2 = ops.to_table(sq), t2
+    k = 10
+    monkeypatch.setenv("OEA_L1_EVAL", "f64")
+    r_ref, c_ref = csls_means_device(s1, s2, d, "manhattan", k)
+    rk_ref, am_ref = ops.rank_eval(s1, s2, d, "manhattan", r_ref, c_ref, gold_offset=off)
+    monkeypatch.setenv("OEA_L1_EVAL", "grid")
+    stats = {}
+    grid = ops.L1Grid(s1, s2, d, block_bytes=4 * 4000 * 600)
+    r = ops.l1_grid_topk_means(s1, s2, grid.q1, grid.q2, d, k, grid.step, grid.err, keep=grid, stats=stats)
+    c = ops.l1_grid_topk_means(s2, s1, grid.q2, grid.q1, d, k, grid.step, grid.err, block_bytes=4 * 1500 * 1000, stats=stats)
+    assert torch.equal(r, r_ref) and torch.equal(c, c_ref), (case, stats)
+    assert len(grid.strips) == 3                                   # left behind for the rank pass
+    rk, am = ops.rank_eval_l1_grid(s1, s2, d, gold_offset=off, csls_r=r, csls_c=c, grid=grid)
+    assert torch.equal(rk, rk_ref) and torch.equal(am, am_ref), case
+    assert not grid.strips
+    rk, am = ops.rank_eval(s1, s2, d, "manhattan", r, c, gold_offset=off)        # the dispatch (fresh grid, default blocks)
+    assert torch.equal(rk, rk_ref) and torch.equal(am, am_ref)
+    if case in ("degenerate", "outliers", "clustered"):
+        assert stats["uncertified"] > 0                             # these tables send rows through the all-pairs fallback
