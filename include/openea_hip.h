@@ -654,6 +654,14 @@ int oea_highway_bwd(const float *a, const float *b, const float *p, const float 
 size_t oea_gemm_tn_workspace_floats(int64_t m, int32_t k1, int32_t k2);
 int oea_gemm_tn_f32(const float *a, int32_t lda, int32_t k1, const float *b, int32_t ldb, int32_t k2, int64_t m, float *out,
                     int32_t ld_out, float *workspace, void *stream);
+/* The same product cut at its row chunks for a row-sharded job (the weight gradients dW = X^T dY of the GNN approaches' dense
+ * layers, approaches/alinet.py:574-582): oea_gemm_tn_plan gives the chunk count and rows per chunk of the single-process call;
+ * a rank runs oea_gemm_tn_partial on ITS chunks (slots [chunk_begin, chunk_end) of workspace [chunks][k1 * k2]), the slots are
+ * all-gathered, and oea_gemm_tn_reduce adds all of them in chunk order -- the single-process summation order: same bits. */
+int oea_gemm_tn_plan(int64_t m, int32_t k1, int32_t k2, int32_t *chunks, int64_t *rows_per_chunk);
+int oea_gemm_tn_partial(const float *a, int32_t lda, int32_t k1, const float *b, int32_t ldb, int32_t k2, int64_t m,
+                        int32_t chunk_begin, int32_t chunk_end, float *workspace, void *stream);
+int oea_gemm_tn_reduce(const float *workspace, int32_t chunks, int32_t k1, int32_t k2, float *out, int32_t ld_out, void *stream);
 
 /* RDGCN's dense glue between its sparse operators, one pass each way (rdgcn.py:184-191, 250-256, 330-333):
  * oea_sigmoid_mix_*: gate = sigmoid(p + bias), out = gate b + (1 - gate) a (highway; p = a W from a library GEMM);

@@ -195,6 +195,9 @@ PROTOTYPES = {
     "oea_highway_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "oea_gemm_tn_workspace_floats": (C.c_size_t, [_i64, _i32, _i32]),
     "oea_gemm_tn_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _vp]),
+    "oea_gemm_tn_plan": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i64)]),
+    "oea_gemm_tn_partial": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "oea_gemm_tn_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "oea_sigmoid_mix_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "oea_sigmoid_mix_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "oea_relu_axpy_fwd": (C.c_int, [_vp, _vp, C.c_float, _i64, _vp, _vp]),

@@ -207,4 +207,46 @@ int oea_gemm_tn_f32(const float *a, int32_t lda, int32_t k1, const float *b, int
     return OEA_OK;
 }
 
+// The same product cut at its row chunks, for a job whose ranks each own a block of the rows (models/graph_ops.py:
+// the weight gradients of the GNN approaches' dense layers): rank r computes the partial products of ITS chunks into their
+// slots of the [chunks][k1 * k2] workspace, the slots are all-gathered, and every rank adds all of them in chunk order --
+// the single-process kernel's summation order, so the sharded job gives the same bits.
+int oea_gemm_tn_plan(int64_t m, int32_t k1, int32_t k2, int32_t *chunks, int64_t *rows_per_chunk) {
+    OEA_REQUIRE(chunks && rows_per_chunk && m > 0 && k1 > 0 && k2 > 0, "arguments");
+    const Plan p = plan_tn(m, k1, k2);
+    *chunks = p.chunks;
+    *rows_per_chunk = p.rows_per_chunk;
+    return OEA_OK;
+}
+
+int oea_gemm_tn_partial(const float *a, int32_t lda, int32_t k1, const float *b, int32_t ldb, int32_t k2, int64_t m,
+                        int32_t chunk_begin, int32_t chunk_end, float *workspace, void *stream) {
+    OEA_REQUIRE(a && b && workspace && k1 > 0 && k2 > 0 && m > 0 && k1 <= lda && k2 <= ldb, "shapes");
+    OEA_REQUIRE(k1 % 4 == 0 && k2 % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "k1, k2, lda, ldb: multiples of 4 (16-byte row segments)");
+    OEA_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "16-byte aligned operands");
+    const Plan p = plan_tn(m, k1, k2);
+    OEA_REQUIRE(0 <= chunk_begin && chunk_begin <= chunk_end && chunk_end <= p.chunks, "0 <= chunk_begin <= chunk_end <= chunks");
+    if (chunk_begin == chunk_end) return OEA_OK;
+    const int64_t r0 = (int64_t)chunk_begin * p.rows_per_chunk;
+    const int64_t r1 = std::min<int64_t>(m, (int64_t)chunk_end * p.rows_per_chunk);
+    const int64_t stride = (int64_t)k1 * k2;
+    const dim3 grid((unsigned)(p.tiles_i * p.tiles_j), (unsigned)(chunk_end - chunk_begin));
+    hipStream_t st = oea::as_stream(stream);
+    // rows_per_chunk is a multiple of the 16-row slab: the offset operands stay 16-byte aligned
+    const float *a0 = a + r0 * lda, *b0 = b + r0 * ldb;
+    float *dst = workspace + (int64_t)chunk_begin * stride;
+    if (p.tj == 128) gemm_tn_kernel<2><<<grid, 256, 0, st>>>(a0, lda, k1, b0, ldb, k2, r1 - r0, p.rows_per_chunk, p.tiles_j, dst, stride, k2);
+    else gemm_tn_kernel<1><<<grid, 256, 0, st>>>(a0, lda, k1, b0, ldb, k2, r1 - r0, p.rows_per_chunk, p.tiles_j, dst, stride, k2);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_gemm_tn_reduce(const float *workspace, int32_t chunks, int32_t k1, int32_t k2, float *out, int32_t ld_out, void *stream) {
+    OEA_REQUIRE(workspace && out && chunks >= 1 && k1 > 0 && k2 > 0 && k2 <= ld_out, "arguments");
+    const int64_t stride = (int64_t)k1 * k2;
+    add_chunks_kernel<<<(unsigned)oea::ceil_div(stride, 256), 256, 0, oea::as_stream(stream)>>>(workspace, chunks, stride, k1, k2, out, ld_out);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
 }  // extern "C"

@@ -368,6 +368,18 @@ class BiasTanhFn(torch.autograd.Function):
         return ops.bias_tanh_bwd(y, gy.contiguous())
 
 
+def weight_grad(x, dy):
+    """dW = x^T dy of a dense layer in front of a sparse aggregate.  Under torch.distributed the row chunks of the product
+    are shared by the ranks (ops.gemm_tn_sharded: this rank's chunk partials, one all-gather of [chunks, d_in * d_out], all
+    chunks added in chunk order = the single-process bits); OEA_DP_DENSE_DW=0 keeps the replicated product."""
+    import os
+    from . import dist as mdist
+    rank, world = mdist.world()
+    if world > 1 and os.environ.get("OEA_DP_DENSE_DW", "1") != "0":
+        return ops.gemm_tn_sharded(x, dy, rank, world, mdist.allgather_blocks)
+    return ops.gemm_tn(x, dy)
+
+
 class DenseFn(torch.autograd.Function):
     """y = x W (+ bias row) for a tall x [E, d_in]: forward and dx on the library's NN / NT kernels (85-105 TFLOP/s at these
     shapes), the weight gradient dW = x^T dy on oea_gemm_tn_f32 (the library's TN kernels run it at 44-57)."""
@@ -383,7 +395,7 @@ class DenseFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dy @ w.t() if ctx.needs_input_grad[0] else None
-        dw = ops.gemm_tn(x.contiguous(), dy) if ctx.needs_input_grad[1] else None
+        dw = weight_grad(x.contiguous(), dy) if ctx.needs_input_grad[1] else None
         return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
 
 
@@ -413,7 +425,7 @@ class DiagHighwayFn(torch.autograd.Function):
         dxs = ctx.graph.bwd.apply(dh_pre, x.shape[1])
         dx = torch.addmm(da, dp, kernel_gate.t())
         dx.addcmul_(dxs, w0)
-        return dx, ops.colsum_prod(dxs, x).reshape(w0.shape), ops.gemm_tn(x, dp), dbias, None
+        return dx, ops.colsum_prod(dxs, x).reshape(w0.shape), weight_grad(x, dp), dbias, None
 
 
 class ReluAxpyFn(torch.autograd.Function):

@@ -1063,6 +1063,30 @@ def gemm_tn(a, b):
     return out
 
 
+def gemm_tn_sharded(a, b, rank, world, allgather_blocks):
+    """a^T @ b in a job whose ranks share the work by ROW CHUNKS (include/openea_hip.h: oea_gemm_tn_partial / _reduce): this
+    rank's chunks, one all-gather of the chunk partials (allgather_blocks(full [chunks, k1*k2], bounds)), then all chunks
+    added in chunk order -- bit-identical with gemm_tn on one process.  Falls back to the replicated product when the shape
+    does not take the kernel or has fewer chunks than ranks."""
+    m, k1 = a.shape
+    k2 = b.shape[1]
+    if (world <= 1 or m == 0 or k1 % 4 or k2 % 4 or not (a.is_contiguous() and b.is_contiguous()) or a.data_ptr() % 16
+            or b.data_ptr() % 16):
+        return gemm_tn(a, b)
+    chunks, rpc = C.c_int32(0), C.c_int64(0)
+    check(lib().oea_gemm_tn_plan(m, k1, k2, C.byref(chunks), C.byref(rpc)))
+    chunks = chunks.value
+    if chunks < world:
+        return gemm_tn(a, b)
+    bounds = [chunks * r // world for r in range(world + 1)]
+    ws = torch.empty((chunks, k1 * k2), dtype=torch.float32, device=a.device)
+    check(lib().oea_gemm_tn_partial(_p(a), k1, k1, _p(b), k2, k2, m, bounds[rank], bounds[rank + 1], _p(ws), _stream()))
+    allgather_blocks(ws, bounds)
+    out = torch.empty((k1, k2), dtype=torch.float32, device=a.device)
+    check(lib().oea_gemm_tn_reduce(_p(ws), chunks, k1, k2, _p(out), k2, _stream()))
+    return out
+
+
 def sigmoid_mix_fwd(a, b, p, bias):
     out = torch.empty_like(a)
     check(lib().oea_sigmoid_mix_fwd(_p(a), _p(b), _p(p), _p(bias), a.shape[0], a.shape[1], _p(out), _stream()))
