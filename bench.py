@@ -783,6 +783,8 @@ def pmc_child(torch, ops, dev):
         for _ in range(reps):
             fn()
         torch.cuda.synchronize()
+        # END marker: what follows (building the next operator, its warm-up calls) belongs to no leg
+        ops.check(ops.lib().oea_fill_f32(mark_buf.data_ptr(), 256 * (PMC_MARK0 + len(PMC_LEGS)), 0.0, torch.cuda.current_stream().cuda_stream))
     m, kgs, se, d, x = _build_gcn(torch, ops, dev, rng)
     se.adj.mm(x, d, act=1)
     leg("gcn_spmm_15k", lambda: se.adj.mm(x, d, act=1), 3)
@@ -838,8 +840,9 @@ def _pmc_pass_legs(counter, timeout_s):
         legs = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
         cur = None
         for _, name, grid, val in rows:
-            if "fill_kernel" in name and grid % 256 == 0 and PMC_MARK0 <= grid // 256 < PMC_MARK0 + len(PMC_LEGS):
-                cur = PMC_LEGS[grid // 256 - PMC_MARK0]
+            if "fill_kernel" in name and grid % 256 == 0 and PMC_MARK0 <= grid // 256 <= PMC_MARK0 + len(PMC_LEGS):
+                i = grid // 256 - PMC_MARK0
+                cur = PMC_LEGS[i] if i < len(PMC_LEGS) else None          # the end marker closes the leg
                 continue
             if cur is not None:
                 legs[cur][name][0] += val
@@ -882,8 +885,10 @@ def measure_gnn_traffic(timeout_s=300):
 
 
 def _with_hbm(block, traffic, leg_name, ms, kernel_sub=None):
-    """attach the counter traffic of one operator call to its roofline block: hbm_frac = counter bytes / time / HBM peak --
-    a formula fraction above ~0.79 (6.3 TB/s achievable of 8) is served by L2 / MALL by definition"""
+    """attach the counter traffic of one operator call to its roofline block: hbm_frac = counter bytes / time / HBM peak.
+    FETCH_SIZE / WRITE_SIZE count what crosses the L2 <-> fabric boundary, i.e. L2 misses INCLUDING those the 256 MB Infinity
+    Cache (MALL) serves: hbm_frac can exceed what HBM delivers (6.3 TB/s achievable = 0.79), and counter bytes above the
+    formula bytes mean gathered rows are fetched more than once per nonzero's share of L2"""
     t = (traffic or {}).get(leg_name)
     if not t:
         block["traffic"] = None
@@ -1003,9 +1008,11 @@ def gnn_legs(torch, ops, dev, traffic=None):
                                                         ms_1hop, formula="nnz*(8+4d) + 4*N*d",
                                                         perfect_reuse_bytes=int(g1.nnz * 8 + 8 * n * d)),
                                              traffic, "alinet_1hop_100k", ms_1hop)}
-    out["note"] = ("frac = SURVEY 8d's formula bytes (every gathered row counted once per nonzero) / time / 8 TB/s; hbm_frac = counter "
-                   "bytes / time / 8 TB/s.  A formula fraction above ~0.79 (6.3 TB/s achievable) means the gathered rows come out "
-                   "of L2 / MALL; perfect_reuse_bytes = nnz*8 + 8*N*d is the floor with every row read once")
+    out["note"] = ("frac = SURVEY 8d's formula bytes (every gathered row counted once per nonzero) / time / 8 TB/s; traffic = counter "
+                   "bytes (2*FETCH_SIZE + WRITE_SIZE) crossing the L2 <-> fabric boundary per call, hbm_frac = traffic / time / 8 TB/s "
+                   "-- the counters include L2 misses served by the 256 MB Infinity Cache, so hbm_frac above 0.79 (6.3 TB/s "
+                   "achievable HBM) means MALL hits, and traffic below the formula bytes means rows re-used out of L2; "
+                   "perfect_reuse_bytes = nnz*8 + 8*N*d is the floor with every row read once")
     return out
 
 
