@@ -1349,6 +1349,9 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     hipStream_t st = oea::as_stream(stream);
 #define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, phase, st)
+    // Measured and dropped (round 4, gpurun_out r04f): 64-lane groups for 64 < ld <= 128 (one positive per wave, two fragments
+    // per lane): scoring kernel 17.8 -> 20.0 us at the 15K shape, 64.2 -> 60.4 us at the 100K shape, where the 64-lane optimiser
+    // kernel loses 18 us against the 16-lane one -- 3 % at best for a second instantiation of every kernel.
     if (ld <= 32) OEA_STEP(32, 1);
     else if (ld <= 64) OEA_STEP(32, 2);
     else if (ld <= 96) OEA_STEP(32, 3);
