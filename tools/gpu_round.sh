@@ -1,28 +1,14 @@
 #!/bin/bash
-# Run ON the GPU box (through gpurun): GPU test suite + bench lines + kernel variants, logs into gpurun_out/$1.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a'
+# Run ON the GPU box (through gpurun): the round-end sequence -- GPU test suite, smoke(), the driver-like bench line, the
+# kernel trace of the same command -- into gpurun_out/$1 (default tag "round").
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r04_final'
+# then on the build host copy what should be judged into profiles/ (profiles are committed, gpurun_out/ is scratch).
 set -u
 TAG=${1:-round}
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/$TAG
-mkdir -p $OUT
-cd $R
-timeout 1200 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
-echo "pytest rc=$?" >> $OUT/pytest_gpu.log
-tail -5 $OUT/pytest_gpu.log
-timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-tail -c 2500 $OUT/bench_default.json
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --no-extra > $OUT/bench_driver_like.json 2> $OUT/bench_driver_like.err
-for r in ; do
-  OEA_APPLY_ROWS=$r timeout 300 python bench.py --no-cpu --no-extra > $OUT/bench_applyrows_$r.json 2> $OUT/bench_applyrows_$r.err
-done
-python - <<PY
-import json, glob
-for f in sorted(glob.glob("$OUT/bench_*.json")):
-    try:
-        j = json.loads([l for l in open(f) if l.startswith("{")][-1])
-        r = j["roofline"]
-        print(f.split("/")[-1], "value %.1f M/s  ms/step %.4f  fwd %.2f us  apply %.2f us" % (j["value"] / 1e6, j["ms_per_step"], r["avg_kernel_us"], r["apply_rows_avg_us"]))
-    except Exception as e:
-        print(f, "unreadable", e)
-PY
+O=gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > $O/pytest_gpu.log 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $O/smoke.log 2>&1
+( S=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 2> $O/bench.err | tail -1; echo "bench wall $(( $(date +%s) - S )) s" ) > $O/bench_driver_like.log 2>&1
+tools/prof.sh trace ${TAG}_trace -- python bench.py --steps 20 --warmup 5 --no-cpu --no-traffic --no-gnn
+tail -3 $O/pytest_gpu.log; cat $O/smoke.log; tail -1 $O/bench_driver_like.log
