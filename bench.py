@@ -415,7 +415,10 @@ def main():
     m = wl.measure(args.steps, args.warmup, args.repeats)
     extra = {}
     if world > 1:
-        extra["exchange_phases"] = wl.phase_times(args.steps)                      # every rank takes part
+        try:
+            extra["exchange_phases"] = wl.phase_times(args.steps)                  # every rank takes part
+        except Exception as e:      # noqa: BLE001 -- a side measurement must not take the line down
+            extra["exchange_phases"] = {"error": repr(e)[:300]}
     if not args.no_extra:                   # eval / neighbour legs: row-sharded over the ranks (every rank takes part)
         extra.update(extra_legs(torch, ops, wl.ent, wl.kgs, args.dim, wl.k1))
     multi = None

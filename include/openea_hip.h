@@ -446,6 +446,25 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
                   int32_t *rank, int32_t *argmax, void *workspace, void *stream);
 /* integer reductions of rank[]: hits[i] = #{rank < top_k[i]}, rank_sum = sum(rank+1) (int64),
  * rr_sum = sum 1/(rank+1) (double, fixed summation order).  alignment.py:163-168. */
+/* Inner-product evaluation through a CERTIFIED bf16 prefilter (round 4): the tile sweep multiplies bf16 splits of the operands
+ * (x = hi + lo: hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, 3/16 of the fp32 matrix time), counts the candidates that are
+ * greater than the gold value beyond the error bound, and RECORDS the (query, candidate) pairs inside the bound of the gold value or
+ * of the row's running maximum; a second kernel decides the records with the exact k-ordered fmaf chain.  rank / argmax are
+ * those of oea_rank_eval(OEA_METRIC_INNER) bit for bit.  status int32[2] (device): [0] != 0 = the record buffer overflowed,
+ * the results are INVALID and the caller must take oea_rank_eval; [1] = records written.  Workspace:
+ * oea_rank_eval_bf16_workspace_bytes(n1, dim).  No CSLS terms (the fp32 sweep takes them). */
+size_t oea_rank_eval_bf16_workspace_bytes(int64_t n1, int32_t dim);
+int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                       int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status, void *workspace, void *stream);
+/* the same + argmax + the metrics of oea_rank_metrics in one go: out int64 [nk + 4] (device) = hits[nk], sum(rank + 1), the bits of
+ * the double sum 1 / (rank + 1) (the reduction order of oea_rank_metrics), overflow flag (!= 0: INVALID, take
+ * oea_rank_eval_metrics), records written -- one device-to-host copy brings results and status back. */
+int oea_rank_eval_metrics_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
+                               int64_t *out_dev, void *workspace, void *stream);
+/* the prefilter's approximate similarities out[i, j] ~ <e1[i], e2[j]> (tests of the error bound, timing) */
+int oea_sim_bf16_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, float *out,
+                        int64_t ld_out, void *stream);
 /* The inner-product evaluation in TWO launches (the 10,500^2 call spent a third of its time in eight small
  * launches around the 0.20 ms sweep): a prologue that packs both operands, computes the gold similarities and clears the
  * merge buffers, and the tile sweep, whose last workgroup extracts argmax and reduces the metrics in a fixed order.

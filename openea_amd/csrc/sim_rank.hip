@@ -1917,6 +1917,446 @@ static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, 
 }
 
 
+// ---- certified bf16 prefilter for the inner-product rank sweep (round 4) ------------------------------------------------------
+// The exact evaluation multiplies in fp32 (v_mfma_f32_32x32x2_f32: 1/16 of the bf16 matrix rate).  Here every operand is split
+// x = hi + lo + r (hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|) and the tile sweep accumulates hi.hi + hi.lo + lo.hi with
+// v_mfma_f32_32x32x16_bf16 -- 3/16 of the fp32 pipe time, the same LDS bytes (hi + lo = 4 B per element).  The result v~ is
+// within tol = eps(dim) |q|max |c|max of the exact k-ordered fmaf chain v (split residue 3 * 2^-18, fp32 accumulation of
+// 3 * Kp products bounded term by term, the chain's own rounding).  So against the exact gold value g:
+//     v~ > g + tol   certainly greater: counted in the sweep;      v~ < g - tol   certainly smaller: ignored;
+//     |v~ - g| <= tol                 a RECORD (query, candidate): decided afterwards by the exact chain, tie rule included;
+// and the nearest candidate: a candidate can only be the exact row maximum if v~ + tol >= (the best lower bound v~' - tol seen
+// so far, gold included), so those are recorded too (the bound is shared by the lanes of a row through an atomic maximum).
+// The fix-up kernel evaluates the records -- a few dozen per row -- exactly.  Ranks and nearest candidates are those of the
+// fp32 sweep, bit for bit; if the record buffer overflows the caller takes the fp32 sweep.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {                   // round to nearest even (finite inputs)
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// packed row = kp "float slots" (kp = dim rounded up to 32): every 32-k chunk is 128 B = 8 granules of 8 bf16; granule
+// (s * 2 + h) * 2 + p holds k = 32 chunk + 16 s + 8 h + [0, 8) of the hi (p = 0) or lo (p = 1) part -- one MFMA operand of lane
+// half h in k-step s.  Same bytes per row as the fp32 packed layout, so stage_packed moves it unchanged.
+__global__ void pack_rows_bf16_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, uint4 *__restrict__ dst,
+                                      int64_t n_pad, int kp) {
+    const int cpr = kp / 4;
+    const int64_t total = n_pad * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const int g = c & 7, k0 = 32 * (c >> 3) + 16 * (g >> 2) + 8 * ((g >> 1) & 1), lo = g & 1;
+        uint32_t h[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float x = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
+            const uint32_t hi = bf16_rne(x);
+            h[t] = lo ? bf16_rne(x - __uint_as_float(hi << 16)) : hi;
+        }
+        dst[i] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+}
+
+// max row norm of a table as the bits of a non-negative float (integer order == float order)
+__global__ void row_norm_max_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, unsigned *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float nr = 0.f;
+    if (i < n) {
+        float ss = 0.f;
+        for (int k = 0; k < dim; ++k) ss = fmaf(src[i * ld + k], src[i * ld + k], ss);
+        nr = sqrtf(ss) * 1.0000005f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nr = fmaxf(nr, __shfl_xor(nr, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(nr));
+}
+
+// acc += hi.hi + hi.lo + lo.hi of one chunk (ksteps = 1 or 2 k-steps of 16)
+__device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, const float *__restrict__ Bs, int ksteps,
+                                               f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = (lane >> 1) & 7, half = lane >> 5;
+    const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
+    const float *bp = Bs + (wn * 64 + (lane & 31)) * PLD;
+    for (int s = 0; s < ksteps; ++s) {
+        const int g = 4 * s + 2 * half;
+        const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
+        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
+        const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
+        const bf16x8 b0h = *reinterpret_cast<const bf16x8 *>(bp + oh), b0l = *reinterpret_cast<const bf16x8 *>(bp + ol);
+        const bf16x8 b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh), b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+    }
+}
+
+// tile_pipeline_packed for the bf16 layout: chunks of two k-steps (32 k = 128 B per row), LDS-DMA staging unchanged
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
+                                                   int64_t n0, int64_t n_tiles, MTile m_tile, float *As, float *Bs,
+                                                   Epilogue epilogue) {
+    const int S = (dim + 15) / 16;
+    const int nchunk = (S + 1) / 2;
+    const int64_t total = n_tiles * nchunk;
+    if (total == 0) return;
+    constexpr int BUF = TILE * LDS_LD;
+    stage_packed(am, kp, m_tile(0), 0, As);
+    stage_packed(bn, kp, n0, 0, Bs);
+    __syncthreads();
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    int64_t t = 0;
+    int kc = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        const int cur = (int)(it & 1);
+        if (it + 1 < total) {
+            int kc1 = kc + 1;
+            int64_t t1 = t;
+            if (kc1 == nchunk) { kc1 = 0; ++t1; }
+            stage_packed(am, kp, m_tile(t1), kc1 * BK, As + (cur ^ 1) * BUF);
+            stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
+        }
+        mma_chunk_bf16(As + cur * BUF, Bs + cur * BUF, min(2, S - 2 * kc), acc);
+        __syncthreads();
+        if (++kc == nchunk) {
+            epilogue(t, acc);
+            zero_acc(acc);
+            kc = 0;
+            ++t;
+        }
+    }
+}
+
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
+
+constexpr uint32_t kRecTop = 0x80000000u;        // record kinds: bit 31 of the candidate word
+
+// gold, tolerance, per-row state of the bf16 sweep
+__global__ void rank_bf16_init_kernel(const float *__restrict__ gold, int64_t n1, int64_t gold_off, const unsigned *__restrict__ nmax,
+                                      float eps_rel, float *__restrict__ tol_out, int32_t *__restrict__ rank,
+                                      unsigned long long *__restrict__ best_key, unsigned *__restrict__ lbrow,
+                                      unsigned *__restrict__ rec_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float tol = eps_rel * __uint_as_float(nmax[0]) * __uint_as_float(nmax[1]) + 1e-30f;
+    if (i == 0) { *tol_out = tol; rec_cnt[0] = 0u; rec_cnt[1] = 0u; }
+    if (i >= n1) return;
+    rank[i] = 0;
+    best_key[i] = ((unsigned long long)f2ord(gold[i]) << 32) | (0xFFFFFFFFu - (uint32_t)(i + gold_off));     // the gold is a candidate
+    lbrow[i] = f2ord(gold[i] - tol);
+}
+
+// WARM: a first pass over the first `tiles_per_chunk` candidate tiles only raises the rows' lower bounds (lbrow = max v~ - tol
+// over a few thousand candidates: about the (n2 / 2048)-th largest value of the row), so that the full sweep records as
+// nearest-candidate suspects only the few dozen candidates above that -- without it a row whose gold is far from the top
+// records every running maximum of every lane (hundreds per row).
+// Records go to a slice of the record buffer PRIVATE to the wave (slot = count + prefix of a ballot; no returning atomic:
+// the first version took one global round trip per recording wave instruction and ran 4x slower on rows whose gold is far
+// from the top).  rec_cnt[2 + wave id] = the slice's length; a full slice raises the overflow flag.
+template <bool WARM, bool INTERIOR, class Acc, class Rec>
+__device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const float (&g)[2], const float (&ghi)[2], float (&lb)[2],
+                                               float (&lbm)[2], int (&cnt)[2], bool (&dirty)[2], const int64_t (&qi)[2], int64_t gold_off,
+                                               float tol, Rec &&record) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
+            const bool jin = INTERIOR || j < n2;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float v = acc[tm][tn][r];
+                if (WARM) {
+                    if (jin) lb[tn] = fmaxf(lb[tn], v - tol);
+                    continue;
+                }
+                cnt[tn] += (v > ghi[tn]) & jin;
+                const bool hit = ((v >= lbm[tn]) | (fabsf(v - g[tn]) <= tol)) & jin;
+                if (__ballot(hit)) {                                  // wave-uniform branch: rare
+                    const bool other = hit && (int64_t)j != qi[tn] + gold_off;
+                    record(other && v + tol >= lb[tn], tn, j, kRecTop);
+                    record(other && fabsf(v - g[tn]) <= tol, tn, j, 0u);
+                    if (hit && v - tol > lb[tn]) { lb[tn] = v - tol; lbm[tn] = lb[tn] - tol; dirty[tn] = true; }
+                }
+            }
+        }
+    }
+}
+
+template <bool WARM>
+__global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
+    const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
+    const float *__restrict__ gold, const float *__restrict__ tol_ptr, int tiles_per_chunk, int64_t gold_off,
+    int32_t *__restrict__ rank, unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t q0 = (int64_t)blockIdx.x * TILE;
+    const int64_t nct = (n2 + TILE - 1) / TILE;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
+    const float tol = *tol_ptr;
+    const unsigned wid = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+    uint2 *__restrict__ my_rec = rec + (size_t)wid * slice_cap;
+    unsigned nrec = 0;                                     // wave-uniform
+    int64_t qi[2];
+    float g[2], ghi[2], lb[2], lbm[2];
+    int cnt[2] = {0, 0};
+    bool dirty[2] = {false, false};
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
+        const bool ok = qi[tn] < n1;
+        g[tn] = ok ? gold[qi[tn]] : INFINITY;             // padding rows: nothing counts, nothing is recorded
+        ghi[tn] = g[tn] + tol;
+        lb[tn] = ok ? g[tn] - tol : INFINITY;
+        lbm[tn] = lb[tn] - tol;
+    }
+    auto record = [&](bool pred, int tn, int j, uint32_t kind) {
+        const unsigned long long m = __ballot(pred);
+        if (m == 0ull) return;
+        const unsigned at = nrec + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (pred && at < slice_cap) my_rec[at] = make_uint2((uint32_t)qi[tn], (uint32_t)j | kind);
+        nrec += (unsigned)__popcll(m);
+    };
+    tile_pipeline_bf16(
+        cp, kp, qp, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
+        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
+        [&](int64_t t, f32x16 (&acc)[2][2]) {
+            const int64_t c0 = (ct_begin + t) * TILE;
+            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)                 // the other lanes / workgroups of the row may have raised the bound
+                if (qi[tn] < n1) {
+                    const float o = ord2f(__hip_atomic_load(lbrow + qi[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (o > lb[tn]) { lb[tn] = o; lbm[tn] = o - tol; }
+                }
+            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true>(acc, jb, (int)n2, g, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, record);
+            else rank_bf16_tile<WARM, false>(acc, jb, (int)n2, g, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, record);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+                if (dirty[tn]) { atomicMax(lbrow + qi[tn], f2ord(lb[tn])); dirty[tn] = false; }
+        });
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        if (WARM) {
+            lb[tn] = fmaxf(lb[tn], __shfl_xor(lb[tn], 32, 64));
+            if (lane < 32 && qi[tn] < n1) atomicMax(lbrow + qi[tn], f2ord(lb[tn]));
+            continue;
+        }
+        cnt[tn] += __shfl_xor(cnt[tn], 32, 64);
+        if (lane < 32 && qi[tn] < n1 && cnt[tn]) atomicAdd(rank + qi[tn], cnt[tn]);
+    }
+    if (!WARM && lane == 0) {
+        rec_cnt[2 + wid] = min(nrec, slice_cap);
+        if (nrec) atomicAdd(rec_cnt, nrec);                   // total (statistics)
+        if (nrec > slice_cap) atomicMax(rec_cnt + 1, 1u);     // overflow: the caller falls back to the fp32 sweep
+    }
+}
+
+// ONE grid-stride prologue: both bf16 packs, the gold similarities (the exact k-ordered chain), the max row norms of both
+// tables, zeroing of ranks / counters
+__global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__restrict__ e1, int64_t n1, int ld1,
+                                                                 const float *__restrict__ e2, int64_t n2, int ld2, int dim,
+                                                                 int64_t gold_off, uint4 *__restrict__ p1, int64_t n1_pad,
+                                                                 uint4 *__restrict__ p2, int64_t n2_pad, int kp,
+                                                                 float *__restrict__ gold, unsigned *__restrict__ nmax,
+                                                                 int32_t *__restrict__ rank) {
+    const int cpr = kp / 4;
+    const int64_t a_end = n1_pad * cpr, b_end = a_end + n2_pad * cpr;
+    // then: the gold chains (one thread per query row), then the row norms (16 lanes per row, table 2 on a wave boundary)
+    const int64_t g_end = b_end + (n1 + 63) / 64 * 64;
+    const int64_t m1_end = g_end + (16 * n1 + 63) / 64 * 64, m2_end = m1_end + (16 * n2 + 63) / 64 * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m2_end; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < b_end) {
+            const bool second = i >= a_end;
+            const int64_t li = second ? i - a_end : i;
+            const float *src = second ? e2 : e1;
+            const int64_t n = second ? n2 : n1;
+            const int ld = second ? ld2 : ld1;
+            const int64_t row = li / cpr;
+            const int c = (int)(li - row * cpr);
+            const int g = c & 7, k0 = 32 * (c >> 3) + 16 * (g >> 2) + 8 * ((g >> 1) & 1), lo = g & 1;
+            uint32_t h[8];
+            float x[8];
+            if (row < n && k0 + 8 <= dim) {
+                const float4 u = oea::ld4(src + row * ld + k0), w = oea::ld4(src + row * ld + k0 + 4);
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) x[t] = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t hi = bf16_rne(x[t]);
+                h[t] = lo ? bf16_rne(x[t] - __uint_as_float(hi << 16)) : hi;
+            }
+            (second ? p2 : p1)[li] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+            continue;
+        }
+        if (i < g_end) {
+            const int64_t row = i - b_end;
+            if (row < n1) {
+                const float *a = e1 + row * ld1, *b = e2 + (row + gold_off) * ld2;
+                float acc = 0.f;
+                int k = 0;
+                for (; k + 4 <= dim; k += 4) {
+                    const float4 x = oea::ld4(a + k), y = oea::ld4(b + k);
+                    acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+                }
+                for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+                gold[row] = acc;
+                rank[row] = 0;
+            }
+            continue;
+        }
+        const bool second = i >= m1_end;
+        const int64_t li = second ? i - m1_end : i - g_end;
+        const int64_t row = li >> 4, n = second ? n2 : n1;
+        const int l16 = (int)(li & 15);
+        float ss = 0.f;
+        if (row < n) {
+            const float *a = second ? e2 + row * ld2 : e1 + row * ld1;
+            for (int k = l16; k < dim; k += 16) ss = fmaf(a[k], a[k], ss);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        float nr = sqrtf(ss) * 1.000001f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nr = fmaxf(nr, __shfl_xor(nr, off, 64));
+        // one atomic per wave, and only when it would raise the maximum (35,000 waves on two addresses took 0.3 ms)
+        unsigned *dst = nmax + (second ? 1 : 0);
+        if ((threadIdx.x & 63) == 0 && nr > __uint_as_float(__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(dst, __float_as_uint(nr));
+    }
+}
+
+// argmax from the keys + Hits@k / sum(rank + 1) / sum 1 / (rank + 1) in a fixed order + the sweep's status, ONE block
+__global__ __launch_bounds__(1024) void rank_bf16_finish_kernel(const int32_t *__restrict__ rank, const unsigned long long *__restrict__ best_key,
+                                                                int64_t n, int4 tk0, int4 tk1, int nk, int32_t *__restrict__ argmax,
+                                                                long long *__restrict__ out, const unsigned *__restrict__ rec_cnt) {
+    __shared__ long long s_i[1024];
+    __shared__ double s_d[1024];
+    const int tks[8] = {tk0.x, tk0.y, tk0.z, tk0.w, tk1.x, tk1.y, tk1.z, tk1.w};
+    long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs = 0;
+    double rr = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = rank[i];
+        argmax[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(best_key[i] & 0xFFFFFFFFull));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] += (k < nk && r < tks[k]);
+        rs += r + 1;
+        rr += 1.0 / (double)(r + 1);
+    }
+    // the reduction order of rank_metrics_kernel (wave butterflies, then the wave results in wave order): the same bits
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long v[9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = h[k];
+    v[8] = rs;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_i[wave * 9 + k] = v[k];
+        s_d[wave] = rr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int k = 0; k < 9; ++k) {
+            long long t = 0;
+            for (int w = 0; w < nw; ++w) t += s_i[w * 9 + k];
+            if (k < nk) out[k] = t;
+            else if (k == 8) out[nk] = t;
+        }
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += s_d[w];
+        out[nk + 1] = __double_as_longlong(t);
+        out[nk + 2] = rec_cnt[1];            // != 0: the record buffer overflowed, nothing above is valid
+        out[nk + 3] = rec_cnt[0];
+    }
+}
+
+// the records by the exact k-ordered fmaf chain (gold_inner_kernel's arithmetic): one thread per record, workgroups
+// stride over the waves' slices
+__global__ __launch_bounds__(256) void rank_bf16_fixup_kernel(const float *__restrict__ e1, int ld1, const float *__restrict__ e2, int ld2,
+                                                              int dim, const float *__restrict__ gold, int64_t gold_off,
+                                                              const uint2 *__restrict__ rec, const unsigned *__restrict__ rec_cnt,
+                                                              unsigned n_slices, unsigned slice_cap, int32_t *__restrict__ rank,
+                                                              unsigned long long *__restrict__ best_key) {
+    if (rec_cnt[0] == 0u) return;
+    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;          // one wave per slice at a time
+    for (unsigned sl = blockIdx.x * 4u + sub; sl < n_slices; sl += gridDim.x * 4u) {
+        const unsigned n = rec_cnt[2 + sl];
+        for (unsigned p = lane; p < n; p += 64) {
+            const uint2 rc = rec[(size_t)sl * slice_cap + p];
+            const int64_t i = rc.x, j = rc.y & 0x7FFFFFFFu;
+            const float *a = e1 + i * ld1, *b = e2 + j * ld2;
+            float acc = 0.f;
+            int k = 0;
+            for (; k + 4 <= dim; k += 4) {
+                const float4 x = oea::ld4(a + k), y = oea::ld4(b + k);
+                acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+            }
+            for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+            if (rc.y & kRecTop) {
+                atomicMax(best_key + i, ((unsigned long long)f2ord(acc) << 32) | (0xFFFFFFFFu - (uint32_t)j));
+            } else {
+                const float gi = gold[i];
+                if (acc > gi || (acc == gi && j < i + gold_off)) atomicAdd(rank + i, 1);
+            }
+        }
+    }
+}
+
+// the approximate similarities themselves (tests: the error bound; timing of the bare sweep)
+__global__ __launch_bounds__(256, 2) void sim_bf16_store_kernel(const float *__restrict__ e1p, int64_t n1, int kp,
+                                                               const float *__restrict__ e2p, int64_t n2, int dim,
+                                                               float *__restrict__ out, int64_t ld_out) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
+    tile_pipeline_bf16(
+        e1p, kp, e2p, dim, c0, 1, [=](int64_t) { return m0; }, As, Bs,
+        [&](int64_t, f32x16 (&acc)[2][2]) {
+            float *tile = out + m0 * ld_out + c0;
+            const int rows_left = (int)(n1 - m0 < TILE ? n1 - m0 : TILE), cols_left = (int)(n2 - c0 < TILE ? n2 - c0 : TILE);
+            const int col = wn * 64 + (lane & 31), rbase = wm * 64 + 4 * (lane >> 5);
+            const bool ok0 = col < cols_left, ok1 = col + 32 < cols_left;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + tm * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < rows_left) {
+                        float *p = tile + (row * (int)ld_out + col);
+                        if (ok0) p[0] = acc[tm][0][r];
+                        if (ok1) p[32] = acc[tm][1][r];
+                    }
+                    asm volatile("" ::: "memory");
+                }
+        });
+}
+
 // workspace layout of oea_csls_means
 struct CslsPlan {
     bool ok = false;
@@ -2076,6 +2516,139 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
         return OEA_EINVAL;
     }
     rank_finalize_kernel<<<gb, 256, 0, st>>>(keys, n1, argmax);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+// ---- inner-product evaluation through the certified bf16 prefilter (see rank_bf16_kernel) --------------------------------------
+// record slots: the band around the gold value grows with the tolerance, i.e. with dim (measured on rows whose gold has a
+// random rank: 30 records per row at dim 100, 114 at dim 300)
+static unsigned bf16_rec_cap(int64_t n1, int dim) { return (unsigned)std::min<int64_t>((96 + (int64_t)dim) * n1 + (1 << 20), (int64_t)1 << 30); }
+// an upper bound of the sweep's wave count: pick_chunks gives at most target / q_tiles + 1 chunks per query tile
+static int64_t bf16_max_waves(int64_t n1) { return 4 * (oea::ceil_div(n1, TILE) + 16384); }
+
+size_t oea_rank_eval_bf16_workspace_bytes(int64_t n1, int32_t dim) {
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    return a256(8 * (size_t)n1) + 2 * a256(4 * (size_t)n1) + 256 + a256(4 * (size_t)(2 + bf16_max_waves(n1))) + 8 * (size_t)bf16_rec_cap(n1, dim);
+}
+
+static float bf16_eps_rel(int dim) {
+    const int kp16 = (dim + 15) / 16 * 16;
+    // split residue (3.02 * 2^-18 of |a||b|) + fp32 accumulation of 3 * Kp products, bounded term by term with a chopping unit
+    // roundoff 2^-23 (the MFMA's internal order and rounding are not documented) + the exact chain's own dim roundings
+    return 1.02f * (3.02f * 3.814697265625e-06f + (float)(3 * kp16 + dim + 8) * 1.1920928955078125e-07f);
+}
+
+static int pack_operand_bf16(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
+    int64_t n_pad = 0;
+    const int rc = reserve_operand(slot, n, dim, st, out, &n_pad);
+    if (rc != OEA_OK) return rc;
+    const int64_t total = n_pad * (out->kp / 4);
+    pack_rows_bf16_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(total, 256), 16384), 256, 0, st>>>(
+        src, n, ld, dim, reinterpret_cast<uint4 *>(out->p), n_pad, out->kp);
+    return OEA_OK;
+}
+
+constexpr int kBf16WarmTiles = 16;          // the warm-up pass sees 2,048 candidates
+
+// prologue | init | warm-up | sweep | fix-up | finish: six launches; metrics_out (may be NULL) = int64 [nk + 4] on the device
+static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
+                               long long *metrics_out, int32_t *status, void *workspace, hipStream_t st) {
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    char *w = static_cast<char *>(workspace);
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(w);
+    float *gold = reinterpret_cast<float *>(w + a256(8 * (size_t)n1));
+    unsigned *lbrow = reinterpret_cast<unsigned *>(w + a256(8 * (size_t)n1) + a256(4 * (size_t)n1));
+    char *sc = w + a256(8 * (size_t)n1) + 2 * a256(4 * (size_t)n1);
+    unsigned *nmax = reinterpret_cast<unsigned *>(sc);              // [2]: max row norms of e1 / e2 (float bits)
+    float *tol = reinterpret_cast<float *>(sc + 16);
+    long long *fin = reinterpret_cast<long long *>(sc + 64);        // [nk + 4] when the caller wants no metrics
+    unsigned *rec_cnt = reinterpret_cast<unsigned *>(sc + 256);     // [0] records, [1] overflow flag, [2 + w] length of wave w's slice
+    uint2 *rec = reinterpret_cast<uint2 *>(sc + 256 + a256(4 * (size_t)(2 + bf16_max_waves(n1))));
+    const unsigned cap = bf16_rec_cap(n1, dim);
+    OEA_CHECK_HIP(hipMemsetAsync(sc, 0, 64, st));                   // norms, tolerance
+    PackedOp p1, p2;
+    int64_t n1_pad = 0, n2_pad = 0;
+    int rc = reserve_operand(0, n1, dim, st, &p1, &n1_pad);
+    if (rc == OEA_OK) rc = reserve_operand(1, n2, dim, st, &p2, &n2_pad);
+    if (rc != OEA_OK) return rc;
+    const int64_t items = (n1_pad + n2_pad) * (p1.kp / 4) + 17 * (n1 + n2) + 256;
+    rank_bf16_prologue_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(items, 256), 16384), 256, 0, st>>>(
+        e1, n1, ld1, e2, n2, ld2, dim, gold_offset, reinterpret_cast<uint4 *>(p1.p), n1_pad, reinterpret_cast<uint4 *>(p2.p), n2_pad,
+        p1.kp, gold, nmax, rank);
+    const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
+    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, bf16_eps_rel(dim), tol, rank, keys, lbrow, rec_cnt);
+    int tpc = 1;
+    const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
+    const int chunks = pick_chunks(qt, ctiles, &tpc);
+    const int64_t n_waves = 4 * qt * chunks;
+    OEA_REQUIRE(n_waves <= bf16_max_waves(n1), "more workgroups than the workspace was sized for (OEA_RANK_WGS)");
+    const unsigned slice_cap = (unsigned)(cap / n_waves);
+    OEA_REQUIRE(slice_cap >= 32, "record slices too small");
+    // warm-up over 1/16 of the candidate tiles (at most 16 = 2,048 candidates, 3 % of a 70,000-row sweep); a small candidate
+    // set needs none: every workgroup sees most of it anyway
+    const int warm = (int)std::min<int64_t>(kBf16WarmTiles, ctiles / 16);
+    if (warm >= 2)
+        rank_bf16_kernel<true><<<dim3((unsigned)qt, 1), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, warm, gold_offset,
+                                                                        rank, lbrow, rec, rec_cnt, slice_cap);
+    rank_bf16_kernel<false><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, tpc, gold_offset,
+                                                                                 rank, lbrow, rec, rec_cnt, slice_cap);
+    rc = release_packed(st);
+    if (rc != OEA_OK) return rc;
+    rank_bf16_fixup_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_waves, 4), 2048), 256, 0, st>>>(
+        e1, ld1, e2, ld2, dim, gold, gold_offset, rec, rec_cnt, (unsigned)n_waves, slice_cap, rank, keys);
+    int t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nk; ++i) t[i] = top_k_host[i];
+    long long *out = metrics_out ? metrics_out : fin;
+    rank_bf16_finish_kernel<<<1, 1024, 0, st>>>(rank, keys, n1, make_int4(t[0], t[1], t[2], t[3]), make_int4(t[4], t[5], t[6], t[7]), nk,
+                                                argmax, out, rec_cnt);
+    if (status) {
+        OEA_CHECK_HIP(hipMemcpyAsync(status, rec_cnt + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        OEA_CHECK_HIP(hipMemcpyAsync(status + 1, rec_cnt, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
+int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                       int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status, void *workspace, void *stream) {
+    OEA_REQUIRE(e1 && e2 && rank && argmax && status && workspace, "null pointer");
+    OEA_REQUIRE(n1 >= 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
+    OEA_REQUIRE(n2 < 0x7fffffff && n1 < 0x7fffffff, "n < 2^31");
+    OEA_REQUIRE(use_glds(), "the bf16 prefilter runs on the packed (LDS-DMA) tile path");
+    hipStream_t st = oea::as_stream(stream);
+    if (n1 == 0) { OEA_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st)); return OEA_OK; }
+    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, gold_offset, nullptr, 0, rank, argmax, nullptr, status, workspace, st);
+}
+
+int oea_rank_eval_metrics_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
+                               int64_t *out_dev, void *workspace, void *stream) {
+    OEA_REQUIRE(e1 && e2 && rank && argmax && workspace && top_k_host && out_dev, "null pointer");
+    OEA_REQUIRE(n1 > 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
+    OEA_REQUIRE(n2 < 0x7fffffff && n1 < 0x7fffffff && nk >= 1 && nk <= 8, "n < 2^31, 1 <= len(top_k) <= 8");
+    OEA_REQUIRE(use_glds(), "the bf16 prefilter runs on the packed (LDS-DMA) tile path");
+    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, gold_offset, top_k_host, nk, rank, argmax,
+                               reinterpret_cast<long long *>(out_dev), nullptr, workspace, oea::as_stream(stream));
+}
+
+int oea_sim_bf16_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, float *out,
+                        int64_t ld_out, void *stream) {
+    OEA_REQUIRE(e1 && e2 && out && ld_out >= n2 && dim > 0 && dim <= ld1 && dim <= ld2 && ld1 % 4 == 0 && ld2 % 4 == 0, "arguments");
+    OEA_REQUIRE(use_glds(), "packed tile path only");
+    if (n1 == 0 || n2 == 0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    PackedOp p1, p2;
+    int rc = pack_operand_bf16(0, e1, n1, ld1, dim, st, &p1);
+    if (rc == OEA_OK) rc = pack_operand_bf16(1, e2, n2, ld2, dim, st, &p2);
+    if (rc != OEA_OK) return rc;
+    sim_bf16_store_kernel<<<dim3((unsigned)oea::ceil_div(n2, TILE), (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p,
+                                                                                                                     n2, dim, out, ld_out);
+    rc = release_packed(st);
+    if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

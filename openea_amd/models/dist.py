@@ -120,30 +120,54 @@ class CAbiComm:
       stages the device buffer through the host (oea_copy_to_host / _from_host, ordered on the call's stream) and runs the
       torch.distributed collective on the host copy.  Same call path, same protocol, slower wire."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device_buffers=()):
+        """device_buffers: the tensors the C call will hand to the collectives (the partition's send / own / rel_x / upd /
+        all buffers, the TransH normal views): with a device-capable backend the callback back end runs the group's
+        collective directly on them (no staging) -- the fallback when the library's own RCCL communicator cannot be made."""
         import ctypes as C
         import os
+        import sys
         from .. import _lib, ops
         from .._lib import check
         self.group = group
         self.rank, self.world = world(group)
         self.lib = lib = ops.lib()
         self.handle = C.c_void_p()
+        self._bufs = {int(t.data_ptr()): t for t in device_buffers if t is not None}
         backend = dist.get_backend(group) if self.world > 1 else "nccl"
+        self.device_collectives = self.world > 1 and backend == "nccl"
         self.callbacks = (self.world > 1 and backend != "nccl") or os.environ.get("OEA_COMM_CALLBACKS") == "1"
-        if self.callbacks:
-            self._fn = _lib.COMM_CALLBACK(self._collective)            # kept alive with the object
-            check(lib.oea_comm_init_callbacks(self.rank, self.world, C.cast(self._fn, C.c_void_p), None, C.byref(self.handle)))
-            return
-        uid = (C.c_char * 128)()
-        if self.rank == 0:
-            check(lib.oea_comm_unique_id(uid))
-        box = [bytes(uid.raw) if self.rank == 0 else None]
-        if self.world > 1:
-            src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
-            dist.broadcast_object_list(box, src=src, group=group)
-        buf = (C.c_char * 128).from_buffer_copy(box[0])
-        check(lib.oea_comm_init(buf, self.rank, self.world, C.byref(self.handle)))
+        if not self.callbacks:
+            # every rank must take the same branch: the outcome of the RCCL set-up is agreed on through the group
+            ok = 1
+            try:
+                uid = (C.c_char * 128)()
+                if self.rank == 0:
+                    check(lib.oea_comm_unique_id(uid))
+                box = [bytes(uid.raw) if self.rank == 0 else None]
+                if self.world > 1:
+                    src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+                    dist.broadcast_object_list(box, src=src, group=group)
+                buf = (C.c_char * 128).from_buffer_copy(box[0])
+                check(lib.oea_comm_init(buf, self.rank, self.world, C.byref(self.handle)))
+            except Exception as e:            # noqa: BLE001 -- e.g. librccl not loadable, ranks sharing a device
+                ok = 0
+                print("[openea_amd] the C ABI's RCCL communicator could not be made (%s): collectives of the one-call epoch go "
+                      "through torch.distributed callbacks" % str(e)[:200], file=sys.stderr)
+            if self.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok_all = int(flag.item())
+            else:
+                ok_all = ok
+            if ok_all:
+                return
+            if ok:                            # made here but not everywhere: drop it
+                lib.oea_comm_destroy(self.handle)
+                self.handle = C.c_void_p()
+            self.callbacks = True
+        self._fn = _lib.COMM_CALLBACK(self._collective)            # kept alive with the object
+        check(lib.oea_comm_init_callbacks(self.rank, self.world, C.cast(self._fn, C.c_void_p), None, C.byref(self.handle)))
 
     _NP = {0: np.float32, 1: np.float64, 2: np.int64}
 
@@ -151,6 +175,18 @@ class CAbiComm:
         """oea_comm_callback: returns 0 on success (an exception cannot cross the C frame: it is printed and reported as 1)"""
         try:
             from .._lib import COMM_ALLGATHER, COMM_ALLREDUCE, check
+            if self.device_collectives and int(send) in self._bufs and int(recv) in self._bufs:
+                # a device-capable group (nccl): the collective on the registered device tensors, ordered on torch's current
+                # stream (the stream the C call enqueues on)
+                n = int(count)
+                src, dst = self._bufs[int(send)].view(-1), self._bufs[int(recv)].view(-1)
+                if op == COMM_ALLREDUCE:
+                    dist.all_reduce(dst[:n], op=dist.ReduceOp.SUM, group=self.group)
+                elif op == COMM_ALLGATHER:
+                    dist.all_gather_into_tensor(dst[: n * self.world], src[:n], group=self.group)
+                else:
+                    dist.reduce_scatter_tensor(dst[:n], src[: n * self.world], op=dist.ReduceOp.SUM, group=self.group)
+                return 0
             npdt = self._NP[int(dtype)]
             n_in = int(count) * (self.world if op != COMM_ALLGATHER and op != COMM_ALLREDUCE else 1)
             host = np.empty(n_in, npdt)
@@ -193,8 +229,8 @@ class CAbiComm:
                 if self.callbacks else "RCCL (the C ABI's own communicator, librccl through dlopen)")
 
 
-def c_abi_comm(group=None):
-    return CAbiComm(group)
+def c_abi_comm(group=None, device_buffers=()):
+    return CAbiComm(group, device_buffers)
 
 
 def allreduce_sum_(t, group=None):

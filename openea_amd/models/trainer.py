@@ -184,7 +184,17 @@ class TripleTrainer:
         import os as _os
         if _os.environ.get("OEA_DP_C_EPOCH", "1") != "0" and cfg_allows_c_epoch(self.cfg):
             from . import dist as mdist
-            self.comm = mdist.c_abi_comm(self.dist)
+            bufs = [p[k] for k in ('send', 'own', 'rel_x', 'upd', 'all')]
+            if self.cfg.score_kind == ops.SCORE_TRANSH:
+                p['nrm'] = ops.step_normal_views(self.ws, ent.rows, rel.rows, ent.ld)
+                bufs += list(p['nrm'])
+            try:
+                self.comm = mdist.c_abi_comm(self.dist, bufs)
+            except Exception as e:            # noqa: BLE001 -- no communicator: the per-step Python loop runs the same protocol
+                import sys
+                print("[openea_amd] one-call partitioned epoch unavailable (%s): per-step exchange from Python" % str(e)[:200],
+                      file=sys.stderr)
+                self.comm = None
 
     def _step_partitioned(self, pos, neg):
         """GRAD | pack | reduce-scatter + relation all-reduce | apply owned rows | all-gather | unpack"""

@@ -579,6 +579,53 @@ def csls_means_l1_grid(e1, e2, dim, k, cols=True):
     return r, c, grid
 
 
+def sim_bf16_matrix(e1, e2, dim):
+    """the bf16 prefilter's approximate inner products (tests / timing) -> fp32 [n1, n2]"""
+    n1, n2 = e1.shape[0], e2.shape[0]
+    out = torch.empty((n1, n2), dtype=torch.float32, device=e1.device)
+    check(lib().oea_sim_bf16_matrix(_p(e1), n1, e1.shape[1], _p(e2), n2, e2.shape[1], dim, _p(out), n2, _stream()))
+    return out
+
+
+def rank_eval_bf16(e1, e2, dim, gold_offset=0, stats=None):
+    """rank_eval(metric='inner') through the certified bf16 prefilter (oea_rank_eval_bf16): the same rank / argmax, the matrix
+    work at 3/16 of the fp32 matrix time.  Falls back to the fp32 sweep when the record buffer overflows (one host read of the
+    status word).  stats: optional dict, receives 'records' and 'fallback'."""
+    n1 = e1.shape[0]
+    ws = torch.empty(lib().oea_rank_eval_bf16_workspace_bytes(n1, dim), dtype=torch.uint8, device=e1.device)
+    rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    status = torch.zeros(2, dtype=torch.int32, device=e1.device)
+    check(lib().oea_rank_eval_bf16(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, int(gold_offset), _p(rank), _p(argmax),
+                                   _p(status), _p(ws), _stream()))
+    st = status.cpu().numpy()
+    if stats is not None:
+        stats['records'], stats['fallback'] = int(st[1]), bool(st[0])
+    if st[0]:
+        return rank_eval(e1, e2, dim, 'inner', gold_offset=gold_offset)
+    return rank, argmax
+
+
+def rank_eval_metrics_bf16(e1, e2, dim, top_k, gold_offset=0, stats=None):
+    """rank_eval_metrics through the certified bf16 prefilter: six launches + ONE device->host copy that carries the metrics and
+    the sweep's status -> (rank, argmax, hits, rank_sum, rr_sum), or None when the record buffer overflowed (the caller takes
+    the fp32 sweep)."""
+    n1, nk = e1.shape[0], len(top_k)
+    ws = torch.empty(lib().oea_rank_eval_bf16_workspace_bytes(n1, dim), dtype=torch.uint8, device=e1.device)
+    rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
+    buf = torch.empty(nk + 4, dtype=torch.int64, device=e1.device)
+    tk = (C.c_int32 * nk)(*[int(k) for k in top_k])
+    check(lib().oea_rank_eval_metrics_bf16(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, int(gold_offset), tk, nk,
+                                           _p(rank), _p(argmax), C.c_void_p(buf.data_ptr()), _p(ws), _stream()))
+    host = buf.cpu().numpy()
+    if stats is not None:
+        stats['records'], stats['fallback'] = int(host[nk + 3]), bool(host[nk + 2])
+    if host[nk + 2]:
+        return None
+    return rank, argmax, [int(x) for x in host[:nk]], int(host[nk]), float(host[nk + 1:nk + 2].view(np.float64)[0])
+
+
 def rank_eval_l1_grid(e1, e2, dim, gold_offset=0, block_bytes=2 << 30, csls_r=None, csls_c=None, grid=None):
     """rank_eval(metric='manhattan') without the fp64 distance of every pair: 16-bit grid distances of all pairs
     (oea_l1_u16_strip, blocks of query rows), then oea_rank_l1_grid_rows[_csls] -- exact similarities only where the grid
