@@ -458,10 +458,11 @@ int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2
                        int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status, void *workspace, void *stream);
 /* the same + argmax + the metrics of oea_rank_metrics in one go: out int64 [nk + 4] (device) = hits[nk], sum(rank + 1), the bits of
  * the double sum 1 / (rank + 1) (the reduction order of oea_rank_metrics), overflow flag (!= 0: INVALID, take
- * oea_rank_eval_metrics), records written -- one device-to-host copy brings results and status back. */
+ * oea_rank_eval_metrics), records written -- one device-to-host copy brings results and status back.  csls_r / csls_c (both or
+ * neither): the CSLS means; the values ranked are then (2 s - csls_r[i]) - csls_c[j] as in oea_rank_eval. */
 int oea_rank_eval_metrics_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
-                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
-                               int64_t *out_dev, void *workspace, void *stream);
+                               const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
+                               int32_t *rank, int32_t *argmax, int64_t *out_dev, void *workspace, void *stream);
 /* the prefilter's approximate similarities out[i, j] ~ <e1[i], e2[j]> (tests of the error bound, timing) */
 int oea_sim_bf16_matrix(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, float *out,
                         int64_t ld_out, void *stream);

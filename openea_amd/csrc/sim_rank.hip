@@ -2044,14 +2044,19 @@ __device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o &
 constexpr uint32_t kRecTop = 0x80000000u;        // record kinds: bit 31 of the candidate word
 
 // gold, tolerance, per-row state of the bf16 sweep
+// nmax: float bits of max |e1 row|, max |e2 row|, max |csls_c|
 __global__ void rank_bf16_init_kernel(const float *__restrict__ gold, int64_t n1, int64_t gold_off, const unsigned *__restrict__ nmax,
-                                      float eps_rel, float *__restrict__ tol_out, int32_t *__restrict__ rank,
-                                      unsigned long long *__restrict__ best_key, unsigned *__restrict__ lbrow,
-                                      unsigned *__restrict__ rec_cnt) {
+                                      float eps_rel, const float *__restrict__ csls_r, float *__restrict__ tol_out,
+                                      int32_t *__restrict__ rank, unsigned long long *__restrict__ best_key,
+                                      unsigned *__restrict__ lbrow, unsigned *__restrict__ rec_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const float tol = eps_rel * __uint_as_float(nmax[0]) * __uint_as_float(nmax[1]) + 1e-30f;
-    if (i == 0) { *tol_out = tol; rec_cnt[0] = 0u; rec_cnt[1] = 0u; }
+    const float smax = __uint_as_float(nmax[0]) * __uint_as_float(nmax[1]);
+    // + an absolute slack for the ulp-level roundings of g +- tol, v~ - tol and of the comparisons themselves (values <= smax)
+    const float tol0 = 1.05f * eps_rel * smax + 1.0e-6f * smax + 1e-30f;
+    const float scale = 2.0f * smax + __uint_as_float(nmax[2]) + 2.0f * tol0;
+    if (i == 0) { tol_out[0] = tol0; tol_out[1] = scale; rec_cnt[0] = 0u; rec_cnt[1] = 0u; }
     if (i >= n1) return;
+    const float tol = csls_r ? 2.0f * tol0 + 3.0e-7f * (scale + fabsf(csls_r[i])) : tol0;      // == the sweep's per-lane tolerance
     rank[i] = 0;
     best_key[i] = ((unsigned long long)f2ord(gold[i]) << 32) | (0xFFFFFFFFu - (uint32_t)(i + gold_off));     // the gold is a candidate
     lbrow[i] = f2ord(gold[i] - tol);
@@ -2064,40 +2069,50 @@ __global__ void rank_bf16_init_kernel(const float *__restrict__ gold, int64_t n1
 // Records go to a slice of the record buffer PRIVATE to the wave (slot = count + prefix of a ballot; no returning atomic:
 // the first version took one global round trip per recording wave instruction and ran 4x slower on rows whose gold is far
 // from the top).  rec_cnt[2 + wave id] = the slice's length; a full slice raises the overflow flag.
-template <bool WARM, bool INTERIOR, class Acc, class Rec>
-__device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const float (&g)[2], const float (&ghi)[2], float (&lb)[2],
+// CSLS: the values compared are (2 s - r_i) - c_j (rank_inner_kernel's expression on the approximate s); tol[tn] then holds
+// 2 tol + the rounding slack of the two extra operations for this lane's query.
+// The three classes are COMPLEMENTARY comparisons against ghi = g + tol and glo = g - tol (counted: v > ghi; band: glo <= v <=
+// ghi; ignored: v < glo) -- a first version tested the band as |v - g| <= tol, whose rounding left a gap of an ulp below ghi
+// through which one candidate in ~10^7 fell.  The ulp-level roundings of g +- tol themselves sit inside the absolute slack
+// of the tolerance (rank_bf16_init_kernel).
+template <bool WARM, bool INTERIOR, bool CSLS, class Acc, class Rec>
+__device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const float (&glo)[2], const float (&ghi)[2], float (&lb)[2],
                                                float (&lbm)[2], int (&cnt)[2], bool (&dirty)[2], const int64_t (&qi)[2], int64_t gold_off,
-                                               float tol, Rec &&record) {
+                                               const float (&tol)[2], const float (&rq)[2], const float *__restrict__ csls_c, Rec &&record) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
             const bool jin = INTERIOR || j < n2;
+            const float cj = (CSLS && jin) ? csls_c[j] : 0.f;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                const float v = acc[tm][tn][r];
+                float v = acc[tm][tn][r];
+                if (CSLS) v = fmaf(2.0f, v, -rq[tn]) - cj;
                 if (WARM) {
-                    if (jin) lb[tn] = fmaxf(lb[tn], v - tol);
+                    if (jin) lb[tn] = fmaxf(lb[tn], v - tol[tn]);
                     continue;
                 }
                 cnt[tn] += (v > ghi[tn]) & jin;
-                const bool hit = ((v >= lbm[tn]) | (fabsf(v - g[tn]) <= tol)) & jin;
+                const bool band = (v <= ghi[tn]) & (v >= glo[tn]);
+                const bool hit = ((v >= lbm[tn]) | band) & jin;
                 if (__ballot(hit)) {                                  // wave-uniform branch: rare
                     const bool other = hit && (int64_t)j != qi[tn] + gold_off;
-                    record(other && v + tol >= lb[tn], tn, j, kRecTop);
-                    record(other && fabsf(v - g[tn]) <= tol, tn, j, 0u);
-                    if (hit && v - tol > lb[tn]) { lb[tn] = v - tol; lbm[tn] = lb[tn] - tol; dirty[tn] = true; }
+                    record(other && v >= lbm[tn], tn, j, kRecTop);
+                    record(other && band, tn, j, 0u);
+                    if (hit && v - tol[tn] > lb[tn]) { lb[tn] = v - tol[tn]; lbm[tn] = lb[tn] - tol[tn]; dirty[tn] = true; }
                 }
             }
         }
     }
 }
 
-template <bool WARM>
+template <bool WARM, bool CSLS>
 __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
-    const float *__restrict__ gold, const float *__restrict__ tol_ptr, int tiles_per_chunk, int64_t gold_off,
+    const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,
+    const float *__restrict__ csls_c, int tiles_per_chunk, int64_t gold_off,
     int32_t *__restrict__ rank, unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
@@ -2107,22 +2122,27 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
     const int64_t nct = (n2 + TILE - 1) / TILE;
     const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
-    const float tol = *tol_ptr;
+    const float tol0 = tol_ptr[0];                         // bound on |s~ - s|; tol_ptr[1] = slack scale of the CSLS expression
     const unsigned wid = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
     uint2 *__restrict__ my_rec = rec + (size_t)wid * slice_cap;
     unsigned nrec = 0;                                     // wave-uniform
     int64_t qi[2];
-    float g[2], ghi[2], lb[2], lbm[2];
+    float glo[2], ghi[2], lb[2], lbm[2], tol[2], rq[2];
     int cnt[2] = {0, 0};
     bool dirty[2] = {false, false};
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         qi[tn] = q0 + wn * 64 + tn * 32 + (lane & 31);
         const bool ok = qi[tn] < n1;
-        g[tn] = ok ? gold[qi[tn]] : INFINITY;             // padding rows: nothing counts, nothing is recorded
-        ghi[tn] = g[tn] + tol;
-        lb[tn] = ok ? g[tn] - tol : INFINITY;
-        lbm[tn] = lb[tn] - tol;
+        const float g = ok ? gold[qi[tn]] : INFINITY;      // padding rows: nothing counts, nothing is recorded
+        rq[tn] = (CSLS && ok) ? csls_r[qi[tn]] : 0.f;
+        // (2 s~ - r) - c against (2 s - r) - c: twice the bound on s, plus the roundings of the fma and of the subtraction on
+        // either side (each <= 2^-24 of a value <= 2 |s|max + |r| + |c|max = tol_ptr[1] + |r|)
+        tol[tn] = CSLS ? 2.0f * tol0 + 3.0e-7f * (tol_ptr[1] + fabsf(rq[tn])) : tol0;
+        ghi[tn] = g + tol[tn];
+        glo[tn] = ok ? g - tol[tn] : INFINITY;
+        lb[tn] = glo[tn];
+        lbm[tn] = lb[tn] - tol[tn];
     }
     auto record = [&](bool pred, int tn, int j, uint32_t kind) {
         const unsigned long long m = __ballot(pred);
@@ -2141,10 +2161,10 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
             for (int tn = 0; tn < 2; ++tn)                 // the other lanes / workgroups of the row may have raised the bound
                 if (qi[tn] < n1) {
                     const float o = ord2f(__hip_atomic_load(lbrow + qi[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (o > lb[tn]) { lb[tn] = o; lbm[tn] = o - tol; }
+                    if (o > lb[tn]) { lb[tn] = o; lbm[tn] = o - tol[tn]; }
                 }
-            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true>(acc, jb, (int)n2, g, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, record);
-            else rank_bf16_tile<WARM, false>(acc, jb, (int)n2, g, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, record);
+            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, csls_c, record);
+            else rank_bf16_tile<WARM, false, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, csls_c, record);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
                 if (dirty[tn]) { atomicMax(lbrow + qi[tn], f2ord(lb[tn])); dirty[tn] = false; }
@@ -2173,7 +2193,8 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
                                                                  int64_t gold_off, uint4 *__restrict__ p1, int64_t n1_pad,
                                                                  uint4 *__restrict__ p2, int64_t n2_pad, int kp,
                                                                  float *__restrict__ gold, unsigned *__restrict__ nmax,
-                                                                 int32_t *__restrict__ rank) {
+                                                                 int32_t *__restrict__ rank, const float *__restrict__ csls_r,
+                                                                 const float *__restrict__ csls_c) {
     const int cpr = kp / 4;
     const int64_t a_end = n1_pad * cpr, b_end = a_end + n2_pad * cpr;
     // then: the gold chains (one thread per query row), then the row norms (16 lanes per row, table 2 on a wave boundary)
@@ -2217,6 +2238,7 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
                     acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
                 }
                 for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+                if (csls_r) acc = (2.0f * acc - csls_r[row]) - csls_c[row + gold_off];       // gold_inner_kernel's expression
                 gold[row] = acc;
                 rank[row] = 0;
             }
@@ -2234,8 +2256,14 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
         float nr = sqrtf(ss) * 1.000001f;
+        float cm = (second && csls_c && row < n && l16 == 0) ? fabsf(csls_c[row]) : 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nr = fmaxf(nr, __shfl_xor(nr, off, 64));
+        for (int off = 32; off > 0; off >>= 1) {
+            nr = fmaxf(nr, __shfl_xor(nr, off, 64));
+            cm = fmaxf(cm, __shfl_xor(cm, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0 && cm > __uint_as_float(__hip_atomic_load(nmax + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(nmax + 2, __float_as_uint(cm));
         // one atomic per wave, and only when it would raise the maximum (35,000 waves on two addresses took 0.3 ms)
         unsigned *dst = nmax + (second ? 1 : 0);
         if ((threadIdx.x & 63) == 0 && nr > __uint_as_float(__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -2298,6 +2326,7 @@ __global__ __launch_bounds__(1024) void rank_bf16_finish_kernel(const int32_t *_
 // stride over the waves' slices
 __global__ __launch_bounds__(256) void rank_bf16_fixup_kernel(const float *__restrict__ e1, int ld1, const float *__restrict__ e2, int ld2,
                                                               int dim, const float *__restrict__ gold, int64_t gold_off,
+                                                              const float *__restrict__ csls_r, const float *__restrict__ csls_c,
                                                               const uint2 *__restrict__ rec, const unsigned *__restrict__ rec_cnt,
                                                               unsigned n_slices, unsigned slice_cap, int32_t *__restrict__ rank,
                                                               unsigned long long *__restrict__ best_key) {
@@ -2316,6 +2345,7 @@ __global__ __launch_bounds__(256) void rank_bf16_fixup_kernel(const float *__res
                 acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
             }
             for (; k < dim; ++k) acc = fmaf(a[k], b[k], acc);
+            if (csls_r) acc = fmaf(2.0f, acc, -csls_r[i]) - csls_c[j];                // rank_inner_kernel's expression
             if (rc.y & kRecTop) {
                 atomicMax(best_key + i, ((unsigned long long)f2ord(acc) << 32) | (0xFFFFFFFFu - (uint32_t)j));
             } else {
@@ -2553,8 +2583,8 @@ constexpr int kBf16WarmTiles = 16;          // the warm-up pass sees 2,048 candi
 
 // prologue | init | warm-up | sweep | fix-up | finish: six launches; metrics_out (may be NULL) = int64 [nk + 4] on the device
 static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
-                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
-                               long long *metrics_out, int32_t *status, void *workspace, hipStream_t st) {
+                               const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
+                               int32_t *rank, int32_t *argmax, long long *metrics_out, int32_t *status, void *workspace, hipStream_t st) {
     auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
     char *w = static_cast<char *>(workspace);
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(w);
@@ -2576,9 +2606,9 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     const int64_t items = (n1_pad + n2_pad) * (p1.kp / 4) + 17 * (n1 + n2) + 256;
     rank_bf16_prologue_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(items, 256), 16384), 256, 0, st>>>(
         e1, n1, ld1, e2, n2, ld2, dim, gold_offset, reinterpret_cast<uint4 *>(p1.p), n1_pad, reinterpret_cast<uint4 *>(p2.p), n2_pad,
-        p1.kp, gold, nmax, rank);
+        p1.kp, gold, nmax, rank, csls_r, csls_c);
     const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
-    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, bf16_eps_rel(dim), tol, rank, keys, lbrow, rec_cnt);
+    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, bf16_eps_rel(dim), csls_r, tol, rank, keys, lbrow, rec_cnt);
     int tpc = 1;
     const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
     const int chunks = pick_chunks(qt, ctiles, &tpc);
@@ -2589,15 +2619,21 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     // warm-up over 1/16 of the candidate tiles (at most 16 = 2,048 candidates, 3 % of a 70,000-row sweep); a small candidate
     // set needs none: every workgroup sees most of it anyway
     const int warm = (int)std::min<int64_t>(kBf16WarmTiles, ctiles / 16);
-    if (warm >= 2)
-        rank_bf16_kernel<true><<<dim3((unsigned)qt, 1), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, warm, gold_offset,
-                                                                        rank, lbrow, rec, rec_cnt, slice_cap);
-    rank_bf16_kernel<false><<<dim3((unsigned)qt, (unsigned)chunks), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, tpc, gold_offset,
-                                                                                 rank, lbrow, rec, rec_cnt, slice_cap);
+    const dim3 gw((unsigned)qt, 1), gs((unsigned)qt, (unsigned)chunks);
+#define OEA_BF16_SWEEP(W, C, GRID, TPC) rank_bf16_kernel<W, C><<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, csls_r, csls_c, TPC, \
+                                                                                  gold_offset, rank, lbrow, rec, rec_cnt, slice_cap)
+    if (csls_r) {
+        if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
+        OEA_BF16_SWEEP(false, true, gs, tpc);
+    } else {
+        if (warm >= 2) OEA_BF16_SWEEP(true, false, gw, warm);
+        OEA_BF16_SWEEP(false, false, gs, tpc);
+    }
+#undef OEA_BF16_SWEEP
     rc = release_packed(st);
     if (rc != OEA_OK) return rc;
     rank_bf16_fixup_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_waves, 4), 2048), 256, 0, st>>>(
-        e1, ld1, e2, ld2, dim, gold, gold_offset, rec, rec_cnt, (unsigned)n_waves, slice_cap, rank, keys);
+        e1, ld1, e2, ld2, dim, gold, gold_offset, csls_r, csls_c, rec, rec_cnt, (unsigned)n_waves, slice_cap, rank, keys);
     int t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < nk; ++i) t[i] = top_k_host[i];
     long long *out = metrics_out ? metrics_out : fin;
@@ -2620,18 +2656,20 @@ int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2
     OEA_REQUIRE(use_glds(), "the bf16 prefilter runs on the packed (LDS-DMA) tile path");
     hipStream_t st = oea::as_stream(stream);
     if (n1 == 0) { OEA_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st)); return OEA_OK; }
-    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, gold_offset, nullptr, 0, rank, argmax, nullptr, status, workspace, st);
+    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, nullptr, nullptr, gold_offset, nullptr, 0, rank, argmax, nullptr, status,
+                               workspace, st);
 }
 
 int oea_rank_eval_metrics_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
-                               int64_t gold_offset, const int32_t *top_k_host, int32_t nk, int32_t *rank, int32_t *argmax,
-                               int64_t *out_dev, void *workspace, void *stream) {
+                               const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
+                               int32_t *rank, int32_t *argmax, int64_t *out_dev, void *workspace, void *stream) {
     OEA_REQUIRE(e1 && e2 && rank && argmax && workspace && top_k_host && out_dev, "null pointer");
+    OEA_REQUIRE((csls_r == nullptr) == (csls_c == nullptr), "csls_r and csls_c go together");
     OEA_REQUIRE(n1 > 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
     OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
     OEA_REQUIRE(n2 < 0x7fffffff && n1 < 0x7fffffff && nk >= 1 && nk <= 8, "n < 2^31, 1 <= len(top_k) <= 8");
     OEA_REQUIRE(use_glds(), "the bf16 prefilter runs on the packed (LDS-DMA) tile path");
-    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, gold_offset, top_k_host, nk, rank, argmax,
+    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, csls_r, csls_c, gold_offset, top_k_host, nk, rank, argmax,
                                reinterpret_cast<long long *>(out_dev), nullptr, workspace, oea::as_stream(stream));
 }
 

@@ -29,6 +29,12 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
     if csls_k > 0:
         r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
     if kmetric == 'inner' and 1 <= len(top_k) <= 8 and ops.tile_glds():
+        if ops.eval_bf16_enabled(t1.shape[0], t2.shape[0]):
+            # certified bf16 prefilter (with or without the CSLS means): the same ranks / nearest candidates at 3/16 of the fp32
+            # matrix time; None = its record buffer overflowed (tables of near-duplicates): the fp32 sweep below
+            res = ops.rank_eval_metrics_bf16(t1, t2, dim, top_k, csls_r=r, csls_c=c)
+            if res is not None:
+                return res
         return ops.rank_eval_metrics(t1, t2, dim, top_k, r, c)             # prologue + sweep: two launches, one copy back
     grid = getattr(csls_means_device, "last_grid", None) if (csls_k > 0 and kmetric == 'manhattan') else None
     csls_means_device.last_grid = None

@@ -473,10 +473,22 @@ def topk_rows(s, k, id_map=None, nc=None):
     return out
 
 
+def eval_bf16_enabled(n1, n2):
+    """the certified bf16 prefilter (oea_rank_eval_bf16) takes the inner-product evaluation without CSLS terms from ~7,000^2
+    pairs on (below that its six launches cost more than the matrix time it saves); OEA_EVAL_BF16=0 keeps the fp32 sweep"""
+    return os.environ.get('OEA_EVAL_BF16', '1')[:1] != '0' and tile_glds() and n1 * n2 >= 5e7
+
+
 def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0):
     """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]
     assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
+    if metric == 'inner' and csls_r is None and n1 > 0 and eval_bf16_enabled(n1, n2) and not getattr(rank_eval, "_in_bf16", False):
+        rank_eval._in_bf16 = True                   # (rank_eval_bf16 falls back to this function on a record overflow)
+        try:
+            return rank_eval_bf16(e1, e2, dim, gold_offset)
+        finally:
+            rank_eval._in_bf16 = False
     if metric == 'manhattan' and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
         return rank_eval_l1_grid(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
     ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
@@ -606,7 +618,7 @@ def rank_eval_bf16(e1, e2, dim, gold_offset=0, stats=None):
     return rank, argmax
 
 
-def rank_eval_metrics_bf16(e1, e2, dim, top_k, gold_offset=0, stats=None):
+def rank_eval_metrics_bf16(e1, e2, dim, top_k, gold_offset=0, stats=None, csls_r=None, csls_c=None):
     """rank_eval_metrics through the certified bf16 prefilter: six launches + ONE device->host copy that carries the metrics and
     the sweep's status -> (rank, argmax, hits, rank_sum, rr_sum), or None when the record buffer overflowed (the caller takes
     the fp32 sweep)."""
@@ -616,8 +628,8 @@ def rank_eval_metrics_bf16(e1, e2, dim, top_k, gold_offset=0, stats=None):
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
     buf = torch.empty(nk + 4, dtype=torch.int64, device=e1.device)
     tk = (C.c_int32 * nk)(*[int(k) for k in top_k])
-    check(lib().oea_rank_eval_metrics_bf16(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, int(gold_offset), tk, nk,
-                                           _p(rank), _p(argmax), C.c_void_p(buf.data_ptr()), _p(ws), _stream()))
+    check(lib().oea_rank_eval_metrics_bf16(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, _p(csls_r), _p(csls_c),
+                                           int(gold_offset), tk, nk, _p(rank), _p(argmax), C.c_void_p(buf.data_ptr()), _p(ws), _stream()))
     host = buf.cpu().numpy()
     if stats is not None:
         stats['records'], stats['fallback'] = int(host[nk + 3]), bool(host[nk + 2])

@@ -398,6 +398,61 @@ def test_triple_step_vs_oracle(ops, case, grouped):
         np.testing.assert_allclose(d_eacc.cpu().numpy()[:, :d], ent_acc, rtol=2e-4, atol=1e-7)
 
 
+def _unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("d", [75, 100, 300, 37])
+def test_bf16_prefilter_evaluation_equals_the_fp32_sweep(ops, d, monkeypatch):
+    """oea_rank_eval[_metrics]_bf16: the tile sweep multiplies bf16 splits (hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16),
+    counts what the error bound decides and records the rest for the exact k-ordered chain.  (1) the approximate similarities
+    stay inside the certified bound; (2) ranks, nearest candidates and the integer metrics equal the fp32 sweep's on random
+    golds (hundreds of records), golds near the top, exact duplicates of gold columns in front of and behind them (the tie rule),
+    unnormalised rows, and a clustered table whose records overflow (the caller's fallback to the fp32 sweep)."""
+    rng = np.random.RandomState(d)
+    a, b = _unit(rng.standard_normal((700, d))), _unit(rng.standard_normal((1300, d)))
+    ta, tb = ops.to_table(a), ops.to_table(b)
+    err = float((ops.sim_matrix(ta, tb, d, "inner") - ops.sim_bf16_matrix(ta, tb, d)).abs().max())
+    kp16 = (d + 15) // 16 * 16
+    assert err <= 1.02 * (3.02 * 2.0 ** -18 + (3 * kp16 + d + 8) * 2.0 ** -23), err
+    n1, n2, off = 1500, 4000, 700
+    e2 = _unit(rng.standard_normal((n2, d)))
+    e2t = e2.copy()
+    e2t[3000:3400] = e2t[off:off + 400]
+    e2t[0:300] = e2t[off + 500:off + 800]
+    e2c = e2.copy()
+    e2c[1000:3000] = _unit(e2c[1000] + 2e-4 * rng.standard_normal((2000, d)))
+    e2u = (e2 * rng.uniform(0.05, 4.0, (n2, 1))).astype(np.float32)
+    cases = {"random gold": (_unit(rng.standard_normal((n1, d))), e2),
+             "gold near the top": (_unit(e2[off:off + n1] + 0.5 * rng.standard_normal((n1, d)) / np.sqrt(d)), e2),
+             "duplicated gold columns": (_unit(e2t[off:off + n1] + 0.1 * rng.standard_normal((n1, d)) / np.sqrt(d)), e2t),
+             "unnormalised rows": ((e2u[off:off + n1] + 0.3 * rng.standard_normal((n1, d)).astype(np.float32) / np.sqrt(d)).astype(np.float32), e2u),
+             "clustered (overflow)": (_unit(e2c[off:off + n1] + 1e-4 * rng.standard_normal((n1, d))), e2c)}
+    monkeypatch.setenv("OEA_EVAL_BF16", "0")
+    for name, (q, c) in cases.items():
+        t1, t2 = ops.to_table(q), ops.to_table(c)
+        r0, a0 = ops.rank_eval(t1, t2, d, "inner", gold_offset=off)
+        st = {}
+        r1, a1 = ops.rank_eval_bf16(t1, t2, d, gold_offset=off, stats=st)
+        assert torch.equal(r0, r1) and torch.equal(a0, a1), (name, st)
+        assert st["fallback"] == name.startswith("clustered"), (name, st)
+        if off == 0 or True:
+            q0, c0 = ops.to_table(q), ops.to_table(c[off:])         # the metrics entry point takes gold_offset too; use 0 here
+            m0 = ops.rank_eval_metrics(q0, c0, d, [1, 5, 10, 50])
+            m1 = ops.rank_eval_metrics_bf16(q0, c0, d, [1, 5, 10, 50])
+            if name.startswith("clustered"):
+                assert m1 is None
+            else:
+                assert torch.equal(m0[0], m1[0]) and torch.equal(m0[1], m1[1]) and m0[2] == m1[2] and m0[3] == m1[3], name
+                assert abs(m0[4] - m1[4]) <= 1e-9 * abs(m0[4])
+                # the same with CSLS means: (2 s - r) - c ranked from the approximate s + exact records
+                from openea_amd.modules.finding.similarity import csls_means_device
+                rr, cc = csls_means_device(q0, c0, d, "inner", 10)
+                m0 = ops.rank_eval_metrics(q0, c0, d, [1, 5, 10, 50], rr, cc)
+                m1 = ops.rank_eval_metrics_bf16(q0, c0, d, [1, 5, 10, 50], csls_r=rr, csls_c=cc)
+                assert m1 is not None and torch.equal(m0[0], m1[0]) and torch.equal(m0[1], m1[1]) and m0[2] == m1[2] and m0[3] == m1[3], name
+
+
 DET_WORKER = r'''
 import os, sys
 import numpy as np

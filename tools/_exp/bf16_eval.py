@@ -87,3 +87,20 @@ for n, d, reps in ((10500, 75, 30), (70000, 100, 4), (70000, 300, 3)):
         same = b is not None and bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) and a[2:] == b[2:]
         print("eval %6d^2 x %3d, %-17s: fp32 %.3f ms, bf16 prefilter %.3f ms (%.2fx), records %d (%.1f per row), fallback %s, identical incl. metrics %s" %
               (n, d, mode, ms32, ms16, ms32 / ms16, st["records"], st["records"] / n, st["fallback"], same), flush=True)
+
+# ---- 4. CSLS: means (fp32 one-sweep) + rank sweep with the means, fp32 vs bf16 prefilter ---------------------------------------
+from openea_amd.modules.finding.similarity import csls_means_device  # noqa: E402
+for n, d, reps in ((10500, 75, 20), (70000, 100, 3)):
+    e1 = unit(rng.standard_normal((n, d)))
+    e2 = unit(e1 + 0.4 * rng.standard_normal((n, d)) / np.sqrt(d))
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    r, c = csls_means_device(t1, t2, d, "inner", 10)
+    st = {}
+    ms_means = wall(lambda: csls_means_device(t1, t2, d, "inner", 10), reps)
+    ms32 = wall(lambda: ops.rank_eval_metrics(t1, t2, d, TOPK, r, c), reps)
+    ms16 = wall(lambda: ops.rank_eval_metrics_bf16(t1, t2, d, TOPK, stats=st, csls_r=r, csls_c=c), reps)
+    a = ops.rank_eval_metrics(t1, t2, d, TOPK, r, c)
+    b = ops.rank_eval_metrics_bf16(t1, t2, d, TOPK, csls_r=r, csls_c=c)
+    same = b is not None and bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) and a[2:4] == b[2:4]
+    print("CSLS %6d^2 x %3d: means %.3f ms; rank sweep fp32 %.3f ms, bf16 %.3f ms (%.2fx); records %d, identical %s" %
+          (n, d, ms_means, ms32, ms16, ms32 / ms16, st["records"], same), flush=True)
