@@ -278,6 +278,117 @@ __device__ __forceinline__ void tile_pipeline_packed(const float *__restrict__ a
     }
 }
 
+// ---- bf16 hi / lo split operands (certified prefilter: see the section before CslsPlan) ----------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {                   // round to nearest even (finite inputs)
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// packed row = kp "float slots" (kp = dim rounded up to 32): every 32-k chunk is 128 B = 8 granules of 8 bf16; granule
+// (s * 2 + h) * 2 + p holds k = 32 chunk + 16 s + 8 h + [0, 8) of the hi (p = 0) or lo (p = 1) part -- one MFMA operand of lane
+// half h in k-step s.  Same bytes per row as the fp32 packed layout, so stage_packed moves it unchanged.
+__global__ void pack_rows_bf16_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, uint4 *__restrict__ dst,
+                                      int64_t n_pad, int kp) {
+    const int cpr = kp / 4;
+    const int64_t total = n_pad * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const int g = c & 7, k0 = 32 * (c >> 3) + 16 * (g >> 2) + 8 * ((g >> 1) & 1), lo = g & 1;
+        uint32_t h[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float x = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
+            const uint32_t hi = bf16_rne(x);
+            h[t] = lo ? bf16_rne(x - __uint_as_float(hi << 16)) : hi;
+        }
+        dst[i] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    }
+}
+
+// max row norm of a table as the bits of a non-negative float (integer order == float order)
+__global__ void row_norm_max_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, unsigned *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float nr = 0.f;
+    if (i < n) {
+        float ss = 0.f;
+        for (int k = 0; k < dim; ++k) ss = fmaf(src[i * ld + k], src[i * ld + k], ss);
+        nr = sqrtf(ss) * 1.0000005f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nr = fmaxf(nr, __shfl_xor(nr, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(nr));
+}
+
+// acc += hi.hi + hi.lo + lo.hi of one chunk (ksteps = 1 or 2 k-steps of 16)
+__device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, const float *__restrict__ Bs, int ksteps,
+                                               f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = (lane >> 1) & 7, half = lane >> 5;
+    const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
+    const float *bp = Bs + (wn * 64 + (lane & 31)) * PLD;
+    for (int s = 0; s < ksteps; ++s) {
+        const int g = 4 * s + 2 * half;
+        const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
+        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
+        const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
+        const bf16x8 b0h = *reinterpret_cast<const bf16x8 *>(bp + oh), b0l = *reinterpret_cast<const bf16x8 *>(bp + ol);
+        const bf16x8 b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh), b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+    }
+}
+
+// tile_pipeline_packed for the bf16 layout: chunks of two k-steps (32 k = 128 B per row), LDS-DMA staging unchanged
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
+                                                   int64_t n0, int64_t n_tiles, MTile m_tile, float *As, float *Bs,
+                                                   Epilogue epilogue) {
+    const int S = (dim + 15) / 16;
+    const int nchunk = (S + 1) / 2;
+    const int64_t total = n_tiles * nchunk;
+    if (total == 0) return;
+    constexpr int BUF = TILE * LDS_LD;
+    stage_packed(am, kp, m_tile(0), 0, As);
+    stage_packed(bn, kp, n0, 0, Bs);
+    __syncthreads();
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    int64_t t = 0;
+    int kc = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        const int cur = (int)(it & 1);
+        if (it + 1 < total) {
+            int kc1 = kc + 1;
+            int64_t t1 = t;
+            if (kc1 == nchunk) { kc1 = 0; ++t1; }
+            stage_packed(am, kp, m_tile(t1), kc1 * BK, As + (cur ^ 1) * BUF);
+            stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
+        }
+        mma_chunk_bf16(As + cur * BUF, Bs + cur * BUF, min(2, S - 2 * kc), acc);
+        __syncthreads();
+        if (++kc == nchunk) {
+            epilogue(t, acc);
+            zero_acc(acc);
+            kc = 0;
+            ++t;
+        }
+    }
+}
+
 // one call site for both stagings: PACKED kernels receive packed operands and their Kp in the ld arguments
 template <bool PACKED, class MTile, class Epilogue>
 __device__ __forceinline__ void run_tiles(const float *__restrict__ am, int64_t m_rows, int lda, const float *__restrict__ bn,
@@ -638,11 +749,15 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
 // a wave ballot -- no atomics, no LDS, no barrier; the segment is written by this wave only, its length goes to
 // ccounts[(j * T + qt) * 2 + wn] (uint8).  (First version: one segment per (j, qt), slots from an LDS counter per candidate,
 // a returning LDS atomic per survivor between two barriers: 17.0 ms for the 100,000^2 sweep.)
-template <bool PACKED>
+// BF16: e = the hi / lo split rows (pack_rows_bf16_kernel), the values appended are v~ with |v~ - v| <= *tol_ptr, and the cut is
+// thr - tol: every pair whose EXACT value reaches thr is in the lists (the select resolves the neighbourhood of the k-th
+// value with exact chains, list_select_kernel).
+template <bool PACKED, bool BF16>
 __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
     const float *__restrict__ e, int64_t n, int ld, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     int nseg, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols, int32_t *__restrict__ counts, int T, int ccap,
-    uint2 *__restrict__ clists, uint8_t *__restrict__ ccounts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap) {
+    uint2 *__restrict__ clists, uint8_t *__restrict__ ccounts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap,
+    const float *__restrict__ tol_ptr) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
@@ -652,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
     const int half = lane >> 5, l32 = lane & 31;
     const int64_t q0 = (int64_t)qt * TILE;
     const int sidx = (item.w * 2 + wm) * 2 + half;
+    const float tol = BF16 ? *tol_ptr : 0.f;
     float th[2];
     uint32_t boff[2], bbeg[2], blast[2];
     int64_t qi[2];
@@ -661,7 +777,7 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
     for (int tn = 0; tn < 2; ++tn) {
         const int ql = wn * 64 + tn * 32 + l32;
         qi[tn] = q0 + ql;
-        th[tn] = qi[tn] < n ? thr[qi[tn]] : INFINITY;
+        th[tn] = qi[tn] < n ? thr[qi[tn]] - tol : INFINITY;
         bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
         blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);
     }
@@ -670,15 +786,12 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
     const int jl0 = wm * 64 + 4 * half;
     const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
     const uint32_t below = (1u << l32) - 1u;
-    run_tiles<PACKED>(
-        e, n, ld, e, n, ld, dim, q0, (int64_t)(item.z - item.y),
-        [=](int64_t t) { return (int64_t)(item.y + t) * TILE; }, As, Bs,
-        [&](int64_t t, f32x16 (&acc)[2][2]) {
+    auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int ct = item.y + (int)t;
             const int64_t c0 = (int64_t)ct * TILE;
             const bool offdiag = ct != qt;                           // workgroup-uniform
             const int64_t my_j = c0 + my_jl;
-            const float my_tc = (offdiag && my_j < n) ? thr[my_j] : INFINITY;
+            const float my_tc = (offdiag && my_j < n) ? thr[my_j] - tol : INFINITY;
             int my_cnt = 0;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
@@ -719,7 +832,10 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
             }
             // lengths saturate at 255; the select reads min(length, ccap - 1) entries, the rest sits in the row's spill list
             if (offdiag && my_j < n) ccounts[(my_j * T + qt) * 2 + wn] = (uint8_t)min(my_cnt, 255);
-        });
+        };
+    auto m_tile = [=](int64_t t) { return (int64_t)(item.y + t) * TILE; };
+    if constexpr (BF16) tile_pipeline_bf16(e, ld, e, dim, q0, (int64_t)(item.z - item.y), m_tile, As, Bs, epilogue);
+    else run_tiles<PACKED>(e, n, ld, e, n, ld, dim, q0, (int64_t)(item.z - item.y), m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
         if (qi[tn] < n) counts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
@@ -1929,116 +2045,8 @@ static void launch_store_packed(const float *e1p, int64_t n1, const float *e2p, 
 // so far, gold included), so those are recorded too (the bound is shared by the lanes of a row through an atomic maximum).
 // The fix-up kernel evaluates the records -- a few dozen per row -- exactly.  Ranks and nearest candidates are those of the
 // fp32 sweep, bit for bit; if the record buffer overflows the caller takes the fp32 sweep.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
-__device__ __forceinline__ uint32_t bf16_rne(float x) {                   // round to nearest even (finite inputs)
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-
-// packed row = kp "float slots" (kp = dim rounded up to 32): every 32-k chunk is 128 B = 8 granules of 8 bf16; granule
-// (s * 2 + h) * 2 + p holds k = 32 chunk + 16 s + 8 h + [0, 8) of the hi (p = 0) or lo (p = 1) part -- one MFMA operand of lane
-// half h in k-step s.  Same bytes per row as the fp32 packed layout, so stage_packed moves it unchanged.
-__global__ void pack_rows_bf16_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, uint4 *__restrict__ dst,
-                                      int64_t n_pad, int kp) {
-    const int cpr = kp / 4;
-    const int64_t total = n_pad * cpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / cpr;
-        const int c = (int)(i - row * cpr);
-        const int g = c & 7, k0 = 32 * (c >> 3) + 16 * (g >> 2) + 8 * ((g >> 1) & 1), lo = g & 1;
-        uint32_t h[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float x = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
-            const uint32_t hi = bf16_rne(x);
-            h[t] = lo ? bf16_rne(x - __uint_as_float(hi << 16)) : hi;
-        }
-        dst[i] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    }
-}
-
-// max row norm of a table as the bits of a non-negative float (integer order == float order)
-__global__ void row_norm_max_kernel(const float *__restrict__ src, int64_t n, int ld, int dim, unsigned *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float nr = 0.f;
-    if (i < n) {
-        float ss = 0.f;
-        for (int k = 0; k < dim; ++k) ss = fmaf(src[i * ld + k], src[i * ld + k], ss);
-        nr = sqrtf(ss) * 1.0000005f;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nr = fmaxf(nr, __shfl_xor(nr, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(nr));
-}
-
-// acc += hi.hi + hi.lo + lo.hi of one chunk (ksteps = 1 or 2 k-steps of 16)
-__device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, const float *__restrict__ Bs, int ksteps,
-                                               f32x16 (&acc)[2][2]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int x = (lane >> 1) & 7, half = lane >> 5;
-    const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
-    const float *bp = Bs + (wn * 64 + (lane & 31)) * PLD;
-    for (int s = 0; s < ksteps; ++s) {
-        const int g = 4 * s + 2 * half;
-        const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
-        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
-        const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
-        const bf16x8 b0h = *reinterpret_cast<const bf16x8 *>(bp + oh), b0l = *reinterpret_cast<const bf16x8 *>(bp + ol);
-        const bf16x8 b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh), b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
-    }
-}
-
-// tile_pipeline_packed for the bf16 layout: chunks of two k-steps (32 k = 128 B per row), LDS-DMA staging unchanged
-template <class MTile, class Epilogue>
-__device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
-                                                   int64_t n0, int64_t n_tiles, MTile m_tile, float *As, float *Bs,
-                                                   Epilogue epilogue) {
-    const int S = (dim + 15) / 16;
-    const int nchunk = (S + 1) / 2;
-    const int64_t total = n_tiles * nchunk;
-    if (total == 0) return;
-    constexpr int BUF = TILE * LDS_LD;
-    stage_packed(am, kp, m_tile(0), 0, As);
-    stage_packed(bn, kp, n0, 0, Bs);
-    __syncthreads();
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    int64_t t = 0;
-    int kc = 0;
-    for (int64_t it = 0; it < total; ++it) {
-        const int cur = (int)(it & 1);
-        if (it + 1 < total) {
-            int kc1 = kc + 1;
-            int64_t t1 = t;
-            if (kc1 == nchunk) { kc1 = 0; ++t1; }
-            stage_packed(am, kp, m_tile(t1), kc1 * BK, As + (cur ^ 1) * BUF);
-            stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
-        }
-        mma_chunk_bf16(As + cur * BUF, Bs + cur * BUF, min(2, S - 2 * kc), acc);
-        __syncthreads();
-        if (++kc == nchunk) {
-            epilogue(t, acc);
-            zero_acc(acc);
-            kc = 0;
-            ++t;
-        }
-    }
-}
-
+// (the split operands' pack kernel, mma_chunk_bf16 and tile_pipeline_bf16 sit beside tile_pipeline_packed above: the neighbour
+// search's append kernel uses them too)
 __device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o); }
 
 constexpr uint32_t kRecTop = 0x80000000u;        // record kinds: bit 31 of the candidate word
@@ -2388,6 +2396,12 @@ __global__ __launch_bounds__(256, 2) void sim_bf16_store_kernel(const float *__r
 }
 
 // workspace layout of oea_csls_means
+// tol[0] = bound on |v~ - v| of the neighbour search's bf16 sweep from tol[1] = bits of the max row norm (as rank_bf16_init_kernel)
+__global__ void knn_tol_kernel(float *tol, float eps_rel) {
+    const float nm = tol[1], smax = nm * nm;
+    tol[0] = 1.05f * eps_rel * smax + 1.0e-6f * smax + 1e-30f;
+}
+
 struct CslsPlan {
     bool ok = false;
     int sample = 0, r1 = 0, r2 = 0, cap = 0, ccap = 0, chunks = 0, nseg = 0, tpc = 0, nqt = 0;
@@ -2437,6 +2451,9 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
 
 }  // namespace
 
+static float bf16_eps_rel(int dim);
+static int pack_operand_bf16(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out);
+
 namespace oea {
 // kNN strips (topk.hip): both operands packed once (slot 0 = queries, slot 1 = candidates), every strip produced from
 // the packed copies; release_packed_rows() after the last strip
@@ -2467,10 +2484,27 @@ int topk_append_chunks(int64_t nq, int64_t nc) {
 void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const float *thr, const void *items, int n_items, int nseg,
                             int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
                             uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st) {
-    topk_append_sym_kernel<true><<<(unsigned)n_items, 256, 0, st>>>(ep, n, kp, dim, thr, static_cast<const int4 *>(items), nseg, cap,
-                                                                    list_vals, list_cols, counts, T, ccap,
-                                                                    static_cast<uint2 *>(clists), ccounts, spill_cnt,
-                                                                    static_cast<uint2 *>(spill), sp_cap);
+    topk_append_sym_kernel<true, false><<<(unsigned)n_items, 256, 0, st>>>(ep, n, kp, dim, thr, static_cast<const int4 *>(items), nseg,
+                                                                           cap, list_vals, list_cols, counts, T, ccap,
+                                                                           static_cast<uint2 *>(clists), ccounts, spill_cnt,
+                                                                           static_cast<uint2 *>(spill), sp_cap, nullptr);
+}
+// the same sweep on the hi / lo split rows of `src` (packed here into slot 3); tol_dev[0] receives the bound on |v~ - v|
+// (max row norm^2 x eps(dim), computed on the device) that the sweep cuts by and the select resolves with
+int topk_append_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, int nseg,
+                         int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
+                         uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, float *tol_dev, hipStream_t st) {
+    PackedOp op;
+    const int rc = pack_operand_bf16(3, src, n, ld, dim, st, &op);
+    if (rc != OEA_OK) return rc;
+    OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
+    row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
+    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
+    topk_append_sym_kernel<true, true><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items), nseg,
+                                                                          cap, list_vals, list_cols, counts, T, ccap,
+                                                                          static_cast<uint2 *>(clists), ccounts, spill_cnt,
+                                                                          static_cast<uint2 *>(spill), sp_cap, tol_dev);
+    return OEA_OK;
 }
 void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc, int kp, int dim, const float *thr, int cap,
                         int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill, int sp_cap,

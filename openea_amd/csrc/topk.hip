@@ -827,7 +827,14 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail,
                                                                    const uint2 *__restrict__ clists, const uint8_t *__restrict__ ccounts,
                                                                    int T, int ccap, const int32_t *__restrict__ spill_cnt,
-                                                                   const uint2 *__restrict__ spill, int stop_after) {
+                                                                   const uint2 *__restrict__ spill, int stop_after,
+                                                                   const float *__restrict__ exact_src, int ld_src, int dim,
+                                                                   const float *__restrict__ tol_ptr) {
+    // tol_ptr != NULL: the list values are APPROXIMATE (v~ of the bf16 sweep, |v~ - v| <= tol = *tol_ptr) and the lists hold every
+    // pair with v~ >= thr - tol.  With t~ = the k-th largest v~ (found exactly as before) the exact k-th value t is within tol
+    // of t~, so  v~ > t~ + 2 tol  =>  v > t: selected;   v~ < t~ - 2 tol  =>  v < t: not selected;  the band in between (a dozen
+    // entries) is decided by the EXACT k-ordered chains against rows of exact_src, (value desc, column asc) as everywhere.
+    // The band must lie inside the lists (t~ - 2 tol >= thr - tol), else the row goes to the strip fallback.
     // stop_after (experiments, OEA_TOPK_SELECT_STOP): leave after phase 1 (lengths + scan), 2 (gather), 3 (histogram + bucket),
     // 4 (threshold bucket ranked), 5 (bitmap set); 0 = run to the end.  Results are garbage when it is set.
     // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
@@ -838,12 +845,13 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     extern __shared__ uint32_t bitmap[];      // ceil(nc / 32) words (dynamic: 12.5 KB at nc = 100,000 keeps 5 workgroups per CU)
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
-    __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol;
+    __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol, s_nband;
     __shared__ uint32_t s_tkey;
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_bad = 0; s_ncand = 0; }
+    if (tid == 0) { s_bad = 0; s_ncand = 0; s_nband = 0; }
     __syncthreads();
+    const float tol = tol_ptr ? *tol_ptr : 0.f;
     // segment lengths -> exclusive offsets (block scan: the symmetric search has hundreds of segments per row)
     // + the row's spill list as the last segment (entries whose own segment was full)
     const int nst = nseg + T + 1;
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         __syncthreads();
         for (int w = tid; w < words; w += SEL_THREADS) bitmap[w] = 0u;       // the owner table is dead: its storage becomes the bitmap
         if (stop_after == 2) { if (mx == 12345.f) out[row] = col[0] + col[kPerThread - 1]; return; }
-        const float lo = thr[row];                               // every survivor is >= thr
+        const float lo = thr[row] - tol;                         // every survivor is >= the sweep's cut (the same expression)
         const float hi = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         const float scale = hi > lo ? (float)(kBins - 2) / (hi - lo) : 0.0f;
 #pragma unroll
@@ -988,13 +996,60 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
             const uint32_t tkey = s_tkey;
             const int tcol = s_tcol;
             if (stop_after == 4) return;
+            if (tol_ptr) {
+                const float tv = ord2f(tkey);
+                const float hi2 = tv + 2.0f * tol, lo2 = tv - 2.0f * tol;      // complementary classes: > hi2 | [lo2, hi2] | < lo2
+                int above = 0;
 #pragma unroll
-            for (int e = 0; e < kPerThread; ++e) {
-                if (col[e] < 0) continue;
-                const uint32_t key = f2ord(val[e]);
-                if (key > tkey || (key == tkey && col[e] <= tcol)) atomicOr(&bitmap[col[e] >> 5], 1u << (col[e] & 31));   // exactly k bits
+                for (int e = 0; e < kPerThread; ++e) {
+                    if (col[e] < 0) continue;
+                    if (val[e] > hi2) {
+                        atomicOr(&bitmap[col[e] >> 5], 1u << (col[e] & 31));
+                        ++above;
+                    } else if (val[e] >= lo2) {
+                        const int p = atomicAdd(&s_nband, 1);
+                        if (p < kCandCap) c_col[p] = col[e];
+                    }
+                }
+                int n_above;
+                block_excl_scan(above, s_wave, &n_above);                     // (two barriers: s_nband and c_col are complete)
+                const int nband = s_nband, need2 = k - n_above;
+                fail = lo2 < lo || nband > kCandCap || need2 < 0 || need2 > nband;      // block-uniform
+                if (!fail) {
+                    const float *__restrict__ a = exact_src + row * (int64_t)ld_src;
+                    for (int i = tid; i < nband; i += SEL_THREADS) {
+                        const float *__restrict__ b = exact_src + (int64_t)c_col[i] * ld_src;
+                        float acc = 0.f;
+                        int kk = 0;
+                        for (; kk + 4 <= dim; kk += 4) {
+                            const float4 x = oea::ld4(a + kk), y = oea::ld4(b + kk);
+                            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+                        }
+                        for (; kk < dim; ++kk) acc = fmaf(a[kk], b[kk], acc);
+                        c_key[i] = f2ord(acc);
+                    }
+                    __syncthreads();
+                    for (int i = tid; i < nband; i += SEL_THREADS) {
+                        const uint32_t ki = c_key[i];
+                        const int ci = c_col[i];
+                        int rank = 0;
+                        for (int j = 0; j < nband; ++j) {
+                            const uint32_t kj = c_key[j];
+                            rank += (kj > ki) || (kj == ki && c_col[j] < ci);
+                        }
+                        if (rank < need2) atomicOr(&bitmap[ci >> 5], 1u << (ci & 31));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < kPerThread; ++e) {
+                    if (col[e] < 0) continue;
+                    const uint32_t key = f2ord(val[e]);
+                    if (key > tkey || (key == tkey && col[e] <= tcol)) atomicOr(&bitmap[col[e] >> 5], 1u << (col[e] & 31));   // exactly k bits
+                }
             }
             __syncthreads();
+            if (!fail) {
             if (stop_after == 5) return;
             // enumerate the set bits in ascending column order: contiguous word ranges per thread + block scan
             const int wpt = (words + SEL_THREADS - 1) / SEL_THREADS;
@@ -1033,6 +1088,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                 }
             }
             return;
+            }
         }
     }
     if (tid == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
@@ -1394,11 +1450,22 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         OEA_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)nq * sy.nseg, st));
         OEA_CHECK_HIP(hipMemsetAsync(ccounts, 0, (size_t)nq * sy.T * 2, st));
         OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)nq, st));
-        oea::topk_append_sym_packed(qp, nq, kp, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
-                                    sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, st);
+        // the sweep on the bf16 hi / lo split of the rows (3/16 of the fp32 matrix time; OEA_TOPK_BF16=0: the exact fp32 sweep):
+        // approximate list values, the select decides the neighbourhood of the k-th value with exact chains -- same result
+        static const bool bf16_on = [] { const char *e = getenv("OEA_TOPK_BF16"); return !(e && e[0] == '0'); }();
+        float *tol_dev = reinterpret_cast<float *>(w + sy.off_nfail + 64);
+        if (bf16_on) {
+            rc = oea::topk_append_sym_bf16(c, nc, ldc, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
+                                           sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, tol_dev, st);
+            if (rc != OEA_OK) return rc;
+        } else {
+            oea::topk_append_sym_packed(qp, nq, kp, dim, thr, items_dev, sy.n_items, sy.nseg, sy.cap, list_vals, list_cols, counts, sy.T,
+                                        sy.ccap, clists, ccounts, spill_cnt, spill, kSpillCap, st);
+        }
         list_select_kernel<<<(unsigned)nq, SEL_THREADS, select_lds_bytes(nc), st>>>(
             list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
-            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill), select_stop());
+            static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill), select_stop(),
+            c, ldc, dim, bf16_on ? tol_dev : nullptr);
         rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
                               8 * (size_t)nq * sy.T * 2 * sy.ccap, sy.ld, st);
         if (rc != OEA_OK) return rc;
@@ -1436,7 +1503,8 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             list_select_kernel<<<(unsigned)rows, SEL_THREADS, select_lds_bytes(nc), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
-                                                                      spill_cnt, static_cast<const uint2 *>(spill), select_stop());
+                                                                      spill_cnt, static_cast<const uint2 *>(spill), select_stop(),
+                                                                      nullptr, 0, 0, nullptr);
             // rows the select gave up on: through the strip path, in batches, inside the (now dead) list storage
             rc = redo_failed_rows(qp + r0 * kp, kp, cp, nc, dim, k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, list_vals,
                                   2 * lp.cols_off, lp.ld, st);

@@ -474,9 +474,12 @@ def topk_rows(s, k, id_map=None, nc=None):
 
 
 def eval_bf16_enabled(n1, n2):
-    """the certified bf16 prefilter (oea_rank_eval_bf16) takes the inner-product evaluation without CSLS terms from ~7,000^2
-    pairs on (below that its six launches cost more than the matrix time it saves); OEA_EVAL_BF16=0 keeps the fp32 sweep"""
-    return os.environ.get('OEA_EVAL_BF16', '1')[:1] != '0' and tile_glds() and n1 * n2 >= 5e7
+    """the certified bf16 prefilter (oea_rank_eval_bf16) takes the inner-product evaluation (with or without CSLS means) from
+    3e8 pairs (~17,000^2) on: its six launches and the exact fix-up cost ~0.1 ms, which the 10,500 test pairs of the 15K
+    datasets do not win back inside greedy_alignment (bench r04k: 34.7 vs 38.5 M pairs/s), the 70,000 of the 100K datasets do
+    (11.6 vs 7.5 M pairs/s).  OEA_EVAL_BF16=0 keeps the fp32 sweep, OEA_EVAL_BF16_MIN_PAIRS moves the limit."""
+    lim = float(os.environ.get('OEA_EVAL_BF16_MIN_PAIRS', '3e8'))
+    return os.environ.get('OEA_EVAL_BF16', '1')[:1] != '0' and tile_glds() and n1 * n2 >= lim
 
 
 def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0):

@@ -453,6 +453,32 @@ def test_bf16_prefilter_evaluation_equals_the_fp32_sweep(ops, d, monkeypatch):
                 assert m1 is not None and torch.equal(m0[0], m1[0]) and torch.equal(m0[1], m1[1]) and m0[2] == m1[2] and m0[3] == m1[3], name
 
 
+def test_greedy_alignment_takes_the_bf16_prefilter_and_reports_the_same(ops, monkeypatch):
+    """greedy_alignment_device routes inner-product evaluations of >= OEA_EVAL_BF16_MIN_PAIRS pairs (3e8 by default) through
+    oea_rank_eval_metrics_bf16, with and without CSLS means; everything it returns equals the fp32 sweep's."""
+    from openea_amd.modules.finding.alignment import greedy_alignment_device
+    rng = np.random.RandomState(5)
+    n, d = 2600, 75
+    e2 = _unit(rng.standard_normal((n, d)))
+    e1 = _unit(e2 + 0.6 * rng.standard_normal((n, d)) / np.sqrt(d))
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    assert not ops.eval_bf16_enabled(10500, 10500) and ops.eval_bf16_enabled(70000, 70000)
+    for csls in (0, 10):
+        monkeypatch.setenv("OEA_EVAL_BF16", "0")
+        r0, a0, h0, rs0, rr0 = greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, csls)
+        monkeypatch.setenv("OEA_EVAL_BF16", "1")
+        monkeypatch.setenv("OEA_EVAL_BF16_MIN_PAIRS", "1")
+        assert ops.eval_bf16_enabled(n, n)
+        calls = []
+        real = ops.rank_eval_metrics_bf16
+        monkeypatch.setattr(ops, "rank_eval_metrics_bf16", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        r1, a1, h1, rs1, rr1 = greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "inner", False, csls)
+        monkeypatch.setattr(ops, "rank_eval_metrics_bf16", real)
+        monkeypatch.delenv("OEA_EVAL_BF16_MIN_PAIRS")
+        assert calls and torch.equal(r0, r1) and torch.equal(a0, a1) and list(h0) == list(h1) and rs0 == rs1
+        assert abs(rr0 - rr1) <= 1e-9 * abs(rr0)
+
+
 DET_WORKER = r'''
 import os, sys
 import numpy as np
