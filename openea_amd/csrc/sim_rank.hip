@@ -1720,11 +1720,16 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
 // the candidate side in one list per candidate (a returning atomic per survivor: ~1 % of the values).  The exact top-k
 // means come from the lists, summed in DESCENDING order like row_topk_mean_kernel (bit-identical with oracle_topk_mean).
 // Rows / columns whose list overflowed or fell short are redone from a recomputed strip (bulk: <= 128 of each).
-template <bool PACKED>
+// BF16 (round 4): q / c are the hi / lo split rows, the values v~ are within *tol_ptr of the exact ones, both cuts are lowered
+// by that bound and every list entry is a PAIR (v~, index of the other side) -- list_mean_rows_kernel<true> finds the entries that
+// can belong to the exact top k and recomputes them with the exact chain.
+template <bool PACKED, bool BF16>
 __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
-    float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts) {
+    float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts,
+    const float *__restrict__ tol_ptr) {
+    constexpr uint32_t ES = BF16 ? 8u : 4u;                 // bytes per list entry
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     // candidate j owns 2 * nqt segments of ccap values: one per (query tile, wave column) -- written by ONE wave, whose
@@ -1743,25 +1748,23 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     float th[2];
     uint32_t boff[2], bbeg[2], blast[2];
     int64_t qi[2];
-    char *__restrict__ vbase = reinterpret_cast<char *>(qlists + q0 * nseg * (int64_t)cap);
+    const float tol = BF16 ? *tol_ptr : 0.f;
+    char *__restrict__ vbase = reinterpret_cast<char *>(qlists) + (size_t)q0 * nseg * cap * ES;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int ql = wn * 64 + tn * 32 + l32;
         qi[tn] = q0 + ql;
-        th[tn] = qi[tn] < nq ? thr_q[qi[tn]] : INFINITY;
-        bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
-        blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);
+        th[tn] = qi[tn] < nq ? thr_q[qi[tn]] - tol : INFINITY;
+        bbeg[tn] = boff[tn] = ES * (uint32_t)((ql * nseg + sidx) * cap);
+        blast[tn] = boff[tn] + ES * (uint32_t)(cap - 1);
     }
     const int jl0 = wm * 64 + 4 * half;
     const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);     // lane l32 = tm * 16 + r looks after that candidate
     const uint32_t below = (1u << l32) - 1u;
-    run_tiles<PACKED>(
-        c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
-        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
-        [&](int64_t t, f32x16 (&acc)[2][2]) {
+    auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * TILE;
             const int64_t my_j = c0 + my_jl;
-            const float my_tc = my_j < nc ? thr_c[my_j] : INFINITY;
+            const float my_tc = my_j < nc ? thr_c[my_j] - tol : INFINITY;
             int my_cnt = 0;
             // k ~ 10: ~0.05 % of the values survive either threshold, so most accumulator registers hold none.  One bound per
             // lane -- the smaller of its own query thresholds and the smallest candidate threshold of this tile's wave --
@@ -1780,30 +1783,38 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
                     const int j = (int)c0 + jl;
                     const bool jin = j < nc;
                     const float tc = __shfl(my_tc, (lane & 32) + tm * 16 + r, 64);
-                    float *__restrict__ seg = clists + (((int64_t)j * nqt + qt) * 2 + wn) * ccap;
+                    char *__restrict__ seg = reinterpret_cast<char *>(clists) + (size_t)((((int64_t)j * nqt + qt) * 2 + wn) * ccap) * ES;
                     int cnt = 0;
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         const float v = acc[tm][tn][r];
                         if (v >= th[tn] && jin) {
-                            *reinterpret_cast<float *>(vbase + min(boff[tn], blast[tn])) = v;
-                            boff[tn] += 4u;
+                            if constexpr (BF16) *reinterpret_cast<uint2 *>(vbase + min(boff[tn], blast[tn])) = make_uint2(__float_as_uint(v), (uint32_t)j);
+                            else *reinterpret_cast<float *>(vbase + min(boff[tn], blast[tn])) = v;
+                            boff[tn] += ES;
                         }
                         const bool pc = v >= tc && qi[tn] < nq;      // tc = +inf past the last candidate
                         const unsigned long long bal = __ballot(pc);
                         const uint32_t bh = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                         const int slot = cnt + __popc(bh & below);
-                        if (pc && slot < ccap) seg[slot] = v;
+                        if (pc && slot < ccap) {
+                            if constexpr (BF16) reinterpret_cast<uint2 *>(seg)[slot] = make_uint2(__float_as_uint(v), (uint32_t)qi[tn]);
+                            else reinterpret_cast<float *>(seg)[slot] = v;
+                        }
                         cnt += __popc(bh);
                     }
                     if (l32 == tm * 16 + r) my_cnt = cnt;
                 }
             }
             if (my_j < nc) ccounts[(my_j * nqt + qt) * 2 + wn] = my_cnt;
-        });
+        };
+    auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
+    const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
+    if constexpr (BF16) tile_pipeline_bf16(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
-        if (qi[tn] < nq) qcounts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
+        if (qi[tn] < nq) qcounts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) / ES);
 }
 
 constexpr int kMeanRegs = 16;                 // list values per lane: lists of up to 1,024 survivors
@@ -1833,9 +1844,17 @@ __device__ __forceinline__ float wave_topk_mean(float (&c)[kMeanRegs], int k, in
 }
 
 // one wave per query row: its survivors sit in nseg segments of `cap`
+// BF16: the entries are pairs (v~, index); with t~ = the k-th largest v~ every entry that can belong to the exact top k has
+// v~ >= t~ - 2 tol (|t - t~| <= tol for the exact k-th value t); those -- k plus a few, at most 64 -- are recomputed with the exact
+// k-ordered chain (row `row` of a against row `index` of b), and the mean is the sum of the k largest of THEM in descending
+// order: row_topk_mean_kernel's arithmetic on row_topk_mean_kernel's values.  The band has to lie inside the list
+// (t~ - 2 tol >= thr - tol, the sweep's cut); otherwise the row fails over to the strip fallback like an overflowed one.
+template <bool BF16>
 __global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__restrict__ lists, const int32_t *__restrict__ counts,
                                                              int nseg, int cap, int64_t n_rows, int k, float *__restrict__ out,
-                                                             int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail) {
+                                                             int32_t *__restrict__ fail_rows, int32_t *__restrict__ n_fail,
+                                                             const float *__restrict__ a, int lda, const float *__restrict__ b, int ldb,
+                                                             int dim, const float *__restrict__ thr, const float *__restrict__ tol_ptr) {
     __shared__ int s_off[4][kMeanSeg + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
@@ -1878,22 +1897,96 @@ __global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__rest
         return;
     }
     float c[kMeanRegs];
-    const float *base = lists + row * nseg * (int64_t)cap;
+    uint32_t id[BF16 ? kMeanRegs : 1];
+    const float *base = lists + row * nseg * (int64_t)cap * (BF16 ? 2 : 1);
 #pragma unroll
     for (int u = 0; u < kMeanRegs; ++u) {
         const int i = u * 64 + lane;
         c[u] = -INFINITY;
+        if (BF16) id[u] = 0u;
         if (i < total) {
             int lo = 0, hi = nseg;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (off[mid] <= i) lo = mid; else hi = mid;
             }
-            c[u] = base[(int64_t)lo * cap + (i - off[lo])];
+            if constexpr (BF16) {
+                const uint2 pr = reinterpret_cast<const uint2 *>(base)[(int64_t)lo * cap + (i - off[lo])];
+                c[u] = __uint_as_float(pr.x);
+                id[u] = pr.y;
+            } else {
+                c[u] = base[(int64_t)lo * cap + (i - off[lo])];
+            }
         }
     }
-    const float res = wave_topk_mean(c, k, lane);
-    if (lane == 0) out[row] = res;
+    if constexpr (!BF16) {
+        const float res = wave_topk_mean(c, k, lane);
+        if (lane == 0) out[row] = res;
+    } else {
+        const float tol = *tol_ptr;
+        float tk = INFINITY;                                   // t~: the k-th largest approximate value (k rounds of wave maximum)
+        {
+            float cc[kMeanRegs];
+#pragma unroll
+            for (int u = 0; u < kMeanRegs; ++u) cc[u] = c[u];
+            for (int round = 0; round < k; ++round) {
+                float h = cc[0];
+#pragma unroll
+                for (int u = 1; u < kMeanRegs; ++u) h = fmaxf(h, cc[u]);
+                float m = h;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const unsigned long long bal = __ballot(h == m);
+                if (lane == __ffsll((long long)bal) - 1) {
+                    bool done = false;
+#pragma unroll
+                    for (int u = 0; u < kMeanRegs; ++u)
+                        if (!done && cc[u] == m) { cc[u] = -INFINITY; done = true; }
+                }
+                tk = m;
+            }
+        }
+        const float lo2 = tk - 2.0f * tol;
+        int *cand = off;                                        // the offsets are dead: 64 candidate indices per wave
+        int ncand = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < kMeanRegs; ++u) {
+            const bool in = c[u] >= lo2;
+            const unsigned long long bal = __ballot(in);
+            const int at = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+            if (in && at < 64) cand[at] = (int)id[u];
+            ncand += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (ncand > 64 || lo2 < thr[row] - tol) {
+            if (lane == 0) fail_rows[atomicAdd(n_fail, 1)] = (int32_t)row;
+            return;
+        }
+        float e = -INFINITY;
+        if (lane < ncand) {
+            const float *__restrict__ x = a + row * lda, *__restrict__ y = b + (int64_t)cand[lane] * ldb;
+            float acc = 0.f;
+            int kk = 0;
+            for (; kk + 4 <= dim; kk += 4) {
+                const float4 xv = oea::ld4(x + kk), yv = oea::ld4(y + kk);
+                acc = fmaf(xv.x, yv.x, acc); acc = fmaf(xv.y, yv.y, acc); acc = fmaf(xv.z, yv.z, acc); acc = fmaf(xv.w, yv.w, acc);
+            }
+            for (; kk < dim; ++kk) acc = fmaf(x[kk], y[kk], acc);
+            e = acc;
+        }
+        float acc = 0.f;
+        for (int round = 0; round < k; ++round) {
+            float m = e;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const unsigned long long bal = __ballot(e == m);
+            if (lane == __ffsll((long long)bal) - 1) e = -INFINITY;
+            acc += m;
+        }
+        if (lane == 0) out[row] = acc / (float)k;
+    }
 }
 
 // failed rows beyond the bulk path (adversarial inputs): the row by the k-ordered fmaf chain into scratch, then the exact mean
@@ -1983,7 +2076,8 @@ struct PackSlot {
     hipStream_t last = nullptr;
     hipEvent_t used = nullptr;
 };
-static PackSlot g_slot[4];       // 0 = queries, 1 = candidates, 2 / 3 = column / row samples (neighbour search, CSLS means)
+static PackSlot g_slot[6];       // 0 = queries, 1 = candidates, 2 / 3 = column / row samples (neighbour search, CSLS means),
+                                 // 3 also = the bf16 split rows of the neighbour search, 4 / 5 = the bf16 split operands of the CSLS means
 
 static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedOp *out, int64_t *n_pad_out);
 
@@ -2021,7 +2115,7 @@ static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedO
 }
 // after the kernels that read the packed operands have been enqueued
 static int release_packed(hipStream_t st) {
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
         if (g_slot[i].used && g_slot[i].last == st) OEA_CHECK_HIP(hipEventRecord(g_slot[i].used, st));
     return OEA_OK;
 }
@@ -2402,6 +2496,12 @@ __global__ void knn_tol_kernel(float *tol, float eps_rel) {
     tol[0] = 1.05f * eps_rel * smax + 1.0e-6f * smax + 1e-30f;
 }
 
+// tol[0] = bound on |v~ - v| of the CSLS means' bf16 sweep from tol[1], tol[2] = bits of the max row norms of the two tables
+__global__ void csls_tol_kernel(float *tol, float eps_rel) {
+    const float smax = tol[1] * tol[2];
+    tol[0] = 1.05f * eps_rel * smax + 1.0e-6f * smax + 1e-30f;
+}
+
 struct CslsPlan {
     bool ok = false;
     int sample = 0, r1 = 0, r2 = 0, cap = 0, ccap = 0, chunks = 0, nseg = 0, tpc = 0, nqt = 0;
@@ -2430,7 +2530,7 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     const double ms = m1 / p.nseg, mc = m2 / (2 * p.nqt);        // column lists: one segment per (query tile, wave column)
     p.cap = ((int)(ms * (1.0 + 5.0 / std::sqrt((double)p.r1)) + 8.0 * std::sqrt(ms) + 16.0) + 7) / 8 * 8;
     p.ccap = ((int)(mc * (1.0 + 5.0 / std::sqrt((double)p.r2)) + 8.0 * std::sqrt(mc) + 8.0) + 3) / 4 * 4;
-    if ((size_t)128 * p.nseg * p.cap * 4 >= ((size_t)1 << 31)) return p;
+    if ((size_t)128 * p.nseg * p.cap * 8 >= ((size_t)1 << 32)) return p;
     p.ld1 = (n1 + 31) / 32 * 32;
     p.ld2 = (n2 + 31) / 32 * 32;
     size_t off = 0;
@@ -2438,8 +2538,8 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     p.off_thr1 = take(4 * (size_t)n1); p.off_thr2 = take(4 * (size_t)n2);
     p.off_qcnt = take(4 * (size_t)n1 * p.nseg); p.off_ccnt = take(4 * (size_t)n2 * 2 * p.nqt);
     p.off_fail1 = take(4 * (size_t)n1); p.off_fail2 = take(4 * (size_t)n2); p.off_nfail = take(256);
-    p.off_qlists = take(4 * (size_t)n1 * p.nseg * p.cap);
-    p.off_clists = take(4 * (size_t)n2 * 2 * p.nqt * p.ccap);
+    p.off_qlists = take(8 * (size_t)n1 * p.nseg * p.cap);             // 8 B per entry: (value, index) pairs under the bf16 sweep
+    p.off_clists = take(8 * (size_t)n2 * 2 * p.nqt * p.ccap);
     // sample strips; the fallback strip [kCslsFb, max ld] reuses the space after the thresholds are taken
     p.off_strip = take(4 * std::max<size_t>((size_t)std::max(n1, n2) * p.sample, (size_t)kCslsFb * std::max(p.ld1, p.ld2)));
     p.off_fbq = take(4 * (size_t)kCslsFb * 4096);
@@ -2949,10 +3049,36 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     if (rc != OEA_OK) return rc;
     // every (candidate, query tile) count is written by the sweep when chunks cover all candidate tiles -- they do
     OEA_CHECK_HIP(hipMemsetAsync(nfail, 0, 256, st));
-    csls_append_kernel<true><<<dim3((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks), 256, 0, st>>>(
-        p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt);
-    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail);
-    list_mean_rows_kernel<<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2, nfail + 1);
+    // from 3e8 pairs on the sweep multiplies the bf16 hi / lo split (3/16 of the fp32 matrix time, see the prefilter section);
+    // the means are still those of the exact values (list_mean_rows_kernel<true>).  OEA_CSLS_BF16=0 keeps the fp32 sweep.
+    // (both read per call: the tests move the limit)
+    const char *env_on = getenv("OEA_CSLS_BF16"), *env_min = getenv("OEA_CSLS_BF16_MIN_PAIRS");
+    const bool bf16_on = !(env_on && env_on[0] == '0');
+    const double bf16_min = env_min ? atof(env_min) : 3e8;
+    const dim3 grid((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks);
+    if (bf16_on && (double)n1 * (double)n2 >= bf16_min) {
+        float *tol = reinterpret_cast<float *>(nfail + 16);                // [0] the bound, [1] / [2] max row norms (zeroed above)
+        PackedOp b1, b2;
+        rc = pack_operand_bf16(4, e1, n1, ld1, dim, st, &b1);
+        if (rc == OEA_OK) rc = pack_operand_bf16(5, e2, n2, ld2, dim, st, &b2);
+        if (rc != OEA_OK) return rc;
+        row_norm_max_kernel<<<(unsigned)oea::ceil_div(n1, 256), 256, 0, st>>>(e1, n1, ld1, dim, reinterpret_cast<unsigned *>(tol) + 1);
+        row_norm_max_kernel<<<(unsigned)oea::ceil_div(n2, 256), 256, 0, st>>>(e2, n2, ld2, dim, reinterpret_cast<unsigned *>(tol) + 2);
+        csls_tol_kernel<<<1, 1, 0, st>>>(tol, bf16_eps_rel(dim));
+        csls_append_kernel<true, true><<<grid, 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt,
+                                                              clists, ccnt, tol);
+        list_mean_rows_kernel<true><<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail,
+                                                                                    e1, ld1, e2, ld2, dim, thr1, tol);
+        list_mean_rows_kernel<true><<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2,
+                                                                                    nfail + 1, e2, ld2, e1, ld1, dim, thr2, tol);
+    } else {
+        csls_append_kernel<true, false><<<grid, 256, 0, st>>>(p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt,
+                                                               clists, ccnt, nullptr);
+        list_mean_rows_kernel<false><<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail,
+                                                                                     nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
+        list_mean_rows_kernel<false><<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2,
+                                                                                     nfail + 1, nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
+    }
     // fallbacks (normally empty): bulk for the first kCslsFb failed rows / columns, slow kernel for the rest
     oea::gather_packed_rows(p1.p, kp, fail1, nfail, fbq, st);
     sim_inner_store_kernel<true><<<dim3((unsigned)oea::ceil_div(n2, TILE), 1), 256, 0, st>>>(fbq, kCslsFb, kp, p2.p, n2, kp, dim, strip, p.ld2, nfail);

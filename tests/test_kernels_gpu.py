@@ -1064,10 +1064,14 @@ def test_topk_strip_free_path_bit_exact(ops, case, monkeypatch):
     assert np.array_equal(out[rows], ref * 3 + 1)
 
 
-@pytest.mark.parametrize("case", ["random", "duplicates", "constant"])
-def test_csls_means_one_sweep_bit_exact(ops, case):
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("case", ["random", "duplicates", "constant", "unnormalised"])
+def test_csls_means_one_sweep_bit_exact(ops, case, bf16, monkeypatch):
     """oea_csls_means (thresholded one-sweep lists + fallbacks) == row_topk_mean over the strips of S and S^T, bit for
-    bit, also when duplicate rows overflow lists or a constant matrix sends every row through the fallbacks."""
+    bit, also when duplicate rows overflow lists or a constant matrix sends every row through the fallbacks.  bf16: the sweep
+    multiplies the hi / lo split (the product path from 3e8 pairs on; forced here), the lists hold approximate values with the
+    index of the other side and the means are taken over the exact chains of the entries that can belong to the top k."""
+    monkeypatch.setenv("OEA_CSLS_BF16_MIN_PAIRS", "1" if bf16 else "1e30")
     rng = np.random.RandomState(21)
     n1, n2, d, k = (10500, 10500, 75, 10) if case == "random" else (4300, 4700, 32, 10)
     e1 = rng.standard_normal((n1, d)).astype(np.float32)
@@ -1080,6 +1084,9 @@ def test_csls_means_one_sweep_bit_exact(ops, case):
         e2[:] = e2[0]
     e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
     e2 /= np.linalg.norm(e2, axis=1, keepdims=True)
+    if case == "unnormalised":
+        e1 = (e1 * rng.uniform(0.2, 3.0, (n1, 1))).astype(np.float32)
+        e2 = (e2 * rng.uniform(0.2, 3.0, (n2, 1))).astype(np.float32)
     t1, t2 = ops.to_table(e1), ops.to_table(e2)
     got = ops.csls_means(t1, t2, d, k)
     assert got is not None

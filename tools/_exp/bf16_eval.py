@@ -84,7 +84,8 @@ for n, d, reps in ((10500, 75, 30), (70000, 100, 4), (70000, 300, 3)):
         ms16 = wall(lambda: ops.rank_eval_metrics_bf16(t1, t2, d, TOPK, stats=st), reps)
         a = ops.rank_eval_metrics(t1, t2, d, TOPK)
         b = ops.rank_eval_metrics_bf16(t1, t2, d, TOPK)
-        same = b is not None and bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) and a[2:] == b[2:]
+        same = (b is not None and bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) and a[2:4] == b[2:4]
+                and abs(a[4] - b[4]) <= 1e-9 * abs(a[4]))            # (the reciprocal-rank sum is a double reduced in another order)
         print("eval %6d^2 x %3d, %-17s: fp32 %.3f ms, bf16 prefilter %.3f ms (%.2fx), records %d (%.1f per row), fallback %s, identical incl. metrics %s" %
               (n, d, mode, ms32, ms16, ms32 / ms16, st["records"], st["records"] / n, st["fallback"], same), flush=True)
 
@@ -94,9 +95,17 @@ for n, d, reps in ((10500, 75, 20), (70000, 100, 3)):
     e1 = unit(rng.standard_normal((n, d)))
     e2 = unit(e1 + 0.4 * rng.standard_normal((n, d)) / np.sqrt(d))
     t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    os.environ["OEA_CSLS_BF16"] = "0"
     r, c = csls_means_device(t1, t2, d, "inner", 10)
-    st = {}
     ms_means = wall(lambda: csls_means_device(t1, t2, d, "inner", 10), reps)
+    os.environ["OEA_CSLS_BF16"] = "1"
+    os.environ["OEA_CSLS_BF16_MIN_PAIRS"] = "1"
+    rb, cb = csls_means_device(t1, t2, d, "inner", 10)
+    ms_means16 = wall(lambda: csls_means_device(t1, t2, d, "inner", 10), reps)
+    del os.environ["OEA_CSLS_BF16_MIN_PAIRS"]
+    print("CSLS %6d^2 x %3d: means fp32 sweep %.3f ms, bf16 sweep %.3f ms (%.2fx), identical %s" %
+          (n, d, ms_means, ms_means16, ms_means / ms_means16, bool(torch.equal(r, rb) and torch.equal(c, cb))), flush=True)
+    st = {}
     ms32 = wall(lambda: ops.rank_eval_metrics(t1, t2, d, TOPK, r, c), reps)
     ms16 = wall(lambda: ops.rank_eval_metrics_bf16(t1, t2, d, TOPK, stats=st, csls_r=r, csls_c=c), reps)
     a = ops.rank_eval_metrics(t1, t2, d, TOPK, r, c)
