@@ -841,6 +841,122 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
         if (qi[tn] < n) counts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
 }
 
+// ---- stream form of the symmetric neighbour sweep (round 4) ------------------------------------------------------------------
+// The append kernel above gives every (query, segment) and every (candidate, query tile) its own little list: 4-byte stores to
+// ~64 different lines per instruction and ~28 vector instructions per accumulator element.  Here every WAVE owns two
+// append-only streams of 8-byte records (value bits, tag): survivors of the query side (v~ >= cut of the query; tag = local
+// query row << 24 | candidate) and of the candidate side (v~ >= cut of the candidate; tag = local candidate row << 24 |
+// query), slots = stream position + prefix of a ballot -- full-line stores, no per-lane bookkeeping.  The candidate stream's
+// position at every tile boundary is kept (col_off), so that the records aimed at one candidate tile can be found again:
+// topk_bucket_kernel (topk.hip) deals the records of one target tile to its 128 rows' compact lists, list_select_kernel selects
+// from those.  A stream that fills up marks the rows it may have lost (row_fail): they go to the strip fallback.
+template <bool INTERIOR>
+__device__ __forceinline__ void stream_tile(const f32x16 (&acc)[2][2], int c0, int jl0, int n, const float (&th)[2], const uint32_t (&rtag)[2],
+                                            const uint32_t (&qidx)[2], float my_tc, int lane, char *__restrict__ rs, uint32_t rbytes,
+                                            char *__restrict__ cs, uint32_t cbytes, uint32_t &rpos, uint32_t &cpos) {
+    // positions and capacities in BYTES (32-bit offsets from wave-uniform bases: one shift per record, no 64-bit address math)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = jl0 + tm * 32 + (r & 3) + 8 * (r >> 2);
+            const int j = c0 + jl;
+            const float tc = __shfl(my_tc, (lane & 32) + tm * 16 + r, 64);
+            const uint32_t ctag = (uint32_t)jl << 24;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float v = acc[tm][tn][r];
+                const bool pr = INTERIOR ? v >= th[tn] : (v >= th[tn] && j < n);
+                unsigned long long m = __ballot(pr);
+                if (pr) {
+                    const uint32_t at = rpos + 8u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (at < rbytes) *reinterpret_cast<uint2 *>(rs + at) = make_uint2(__float_as_uint(v), rtag[tn] | (uint32_t)j);
+                }
+                rpos += 8u * (uint32_t)__popcll(m);
+                const bool pc = v >= tc;                          // tc = +inf on the diagonal, past the last row; th-side rows past n never match
+                m = __ballot(pc);
+                if (pc) {
+                    const uint32_t at = cpos + 8u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (at < cbytes) *reinterpret_cast<uint2 *>(cs + at) = make_uint2(__float_as_uint(v), ctag | qidx[tn]);
+                }
+                cpos += 8u * (uint32_t)__popcll(m);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
+    const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
+    uint2 *__restrict__ row_streams, int rcap, uint2 *__restrict__ col_streams, int ccap, int32_t *__restrict__ row_cnt,
+    int32_t *__restrict__ col_off, int lp1, uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
+    const int qt = item.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t q0 = (int64_t)qt * TILE;
+    const size_t wid = (size_t)blockIdx.x * 4 + wave;
+    char *__restrict__ rs = reinterpret_cast<char *>(row_streams + wid * rcap);
+    char *__restrict__ cs = reinterpret_cast<char *>(col_streams + wid * ccap);
+    int32_t *__restrict__ coff = col_off + wid * lp1;
+    const uint32_t rbytes = 8u * (uint32_t)rcap, cbytes = 8u * (uint32_t)ccap;
+    const float tol = *tol_ptr;
+    float th[2];
+    uint32_t rtag[2], qidx[2];
+    int64_t qi[2];
+    bool q_in = true;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int ql = wn * 64 + tn * 32 + l32;
+        qi[tn] = q0 + ql;
+        q_in = q_in && qi[tn] < n;
+        th[tn] = qi[tn] < n ? thr[qi[tn]] - tol : INFINITY;
+        rtag[tn] = (uint32_t)ql << 24;
+        qidx[tn] = (uint32_t)qi[tn];
+    }
+    const bool q_all = __ballot(!q_in) == 0ull;                    // every query row of this wave exists (else: candidate side per lane)
+    const int jl0 = wm * 64 + 4 * half;
+    const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
+    uint32_t rpos = 0, cpos = 0;                                   // wave-uniform, bytes
+    auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
+        const int ct = item.y + (int)t;
+        const int64_t c0 = (int64_t)ct * TILE;
+        const bool offdiag = ct != qt;                               // workgroup-uniform
+        const int64_t my_j = c0 + my_jl;
+        // the candidate-side cut is +inf where nothing may be recorded: on the diagonal, past the last candidate row, and (ragged
+        // last query tile) in a wave with missing query rows -- those rows' own similarities are zero vectors' (0 >= cut only if
+        // cut <= 0; such waves take the cut of the lanes that exist, and th = +inf keeps their query side silent)
+        float my_tc = (offdiag && my_j < n) ? thr[my_j] - tol : INFINITY;
+        if (lane == 0) coff[t] = (int32_t)(cpos >> 3);
+        if (!q_all) {                                                // ragged query tile: the rows past n must not reach candidate lists
+            // (rare: one tile row) fall back to masking the accumulators of the missing queries
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        if (qi[tn] >= n) acc[tm][tn][r] = -INFINITY;
+        }
+        if (c0 + TILE <= n) stream_tile<true>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
+        else stream_tile<false>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
+        if (cpos > cbytes && offdiag && my_j < n) row_fail[my_j] = 1;   // records of this tile (or a later one) were dropped
+    };
+    const int64_t n_tiles = (int64_t)(item.z - item.y);
+    tile_pipeline_bf16(e, kp, e, dim, q0, n_tiles, [=](int64_t t) { return (int64_t)(item.y + t) * TILE; }, As, Bs, epilogue);
+    if (lane == 0) {
+        coff[n_tiles] = (int32_t)(cpos >> 3);
+        row_cnt[wid] = (int32_t)(min(rpos, rbytes) >> 3);
+    }
+    if (rpos > rbytes) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+            if (qi[tn] < n) row_fail[qi[tn]] = 1;
+    }
+}
+
 __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best_key, int64_t n1,
                                      int32_t *__restrict__ argmax) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2588,6 +2704,21 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
                                                                            cap, list_vals, list_cols, counts, T, ccap,
                                                                            static_cast<uint2 *>(clists), ccounts, spill_cnt,
                                                                            static_cast<uint2 *>(spill), sp_cap, nullptr);
+}
+// stream form (topk_stream_sym_kernel): rows split and packed into slot 3, the bound into tol_dev[0], one launch
+int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, void *row_streams,
+                         int rcap, void *col_streams, int ccap, int32_t *row_cnt, int32_t *col_off, int lp1, uint8_t *row_fail,
+                         float *tol_dev, hipStream_t st) {
+    PackedOp op;
+    const int rc = pack_operand_bf16(3, src, n, ld, dim, st, &op);
+    if (rc != OEA_OK) return rc;
+    OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
+    row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
+    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
+    topk_stream_sym_kernel<<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),
+                                                              static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), ccap,
+                                                              row_cnt, col_off, lp1, row_fail, tol_dev);
+    return OEA_OK;
 }
 // the same sweep on the hi / lo split rows of `src` (packed here into slot 3); tol_dev[0] receives the bound on |v~ - v|
 // (max row norm^2 x eps(dim), computed on the device) that the sweep cuts by and the select resolves with

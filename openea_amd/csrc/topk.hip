@@ -813,6 +813,7 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
     if (lane == 0) thr[row] = ord2f(prefix);
 }
 
+constexpr int kStreamMaxT = 1024;             // target tiles: <= 131,072 rows (the slice table is (64 + 4 T) * 8 B of LDS)
 constexpr int kPerThread = 24;            // list entries a thread keeps in registers: lists of up to 6,144 survivors
 constexpr int kBitWords = 8192;           // bitmap of selected columns in (dynamic) LDS: nc <= 262,144
 
@@ -829,7 +830,11 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    int T, int ccap, const int32_t *__restrict__ spill_cnt,
                                                                    const uint2 *__restrict__ spill, int stop_after,
                                                                    const float *__restrict__ exact_src, int ld_src, int dim,
-                                                                   const float *__restrict__ tol_ptr) {
+                                                                   const float *__restrict__ tol_ptr,
+                                                                   const uint2 *__restrict__ compact, const int32_t *__restrict__ compact_cnt,
+                                                                   int compact_cap, const uint8_t *__restrict__ row_fail) {
+    // compact != NULL: the row's survivors are ONE list of compact_cnt[row] (value, column) pairs (topk_bucket_kernel); rows a
+    // full stream or a full list may have lost entries of (row_fail) go to the strip fallback
     // tol_ptr != NULL: the list values are APPROXIMATE (v~ of the bf16 sweep, |v~ - v| <= tol = *tol_ptr) and the lists hold every
     // pair with v~ >= thr - tol.  With t~ = the k-th largest v~ (found exactly as before) the exact k-th value t is within tol
     // of t~, so  v~ > t~ + 2 tol  =>  v > t: selected;   v~ < t~ - 2 tol  =>  v < t: not selected;  the band in between (a dozen
@@ -858,8 +863,14 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     constexpr int kSegPer = (kMaxSegAll + SEL_THREADS - 1) / SEL_THREADS;
     int seg_c[kSegPer];
     int mine = 0;
+    if (compact) {
+        const int c = compact_cnt[row];
+        if (tid == 0 && row_fail[row]) s_bad = 1;
+        mine = tid == 0 ? c : 0;
+    }
 #pragma unroll
     for (int u = 0; u < kSegPer; ++u) {
+        if (compact) { seg_c[u] = 0; continue; }
         const int sg = tid * kSegPer + u;
         int c = 0;
         if (sg < nseg) {
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     // gather was 2.3 ms of the select's 4.7 at 100,000 rows).  The table lives in the bitmap's storage, which is zeroed after
     // the gather.
     uint16_t *owner = reinterpret_cast<uint16_t *>(bitmap);
-    if (total_all <= kPerThread * SEL_THREADS) {
+    if (!compact && total_all <= kPerThread * SEL_THREADS) {
         int at = run;                                            // == s_off[tid * kSegPer + kSegPer] after the loop above
 #pragma unroll
         for (int u = kSegPer - 1; u >= 0; --u) {
@@ -899,7 +910,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
         }
     }
     __syncthreads();
-    const int total = s_off[nst];
+    const int total = compact ? total_all : s_off[nst];
     bool fail = s_bad != 0;                                      // block-uniform from here on
     if (stop_after == 1) return;
     if (!fail) {
@@ -913,7 +924,12 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
             const int i = tid + e * SEL_THREADS;
             val[e] = -INFINITY;
             col[e] = -1;
-            if (i < total) {
+            if (i < total && compact) {
+                const uint2 pr = compact[row * compact_cap + i];
+                val[e] = __uint_as_float(pr.x);
+                col[e] = (int)pr.y;
+                mx = fmaxf(mx, val[e]);
+            } else if (i < total) {
                 // (round 3, measured and dropped: consecutive positions per thread with one binary search + a forward walk
                 //  instead of a binary search per position -- 4.41 -> 5.02 ms: the strided assignment keeps a wave's loads in
                 //  neighbouring entries of the same segments)
@@ -1021,6 +1037,16 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                         const float *__restrict__ b = exact_src + (int64_t)c_col[i] * ld_src;
                         float acc = 0.f;
                         int kk = 0;
+                        for (; kk + 32 <= dim; kk += 32) {                    // 16 loads in flight, then the chain in k order
+                            float4 x[8], y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { x[u] = oea::ld4(a + kk + 4 * u); y[u] = oea::ld4(b + kk + 4 * u); }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                acc = fmaf(x[u].x, y[u].x, acc); acc = fmaf(x[u].y, y[u].y, acc);
+                                acc = fmaf(x[u].z, y[u].z, acc); acc = fmaf(x[u].w, y[u].w, acc);
+                            }
+                        }
                         for (; kk + 4 <= dim; kk += 4) {
                             const float4 x = oea::ld4(a + kk), y = oea::ld4(b + kk);
                             acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
@@ -1249,6 +1275,62 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
     return p;
 }
 
+struct StreamPlan {
+    bool ok = false;
+    int r = 0, T = 0, L = 0, groups = 0, n_items = 0, rcap = 0, ccap = 0, row_cap = 0;
+    int64_t stride = 0, ld = 0;
+    size_t off_thr = 0, off_fail = 0, off_nfail = 0, off_items = 0, off_rcnt = 0, off_coff = 0, off_lcnt = 0, off_rowfail = 0, off_strip = 0,
+           off_rstream = 0, off_cstream = 0, off_lists = 0, stream_bytes = 0, total = 0;
+};
+
+// the stream form of the symmetric search (bf16 sweep only): same thresholds and work items as plan_sym
+static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
+    StreamPlan p;
+    static const bool on = [] { const char *e = getenv("OEA_TOPK_STREAM"); return !(e && e[0] == '0'); }();
+    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
+    if (!on || n < min_n) return p;
+    const double e = (double)k * kSample / (double)n;
+    p.r = threshold_rank(e);
+    const double frac = (double)p.r / kSample;
+    const double m_total = frac * (double)n;
+    if (p.r >= kSample / 2 || m_total * 1.4 > kPerThread * SEL_THREADS || n > (int64_t)kBitWords * 32) return p;
+    p.T = (int)oea::ceil_div(n, 128);
+    if (p.T > kStreamMaxT) return p;
+    p.groups = 16;
+    p.L = std::max(8, (int)oea::ceil_div(p.T, p.groups));
+    p.groups = (int)oea::ceil_div(p.T, p.L);
+    // records per wave and side: L tiles of 64 x 64 pairs; the thresholds' common noise averages over the wave's 64 rows
+    const double ew = frac * p.L * 4096.0;
+    p.rcap = p.ccap = ((int)(ew * 1.25 + 8.0 * std::sqrt(ew) + 256.0) + 63) / 64 * 64;
+    p.row_cap = std::min(kPerThread * SEL_THREADS,
+                         ((int)(m_total * (1.0 + 4.0 / std::sqrt((double)p.r)) + 8.0 * std::sqrt(m_total) + 64.0) + 7) / 8 * 8);
+    int64_t items = 0;
+    for (int c = 0; c < p.groups; ++c) items += std::min(p.T, (c + 1) * p.L);
+    p.n_items = (int)items;
+    if ((size_t)items * 4 * (size_t)p.rcap >= ((size_t)1 << 32)) return p;            // record indices are 32-bit
+    p.stride = n / kSample;
+    p.ld = (n + 31) / 32 * 32;
+    auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += a256(bytes); return o; };
+    p.off_thr = take(sizeof(float) * (size_t)n);
+    p.off_fail = take(sizeof(int32_t) * (size_t)n);
+    p.off_nfail = take(256);
+    p.off_items = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
+    p.off_rcnt = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
+    p.off_coff = take(sizeof(int32_t) * 4 * (size_t)p.n_items * (p.L + 1));
+    p.off_lcnt = take(sizeof(int32_t) * (size_t)n);
+    p.off_rowfail = take((size_t)n);
+    p.off_strip = take(sizeof(float) * (size_t)n * kSample);
+    p.stream_bytes = 8 * (size_t)p.n_items * 4 * (size_t)p.rcap;
+    p.off_rstream = take(p.stream_bytes);
+    p.off_cstream = take(p.stream_bytes);
+    p.off_lists = take(8 * (size_t)p.T * 128 * (size_t)p.row_cap);
+    p.total = off;
+    p.ok = off <= ws_bytes;
+    return p;
+}
+
 // long rows with k well inside the LDS candidate lists take the one-read kernel
 static void launch_select(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int k, const int32_t *id_map, int32_t *out,
                           hipStream_t st) {
@@ -1293,6 +1375,171 @@ __global__ void sym_items_kernel(int T, int L, int chunks, int4 *__restrict__ it
     int base = 0;
     for (int h = 0; h < c; ++h) base += min(T, (h + 1) * L);
     items[base + qt] = make_int4(qt, max(qt, c * L), min(T, (c + 1) * L), c - qt / L);
+}
+
+// ---- stream form of the symmetric search (bf16 sweep): the records of one target tile -> its 128 rows' compact lists -----------
+// topk_stream_sym_kernel (sim_rank.hip) leaves, per wave of every work item, a stream of query-side records (targets: the 128
+// rows of the item's query tile) and a stream of candidate-side records whose position at every candidate-tile boundary is
+// known (col_off).  One workgroup per target tile tau collects its records: the whole query-side streams of the items (tau, c),
+// c >= tau / L, and from every item (qt <= tau, c = tau / L) the slice of the candidate-side streams written while it was on
+// candidate tile tau.  The slices (a few thousand, ~100 records each) are laid end to end through a prefix table in LDS, every
+// thread walks the concatenation with a stride of the workgroup (its slice index only moves forward), and a record goes to slot
+// atomicAdd(LDS counter of its target row) of that row's compact list -- (value, other index) pairs in no particular order: the
+// select (histogram + bitmap) needs none.
+
+__device__ __forceinline__ int sym_item_base(int T, int L, int c) {
+    int b = 0;
+    for (int h = 0; h < c; ++h) b += min(T, (h + 1) * L);
+    return b;
+}
+
+constexpr int kBucketThreads = 512, kBucketFlight = 8;         // 4,096 records in flight per workgroup, four workgroups per CU: the pass is
+                                                               // HBM latency; every target tile's workgroup resident at once up to 1,024 tiles
+
+__global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int L, int groups, int64_t n, const uint2 *__restrict__ row_streams, int rcap,
+                                                          const int32_t *__restrict__ row_cnt, const uint2 *__restrict__ col_streams,
+                                                          int ccap, const int32_t *__restrict__ col_off, int lp1,
+                                                          uint2 *__restrict__ lists, int row_cap, int32_t *__restrict__ counts,
+                                                          uint8_t *__restrict__ row_fail) {
+    extern __shared__ uint32_t seg_tab[];                    // prefix[nseg + 1] | src[nseg]
+    __shared__ int cnt[128], hist[128], loff[129], gbase[128];
+    __shared__ int s_part[kBucketThreads / 64];
+    const int tau = blockIdx.x, tid = threadIdx.x;
+    const int c0 = tau / L;
+    const int nrow = (groups - c0) * 4, ncol = (tau + 1) * 4, nseg = nrow + ncol;
+    uint32_t *prefix = seg_tab, *src = seg_tab + (64 + 4 * T + 1);
+    if (tid < 128) { cnt[tid] = 0; hist[tid] = 0; }
+    const int base_c0 = sym_item_base(T, L, c0);
+    const int per = (nseg + kBucketThreads - 1) / kBucketThreads;
+    int mine = 0;
+    for (int u = 0; u < per; ++u) {
+        const int sg = tid * per + u;
+        if (sg >= nseg) break;
+        uint32_t start;
+        int len;
+        if (sg < nrow) {                                     // query-side stream of item (tau, c0 + sg / 4), wave sg % 4: all of it
+            const int c = c0 + (sg >> 2);
+            const size_t wid = (size_t)(sym_item_base(T, L, c) + tau) * 4 + (sg & 3);
+            start = (uint32_t)(wid * rcap);
+            len = row_cnt[wid];
+        } else {                                             // candidate-side stream of item (qt, c0), wave: the slice of tile tau
+            const int qt = (sg - nrow) >> 2;
+            const size_t wid = (size_t)(base_c0 + qt) * 4 + ((sg - nrow) & 3);
+            const int ti = tau - max(qt, c0 * L);
+            const int o0 = min(col_off[wid * lp1 + ti], ccap), o1 = min(col_off[wid * lp1 + ti + 1], ccap);
+            start = (uint32_t)(wid * ccap) + (uint32_t)o0;
+            len = o1 - o0;
+        }
+        src[sg] = start;
+        prefix[sg + 1] = (uint32_t)len;
+        mine += len;
+    }
+    int total, run;
+    {   // exclusive scan over the workgroup's 16 waves
+        const int lane = tid & 63, wv = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        total = 0;
+        for (int w = 0; w < kBucketThreads / 64; ++w) {
+            if (w < wv) base += s_part[w];
+            total += s_part[w];
+        }
+        run = base + incl - mine;
+    }
+    for (int u = 0; u < per; ++u) {
+        const int sg = tid * per + u;
+        if (sg >= nseg) break;
+        run += (int)prefix[sg + 1];
+        prefix[sg + 1] = (uint32_t)run;
+    }
+    if (tid == 0) prefix[0] = 0u;
+    __syncthreads();
+    uint2 *__restrict__ out = lists + (size_t)tau * 128 * row_cap;
+    // every wave takes a contiguous sixteenth of the concatenation, its lanes consecutive records (512 B per load instruction);
+    // the slice index of a lane then moves forward by less than one slice per step
+    const uint32_t per_wave = ((uint32_t)total + kBucketThreads / 64 - 1) / (kBucketThreads / 64);
+    const uint32_t w_begin = (uint32_t)(tid >> 6) * per_wave, w_end = min(w_begin + per_wave, (uint32_t)total);
+    int sg = 0;
+    {
+        int lo = 0, hi = nseg;                               // prefix[lo] <= w_begin < prefix[hi] (when the range is not empty)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= w_begin) lo = mid; else hi = mid;
+        }
+        sg = lo;
+    }
+    // Rounds of kBucketFlight * kBucketThreads records: a returning LDS atomic ranks every record inside its target row's bucket
+    // of the round, the records are laid out bucket by bucket in LDS and leave in that order -- a row's records of the round
+    // (~30) go to consecutive slots of its list: runs of ~256 B instead of 8-byte stores to 128 different lines (which the L2
+    // evicted half-written: 2.4 ms for this pass against 0.9 now at 100,000 rows).
+    uint2 *sorted = reinterpret_cast<uint2 *>(seg_tab + 2 * (64 + 4 * T) + 2);
+    const uint32_t n_rounds = (per_wave + kBucketFlight * 64 - 1) / (kBucketFlight * 64);
+    for (uint32_t round = 0; round < n_rounds; ++round) {
+        const uint32_t g0 = w_begin + (tid & 63) + round * (kBucketFlight * 64);
+        uint2 rec[kBucketFlight];
+        int rk[kBucketFlight];
+#pragma unroll
+        for (int u = 0; u < kBucketFlight; ++u) {
+            const uint32_t g = g0 + u * 64;
+            rec[u] = make_uint2(0u, 0xFFFFFFFFu);
+            if (g < w_end) {
+                while (prefix[sg + 1] <= g) ++sg;
+                const uint32_t idx = src[sg] + (g - prefix[sg]);
+                rec[u] = sg < nrow ? row_streams[idx] : col_streams[idx];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBucketFlight; ++u)
+            if (g0 + u * 64 < w_end) rk[u] = atomicAdd(&hist[rec[u].y >> 24], 1);
+        __syncthreads();
+        if (tid < 64) {                                      // one wave: offsets of the 128 buckets inside the round, their list slots
+            const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+            int incl = h0 + h1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            const int excl = incl - h0 - h1;
+            loff[2 * tid] = excl;
+            loff[2 * tid + 1] = excl + h0;
+            if (tid == 63) loff[128] = incl;
+            gbase[2 * tid] = cnt[2 * tid];
+            gbase[2 * tid + 1] = cnt[2 * tid + 1];
+            cnt[2 * tid] += h0;
+            cnt[2 * tid + 1] += h1;
+            hist[2 * tid] = 0;
+            hist[2 * tid + 1] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBucketFlight; ++u)
+            if (g0 + u * 64 < w_end) sorted[loff[rec[u].y >> 24] + rk[u]] = rec[u];
+        __syncthreads();
+        const int n_round = loff[128];
+        for (int i = tid; i < n_round; i += kBucketThreads) {
+            const uint2 r = sorted[i];
+            const int t = (int)(r.y >> 24);
+            const int slot = gbase[t] + (i - loff[t]);
+            if (slot < row_cap) out[(size_t)t * row_cap + slot] = make_uint2(r.x, r.y & 0xFFFFFFu);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int64_t row = (int64_t)tau * 128 + tid;
+        if (row < n) {
+            counts[row] = min(cnt[tid], row_cap);
+            if (cnt[tid] > row_cap) row_fail[row] = 1;
+        }
+    }
 }
 
 // ---- rows the list select gave up on: redone through the strip path, in batches -------------------------------------------
@@ -1380,7 +1627,8 @@ size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
 
 size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k) {
     const SymPlan p = plan_sym(n, k, ~(size_t)0);
-    return p.ok ? p.total : 0;
+    const StreamPlan q = plan_stream(n, k, ~(size_t)0);
+    return std::max(p.ok ? p.total : (size_t)0, q.ok ? q.total : (size_t)0);
 }
 
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,
@@ -1420,6 +1668,52 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
     static const bool lists_on = [] { const char *e = getenv("OEA_TOPK_LISTS"); return !(e && e[0] == '0'); }();
     static const bool sym_on = [] { const char *e = getenv("OEA_TOPK_SYM"); return !(e && e[0] == '0'); }();
     const bool same = q == c && nq == nc && ldq == ldc;
+    static const bool bf16_sweep = [] { const char *e = getenv("OEA_TOPK_BF16"); return !(e && e[0] == '0'); }();
+    const StreamPlan sp = (same && packed && lists_on && sym_on && bf16_sweep && dim <= 2048) ? plan_stream(nc, k, ws_bytes) : StreamPlan();
+    if (sp.ok) {                                    // stream form: wave-private record streams -> per-tile bucketing -> compact lists
+        char *w = static_cast<char *>(workspace);
+        float *thr = reinterpret_cast<float *>(w + sp.off_thr);
+        int32_t *fail_rows = reinterpret_cast<int32_t *>(w + sp.off_fail);
+        int32_t *n_fail = reinterpret_cast<int32_t *>(w + sp.off_nfail);
+        float *tol_dev = reinterpret_cast<float *>(w + sp.off_nfail + 64);
+        int32_t *items_dev = reinterpret_cast<int32_t *>(w + sp.off_items);
+        int32_t *row_cnt = reinterpret_cast<int32_t *>(w + sp.off_rcnt);
+        int32_t *col_off = reinterpret_cast<int32_t *>(w + sp.off_coff);
+        int32_t *list_cnt = reinterpret_cast<int32_t *>(w + sp.off_lcnt);
+        uint8_t *row_fail = reinterpret_cast<uint8_t *>(w + sp.off_rowfail);
+        float *sstrip = reinterpret_cast<float *>(w + sp.off_strip);
+        uint2 *lists = reinterpret_cast<uint2 *>(w + sp.off_lists);
+        OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
+        sym_items_kernel<<<(unsigned)oea::ceil_div((int64_t)sp.groups * sp.T, 256), 256, 0, st>>>(sp.T, sp.L, sp.groups,
+                                                                                              reinterpret_cast<int4 *>(items_dev));
+        float *smp = nullptr;
+        int kps = 0;
+        int rc = oea::pack_rows(2, c, kSample, ldc * (int)sp.stride, dim, st, &smp, &kps);
+        if (rc != OEA_OK) return rc;
+        oea::sim_inner_store_packed(qp, nq, smp, kSample, kp, dim, sstrip, kSample, st);
+        kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(nq, 4), 256, 0, st>>>(sstrip, nq, kSample, sp.r, thr);
+        OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
+        OEA_CHECK_HIP(hipMemsetAsync(row_fail, 0, (size_t)nq, st));
+        rc = oea::topk_stream_sym_bf16(c, nc, ldc, dim, thr, items_dev, sp.n_items, w + sp.off_rstream, sp.rcap, w + sp.off_cstream, sp.ccap,
+                                       row_cnt, col_off, sp.L + 1, row_fail, tol_dev, st);
+        if (rc != OEA_OK) return rc;
+        const size_t bucket_lds = sizeof(uint32_t) * (2 * (64 + 4 * (size_t)sp.T) + 2) + 8 * (size_t)kBucketFlight * kBucketThreads;
+        static const hipError_t bucket_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_bucket_kernel),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 1024 * (4 + kBucketFlight * kBucketThreads / 1024) + 1024);
+        OEA_CHECK_HIP(bucket_attr);
+        topk_bucket_kernel<<<(unsigned)sp.T, kBucketThreads, bucket_lds, st>>>(
+            sp.T, sp.L, sp.groups, nq, reinterpret_cast<const uint2 *>(w + sp.off_rstream), sp.rcap, row_cnt,
+            reinterpret_cast<const uint2 *>(w + sp.off_cstream), sp.ccap, col_off, sp.L + 1, lists, sp.row_cap, list_cnt, row_fail);
+        list_select_kernel<<<(unsigned)nq, SEL_THREADS, select_lds_bytes(nc), st>>>(
+            nullptr, nullptr, nullptr, thr, 0, 0, nc, k, id_map, out_idx, fail_rows, n_fail, nullptr, nullptr, 0, 0, nullptr, nullptr,
+            select_stop(), c, ldc, dim, tol_dev, lists, list_cnt, sp.row_cap, row_fail);
+        rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, w + sp.off_rstream, 2 * sp.stream_bytes, sp.ld, st);
+        if (rc != OEA_OK) return rc;
+        rc = oea::release_packed_rows(st);
+        if (rc != OEA_OK) return rc;
+        OEA_CHECK_HIP(hipGetLastError());
+        return OEA_OK;
+    }
     const SymPlan sy = (same && packed && lists_on && sym_on && dim <= 2048) ? plan_sym(nc, k, ws_bytes) : SymPlan();
     if (sy.ok) {                                    // queries == candidates: the upper triangle's tiles feed rows and columns
         char *w = static_cast<char *>(workspace);
@@ -1465,7 +1759,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         list_select_kernel<<<(unsigned)nq, SEL_THREADS, select_lds_bytes(nc), st>>>(
             list_vals, list_cols, counts, thr, sy.nseg, sy.cap, nc, k, id_map, out_idx, fail_rows, n_fail,
             static_cast<const uint2 *>(clists), ccounts, 2 * sy.T, sy.ccap, spill_cnt, static_cast<const uint2 *>(spill), select_stop(),
-            c, ldc, dim, bf16_on ? tol_dev : nullptr);
+            c, ldc, dim, bf16_on ? tol_dev : nullptr, nullptr, nullptr, 0, nullptr);
         rc = redo_failed_rows(qp, kp, cp, nc, dim, k, id_map, out_idx, fail_rows, n_fail, clists,
                               8 * (size_t)nq * sy.T * 2 * sy.ccap, sy.ld, st);
         if (rc != OEA_OK) return rc;
@@ -1504,7 +1798,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
                                                                       spill_cnt, static_cast<const uint2 *>(spill), select_stop(),
-                                                                      nullptr, 0, 0, nullptr);
+                                                                      nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr);
             // rows the select gave up on: through the strip path, in batches, inside the (now dead) list storage
             rc = redo_failed_rows(qp + r0 * kp, kp, cp, nc, dim, k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, list_vals,
                                   2 * lp.cols_off, lp.ld, st);
