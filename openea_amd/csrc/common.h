@@ -62,7 +62,8 @@ int topk_append_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
 
 int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, void *row_streams,
                          int rcap, void *col_streams, int ccap, int32_t *row_cnt, int32_t *col_off, int lp1, uint8_t *row_fail,
-                         float *tol_dev, hipStream_t st);
+                         float *tol_dev, void *ovf_pool, int32_t *ovf_alloc, int32_t *ovf_len, int ovf_chunks, int32_t *redo_cnt,
+                         void *redo, int redo_cap, hipStream_t st);
 int comm_phase_mark(struct ::oea_comm *c, hipStream_t st);      // comm.hip: phase boundary of the one-call partitioned epoch
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

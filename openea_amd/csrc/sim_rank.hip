@@ -849,7 +849,70 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
 // query), slots = stream position + prefix of a ballot -- full-line stores, no per-lane bookkeeping.  The candidate stream's
 // position at every tile boundary is kept (col_off), so that the records aimed at one candidate tile can be found again:
 // topk_bucket_kernel (topk.hip) deals the records of one target tile to its 128 rows' compact lists, list_select_kernel selects
-// from those.  A stream that fills up marks the rows it may have lost (row_fail): they go to the strip fallback.
+// from those.  Trained tables crowd a row's neighbours into few candidate ranges, so some waves see several times the average
+// number of records.  A wave whose stream is full only notes (work item, tile, wave, positions at the tile's start) in a redo
+// list; topk_stream_redo_kernel computes those tiles again and puts the records that did not fit (stream_ovf_tile: same ballots,
+// same positions), as self-describing 16-byte records (value, target row, other index), into 512-record chunks taken from a
+// shared pool with one atomic per chunk; topk_overflow_kernel (topk.hip) appends them to the compact lists after the bucketing.
+// (Handling the overflow inside the sweep -- a second pass over the accumulators -- cost the sweep 1.2 ms of spills and code size
+// on tables that never overflow.)  Only a pool or redo list that runs dry marks rows as lost (row_fail): strip fallback.
+constexpr int kOvfChunk = 512;                       // records per overflow chunk
+
+struct OvfState {                                    // per wave (wave-uniform)
+    uint4 *__restrict__ pool;
+    int32_t *__restrict__ alloc, *__restrict__ len;
+    uint8_t *__restrict__ row_fail;
+    uint32_t cap_chunks, chunk, used;
+};
+
+__device__ __forceinline__ void ovf_append(OvfState &o, bool over, float v, uint32_t target, uint32_t other, int lane) {
+    const unsigned long long om = __ballot(over);
+    if (om == 0ull) return;                          // wave-uniform
+    const uint32_t cnt = (uint32_t)__popcll(om);
+    if (o.used + cnt > (uint32_t)kOvfChunk) {
+        if (o.chunk < o.cap_chunks && lane == 0) o.len[o.chunk] = (int32_t)o.used;
+        uint32_t idx = 0;
+        if (lane == 0) idx = (uint32_t)atomicAdd(o.alloc, 1);
+        o.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        o.used = 0;
+    }
+    if (over) {
+        const uint32_t slot = o.used + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+        if (o.chunk < o.cap_chunks) o.pool[(size_t)o.chunk * kOvfChunk + slot] = make_uint4(__float_as_uint(v), target, other, 0u);
+        else o.row_fail[target] = 1;                 // the pool ran dry: this row goes to the strip fallback
+    }
+    o.used += cnt;
+}
+
+// second pass over a tile whose records did not all fit: identical predicates and positions, only the overflow is written
+template <bool INTERIOR>
+__device__ __forceinline__ void stream_ovf_tile(const f32x16 (&acc)[2][2], int c0, int jl0, int n, const float (&th)[2], const uint32_t (&qidx)[2],
+                                                float my_tc, int lane, uint32_t rbytes, uint32_t cbytes, uint32_t rpos, uint32_t cpos,
+                                                OvfState &o) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = c0 + jl0 + tm * 32 + (r & 3) + 8 * (r >> 2);
+            const float tc = __shfl(my_tc, (lane & 32) + tm * 16 + r, 64);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float v = acc[tm][tn][r];
+                const bool pr = INTERIOR ? v >= th[tn] : (v >= th[tn] && j < n);
+                unsigned long long m = __ballot(pr);
+                uint32_t at = rpos + 8u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                ovf_append(o, pr && at >= rbytes, v, qidx[tn], (uint32_t)j, lane);
+                rpos += 8u * (uint32_t)__popcll(m);
+                const bool pc = v >= tc;
+                m = __ballot(pc);
+                at = cpos + 8u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                ovf_append(o, pc && at >= cbytes, v, (uint32_t)j, qidx[tn], lane);
+                cpos += 8u * (uint32_t)__popcll(m);
+            }
+        }
+    }
+}
+
 template <bool INTERIOR>
 __device__ __forceinline__ void stream_tile(const f32x16 (&acc)[2][2], int c0, int jl0, int n, const float (&th)[2], const uint32_t (&rtag)[2],
                                             const uint32_t (&qidx)[2], float my_tc, int lane, char *__restrict__ rs, uint32_t rbytes,
@@ -888,7 +951,8 @@ __device__ __forceinline__ void stream_tile(const f32x16 (&acc)[2][2], int c0, i
 __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     uint2 *__restrict__ row_streams, int rcap, uint2 *__restrict__ col_streams, int ccap, int32_t *__restrict__ row_cnt,
-    int32_t *__restrict__ col_off, int lp1, uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr) {
+    int32_t *__restrict__ col_off, int lp1, uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr,
+    int32_t *__restrict__ redo_cnt, int4 *__restrict__ redo, int redo_cap) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
@@ -925,13 +989,11 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
         const int64_t c0 = (int64_t)ct * TILE;
         const bool offdiag = ct != qt;                               // workgroup-uniform
         const int64_t my_j = c0 + my_jl;
-        // the candidate-side cut is +inf where nothing may be recorded: on the diagonal, past the last candidate row, and (ragged
-        // last query tile) in a wave with missing query rows -- those rows' own similarities are zero vectors' (0 >= cut only if
-        // cut <= 0; such waves take the cut of the lanes that exist, and th = +inf keeps their query side silent)
-        float my_tc = (offdiag && my_j < n) ? thr[my_j] - tol : INFINITY;
+        // the candidate-side cut is +inf where nothing may be recorded: on the diagonal and past the last candidate row
+        const float my_tc = (offdiag && my_j < n) ? thr[my_j] - tol : INFINITY;
         if (lane == 0) coff[t] = (int32_t)(cpos >> 3);
-        if (!q_all) {                                                // ragged query tile: the rows past n must not reach candidate lists
-            // (rare: one tile row) fall back to masking the accumulators of the missing queries
+        if (!q_all) {                                                // ragged last query tile: the (zero) rows past n must not reach
+                                                                     // the candidate lists: their accumulators become -inf
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -940,9 +1002,26 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
                     for (int tn = 0; tn < 2; ++tn)
                         if (qi[tn] >= n) acc[tm][tn][r] = -INFINITY;
         }
+        const uint32_t r0 = rpos, p0 = cpos;
         if (c0 + TILE <= n) stream_tile<true>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
         else stream_tile<false>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
-        if (cpos > cbytes && offdiag && my_j < n) row_fail[my_j] = 1;   // records of this tile (or a later one) were dropped
+        if (rpos > rbytes || cpos > cbytes) {                        // wave-uniform, rare: records of this tile did not fit
+            int slot = 0;
+            if (lane == 0) {
+                slot = atomicAdd(redo_cnt, 1);
+                if (slot < redo_cap) {
+                    redo[2 * (size_t)slot] = make_int4((int)blockIdx.x, (int)t, wave, 0);
+                    redo[2 * (size_t)slot + 1] = make_int4((int)r0, (int)p0, 0, 0);
+                }
+            }
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= redo_cap) {                                  // (never, in practice) the rows this wave may have lost
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    if (qi[tn] < n) row_fail[qi[tn]] = 1;
+                if (offdiag && my_j < n) row_fail[my_j] = 1;
+            }
+        }
     };
     const int64_t n_tiles = (int64_t)(item.z - item.y);
     tile_pipeline_bf16(e, kp, e, dim, q0, n_tiles, [=](int64_t t) { return (int64_t)(item.y + t) * TILE; }, As, Bs, epilogue);
@@ -950,11 +1029,55 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
         coff[n_tiles] = (int32_t)(cpos >> 3);
         row_cnt[wid] = (int32_t)(min(rpos, rbytes) >> 3);
     }
-    if (rpos > rbytes) {
+}
+
+// the tiles of the redo list, again: only the recorded wave writes, and only what did not fit its streams
+__global__ __launch_bounds__(256, 2) void topk_stream_redo_kernel(
+    const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items, int rcap, int ccap,
+    uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr, const int32_t *__restrict__ redo_cnt, const int4 *__restrict__ redo,
+    int redo_cap, uint4 *__restrict__ ovf_pool, int32_t *__restrict__ ovf_alloc, int32_t *__restrict__ ovf_len, int ovf_chunks) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    const int n_redo = min(*redo_cnt, redo_cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l32 = lane & 31;
+    const uint32_t rbytes = 8u * (uint32_t)rcap, cbytes = 8u * (uint32_t)ccap;
+    const float tol = *tol_ptr;
+    OvfState ovf{ovf_pool, ovf_alloc, ovf_len, row_fail, (uint32_t)ovf_chunks, 0xFFFFFFFFu, (uint32_t)kOvfChunk};
+    const int jl0 = wm * 64 + 4 * half;
+    const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
+    for (int idx = blockIdx.x; idx < n_redo; idx += gridDim.x) {
+        const int4 ent = redo[2 * (size_t)idx], pos = redo[2 * (size_t)idx + 1];
+        const int4 item = items[ent.x];
+        const int qt = item.x, ct = item.y + ent.y;
+        const int64_t q0 = (int64_t)qt * TILE, c0 = (int64_t)ct * TILE;
+        float th[2];
+        uint32_t qidx[2];
+        int64_t qi[2];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-            if (qi[tn] < n) row_fail[qi[tn]] = 1;
+        for (int tn = 0; tn < 2; ++tn) {
+            qi[tn] = q0 + wn * 64 + tn * 32 + l32;
+            th[tn] = qi[tn] < n ? thr[qi[tn]] - tol : INFINITY;
+            qidx[tn] = (uint32_t)qi[tn];
+        }
+        const int64_t my_j = c0 + my_jl;
+        const float my_tc = (ct != qt && my_j < n) ? thr[my_j] - tol : INFINITY;
+        tile_pipeline_bf16(e, kp, e, dim, q0, 1, [=](int64_t) { return c0; }, As, Bs, [&](int64_t, f32x16 (&acc)[2][2]) {
+            if (wave != ent.z) return;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        if (qi[tn] >= n) acc[tm][tn][r] = -INFINITY;
+            if (c0 + TILE <= n) stream_ovf_tile<true>(acc, (int)c0, jl0, (int)n, th, qidx, my_tc, lane, rbytes, cbytes, (uint32_t)pos.x, (uint32_t)pos.y, ovf);
+            else stream_ovf_tile<false>(acc, (int)c0, jl0, (int)n, th, qidx, my_tc, lane, rbytes, cbytes, (uint32_t)pos.x, (uint32_t)pos.y, ovf);
+        });
+        __syncthreads();                                             // the LDS buffers are staged again by the next entry
     }
+    if (lane == 0 && ovf.chunk < ovf.cap_chunks) ovf_len[ovf.chunk] = (int32_t)ovf.used;
 }
 
 __global__ void rank_finalize_kernel(const unsigned long long *__restrict__ best_key, int64_t n1,
@@ -2708,7 +2831,8 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
 // stream form (topk_stream_sym_kernel): rows split and packed into slot 3, the bound into tol_dev[0], one launch
 int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, void *row_streams,
                          int rcap, void *col_streams, int ccap, int32_t *row_cnt, int32_t *col_off, int lp1, uint8_t *row_fail,
-                         float *tol_dev, hipStream_t st) {
+                         float *tol_dev, void *ovf_pool, int32_t *ovf_alloc, int32_t *ovf_len, int ovf_chunks, int32_t *redo_cnt,
+                         void *redo, int redo_cap, hipStream_t st) {
     PackedOp op;
     const int rc = pack_operand_bf16(3, src, n, ld, dim, st, &op);
     if (rc != OEA_OK) return rc;
@@ -2717,7 +2841,11 @@ int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
     topk_stream_sym_kernel<<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),
                                                               static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), ccap,
-                                                              row_cnt, col_off, lp1, row_fail, tol_dev);
+                                                              row_cnt, col_off, lp1, row_fail, tol_dev, redo_cnt, static_cast<int4 *>(redo),
+                                                              redo_cap);
+    topk_stream_redo_kernel<<<2048, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items), rcap, ccap, row_fail, tol_dev,
+                                                  redo_cnt, static_cast<const int4 *>(redo), redo_cap, static_cast<uint4 *>(ovf_pool), ovf_alloc,
+                                                  ovf_len, ovf_chunks);
     return OEA_OK;
 }
 // the same sweep on the hi / lo split rows of `src` (packed here into slot 3); tol_dev[0] receives the bound on |v~ - v|

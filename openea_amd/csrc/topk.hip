@@ -814,6 +814,7 @@ __global__ __launch_bounds__(256) void kth_value_kernel(const float *__restrict_
 }
 
 constexpr int kStreamMaxT = 1024;             // target tiles: <= 131,072 rows (the slice table is (64 + 4 T) * 8 B of LDS)
+constexpr int kOvfChunkRecs = 512;            // == kOvfChunk (sim_rank.hip)
 constexpr int kPerThread = 24;            // list entries a thread keeps in registers: lists of up to 6,144 survivors
 constexpr int kBitWords = 8192;           // bitmap of selected columns in (dynamic) LDS: nc <= 262,144
 
@@ -1277,10 +1278,11 @@ static SymPlan plan_sym(int64_t n, int k, size_t ws_bytes) {
 
 struct StreamPlan {
     bool ok = false;
-    int r = 0, T = 0, L = 0, groups = 0, n_items = 0, rcap = 0, ccap = 0, row_cap = 0;
+    int r = 0, T = 0, L = 0, groups = 0, n_items = 0, rcap = 0, ccap = 0, row_cap = 0, ovf_chunks = 0;
     int64_t stride = 0, ld = 0;
     size_t off_thr = 0, off_fail = 0, off_nfail = 0, off_items = 0, off_rcnt = 0, off_coff = 0, off_lcnt = 0, off_rowfail = 0, off_strip = 0,
-           off_rstream = 0, off_cstream = 0, off_lists = 0, stream_bytes = 0, total = 0;
+           off_rstream = 0, off_cstream = 0, off_lists = 0, off_ovf = 0, off_ovflen = 0, off_redo = 0, stream_bytes = 0, total = 0;
+    int redo_cap = 0;
 };
 
 // the stream form of the symmetric search (bf16 sweep only): same thresholds and work items as plan_sym
@@ -1326,6 +1328,12 @@ static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     p.off_rstream = take(p.stream_bytes);
     p.off_cstream = take(p.stream_bytes);
     p.off_lists = take(8 * (size_t)p.T * 128 * (size_t)p.row_cap);
+    // overflow pool: 40 % of the expected records (both sides) + a chunk per wave
+    p.ovf_chunks = (int)std::min<double>(0.4 * 2.0 * ew * 4.0 * (double)items / kOvfChunkRecs + 4.0 * (double)items, 4.0e6);
+    p.off_ovf = take(16 * (size_t)kOvfChunkRecs * (size_t)p.ovf_chunks);
+    p.off_ovflen = take(sizeof(int32_t) * (size_t)p.ovf_chunks);
+    p.redo_cap = (int)std::min<int64_t>(items * 4 * p.L, 1 << 22);     // (work item, tile, wave) triples: all of them, up to 4 M
+    p.off_redo = take(32 * (size_t)p.redo_cap);
     p.total = off;
     p.ok = off <= ws_bytes;
     return p;
@@ -1542,6 +1550,24 @@ __global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int 
     }
 }
 
+// records that did not fit their wave's stream (16 B: value, target row, other index; chunks of kOvfChunk from the shared pool):
+// appended to the compact lists behind the bucketed records, one returning atomic on the row's count each
+__global__ __launch_bounds__(256) void topk_overflow_kernel(const uint4 *__restrict__ pool, const int32_t *__restrict__ alloc,
+                                                            const int32_t *__restrict__ len, int cap_chunks, uint2 *__restrict__ lists,
+                                                            int row_cap, int32_t *__restrict__ counts, uint8_t *__restrict__ row_fail) {
+    const int n_chunks = min(*alloc, cap_chunks);
+    const int lane = threadIdx.x & 63;
+    for (int ch = blockIdx.x * 4 + (threadIdx.x >> 6); ch < n_chunks; ch += gridDim.x * 4) {
+        const int l = min(len[ch], kOvfChunkRecs);
+        for (int i = lane; i < l; i += 64) {
+            const uint4 rec = pool[(size_t)ch * kOvfChunkRecs + i];
+            const int slot = atomicAdd(counts + rec.y, 1);
+            if (slot < row_cap) lists[(size_t)rec.y * row_cap + slot] = make_uint2(rec.x, rec.z);
+            else row_fail[rec.y] = 1;
+        }
+    }
+}
+
 // ---- rows the list select gave up on: redone through the strip path, in batches -------------------------------------------
 // (overflowed segments -- trained embeddings cluster: a row's neighbours crowd into a few candidate ranges -- fewer than k
 // survivors, tie-heavy rows.)  The survivor lists are dead once list_select_kernel has run, so their storage holds the
@@ -1692,10 +1718,13 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         if (rc != OEA_OK) return rc;
         oea::sim_inner_store_packed(qp, nq, smp, kSample, kp, dim, sstrip, kSample, st);
         kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(nq, 4), 256, 0, st>>>(sstrip, nq, kSample, sp.r, thr);
-        OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
+        int32_t *ovf_alloc = reinterpret_cast<int32_t *>(w + sp.off_nfail + 128);
+        int32_t *ovf_len = reinterpret_cast<int32_t *>(w + sp.off_ovflen);
+        OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, 256, st));           // failure count, tolerance block, overflow chunk count
         OEA_CHECK_HIP(hipMemsetAsync(row_fail, 0, (size_t)nq, st));
         rc = oea::topk_stream_sym_bf16(c, nc, ldc, dim, thr, items_dev, sp.n_items, w + sp.off_rstream, sp.rcap, w + sp.off_cstream, sp.ccap,
-                                       row_cnt, col_off, sp.L + 1, row_fail, tol_dev, st);
+                                       row_cnt, col_off, sp.L + 1, row_fail, tol_dev, w + sp.off_ovf, ovf_alloc, ovf_len, sp.ovf_chunks,
+                                       ovf_alloc + 1, w + sp.off_redo, sp.redo_cap, st);
         if (rc != OEA_OK) return rc;
         const size_t bucket_lds = sizeof(uint32_t) * (2 * (64 + 4 * (size_t)sp.T) + 2) + 8 * (size_t)kBucketFlight * kBucketThreads;
         static const hipError_t bucket_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_bucket_kernel),
@@ -1704,6 +1733,17 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         topk_bucket_kernel<<<(unsigned)sp.T, kBucketThreads, bucket_lds, st>>>(
             sp.T, sp.L, sp.groups, nq, reinterpret_cast<const uint2 *>(w + sp.off_rstream), sp.rcap, row_cnt,
             reinterpret_cast<const uint2 *>(w + sp.off_cstream), sp.ccap, col_off, sp.L + 1, lists, sp.row_cap, list_cnt, row_fail);
+        topk_overflow_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4 *>(w + sp.off_ovf), ovf_alloc, ovf_len, sp.ovf_chunks, lists,
+                                                   sp.row_cap, list_cnt, row_fail);
+        static const bool dbg_ovf = getenv("OEA_TOPK_DEBUG") != nullptr;
+        if (dbg_ovf) {
+            int32_t na = 0;
+            OEA_CHECK_HIP(hipMemcpyAsync(&na, ovf_alloc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            OEA_CHECK_HIP(hipStreamSynchronize(st));
+            int32_t nr = 0;
+            OEA_CHECK_HIP(hipMemcpy(&nr, ovf_alloc + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[oea_topk_inner] overflow chunks: %d of %d, redone wave tiles: %d of %d\n", na, sp.ovf_chunks, nr, sp.redo_cap);
+        }
         list_select_kernel<<<(unsigned)nq, SEL_THREADS, select_lds_bytes(nc), st>>>(
             nullptr, nullptr, nullptr, thr, 0, 0, nc, k, id_map, out_idx, fail_rows, n_fail, nullptr, nullptr, 0, 0, nullptr, nullptr,
             select_stop(), c, ldc, dim, tol_dev, lists, list_cnt, sp.row_cap, row_fail);
