@@ -666,7 +666,9 @@ def extra_legs(torch, ops, ent, kgs, d, k1):
     out["eval_inner_mfma_frac"] = round(2.0 * n1 * n1 * dd * out["eval_pairs_per_s_inner_fp32_sweep"] / n1 / 157.3e12, 4)
     out["neighbour_mfma_frac"] = round(2.0 * nn * nn * dd * out["neighbour_rows_per_s"] / nn / 157.3e12, 4)
     out["mfma_frac_note"] = ("2*N1*N2*d flop of the full similarity matrix / wall time of the whole call / 157.3 TFLOP/s fp32 MFMA peak; "
-                             "eval_inner_mfma_frac is the exact fp32 sweep's (OEA_EVAL_BF16=0), the neighbour search has no bf16 path")
+                             "eval_inner_mfma_frac is the exact fp32 sweep's (OEA_EVAL_BF16=0); the symmetric neighbour search (>= 32,768 rows) sweeps on "
+                             "the bf16 split (3 bf16 products per exact product), so its fraction of the FP32 peak can exceed what the fp32 "
+                             "pipe could deliver")
     return out
 
 
