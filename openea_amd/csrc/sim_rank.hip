@@ -379,13 +379,115 @@ __device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am,
             stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
         }
         mma_chunk_bf16(As + cur * BUF, Bs + cur * BUF, min(2, S - 2 * kc), acc);
-        __syncthreads();
+        // the epilogue works on registers only: it runs BEFORE the barrier (and the vmcnt(0) in front of it), so the DMA of the
+        // next tile's first chunk lands behind it instead of being waited for first (the bf16 chunks are too short to hide it)
         if (++kc == nchunk) {
             epilogue(t, acc);
             zero_acc(acc);
             kc = 0;
             ++t;
         }
+        __syncthreads();
+    }
+}
+
+// B IN REGISTERS (round 4, Kp = 32 NCH <= 128).  tile_pipeline_bf16 stages a 16 KB chunk of BOTH operands per iteration and waits for
+// it at the next barrier: with the matrix part of a chunk down to ~700 cycles the L2 / fabric latency of the chunk (~2 us) is what
+// an iteration takes -- the bf16 pipeline alone ran at 15 % of the matrix pipe.  The B tile of a work item never changes: here every
+// lane loads its B fragments of ALL k-steps once, straight from the packed rows into registers (32 NCH VGPRs), the LDS holds only A
+// stages, and a stage is TWO chunks (32 KB): half the barriers and exposed latencies per tile, half the LDS reads, no B re-reads.
+// As: 2 slots x 2 chunks x (128 x 32) floats = 64 KB.
+template <int NCH>
+struct BRegs {
+    bf16x8 h[2 * NCH][2], l[2 * NCH][2];             // [k-step][row block tn]: hi and lo fragments of this lane
+};
+
+template <int NCH>
+__device__ __forceinline__ void load_bregs(const float *__restrict__ bn, int kp, int64_t n0, BRegs<NCH> &b) {
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int wn = wave & 1, half = lane >> 5;
+    const float *row = bn + (n0 + wn * 64 + (lane & 31)) * kp + half * 8;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float *p = row + (int64_t)tn * 32 * kp + c * 32 + s2 * 16;     // granules ((s2 * 2 + half) * 2 + {0, 1}) of chunk c
+                b.h[2 * c + s2][tn] = *reinterpret_cast<const bf16x8 *>(p);
+                b.l[2 * c + s2][tn] = *reinterpret_cast<const bf16x8 *>(p + 4);
+            }
+}
+
+// acc += the three split products of chunk c (two k-steps): A fragments from the staged chunk, B fragments from registers
+template <int NCH>
+__device__ __forceinline__ void mma_chunk_breg(const float *__restrict__ As, const BRegs<NCH> &b, int c, f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int wm = wave >> 1;
+    const int x = (lane >> 1) & 7, half = lane >> 5;
+    const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int g = 4 * s2 + 2 * half;
+        const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
+        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
+        const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
+        const bf16x8 b0h = b.h[2 * c + s2][0], b0l = b.l[2 * c + s2][0], b1h = b.h[2 * c + s2][1], b1l = b.l[2 * c + s2][1];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+    }
+}
+
+template <int NCH, class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_bf16_breg(const float *__restrict__ am, int kp, const float *__restrict__ bn, int64_t n0,
+                                                        int64_t n_tiles, MTile m_tile, float *As, Epilogue epilogue) {
+    constexpr int BUF = TILE * PLD;                                   // one chunk
+    constexpr int NS = (NCH + 1) / 2;                                 // stages per tile: chunks [2 s, min(2 s + 2, NCH))
+    const int64_t total = n_tiles * NS;
+    if (total == 0) return;
+    BRegs<NCH> b;
+    load_bregs<NCH>(bn, kp, n0, b);
+    auto stage = [&](int64_t t, int s, float *slot) {
+        stage_packed(am, kp, m_tile(t), (2 * s) * BK, slot);
+        if (2 * s + 1 < NCH) stage_packed(am, kp, m_tile(t), (2 * s + 1) * BK, slot + BUF);
+    };
+    stage(0, 0, As);
+    __syncthreads();
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    int64_t t = 0;
+    int sidx = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        float *cur = As + (it & 1) * 2 * BUF, *nxt = As + ((it & 1) ^ 1) * 2 * BUF;
+        if (it + 1 < total) {
+            int s1 = sidx + 1;
+            int64_t t1 = t;
+            if (s1 == NS) { s1 = 0; ++t1; }
+            stage(t1, s1, nxt);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)                                 // (compile-time chunk indices for the register file)
+            if (s == sidx) {
+                mma_chunk_breg<NCH>(cur, b, 2 * s, acc);
+                if (2 * s + 1 < NCH) mma_chunk_breg<NCH>(cur + BUF, b, 2 * s + 1, acc);
+            }
+        if (++sidx == NS) {                                          // before the barrier: see tile_pipeline_bf16
+            epilogue(t, acc);
+            zero_acc(acc);
+            sidx = 0;
+            ++t;
+        }
+        __syncthreads();
     }
 }
 
@@ -948,13 +1050,15 @@ __device__ __forceinline__ void stream_tile(const f32x16 (&acc)[2][2], int c0, i
     }
 }
 
+// NCH = Kp / 32 in {1..4}: the query tile's operand in registers (tile_pipeline_bf16_breg); 0: both operands through LDS
+template <int NCH>
 __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     uint2 *__restrict__ row_streams, int rcap, uint2 *__restrict__ col_streams, int ccap, int32_t *__restrict__ row_cnt,
     int32_t *__restrict__ col_off, int lp1, uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr,
     int32_t *__restrict__ redo_cnt, int4 *__restrict__ redo, int redo_cap) {
-    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD];
+    float *As = lds, *Bs = lds + 2 * TILE * LDS_LD;
     const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
     const int qt = item.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1024,7 +1128,9 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
         }
     };
     const int64_t n_tiles = (int64_t)(item.z - item.y);
-    tile_pipeline_bf16(e, kp, e, dim, q0, n_tiles, [=](int64_t t) { return (int64_t)(item.y + t) * TILE; }, As, Bs, epilogue);
+    auto m_tile = [=](int64_t t) { return (int64_t)(item.y + t) * TILE; };
+    if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(e, kp, e, q0, n_tiles, m_tile, As, epilogue);
+    else tile_pipeline_bf16(e, kp, e, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     if (lane == 0) {
         coff[n_tiles] = (int32_t)(cpos >> 3);
         row_cnt[wid] = (int32_t)(min(rpos, rbytes) >> 3);
@@ -1962,15 +2068,15 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
 // BF16 (round 4): q / c are the hi / lo split rows, the values v~ are within *tol_ptr of the exact ones, both cuts are lowered
 // by that bound and every list entry is a PAIR (v~, index of the other side) -- list_mean_rows_kernel<true> finds the entries that
 // can belong to the exact top k and recomputes them with the exact chain.
-template <bool PACKED, bool BF16>
+template <bool PACKED, bool BF16, int NCH = 0>
 __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
     float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts,
     const float *__restrict__ tol_ptr) {
     constexpr uint32_t ES = BF16 ? 8u : 4u;                 // bytes per list entry
-    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD];
+    float *As = lds, *Bs = lds + 2 * TILE * LDS_LD;
     // candidate j owns 2 * nqt segments of ccap values: one per (query tile, wave column) -- written by ONE wave, whose
     // half-waves hold the same candidate for 32 queries each: slots = prefix counts of a wave ballot (no atomics, no barrier;
     // the first version took a returning LDS atomic per survivor between two barriers per tile)
@@ -2049,7 +2155,8 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
         };
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (BF16) tile_pipeline_bf16(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (BF16) tile_pipeline_bf16(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -2449,14 +2556,14 @@ __device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const f
     }
 }
 
-template <bool WARM, bool CSLS>
-__global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
+// NCH = 0: both operands through LDS (tile_pipeline_bf16, any Kp); NCH = Kp / 32 in {1..4}: B in registers (tile_pipeline_bf16_breg)
+template <bool WARM, bool CSLS, int NCH>
+__device__ __forceinline__ void rank_bf16_body(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
     const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,
     const float *__restrict__ csls_c, int tiles_per_chunk, int64_t gold_off,
-    int32_t *__restrict__ rank, unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap) {
-    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    int32_t *__restrict__ rank, unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap,
+    float *As, float *Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t q0 = (int64_t)blockIdx.x * TILE;
@@ -2492,10 +2599,7 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
         if (pred && at < slice_cap) my_rec[at] = make_uint2((uint32_t)qi[tn], (uint32_t)j | kind);
         nrec += (unsigned)__popcll(m);
     };
-    tile_pipeline_bf16(
-        cp, kp, qp, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
-        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
-        [&](int64_t t, f32x16 (&acc)[2][2]) {
+    auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * TILE;
             const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
 #pragma unroll
@@ -2509,7 +2613,11 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
                 if (dirty[tn]) { atomicMax(lbrow + qi[tn], f2ord(lb[tn])); dirty[tn] = false; }
-        });
+        };
+    auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
+    const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
+    if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
+    else tile_pipeline_bf16(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (WARM) {
@@ -2525,6 +2633,26 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(
         if (nrec) atomicAdd(rec_cnt, nrec);                   // total (statistics)
         if (nrec > slice_cap) atomicMax(rec_cnt + 1, 1u);     // overflow: the caller falls back to the fp32 sweep
     }
+}
+
+#define OEA_RANK_BF16_PARAMS                                                                                                        \
+    const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,                            \
+    const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,                            \
+    const float *__restrict__ csls_c, int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank,                            \
+    unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap
+#define OEA_RANK_BF16_ARGS qp, n1, kp, cp, n2, dim, gold, tol_ptr, csls_r, csls_c, tiles_per_chunk, gold_off, rank, lbrow, rec, rec_cnt, slice_cap
+
+template <bool WARM, bool CSLS>
+__global__ __launch_bounds__(256, 2) void rank_bf16_kernel(OEA_RANK_BF16_PARAMS) {
+    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    rank_bf16_body<WARM, CSLS, 0>(OEA_RANK_BF16_ARGS, As, Bs);
+}
+
+template <bool WARM, bool CSLS, int NCH>
+__global__ __launch_bounds__(256, 2) void rank_bf16_breg_kernel(OEA_RANK_BF16_PARAMS) {
+    __shared__ __attribute__((aligned(16))) float As[4 * TILE * PLD];           // 2 slots x 2 chunks
+    rank_bf16_body<WARM, CSLS, NCH>(OEA_RANK_BF16_ARGS, As, nullptr);
 }
 
 // ONE grid-stride prologue: both bf16 packs, the gold similarities (the exact k-ordered chain), the max row norms of both
@@ -2839,10 +2967,17 @@ int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
     row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
     knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
-    topk_stream_sym_kernel<<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),
-                                                              static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), ccap,
-                                                              row_cnt, col_off, lp1, row_fail, tol_dev, redo_cnt, static_cast<int4 *>(redo),
-                                                              redo_cap);
+    // (the B-in-registers pipeline, NCH = Kp / 32, spills in this kernel -- its epilogue already takes the register file: 13.3 -> 20.8 ms
+    //  at 100,000 rows; it stays on the LDS pipeline.  OEA_TOPK_STREAM_NCH = 1..4 selects the register form for experiments.)
+    static const int nch_env = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return e ? atoi(e) : 0; }();
+#define OEA_STREAM_LAUNCH(N)                                                                                                          \
+    topk_stream_sym_kernel<N><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),            \
+                                                                 static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), \
+                                                                 ccap, row_cnt, col_off, lp1, row_fail, tol_dev, redo_cnt,              \
+                                                                 static_cast<int4 *>(redo), redo_cap)
+    if (nch_env == 4 && op.kp == 128) OEA_STREAM_LAUNCH(4);
+    else OEA_STREAM_LAUNCH(0);
+#undef OEA_STREAM_LAUNCH
     topk_stream_redo_kernel<<<2048, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items), rcap, ccap, row_fail, tol_dev,
                                                   redo_cnt, static_cast<const int4 *>(redo), redo_cap, static_cast<uint4 *>(ovf_pool), ovf_alloc,
                                                   ovf_len, ovf_chunks);
@@ -3013,8 +3148,20 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     // set needs none: every workgroup sees most of it anyway
     const int warm = (int)std::min<int64_t>(kBf16WarmTiles, ctiles / 16);
     const dim3 gw((unsigned)qt, 1), gs((unsigned)qt, (unsigned)chunks);
-#define OEA_BF16_SWEEP(W, C, GRID, TPC) rank_bf16_kernel<W, C><<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, csls_r, csls_c, TPC, \
-                                                                                  gold_offset, rank, lbrow, rec, rec_cnt, slice_cap)
+    // Kp <= 128 (dim <= 128): the candidates' operand stays in registers (OEA_BF16_BREG=0: both operands through LDS)
+    static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
+    // (with the CSLS terms the epilogue's registers + 32 NCH of B spill from NCH = 3 on: measured slower, stays on the LDS pipeline)
+    const int nch = (breg_on && p1.kp <= (csls_r ? 64 : 128)) ? p1.kp / 32 : 0;
+#define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, csls_r, csls_c, TPC, gold_offset, \
+                                                              rank, lbrow, rec, rec_cnt, slice_cap)
+#define OEA_BF16_SWEEP(W, C, GRID, TPC)                                                                 \
+    do {                                                                                                \
+        if (nch == 4) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 4>), GRID, TPC);                     \
+        else if (nch == 3) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 3>), GRID, TPC);                \
+        else if (nch == 2) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 2>), GRID, TPC);                \
+        else if (nch == 1) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 1>), GRID, TPC);                \
+        else OEA_BF16_LAUNCH((rank_bf16_kernel<W, C>), GRID, TPC);                                      \
+    } while (0)
     if (csls_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
         OEA_BF16_SWEEP(false, true, gs, tpc);
@@ -3023,6 +3170,7 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         OEA_BF16_SWEEP(false, false, gs, tpc);
     }
 #undef OEA_BF16_SWEEP
+#undef OEA_BF16_LAUNCH
     rc = release_packed(st);
     if (rc != OEA_OK) return rc;
     rank_bf16_fixup_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_waves, 4), 2048), 256, 0, st>>>(
@@ -3324,8 +3472,17 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n1, 256), 256, 0, st>>>(e1, n1, ld1, dim, reinterpret_cast<unsigned *>(tol) + 1);
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n2, 256), 256, 0, st>>>(e2, n2, ld2, dim, reinterpret_cast<unsigned *>(tol) + 2);
         csls_tol_kernel<<<1, 1, 0, st>>>(tol, bf16_eps_rel(dim));
-        csls_append_kernel<true, true><<<grid, 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt,
-                                                              clists, ccnt, tol);
+        static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
+#define OEA_CSLS_APPEND(N) csls_append_kernel<true, true, N><<<grid, 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, \
+                                                                                 qlists, qcnt, clists, ccnt, tol)
+        switch ((breg_on && kp <= 128) ? kp / 32 : 0) {
+            case 4: OEA_CSLS_APPEND(4); break;
+            case 3: OEA_CSLS_APPEND(3); break;
+            case 2: OEA_CSLS_APPEND(2); break;
+            case 1: OEA_CSLS_APPEND(1); break;
+            default: OEA_CSLS_APPEND(0); break;
+        }
+#undef OEA_CSLS_APPEND
         list_mean_rows_kernel<true><<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail,
                                                                                     e1, ld1, e2, ld2, dim, thr1, tol);
         list_mean_rows_kernel<true><<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2,
