@@ -409,7 +409,11 @@ int oea_pair_dots(const float *e1, int32_t ld1, const float *e2, int32_t ld2, in
 size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc);
 /* queries == candidates (q == c, the truncated-sampling refresh of one KG's entities against themselves): with a
  * workspace of this many bytes (0: shape not covered) oea_topk_inner computes only the tiles on and above the diagonal of
- * S = E E^T and feeds rows and columns from them (bit-identical result: S_ij == S_ji in the k-ordered fmaf chain). */
+ * S = E E^T and feeds rows and columns from them (bit-identical result: S_ij == S_ji in the k-ordered fmaf chain).
+ * Round 4: that sweep multiplies the bf16 hi / lo split of the rows (approximate survivors, the neighbourhood of the k-th value
+ * decided by exact chains: the same neighbour sets) and collects the survivors in per-wave record streams that a second kernel
+ * deals to per-row lists; OEA_TOPK_BF16=0 / OEA_TOPK_STREAM=0 (read once per process) select the fp32 sweep / the per-row
+ * segment lists of round 3. */
 size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k);
 int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int64_t nc, int32_t ldc,
                    int32_t dim, int32_t k, const int32_t *id_map, int32_t *out_idx, void *workspace,
@@ -452,7 +456,7 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
  * of the row's running maximum; a second kernel decides the records with the exact k-ordered fmaf chain.  rank / argmax are
  * those of oea_rank_eval(OEA_METRIC_INNER) bit for bit.  status int32[2] (device): [0] != 0 = the record buffer overflowed,
  * the results are INVALID and the caller must take oea_rank_eval; [1] = records written.  Workspace:
- * oea_rank_eval_bf16_workspace_bytes(n1, dim).  No CSLS terms (the fp32 sweep takes them). */
+ * oea_rank_eval_bf16_workspace_bytes(n1, dim).  No CSLS terms here (oea_rank_eval_metrics_bf16 takes them). */
 size_t oea_rank_eval_bf16_workspace_bytes(int64_t n1, int32_t dim);
 int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
                        int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status, void *workspace, void *stream);

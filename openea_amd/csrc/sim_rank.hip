@@ -2526,14 +2526,17 @@ __global__ void rank_bf16_init_kernel(const float *__restrict__ gold, int64_t n1
 template <bool WARM, bool INTERIOR, bool CSLS, class Acc, class Rec>
 __device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const float (&glo)[2], const float (&ghi)[2], float (&lb)[2],
                                                float (&lbm)[2], int (&cnt)[2], bool (&dirty)[2], const int64_t (&qi)[2], int64_t gold_off,
-                                               const float (&tol)[2], const float (&rq)[2], const float *__restrict__ csls_c, Rec &&record) {
+                                               const float (&tol)[2], const float (&rq)[2], float my_c, Rec &&record) {
+    // my_c: the column mean of the candidate this lane looks after (lane l32 = tm * 16 + r of either half: one load per tile and
+    // lane + a lane shuffle per register instead of 32 loaded values held in registers)
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = jb + tm * 32 + (r & 3) + 8 * (r >> 2);
             const bool jin = INTERIOR || j < n2;
-            const float cj = (CSLS && jin) ? csls_c[j] : 0.f;
+            const float cj = CSLS ? __shfl(my_c, (lane & 32) + tm * 16 + r, 64) : 0.f;
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
                 float v = acc[tm][tn][r];
@@ -2608,8 +2611,14 @@ __device__ __forceinline__ void rank_bf16_body(
                     const float o = ord2f(__hip_atomic_load(lbrow + qi[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (o > lb[tn]) { lb[tn] = o; lbm[tn] = o - tol[tn]; }
                 }
-            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, csls_c, record);
-            else rank_bf16_tile<WARM, false, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, csls_c, record);
+            float my_c = 0.f;
+            if (CSLS) {
+                const int l32 = lane & 31;
+                const int64_t my_j = (int64_t)jb + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
+                my_c = my_j < n2 ? csls_c[my_j] : 0.f;
+            }
+            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
+            else rank_bf16_tile<WARM, false, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
                 if (dirty[tn]) { atomicMax(lbrow + qi[tn], f2ord(lb[tn])); dirty[tn] = false; }
@@ -3150,7 +3159,7 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     const dim3 gw((unsigned)qt, 1), gs((unsigned)qt, (unsigned)chunks);
     // Kp <= 128 (dim <= 128): the candidates' operand stays in registers (OEA_BF16_BREG=0: both operands through LDS)
     static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
-    // (with the CSLS terms the epilogue's registers + 32 NCH of B spill from NCH = 3 on: measured slower, stays on the LDS pipeline)
+    // (with the CSLS terms the epilogue's registers + 32 NCH of B spill from NCH = 3 on: 6.5 -> 7.6 ms, stays on the LDS pipeline)
     const int nch = (breg_on && p1.kp <= (csls_r ? 64 : 128)) ? p1.kp / 32 : 0;
 #define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, csls_r, csls_c, TPC, gold_offset, \
                                                               rank, lbrow, rec, rec_cnt, slice_cap)
