@@ -1304,6 +1304,9 @@ static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     // records per wave and side: L tiles of 64 x 64 pairs; the thresholds' common noise averages over the wave's 64 rows
     const double ew = frac * p.L * 4096.0;
     p.rcap = p.ccap = ((int)(ew * 1.25 + 8.0 * std::sqrt(ew) + 256.0) + 63) / 64 * 64;
+    // tests: OEA_TOPK_STREAM_CAP shrinks the streams (every wave then overflows into the pool), OEA_TOPK_OVF_CHUNKS the pool (it
+    // runs dry: rows go to the strip fallback) -- both read per call
+    if (const char *ec = getenv("OEA_TOPK_STREAM_CAP")) p.rcap = p.ccap = std::max(64, atoi(ec) / 64 * 64);
     p.row_cap = std::min(kPerThread * SEL_THREADS,
                          ((int)(m_total * (1.0 + 4.0 / std::sqrt((double)p.r)) + 8.0 * std::sqrt(m_total) + 64.0) + 7) / 8 * 8);
     int64_t items = 0;
@@ -1330,6 +1333,8 @@ static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     p.off_lists = take(8 * (size_t)p.T * 128 * (size_t)p.row_cap);
     // overflow pool: 40 % of the expected records (both sides) + a chunk per wave
     p.ovf_chunks = (int)std::min<double>(0.4 * 2.0 * ew * 4.0 * (double)items / kOvfChunkRecs + 4.0 * (double)items, 4.0e6);
+    if (getenv("OEA_TOPK_STREAM_CAP")) p.ovf_chunks = (int)std::min<double>(2.0 * 2.0 * ew * 4.0 * (double)items / kOvfChunkRecs + 8.0 * (double)items, 4.0e6);
+    if (const char *eo = getenv("OEA_TOPK_OVF_CHUNKS")) p.ovf_chunks = std::max(1, atoi(eo));
     p.off_ovf = take(16 * (size_t)kOvfChunkRecs * (size_t)p.ovf_chunks);
     p.off_ovflen = take(sizeof(int32_t) * (size_t)p.ovf_chunks);
     p.redo_cap = (int)std::min<int64_t>(items * 4 * p.L, 1 << 22);     // (work item, tile, wave) triples: all of them, up to 4 M

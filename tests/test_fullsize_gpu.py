@@ -193,6 +193,28 @@ def test_symmetric_neighbour_search_equals_general_path(ops):
     assert np.array_equal(sym[rows], cport.topk_inner(emb[rows], emb, k))
 
 
+@pytest.mark.parametrize("case", ["tiny streams", "tiny streams, dry pool"])
+def test_stream_neighbour_search_overflow_paths_stay_exact(ops, case, monkeypatch):
+    """the stream form with its per-wave streams shrunk to 256 records: nearly every wave overflows, its tiles are recomputed
+    (topk_stream_redo_kernel) and the records go through the shared overflow pool (topk_overflow_kernel); with a pool of 64
+    chunks most of them are lost and the rows they belonged to must arrive through the strip fallback.  Same neighbour sets."""
+    from oracle import cport
+    monkeypatch.setenv("OEA_TOPK_STREAM_CAP", "256")
+    if case.endswith("dry pool"):
+        monkeypatch.setenv("OEA_TOPK_OVF_CHUNKS", "64")
+    rng = np.random.RandomState(13)
+    n, d, k = 33100, 48, 500
+    emb = _unit_rows(rng, n, d)
+    t = ops.to_table(emb)
+    out = ops.topk_inner(t, t, d, k).cpu().numpy()
+    monkeypatch.delenv("OEA_TOPK_STREAM_CAP")
+    monkeypatch.delenv("OEA_TOPK_OVF_CHUNKS", raising=False)
+    ref_dev = ops.topk_inner(t, t, d, k).cpu().numpy()
+    assert np.array_equal(out, ref_dev)
+    rows = np.concatenate([[0, 127, 128, n - 1], rng.choice(n, 12, replace=False)])
+    assert np.array_equal(out[rows], cport.topk_inner(emb[rows], emb, k))
+
+
 def test_neighbour_search_on_clustered_rows_spills_and_stays_exact(ops):
     """clustered embeddings (blocks of ~600 consecutive near-duplicate rows, as trained tables have them): a row's neighbours
     crowd into a few candidate tiles, its list segments overflow into the spill list (and some rows into the strip
