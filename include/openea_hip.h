@@ -460,6 +460,11 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
 size_t oea_rank_eval_bf16_workspace_bytes(int64_t n1, int32_t dim);
 int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
                        int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status, void *workspace, void *stream);
+/* oea_rank_eval_bf16 with the CSLS means (csls_r [n1] of the query rows, csls_c [n2]; both NULL = oea_rank_eval_bf16): what a rank
+ * of a row-sharded evaluation calls for its block of query rows (gold_offset = its first row). */
+int oea_rank_eval_bf16_csls(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                            const float *csls_r, const float *csls_c, int64_t gold_offset, int32_t *rank, int32_t *argmax,
+                            int32_t *status, void *workspace, void *stream);
 /* the same + argmax + the metrics of oea_rank_metrics in one go: out int64 [nk + 4] (device) = hits[nk], sum(rank + 1), the bits of
  * the double sum 1 / (rank + 1) (the reduction order of oea_rank_metrics), overflow flag (!= 0: INVALID, take
  * oea_rank_eval_metrics), records written -- one device-to-host copy brings results and status back.  csls_r / csls_c (both or

@@ -174,6 +174,7 @@ PROTOTYPES = {
     "oea_rank_metrics": (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "oea_rank_eval_bf16_workspace_bytes": (_sz, [_i64, _i32]),
     "oea_rank_eval_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "oea_rank_eval_bf16_csls": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "oea_sim_bf16_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "oea_rank_eval_metrics_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "oea_rank_eval_metrics_workspace_bytes": (_sz, [_i64]),

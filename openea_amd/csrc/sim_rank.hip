@@ -3210,6 +3210,21 @@ int oea_rank_eval_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2
                                workspace, st);
 }
 
+int oea_rank_eval_bf16_csls(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
+                            const float *csls_r, const float *csls_c, int64_t gold_offset, int32_t *rank, int32_t *argmax, int32_t *status,
+                            void *workspace, void *stream) {
+    OEA_REQUIRE(e1 && e2 && rank && argmax && status && workspace, "null pointer");
+    OEA_REQUIRE((csls_r == nullptr) == (csls_c == nullptr), "csls_r and csls_c: both or neither");
+    OEA_REQUIRE(n1 >= 0 && gold_offset >= 0 && n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2");
+    OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2, "ld % 4 == 0, dim <= ld");
+    OEA_REQUIRE(n2 < 0x7fffffff && n1 < 0x7fffffff, "n < 2^31");
+    OEA_REQUIRE(use_glds(), "the bf16 prefilter runs on the packed (LDS-DMA) tile path");
+    hipStream_t st = oea::as_stream(stream);
+    if (n1 == 0) { OEA_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st)); return OEA_OK; }
+    return rank_eval_bf16_impl(e1, n1, ld1, e2, n2, ld2, dim, csls_r, csls_c, gold_offset, nullptr, 0, rank, argmax, nullptr, status,
+                               workspace, st);
+}
+
 int oea_rank_eval_metrics_bf16(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim,
                                const float *csls_r, const float *csls_c, int64_t gold_offset, const int32_t *top_k_host, int32_t nk,
                                int32_t *rank, int32_t *argmax, int64_t *out_dev, void *workspace, void *stream) {

@@ -486,10 +486,10 @@ def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset
     """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
     n1, n2 = e1.shape[0], e2.shape[0]
     assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
-    if metric == 'inner' and csls_r is None and n1 > 0 and eval_bf16_enabled(n1, n2) and not getattr(rank_eval, "_in_bf16", False):
+    if metric == 'inner' and n1 > 0 and eval_bf16_enabled(n1, n2) and not getattr(rank_eval, "_in_bf16", False):
         rank_eval._in_bf16 = True                   # (rank_eval_bf16 falls back to this function on a record overflow)
         try:
-            return rank_eval_bf16(e1, e2, dim, gold_offset)
+            return rank_eval_bf16(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
         finally:
             rank_eval._in_bf16 = False
     if metric == 'manhattan' and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
@@ -602,22 +602,22 @@ def sim_bf16_matrix(e1, e2, dim):
     return out
 
 
-def rank_eval_bf16(e1, e2, dim, gold_offset=0, stats=None):
-    """rank_eval(metric='inner') through the certified bf16 prefilter (oea_rank_eval_bf16): the same rank / argmax, the matrix
-    work at 3/16 of the fp32 matrix time.  Falls back to the fp32 sweep when the record buffer overflows (one host read of the
-    status word).  stats: optional dict, receives 'records' and 'fallback'."""
+def rank_eval_bf16(e1, e2, dim, gold_offset=0, stats=None, csls_r=None, csls_c=None):
+    """rank_eval(metric='inner') through the certified bf16 prefilter (oea_rank_eval_bf16[_csls]): the same rank / argmax, the
+    matrix work at 3/16 of the fp32 matrix time.  Falls back to the fp32 sweep when the record buffer overflows (one host read
+    of the status word).  stats: optional dict, receives 'records' and 'fallback'."""
     n1 = e1.shape[0]
     ws = torch.empty(lib().oea_rank_eval_bf16_workspace_bytes(n1, dim), dtype=torch.uint8, device=e1.device)
     rank = torch.empty(n1, dtype=torch.int32, device=e1.device)
     argmax = torch.empty(n1, dtype=torch.int32, device=e1.device)
     status = torch.zeros(2, dtype=torch.int32, device=e1.device)
-    check(lib().oea_rank_eval_bf16(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, int(gold_offset), _p(rank), _p(argmax),
-                                   _p(status), _p(ws), _stream()))
+    check(lib().oea_rank_eval_bf16_csls(_p(e1), n1, e1.shape[1], _p(e2), e2.shape[0], e2.shape[1], dim, _p(csls_r), _p(csls_c),
+                                        int(gold_offset), _p(rank), _p(argmax), _p(status), _p(ws), _stream()))
     st = status.cpu().numpy()
     if stats is not None:
         stats['records'], stats['fallback'] = int(st[1]), bool(st[0])
     if st[0]:
-        return rank_eval(e1, e2, dim, 'inner', gold_offset=gold_offset)
+        return rank_eval(e1, e2, dim, 'inner', csls_r, csls_c, gold_offset=gold_offset)
     return rank, argmax
 
 

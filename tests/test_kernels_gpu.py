@@ -436,6 +436,13 @@ def test_bf16_prefilter_evaluation_equals_the_fp32_sweep(ops, d, monkeypatch):
         r1, a1 = ops.rank_eval_bf16(t1, t2, d, gold_offset=off, stats=st)
         assert torch.equal(r0, r1) and torch.equal(a0, a1), (name, st)
         assert st["fallback"] == name.startswith("clustered"), (name, st)
+        if not name.startswith("clustered"):       # a block of query rows with its gold offset AND CSLS terms (the sharded evaluation)
+            g = torch.Generator(device=t1.device).manual_seed(3)
+            rr = torch.rand(t1.shape[0], device=t1.device, generator=g) * 0.3
+            cc = torch.rand(t2.shape[0], device=t1.device, generator=g) * 0.3
+            r0c, a0c = ops.rank_eval(t1, t2, d, "inner", rr, cc, gold_offset=off)
+            r1c, a1c = ops.rank_eval_bf16(t1, t2, d, gold_offset=off, csls_r=rr, csls_c=cc)
+            assert torch.equal(r0c, r1c) and torch.equal(a0c, a1c), name
         if off == 0 or True:
             q0, c0 = ops.to_table(q), ops.to_table(c[off:])         # the metrics entry point takes gold_offset too; use 0 here
             m0 = ops.rank_eval_metrics(q0, c0, d, [1, 5, 10, 50])
