@@ -76,10 +76,10 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
     cols=False: only the row means (second result None)."""
     import os
     import torch
-    if kmetric == 'inner' and cols:        # one sweep, no strips of S / S^T (n1, n2 >= 4096)
+    if kmetric == 'inner':                 # one sweep, no strips of S / S^T (n1, n2 >= 4096)
         rc = ops.csls_means(t1, t2, dim, k)
-        if rc is not None:
-            return rc
+        if rc is not None:                 # (cols=False -- a rank's block of rows in the sharded evaluation -- drops the column means:
+            return rc if cols else (rc[0], None)   #  the sweep that finds both is still several times faster than the strips below)
     if (kmetric == 'manhattan' and min(t1.shape[0], t2.shape[0]) >= 2048 and k + 32 < min(t1.shape[0], t2.shape[0])
             and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64'):
         # 16-bit grid distances + exact similarities of the k + margin nearest (certified): the same means without the fp64
