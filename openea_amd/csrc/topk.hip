@@ -1289,7 +1289,9 @@ struct StreamPlan {
 static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     StreamPlan p;
     static const bool on = [] { const char *e = getenv("OEA_TOPK_STREAM"); return !(e && e[0] == '0'); }();
-    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)32768; }();
+    // from 12,288 rows on (the 15K datasets: 15,000 rows, k = 1,499: 0.95 ms on random rows / 1.26 ms on the trained table against
+    // 1.21 / 1.31 ms of the N x N strip path; with one bucketing workgroup per tile it lost there)
+    static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)12288; }();
     if (!on || n < min_n) return p;
     const double e = (double)k * kSample / (double)n;
     p.r = threshold_rank(e);
@@ -1324,8 +1326,8 @@ static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     p.off_items = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
     p.off_rcnt = take(sizeof(int32_t) * 4 * (size_t)p.n_items);
     p.off_coff = take(sizeof(int32_t) * 4 * (size_t)p.n_items * (p.L + 1));
-    p.off_lcnt = take(sizeof(int32_t) * (size_t)n);
-    p.off_rowfail = take((size_t)n);
+    p.off_lcnt = take(sizeof(int32_t) * (size_t)p.T * 128);
+    p.off_rowfail = take((size_t)p.T * 128);
     p.off_strip = take(sizeof(float) * (size_t)n * kSample);
     p.stream_bytes = 8 * (size_t)p.n_items * 4 * (size_t)p.rcap;
     p.off_rstream = take(p.stream_bytes);
@@ -1413,15 +1415,18 @@ __global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int 
                                                           const int32_t *__restrict__ row_cnt, const uint2 *__restrict__ col_streams,
                                                           int ccap, const int32_t *__restrict__ col_off, int lp1,
                                                           uint2 *__restrict__ lists, int row_cap, int32_t *__restrict__ counts,
-                                                          uint8_t *__restrict__ row_fail) {
+                                                          uint8_t *__restrict__ row_fail, int parts) {
+    // `parts` workgroups share a target tile (each an equal share of the concatenated records): a row's slots then come from ONE
+    // returning atomic on its (zeroed) global count per round and workgroup -- 128 per 4,096 records -- instead of a counter in LDS.
+    // With one workgroup per tile a 15,000-row table has 118 workgroups for 256 CUs, a 100,000-row one 782 for 512 slots.
     extern __shared__ uint32_t seg_tab[];                    // prefix[nseg + 1] | src[nseg]
-    __shared__ int cnt[128], hist[128], loff[129], gbase[128];
+    __shared__ int hist[128], loff[129], gbase[128];
     __shared__ int s_part[kBucketThreads / 64];
-    const int tau = blockIdx.x, tid = threadIdx.x;
+    const int tau = blockIdx.x / parts, part = blockIdx.x - tau * parts, tid = threadIdx.x;
     const int c0 = tau / L;
     const int nrow = (groups - c0) * 4, ncol = (tau + 1) * 4, nseg = nrow + ncol;
     uint32_t *prefix = seg_tab, *src = seg_tab + (64 + 4 * T + 1);
-    if (tid < 128) { cnt[tid] = 0; hist[tid] = 0; }
+    if (tid < 128) hist[tid] = 0;
     const int base_c0 = sym_item_base(T, L, c0);
     const int per = (nseg + kBucketThreads - 1) / kBucketThreads;
     int mine = 0;
@@ -1477,8 +1482,10 @@ __global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int 
     uint2 *__restrict__ out = lists + (size_t)tau * 128 * row_cap;
     // every wave takes a contiguous sixteenth of the concatenation, its lanes consecutive records (512 B per load instruction);
     // the slice index of a lane then moves forward by less than one slice per step
-    const uint32_t per_wave = ((uint32_t)total + kBucketThreads / 64 - 1) / (kBucketThreads / 64);
-    const uint32_t w_begin = (uint32_t)(tid >> 6) * per_wave, w_end = min(w_begin + per_wave, (uint32_t)total);
+    const uint32_t per_part = ((uint32_t)total + parts - 1) / parts;
+    const uint32_t p_begin = min((uint32_t)part * per_part, (uint32_t)total), p_end = min(p_begin + per_part, (uint32_t)total);
+    const uint32_t per_wave = (p_end - p_begin + kBucketThreads / 64 - 1) / (kBucketThreads / 64);
+    const uint32_t w_begin = min(p_begin + (uint32_t)(tid >> 6) * per_wave, p_end), w_end = min(w_begin + per_wave, p_end);
     int sg = 0;
     {
         int lo = 0, hi = nseg;                               // prefix[lo] <= w_begin < prefix[hi] (when the range is not empty)
@@ -1524,10 +1531,11 @@ __global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int 
             loff[2 * tid] = excl;
             loff[2 * tid + 1] = excl + h0;
             if (tid == 63) loff[128] = incl;
-            gbase[2 * tid] = cnt[2 * tid];
-            gbase[2 * tid + 1] = cnt[2 * tid + 1];
-            cnt[2 * tid] += h0;
-            cnt[2 * tid + 1] += h1;
+            const int64_t row0 = (int64_t)tau * 128 + 2 * tid;
+            gbase[2 * tid] = h0 ? atomicAdd(counts + row0, h0) : 0;
+            gbase[2 * tid + 1] = h1 ? atomicAdd(counts + row0 + 1, h1) : 0;
+            if (h0 && gbase[2 * tid] + h0 > row_cap) row_fail[row0] = 1;
+            if (h1 && gbase[2 * tid + 1] + h1 > row_cap) row_fail[row0 + 1] = 1;
             hist[2 * tid] = 0;
             hist[2 * tid + 1] = 0;
         }
@@ -1544,14 +1552,6 @@ __global__ __launch_bounds__(kBucketThreads) void topk_bucket_kernel(int T, int 
             if (slot < row_cap) out[(size_t)t * row_cap + slot] = make_uint2(r.x, r.y & 0xFFFFFFu);
         }
         __syncthreads();
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int64_t row = (int64_t)tau * 128 + tid;
-        if (row < n) {
-            counts[row] = min(cnt[tid], row_cap);
-            if (cnt[tid] > row_cap) row_fail[row] = 1;
-        }
     }
 }
 
@@ -1735,9 +1735,12 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         static const hipError_t bucket_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_bucket_kernel),
                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 1024 * (4 + kBucketFlight * kBucketThreads / 1024) + 1024);
         OEA_CHECK_HIP(bucket_attr);
-        topk_bucket_kernel<<<(unsigned)sp.T, kBucketThreads, bucket_lds, st>>>(
+        // (rows past n of the last tile never get records; the counts array covers T * 128 rows)
+        OEA_CHECK_HIP(hipMemsetAsync(list_cnt, 0, sizeof(int32_t) * (size_t)sp.T * 128, st));
+        const int parts = std::max(1, std::min(16, (int)oea::ceil_div(1024, sp.T)));
+        topk_bucket_kernel<<<(unsigned)(sp.T * parts), kBucketThreads, bucket_lds, st>>>(
             sp.T, sp.L, sp.groups, nq, reinterpret_cast<const uint2 *>(w + sp.off_rstream), sp.rcap, row_cnt,
-            reinterpret_cast<const uint2 *>(w + sp.off_cstream), sp.ccap, col_off, sp.L + 1, lists, sp.row_cap, list_cnt, row_fail);
+            reinterpret_cast<const uint2 *>(w + sp.off_cstream), sp.ccap, col_off, sp.L + 1, lists, sp.row_cap, list_cnt, row_fail, parts);
         topk_overflow_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4 *>(w + sp.off_ovf), ovf_alloc, ovf_len, sp.ovf_chunks, lists,
                                                    sp.row_cap, list_cnt, row_fail);
         static const bool dbg_ovf = getenv("OEA_TOPK_DEBUG") != nullptr;
