@@ -41,8 +41,11 @@ def test_host_side_planners_of_the_library():
     """pure host entry points (no device): workspace planners answer without a GPU and follow their documented domains."""
     from openea_amd import _lib
     lib = _lib.load(require_device=False)
-    # symmetric neighbour search: covered from 32,768 rows up to the select's segment table (~140,000 rows)
-    assert lib.oea_topk_sym_workspace_bytes(20000, 400) == 0
+    # symmetric neighbour search: the stream form from 12,288 rows (round 4), the segment lists from 32,768, up to the select's
+    # segment table (~140,000 rows)
+    assert lib.oea_topk_sym_workspace_bytes(10000, 200) == 0
+    assert 0 < lib.oea_topk_sym_workspace_bytes(15000, 1499) < 2 << 30
+    assert 0 < lib.oea_topk_sym_workspace_bytes(20000, 400) < 2 << 30
     need = lib.oea_topk_sym_workspace_bytes(100000, 2000)
     assert 20 << 30 < need < 48 << 30               # ~30 GB: mostly the candidate-side segments
     assert lib.oea_topk_sym_workspace_bytes(400000, 8000) == 0
