@@ -1288,7 +1288,10 @@ struct StreamPlan {
 // the stream form of the symmetric search (bf16 sweep only): same thresholds and work items as plan_sym
 static StreamPlan plan_stream(int64_t n, int k, size_t ws_bytes) {
     StreamPlan p;
-    static const bool on = [] { const char *e = getenv("OEA_TOPK_STREAM"); return !(e && e[0] == '0'); }();
+    static const bool on = [] {
+        const char *e = getenv("OEA_TOPK_STREAM"), *b = getenv("OEA_TOPK_BF16");      // the streams hold the bf16 sweep's records
+        return !(e && e[0] == '0') && !(b && b[0] == '0');
+    }();
     // from 12,288 rows on (the 15K datasets: 15,000 rows, k = 1,499: 0.95 ms on random rows / 1.26 ms on the trained table against
     // 1.21 / 1.31 ms of the N x N strip path; with one bucketing workgroup per tile it lost there)
     static const int64_t min_n = [] { const char *e = getenv("OEA_TOPK_SYM_MIN"); return e ? (int64_t)atoll(e) : (int64_t)12288; }();
@@ -1657,9 +1660,10 @@ size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
 }
 
 size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k) {
+    const StreamPlan q = plan_stream(n, k, ~(size_t)0);         // the form oea_topk_inner takes when it is covered
+    if (q.ok) return q.total;
     const SymPlan p = plan_sym(n, k, ~(size_t)0);
-    const StreamPlan q = plan_stream(n, k, ~(size_t)0);
-    return std::max(p.ok ? p.total : (size_t)0, q.ok ? q.total : (size_t)0);
+    return p.ok ? p.total : 0;
 }
 
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,

@@ -47,7 +47,7 @@ def test_host_side_planners_of_the_library():
     assert 0 < lib.oea_topk_sym_workspace_bytes(15000, 1499) < 2 << 30
     assert 0 < lib.oea_topk_sym_workspace_bytes(20000, 400) < 2 << 30
     need = lib.oea_topk_sym_workspace_bytes(100000, 2000)
-    assert 20 << 30 < need < 48 << 30               # ~30 GB: mostly the candidate-side segments
+    assert 5 << 30 < need < 12 << 30                # ~8 GB: record streams + compact lists + overflow pool (segment lists: ~30 GB)
     assert lib.oea_topk_sym_workspace_bytes(400000, 8000) == 0
     assert lib.oea_topk_workspace_bytes(1000, 100000) == 1000 * 100000 * 4
     # one-sweep CSLS means: from 4,096 x 4,096 on, k <= 32
