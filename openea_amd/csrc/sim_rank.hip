@@ -2315,6 +2315,16 @@ __global__ __launch_bounds__(256) void list_mean_rows_kernel(const float *__rest
             const float *__restrict__ x = a + row * lda, *__restrict__ y = b + (int64_t)cand[lane] * ldb;
             float acc = 0.f;
             int kk = 0;
+            for (; kk + 32 <= dim; kk += 32) {                      // 16 loads in flight, then the chain in k order
+                float4 xv[8], yv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { xv[u] = oea::ld4(x + kk + 4 * u); yv[u] = oea::ld4(y + kk + 4 * u); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = fmaf(xv[u].x, yv[u].x, acc); acc = fmaf(xv[u].y, yv[u].y, acc);
+                    acc = fmaf(xv[u].z, yv[u].z, acc); acc = fmaf(xv[u].w, yv[u].w, acc);
+                }
+            }
             for (; kk + 4 <= dim; kk += 4) {
                 const float4 xv = oea::ld4(x + kk), yv = oea::ld4(y + kk);
                 acc = fmaf(xv.x, yv.x, acc); acc = fmaf(xv.y, yv.y, acc); acc = fmaf(xv.z, yv.z, acc); acc = fmaf(xv.w, yv.w, acc);
@@ -2818,6 +2828,16 @@ __global__ __launch_bounds__(256) void rank_bf16_fixup_kernel(const float *__res
             const float *a = e1 + i * ld1, *b = e2 + j * ld2;
             float acc = 0.f;
             int k = 0;
+            for (; k + 32 <= dim; k += 32) {                        // 16 loads in flight, then the chain in k order
+                float4 x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { x[u] = oea::ld4(a + k + 4 * u); y[u] = oea::ld4(b + k + 4 * u); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc = fmaf(x[u].x, y[u].x, acc); acc = fmaf(x[u].y, y[u].y, acc);
+                    acc = fmaf(x[u].z, y[u].z, acc); acc = fmaf(x[u].w, y[u].w, acc);
+                }
+            }
             for (; k + 4 <= dim; k += 4) {
                 const float4 x = oea::ld4(a + k), y = oea::ld4(b + k);
                 acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
