@@ -2911,6 +2911,8 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     CslsPlan p;
     if (n1 < 4096 || n2 < 4096 || k > 32) return p;
     p.sample = std::max(n1, n2) >= 32768 ? 4096 : 1024;       // keeps r n / S, the survivors per row, in the low hundreds
+    static const int env_sample = [] { const char *e = getenv("OEA_CSLS_SAMPLE"); return e ? atoi(e) : 0; }();       // experiments
+    if (env_sample == 1024 || env_sample == 2048 || env_sample == 4096) p.sample = env_sample;
     auto rank_of = [&](int64_t n) { const double e = (double)k * p.sample / (double)n; return (int)(e + 3.5 * std::sqrt(e) + 8.0); };
     p.r1 = rank_of(n2);                       // thresholds of the rows of S (queries against sampled candidates)
     p.r2 = rank_of(n1);
