@@ -19,6 +19,16 @@
 //      from a sample of the row, candidates kept in LDS, exact selection on the LDS copy.
 //   All paths give the (value desc, column asc) selection in ascending column order, bit-identical with
 //   oracle_topk_inner.
+//
+// Which path oea_topk_inner takes (all give the same result):
+//   queries == candidates, 12,288 <= N <= 131,072   stream form (round 4): sampled thresholds; upper-triangle tile sweep on the bf16
+//                                                   hi / lo split writing per-wave record streams (sim_rank.hip:
+//                                                   topk_stream_sym_kernel, redo list + overflow pool for crowded waves);
+//                                                   topk_bucket_kernel -> compact per-row lists; list_select_kernel (exact
+//                                                   chains around the k-th approximate value); strip fallback for failed rows
+//   queries == candidates, N >= 32,768, else        per-row segment lists from the symmetric sweep (round 3; bf16 or fp32 sweep)
+//   nc >= 32,768, nq >= 4,096                       per-query segment lists from the full sweep (fp32)
+//   otherwise                                       N x N strips + per-row select (above)
 #include <math.h>
 #include <stdlib.h>
 
