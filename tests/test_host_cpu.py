@@ -348,3 +348,22 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_entity_id_cache_of_the_neighbour_refresh(monkeypatch):
+    """refresh_neighbours converts a KG's entity list to a device tensor once: the same list object hits the cache, a copy or an
+    edited list does not (models/trainer.py:_entity_ids_on_device)."""
+    from openea_amd.models import trainer
+    calls = []
+    monkeypatch.setattr(trainer.ops, "to_ids", lambda a, d=None: (calls.append(1), np.array(a))[1])
+    trainer._IDS_CACHE.clear()
+    ents = [3, 4, 5, 6]
+    a = trainer._entity_ids_on_device(ents, "cpu")
+    assert trainer._entity_ids_on_device(ents, "cpu") is a and len(calls) == 1
+    trainer._entity_ids_on_device(list(ents), "cpu")
+    assert len(calls) == 2
+    ents.append(9)
+    assert len(trainer._entity_ids_on_device(ents, "cpu")) == 5 and len(calls) == 3
+    ents[2] = 77                                   # an edit the three probes see
+    assert trainer._entity_ids_on_device(ents, "cpu")[2] == 77 and len(calls) == 4
+    trainer._IDS_CACHE.clear()
