@@ -2682,7 +2682,10 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
                                                                  uint4 *__restrict__ p2, int64_t n2_pad, int kp,
                                                                  float *__restrict__ gold, unsigned *__restrict__ nmax,
                                                                  int32_t *__restrict__ rank, const float *__restrict__ csls_r,
-                                                                 const float *__restrict__ csls_c) {
+                                                                 const float *__restrict__ csls_c, int aug) {
+    // aug (with the CSLS means): the packed rows carry two more coordinates, q' = [2 q, -r_i, -1] and c' = [c, 1, c_j], so that the
+    // tile sweep's product IS 2 <q, c> - r_i - c_j and the sweep runs without the CSLS terms in its epilogue (same kernel, same
+    // registers as the plain evaluation); the norms below are those of the augmented rows
     const int cpr = kp / 4;
     const int64_t a_end = n1_pad * cpr, b_end = a_end + n2_pad * cpr;
     // then: the gold chains (one thread per query row), then the row norms (16 lanes per row, table 2 on a wave boundary)
@@ -2705,7 +2708,16 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
                 x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
             } else {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) x[t] = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
+                for (int t = 0; t < 8; ++t) {
+                    x[t] = (row < n && k0 + t < dim) ? src[row * ld + k0 + t] : 0.f;
+                    if (aug && row < n && k0 + t == dim) x[t] = second ? 1.0f : -csls_r[row];
+                    if (aug && row < n && k0 + t == dim + 1) x[t] = second ? csls_c[row] : -1.0f;
+                }
+            }
+            if (aug && !second) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (k0 + t < dim) x[t] *= 2.0f;                   // exact
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -2743,6 +2755,10 @@ __global__ __launch_bounds__(256) void rank_bf16_prologue_kernel(const float *__
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (aug && row < n) {
+            const float extra = second ? csls_c[row] : csls_r[row];
+            ss = (second ? ss : 4.0f * ss) + fmaf(extra, extra, 1.0f);
+        }
         float nr = sqrtf(ss) * 1.000001f;
         float cm = (second && csls_c && row < n && l16 == 0) ? fabsf(csls_c[row]) : 0.f;
 #pragma unroll
@@ -3159,15 +3175,24 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     OEA_CHECK_HIP(hipMemsetAsync(sc, 0, 64, st));                   // norms, tolerance
     PackedOp p1, p2;
     int64_t n1_pad = 0, n2_pad = 0;
-    int rc = reserve_operand(0, n1, dim, st, &p1, &n1_pad);
-    if (rc == OEA_OK) rc = reserve_operand(1, n2, dim, st, &p2, &n2_pad);
+    // CSLS means: the rows are packed with two more coordinates (see the prologue) when that costs no k chunk, and the sweep is
+    // the plain one.  Its bound: split + accumulation over dim + 2 coordinates on the augmented norms, + the roundings of the
+    // exact expression fl(fl(2 s - r) - c) it is compared with (<= 2 * 2^-24 * (2 |s| + |r| + |c|) <= 3.6e-7 * |q'|max |c'|max,
+    // the chain's own error inside eps(dim + 2)); OEA_CSLS_AUG=0: the CSLS terms in the sweep's epilogue
+    static const bool aug_on = [] { const char *e = getenv("OEA_CSLS_AUG"); return !(e && e[0] == '0'); }();
+    const bool aug = csls_r && aug_on && (dim + 2 + BK - 1) / BK == (dim + BK - 1) / BK;
+    const int dim_p = aug ? dim + 2 : dim;
+    const float *sweep_r = aug ? nullptr : csls_r, *sweep_c = aug ? nullptr : csls_c;
+    int rc = reserve_operand(0, n1, dim_p, st, &p1, &n1_pad);
+    if (rc == OEA_OK) rc = reserve_operand(1, n2, dim_p, st, &p2, &n2_pad);
     if (rc != OEA_OK) return rc;
     const int64_t items = (n1_pad + n2_pad) * (p1.kp / 4) + 17 * (n1 + n2) + 256;
     rank_bf16_prologue_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(items, 256), 16384), 256, 0, st>>>(
         e1, n1, ld1, e2, n2, ld2, dim, gold_offset, reinterpret_cast<uint4 *>(p1.p), n1_pad, reinterpret_cast<uint4 *>(p2.p), n2_pad,
-        p1.kp, gold, nmax, rank, csls_r, csls_c);
+        p1.kp, gold, nmax, rank, csls_r, csls_c, aug ? 1 : 0);
     const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
-    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, bf16_eps_rel(dim), csls_r, tol, rank, keys, lbrow, rec_cnt);
+    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, aug ? bf16_eps_rel(dim_p) + 1.0e-6f : bf16_eps_rel(dim), sweep_r, tol,
+                                              rank, keys, lbrow, rec_cnt);
     int tpc = 1;
     const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
     const int chunks = pick_chunks(qt, ctiles, &tpc);
@@ -3182,8 +3207,8 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     // Kp <= 128 (dim <= 128): the candidates' operand stays in registers (OEA_BF16_BREG=0: both operands through LDS)
     static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
     // (with the CSLS terms the epilogue's registers + 32 NCH of B spill from NCH = 3 on: 6.5 -> 7.6 ms, stays on the LDS pipeline)
-    const int nch = (breg_on && p1.kp <= (csls_r ? 64 : 128)) ? p1.kp / 32 : 0;
-#define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim, gold, tol, csls_r, csls_c, TPC, gold_offset, \
+    const int nch = (breg_on && p1.kp <= (sweep_r ? 64 : 128)) ? p1.kp / 32 : 0;
+#define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, TPC, gold_offset, \
                                                               rank, lbrow, rec, rec_cnt, slice_cap)
 #define OEA_BF16_SWEEP(W, C, GRID, TPC)                                                                 \
     do {                                                                                                \
@@ -3193,7 +3218,7 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         else if (nch == 1) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 1>), GRID, TPC);                \
         else OEA_BF16_LAUNCH((rank_bf16_kernel<W, C>), GRID, TPC);                                      \
     } while (0)
-    if (csls_r) {
+    if (sweep_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
         OEA_BF16_SWEEP(false, true, gs, tpc);
     } else {
