@@ -5,12 +5,45 @@ counted inside the similarity tiles (csrc/sim_rank.hip).  Ranks are exact in BOT
 reference's quick mode (accurate=False) only trusts Hits@k and leaves MR/MRR to
 argpartition's internal order (alignment.py:157-162); Hits@k agree in both.
 """
+import collections.abc
 import time
 
 import numpy as np
 
 from ... import ops
 from .similarity import csls_means_device, device_metric
+
+
+class AlignmentPairs(collections.abc.Set):
+    """{(i, argmax[i])} -- what greedy_alignment returns as `alignment_rest`.  The reference builds a Python set of tuples
+    (alignment.py:47-63); for the 70,000 test pairs of a 100K dataset that alone is 17 ms of host time, more than the whole
+    evaluation on the device.  This is that set without the tuples: len, iteration, membership, equality with a real set and
+    the set algebra of collections.abc.Set (whose results are real sets) behave the same; the callers of the reference
+    only iterate it (`for i, j in rest_12`, basic_model.py:146-148)."""
+    __slots__ = ("_am",)
+
+    def __init__(self, argmax):
+        self._am = np.asarray(argmax)
+
+    def __len__(self):
+        return len(self._am)
+
+    def __iter__(self):
+        return zip(range(len(self._am)), self._am.tolist())
+
+    def __contains__(self, pair):
+        try:
+            i, j = pair
+        except (TypeError, ValueError):
+            return False
+        return isinstance(i, (int, np.integer)) and 0 <= i < len(self._am) and int(self._am[i]) == j
+
+    @classmethod
+    def _from_iterable(cls, it):
+        return set(it)
+
+    def __repr__(self):
+        return "AlignmentPairs(%d pairs)" % len(self._am)
 
 
 def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
@@ -80,7 +113,7 @@ def greedy_alignment(embed1, embed2, top_k, nums_threads, metric, normalize, csl
     num = e1.shape[0]
     rank, argmax, hits_cnt, rank_sum, rr_sum = greedy_alignment_device(e1, e2, dim, top_k, metric, normalize, csls_k)
     am = argmax.cpu().numpy()
-    alignment_rest = set(zip(range(num), am.tolist()))
+    alignment_rest = AlignmentPairs(am)               # (one pair per row: the reference's len(alignment_rest) == num holds)
     assert len(alignment_rest) == num
     hits = np.array(hits_cnt) / num * 100
     for i in range(len(hits)):

@@ -367,3 +367,16 @@ def test_entity_id_cache_of_the_neighbour_refresh(monkeypatch):
     ents[2] = 77                                   # an edit the three probes see
     assert trainer._entity_ids_on_device(ents, "cpu")[2] == 77 and len(calls) == 4
     trainer._IDS_CACHE.clear()
+
+
+def test_alignment_pairs_behave_as_the_reference_set():
+    """greedy_alignment's `alignment_rest` without the Python tuples (modules/finding/alignment.py:AlignmentPairs): the same set"""
+    from openea_amd.modules.finding.alignment import AlignmentPairs
+    am = np.array([2, 0, 2, 1], np.int32)
+    ref = set(zip(range(4), am.tolist()))
+    got = AlignmentPairs(am)
+    assert len(got) == 4 and got == ref and ref == got and set(got) == ref
+    assert (0, 2) in got and (1, 2) not in got and (9, 0) not in got and "x" not in got
+    assert sorted(got) == sorted(ref) and [(i, j) for i, j in got] == [(0, 2), (1, 0), (2, 2), (3, 1)]
+    assert (got & {(0, 2), (5, 5)}) == {(0, 2)} and (got - {(0, 2)}) == ref - {(0, 2)} and (got | {(7, 7)}) == ref | {(7, 7)}
+    assert got != ref - {(0, 2)} and not (got < ref) and got <= ref
