@@ -109,6 +109,11 @@ def allgather_blocks(full, bounds, group=None):
     return full
 
 
+def _collective_device(backend):
+    """where a tensor handed to the group's collectives lives ("nccl" = RCCL moves device memory)"""
+    return "cuda" if backend == "nccl" else "cpu"
+
+
 class CAbiComm:
     """The C ABI's communicator (include/openea_hip.h: oea_comm_*) over the ranks of `group`, for the one-call partitioned
     epoch (oea_triple_epoch_range_comm).
@@ -139,23 +144,31 @@ class CAbiComm:
         self.callbacks = (self.world > 1 and backend != "nccl") or os.environ.get("OEA_COMM_CALLBACKS") == "1"
         if not self.callbacks:
             # every rank must take the same branch: the outcome of the RCCL set-up is agreed on through the group
+            # (every rank runs the SAME sequence of group operations whatever fails locally -- rank 0 broadcasts its id
+            # or None, every rank treats None as "no RCCL", oea_comm_init runs only with a valid id, the MIN all-reduce decides)
             ok = 1
-            try:
-                uid = (C.c_char * 128)()
-                if self.rank == 0:
+            box = [None]
+            if self.rank == 0:
+                try:
+                    uid = (C.c_char * 128)()
                     check(lib.oea_comm_unique_id(uid))
-                box = [bytes(uid.raw) if self.rank == 0 else None]
-                if self.world > 1:
-                    src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
-                    dist.broadcast_object_list(box, src=src, group=group)
-                buf = (C.c_char * 128).from_buffer_copy(box[0])
-                check(lib.oea_comm_init(buf, self.rank, self.world, C.byref(self.handle)))
-            except Exception as e:            # noqa: BLE001 -- e.g. librccl not loadable, ranks sharing a device
-                ok = 0
-                print("[openea_amd] the C ABI's RCCL communicator could not be made (%s): collectives of the one-call epoch go "
-                      "through torch.distributed callbacks" % str(e)[:200], file=sys.stderr)
+                    box = [bytes(uid.raw)]
+                except Exception as e:        # noqa: BLE001 -- e.g. librccl not loadable: the others must still get an answer
+                    self._note_no_rccl(e)
             if self.world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+                src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+                dist.broadcast_object_list(box, src=src, group=group)
+            if box[0] is None:
+                ok = 0
+            else:
+                try:
+                    buf = (C.c_char * 128).from_buffer_copy(box[0])
+                    check(lib.oea_comm_init(buf, self.rank, self.world, C.byref(self.handle)))
+                except Exception as e:        # noqa: BLE001 -- e.g. ranks sharing a device
+                    ok = 0
+                    self._note_no_rccl(e)
+            if self.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=_collective_device(backend))
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 ok_all = int(flag.item())
             else:
@@ -168,6 +181,24 @@ class CAbiComm:
             self.callbacks = True
         self._fn = _lib.COMM_CALLBACK(self._collective)            # kept alive with the object
         check(lib.oea_comm_init_callbacks(self.rank, self.world, C.cast(self._fn, C.c_void_p), None, C.byref(self.handle)))
+
+    @staticmethod
+    def _note_no_rccl(e):
+        import sys
+        print("[openea_amd] the C ABI's RCCL communicator could not be made (%s): collectives of the one-call epoch go "
+              "through torch.distributed callbacks" % str(e)[:200], file=sys.stderr)
+
+    def close(self):
+        """oea_comm_destroy (the RCCL communicator and its staging buffers); idempotent"""
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None and getattr(h, "value", None):
+            try:
+                self.lib.oea_comm_destroy(h)
+            except Exception:            # noqa: BLE001 -- interpreter shutdown
+                pass
+
+    def __del__(self):
+        self.close()
 
     _NP = {0: np.float32, 1: np.float64, 2: np.int64}
 

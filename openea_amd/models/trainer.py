@@ -196,6 +196,13 @@ class TripleTrainer:
                       file=sys.stderr)
                 self.comm = None
 
+    def close(self):
+        """release the C ABI communicator of the partitioned step (RCCL communicator + staging buffers); the garbage collector
+        does the same through CAbiComm.__del__"""
+        comm, self.comm = getattr(self, "comm", None), None
+        if comm is not None:
+            comm.close()
+
     def _step_partitioned(self, pos, neg):
         """GRAD | pack | reduce-scatter + relation all-reduce | apply owned rows | all-gather | unpack"""
         from . import dist as mdist

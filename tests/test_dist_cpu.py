@@ -170,3 +170,68 @@ def _spmm_worker(rank, world, seed):
 
 def test_row_sharded_aggregate_equals_unsharded():
     _run(_spmm_worker, 2, 5)
+
+
+class _FakeLib:
+    """stand-in for libopenea_hip.so's communicator entry points (no GPU here): records the calls"""
+
+    def __init__(self, rank, fail_unique_id=False, fail_init_on=()):
+        self.rank, self.fail_unique_id, self.fail_init_on, self.calls = rank, fail_unique_id, fail_init_on, []
+
+    def oea_comm_unique_id(self, uid):
+        self.calls.append("unique_id")
+        if self.fail_unique_id:
+            return -1
+        uid.raw = bytes(range(128))
+        return 0
+
+    def oea_comm_init(self, buf, rank, world, handle):
+        self.calls.append("init")
+        assert bytes(buf.raw) == bytes(range(128))
+        if rank in self.fail_init_on:
+            return -1
+        handle._obj.value = 1000 + rank
+        return 0
+
+    def oea_comm_init_callbacks(self, rank, world, fn, user, handle):
+        self.calls.append("init_callbacks")
+        handle._obj.value = 2000 + rank
+        return 0
+
+    def oea_comm_destroy(self, h):
+        self.calls.append("destroy")
+        return 0
+
+    def oea_last_error(self):
+        return b"fake failure"
+
+
+def _comm_setup_worker(rank, world, mode):
+    import openea_amd._lib as _lib
+    from openea_amd import ops
+    fake = _FakeLib(rank, fail_unique_id=(mode == "no_rccl"), fail_init_on=(1,) if mode == "init_fails_on_1" else ())
+    ops.lib = lambda: fake
+    _lib.load = lambda: fake
+    odist.dist.get_backend = lambda group=None: "nccl"           # take the RCCL branch over the gloo group
+    odist._collective_device = lambda backend: "cpu"
+    c = odist.CAbiComm(None)
+    if mode == "ok":
+        assert not c.callbacks and c.handle.value == 1000 + rank and "init_callbacks" not in fake.calls
+    else:
+        # rank 0 could not make an id / rank 1 could not join: EVERY rank ends on the callbacks back end (no hang, no mismatch)
+        assert c.callbacks and c.handle.value == 2000 + rank and fake.calls[-1] == "init_callbacks"
+        if mode == "no_rccl":
+            assert "init" not in fake.calls                    # oea_comm_init only ever runs with a valid id
+        else:
+            assert ("destroy" in fake.calls) == (rank == 0)      # the communicator made on rank 0 alone is dropped
+    dist.barrier()
+    c.close()
+    c.close()
+    assert fake.calls.count("destroy") == (2 if (mode == "init_fails_on_1" and rank == 0) else 1)
+
+
+def test_cabi_comm_setup_agrees_on_the_back_end_when_rccl_fails_on_one_rank():
+    """when rank 0's oea_comm_unique_id fails the other ranks used to wait in broadcast_object_list while
+    rank 0 went on to the all-reduce -- mismatched collectives.  Now every rank runs broadcast (id or None) -> MIN all-reduce."""
+    for mode in ("ok", "no_rccl", "init_fails_on_1"):
+        _run(_comm_setup_worker, 2, mode)

@@ -264,9 +264,10 @@ def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
     (OEA_BENCH_ONE_GPU / OEA_BENCH_BACKEND, bench.py's test hooks): the partitioned step and the row-sharded eval /
     neighbour legs run through the timed regions and rank 0 prints one well-formed line."""
     import json
-    env = dict(os.environ, OEA_BENCH_ONE_GPU="1", OEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    detail = str(tmp_path / "detail.json")
+    env = dict(os.environ, OEA_BENCH_ONE_GPU="1", OEA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OEA_BENCH_DETAIL=detail)
     env.pop("WORLD_SIZE", None)
-    # the N > 1 default is the EN-FR-100K-V1 shape; with both ranks on one GPU and the collectives staged through the host the
+    # the default at every N is the EN-FR-100K-V1 shape; with both ranks on one GPU and the collectives staged through the host the
     # test takes the 15K shape (same code path: strong scaling, per-step partition exchange from one C call per epoch)
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--repeats", "3", "--shape", "EN-FR-15K-V1"]
     if launcher == "self":
@@ -278,8 +279,14 @@ def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "strong" and j["value"] > 0
+    assert lines[0] == p.stdout.decode().strip().splitlines()[-1] and len(lines[0]) < 4096      # the compact line is the LAST line
+    c = json.loads(lines[0])
+    assert c["n_gpus"] == 2 and c["steps"] == 10 and c["warmup"] == 3 and c["scaling"] == "strong" and c["value"] > 0
+    assert 0 < c["roofline"]["frac"] <= 1 and c["roofline"]["avg_kernel_us"] > 0 and c["extra"]["exchange_mode"] == "step"
+    assert c["extra"]["exchange_phases"]["steps_timed"] == 10 and c["extra"]["single_gpu_same_config"]["value"] > 0
+    assert c["extra"]["collective_world_size"] == 2 and c["extra"]["eval_pairs_per_s_inner"] > 0
+    j = json.load(open(detail))                 # everything measured: bench_detail.json
+    assert j["value"] == c["value"] and j["roofline"]["frac"] == c["roofline"]["frac"]
     assert j["roofline"]["launches_timed"] > 0 and j["roofline"]["avg_kernel_us"] > 0 and j["roofline"]["apply_rows_avg_us"] > 0
     assert 0 < j["roofline"]["frac"] <= 1 and 0 < j["roofline"]["frac_sec8d"] <= 1
     x = j["extra"]

@@ -380,3 +380,45 @@ def test_alignment_pairs_behave_as_the_reference_set():
     assert sorted(got) == sorted(ref) and [(i, j) for i, j in got] == [(0, 2), (1, 0), (2, 2), (3, 1)]
     assert (got & {(0, 2), (5, 5)}) == {(0, 2)} and (got - {(0, 2)}) == ref - {(0, 2)} and (got | {(7, 7)}) == ref | {(7, 7)}
     assert got != ref - {(0, 2)} and not (got < ref) and got <= ref
+
+
+def test_bench_line_is_compact_strict_json():
+    """the LAST stdout line of bench.py must reach the driver: BENCH_r04's 21.8 KB line was not parsed (the driver keeps an 8 KB
+    tail).  compact_line() of a full-size result (round 4's own detail, with kernel-name-keyed counter dictionaries) stays
+    under 4 KB, is strict JSON, and carries the contract's keys + roofline + roofline_eval + cpu_baseline."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_driver_like.json")))
+    assert len(json.dumps(full)) > 20000
+    # the round-5 layout: the side shape block is shape_15k, the eval legs sit in extra
+    full["extra"]["shape_15k"] = full["extra"].pop("shape_100k")
+    full["extra"]["gnn"]["alinet_eval_70000x1200"] = {"inner_ms": 21.0, "inner_csls10_ms": 55.5, "frac": 0.67, "csls_frac": 0.5,
+                                                      "peak": 833.3, "bf16_prefilter": True, "records_per_row": 12.5, "fallback": False,
+                                                      "note": "x" * 3000}
+    full["extra"]["exchange_phases"] = {"grad_us": 1.0, "pack_us": 2.0, "note": "y" * 2000, "steps_timed": 20}
+    full["extra"]["junk"] = {"k" * 90: list(range(500))}
+    line = bench.compact_line(full, "bench_detail.json")
+    assert "\n" not in line and len(line.encode()) <= bench.COMPACT_LIMIT < 8000
+
+    def no_constants(x):
+        raise ValueError("non-strict JSON constant %s" % x)
+    j = json.loads(line, parse_constant=no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_eval", "cpu_baseline", "extra", "detail"):
+        assert k in j, k
+    assert j["value"] == full["value"] and j["ms_per_step"] == full["ms_per_step"] and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] == round(r["achieved"] / r["peak"], 4) and "traffic" in r and r["avg_kernel_us"] > 0
+    assert j["roofline_eval"]["bound"] == "mfma" and 0 < j["roofline_eval"]["frac"] <= 1
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["kind"] == "port"
+    x = j["extra"]
+    assert x["shape_15k"]["value"] > 0 and x["gnn"]["alinet_eval_70000x1200"]["inner_ms"] == 21.0
+    assert "note" not in x["gnn"]["alinet_eval_70000x1200"] and "junk" not in x and "note" not in x["exchange_phases"]
+    # a block that alone would push the line past the limit is dropped, never the contract's keys
+    full["extra"]["shape_15k"]["value"] = 1.0
+    full["config"]["workload"] = "w" * 5000
+    full["extra"]["gnn"] = {"error": "e" * 9000}
+    line2 = bench.compact_line(full, None)
+    assert len(line2.encode()) <= bench.COMPACT_LIMIT and json.loads(line2)["roofline"]["frac"] == r["frac"]
