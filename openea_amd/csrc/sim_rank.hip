@@ -27,6 +27,25 @@ constexpr int TILE = 128;      // block tile edge (both operands)
 constexpr int BK = 32;         // K chunk
 constexpr int LDS_LD = BK + 4; // padded row stride (floats)
 
+// ---- XCD-aware order of the (query tile, candidate chunk) work items (round 5) --------------------------------------------------
+// Block b of a launch runs on XCD b % 8 (observed dispatch rule, MI355X_MICROARCH.md: "for speed only"), and every XCD has its own
+// 4 MB L2.  In launch order (query tile fastest) the 64 workgroups resident on one XCD hold 64 DIFFERENT query tiles: from K = 300
+// on their operand panels (128 rows x Kp x 4 B each, re-read once per candidate tile) no longer fit the L2 and every chunk comes
+// from the Infinity Cache -- 185 GB per 70,000^2 x 1,200 sweep.  Here XCD c takes the contiguous share [c * per, (c + 1) * per) of
+// the items in CHUNK-FASTEST order: its resident workgroups are ~64 / ny query tiles x all ny candidate chunks, i.e. 64 / ny + ny
+// operand streams instead of 65, each k chunk fetched from the fabric once and hit in L2 by the other workgroups that walk the
+// same panel in step.  per = 0: the plain order (OEA_XCD_MAP=0, ablation).  Correctness never depends on the placement.
+struct TileGrid { unsigned nx, ny, per; };
+
+__device__ __forceinline__ bool tile_grid_item(const TileGrid &g, unsigned &bx, unsigned &by) {
+    const unsigned L = blockIdx.x;
+    if (g.per == 0u) { bx = L % g.nx; by = L / g.nx; return L < g.nx * g.ny; }
+    const unsigned slot = L >> 3, w = (L & 7u) * g.per + slot;
+    if (slot >= g.per || w >= g.nx * g.ny) return false;
+    bx = w / g.ny; by = w % g.ny;
+    return true;
+}
+
 __device__ __forceinline__ uint32_t f2ord(float f) {   // order-preserving float -> uint
     uint32_t u = __float_as_uint(f + 0.0f);   // -0 -> +0 so that key order == float order
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -352,8 +371,25 @@ __device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, con
     }
 }
 
-// tile_pipeline_packed for the bf16 layout: chunks of two k-steps (32 k = 128 B per row), LDS-DMA staging unchanged
-template <class MTile, class Epilogue>
+// tile_pipeline_packed for the bf16 layout: chunks of two k-steps (32 k = 128 B per row), LDS-DMA staging unchanged.
+// K BLOCKS (round 5; KBLK: the evaluation / CSLS sweeps -- the neighbour sweeps' epilogues have no 64 registers to spare and run at
+// K = 100): the MFMA accumulators restart from zero every kBf16BlockChunks chunks (128 k) and
+// the block results are added in block order on the VALU (64 v_add per 96 MFMAs).  The accumulation term of the certificate
+// (bf16_eps_rel) then counts the products of ONE block: the error of n additions in any order is <= n u (sum of |terms|), and the
+// blocks' sums of |terms| add up to <= |q||c| (Cauchy-Schwarz per block, then over the blocks) -- 3 * 128 + (blocks - 1)
+// roundings instead of 3 * Kp: at K = 1,200 the bound drops from 5.9e-4 to 1.3e-4 and with it the records per row.
+constexpr int kBf16BlockChunks = 4;
+
+__device__ __forceinline__ void add_acc(f32x16 (&tot)[2][2], const f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[a][b][r] += acc[a][b][r];
+}
+
+template <bool KBLK, class MTile, class Epilogue>
 __device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
                                                    int64_t n0, int64_t n_tiles, MTile m_tile, float *As, float *Bs,
                                                    Epilogue epilogue) {
@@ -365,8 +401,9 @@ __device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am,
     stage_packed(am, kp, m_tile(0), 0, As);
     stage_packed(bn, kp, n0, 0, Bs);
     __syncthreads();
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
     zero_acc(acc);
+    zero_acc(tot);
     int64_t t = 0;
     int kc = 0;
     for (int64_t it = 0; it < total; ++it) {
@@ -379,15 +416,105 @@ __device__ __forceinline__ void tile_pipeline_bf16(const float *__restrict__ am,
             stage_packed(bn, kp, n0, kc1 * BK, Bs + (cur ^ 1) * BUF);
         }
         mma_chunk_bf16(As + cur * BUF, Bs + cur * BUF, min(2, S - 2 * kc), acc);
+        ++kc;
+        if constexpr (KBLK) {
+            if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {   // end of a 128-k block: block sums in block order (one
+                add_acc(tot, acc);                                      // block when K <= 128: tot = 0 + acc, the same values)
+                zero_acc(acc);
+            }
+        }
         // the epilogue works on registers only: it runs BEFORE the barrier (and the vmcnt(0) in front of it), so the DMA of the
         // next tile's first chunk lands behind it instead of being waited for first (the bf16 chunks are too short to hide it)
-        if (++kc == nchunk) {
-            epilogue(t, acc);
-            zero_acc(acc);
+        if (kc == nchunk) {
+            if constexpr (KBLK) { epilogue(t, tot); zero_acc(tot); }
+            else { epilogue(t, acc); zero_acc(acc); }
             kc = 0;
             ++t;
         }
         __syncthreads();
+    }
+}
+
+// ---- 256 x 128 tiles, three LDS stages (round 5: K > 128, i.e. AliNet's 1,200-d / RDGCN's 300-d evaluation rows) ---------------
+// tile_pipeline_bf16 keeps ONE 32 KB chunk per workgroup in flight (64 KB per CU): with ~1.9 us between the issue of a chunk's
+// LDS-DMA and its arrival under load that is 34 GB/s per CU -- the 70,000^2 x 1,200 sweep sat at 34 % of the bf16 pipe whatever
+// the epilogue did.  Here 512 threads (8 waves as 4 (M) x 2 (N), each still a 64 x 64 sub-tile: every epilogue is unchanged) own
+// 256 candidate rows x 128 query rows -- 3/4 of the operand bytes per flop -- and a ring of THREE 48 KB stages keeps TWO chunks in
+// flight (96 KB per CU): a chunk is waited for with a COUNTED s_waitcnt vmcnt(6) (6 DMA instructions per wave and stage: the
+// newer stage stays in flight) in front of a RAW s_barrier -- __syncthreads() would drain the DMA queue (vmcnt(0)) on every chunk.
+// K blocks as in tile_pipeline_bf16<true>.  LDS: 3 x (256 + 128) x 128 B = 144 KB (dynamic), one workgroup per CU.
+constexpr int BIG_MT = 256;                       // candidate rows of a tile
+constexpr int BIG_A = BIG_MT * PLD;               // floats of an A stage
+constexpr int BIG_STAGE = BIG_A + TILE * PLD;     // + the B stage: 48 KB
+constexpr int BIG_STAGES = 3;
+constexpr int BIG_LDS_BYTES = BIG_STAGES * BIG_STAGE * 4;
+
+__device__ __forceinline__ void stage_packed_big(const float *__restrict__ am, const float *__restrict__ bn, int kp, int64_t a_row0,
+                                                 int64_t b_row0, int k0, float *__restrict__ slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // 8 waves: 32 A rows + 16 B rows each
+    const int sub = lane >> 3;
+    const float *asrc = am + (a_row0 + wave * 32 + sub) * kp + k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float *base = slot + (wave * 4 + j) * 8 * PLD;
+        const int swz = (4 * j + (sub >> 1)) & 7;                         // ((row >> 1) & 7) of row = 32 wave + 8 j + sub
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + (int64_t)j * 8 * kp + 4 * ((lane & 7) ^ swz)),
+                                         reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
+                                         16, 0, 0);
+    }
+    const float *bsrc = bn + (b_row0 + wave * 16 + sub) * kp + k0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float *base = slot + BIG_A + (wave * 2 + j) * 8 * PLD;
+        const int swz = (4 * j + (sub >> 1)) & 7;                         // row = 16 wave + 8 j + sub
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (int64_t)j * 8 * kp + 4 * ((lane & 7) ^ swz)),
+                                         reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
+                                         16, 0, 0);
+    }
+}
+
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
+                                                       int64_t n0, int64_t n_tiles, MTile m_tile, float *lds, Epilogue epilogue) {
+    const int S = (dim + 15) / 16;
+    const int nchunk = (S + 1) / 2;
+    const int64_t total = n_tiles * nchunk;
+    if (total == 0) return;
+    int64_t ti = 0;                                  // (tile, chunk) of the next stage to issue
+    int ki = 0;
+    auto issue = [&](int64_t it) {
+        stage_packed_big(am, bn, kp, m_tile(ti), n0, ki * BK, lds + (int)(it % BIG_STAGES) * BIG_STAGE);
+        if (++ki == nchunk) { ki = 0; ++ti; }
+    };
+    issue(0);
+    if (total > 1) issue(1);
+    f32x16 acc[2][2], tot[2][2];
+    zero_acc(acc);
+    zero_acc(tot);
+    int64_t t = 0;
+    int kc = 0;
+    for (int64_t it = 0; it < total; ++it) {
+        // stage `it` has landed when at most the newer stage's 6 DMA instructions of this wave are outstanding (loads complete in
+        // order; whatever the epilogue issued since only makes the count stricter); the barrier then covers the other waves' parts
+        // and tells everybody that the slot read in iteration it - 1 is free
+        if (it + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 2 < total) issue(it + 2);
+        const float *slot = lds + (int)(it % BIG_STAGES) * BIG_STAGE;
+        mma_chunk_bf16(slot, slot + BIG_A, min(2, S - 2 * kc), acc);
+        ++kc;
+        if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {
+            add_acc(tot, acc);
+            zero_acc(acc);
+        }
+        if (kc == nchunk) {
+            epilogue(t, tot);
+            zero_acc(tot);
+            kc = 0;
+            ++t;
+        }
     }
 }
 
@@ -936,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void topk_append_sym_kernel(
             if (offdiag && my_j < n) ccounts[(my_j * T + qt) * 2 + wn] = (uint8_t)min(my_cnt, 255);
         };
     auto m_tile = [=](int64_t t) { return (int64_t)(item.y + t) * TILE; };
-    if constexpr (BF16) tile_pipeline_bf16(e, ld, e, dim, q0, (int64_t)(item.z - item.y), m_tile, As, Bs, epilogue);
+    if constexpr (BF16) tile_pipeline_bf16<false>(e, ld, e, dim, q0, (int64_t)(item.z - item.y), m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(e, n, ld, e, n, ld, dim, q0, (int64_t)(item.z - item.y), m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -1130,7 +1257,7 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const int64_t n_tiles = (int64_t)(item.z - item.y);
     auto m_tile = [=](int64_t t) { return (int64_t)(item.y + t) * TILE; };
     if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(e, kp, e, q0, n_tiles, m_tile, As, epilogue);
-    else tile_pipeline_bf16(e, kp, e, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    else tile_pipeline_bf16<false>(e, kp, e, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     if (lane == 0) {
         coff[n_tiles] = (int32_t)(cpos >> 3);
         row_cnt[wid] = (int32_t)(min(rpos, rbytes) >> 3);
@@ -1169,7 +1296,7 @@ __global__ __launch_bounds__(256, 2) void topk_stream_redo_kernel(
         }
         const int64_t my_j = c0 + my_jl;
         const float my_tc = (ct != qt && my_j < n) ? thr[my_j] - tol : INFINITY;
-        tile_pipeline_bf16(e, kp, e, dim, q0, 1, [=](int64_t) { return c0; }, As, Bs, [&](int64_t, f32x16 (&acc)[2][2]) {
+        tile_pipeline_bf16<false>(e, kp, e, dim, q0, 1, [=](int64_t) { return c0; }, As, Bs, [&](int64_t, f32x16 (&acc)[2][2]) {
             if (wave != ent.z) return;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -2058,6 +2185,16 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
 }
 
 
+// launch geometry of the XCD-aware item order (tile_grid_item): 8 * per blocks, XCD c = items [c * per, (c + 1) * per)
+static TileGrid make_tile_grid(unsigned nx, unsigned ny) {
+    static const bool on = [] { const char *e = getenv("OEA_XCD_MAP"); return !(e && e[0] == '0'); }();
+    TileGrid g;
+    g.nx = nx; g.ny = ny;
+    g.per = on ? (nx * ny + 7u) / 8u : 0u;
+    return g;
+}
+static unsigned tile_grid_blocks(const TileGrid &g) { return g.per ? 8u * g.per : g.nx * g.ny; }
+
 // ---- CSLS means in ONE sweep (similarity.py:57-83 without S or S^T in HBM) ------------------------------------------------
 // r_i = mean of the k largest of row i of S = e1 e2^T, c_j = the same for column j.  Both are top-k problems with k ~ 10, so
 // a per-row / per-column threshold estimated from a strided sample (as in the strip-free neighbour search, topk.hip) lets
@@ -2068,28 +2205,35 @@ static int pick_chunks(int64_t q_tiles, int64_t c_tiles, int *tiles_per_chunk) {
 // BF16 (round 4): q / c are the hi / lo split rows, the values v~ are within *tol_ptr of the exact ones, both cuts are lowered
 // by that bound and every list entry is a PAIR (v~, index of the other side) -- list_mean_rows_kernel<true> finds the entries that
 // can belong to the exact top k and recomputes them with the exact chain.
-template <bool PACKED, bool BF16, int NCH = 0>
-__global__ __launch_bounds__(256, 2) void csls_append_kernel(
+// NW = 8 (BF16, K > 128): 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big, dynamic LDS);
+// the query lists then have 8 * chunks segments (one per chunk, wave row and half-wave)
+template <bool PACKED, bool BF16, int NCH = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
     float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts,
-    const float *__restrict__ tol_ptr) {
+    const float *__restrict__ tol_ptr, TileGrid tg) {
     constexpr uint32_t ES = BF16 ? 8u : 4u;                 // bytes per list entry
-    __shared__ __attribute__((aligned(16))) float lds[NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD];
+    constexpr int MT = NW * 32;                             // candidate rows of a tile
+    extern __shared__ __attribute__((aligned(16))) float csls_dyn_lds[];          // NW == 8: BIG_LDS_BYTES
+    __shared__ __attribute__((aligned(16))) float lds_static[NW == 8 ? 4 : (NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD)];
+    float *lds = NW == 8 ? csls_dyn_lds : lds_static;
     float *As = lds, *Bs = lds + 2 * TILE * LDS_LD;
+    unsigned bx, by;
+    if (!tile_grid_item(tg, bx, by)) return;
     // candidate j owns 2 * nqt segments of ccap values: one per (query tile, wave column) -- written by ONE wave, whose
     // half-waves hold the same candidate for 32 queries each: slots = prefix counts of a wave ballot (no atomics, no barrier;
     // the first version took a returning LDS atomic per survivor between two barriers per tile)
-    const int nqt = (int)gridDim.x, qt = (int)blockIdx.x;
+    const int nqt = (int)tg.nx, qt = (int)bx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l32 = lane & 31;
-    const int64_t q0 = (int64_t)blockIdx.x * TILE;
-    const int64_t nct = (nc + TILE - 1) / TILE;
-    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t q0 = (int64_t)bx * TILE;
+    const int64_t nct = (nc + MT - 1) / MT;
+    const int64_t ct_begin = (int64_t)by * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
-    const int nseg = 4 * (int)gridDim.y;
-    const int sidx = ((int)blockIdx.y * 2 + wm) * 2 + half;
+    const int nseg = NW * (int)tg.ny;
+    const int sidx = ((int)by * (NW / 2) + wm) * 2 + half;
     float th[2];
     uint32_t boff[2], bbeg[2], blast[2];
     int64_t qi[2];
@@ -2107,7 +2251,7 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
     const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);     // lane l32 = tm * 16 + r looks after that candidate
     const uint32_t below = (1u << l32) - 1u;
     auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
-            const int64_t c0 = (ct_begin + t) * TILE;
+            const int64_t c0 = (ct_begin + t) * MT;
             const int64_t my_j = c0 + my_jl;
             const float my_tc = my_j < nc ? thr_c[my_j] - tol : INFINITY;
             int my_cnt = 0;
@@ -2153,10 +2297,11 @@ __global__ __launch_bounds__(256, 2) void csls_append_kernel(
             }
             if (my_j < nc) ccounts[(my_j * nqt + qt) * 2 + wn] = my_cnt;
         };
-    auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
+    auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
-    else if constexpr (BF16) tile_pipeline_bf16(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
+    else if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (BF16) tile_pipeline_bf16<true>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -2453,7 +2598,8 @@ static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedO
     const int64_t n_pad = (n + TILE - 1) / TILE * TILE;
     *n_pad_out = n_pad;
     out->kp = (dim + BK - 1) / BK * BK;
-    const size_t need = sizeof(float) * (size_t)n_pad * out->kp;
+    // (+ one tile of rows: the 256-candidate tiles of tile_pipeline_bf16_big read up to 128 rows past n_pad; products discarded)
+    const size_t need = sizeof(float) * (size_t)(n_pad + TILE) * out->kp;
     if (!sl.used) OEA_CHECK_HIP(hipEventCreateWithFlags(&sl.used, hipEventDisableTiming));
     if (need > sl.cap) {
         if (sl.p) OEA_CHECK_HIP(hipFree(sl.p));
@@ -2569,22 +2715,26 @@ __device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const f
     }
 }
 
-// NCH = 0: both operands through LDS (tile_pipeline_bf16, any Kp); NCH = Kp / 32 in {1..4}: B in registers (tile_pipeline_bf16_breg)
-template <bool WARM, bool CSLS, int NCH>
+// NCH = 0: both operands through LDS (tile_pipeline_bf16, any Kp); NCH = Kp / 32 in {1..4}: B in registers (tile_pipeline_bf16_breg);
+// NW = 8: 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big; tiles_per_chunk counts THOSE tiles)
+template <bool WARM, bool CSLS, int NCH, int NW = 4>
 __device__ __forceinline__ void rank_bf16_body(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
     const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,
     const float *__restrict__ csls_c, int tiles_per_chunk, int64_t gold_off,
     int32_t *__restrict__ rank, unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap,
-    float *As, float *Bs) {
+    TileGrid tg, float *As, float *Bs) {
+    unsigned bx, by;
+    if (!tile_grid_item(tg, bx, by)) return;               // (the whole workgroup: padding of the XCD-aware launch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t q0 = (int64_t)blockIdx.x * TILE;
-    const int64_t nct = (n2 + TILE - 1) / TILE;
-    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t q0 = (int64_t)bx * TILE;
+    constexpr int MT = NW * 32;                              // candidate rows of a tile
+    const int64_t nct = (n2 + MT - 1) / MT;
+    const int64_t ct_begin = (int64_t)by * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
     const float tol0 = tol_ptr[0];                         // bound on |s~ - s|; tol_ptr[1] = slack scale of the CSLS expression
-    const unsigned wid = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+    const unsigned wid = (by * tg.nx + bx) * (unsigned)NW + (unsigned)wave;
     uint2 *__restrict__ my_rec = rec + (size_t)wid * slice_cap;
     unsigned nrec = 0;                                     // wave-uniform
     int64_t qi[2];
@@ -2613,7 +2763,7 @@ __device__ __forceinline__ void rank_bf16_body(
         nrec += (unsigned)__popcll(m);
     };
     auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
-            const int64_t c0 = (ct_begin + t) * TILE;
+            const int64_t c0 = (ct_begin + t) * MT;
             const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)                 // the other lanes / workgroups of the row may have raised the bound
@@ -2627,16 +2777,17 @@ __device__ __forceinline__ void rank_bf16_body(
                 const int64_t my_j = (int64_t)jb + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
                 my_c = my_j < n2 ? csls_c[my_j] : 0.f;
             }
-            if (c0 + TILE <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
+            if (c0 + MT <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
             else rank_bf16_tile<WARM, false, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
                 if (dirty[tn]) { atomicMax(lbrow + qi[tn], f2ord(lb[tn])); dirty[tn] = false; }
         };
-    auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
+    auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
-    else tile_pipeline_bf16(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    if constexpr (NW == 8) tile_pipeline_bf16_big(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
+    else tile_pipeline_bf16<true>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         if (WARM) {
@@ -2658,8 +2809,8 @@ __device__ __forceinline__ void rank_bf16_body(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,                            \
     const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,                            \
     const float *__restrict__ csls_c, int tiles_per_chunk, int64_t gold_off, int32_t *__restrict__ rank,                            \
-    unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap
-#define OEA_RANK_BF16_ARGS qp, n1, kp, cp, n2, dim, gold, tol_ptr, csls_r, csls_c, tiles_per_chunk, gold_off, rank, lbrow, rec, rec_cnt, slice_cap
+    unsigned *__restrict__ lbrow, uint2 *__restrict__ rec, unsigned *__restrict__ rec_cnt, unsigned slice_cap, TileGrid tg
+#define OEA_RANK_BF16_ARGS qp, n1, kp, cp, n2, dim, gold, tol_ptr, csls_r, csls_c, tiles_per_chunk, gold_off, rank, lbrow, rec, rec_cnt, slice_cap, tg
 
 template <bool WARM, bool CSLS>
 __global__ __launch_bounds__(256, 2) void rank_bf16_kernel(OEA_RANK_BF16_PARAMS) {
@@ -2672,6 +2823,12 @@ template <bool WARM, bool CSLS, int NCH>
 __global__ __launch_bounds__(256, 2) void rank_bf16_breg_kernel(OEA_RANK_BF16_PARAMS) {
     __shared__ __attribute__((aligned(16))) float As[4 * TILE * PLD];           // 2 slots x 2 chunks
     rank_bf16_body<WARM, CSLS, NCH>(OEA_RANK_BF16_ARGS, As, nullptr);
+}
+
+template <bool CSLS>
+__global__ __launch_bounds__(512, 2) void rank_bf16_big_kernel(OEA_RANK_BF16_PARAMS) {
+    extern __shared__ __attribute__((aligned(16))) float big_lds[];                // BIG_LDS_BYTES
+    rank_bf16_body<false, CSLS, 0, 8>(OEA_RANK_BF16_ARGS, big_lds, nullptr);
 }
 
 // ONE grid-stride prologue: both bf16 packs, the gold similarities (the exact k-ordered chain), the max row norms of both
@@ -2879,7 +3036,7 @@ __global__ __launch_bounds__(256, 2) void sim_bf16_store_kernel(const float *__r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * TILE, c0 = (int64_t)blockIdx.x * TILE;
-    tile_pipeline_bf16(
+    tile_pipeline_bf16<true>(
         e1p, kp, e2p, dim, c0, 1, [=](int64_t) { return m0; }, As, Bs,
         [&](int64_t, f32x16 (&acc)[2][2]) {
             float *tile = out + m0 * ld_out + c0;
@@ -2923,7 +3080,8 @@ struct CslsPlan {
 };
 constexpr int kCslsFb = 128, kCslsSlow = 64;
 
-static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
+// big: the sweep runs on 256-candidate tiles with 8 waves (csls_append_kernel<.., 8>): chunks count those tiles, 8 segments per chunk
+static CslsPlan plan_csls(int64_t n1, int64_t n2, int k, bool big = false) {
     CslsPlan p;
     if (n1 < 4096 || n2 < 4096 || k > 32) return p;
     p.sample = std::max(n1, n2) >= 32768 ? 4096 : 1024;       // keeps r n / S, the survivors per row, in the low hundreds
@@ -2934,8 +3092,8 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
     p.r2 = rank_of(n1);
     const double m1 = (double)p.r1 * n2 / p.sample, m2 = (double)p.r2 * n1 / p.sample;      // survivors per row / per column
     if (m1 * (1.0 + 5.0 / std::sqrt((double)p.r1)) > kMeanRegs * 64 || m2 * (1.0 + 5.0 / std::sqrt((double)p.r2)) > kMeanRegs * 64) return p;
-    p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, TILE), &p.tpc);
-    p.nseg = 4 * p.chunks;
+    p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, big ? BIG_MT : TILE), &p.tpc);
+    p.nseg = (big ? 8 : 4) * p.chunks;
     if (p.nseg > kMeanSeg) return p;
     // the threshold is the r-th of a sample: the survivor count of a row scales with a factor of relative spread 1 / sqrt(r)
     // COMMON to its segments, on top of each segment's own sqrt(m) noise
@@ -2965,7 +3123,7 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k) {
 
 }  // namespace
 
-static float bf16_eps_rel(int dim);
+static float bf16_eps_rel(int dim, bool k_blocks);
 static int pack_operand_bf16(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out);
 
 namespace oea {
@@ -3013,7 +3171,7 @@ int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
     row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
-    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
+    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim, false));
     // (the B-in-registers pipeline, NCH = Kp / 32, spills in this kernel -- its epilogue already takes the register file: 13.3 -> 20.8 ms
     //  at 100,000 rows; it stays on the LDS pipeline.  OEA_TOPK_STREAM_NCH = 1..4 selects the register form for experiments.)
     static const int nch_env = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return e ? atoi(e) : 0; }();
@@ -3040,7 +3198,7 @@ int topk_append_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
     row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
-    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim));
+    knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim, false));
     topk_append_sym_kernel<true, true><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items), nseg,
                                                                           cap, list_vals, list_cols, counts, T, ccap,
                                                                           static_cast<uint2 *>(clists), ccounts, spill_cnt,
@@ -3130,18 +3288,25 @@ int oea_rank_eval(const float *e1, int64_t n1, int32_t ld1, const float *e2, int
 // random rank: 30 records per row at dim 100, 114 at dim 300)
 static unsigned bf16_rec_cap(int64_t n1, int dim) { return (unsigned)std::min<int64_t>((96 + (int64_t)dim) * n1 + (1 << 20), (int64_t)1 << 30); }
 // an upper bound of the sweep's wave count: pick_chunks gives at most target / q_tiles + 1 chunks per query tile
-static int64_t bf16_max_waves(int64_t n1) { return 4 * (oea::ceil_div(n1, TILE) + 16384); }
+static int64_t bf16_max_waves(int64_t n1) { return 8 * (oea::ceil_div(n1, TILE) + 16384); }
 
 size_t oea_rank_eval_bf16_workspace_bytes(int64_t n1, int32_t dim) {
     auto a256 = [](size_t x) { return (x + 255) / 256 * 256; };
     return a256(8 * (size_t)n1) + 2 * a256(4 * (size_t)n1) + 256 + a256(4 * (size_t)(2 + bf16_max_waves(n1))) + 8 * (size_t)bf16_rec_cap(n1, dim);
 }
 
-static float bf16_eps_rel(int dim) {
+static float bf16_eps_rel(int dim, bool k_blocks) {
     const int kp16 = (dim + 15) / 16 * 16;
-    // split residue (3.02 * 2^-18 of |a||b|) + fp32 accumulation of 3 * Kp products, bounded term by term with a chopping unit
-    // roundoff 2^-23 (the MFMA's internal order and rounding are not documented) + the exact chain's own dim roundings
-    return 1.02f * (3.02f * 3.814697265625e-06f + (float)(3 * kp16 + dim + 8) * 1.1920928955078125e-07f);
+    // (1) split residue: 3.02 * 2^-18 of |a||b|;
+    // (2) fp32 accumulation of the products, bounded term by term with a chopping unit roundoff 2^-23 (the MFMA's internal order
+    //     and rounding are not documented): the 3 * min(Kp, 128) products of ONE 128-k block (tile_pipeline_bf16 restarts the
+    //     accumulators per block from 5 chunks on; the B-in-registers form only exists for Kp <= 128 = one block) + one rounding
+    //     per block sum added;
+    // (3) the exact chain's own roundings: fmaf rounds to nearest, <= 2^-24 of a partial sum <= |a||b| per step
+    // k_blocks = false (the neighbour sweeps: tile_pipeline_bf16<false>): one accumulation chain over all 3 * Kp products
+    const int blocks = k_blocks ? (kp16 + 127) / 128 : 1;
+    const int n_acc = blocks > 1 ? 3 * 128 + blocks : 3 * kp16;
+    return 1.02f * (3.02f * 3.814697265625e-06f + (float)n_acc * 1.1920928955078125e-07f + (float)(dim + 8) * 5.9604644775390625e-08f);
 }
 
 static int pack_operand_bf16(int slot, const float *src, int64_t n, int ld, int dim, hipStream_t st, PackedOp *out) {
@@ -3191,25 +3356,29 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         e1, n1, ld1, e2, n2, ld2, dim, gold_offset, reinterpret_cast<uint4 *>(p1.p), n1_pad, reinterpret_cast<uint4 *>(p2.p), n2_pad,
         p1.kp, gold, nmax, rank, csls_r, csls_c, aug ? 1 : 0);
     const unsigned gb = (unsigned)oea::ceil_div(n1, 256);
-    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, aug ? bf16_eps_rel(dim_p) + 1.0e-6f : bf16_eps_rel(dim), sweep_r, tol,
+    rank_bf16_init_kernel<<<gb, 256, 0, st>>>(gold, n1, gold_offset, nmax, aug ? bf16_eps_rel(dim_p, true) + 1.0e-6f : bf16_eps_rel(dim, true), sweep_r, tol,
                                               rank, keys, lbrow, rec_cnt);
     int tpc = 1;
     const int64_t qt = oea::ceil_div(n1, TILE), ctiles = oea::ceil_div(n2, TILE);
-    const int chunks = pick_chunks(qt, ctiles, &tpc);
-    const int64_t n_waves = 4 * qt * chunks;
+    // Kp > 128: 256-candidate tiles, 512 threads, three-stage ring (tile_pipeline_bf16_big); OEA_BF16_BIG=0: the 128 x 128 kernel
+    static const bool big_on = [] { const char *e = getenv("OEA_BF16_BIG"); return !(e && e[0] == '0'); }();
+    const bool big = big_on && p1.kp > 128;
+    const int nw = big ? 8 : 4;
+    const int chunks = pick_chunks(qt, big ? oea::ceil_div(n2, BIG_MT) : ctiles, &tpc);
+    const int64_t n_waves = (int64_t)nw * qt * chunks;
     OEA_REQUIRE(n_waves <= bf16_max_waves(n1), "more workgroups than the workspace was sized for (OEA_RANK_WGS)");
     const unsigned slice_cap = (unsigned)(cap / n_waves);
     OEA_REQUIRE(slice_cap >= 32, "record slices too small");
     // warm-up over 1/16 of the candidate tiles (at most 16 = 2,048 candidates, 3 % of a 70,000-row sweep); a small candidate
     // set needs none: every workgroup sees most of it anyway
     const int warm = (int)std::min<int64_t>(kBf16WarmTiles, ctiles / 16);
-    const dim3 gw((unsigned)qt, 1), gs((unsigned)qt, (unsigned)chunks);
+    const TileGrid gw = make_tile_grid((unsigned)qt, 1), gs = make_tile_grid((unsigned)qt, (unsigned)chunks);
     // Kp <= 128 (dim <= 128): the candidates' operand stays in registers (OEA_BF16_BREG=0: both operands through LDS)
     static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
     // (with the CSLS terms the epilogue's registers + 32 NCH of B spill from NCH = 3 on: 6.5 -> 7.6 ms, stays on the LDS pipeline)
     const int nch = (breg_on && p1.kp <= (sweep_r ? 64 : 128)) ? p1.kp / 32 : 0;
-#define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<GRID, 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, TPC, gold_offset, \
-                                                              rank, lbrow, rec, rec_cnt, slice_cap)
+#define OEA_BF16_LAUNCH(K, GRID, TPC) K<<<tile_grid_blocks(GRID), 256, 0, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, TPC, \
+                                                                                gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, GRID)
 #define OEA_BF16_SWEEP(W, C, GRID, TPC)                                                                 \
     do {                                                                                                \
         if (nch == 4) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 4>), GRID, TPC);                     \
@@ -3218,13 +3387,27 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         else if (nch == 1) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 1>), GRID, TPC);                \
         else OEA_BF16_LAUNCH((rank_bf16_kernel<W, C>), GRID, TPC);                                      \
     } while (0)
+#define OEA_BF16_BIG_SWEEP(C)                                                                                                        \
+    do {                                                                                                                            \
+        static bool attr_set = false;                                                                                               \
+        if (!attr_set) {                                                                                                            \
+            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              BIG_LDS_BYTES));                                                                      \
+            attr_set = true;                                                                                                        \
+        }                                                                                                                           \
+        rank_bf16_big_kernel<C><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
+                                                                                  gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, gs);       \
+    } while (0)
     if (sweep_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
-        OEA_BF16_SWEEP(false, true, gs, tpc);
+        if (big) OEA_BF16_BIG_SWEEP(true);
+        else OEA_BF16_SWEEP(false, true, gs, tpc);
     } else {
         if (warm >= 2) OEA_BF16_SWEEP(true, false, gw, warm);
-        OEA_BF16_SWEEP(false, false, gs, tpc);
+        if (big) OEA_BF16_BIG_SWEEP(false);
+        else OEA_BF16_SWEEP(false, false, gs, tpc);
     }
+#undef OEA_BF16_BIG_SWEEP
 #undef OEA_BF16_SWEEP
 #undef OEA_BF16_LAUNCH
     rc = release_packed(st);
@@ -3489,8 +3672,8 @@ int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_
 }
 
 size_t oea_csls_means_workspace_bytes(int64_t n1, int64_t n2, int32_t k) {
-    const CslsPlan p = plan_csls(n1, n2, k);
-    return p.ok ? p.total : 0;
+    const CslsPlan p = plan_csls(n1, n2, k), pb = plan_csls(n1, n2, k, true);       // (the call picks one of the two by the row width)
+    return p.ok ? std::max(p.total, pb.ok ? pb.total : 0) : 0;
 }
 
 int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, int32_t k,
@@ -3498,7 +3681,16 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     OEA_REQUIRE(e1 && e2 && r_out && c_out && workspace, "null pointer");
     OEA_REQUIRE(ld1 % 4 == 0 && ld2 % 4 == 0 && dim > 0 && dim <= ld1 && dim <= ld2 && dim <= 2048, "ld % 4 == 0, dim <= min(ld, 2048)");
     OEA_REQUIRE(k >= 1 && k <= n1 && k <= n2, "1 <= k <= min(n1, n2)");
-    const CslsPlan p = plan_csls(n1, n2, k);
+    // from 3e8 pairs on the sweep multiplies the bf16 hi / lo split (3/16 of the fp32 matrix time, see the prefilter section);
+    // the means are still those of the exact values (list_mean_rows_kernel<true>).  OEA_CSLS_BF16=0 keeps the fp32 sweep.
+    // (both read per call: the tests move the limit).  Rows wider than 128: 256-candidate tiles, 512 threads, three-stage ring.
+    const char *env_on = getenv("OEA_CSLS_BF16"), *env_min = getenv("OEA_CSLS_BF16_MIN_PAIRS");
+    const bool bf16_on = !(env_on && env_on[0] == '0');
+    const double bf16_min = env_min ? atof(env_min) : 3e8;
+    const bool bf16 = bf16_on && (double)n1 * (double)n2 >= bf16_min;
+    static const bool big_on = [] { const char *e = getenv("OEA_BF16_BIG"); return !(e && e[0] == '0'); }();
+    const bool big = bf16 && big_on && (dim + BK - 1) / BK * BK > 128 && plan_csls(n1, n2, k, true).ok;
+    const CslsPlan p = plan_csls(n1, n2, k, big);
     if (!p.ok || !use_glds()) { oea::set_error("oea_csls_means: shape not covered (n1, n2 >= 4096, k <= 32, packed tiles)"); return OEA_EUNSUPPORTED; }
     OEA_REQUIRE(ws_bytes >= p.total, "workspace smaller than oea_csls_means_workspace_bytes");
     hipStream_t st = oea::as_stream(stream);
@@ -3527,14 +3719,8 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     if (rc != OEA_OK) return rc;
     // every (candidate, query tile) count is written by the sweep when chunks cover all candidate tiles -- they do
     OEA_CHECK_HIP(hipMemsetAsync(nfail, 0, 256, st));
-    // from 3e8 pairs on the sweep multiplies the bf16 hi / lo split (3/16 of the fp32 matrix time, see the prefilter section);
-    // the means are still those of the exact values (list_mean_rows_kernel<true>).  OEA_CSLS_BF16=0 keeps the fp32 sweep.
-    // (both read per call: the tests move the limit)
-    const char *env_on = getenv("OEA_CSLS_BF16"), *env_min = getenv("OEA_CSLS_BF16_MIN_PAIRS");
-    const bool bf16_on = !(env_on && env_on[0] == '0');
-    const double bf16_min = env_min ? atof(env_min) : 3e8;
-    const dim3 grid((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks);
-    if (bf16_on && (double)n1 * (double)n2 >= bf16_min) {
+    const TileGrid grid = make_tile_grid((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks);
+    if (bf16) {
         float *tol = reinterpret_cast<float *>(nfail + 16);                // [0] the bound, [1] / [2] max row norms (zeroed above)
         PackedOp b1, b2;
         rc = pack_operand_bf16(4, e1, n1, ld1, dim, st, &b1);
@@ -3542,11 +3728,20 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         if (rc != OEA_OK) return rc;
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n1, 256), 256, 0, st>>>(e1, n1, ld1, dim, reinterpret_cast<unsigned *>(tol) + 1);
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n2, 256), 256, 0, st>>>(e2, n2, ld2, dim, reinterpret_cast<unsigned *>(tol) + 2);
-        csls_tol_kernel<<<1, 1, 0, st>>>(tol, bf16_eps_rel(dim));
+        csls_tol_kernel<<<1, 1, 0, st>>>(tol, bf16_eps_rel(dim, true));
         static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
-#define OEA_CSLS_APPEND(N) csls_append_kernel<true, true, N><<<grid, 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, \
-                                                                                 qlists, qcnt, clists, ccnt, tol)
-        switch ((breg_on && kp <= 128) ? kp / 32 : 0) {
+#define OEA_CSLS_APPEND(N) csls_append_kernel<true, true, N><<<tile_grid_blocks(grid), 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, \
+                                                                                                   p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid)
+        if (big) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
+                attr_set = true;
+            }
+            csls_append_kernel<true, true, 0, 8><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc,
+                                                                                                  p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
+        } else switch ((breg_on && kp <= 128) ? kp / 32 : 0) {
             case 4: OEA_CSLS_APPEND(4); break;
             case 3: OEA_CSLS_APPEND(3); break;
             case 2: OEA_CSLS_APPEND(2); break;
@@ -3559,8 +3754,8 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         list_mean_rows_kernel<true><<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2,
                                                                                     nfail + 1, e2, ld2, e1, ld1, dim, thr2, tol);
     } else {
-        csls_append_kernel<true, false><<<grid, 256, 0, st>>>(p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt,
-                                                               clists, ccnt, nullptr);
+        csls_append_kernel<true, false><<<tile_grid_blocks(grid), 256, 0, st>>>(p1.p, n1, kp, p2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap,
+                                                                                 qlists, qcnt, clists, ccnt, nullptr, grid);
         list_mean_rows_kernel<false><<<(unsigned)oea::ceil_div(n1, 4), 256, 0, st>>>(qlists, qcnt, p.nseg, p.cap, n1, k, r_out, fail1, nfail,
                                                                                      nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
         list_mean_rows_kernel<false><<<(unsigned)oea::ceil_div(n2, 4), 256, 0, st>>>(clists, ccnt, 2 * p.nqt, p.ccap, n2, k, c_out, fail2,
