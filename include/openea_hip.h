@@ -834,9 +834,44 @@ int oea_allreduce_i64(oea_comm_t c, int64_t *buf, int64_t n, void *stream);
 int oea_comm_allgather(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream);
 int oea_comm_reduce_scatter(oea_comm_t c, const void *send, void *recv, int64_t n_per_rank, int32_t dtype, void *stream);
 int oea_comm_allreduce(oea_comm_t c, void *buf, int64_t n, int32_t dtype, void *stream);
+/* All-to-all with per-peer element counts known on the host: peer p receives send[send_displs[p] .. + send_counts[p]) and
+ * recv[recv_displs[p] ..] takes recv_counts[p] elements from p.  RCCL: one group of ncclSend / ncclRecv; a callback communicator
+ * hands it to the function set by oea_comm_set_alltoallv (same ordering contract as oea_comm_callback). */
+typedef int (*oea_comm_alltoallv_callback)(void *user, const void *send, const int64_t *send_counts, const int64_t *send_displs,
+                                           void *recv, const int64_t *recv_counts, const int64_t *recv_displs, int32_t dtype, void *stream);
+int oea_comm_set_alltoallv(oea_comm_t c, oea_comm_alltoallv_callback fn);
+int oea_comm_alltoallv(oea_comm_t c, const void *send, const int64_t *send_counts, const int64_t *send_displs, void *recv,
+                       const int64_t *recv_counts, const int64_t *recv_displs, int32_t dtype, void *stream);
+
+/* oea_triple_epoch_range_comm with the BOUNDARY-ROW ("halo") exchange (BASELINE.json north_star: "all-gather of boundary
+ * embeddings"): instead of every owned row (reduce-scatter + all-gather of [E, ld] per step) a step moves only the rows its batch
+ * refers to.  Every rank derives from the epoch's positives and negatives (drawn ahead, the same Philox streams everywhere) the
+ * sorted list of rows each rank's share of each step refers to, per owner (owner = id mod world) -- no index travels and all
+ * message sizes are known after ONE host read of the [steps][world][world] counts per call.  Per step: GRAD -> all-to-all of the
+ * gradient rows (+ flag) to their owners, added into the owner's scratch (exact in the fixed-point build: the G-rank job is the
+ * single-GPU job bit for bit) -> relation rows all-reduced -> optimiser on the owned rows -> all-to-all of the current values of
+ * the rows the next step's readers refer to.  The last step of the range ends with the dense all-gather of the owned rows
+ * (upd / all as above), so outside the call every rank holds the whole table.  TransE / TransH scores, SGD / Adagrad.
+ *   halo_ws: oea_halo_workspace_bytes(n_ent, world, step_end - step_begin or more, largest batch, k) device bytes;
+ *   buf_a, buf_b: two exchange buffers of oea_halo_buffer_bytes(...) device bytes each;
+ *   stats_host (may be NULL): int64 [4] = bytes pushed (gradient rows sent), bytes pulled (rows received), largest number of
+ *   rows sent in a step, steps run. */
+size_t oea_halo_workspace_bytes(int64_t n_ent, int32_t world, int32_t steps, int64_t max_batch, int32_t k);
+size_t oea_halo_buffer_bytes(int64_t n_ent, int32_t world, int64_t max_batch, int32_t k, int32_t ld);
+int oea_triple_epoch_range_halo(oea_comm_t comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
+                                int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
+                                int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, void *halo_ws, size_t halo_ws_bytes,
+                                void *buf_a, void *buf_b, size_t buf_bytes, void *rel_x, float *upd, float *all,
+                                int64_t *stats_host, void *stream);
+
 /* Phase times of oea_triple_epoch_range_comm: between _begin and _end every step records HIP events at its phase boundaries
  * on the call's stream; _end waits for the last one and returns the summed milliseconds per phase
- * (GRAD | pack | reduce-scatter + relation all-reduce | apply | all-gather | unpack) and the number of steps recorded. */
+ * (GRAD | pack | reduce-scatter + relation all-reduce | apply | all-gather | unpack; for oea_triple_epoch_range_halo: GRAD | pack |
+ * gradient all-to-all + relation all-reduce | add + apply | row all-to-all (or the closing all-gather) | unpack) and the number of
+ * steps recorded. */
 enum { OEA_COMM_PHASES = 6 };
 int oea_comm_profile_begin(oea_comm_t c);
 int oea_comm_profile_end(oea_comm_t c, double *phase_ms /* [OEA_COMM_PHASES] */, int32_t *steps);

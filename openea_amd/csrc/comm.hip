@@ -38,6 +38,10 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -61,6 +65,10 @@ static Rccl *rccl() {
     OEA_SYM(AllReduce, "ncclAllReduce")
     OEA_SYM(AllGather, "ncclAllGather")
     OEA_SYM(ReduceScatter, "ncclReduceScatter")
+    OEA_SYM(Send, "ncclSend")
+    OEA_SYM(Recv, "ncclRecv")
+    OEA_SYM(GroupStart, "ncclGroupStart")
+    OEA_SYM(GroupEnd, "ncclGroupEnd")
     OEA_SYM(GetErrorString, "ncclGetErrorString")
 #undef OEA_SYM
     return &r;
@@ -73,6 +81,7 @@ struct oea_comm {
     int rank, nranks;
     oea_comm_callback fn;           // non-null: every collective goes to the host callback instead of RCCL
     void *user;
+    oea_comm_alltoallv_callback a2a;       // the all-to-all of a callback communicator (oea_comm_set_alltoallv)
     // phase profile of oea_triple_epoch_range_comm (oea_comm_profile_begin / _end): events at the phase boundaries
     bool profiling;
     std::vector<hipEvent_t> events;        // OEA_COMM_PHASES + 1 per step
@@ -109,13 +118,13 @@ int oea_comm_init(const void *unique_id_128, int32_t rank, int32_t nranks, oea_c
     memcpy(&id, unique_id_128, sizeof(id));
     ncclComm_t c = nullptr;
     OEA_CHECK_RCCL(r->CommInitRank(&c, nranks, id, rank));       // binds the calling thread's current HIP device
-    *out = new oea_comm{c, rank, nranks, nullptr, nullptr, false, {}};
+    *out = new oea_comm{c, rank, nranks, nullptr, nullptr, nullptr, false, {}};
     return OEA_OK;
 }
 
 int oea_comm_init_callbacks(int32_t rank, int32_t nranks, oea_comm_callback fn, void *user, oea_comm_t *out) {
     OEA_REQUIRE(fn && out && nranks >= 1 && rank >= 0 && rank < nranks, "arguments");
-    *out = new oea_comm{nullptr, rank, nranks, fn, user, false, {}};
+    *out = new oea_comm{nullptr, rank, nranks, fn, user, nullptr, false, {}};
     return OEA_OK;
 }
 
@@ -158,6 +167,40 @@ int oea_comm_allreduce(oea_comm_t c, void *buf, int64_t n, int32_t dtype, void *
     return OEA_OK;
 }
 #undef OEA_CALLBACK
+
+int oea_comm_set_alltoallv(oea_comm_t c, oea_comm_alltoallv_callback fn) {
+    OEA_REQUIRE(c && c->fn, "a communicator made by oea_comm_init_callbacks");
+    c->a2a = fn;
+    return OEA_OK;
+}
+
+// peer p gets send[send_displs[p] .. + send_counts[p]) and recv[recv_displs[p] ..] takes recv_counts[p] elements from p (host arrays,
+// elements of `dtype`).  RCCL: one group of ncclSend / ncclRecv pairs (the halo exchange of the partitioned step: ~24 MB per rank in
+// 2 (G - 1) messages of ~1.5 MB each at G = 8 -- point-to-point xGMI links carry them concurrently)
+int oea_comm_alltoallv(oea_comm_t c, const void *send, const int64_t *send_counts, const int64_t *send_displs, void *recv,
+                       const int64_t *recv_counts, const int64_t *recv_displs, int32_t dtype, void *stream) {
+    OEA_REQUIRE(c && send && recv && send_counts && send_displs && recv_counts && recv_displs, "null pointer");
+    OEA_REQUIRE(dtype >= OEA_COMM_F32 && dtype <= OEA_COMM_I64, "dtype");
+    if (c->fn) {
+        OEA_REQUIRE(c->a2a, "callback communicator without an all-to-all (oea_comm_set_alltoallv)");
+        const int rc = c->a2a(c->user, send, send_counts, send_displs, recv, recv_counts, recv_displs, dtype, stream);
+        if (rc != 0) { oea::set_error("%s:%d: the all-to-all callback returned %d", __FILE__, __LINE__, rc); return OEA_EHIP; }
+        return OEA_OK;
+    }
+    const size_t es = dtype == OEA_COMM_F32 ? 4 : 8;
+    Rccl *r = rccl();
+    OEA_CHECK_RCCL(r->GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        if (send_counts[p] > 0)
+            OEA_CHECK_RCCL(r->Send(static_cast<const char *>(send) + (size_t)send_displs[p] * es, (size_t)send_counts[p], nccl_dtype(dtype), p, c->comm,
+                                   oea::as_stream(stream)));
+        if (recv_counts[p] > 0)
+            OEA_CHECK_RCCL(r->Recv(static_cast<char *>(recv) + (size_t)recv_displs[p] * es, (size_t)recv_counts[p], nccl_dtype(dtype), p, c->comm,
+                                   oea::as_stream(stream)));
+    }
+    OEA_CHECK_RCCL(r->GroupEnd());
+    return OEA_OK;
+}
 
 int oea_allgather_rows(oea_comm_t c, const float *send, float *recv, int64_t rows_per_rank, int32_t ld, void *stream) {
     OEA_REQUIRE(ld > 0, "arguments");

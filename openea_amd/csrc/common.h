@@ -146,12 +146,17 @@ __device__ __forceinline__ void grad_add(long long *p, float v) {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p), (unsigned long long)to_fixed(v), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
+// a value already in the scratch's own type (another rank's partial sum): exact integer add
+__device__ __forceinline__ void grad_add_raw(long long *p, long long q) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(p), (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #else
 typedef float grad_t;
 typedef float flag_t;
 constexpr int kDetScratch = 0;
 __device__ __forceinline__ float grad_val(float q) { return q; }
 __device__ __forceinline__ void grad_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void grad_add_raw(float *p, float q) { unsafeAtomicAdd(p, q); }
 #endif
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }

@@ -342,6 +342,10 @@ __global__ void row_norm_max_kernel(const float *__restrict__ src, int64_t n, in
 }
 
 // acc += hi.hi + hi.lo + lo.hi of one chunk (ksteps = 1 or 2 k-steps of 16)
+// EARLY (the 256 x 128 kernels): all eight fragment reads of a k-step are issued in front of its MFMAs (a scheduling fence keeps
+// them there) in the order the products consume them, so the waits are counted lgkmcnt(6 / 4 / 2 / 0) behind running MFMAs; left
+// to itself hipcc re-uses the hi fragments' registers for the lo ones and waits for the LDS with lgkmcnt(0) three times per k-step
+template <bool EARLY = false>
 __device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, const float *__restrict__ Bs, int ksteps,
                                                f32x16 (&acc)[2][2]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -352,10 +356,11 @@ __device__ __forceinline__ void mma_chunk_bf16(const float *__restrict__ As, con
     for (int s = 0; s < ksteps; ++s) {
         const int g = 4 * s + 2 * half;
         const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
-        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
-        const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
-        const bf16x8 b0h = *reinterpret_cast<const bf16x8 *>(bp + oh), b0l = *reinterpret_cast<const bf16x8 *>(bp + ol);
-        const bf16x8 b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh), b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
+        const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), b0h = *reinterpret_cast<const bf16x8 *>(bp + oh);
+        const bf16x8 b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh), a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh);
+        const bf16x8 b0l = *reinterpret_cast<const bf16x8 *>(bp + ol), b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
+        const bf16x8 a0l = *reinterpret_cast<const bf16x8 *>(ap + ol), a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
+        if constexpr (EARLY) __builtin_amdgcn_sched_barrier(0);
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
@@ -449,25 +454,42 @@ constexpr int BIG_STAGE = BIG_A + TILE * PLD;     // + the B stage: 48 KB
 constexpr int BIG_STAGES = 3;
 constexpr int BIG_LDS_BYTES = BIG_STAGES * BIG_STAGE * 4;
 
-__device__ __forceinline__ void stage_packed_big(const float *__restrict__ am, const float *__restrict__ bn, int kp, int64_t a_row0,
-                                                 int64_t b_row0, int k0, float *__restrict__ slot) {
+// per-lane part of the DMA source addresses of a stage (elements): the swizzled 16-byte column of the lane's row for the even /
+// odd 8-row pieces; everything else of an address is wave-uniform (tile row, k chunk, piece) and stays on the scalar unit
+struct BigLane {
+    unsigned a_even, a_odd, b_even, b_odd;
+    float *a_dst, *b_dst;                 // LDS offsets of the wave's pieces inside a stage
+};
+
+__device__ __forceinline__ BigLane big_lane(int kp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;          // 8 waves: 32 A rows + 16 B rows each
     const int sub = lane >> 3;
-    const float *asrc = am + (a_row0 + wave * 32 + sub) * kp + k0;
+    BigLane l;
+    const unsigned c_even = 4u * ((lane & 7) ^ ((sub >> 1) & 7)), c_odd = 4u * ((lane & 7) ^ ((4 + (sub >> 1)) & 7));   // ((row >> 1) & 7), row = 8 j + sub (+ 16 or 32 wave)
+    l.a_even = (unsigned)(wave * 32 + sub) * (unsigned)kp + c_even;
+    l.a_odd = (unsigned)(wave * 32 + sub) * (unsigned)kp + c_odd;
+    l.b_even = (unsigned)(wave * 16 + sub) * (unsigned)kp + c_even;
+    l.b_odd = (unsigned)(wave * 16 + sub) * (unsigned)kp + c_odd;
+    l.a_dst = nullptr; l.b_dst = nullptr;
+    return l;
+}
+
+__device__ __forceinline__ void stage_packed_big(const float *__restrict__ a_tile /* am + row0 * kp + k0: wave-uniform */,
+                                                 const float *__restrict__ b_tile, int kp, const BigLane &l, float *__restrict__ slot) {
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float *base = slot + (wave * 4 + j) * 8 * PLD;
-        const int swz = (4 * j + (sub >> 1)) & 7;                         // ((row >> 1) & 7) of row = 32 wave + 8 j + sub
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + (int64_t)j * 8 * kp + 4 * ((lane & 7) ^ swz)),
+        const float *src = a_tile + (size_t)((j & 1 ? l.a_odd : l.a_even) + (unsigned)(j * 8 * kp));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
                                          16, 0, 0);
     }
-    const float *bsrc = bn + (b_row0 + wave * 16 + sub) * kp + k0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float *base = slot + BIG_A + (wave * 2 + j) * 8 * PLD;
-        const int swz = (4 * j + (sub >> 1)) & 7;                         // row = 16 wave + 8 j + sub
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (int64_t)j * 8 * kp + 4 * ((lane & 7) ^ swz)),
+        const float *src = b_tile + (size_t)((j & 1 ? l.b_odd : l.b_even) + (unsigned)(j * 8 * kp));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
                                          16, 0, 0);
     }
@@ -478,22 +500,24 @@ __device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__
                                                        int64_t n0, int64_t n_tiles, MTile m_tile, float *lds, Epilogue epilogue) {
     const int S = (dim + 15) / 16;
     const int nchunk = (S + 1) / 2;
-    const int64_t total = n_tiles * nchunk;
-    if (total == 0) return;
-    int64_t ti = 0;                                  // (tile, chunk) of the next stage to issue
-    int ki = 0;
-    auto issue = [&](int64_t it) {
-        stage_packed_big(am, bn, kp, m_tile(ti), n0, ki * BK, lds + (int)(it % BIG_STAGES) * BIG_STAGE);
-        if (++ki == nchunk) { ki = 0; ++ti; }
+    const int total = (int)n_tiles * nchunk;          // (a work item walks at most a few thousand chunks)
+    if (total <= 0) return;
+    const BigLane lane_off = big_lane(kp);
+    const float *b_base = bn + n0 * kp;
+    int ti = 0, ki = 0, si = 0;                       // (tile, chunk, LDS stage) of the next stage to issue
+    const float *a_base = am + m_tile(0) * kp;
+    auto issue = [&]() {
+        stage_packed_big(a_base + ki * BK, b_base + ki * BK, kp, lane_off, lds + si * BIG_STAGE);
+        si = si == BIG_STAGES - 1 ? 0 : si + 1;
+        if (++ki == nchunk) { ki = 0; ++ti; a_base = am + m_tile(ti) * kp; }
     };
-    issue(0);
-    if (total > 1) issue(1);
+    issue();
+    if (total > 1) issue();
     f32x16 acc[2][2], tot[2][2];
     zero_acc(acc);
     zero_acc(tot);
-    int64_t t = 0;
-    int kc = 0;
-    for (int64_t it = 0; it < total; ++it) {
+    int t = 0, kc = 0, sc = 0;                        // (tile, chunk, stage) being multiplied
+    for (int it = 0; it < total; ++it) {
         // stage `it` has landed when at most the newer stage's 6 DMA instructions of this wave are outstanding (loads complete in
         // order; whatever the epilogue issued since only makes the count stricter); the barrier then covers the other waves' parts
         // and tells everybody that the slot read in iteration it - 1 is free
@@ -501,16 +525,17 @@ __device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 2 < total) issue(it + 2);
-        const float *slot = lds + (int)(it % BIG_STAGES) * BIG_STAGE;
-        mma_chunk_bf16(slot, slot + BIG_A, min(2, S - 2 * kc), acc);
+        if (it + 2 < total) issue();
+        const float *slot = lds + sc * BIG_STAGE;
+        sc = sc == BIG_STAGES - 1 ? 0 : sc + 1;
+        mma_chunk_bf16<true>(slot, slot + BIG_A, min(2, S - 2 * kc), acc);
         ++kc;
         if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {
             add_acc(tot, acc);
             zero_acc(acc);
         }
         if (kc == nchunk) {
-            epilogue(t, tot);
+            epilogue((int64_t)t, tot);
             zero_acc(tot);
             kc = 0;
             ++t;
@@ -3702,30 +3727,49 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     float *qlists = reinterpret_cast<float *>(w + p.off_qlists), *clists = reinterpret_cast<float *>(w + p.off_clists);
     float *strip = reinterpret_cast<float *>(w + p.off_strip), *fbq = reinterpret_cast<float *>(w + p.off_fbq);
     float *scratch = reinterpret_cast<float *>(w + p.off_scratch);
-    PackedOp p1, p2, s1, s2;
-    int rc = pack_operand(0, e1, n1, ld1, dim, st, &p1);
+    PackedOp p1, p2, s1, s2, b1, b2;
+    int rc = pack_operand(0, e1, n1, ld1, dim, st, &p1);          // (fp32 packs: the exact strips of the fallbacks)
     if (rc == OEA_OK) rc = pack_operand(1, e2, n2, ld2, dim, st, &p2);
-    if (rc == OEA_OK) rc = pack_operand(2, e2, p.sample, ld2 * (int)(n2 / p.sample), dim, st, &s2);      // every (n2/S)-th candidate
-    if (rc == OEA_OK) rc = pack_operand(3, e1, p.sample, ld1 * (int)(n1 / p.sample), dim, st, &s1);
     if (rc != OEA_OK) return rc;
     const int kp = p1.kp;
     OEA_REQUIRE(kp <= 4096, "dim <= 4096");
-    // thresholds: rows of S against sampled candidates, columns against sampled queries
-    launch_store_packed(p1.p, n1, s2.p, p.sample, kp, dim, strip, p.sample, st);
-    rc = oea::kth_value(strip, n1, p.sample, p.r1, thr1, st);
-    if (rc != OEA_OK) return rc;
-    launch_store_packed(p2.p, n2, s1.p, p.sample, kp, dim, strip, p.sample, st);
-    rc = oea::kth_value(strip, n2, p.sample, p.r2, thr2, st);
-    if (rc != OEA_OK) return rc;
+    // thresholds: rows of S against sampled candidates (every (n2 / S)-th), columns against sampled queries.  Under the bf16 sweep
+    // the sample strips are bf16 products too (round 5): a threshold is an ESTIMATE of where the k-th value lies -- the lists are
+    // cut below it by the bound and rows whose list comes out short or long take the exact fallback either way -- and at K = 1,200
+    // the two fp32 strips cost 10.9 ms of a 90 ms evaluation
+    static const bool bf16_strips = [] { const char *e = getenv("OEA_CSLS_BF16_STRIPS"); return !(e && e[0] == '0'); }();
+    if (bf16) {
+        rc = pack_operand_bf16(4, e1, n1, ld1, dim, st, &b1);
+        if (rc == OEA_OK) rc = pack_operand_bf16(5, e2, n2, ld2, dim, st, &b2);
+        if (rc != OEA_OK) return rc;
+    }
+    if (bf16 && bf16_strips) {
+        rc = pack_operand_bf16(2, e2, p.sample, ld2 * (int)(n2 / p.sample), dim, st, &s2);
+        if (rc == OEA_OK) rc = pack_operand_bf16(3, e1, p.sample, ld1 * (int)(n1 / p.sample), dim, st, &s1);
+        if (rc != OEA_OK) return rc;
+        const unsigned gs = (unsigned)oea::ceil_div(p.sample, TILE);
+        sim_bf16_store_kernel<<<dim3(gs, (unsigned)oea::ceil_div(n1, TILE)), 256, 0, st>>>(b1.p, n1, kp, s2.p, p.sample, dim, strip, p.sample);
+        rc = oea::kth_value(strip, n1, p.sample, p.r1, thr1, st);
+        if (rc != OEA_OK) return rc;
+        sim_bf16_store_kernel<<<dim3(gs, (unsigned)oea::ceil_div(n2, TILE)), 256, 0, st>>>(b2.p, n2, kp, s1.p, p.sample, dim, strip, p.sample);
+        rc = oea::kth_value(strip, n2, p.sample, p.r2, thr2, st);
+        if (rc != OEA_OK) return rc;
+    } else {
+        rc = pack_operand(2, e2, p.sample, ld2 * (int)(n2 / p.sample), dim, st, &s2);
+        if (rc == OEA_OK) rc = pack_operand(3, e1, p.sample, ld1 * (int)(n1 / p.sample), dim, st, &s1);
+        if (rc != OEA_OK) return rc;
+        launch_store_packed(p1.p, n1, s2.p, p.sample, kp, dim, strip, p.sample, st);
+        rc = oea::kth_value(strip, n1, p.sample, p.r1, thr1, st);
+        if (rc != OEA_OK) return rc;
+        launch_store_packed(p2.p, n2, s1.p, p.sample, kp, dim, strip, p.sample, st);
+        rc = oea::kth_value(strip, n2, p.sample, p.r2, thr2, st);
+        if (rc != OEA_OK) return rc;
+    }
     // every (candidate, query tile) count is written by the sweep when chunks cover all candidate tiles -- they do
     OEA_CHECK_HIP(hipMemsetAsync(nfail, 0, 256, st));
     const TileGrid grid = make_tile_grid((unsigned)oea::ceil_div(n1, TILE), (unsigned)p.chunks);
     if (bf16) {
         float *tol = reinterpret_cast<float *>(nfail + 16);                // [0] the bound, [1] / [2] max row norms (zeroed above)
-        PackedOp b1, b2;
-        rc = pack_operand_bf16(4, e1, n1, ld1, dim, st, &b1);
-        if (rc == OEA_OK) rc = pack_operand_bf16(5, e2, n2, ld2, dim, st, &b2);
-        if (rc != OEA_OK) return rc;
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n1, 256), 256, 0, st>>>(e1, n1, ld1, dim, reinterpret_cast<unsigned *>(tol) + 1);
         row_norm_max_kernel<<<(unsigned)oea::ceil_div(n2, 256), 256, 0, st>>>(e2, n2, ld2, dim, reinterpret_cast<unsigned *>(tol) + 2);
         csls_tol_kernel<<<1, 1, 0, st>>>(tol, bf16_eps_rel(dim, true));

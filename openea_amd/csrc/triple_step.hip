@@ -29,6 +29,9 @@
 // Algorithmic bytes per scored triple: 3 rows read + 3 rows of gradient = 24*d.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -1180,6 +1183,241 @@ __global__ void scatter_rows_kernel(grad_t *__restrict__ grad, flag_t *__restric
     }
 }
 
+// ---- boundary-row ("halo") exchange of the partitioned step (round 5) --------------------------------------------------------------
+// The dense protocol above moves every owned row every step: (G-1)/G * E * (2 ld + 1) * 4 B per rank (161 MB at the 100K shape)
+// for a step that reads ~27,000 rows per rank.  BASELINE.json's north star asks for "all-gather of BOUNDARY embeddings": the rows
+// a rank's share of the batch refers to.  Which rows those are is known before the step runs -- the epoch's positives and its
+// negatives (drawn ahead for the whole epoch, the same Philox streams on every rank) name them -- so EVERY rank computes, for
+// every step s and every rank r, the sorted list of entity rows r's share refers to, bucketed by owner (halo_mark / halo_compact;
+// one copy of the [steps][G][G] counts to the host per call).  No index ever travels, the sizes of all exchanges of the call are
+// known on the host, and a step is:
+//   GRAD on the share -> PUSH: all-to-all of the gradient rows (+ flag) of list(s, me, o) to their owners o, added into the owner's
+//   scratch (exact sums in the fixed-point build) -> relation rows all-reduced as before -> optimiser on the owned touched rows ->
+//   PULL: all-to-all of the CURRENT values of list(s + 1, r, me) to the readers r of the next step.
+// Rows a rank does not refer to stay stale in its local copy until the call's last step: one dense all-gather of the owned rows
+// ends the range, so everything outside (evaluation, neighbour refresh, the other trainers) sees the single-GPU table.
+// ~19 MB per rank and step at the 100K shape with 8 ranks (2,500 positives x (2 + 10) rows, 7/8 remote, ld + 1 floats out and ld
+// back) instead of 161 MB.  TransE / TransH scores (TransD's stacked transfer rows are not in the lists: dense protocol).
+struct HaloGeom {
+    int world, rank;
+    int64_t rpr, rpr32;            // owned rows per rank; the same rounded up to 32 (bitmap words per owner = rpr32 / 32)
+    int64_t cap;                   // list entries per (step, rank)
+    int nwords;                    // bitmap words per (step, rank) = world * rpr32 / 32
+};
+
+__device__ __forceinline__ void halo_mark_id(uint32_t *__restrict__ bm, const HaloGeom &g, int id) {
+    const int64_t bit = (int64_t)(id % g.world) * g.rpr32 + id / g.world;
+    atomicOr(bm + (bit >> 5), 1u << (bit & 31));
+}
+
+// one thread per (batch row, entry): entry 0 = the positive, 1..k its negatives; marks head and tail in the bitmap of the
+// (step, rank) whose share holds the row
+__global__ void halo_mark_kernel(const int32_t *__restrict__ pos_all, const int32_t *__restrict__ neg_all, int k,
+                                 const int64_t *__restrict__ offsets, int s0, int s1, HaloGeom g, uint32_t *__restrict__ bitmaps) {
+    const int64_t row_lo = offsets[s0], rows = offsets[s1] - row_lo;
+    const int64_t total = rows * (k + 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row_lo + i / (k + 1);
+        const int e = (int)(i % (k + 1));
+        int a = s0, b = s1;                                  // step of the row: offsets[s] <= row < offsets[s + 1]
+        while (b - a > 1) { const int m = (a + b) >> 1; if (offsets[m] <= row) a = m; else b = m; }
+        const int64_t b0 = offsets[a], nb = offsets[a + 1] - b0, p = row - b0;
+        int r = (int)((p * g.world) / nb);
+        while (r + 1 < g.world && nb * (r + 1) / g.world <= p) ++r;
+        while (r > 0 && nb * r / g.world > p) --r;
+        const int32_t *tr = e == 0 ? pos_all + 3 * row : neg_all + 3 * (row * k + (e - 1));
+        uint32_t *bm = bitmaps + ((int64_t)(a - s0) * g.world + r) * g.nwords;
+        halo_mark_id(bm, g, tr[0]);
+        halo_mark_id(bm, g, tr[2]);
+    }
+}
+
+// one workgroup per (step, rank): the set bits of owner o's words, ascending, as local row indices j (id = j * world + o);
+// counts[(step, rank)][o]; the lists of the owners follow each other (prefix of the counts)
+__global__ __launch_bounds__(256) void halo_compact_kernel(const uint32_t *__restrict__ bitmaps, HaloGeom g, int32_t *__restrict__ lists,
+                                                           int32_t *__restrict__ counts, int32_t *__restrict__ err) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int sr = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *bm = bitmaps + (int64_t)sr * g.nwords;
+    int32_t *out = lists + (int64_t)sr * g.cap;
+    const int wpo = (int)(g.rpr32 >> 5);                     // words per owner
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int o = 0; o < g.world; ++o) {
+        const int start = s_base;
+        for (int w0 = 0; w0 < wpo; w0 += 256) {
+            const int w = w0 + tid;
+            uint32_t bits = w < wpo ? bm[o * wpo + w] : 0u;
+            const int c = __popc(bits);
+            int incl = c;                                    // inclusive scan inside the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            int before = 0;
+            for (int u = 0; u < wave; ++u) before += s_wave[u];
+            const int chunk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            int at = s_base + before + incl - c;
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                if (at < g.cap) out[at] = w * 32 + b;
+                ++at;
+            }
+            __syncthreads();
+            if (tid == 0) s_base += chunk_total;
+            __syncthreads();
+        }
+        if (tid == 0) counts[(int64_t)sr * g.world + o] = s_base - start;
+    }
+    if (tid == 0 && s_base > g.cap) atomicMax(err, 1);
+}
+
+// entry q of a concatenation of per-peer lists -> (peer, position inside the peer's list); pfx [world + 1] ascending
+__device__ __forceinline__ int halo_peer_of(const int32_t *__restrict__ pfx, int world, int64_t q) {
+    int a = 0, b = world;
+    while (b - a > 1) { const int m = (a + b) >> 1; if (pfx[m] <= q) a = m; else b = m; }
+    return a;
+}
+
+// PUSH, reader side: gradient row + flag of every remote row of list(s, me, .) -> send[q * (ld + 1)], scratch row and flag cleared
+template <int G, int IT>
+__global__ __launch_bounds__(256) void halo_push_pack_kernel(StepWs ws, int ld, HaloGeom g, const int32_t *__restrict__ list /* (s, me) */,
+                                                             const int32_t *__restrict__ pfx /* [world + 1] over owners */,
+                                                             grad_t *__restrict__ send) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    const int64_t total = pfx[g.world];
+    for (int64_t q = grp; q < total; q += ngrp) {
+        const int o = halo_peer_of(pfx, g.world, q);
+        if (o == g.rank) continue;                                   // own rows stay in the scratch
+        const int64_t id = (int64_t)list[q] * g.world + o;
+        const flag_t f = ws.ent_touched[id];
+        grad_t *dst = send + q * (ld + 1);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * G + lane;
+            if (c < ld) {
+                dst[c] = f != 0 ? ws.ent_grad[id * ld + c] : (grad_t)0;
+                if (f != 0) ws.ent_grad[id * ld + c] = 0;
+            }
+        }
+        if (lane == 0) { dst[ld] = f; if (f != 0) ws.ent_touched[id] = 0; }
+    }
+}
+
+// PUSH, owner side: the rows received from reader r (= list(s, r, me), known here) added into the own scratch
+template <int G, int IT>
+__global__ __launch_bounds__(256) void halo_push_unpack_kernel(StepWs ws, int ld, HaloGeom g, const int32_t *__restrict__ lists_s /* (s, 0) */,
+                                                               const int32_t *__restrict__ own_off /* [world]: where list(s, r, me) starts in (s, r) */,
+                                                               const int32_t *__restrict__ rpfx /* [world + 1] over readers */,
+                                                               const grad_t *__restrict__ recv) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G, ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    const int64_t total = rpfx[g.world];
+    for (int64_t q = grp; q < total; q += ngrp) {
+        const int r = halo_peer_of(rpfx, g.world, q);
+        const int64_t j = lists_s[(int64_t)r * g.cap + own_off[r] + (q - rpfx[r])];
+        const int64_t id = j * g.world + g.rank;
+        const grad_t *src = recv + q * (ld + 1);
+        if (src[ld] == 0) continue;                                  // the reader's share left the row alone
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * G + lane;
+            if (c < ld) { const grad_t v = src[c]; if (v != 0) oea::grad_add_raw(ws.ent_grad + id * ld + c, v); }
+        }
+        if (lane == 0) ws.ent_touched[id] = 1;
+    }
+}
+
+// optimiser on the OWNED touched rows (gradient sums in the own scratch) + the relation rows from rel_x; part_apply_kernel's
+// arithmetic and group widths, nothing written for the other ranks
+template <int G, int IT>
+__global__ __launch_bounds__(256) void halo_apply_kernel(float *__restrict__ ent, float *__restrict__ acc_own, int64_t n_ent,
+                                                         float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel,
+                                                         int ld, int world, int rank, int64_t rpr, grad_t *__restrict__ rel_x,
+                                                         oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum) {
+    const int lane = threadIdx.x % G;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
+    for (int64_t w = grp; w < rpr + n_rel; w += ngrp) {
+        Row<G, IT> rv, rg, ra;
+        if (w >= rpr) {
+            const int64_t r = w - rpr;
+            if (rel_x[n_rel * ld + r] == 0) continue;
+            load_row<G, IT>(rel + r * ld, ld, lane, rv);
+            load_grad_row<G, IT>(rel_x + r * ld, ld, lane, rg);
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(rel_acc + r * ld, ld, lane, ra);
+            flag_t dummy;
+            apply_one_row<G, IT>(rel + r * ld, rel_acc + r * ld, rel_x + r * ld, &dummy, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
+            continue;
+        }
+        const int64_t j = w, id = j * world + rank;
+        if (id >= n_ent || ws.ent_touched[id] == 0) continue;
+        float *v = ent + id * ld;
+        load_row<G, IT>(v, ld, lane, rv);
+        load_grad_row<G, IT>(ws.ent_grad + id * ld, ld, lane, rg);
+        if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc_own + j * ld, ld, lane, ra);
+        apply_one_row<G, IT>(v, acc_own + j * ld, ws.ent_grad + id * ld, ws.ent_touched + id, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {                      // fixed-order reduction of the loss partials
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_partials; i += 64) s += ws.partials[i];
+        s = oea::wave_sum_d(s);
+        if (threadIdx.x == 0) *loss_accum += s;
+    }
+}
+
+// relation rows of the scratch (copies folded by the GRAD phase) + flags -> rel_x, scratch cleared (part_pack_kernel's relation half)
+__global__ void halo_rel_pack_kernel(StepWs ws, int64_t n_rel, int ld, grad_t *__restrict__ rel_x) {
+    const int64_t total = n_rel * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const flag_t f = ws.rel_touched[r];
+        rel_x[i] = f != 0 ? ws.rel_grad[i] : (grad_t)0;
+        if (f != 0) ws.rel_grad[i] = 0;
+    }
+}
+__global__ void halo_rel_flags_kernel(StepWs ws, int64_t n_rel, int ld, grad_t *__restrict__ rel_x) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rel) { rel_x[n_rel * ld + r] = ws.rel_touched[r]; ws.rel_touched[r] = 0; }
+}
+
+// PULL: rows of the table <-> a packed buffer.  owner side (PACK): entry q of the readers' lists list(s, r, me) -> buf[q * ld];
+// reader side (!PACK): buf[q * ld] -> row list(s, me, o) of owner o.  16-byte pieces.
+template <bool PACK>
+__global__ void halo_pull_kernel(float *__restrict__ ent, int ld, HaloGeom g, const int32_t *__restrict__ lists_s /* PACK: (s, 0); else (s, me) */,
+                                 const int32_t *__restrict__ own_off, const int32_t *__restrict__ pfx, float *__restrict__ buf) {
+    const int cpr = ld / 4;
+    const int64_t total = (int64_t)pfx[g.world] * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = i / cpr;
+        const int c = (int)(i - q * cpr);
+        const int peer = halo_peer_of(pfx, g.world, q);
+        if (peer == g.rank) continue;
+        if (PACK) {
+            const int64_t j = lists_s[(int64_t)peer * g.cap + own_off[peer] + (q - pfx[peer])];
+            oea::st4(buf + q * ld + 4 * c, oea::ld4(ent + (j * g.world + g.rank) * ld + 4 * c));
+        } else {
+            const int64_t j = lists_s[q];
+            oea::st4(ent + (j * g.world + peer) * ld + 4 * c, oea::ld4(buf + q * ld + 4 * c));
+        }
+    }
+}
+
+// the owned rows -> upd [rpr, ld] (source of the dense all-gather that ends a halo range)
+__global__ void halo_owned_rows_kernel(const float *__restrict__ ent, int64_t n_ent, int ld, int world, int rank, int64_t rpr,
+                                       float *__restrict__ upd) {
+    const int cpr = ld / 4;
+    const int64_t total = rpr * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = i / cpr, id = j * world + rank;
+        const int c = (int)(i - j * cpr);
+        oea::st4(upd + j * ld + 4 * c, id < n_ent ? oea::ld4(ent + id * ld + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
 // triple_grouped specialised on (loss kind, norm) -- the per-triple losses that reach it (margin pairs go to
 // triple_generic); OEA_STEP_RUNTIME_KIND=1 keeps the one kernel with the run-time switch (experiments).
 template <int G, int IT>
@@ -1659,6 +1897,247 @@ int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int
         ++step_cfg.opt_t;
     }
 #undef OEA_TRY_RC
+    return OEA_OK;
+}
+
+}  // extern "C"
+
+// ---- the halo form of the one-call partitioned epoch ---------------------------------------------------------------------------------
+static HaloGeom halo_geom(int64_t n_ent, int32_t world, int32_t rank, int64_t max_batch, int32_t k) {
+    HaloGeom g;
+    g.world = world; g.rank = rank;
+    g.rpr = oea_part_rows_per_rank(n_ent, world);
+    g.rpr32 = (g.rpr + 31) / 32 * 32;
+    g.nwords = (int)((int64_t)world * g.rpr32 / 32);
+    const int64_t share = oea::ceil_div(max_batch, world) + 1;
+    g.cap = std::min<int64_t>(2 * share * (1 + (int64_t)k), (int64_t)world * g.rpr);
+    g.cap = (g.cap + 3) / 4 * 4;
+    return g;
+}
+struct HaloWs { uint32_t *bitmaps; int32_t *lists, *counts, *tables, *err; };
+// tables: per step [4][world + 1] int32: 0 = prefix over owners of count(s, me, .), 1 = prefix over readers of count(s, ., me) (me
+// excluded), 2 = where list(s, r, me) starts inside (s, r) (index r), 3 = spare
+static size_t halo_ws_layout(const HaloGeom &g, int32_t steps, void *base, HaloWs *ws) {
+    size_t off = 0;
+    char *b = static_cast<char *>(base);
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return b ? b + o : nullptr; };
+    uint32_t *bm = (uint32_t *)take(4 * (size_t)steps * g.world * g.nwords);
+    int32_t *li = (int32_t *)take(4 * (size_t)steps * g.world * g.cap);
+    int32_t *co = (int32_t *)take(4 * (size_t)steps * g.world * g.world);
+    int32_t *ta = (int32_t *)take(4 * (size_t)steps * 4 * (g.world + 1));
+    int32_t *er = (int32_t *)take(256);
+    if (ws) { ws->bitmaps = bm; ws->lists = li; ws->counts = co; ws->tables = ta; ws->err = er; }
+    return off;
+}
+
+extern "C" {
+
+size_t oea_halo_workspace_bytes(int64_t n_ent, int32_t world, int32_t steps, int64_t max_batch, int32_t k) {
+    if (world < 1 || steps < 0) return 0;
+    return halo_ws_layout(halo_geom(n_ent, world, 0, max_batch, k), steps, nullptr, nullptr);
+}
+
+// bytes of EACH of the two exchange buffers: the larger of what a rank can send (its lists: <= cap rows) and receive (the other
+// ranks' lists of its rows: <= (world - 1) * min(cap, rpr) rows), ld + 1 scratch elements per row
+size_t oea_halo_buffer_bytes(int64_t n_ent, int32_t world, int64_t max_batch, int32_t k, int32_t ld) {
+    if (world < 1) return 0;
+    const HaloGeom g = halo_geom(n_ent, world, 0, max_batch, k);
+    const int64_t rows = std::max<int64_t>(g.cap, (int64_t)(world - 1) * std::min<int64_t>(g.cap, g.rpr));
+    return align256((size_t)rows * (ld + 1) * sizeof(grad_t));
+}
+
+int oea_triple_epoch_range_halo(oea_comm_t comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
+                                int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed, uint32_t step_base,
+                                int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg, void *workspace, double *loss_accum,
+                                const int64_t *offsets_dev, const int64_t *splits_dev, void *halo_ws, size_t halo_ws_bytes,
+                                void *buf_a, void *buf_b, size_t buf_bytes, void *rel_x, float *upd, float *all,
+                                int64_t *stats_host, void *stream) {
+    OEA_REQUIRE(comm && ent && rel && pos_all && offsets_host && splits_host && cfg && workspace && loss_accum && halo_ws && buf_a && buf_b &&
+                rel_x && upd && all, "null pointer");
+    OEA_REQUIRE(steps >= 0 && k >= 0 && 0 <= step_begin && step_begin <= step_end && step_end <= steps, "step range");
+    OEA_REQUIRE(offsets_dev && splits_dev, "the halo exchange plans from the epoch's batches on the device: offsets_dev / splits_dev");
+    OEA_REQUIRE(cfg->opt_kind == OEA_OPT_SGD || cfg->opt_kind == OEA_OPT_ADAGRAD, "the partition runs SGD / Adagrad");
+    OEA_REQUIRE(cfg->score_kind == OEA_SCORE_TRANSE || cfg->score_kind == OEA_SCORE_TRANSH, "halo exchange: TransE / TransH scores");
+    OEA_REQUIRE(ld % 4 == 0, "ld % 4 == 0");
+    const int32_t world = oea_comm_size(comm), rank = oea_comm_rank(comm);
+    const bool presampled = k > 0 && side0 == nullptr && side1 == nullptr;
+    OEA_REQUIRE(k == 0 || (neg_buf && (presampled || (err_flag && side0 && side1))), "sampling needs neg_buf, err_flag and both sides");
+    OEA_REQUIRE(k == 0 || presampled || step_begin == 0, "the whole epoch's negatives are drawn by the range that starts it");
+    hipStream_t st = oea::as_stream(stream);
+    if (k > 0 && !presampled) {
+        const int rc = oea_sample_negatives_epoch(pos_all, offsets_host[steps], offsets_dev, splits_dev, steps, k, side0, side1, seed,
+                                                  step_base, 10, neg_buf, err_flag, stream);
+        if (rc != OEA_OK) return rc;
+    }
+    const int32_t nS = step_end - step_begin;
+    if (stats_host) { stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0; }
+    if (nS == 0) return OEA_OK;
+    int64_t max_batch = 0;
+    for (int32_t s = 0; s < steps; ++s) max_batch = std::max(max_batch, offsets_host[s + 1] - offsets_host[s]);
+    const HaloGeom g = halo_geom(n_ent, world, rank, max_batch, k);
+    HaloWs hw;
+    OEA_REQUIRE(halo_ws_bytes >= halo_ws_layout(g, nS, halo_ws, &hw), "halo workspace smaller than oea_halo_workspace_bytes(n_ent, world, steps, max_batch, k)");
+    OEA_REQUIRE(buf_bytes >= oea_halo_buffer_bytes(n_ent, world, max_batch, k, ld), "exchange buffers smaller than oea_halo_buffer_bytes");
+    // ---- plan: who refers to which rows in which step (every rank computes the same tables) -----------------------------------
+    OEA_CHECK_HIP(hipMemsetAsync(hw.bitmaps, 0, 4 * (size_t)nS * world * g.nwords, st));
+    OEA_CHECK_HIP(hipMemsetAsync(hw.err, 0, 4, st));
+    const int64_t rows = offsets_host[step_end] - offsets_host[step_begin];
+    if (rows > 0)
+        halo_mark_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(rows * (k + 1), 256), 16384), 256, 0, st>>>(
+            pos_all, neg_buf, k, offsets_dev, step_begin, step_end, g, hw.bitmaps);
+    halo_compact_kernel<<<(unsigned)(nS * world), 256, 0, st>>>(hw.bitmaps, g, hw.lists, hw.counts, hw.err);
+    std::vector<int32_t> counts((size_t)nS * world * world + 1);
+    OEA_CHECK_HIP(hipMemcpyAsync(counts.data(), hw.counts, 4 * (size_t)nS * world * world, hipMemcpyDeviceToHost, st));
+    OEA_CHECK_HIP(hipMemcpyAsync(counts.data() + (size_t)nS * world * world, hw.err, 4, hipMemcpyDeviceToHost, st));
+    OEA_CHECK_HIP(hipStreamSynchronize(st));                          // the ONE host read of the call
+    OEA_REQUIRE(counts[(size_t)nS * world * world] == 0, "halo lists overflowed their capacity (entries of a batch that are not corruptions?)");
+    auto cnt = [&](int s, int r, int o) { return (int64_t)counts[((size_t)s * world + r) * world + o]; };
+    std::vector<int32_t> tables((size_t)nS * 4 * (world + 1), 0);
+    for (int s = 0; s < nS; ++s) {
+        int32_t *t0 = tables.data() + (size_t)s * 4 * (world + 1), *t1 = t0 + (world + 1), *t2 = t1 + (world + 1);
+        for (int o = 0; o < world; ++o) t0[o + 1] = t0[o] + (int32_t)cnt(s, rank, o);
+        for (int r = 0; r < world; ++r) {
+            t1[r + 1] = t1[r] + (r == rank ? 0 : (int32_t)cnt(s, r, rank));
+            int32_t off = 0;
+            for (int o = 0; o < rank; ++o) off += (int32_t)cnt(s, r, o);
+            t2[r] = off;
+        }
+    }
+    OEA_CHECK_HIP(hipMemcpyAsync(hw.tables, tables.data(), 4 * tables.size(), hipMemcpyHostToDevice, st));
+    OEA_CHECK_HIP(hipStreamSynchronize(st));                          // (tables lives on this stack frame)
+    const int64_t rpr = g.rpr;
+    const bool transh = cfg->score_kind == OEA_SCORE_TRANSH;
+    void *nrm_grad = nullptr, *nrm_touched = nullptr;
+    if (transh) {
+        int64_t g_off = 0, t_off = 0;
+        const int rc = oea_step_normal_scratch(n_ent, n_rel, ld, &g_off, &t_off);
+        if (rc != OEA_OK) return rc;
+        nrm_grad = static_cast<char *>(workspace) + g_off;
+        nrm_touched = static_cast<char *>(workspace) + t_off;
+    }
+    const int32_t gdt = oea::kDetScratch ? OEA_COMM_I64 : OEA_COMM_F32;
+    StepWs ws;
+    ws_layout(n_ent, n_rel, ld, workspace, &ws);
+    grad_t *xa = static_cast<grad_t *>(buf_a), *xb = static_cast<grad_t *>(buf_b), *relx = static_cast<grad_t *>(rel_x);
+    std::vector<int64_t> sc(world), sd(world), rc_(world), rd(world);
+    oea_step_cfg step_cfg = *cfg;
+#define OEA_TRY_RC(call) do { const int _rc = (call); if (_rc != OEA_OK) return _rc; } while (0)
+    for (int32_t s = step_begin; s < step_end; ++s) {
+        const int sl = s - step_begin;
+        const int64_t b0 = offsets_host[s], nb = offsets_host[s + 1] - b0;
+        if (nb <= 0) continue;
+        const int64_t r_lo = nb * rank / world, r_hi = nb * (rank + 1) / world;
+        const int64_t lo = b0 + r_lo, n = r_hi - r_lo;
+        const int32_t *pos = pos_all + 3 * lo;
+        int32_t *negs = k > 0 ? neg_buf + 3 * lo * (int64_t)k : nullptr;
+        const int32_t *tab = hw.tables + (size_t)sl * 4 * (world + 1);
+        const int32_t *t0h = tables.data() + (size_t)sl * 4 * (world + 1), *t1h = t0h + (world + 1);
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        OEA_TRY_RC(oea_triple_step_phase(ent, nullptr, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n, negs, n * (int64_t)k, &step_cfg, workspace,
+                                         loss_accum, OEA_PHASE_GRAD, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        // ---- PUSH -------------------------------------------------------------------------------------------------------------
+        const int64_t n_send = t0h[world], n_recv = t1h[world];
+        const int32_t *list_me = hw.lists + ((size_t)sl * world + rank) * g.cap, *lists_s = hw.lists + (size_t)sl * world * g.cap;
+#define OEA_CALL(G, IT)                                                                                                             \
+        if (n_send > 0) halo_push_pack_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_send, 256 / G), 16384), 256, 0, st>>>( \
+            ws, ld, g, list_me, tab, xa);
+        OEA_PART_DISPATCH(OEA_CALL)
+#undef OEA_CALL
+        halo_rel_pack_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(n_rel * (int64_t)ld, 256), 4096), 256, 0, st>>>(ws, n_rel, ld, relx);
+        halo_rel_flags_kernel<<<(unsigned)oea::ceil_div(n_rel, 256), 256, 0, st>>>(ws, n_rel, ld, relx);
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        for (int p = 0; p < world; ++p) {
+            sc[p] = p == rank ? 0 : cnt(sl, rank, p) * (ld + 1);
+            sd[p] = (int64_t)t0h[p] * (ld + 1);
+            rc_[p] = p == rank ? 0 : cnt(sl, p, rank) * (ld + 1);
+            rd[p] = (int64_t)t1h[p] * (ld + 1);
+        }
+        OEA_TRY_RC(oea_comm_alltoallv(comm, xa, sc.data(), sd.data(), xb, rc_.data(), rd.data(), gdt, stream));
+        OEA_TRY_RC(oea_comm_allreduce(comm, relx, n_rel * (int64_t)(ld + 1), gdt, stream));
+        if (transh) {
+            OEA_TRY_RC(oea_comm_allreduce(comm, nrm_grad, n_rel * (int64_t)ld, gdt, stream));
+            OEA_TRY_RC(oea_comm_allreduce(comm, nrm_touched, n_rel, gdt, stream));
+        }
+        if (stats_host) {
+            int64_t out_rows = 0;
+            for (int p = 0; p < world; ++p) out_rows += p == rank ? 0 : cnt(sl, rank, p);
+            stats_host[0] += out_rows * (ld + 1) * (int64_t)sizeof(grad_t);
+            stats_host[2] = std::max(stats_host[2], out_rows);
+            stats_host[3] += 1;
+        }
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+#define OEA_CALL(G, IT)                                                                                                             \
+        if (n_recv > 0) halo_push_unpack_kernel<G, IT><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_recv, 256 / G), 16384), 256, 0, st>>>( \
+            ws, ld, g, lists_s, tab + 2 * (world + 1), tab + (world + 1), xb);
+        OEA_PART_DISPATCH(OEA_CALL)
+#undef OEA_CALL
+        // ---- optimiser on the owned rows (the single-GPU job's group width at this table size) ---------------------------------
+        const bool grouped = step_cfg.neg_group_k > 0 || step_cfg.loss_kind == OEA_LOSS_MARGIN;
+        const int64_t n_items = grouped ? n : n + n * (int64_t)k;
+        {
+            const int grad_gpb = 256 / (ld <= 128 ? 32 : 64);
+            const int n_part = n_items > 0 ? (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_items, grad_gpb), 1), kMaxBlocks) : 0;
+#define OEA_CALL(G, IT)                                                                                                             \
+            oea::launch_timed(halo_apply_kernel<G, IT>, (unsigned)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(rpr + n_rel, 256 / G), 1), 16384), \
+                              256, st, ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, rpr, relx, step_cfg, ws, n_part, loss_accum);
+            if (ld <= 128 && apply_g16(n_ent, n_rel, ld)) {
+                const int it16 = (ld + 15) / 16;
+                if (it16 <= 2) { OEA_CALL(16, 2) }
+                else if (it16 <= 4) { OEA_CALL(16, 4) }
+                else if (it16 == 5) { OEA_CALL(16, 5) }
+                else if (it16 == 6) { OEA_CALL(16, 6) }
+                else if (it16 == 7) { OEA_CALL(16, 7) }
+                else { OEA_CALL(16, 8) }
+            } else {
+                OEA_PART_DISPATCH(OEA_CALL)
+            }
+#undef OEA_CALL
+        }
+        if (transh) OEA_TRY_RC(oea_step_apply_normals(n_ent, n_rel, ld, &step_cfg, workspace, stream));
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        // ---- PULL for the next step of the range: the current values of the rows its readers refer to ---------------------------
+        int32_t s2 = s + 1;
+        while (s2 < step_end && offsets_host[s2 + 1] - offsets_host[s2] <= 0) ++s2;
+        if (s2 < step_end) {
+            const int sl2 = s2 - step_begin;
+            const int32_t *tab2 = hw.tables + (size_t)sl2 * 4 * (world + 1);
+            const int32_t *u0 = tables.data() + (size_t)sl2 * 4 * (world + 1), *u1 = u0 + (world + 1);
+            const int64_t n_out = u1[world], n_in = u0[world];
+            float *fa = reinterpret_cast<float *>(xa), *fb = reinterpret_cast<float *>(xb);
+            if (n_out > 0)
+                halo_pull_kernel<true><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_out * (ld / 4), 256), 16384), 256, 0, st>>>(
+                    ent, ld, g, hw.lists + (size_t)sl2 * world * g.cap, tab2 + 2 * (world + 1), tab2 + (world + 1), fb);
+            for (int p = 0; p < world; ++p) {
+                sc[p] = p == rank ? 0 : cnt(sl2, p, rank) * ld;
+                sd[p] = (int64_t)u1[p] * ld;
+                rc_[p] = p == rank ? 0 : cnt(sl2, rank, p) * ld;
+                rd[p] = (int64_t)u0[p] * ld;
+            }
+            OEA_TRY_RC(oea_comm_alltoallv(comm, fb, sc.data(), sd.data(), fa, rc_.data(), rd.data(), OEA_COMM_F32, stream));
+            OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+            if (n_in > 0)
+                halo_pull_kernel<false><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_in * (ld / 4), 256), 16384), 256, 0, st>>>(
+                    ent, ld, g, hw.lists + ((size_t)sl2 * world + rank) * g.cap, nullptr, tab2, fa);
+            if (stats_host) {
+                int64_t in_rows = 0;
+                for (int p = 0; p < world; ++p) in_rows += p == rank ? 0 : cnt(sl2, rank, p);
+                stats_host[1] += in_rows * ld * 4;
+            }
+        } else {
+            // the range ends: one dense all-gather of the owned rows makes every copy the single-GPU table
+            halo_owned_rows_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(rpr * (ld / 4), 256), 16384), 256, 0, st>>>(ent, n_ent, ld, world, rank, rpr, upd);
+            OEA_TRY_RC(oea_allgather_rows(comm, upd, all, rpr, ld, stream));
+            OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+            OEA_TRY_RC(oea_part_unpack(ent, n_ent, ld, world, rank, all, stream));
+        }
+        OEA_TRY_RC(oea::comm_phase_mark(comm, st));
+        ++step_cfg.opt_t;
+    }
+#undef OEA_TRY_RC
+    OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
 
