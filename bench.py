@@ -17,8 +17,10 @@ and negatives on a side stream).  value = positives (training triples) consumed 
 N > 1: `python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1, one process per GPU,
 RCCL); started under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  The batch of 20,000 stays GLOBAL (STRONG
 scaling: every rank scores 20,000 / N positives of every batch) with the PARITY-PRESERVING exchange (--exchange step: entity
-rows owned by id mod N; the N-rank job equals the single-GPU job), one C call per epoch over the C ABI's RCCL communicator
-(oea_triple_epoch_range_comm), with HIP-event phase times.  The same configuration on ONE GPU is timed in the same run
+rows owned by id mod N; the N-rank job equals the single-GPU job) moving only the BOUNDARY rows a step's batch refers to
+(--exchange halo: all-to-all of the gradient rows to their owners, all-to-all of the rows the next step reads; --exchange step
+= the dense reduce-scatter / all-gather of every owned row, a side leg), one C call per epoch over the C ABI's RCCL
+communicator (oea_triple_epoch_range_halo), with HIP-event phase times.  The same configuration on ONE GPU is timed in the same run
 (extra.single_gpu_same_config).  --exchange epoch (local SGD, one exchange per epoch: drifts from the single-GPU job,
 tests/test_dist_gpu.py) and --scaling weak are named side legs.
 
@@ -75,11 +77,13 @@ def parse():
     ap.add_argument("--neg", type=int, default=10)
     ap.add_argument("--eps", type=float, default=None, help="truncated_epsilon; default 0.9 (15K) / 0.98 (100K)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong at N > 1 (the BASELINE batch)")
-    ap.add_argument("--exchange", choices=("epoch", "step", "allreduce"), default="step",
-                    help="N > 1: how the ranks exchange (models/trainer.py:TripleTrainer).  step (default): per-step reduce-scatter / "
-                         "all-gather under the entity-id partition, the N-rank job EQUALS the single-GPU job; epoch: local steps on "
-                         "each rank's share of the batch, one exchange per epoch (local SGD: drifts).  The other mode is measured too "
-                         "(extra.other_exchange)")
+    ap.add_argument("--exchange", choices=("halo", "epoch", "step", "allreduce"), default="halo",
+                    help="N > 1: how the ranks exchange (models/trainer.py:TripleTrainer).  halo (default): the entity-id partition "
+                         "moving only the BOUNDARY rows a step's batch refers to (all-to-all of gradient rows to their owners, "
+                         "all-to-all of the rows the next step reads; the N-rank job EQUALS the single-GPU job); step: the same "
+                         "partition with a dense reduce-scatter / all-gather of every owned row per step; epoch: local steps on "
+                         "each rank's share of the batch, one exchange per epoch (local SGD: drifts).  step and epoch are measured "
+                         "too (extra.other_exchange, extra.local_sgd)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the eval / neighbour / 100K-shape legs")
     ap.add_argument("--no-gnn", action="store_true", help="skip the GNN legs (BASELINE configs 3-5)")
@@ -613,7 +617,7 @@ def compact_line(out, detail_path=None):
     one = x.get("single_gpu_same_config")
     if isinstance(one, dict):
         e["single_gpu_same_config"] = _pick(one, ("value", "ms_per_step"))
-    for k in ("other_exchange", "other_scaling"):
+    for k in ("other_exchange", "local_sgd", "other_scaling"):
         if isinstance(x.get(k), dict):
             e[k] = _pick(x[k], ("value", "ms_per_step", "exchange_mode", "scaling", "global_batch"))
     s15 = x.get("shape_15k")
@@ -634,6 +638,7 @@ def compact_line(out, detail_path=None):
                                      "spmm_hbm_frac": (gc.get("roofline") or {}).get("hbm_frac")}
             al = g.get("alinet_EN-DE-100K") or {}
             gg["alinet_EN-DE-100K"] = {"ms_per_epoch": al.get("ms_per_epoch"), "ms_per_epoch_row": al.get("ms_per_epoch_grouping_row"),
+                                       "ms_per_epoch_reorder": al.get("ms_per_epoch_grouping_reorder"),
                                        "attn_fwd_ms": al.get("attention_fwd_ms"), "attn_bwd_ms": al.get("attention_bwd_ms"),
                                        "attn_frac": (al.get("roofline") or {}).get("frac"),
                                        "attn_row_fwd_ms": (al.get("grouping_row") or {}).get("attention_fwd_ms"),
@@ -666,7 +671,7 @@ def compact_line(out, detail_path=None):
     c = clean(c)
     line = json.dumps(c, separators=(",", ":"))
     # never let the line grow past the limit: drop the optional blocks, least important first
-    for k in ("gnn", "shape_15k", "other_scaling", "other_exchange", "exchange_phases"):
+    for k in ("gnn", "shape_15k", "other_scaling", "local_sgd", "other_exchange", "exchange_phases"):
         if len(line) <= COMPACT_LIMIT:
             break
         c["extra"].pop(k, None)
@@ -730,8 +735,10 @@ def multi_gpu_legs(torch, ops, dev, args, rank, world, group, main_wl):
     one = run(args.shape, args.dim, args.batch, args.eps, None, None, steps, wu, 5, single=True)
     one["note"] = "the same shape / dim / batch / k on ONE GPU (rank 0's; every rank ran it on its own GPU at the same time)"
     out["single_gpu_same_config"] = one
-    other = "epoch" if main_wl.trainer.exchange != "epoch" else "step"
+    other = "step" if main_wl.trainer.exchange != "step" else "halo"
     out["other_exchange"] = run(args.shape, args.dim, args.batch, args.eps, other, args.scaling, steps, wu, 5)
+    if main_wl.trainer.exchange != "epoch":
+        out["local_sgd"] = run(args.shape, args.dim, args.batch, args.eps, "epoch", args.scaling, steps, wu, 5)
     if not args.no_extra and not os.environ.get("OEA_BENCH_ONE_GPU"):       # (the one-GPU wiring test stops here: host-staged collectives)
         out["other_scaling"] = run(args.shape, args.dim, args.batch, args.eps, args.exchange, "weak" if args.scaling == "strong" else "strong",
                                    steps, wu, 3)
@@ -1208,12 +1215,20 @@ def gnn_legs(torch, ops, dev, traffic=None):
     torch.cuda.empty_cache()
     a_row, _, _, ms_epoch_row = _build_alinet(torch, ops, dev, grouping="row", epochs=3)
     del a_row
+    torch.cuda.empty_cache()
+    try:        # the third reading of tf.sparse_softmax (canonical re-ordering before the row softmax, values re-attached as fed)
+        a_reo, _, _, ms_epoch_reo = _build_alinet(torch, ops, dev, grouping="reorder", epochs=3)
+        del a_reo
+    except Exception as e:      # noqa: BLE001
+        ms_epoch_reo = None
+        out["alinet_reorder_error"] = repr(e)[:200]
     out["alinet_EN-DE-100K"] = {
         "workload": "AliNet, layer_dims [500, 400, 300], EN-DE-100K-V1 shape: E=%d, 1-hop nnz=%d, 2-hop nnz=%d; one epoch = one "
                     "full-graph step + Adam; default attn_grouping 'runs' (TF1's run grouping on the column-major adjacency: %d "
                     "groups), 'row' (per-row softmax: %d groups) beside it" % (n, g1.nnz, nnz2, att["runs"]["softmax_groups"],
                                                                              att["row"]["softmax_groups"]),
         "init_s": round(init_s, 2), "ms_per_epoch": round(ms_epoch, 2), "ms_per_epoch_grouping_row": round(ms_epoch_row, 2),
+        "ms_per_epoch_grouping_reorder": None if ms_epoch_reo is None else round(ms_epoch_reo, 2),
         "attention_fwd_ms": att["runs"]["attention_fwd_ms"], "attention_bwd_ms": att["runs"]["attention_bwd_ms"],
         "roofline": att["runs"]["roofline"], "grouping_row": att["row"],
         "roofline_1hop_aggregate": _with_hbm(_hbm_block("spmm_csr_kernel (1-hop aggregate, d=%d)" % d, g1.nnz * (8 + 4 * d) + 4 * n * d,

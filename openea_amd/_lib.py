@@ -234,12 +234,22 @@ PROTOTYPES = {
     "oea_comm_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "oea_comm_reduce_scatter": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "oea_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "oea_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
+    "oea_comm_alltoallv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "oea_halo_workspace_bytes": (_sz, [_i64, _i32, _i32, _i64, _i32]),
+    "oea_halo_buffer_bytes": (_sz, [_i64, _i32, _i64, _i32, _i32]),
+    "oea_triple_epoch_range_halo": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                        C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
+                                        C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "oea_comm_profile_begin": (C.c_int, [_vp]),
     "oea_comm_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i32)]),
 }
 
 # oea_comm_callback: int (*)(void *user, int32 op, const void *send, void *recv, int64 count, int32 dtype, void *stream)
 COMM_CALLBACK = C.CFUNCTYPE(C.c_int, _vp, _i32, _vp, _vp, _i64, _i32, _vp)
+# oea_comm_alltoallv_callback: int (*)(void *user, const void *send, const int64 *send_counts, const int64 *send_displs, void *recv,
+#                                     const int64 *recv_counts, const int64 *recv_displs, int32 dtype, void *stream)
+COMM_ALLTOALLV_CALLBACK = C.CFUNCTYPE(C.c_int, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp, C.POINTER(_i64), C.POINTER(_i64), _i32, _vp)
 COMM_ALLREDUCE, COMM_ALLGATHER, COMM_REDUCE_SCATTER = 0, 1, 2
 COMM_F32, COMM_F64, COMM_I64 = 0, 1, 2
 COMM_PHASES = ("grad", "pack", "reduce_scatter", "apply", "all_gather", "unpack")

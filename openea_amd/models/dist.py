@@ -181,6 +181,8 @@ class CAbiComm:
             self.callbacks = True
         self._fn = _lib.COMM_CALLBACK(self._collective)            # kept alive with the object
         check(lib.oea_comm_init_callbacks(self.rank, self.world, C.cast(self._fn, C.c_void_p), None, C.byref(self.handle)))
+        self._fn_a2a = _lib.COMM_ALLTOALLV_CALLBACK(self._alltoallv)
+        check(lib.oea_comm_set_alltoallv(self.handle, C.cast(self._fn_a2a, C.c_void_p)))
 
     @staticmethod
     def _note_no_rccl(e):
@@ -241,6 +243,47 @@ class CAbiComm:
             import traceback
             traceback.print_exc()
             return 1
+
+    def _alltoallv(self, user, send, send_counts, send_displs, recv, recv_counts, recv_displs, dtype, stream):
+        """oea_comm_alltoallv_callback over torch.distributed point-to-point messages, staged through the host (gloo; N ranks on
+        one GPU): peer p gets send[send_displs[p] : + send_counts[p]] (elements)"""
+        try:
+            from .._lib import check
+            npdt = np.dtype(self._NP[int(dtype)])
+            w, me = self.world, self.rank
+            sc = [int(send_counts[p]) for p in range(w)]
+            sd = [int(send_displs[p]) for p in range(w)]
+            rc = [int(recv_counts[p]) for p in range(w)]
+            rd = [int(recv_displs[p]) for p in range(w)]
+            outs, ins, reqs = {}, {}, []
+            for p in range(w):
+                if sc[p] > 0:
+                    h = np.empty(sc[p], npdt)
+                    check(self.lib.oea_copy_to_host(int(send) + sd[p] * npdt.itemsize, h.ctypes.data, h.nbytes, stream))
+                    outs[p] = torch.from_numpy(h)
+                if rc[p] > 0:
+                    ins[p] = torch.empty(rc[p], dtype=torch.from_numpy(np.empty(0, npdt)).dtype)
+            for p in range(w):               # post every receive, then the sends (any order completes)
+                if p != me and p in ins:
+                    reqs.append(dist.irecv(ins[p], src=self._global(p), group=self.group))
+            for p in range(w):
+                if p != me and p in outs:
+                    reqs.append(dist.isend(outs[p], dst=self._global(p), group=self.group))
+            if me in ins:
+                ins[me].copy_(outs[me])
+            for r in reqs:
+                r.wait()
+            for p, t in ins.items():
+                o = t.numpy()
+                check(self.lib.oea_copy_from_host(int(recv) + rd[p] * npdt.itemsize, o.ctypes.data, o.nbytes, stream))
+            return 0
+        except Exception:            # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _global(self, p):
+        return dist.get_global_rank(self.group, p) if self.group is not None and self.group is not dist.group.WORLD else p
 
     def profile_begin(self):
         from .._lib import check

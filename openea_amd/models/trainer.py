@@ -64,6 +64,13 @@ class TripleTrainer:
         exchange (with a dist_group, not replicated; default: OEA_DP_EXCHANGE or 'step'):
           'step'      the G-rank job EQUALS the single-GPU job: per step, gradients reduce-scattered to the owners of the
                       entity rows (owner = id mod G), owners run the optimiser, updated rows all-gathered;
+          'halo'      the same partition and the same result as 'step' (bit for bit in the fixed-point build), but a step moves only
+                      the BOUNDARY rows -- the rows its batch refers to (BASELINE.json north_star: "all-gather of boundary
+                      embeddings"): every rank derives the row lists of every rank's share of every step from the epoch's
+                      positives and negatives, gradient rows go to their owners by all-to-all, the rows the next step's readers
+                      refer to come back by all-to-all, one dense all-gather ends each call (oea_triple_epoch_range_halo:
+                      ~19 MB per rank and step instead of 161 MB at the 100K shape with 8 ranks).  TransE / TransH scores with the
+                      one-call epoch; anything else runs 'step';
           'allreduce' the same with one dense all-reduce and a replicated update (round 1);
           'epoch'     BASELINE.json north_star: "RCCL all-gather of boundary embeddings ... each epoch" -- every rank trains
                       its share of every batch on its LOCAL copy of the tables with the fused single-GPU epoch call (no
@@ -77,8 +84,10 @@ class TripleTrainer:
         import os as _os
         self.exchange = exchange or {"partition": "step"}.get(_os.environ.get("OEA_DP_EXCHANGE", "step"),
                                                                _os.environ.get("OEA_DP_EXCHANGE", "step"))
-        if self.exchange not in ("step", "allreduce", "epoch"):
-            raise ValueError("dp_exchange: 'step', 'allreduce' or 'epoch'")
+        if self.exchange not in ("step", "halo", "allreduce", "epoch"):
+            raise ValueError("dp_exchange: 'step', 'halo', 'allreduce' or 'epoch'")
+        if self.exchange == "halo" and (cfg.score_kind not in (ops.SCORE_TRANSE, ops.SCORE_TRANSH) or optimizer not in ('Adagrad', 'SGD')):
+            self.exchange = "step"        # TransD's stacked transfer rows are not in the boundary lists; dense optimisers move every row
         if dist_group is None or self.replicated:
             self.exchange = "step"
         if self.exchange == "epoch" and cfg.score_kind not in (ops.SCORE_TRANSE, ops.SCORE_TRANSD):
@@ -111,8 +120,12 @@ class TripleTrainer:
         self.part = None
         import os
         if (dist_group is not None and not self.replicated and optimizer in ('Adagrad', 'SGD')
-                and cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD) and self.exchange == "step"):
+                and cfg.score_kind in (ops.SCORE_TRANSE, ops.SCORE_TRANSH, ops.SCORE_TRANSD) and self.exchange in ("step", "halo")):
             self._init_partition(optimizer)
+        self.halo = None                  # workspace + buffers of the boundary-row exchange (halo_buffers, made on first use)
+        self.halo_stats = [0, 0, 0, 0]    # bytes pushed, bytes pulled, largest rows sent in a step, steps (this rank)
+        if self.exchange == "halo" and (self.part is None or getattr(self, "comm", None) is None):
+            self.exchange = "step"        # no communicator for the one-call epoch: the dense per-step protocol (same result)
 
     # ---- dp_exchange = 'epoch': local steps, one exchange per epoch ----------------------------------------------
     @property
@@ -195,6 +208,14 @@ class TripleTrainer:
                 print("[openea_amd] one-call partitioned epoch unavailable (%s): per-step exchange from Python" % str(e)[:200],
                       file=sys.stderr)
                 self.comm = None
+
+    def halo_buffers(self, steps, max_batch, k):
+        """workspace + exchange buffers of the boundary-row exchange, sized for `steps` steps of batches of <= max_batch rows"""
+        key = (int(steps), int(max_batch), int(k))
+        if self.halo is None or self.halo['key'] != key:
+            import torch.distributed as dist
+            self.halo = ops.halo_buffers(self.ent.rows, self.ent.ld, dist.get_world_size(self.dist), steps, max_batch, k, self.dev)
+        return self.halo
 
     def close(self):
         """release the C ABI communicator of the partitioned step (RCCL communicator + staging buffers); the garbage collector
@@ -301,6 +322,11 @@ class TripleTrainer:
             return ("dp_exchange = 'epoch': local steps on this rank's share of every batch (fused epoch call, no collective); "
                     "per epoch one all-reduce of the changes of tables + optimiser state (= reduce-scatter to the row owners + "
                     "all-gather of the owned rows)")
+        if self.part is not None and self.exchange == "halo":
+            return ("owner = id mod G, boundary rows only: all-to-all of the gradient rows (+ flag) a rank's share of the batch "
+                    "refers to (lists derived on every rank from the epoch's batches: no index travels), all-reduce of the relation "
+                    "rows, all-to-all of the current values of the rows the next step's readers refer to; one dense all-gather "
+                    "of the owned rows ends each call")
         if self.part is not None:
             return ("owner = id mod G: reduce-scatter of the packed gradient rows + touched flags ([G][rows/G][ld+1] fp32), "
                     "all-reduce of the relation rows, all-gather of the updated owned rows ([G][rows/G][ld])")
@@ -313,6 +339,12 @@ class TripleTrainer:
             return 0
         import torch.distributed as dist
         g = dist.get_world_size(self.dist)
+        if self.part is not None and self.exchange == "halo" and self.halo_stats[3] > 0:
+            # measured: gradient rows sent + rows received per step (the closing all-gather of a call is amortised over its steps by
+            # the caller: epoch_exchange_bytes has no halo term) + the relation all-reduce
+            p = self.part
+            nb = lambda t: t.numel() * t.element_size()
+            return int((self.halo_stats[0] + self.halo_stats[1]) / self.halo_stats[3] + nb(p['rel_x']) * 2 * (g - 1) / g)
         if self.part is not None:       # reduce-scatter of the packed gradients + all-gather of the updated rows + relation all-reduce
             p = self.part            # the gradients travel as fp32 or (deterministic build) int64, the updated rows as fp32
             nb = lambda t: t.numel() * t.element_size()
@@ -430,7 +462,20 @@ class RelationTripleEpochs:
             have = self.k and self._epoch_negs_ready
             if hasattr(trainer, "count_steps"):
                 trainer.count_steps(int((np.diff(b.offsets[lo:hi + 1]) > 0).sum()))
-            if c_part:
+            if c_part and getattr(trainer, "exchange", None) == "halo":
+                halo = trainer.halo_buffers(S, int(np.diff(b.offsets).max()), self.k)
+                if getattr(self, "_off_dev", None) is None:          # (k = 0: no negatives buffer made them)
+                    self._off_dev = torch.from_numpy(b.offsets).to(self.dev)
+                    self._spl_dev = torch.from_numpy(b.splits).to(self.dev)
+                st = ops.triple_epoch_halo(trainer.comm.handle, trainer.ent.var, trainer.part['acc_own'], trainer.rel.var, trainer.rel_acc,
+                                           trainer.ent.dim, b.dall, b.offsets, b.splits, self.k,
+                                           None if (have or not self.k) else self._sides[0],
+                                           None if (have or not self.k) else self._sides[1], self.seed, self._epoch_base,
+                                           self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
+                                           trainer.ws, trainer.loss, self._off_dev, self._spl_dev, trainer.part, halo, step_range=(lo, hi))
+                trainer.halo_stats = [trainer.halo_stats[0] + st[0], trainer.halo_stats[1] + st[1], max(trainer.halo_stats[2], st[2]),
+                                      trainer.halo_stats[3] + st[3]]
+            elif c_part:
                 ops.triple_epoch_comm(trainer.comm.handle, trainer.ent.var, trainer.part['acc_own'], trainer.rel.var, trainer.rel_acc,
                                       trainer.ent.dim, b.dall, b.offsets, b.splits, self.k,
                                       None if (have or not self.k) else self._sides[0],

@@ -394,6 +394,33 @@ def triple_epoch_comm(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, s
                                             _p(bufs['upd']), _p(bufs['all']), _stream()))
 
 
+def halo_buffers(n_ent, ld, world, steps, max_batch, k, dev):
+    """workspace + the two exchange buffers of the boundary-row exchange (oea_triple_epoch_range_halo)"""
+    wsb = lib().oea_halo_workspace_bytes(int(n_ent), int(world), int(steps), int(max_batch), int(k))
+    xb = lib().oea_halo_buffer_bytes(int(n_ent), int(world), int(max_batch), int(k), int(ld))
+    u8 = dict(dtype=torch.uint8, device=dev)
+    return dict(ws=torch.empty(wsb, **u8), a=torch.empty(xb, **u8), b=torch.empty(xb, **u8), key=(int(steps), int(max_batch), int(k)))
+
+
+def triple_epoch_halo(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base, neg_buf,
+                      err_flag, cfg, workspace, loss_accum, offsets_dev, splits_dev, bufs, halo, step_range=None):
+    """triple_epoch_comm with the boundary-row exchange (oea_triple_epoch_range_halo); bufs = part_buffers(...), halo =
+    halo_buffers(...) -> (bytes pushed, bytes pulled, largest rows sent in a step, steps) of this rank"""
+    steps = len(splits)
+    lo, hi = (0, steps) if step_range is None else step_range
+    stats = (C.c_int64 * 4)()
+    check(lib().oea_triple_epoch_range_halo(comm, _p(ent), _p(acc_own), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+                                            ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
+                                            splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
+                                            C.byref(side0) if side0 is not None else None,
+                                            C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
+                                            _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
+                                            _p(offsets_dev), _p(splits_dev), _p(halo['ws']), halo['ws'].numel(), _p(halo['a']),
+                                            _p(halo['b']), halo['a'].numel(), _p(bufs['rel_x']), _p(bufs['upd']), _p(bufs['all']),
+                                            C.cast(stats, C.c_void_p), _stream()))
+    return tuple(int(x) for x in stats)
+
+
 def sample_link_negatives(n_pos, k, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None, row2=None,
                           exclude=None, seed=0, step=0, scratch=None):
     """AliNet.generate_input_batch negatives on the device -> (pairs int32 [m, 2], valid fp32 [m]).

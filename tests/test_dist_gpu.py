@@ -282,7 +282,7 @@ def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
     assert lines[0] == p.stdout.decode().strip().splitlines()[-1] and len(lines[0]) < 4096      # the compact line is the LAST line
     c = json.loads(lines[0])
     assert c["n_gpus"] == 2 and c["steps"] == 10 and c["warmup"] == 3 and c["scaling"] == "strong" and c["value"] > 0
-    assert 0 < c["roofline"]["frac"] <= 1 and c["roofline"]["avg_kernel_us"] > 0 and c["extra"]["exchange_mode"] == "step"
+    assert 0 < c["roofline"]["frac"] <= 1 and c["roofline"]["avg_kernel_us"] > 0 and c["extra"]["exchange_mode"] == "halo"
     assert c["extra"]["exchange_phases"]["steps_timed"] == 10 and c["extra"]["single_gpu_same_config"]["value"] > 0
     assert c["extra"]["collective_world_size"] == 2 and c["extra"]["eval_pairs_per_s_inner"] > 0
     j = json.load(open(detail))                 # everything measured: bench_detail.json
@@ -290,11 +290,12 @@ def test_bench_two_ranks_like_the_driver(tmp_path, launcher):
     assert j["roofline"]["launches_timed"] > 0 and j["roofline"]["avg_kernel_us"] > 0 and j["roofline"]["apply_rows_avg_us"] > 0
     assert 0 < j["roofline"]["frac"] <= 1 and 0 < j["roofline"]["frac_sec8d"] <= 1
     x = j["extra"]
-    assert x["exchange_bytes_per_step_per_rank"] > 0 and x["collective_world_size"] == 2 and x["exchange_mode"] == "step"
+    assert x["exchange_bytes_per_step_per_rank"] > 0 and x["collective_world_size"] == 2 and x["exchange_mode"] == "halo"
+    assert x["exchange_bytes_per_step_per_rank"] < x["other_exchange"]["exchange_bytes_per_step_per_rank"]      # boundary rows < every owned row
     assert x["eval_pairs_per_s_inner"] > 0 and x["neighbour_rows_per_s"] > 0
     assert j["config"]["parallelism"].startswith("dp2") and j["config"]["global_batch"] == 5000       # BASELINE config 2's batch, kept global
     ph = x["exchange_phases"]                  # HIP events of the one-call partitioned epoch
     assert ph["steps_timed"] == 10 and all(ph[k + "_us"] >= 0 for k in ("grad", "pack", "reduce_scatter", "apply", "all_gather", "unpack"))
     assert ph["grad_us"] > 0 and ph["apply_us"] > 0
     assert x["single_gpu_same_config"]["value"] > 0 and x["speedup_vs_single_gpu_same_config"] > 0
-    assert x["other_exchange"]["exchange_mode"] == "epoch" and "parity" in x["other_exchange"]
+    assert x["other_exchange"]["exchange_mode"] == "step" and x["local_sgd"]["exchange_mode"] == "epoch" and "parity" in x["local_sgd"]

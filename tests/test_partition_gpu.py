@@ -287,19 +287,30 @@ opt = os.environ["OEA_OPT"]
 cfg = ops.make_step_cfg(loss="limited", loss_norm="L2", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer=opt, lr=0.02,
                         neg_group_k=k)
 ent, rel = EmbeddingTable(ent_h, True, "e"), EmbeddingTable(rel_h, True, "r")
-tr = TripleTrainer(ent, rel, cfg, opt, dist_group=group)
+exchange = os.environ.get("OEA_EXCHANGE", "step")
+tr = TripleTrainer(ent, rel, cfg, opt, dist_group=group, exchange=exchange if world > 1 else None)
 if world > 1:
     assert tr.part is not None and tr.comm is not None and tr.comm.callbacks      # the one-call epoch is the default path
+    assert tr.exchange == exchange
     tr.comm.profile_begin()
 ep = RelationTripleEpochs(kgs, 700, k, seed=3, rank=rank, world=world)
 n = 0
 n_epochs, refresh = int(os.environ["OEA_EPOCHS"]), os.environ["OEA_REFRESH"] == "1"
+chunk = int(os.environ.get("OEA_CHUNK", "0"))            # > 0: the epoch in ranges of that many steps (partial ranges of the C call)
+S = len(ep.batches.splits)
 for e in range(n_epochs):
     if e == 2 and refresh:            # a truncated-sampling refresh in between, as BootEA / AlignE do
         nbr1 = refresh_neighbours(ent, kgs.kg1.entities_list, 40)
         nbr2 = refresh_neighbours(ent, kgs.kg2.entities_list, 40)
         ep.set_neighbours(nbr1, nbr2)
-    n += ep.run_epoch(tr)
+    if chunk:
+        done = 0
+        while done < S:
+            c = min(chunk, S - done)
+            n += ep.run_steps(tr, c)
+            done += c
+    else:
+        n += ep.run_epoch(tr)
 ep.check()
 torch.cuda.synchronize()
 phases = None
@@ -308,18 +319,20 @@ if world > 1:
     assert steps == n_epochs * len(ep.batches.splits) and all(v >= 0 for v in phases.values()) and phases["grad"] > 0, (phases, steps)
 loss = tr.pop_loss()
 np.savez(os.environ["OEA_OUT"] + "/ep_w%d_r%d.npz" % (world, rank), ent=ent.raw(), rel=rel.raw(), loss=loss, n=n,
-         det=int(ops.deterministic()))
+         det=int(ops.deterministic()), halo=np.asarray(tr.halo_stats, np.int64), xbytes=tr.exchange_bytes_per_step(),
+         rows=kgs.entities_num, ld=ent.ld, steps=n_epochs * S)
 if world > 1:
     dist.barrier()
 '''
 
 
-def _launch_epochs(tmp_path, world, opt, det):
+def _launch_epochs(tmp_path, world, opt, det, exchange="step", chunk=0):
     # fixed point: five epochs with a neighbour refresh in between, compared BIT FOR BIT.  fp32 atomics: the single-GPU job is
     # not reproducible run to run (the order of the atomics), a flipped hinge or a neighbour set that differs by one entity
     # after the refresh grows into 5e-3 per row within three epochs -- two epochs without the refresh are held to 1e-4
     env = dict(os.environ, OEA_ROOT=ROOT, OEA_OUT=str(tmp_path), OEA_PORT=str(_free_port()), WORLD_SIZE=str(world), OEA_OPT=opt,
-               OEA_STEP_DETERMINISTIC="1" if det else "0", OEA_EPOCHS="5" if det else "2", OEA_REFRESH="1" if det else "0")
+               OEA_STEP_DETERMINISTIC="1" if det else "0", OEA_EPOCHS="5" if det else "2", OEA_REFRESH="1" if det else "0",
+               OEA_EXCHANGE=exchange, OEA_CHUNK=str(chunk))
     env.pop("OEA_DP_C_EPOCH", None)
     procs = [subprocess.Popen([sys.executable, "-c", EPOCH_RANKS_WORKER], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(world)]
@@ -368,3 +381,38 @@ def test_one_call_partitioned_epochs_with_2_and_4_ranks_equal_the_single_process
         if det:
             assert np.array_equal(ranks[0]["ent"], single["ent"]) and np.array_equal(ranks[0]["rel"], single["rel"]), \
                 "fixed-point build: the %d-rank job must equal the single-process job bit for bit" % world
+
+
+@pytest.mark.parametrize("det,opt,chunk", [(True, "Adagrad", 0), (True, "SGD", 3), (False, "Adagrad", 0)],
+                         ids=["fixed_point-Adagrad", "fixed_point-SGD-ranges_of_3", "fp32_atomics-Adagrad"])
+def test_boundary_row_exchange_with_2_and_4_ranks_equals_the_single_process_job(tmp_path, det, opt, chunk, capsys):
+    """dp_exchange = 'halo' (oea_triple_epoch_range_halo): the partitioned step moving only the rows a step's batch refers to -- row
+    lists derived on every rank from the epoch's positives and negatives, all-to-all of the gradient rows to their owners,
+    all-to-all of the rows the next step's readers refer to, one dense all-gather at the end of every call.  2 and 4 ranks on this
+    box's GPU (host callbacks over gloo, point-to-point messages): replicas hold the same bits, the tables are the single-process
+    job's BIT FOR BIT in the fixed-point build (five epochs, a neighbour refresh in between, also when an epoch is run in ranges of
+    3 steps: pulls between ranges, presampled negatives) and within the north-star tolerance with fp32 atomics; and the bytes a
+    rank moves per step are a fraction of the dense protocol's."""
+    from _tol import assert_rows_close
+    single = _launch_epochs(tmp_path, 1, opt, det)[0]
+    for world in (2, 4):
+        ranks = _launch_epochs(tmp_path, world, opt, det, exchange="halo", chunk=chunk)
+        for r in ranks[1:]:
+            assert np.array_equal(r["ent"], ranks[0]["ent"]) and np.array_equal(r["rel"], ranks[0]["rel"])
+        assert sum(int(r["n"]) for r in ranks) == int(single["n"])
+        with capsys.disabled():
+            assert_rows_close(ranks[0]["ent"], single["ent"], "halo exchange, %s%s, %d ranks vs 1 process, entity table"
+                              % (opt, " fixed point" if det else "", world))
+            assert_rows_close(ranks[0]["rel"], single["rel"], "relation table")
+        assert abs(float(ranks[0]["loss"]) - float(single["loss"])) <= 1e-5 * abs(float(single["loss"]))
+        if det:
+            assert np.array_equal(ranks[0]["ent"], single["ent"]) and np.array_equal(ranks[0]["rel"], single["rel"]), \
+                "fixed-point build: the %d-rank halo job must equal the single-process job bit for bit" % world
+        for r in ranks:
+            pushed, pulled, max_rows, steps = (int(x) for x in r["halo"])
+            assert steps == int(r["steps"]) and pushed > 0 and pulled > 0 and 0 < max_rows <= int(r["rows"])
+        rows, ld = int(ranks[0]["rows"]), int(ranks[0]["ld"])
+        dense = (world - 1) / world * rows * (2 * ld + 1) * (8 if det else 4)          # reduce-scatter + all-gather of every owned row
+        with capsys.disabled():
+            print("halo exchange at world %d: %.0f bytes per step and rank (dense protocol: %.0f)" % (world, float(ranks[0]["xbytes"]), dense))
+        assert float(ranks[0]["xbytes"]) < dense
