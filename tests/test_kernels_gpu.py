@@ -1208,3 +1208,59 @@ def test_manhattan_evaluation_from_grid_distances_equals_all_pairs_fp64(ops, cas
     assert torch.equal(rk, rk_ref) and torch.equal(am, am_ref)
     if case in ("degenerate", "outliers", "clustered"):
         assert stats["uncertified"] > 0                             # these tables send rows through the all-pairs fallback
+
+
+PIPE_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["OEA_ROOT"])
+from openea_amd import ops
+assert ops.deterministic()
+out = {}
+for d, n_pos, k in ((100, 6500, 10), (75, 5000, 10), (37, 4100, 7), (128, 3000, 3)):
+    rng = np.random.RandomState(d)
+    n_ent, n_rel = 5000, 61
+    ent0 = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32) * 1.3
+    rel0 = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32) * 0.7
+    w = 1.0 / np.arange(1, n_ent + 1) ** 0.9
+    pos = np.stack([rng.choice(n_ent, n_pos, p=w / w.sum()), rng.randint(0, n_rel, n_pos), rng.randint(0, n_ent, n_pos)], 1).astype(np.int32)
+    neg = np.repeat(pos, k, 0)
+    flip = rng.rand(len(neg)) < 0.5
+    neg[flip, 0] = rng.randint(0, n_ent, int(flip.sum()))
+    neg[~flip, 2] = rng.randint(0, n_ent, int((~flip).sum()))
+    neg[5] = (3, 1, 4)                      # an entry that is NOT a corruption of its positive: the independent-triple path
+    e, r = ops.to_table(ent0), ops.to_table(rel0)
+    ea, ra = torch.full_like(e, 0.1), torch.full_like(r, 0.1)
+    ws = ops.step_workspace(n_ent, n_rel, ops.pad4(d))
+    loss = torch.zeros(1, dtype=torch.float64, device=e.device)
+    cfg = ops.make_step_cfg(loss="limited", loss_norm="L2" if d != 37 else "L1", pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad",
+                            lr=0.01, neg_group_k=k)
+    for _ in range(3):
+        ops.triple_step(e, ea, r, ra, d, ops.to_ids(pos), ops.to_ids(neg), cfg, ws, loss)
+    torch.cuda.synchronize()
+    out["e%d" % d], out["r%d" % d], out["l%d" % d] = e.cpu().numpy(), r.cpu().numpy(), float(loss.item())
+np.savez(os.environ["OEA_OUT"], **out)
+'''
+
+
+def test_software_pipelined_step_kernel_equals_the_one_positive_kernel(tmp_path):
+    """triple_grouped_dma (OEA_STEP_PIPE=1: a group walks several positives, the next positive's rows travel through the LDS by DMA
+    behind the current one's arithmetic) against triple_grouped (one positive per group) in the fixed-point build: the arithmetic
+    per positive is the same statement for statement and integer sums have no order, so three Adagrad steps on Zipf-headed batches
+    (d = 100 / 75 / 37 with the L1 norm / 128; k = 10 / 7 / 3; an entry that is no corruption of its positive) must leave the SAME
+    BITS in both tables; the epoch loss differs only by the grouping of its fp64 partial sums."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for pipe in ("0", "1"):
+        out = str(tmp_path / ("pipe%s.npz" % pipe))
+        env = dict(os.environ, OEA_ROOT=root, OEA_OUT=out, OEA_STEP_DETERMINISTIC="1", OEA_STEP_PIPE=pipe)
+        p = subprocess.run([sys.executable, "-c", PIPE_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+        res[pipe] = dict(np.load(out))
+    for d in (100, 75, 37, 128):
+        assert np.array_equal(res["0"]["e%d" % d], res["1"]["e%d" % d]), d
+        assert np.array_equal(res["0"]["r%d" % d], res["1"]["r%d" % d]), d
+        assert abs(float(res["0"]["l%d" % d]) - float(res["1"]["l%d" % d])) <= 1e-12 * abs(float(res["0"]["l%d" % d])), d
