@@ -167,6 +167,10 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                           double *loss_accum, int32_t phase, void *stream);
 
+/* work items of the scoring kernel of a step with n_pos positives and n_neg negatives under `cfg` (= the n_items oea_part_apply is
+ * told, which decides how many loss partials it adds up): n_pos when the negatives ride with their positives, n_pos + n_neg else. */
+int64_t oea_step_items(const oea_step_cfg *cfg, int64_t n_pos, int64_t n_neg);
+
 /* Entity-id partitioning of the same step across `world` processes (one per GPU): owner of entity row id = id mod world
  * (BASELINE.json north_star; SURVEY 8e: ids are degree-ordered, contiguous ranges would put every hub on rank 0).  Every rank
  * keeps a full read copy of the entity table and the optimiser state of ITS rows only (acc_own [rows_per_rank, ld]).

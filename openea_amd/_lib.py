@@ -234,6 +234,7 @@ PROTOTYPES = {
     "oea_comm_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "oea_comm_reduce_scatter": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "oea_comm_allreduce": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "oea_step_items": (_i64, [C.POINTER(StepCfg), _i64, _i64]),
     "oea_comm_set_alltoallv": (C.c_int, [_vp, _vp]),
     "oea_comm_alltoallv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "oea_halo_workspace_bytes": (_sz, [_i64, _i32, _i32, _i64, _i32]),

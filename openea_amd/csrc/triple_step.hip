@@ -1674,6 +1674,17 @@ static bool apply_g16(int64_t n_ent, int64_t n_rel, int32_t ld) {
     return env_g16 >= 0 ? env_g16 != 0 : (n_ent + n_rel) * (int64_t)ld * 12 > (int64_t)128 << 20;   // 3 arrays > 128 MB
 }
 
+// work items of the GRAD kernel of a step = how many loss partials it leaves (one per workgroup of ceil(items / groups per block)):
+// ONE rule for launch_step and for everything that adds the partials up afterwards (oea_part_apply, the one-call epochs; ADVICE
+// r04: the partitioned epoch took "grouped" from neg_group_k alone and under-counted TransD's partials -- the printed loss only)
+static int64_t step_items(const oea_step_cfg &cfg, int64_t n_pos, int64_t n_neg) {
+    const bool transh = cfg.score_kind == OEA_SCORE_TRANSH, transd = cfg.score_kind == OEA_SCORE_TRANSD;
+    const bool transh_grouped = transh && cfg.loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg.neg_group_k > 0);
+    const bool projected = transd || (transh && !transh_grouped);
+    const bool grouped = transh_grouped || (!projected && cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
+    return (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
+}
+
 template <int G, int IT>
 int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
@@ -1686,7 +1697,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     const bool transh_grouped = transh && cfg.loss_kind != OEA_LOSS_MARGIN && (n_neg == 0 || cfg.neg_group_k > 0);
     const bool projected = transd || (transh && !transh_grouped);
     const bool grouped = transh_grouped || (!projected && cfg.neg_group_k > 0 && cfg.loss_kind != OEA_LOSS_MARGIN);
-    const int64_t items = (grouped || cfg.loss_kind == OEA_LOSS_MARGIN) ? n_pos : n_pos + n_neg;
+    const int64_t items = step_items(cfg, n_pos, n_neg);
     const int nb1 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(items, gpb), 1), kMaxBlocks);
     // profiling events, 4 per STEP: [m0 fwd_bwd m1] ... [m2 apply m3], each pair attached to its kernel's dispatch
     // (oea::launch_timed); a GRAD call takes the first pair and decides whether the step is sampled, the APPLY call
@@ -1899,6 +1910,8 @@ int oea_step_apply_normals(int64_t n_ent, int64_t n_rel, int32_t ld, const oea_s
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
+
+int64_t oea_step_items(const oea_step_cfg *cfg, int64_t n_pos, int64_t n_neg) { return cfg ? step_items(*cfg, n_pos, n_neg) : -1; }
 
 int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, void *send_, void *rel_x_,
                   void *stream) {
@@ -2116,8 +2129,7 @@ int oea_triple_epoch_range_comm(oea_comm_t comm, float *ent, float *acc_own, int
             OEA_TRY_RC(oea_comm_allreduce(comm, nrm_touched, n_rel, gdt, stream));
         }
         OEA_TRY_RC(oea::comm_phase_mark(comm, st));
-        const bool grouped = step_cfg.neg_group_k > 0 || step_cfg.loss_kind == OEA_LOSS_MARGIN;
-        const int64_t n_items = grouped ? n : n + n * (int64_t)k;
+        const int64_t n_items = step_items(step_cfg, n, n * (int64_t)k);
         OEA_TRY_RC(oea_part_apply(ent, acc_own, n_ent, rel, rel_acc, n_rel, ld, world, rank, own, rel_x, upd, &step_cfg, workspace, n_items,
                                   loss_accum, stream));
         if (transh) OEA_TRY_RC(oea_step_apply_normals(n_ent, n_rel, ld, &step_cfg, workspace, stream));
@@ -2307,8 +2319,7 @@ int oea_triple_epoch_range_halo(oea_comm_t comm, float *ent, float *acc_own, int
         OEA_PART_DISPATCH(OEA_CALL)
 #undef OEA_CALL
         // ---- optimiser on the owned rows (the single-GPU job's group width at this table size) ---------------------------------
-        const bool grouped = step_cfg.neg_group_k > 0 || step_cfg.loss_kind == OEA_LOSS_MARGIN;
-        const int64_t n_items = grouped ? n : n + n * (int64_t)k;
+        const int64_t n_items = step_items(step_cfg, n, n * (int64_t)k);
         {
             const int grad_gpb = 256 / (ld <= 128 ? 32 : 64);
             const int n_part = n_items > 0 ? (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_items, grad_gpb), 1), kMaxBlocks) : 0;

@@ -239,8 +239,8 @@ class TripleTrainer:
                 p['nrm'] = ops.step_normal_views(self.ws, self.ent.rows, self.rel.rows, self.ent.ld)
             mdist.allreduce_sum_(p['nrm'][0], self.dist)
             mdist.allreduce_sum_(p['nrm'][1], self.dist)
-        grouped = self.cfg.neg_group_k > 0 or self.cfg.loss_kind == 0
-        n_items = pos.shape[0] if grouped else pos.shape[0] + (0 if neg is None else neg.shape[0])
+        import ctypes as _C
+        n_items = int(ops.lib().oea_step_items(_C.byref(self.cfg), int(pos.shape[0]), 0 if neg is None else int(neg.shape[0])))
         ops.part_apply(self.ent.var, p['acc_own'], self.rel.var, self.rel_acc, p['world'], p['rank'], p['own'], p['rel_x'],
                        p['upd'], self.cfg, self.ws, n_items, self.loss)
         if transh:

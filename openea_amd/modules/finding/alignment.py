@@ -58,9 +58,9 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
     rk, ws = mdist.world()
     if ws > 1:
         return _greedy_alignment_sharded(t1, t2, dim, top_k, kmetric, csls_k, rk, ws)
-    r = c = None
+    r = c = grid = None
     if csls_k > 0:
-        r, c = csls_means_device(t1, t2, dim, kmetric, csls_k)
+        r, c, grid = csls_means_device(t1, t2, dim, kmetric, csls_k, return_grid=True)
     if kmetric == 'inner' and 1 <= len(top_k) <= 8 and ops.tile_glds():
         if ops.eval_bf16_enabled(t1.shape[0], t2.shape[0]):
             # certified bf16 prefilter (with or without the CSLS means): the same ranks / nearest candidates at 3/16 of the fp32
@@ -69,8 +69,6 @@ def greedy_alignment_device(t1, t2, dim, top_k, metric, normalize, csls_k):
             if res is not None:
                 return res
         return ops.rank_eval_metrics(t1, t2, dim, top_k, r, c)             # prologue + sweep: two launches, one copy back
-    grid = getattr(csls_means_device, "last_grid", None) if (csls_k > 0 and kmetric == 'manhattan') else None
-    csls_means_device.last_grid = None
     if grid is not None:       # manhattan + CSLS: the rank pass reads the strips the means pass left behind
         rank, argmax = ops.rank_eval_l1_grid(t1, t2, dim, csls_r=r, csls_c=c, grid=grid)
     else:
@@ -93,7 +91,6 @@ def _greedy_alignment_sharded(t1, t2, dim, top_k, kmetric, csls_k, rk, ws):
         r_loc, _ = csls_means_device(t1[lo1:hi1], t2, dim, kmetric, csls_k, cols=False)
         c_loc, _ = csls_means_device(t2[lo2:hi2], t1, dim, kmetric, csls_k, cols=False)
         r, c = mdist.allgather_rows(r_loc, n1), mdist.allgather_rows(c_loc, n2)
-        csls_means_device.last_grid = None
 
     def rank_fn(block, cand, d, off):
         return ops.rank_eval(block, cand, d, kmetric, None if r is None else r[off: off + block.shape[0]].contiguous(),

@@ -70,23 +70,26 @@ def csls_sim(sim_mat, k):
     return s.cpu().numpy()
 
 
-def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
+def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True, return_grid=False):
     """Per-row and per-column top-k means WITHOUT holding the whole matrix: strips of rows of S
     and of S^T are produced and reduced one after the other (each strip <= max_bytes).
-    cols=False: only the row means (second result None)."""
+    cols=False: only the row means (second result None).  return_grid=True: -> (r, c, grid) where grid is the L1Grid of a
+    manhattan evaluation (its kept strips are what the rank pass reads next) or None -- handed over explicitly: it used to
+    travel in a function attribute, which pinned up to a third of the free memory after a direct call and could hand a stale
+    quantisation to a later evaluation."""
     import os
     import torch
     if kmetric == 'inner':                 # one sweep, no strips of S / S^T (n1, n2 >= 4096)
         rc = ops.csls_means(t1, t2, dim, k)
         if rc is not None:                 # (cols=False -- a rank's block of rows in the sharded evaluation -- drops the column means:
-            return rc if cols else (rc[0], None)   #  the sweep that finds both is still several times faster than the strips below)
+            rc = rc if cols else (rc[0], None)     #  the sweep that finds both is still several times faster than the strips below)
+            return (rc[0], rc[1], None) if return_grid else rc
     if (kmetric == 'manhattan' and min(t1.shape[0], t2.shape[0]) >= 2048 and k + 32 < min(t1.shape[0], t2.shape[0])
             and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64'):
         # 16-bit grid distances + exact similarities of the k + margin nearest (certified): the same means without the fp64
         # distance of every pair, twice (ops.l1_grid_topk_means); the grid and the query strips go on to the rank pass
         r, c, grid = ops.csls_means_l1_grid(t1, t2, dim, k, cols=cols)
-        csls_means_device.last_grid = grid
-        return r, c
+        return (r, c, grid) if return_grid else (r, c)
 
     def strip_means(a, b):
         n, m = a.shape[0], b.shape[0]
@@ -97,7 +100,8 @@ def csls_means_device(t1, t2, dim, kmetric, k, max_bytes=4 << 30, cols=True):
             out[r0:r0 + rows_per] = ops.row_topk_mean(s, k)
             del s
         return out
-    return strip_means(t1, t2), (strip_means(t2, t1) if cols else None)
+    r, c = strip_means(t1, t2), (strip_means(t2, t1) if cols else None)
+    return (r, c, None) if return_grid else (r, c)
 
 
 # ---- the reference's thread- / block-parallel spellings of the same products (similarity.py:86-127) ------------------

@@ -509,16 +509,14 @@ def eval_bf16_enabled(n1, n2):
     return os.environ.get('OEA_EVAL_BF16', '1')[:1] != '0' and tile_glds() and n1 * n2 >= lim
 
 
-def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0):
-    """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo)."""
+def rank_eval(e1, e2, dim, metric='inner', csls_r=None, csls_c=None, gold_offset=0, allow_bf16=True):
+    """gold of query row i is candidate row gold_offset + i (row-sharded evaluation passes its lo).  allow_bf16=False: the fp32
+    sweep whatever the size (rank_eval_bf16's fallback on a record overflow -- an explicit argument instead of a process-global
+    re-entrancy flag)."""
     n1, n2 = e1.shape[0], e2.shape[0]
     assert n1 + gold_offset <= n2, "gold of row i is column gold_offset + i <= n2"
-    if metric == 'inner' and n1 > 0 and eval_bf16_enabled(n1, n2) and not getattr(rank_eval, "_in_bf16", False):
-        rank_eval._in_bf16 = True                   # (rank_eval_bf16 falls back to this function on a record overflow)
-        try:
-            return rank_eval_bf16(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
-        finally:
-            rank_eval._in_bf16 = False
+    if metric == 'inner' and n1 > 0 and allow_bf16 and eval_bf16_enabled(n1, n2):
+        return rank_eval_bf16(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
     if metric == 'manhattan' and n1 > 0 and n2 >= 2048 and os.environ.get('OEA_L1_EVAL', 'grid') != 'f64':
         return rank_eval_l1_grid(e1, e2, dim, gold_offset, csls_r=csls_r, csls_c=csls_c)
     ws = torch.empty(lib().oea_rank_workspace_bytes(n1), dtype=torch.uint8, device=e1.device)
@@ -644,7 +642,7 @@ def rank_eval_bf16(e1, e2, dim, gold_offset=0, stats=None, csls_r=None, csls_c=N
     if stats is not None:
         stats['records'], stats['fallback'] = int(st[1]), bool(st[0])
     if st[0]:
-        return rank_eval(e1, e2, dim, 'inner', csls_r, csls_c, gold_offset=gold_offset)
+        return rank_eval(e1, e2, dim, 'inner', csls_r, csls_c, gold_offset=gold_offset, allow_bf16=False)
     return rank, argmax
 
 
