@@ -126,6 +126,10 @@ class TripleTrainer:
         self.halo_stats = [0, 0, 0, 0]    # bytes pushed, bytes pulled, largest rows sent in a step, steps (this rank)
         if self.exchange == "halo" and (self.part is None or getattr(self, "comm", None) is None):
             self.exchange = "step"        # no communicator for the one-call epoch: the dense per-step protocol (same result)
+        if self.exchange == "halo" and self.comm.callbacks and self.comm.device_collectives:
+            # the library's own RCCL communicator could not be made on an nccl group: the callback back end runs the dense
+            # protocol's collectives on the registered device buffers, but has no device all-to-all -- dense protocol
+            self.exchange = "step"
 
     # ---- dp_exchange = 'epoch': local steps, one exchange per epoch ----------------------------------------------
     @property

@@ -198,6 +198,9 @@ class _FakeLib:
         handle._obj.value = 2000 + rank
         return 0
 
+    def oea_comm_set_alltoallv(self, h, fn):
+        return 0
+
     def oea_comm_destroy(self, h):
         self.calls.append("destroy")
         return 0
