@@ -495,7 +495,40 @@ __device__ __forceinline__ void stage_packed_big(const float *__restrict__ a_til
     }
 }
 
-template <class MTile, class Epilogue>
+// the eight fragments of one k-step of a wave's 64 x 64 sub-tile
+struct BfFrag { bf16x8 a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l; };
+
+__device__ __forceinline__ void load_bf_frag(const float *__restrict__ ap, const float *__restrict__ bp, int s, int half, int x, BfFrag &f) {
+    const int g = 4 * s + 2 * half;
+    const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
+    f.a0h = *reinterpret_cast<const bf16x8 *>(ap + oh); f.b0h = *reinterpret_cast<const bf16x8 *>(bp + oh);
+    f.b1h = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + oh); f.a1h = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + oh);
+    f.b0l = *reinterpret_cast<const bf16x8 *>(bp + ol); f.b1l = *reinterpret_cast<const bf16x8 *>(bp + 32 * PLD + ol);
+    f.a0l = *reinterpret_cast<const bf16x8 *>(ap + ol); f.a1l = *reinterpret_cast<const bf16x8 *>(ap + 32 * PLD + ol);
+}
+
+__device__ __forceinline__ void mma_bf_frag(const BfFrag &f, f32x16 (&acc)[2][2]) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0h, f.b0h, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0h, f.b1h, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1h, f.b0h, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1h, f.b1h, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0h, f.b0l, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0h, f.b1l, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1h, f.b0l, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1h, f.b1l, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0l, f.b0h, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0l, f.b1h, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1l, f.b0h, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1l, f.b1h, acc[1][1], 0, 0, 0);
+}
+
+// PF (OEA_BF16_BIG_PF, default on): the fragment reads never wait in front of idle matrix cores.  A chunk is two k-steps; the loop
+// body is  [reads of k-step 1 of chunk c] [MFMAs of k-step 0] [chunk c + 1 landed? counted vmcnt, raw barrier] [DMA of chunk c + 3 into
+// the slot chunk c just left] [reads of k-step 0 of chunk c + 1] [MFMAs of k-step 1 of chunk c]: every read is issued one MFMA group
+// (12 x 32 cycles) before its use, the barrier sits between the two groups, and the DMA runs three chunks ahead.  The second k-step of
+// a tile's last chunk may be zero padding of the packed rows (Kp is a multiple of 32): it adds +0.  !PF = the first form of this
+// pipeline (reads in front of each group, barrier at the top), kept for the ablation.
+template <bool PF, class MTile, class Epilogue>
 __device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
                                                        int64_t n0, int64_t n_tiles, MTile m_tile, float *lds, Epilogue epilogue) {
     const int S = (dim + 15) / 16;
@@ -511,24 +544,75 @@ __device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__
         si = si == BIG_STAGES - 1 ? 0 : si + 1;
         if (++ki == nchunk) { ki = 0; ++ti; a_base = am + m_tile(ti) * kp; }
     };
-    issue();
-    if (total > 1) issue();
     f32x16 acc[2][2], tot[2][2];
     zero_acc(acc);
     zero_acc(tot);
     int t = 0, kc = 0, sc = 0;                        // (tile, chunk, stage) being multiplied
+    if constexpr (!PF) {
+        issue();
+        if (total > 1) issue();
+        for (int it = 0; it < total; ++it) {
+            // stage `it` has landed when at most the newer stage's 6 DMA instructions of this wave are outstanding (loads complete in
+            // order; whatever the epilogue issued since only makes the count stricter); the barrier then covers the other waves' parts
+            // and tells everybody that the slot read in iteration it - 1 is free
+            if (it + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + 2 < total) issue();
+            const float *slot = lds + sc * BIG_STAGE;
+            sc = sc == BIG_STAGES - 1 ? 0 : sc + 1;
+            mma_chunk_bf16<true>(slot, slot + BIG_A, min(2, S - 2 * kc), acc);
+            ++kc;
+            if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {
+                add_acc(tot, acc);
+                zero_acc(acc);
+            }
+            if (kc == nchunk) {
+                epilogue((int64_t)t, tot);
+                zero_acc(tot);
+                kc = 0;
+                ++t;
+            }
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = (lane >> 1) & 7, half = lane >> 5;
+    const int a_off = (wm * 64 + (lane & 31)) * PLD, b_off = BIG_A + (wn * 64 + (lane & 31)) * PLD;
+    // prologue: three chunks on their way, chunk 0 landed, its first fragments requested
+    issue();
+    if (total > 1) issue();
+    if (total > 2) issue();
+    if (total > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    BfFrag f0, f1;
+    load_bf_frag(lds + a_off, lds + b_off, 0, half, x, f0);
     for (int it = 0; it < total; ++it) {
-        // stage `it` has landed when at most the newer stage's 6 DMA instructions of this wave are outstanding (loads complete in
-        // order; whatever the epilogue issued since only makes the count stricter); the barrier then covers the other waves' parts
-        // and tells everybody that the slot read in iteration it - 1 is free
-        if (it + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (it + 2 < total) issue();
         const float *slot = lds + sc * BIG_STAGE;
+        load_bf_frag(slot + a_off, slot + b_off, 1, half, x, f1);            // k-step 1 of this chunk, behind the MFMAs of k-step 0
+        __builtin_amdgcn_sched_barrier(0);
+        mma_bf_frag(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
         sc = sc == BIG_STAGES - 1 ? 0 : sc + 1;
-        mma_chunk_bf16<true>(slot, slot + BIG_A, min(2, S - 2 * kc), acc);
+        if (it + 1 < total) {
+            // chunk it + 1 must have landed: of this wave's DMA only chunk it + 2's (6 instructions) may still be out; f1 has arrived
+            // too (lgkmcnt(0)): after the barrier nobody reads chunk it's slot any more
+            if (it + 2 < total) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + 3 < total) issue();                                     // into the slot of chunk it
+            const float *nxt = lds + sc * BIG_STAGE;
+            load_bf_frag(nxt + a_off, nxt + b_off, 0, half, x, f0);          // k-step 0 of the next chunk, behind the MFMAs of k-step 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_bf_frag(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
         ++kc;
         if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {
             add_acc(tot, acc);
@@ -2232,7 +2316,7 @@ static unsigned tile_grid_blocks(const TileGrid &g) { return g.per ? 8u * g.per 
 // can belong to the exact top k and recomputes them with the exact chain.
 // NW = 8 (BF16, K > 128): 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big, dynamic LDS);
 // the query lists then have 8 * chunks segments (one per chunk, wave row and half-wave)
-template <bool PACKED, bool BF16, int NCH = 0, int NW = 4>
+template <bool PACKED, bool BF16, int NCH = 0, int NW = 4, bool PF = true>
 __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
@@ -2324,7 +2408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
         };
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
+    if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big<PF>(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
     else if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
     else if constexpr (BF16) tile_pipeline_bf16<true>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
@@ -2742,7 +2826,7 @@ __device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const f
 
 // NCH = 0: both operands through LDS (tile_pipeline_bf16, any Kp); NCH = Kp / 32 in {1..4}: B in registers (tile_pipeline_bf16_breg);
 // NW = 8: 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big; tiles_per_chunk counts THOSE tiles)
-template <bool WARM, bool CSLS, int NCH, int NW = 4>
+template <bool WARM, bool CSLS, int NCH, int NW = 4, bool PF = true>
 __device__ __forceinline__ void rank_bf16_body(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
     const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,
@@ -2810,7 +2894,7 @@ __device__ __forceinline__ void rank_bf16_body(
         };
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (NW == 8) tile_pipeline_bf16_big(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
+    if constexpr (NW == 8) tile_pipeline_bf16_big<PF>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
     else if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
     else tile_pipeline_bf16<true>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
@@ -2850,10 +2934,10 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_breg_kernel(OEA_RANK_BF16_PA
     rank_bf16_body<WARM, CSLS, NCH>(OEA_RANK_BF16_ARGS, As, nullptr);
 }
 
-template <bool CSLS>
+template <bool CSLS, bool PF>
 __global__ __launch_bounds__(512, 2) void rank_bf16_big_kernel(OEA_RANK_BF16_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];                // BIG_LDS_BYTES
-    rank_bf16_body<false, CSLS, 0, 8>(OEA_RANK_BF16_ARGS, big_lds, nullptr);
+    rank_bf16_body<false, CSLS, 0, 8, PF>(OEA_RANK_BF16_ARGS, big_lds, nullptr);
 }
 
 // ONE grid-stride prologue: both bf16 packs, the gold similarities (the exact k-ordered chain), the max row norms of both
@@ -3412,24 +3496,27 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         else if (nch == 1) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 1>), GRID, TPC);                \
         else OEA_BF16_LAUNCH((rank_bf16_kernel<W, C>), GRID, TPC);                                      \
     } while (0)
-#define OEA_BF16_BIG_SWEEP(C)                                                                                                        \
+    static const bool big_pf = [] { const char *e = getenv("OEA_BF16_BIG_PF"); return !(e && e[0] == '0'); }();
+#define OEA_BF16_BIG_SWEEP(C, P)                                                                                                     \
     do {                                                                                                                            \
         static bool attr_set = false;                                                                                               \
         if (!attr_set) {                                                                                                            \
-            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C, P>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               BIG_LDS_BYTES));                                                                      \
             attr_set = true;                                                                                                        \
         }                                                                                                                           \
-        rank_bf16_big_kernel<C><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
-                                                                                  gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, gs);       \
+        rank_bf16_big_kernel<C, P><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
+                                                                                     gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, gs);    \
     } while (0)
     if (sweep_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
-        if (big) OEA_BF16_BIG_SWEEP(true);
+        if (big) OEA_BF16_BIG_SWEEP(true, false);      // (CSLS terms in the epilogue -- only when the two extra coordinates would cost a
+                                                       //  chunk: the prefetched form spills there, 188 B per lane)
         else OEA_BF16_SWEEP(false, true, gs, tpc);
     } else {
         if (warm >= 2) OEA_BF16_SWEEP(true, false, gw, warm);
-        if (big) OEA_BF16_BIG_SWEEP(false);
+        if (big && big_pf) OEA_BF16_BIG_SWEEP(false, true);
+        else if (big) OEA_BF16_BIG_SWEEP(false, false);
         else OEA_BF16_SWEEP(false, false, gs, tpc);
     }
 #undef OEA_BF16_BIG_SWEEP
@@ -3776,15 +3863,22 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
 #define OEA_CSLS_APPEND(N) csls_append_kernel<true, true, N><<<tile_grid_blocks(grid), 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, \
                                                                                                    p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid)
+        static const bool big_pf = [] { const char *e = getenv("OEA_BF16_BIG_PF"); return !(e && e[0] == '0'); }();
         if (big) {
             static bool attr_set = false;
             if (!attr_set) {
-                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8>),
+                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
+                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
                 attr_set = true;
             }
-            csls_append_kernel<true, true, 0, 8><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc,
-                                                                                                  p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
+            if (big_pf)
+                csls_append_kernel<true, true, 0, 8, true><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(
+                    b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
+            else
+                csls_append_kernel<true, true, 0, 8, false><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(
+                    b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
         } else switch ((breg_on && kp <= 128) ? kp / 32 : 0) {
             case 4: OEA_CSLS_APPEND(4); break;
             case 3: OEA_CSLS_APPEND(3); break;
