@@ -522,7 +522,7 @@ __device__ __forceinline__ void mma_bf_frag(const BfFrag &f, f32x16 (&acc)[2][2]
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1l, f.b1h, acc[1][1], 0, 0, 0);
 }
 
-// PF (OEA_BF16_BIG_PF, default on): the fragment reads never wait in front of idle matrix cores.  A chunk is two k-steps; the loop
+// PF (OEA_BF16_BIG_MODE=1, the default; 0 = !PF): the fragment reads never wait in front of idle matrix cores.  A chunk is two k-steps; the loop
 // body is  [reads of k-step 1 of chunk c] [MFMAs of k-step 0] [chunk c + 1 landed? counted vmcnt, raw barrier] [DMA of chunk c + 3 into
 // the slot chunk c just left] [reads of k-step 0 of chunk c + 1] [MFMAs of k-step 1 of chunk c]: every read is issued one MFMA group
 // (12 x 32 cycles) before its use, the barrier sits between the two groups, and the DMA runs three chunks ahead.  The second k-step of
@@ -609,6 +609,114 @@ __device__ __forceinline__ void tile_pipeline_bf16_big(const float *__restrict__
             if (it + 3 < total) issue();                                     // into the slot of chunk it
             const float *nxt = lds + sc * BIG_STAGE;
             load_bf_frag(nxt + a_off, nxt + b_off, 0, half, x, f0);          // k-step 0 of the next chunk, behind the MFMAs of k-step 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_bf_frag(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ++kc;
+        if ((kc & (kBf16BlockChunks - 1)) == 0 || kc == nchunk) {
+            add_acc(tot, acc);
+            zero_acc(acc);
+        }
+        if (kc == nchunk) {
+            epilogue((int64_t)t, tot);
+            zero_acc(tot);
+            kc = 0;
+            ++t;
+        }
+    }
+}
+
+// ---- producer / consumer waves (round 5, OEA_BF16_BIG_MODE=2; not the default: measured equal to mode 1) -------------------------
+// Hypothesis: what the 256 x 128 pipeline above spends its time on is the ISSUE of its LDS-DMA: a `global_load_lds_dwordx4` costs the
+// issuing wave ~60-180 cycles when it sits between MFMAs and fragment reads (MI355X_MICROARCH.md), 6 per wave and chunk = a third
+// of an iteration on every SIMD; a wave that does nothing else issues one in ~25 cycles.  So of the 8 waves of the workgroup (two per
+// SIMD, 256 VGPRs each: more waves would halve the register budget of the multiplying ones) waves 6 and 7 become LOADERS -- each
+// issues half of a stage's 40 instructions, waits for the stage the consumers need next (counted vmcnt) and meets them at the
+// barrier -- and waves 0-5 are CONSUMERS as 3 (M) x 2 (N) on 192 candidate rows x 128 query rows: fragment reads one MFMA group
+// ahead, MFMAs, K-block sums, epilogue, and nothing else.  LDS: 3 stages x (192 + 128) x 128 B = 120 KB.
+// Measured at 70,000^2 x 1,200: 35.3 ms against 34.7 ms for mode 1 -- six multiplying waves each run 1.3x faster than eight did, which
+// cancels; identical results.  (hipcc still answers the loop-carried fragment reads with lgkmcnt(0) in front of the first MFMA
+// group and counted waits on the NEXT chunk's reads in the second: the prefetch of both modes is only half effective.)
+constexpr int SPEC_MT = 192, SPEC_NC = 6;
+constexpr int SPEC_A = SPEC_MT * PLD;
+constexpr int SPEC_STAGE = SPEC_A + TILE * PLD;            // 40 KB
+constexpr int SPEC_BLOCKS = (SPEC_MT + TILE) / 8;          // 8-row pieces of a stage: 24 of A, 16 of B
+
+template <class MTile, class Epilogue>
+__device__ __forceinline__ void tile_pipeline_bf16_spec(const float *__restrict__ am, int kp, const float *__restrict__ bn, int dim,
+                                                        int64_t n0, int64_t n_tiles, MTile m_tile, float *lds, Epilogue epilogue) {
+    const int S = (dim + 15) / 16;
+    const int nchunk = (S + 1) / 2;
+    const int total = (int)n_tiles * nchunk;
+    if (total <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= SPEC_NC) {
+        // ---- loader ------------------------------------------------------------------------------------------------------------
+        const int lw = wave - SPEC_NC, sub = lane >> 3;
+        const unsigned c_even = 4u * ((lane & 7) ^ ((sub >> 1) & 7)), c_odd = 4u * ((lane & 7) ^ ((4 + (sub >> 1)) & 7));
+        const float *b_base = bn + n0 * kp;
+        int ti = 0, ki = 0, si = 0;
+        const float *a_base = am + m_tile(0) * kp;
+        auto issue = [&]() {
+            float *slot = lds + si * SPEC_STAGE;
+            const float *a_tile = a_base + ki * BK, *b_tile = b_base + ki * BK;
+#pragma unroll
+            for (int u = 0; u < SPEC_BLOCKS / 2; ++u) {
+                const int b = lw * (SPEC_BLOCKS / 2) + u;                    // loader 0: A pieces 0-19; loader 1: A 20-23, B 0-15
+                const bool is_a = b < SPEC_MT / 8;
+                const int piece = is_a ? b : b - SPEC_MT / 8;
+                const float *src = (is_a ? a_tile : b_tile) + (size_t)((unsigned)(piece * 8 + sub) * (unsigned)kp + (piece & 1 ? c_odd : c_even));
+                float *base = slot + (is_a ? 0 : SPEC_A) + piece * 8 * PLD;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(base)),
+                                                 16, 0, 0);
+            }
+            si = si == BIG_STAGES - 1 ? 0 : si + 1;
+            if (++ki == nchunk) { ki = 0; ++ti; a_base = am + m_tile(ti) * kp; }
+        };
+        issue();
+        if (total > 1) issue();
+        if (total > 2) issue();
+        if (total > 2) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else if (total > 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int it = 0; it + 1 < total; ++it) {
+            // chunk it + 1 landed (of this wave's DMA only chunk it + 2's 20 instructions may still be out)
+            if (it + 2 < total) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + 3 < total) issue();                                     // into the slot the consumers have just left
+        }
+        return;
+    }
+    // ---- consumer ----------------------------------------------------------------------------------------------------------------
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = (lane >> 1) & 7, half = lane >> 5;
+    const int a_off = (wm * 64 + (lane & 31)) * PLD, b_off = SPEC_A + (wn * 64 + (lane & 31)) * PLD;
+    f32x16 acc[2][2], tot[2][2];
+    zero_acc(acc);
+    zero_acc(tot);
+    int t = 0, kc = 0, sc = 0;
+    __builtin_amdgcn_s_barrier();                                            // chunk 0 landed
+    asm volatile("" ::: "memory");
+    BfFrag f0, f1;
+    load_bf_frag(lds + a_off, lds + b_off, 0, half, x, f0);
+    for (int it = 0; it < total; ++it) {
+        const float *slot = lds + sc * SPEC_STAGE;
+        load_bf_frag(slot + a_off, slot + b_off, 1, half, x, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_bf_frag(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        sc = sc == BIG_STAGES - 1 ? 0 : sc + 1;
+        if (it + 1 < total) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // f1 is here: nobody reads chunk it's slot after the barrier
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const float *nxt = lds + sc * SPEC_STAGE;
+            load_bf_frag(nxt + a_off, nxt + b_off, 0, half, x, f0);
         }
         __builtin_amdgcn_sched_barrier(0);
         mma_bf_frag(f1, acc);
@@ -2316,14 +2424,15 @@ static unsigned tile_grid_blocks(const TileGrid &g) { return g.per ? 8u * g.per 
 // can belong to the exact top k and recomputes them with the exact chain.
 // NW = 8 (BF16, K > 128): 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big, dynamic LDS);
 // the query lists then have 8 * chunks segments (one per chunk, wave row and half-wave)
-template <bool PACKED, bool BF16, int NCH = 0, int NW = 4, bool PF = true>
+template <bool PACKED, bool BF16, int NCH = 0, int NW = 4, int MODE = 1>
 __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr_q, const float *__restrict__ thr_c, int tiles_per_chunk, int cap, int ccap,
     float *__restrict__ qlists, int32_t *__restrict__ qcounts, float *__restrict__ clists, int32_t *__restrict__ ccounts,
     const float *__restrict__ tol_ptr, TileGrid tg) {
     constexpr uint32_t ES = BF16 ? 8u : 4u;                 // bytes per list entry
-    constexpr int MT = NW * 32;                             // candidate rows of a tile
+    constexpr int NC = (NW == 8 && MODE == 2) ? SPEC_NC : NW;       // multiplying waves (MODE 2: waves 6 and 7 only load)
+    constexpr int MT = NC * 32;                             // candidate rows of a tile
     extern __shared__ __attribute__((aligned(16))) float csls_dyn_lds[];          // NW == 8: BIG_LDS_BYTES
     __shared__ __attribute__((aligned(16))) float lds_static[NW == 8 ? 4 : (NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD)];
     float *lds = NW == 8 ? csls_dyn_lds : lds_static;
@@ -2341,8 +2450,8 @@ __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
     const int64_t nct = (nc + MT - 1) / MT;
     const int64_t ct_begin = (int64_t)by * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
-    const int nseg = NW * (int)tg.ny;
-    const int sidx = ((int)by * (NW / 2) + wm) * 2 + half;
+    const int nseg = NC * (int)tg.ny;
+    const int sidx = ((int)by * (NC / 2) + wm) * 2 + half;        // (a loader wave has no segment)
     float th[2];
     uint32_t boff[2], bbeg[2], blast[2];
     int64_t qi[2];
@@ -2408,7 +2517,10 @@ __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
         };
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big<PF>(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
+    if constexpr (BF16 && NW == 8 && MODE == 2) {
+        tile_pipeline_bf16_spec(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
+        if (wave >= NC) return;                                // a loader
+    } else if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big<MODE == 1>(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
     else if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
     else if constexpr (BF16) tile_pipeline_bf16<true>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
@@ -2707,8 +2819,8 @@ static int reserve_operand(int slot, int64_t n, int dim, hipStream_t st, PackedO
     const int64_t n_pad = (n + TILE - 1) / TILE * TILE;
     *n_pad_out = n_pad;
     out->kp = (dim + BK - 1) / BK * BK;
-    // (+ one tile of rows: the 256-candidate tiles of tile_pipeline_bf16_big read up to 128 rows past n_pad; products discarded)
-    const size_t need = sizeof(float) * (size_t)(n_pad + TILE) * out->kp;
+    // (+ two tiles of rows: the 256- / 192-candidate tiles of the big pipelines read up to 191 rows past n_pad; products discarded)
+    const size_t need = sizeof(float) * (size_t)(n_pad + 2 * TILE) * out->kp;
     if (!sl.used) OEA_CHECK_HIP(hipEventCreateWithFlags(&sl.used, hipEventDisableTiming));
     if (need > sl.cap) {
         if (sl.p) OEA_CHECK_HIP(hipFree(sl.p));
@@ -2826,7 +2938,9 @@ __device__ __forceinline__ void rank_bf16_tile(Acc &acc, int jb, int n2, const f
 
 // NCH = 0: both operands through LDS (tile_pipeline_bf16, any Kp); NCH = Kp / 32 in {1..4}: B in registers (tile_pipeline_bf16_breg);
 // NW = 8: 512 threads on 256-candidate tiles through the three-stage ring (tile_pipeline_bf16_big; tiles_per_chunk counts THOSE tiles)
-template <bool WARM, bool CSLS, int NCH, int NW = 4, bool PF = true>
+// MODE (NW = 8): 0 / 1 = tile_pipeline_bf16_big<PF = MODE> on 256-candidate tiles, all 8 waves multiply; 2 = tile_pipeline_bf16_spec on
+// 192-candidate tiles: waves 0-5 multiply, waves 6-7 load
+template <bool WARM, bool CSLS, int NCH, int NW = 4, int MODE = 1>
 __device__ __forceinline__ void rank_bf16_body(
     const float *__restrict__ qp, int64_t n1, int kp, const float *__restrict__ cp, int64_t n2, int dim,
     const float *__restrict__ gold, const float *__restrict__ tol_ptr, const float *__restrict__ csls_r,
@@ -2838,7 +2952,8 @@ __device__ __forceinline__ void rank_bf16_body(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t q0 = (int64_t)bx * TILE;
-    constexpr int MT = NW * 32;                              // candidate rows of a tile
+    constexpr int NC = (NW == 8 && MODE == 2) ? SPEC_NC : NW;   // multiplying waves
+    constexpr int MT = NC * 32;                              // candidate rows of a tile
     const int64_t nct = (n2 + MT - 1) / MT;
     const int64_t ct_begin = (int64_t)by * tiles_per_chunk;
     const int64_t ct_end = (ct_begin + tiles_per_chunk < nct) ? ct_begin + tiles_per_chunk : nct;
@@ -2894,7 +3009,13 @@ __device__ __forceinline__ void rank_bf16_body(
         };
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * MT; };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
-    if constexpr (NW == 8) tile_pipeline_bf16_big<PF>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
+    if constexpr (NW == 8 && MODE == 2) {
+        tile_pipeline_bf16_spec(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
+        if (wave >= NC) {                                  // a loader: no ranks, an empty record slice
+            if (!WARM && lane == 0) rec_cnt[2 + wid] = 0u;
+            return;
+        }
+    } else if constexpr (NW == 8) tile_pipeline_bf16_big<MODE == 1>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
     else if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
     else tile_pipeline_bf16<true>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
@@ -2934,10 +3055,10 @@ __global__ __launch_bounds__(256, 2) void rank_bf16_breg_kernel(OEA_RANK_BF16_PA
     rank_bf16_body<WARM, CSLS, NCH>(OEA_RANK_BF16_ARGS, As, nullptr);
 }
 
-template <bool CSLS, bool PF>
+template <bool CSLS, int MODE>
 __global__ __launch_bounds__(512, 2) void rank_bf16_big_kernel(OEA_RANK_BF16_PARAMS) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];                // BIG_LDS_BYTES
-    rank_bf16_body<false, CSLS, 0, 8, PF>(OEA_RANK_BF16_ARGS, big_lds, nullptr);
+    rank_bf16_body<false, CSLS, 0, 8, MODE>(OEA_RANK_BF16_ARGS, big_lds, nullptr);
 }
 
 // ONE grid-stride prologue: both bf16 packs, the gold similarities (the exact k-ordered chain), the max row norms of both
@@ -3190,7 +3311,7 @@ struct CslsPlan {
 constexpr int kCslsFb = 128, kCslsSlow = 64;
 
 // big: the sweep runs on 256-candidate tiles with 8 waves (csls_append_kernel<.., 8>): chunks count those tiles, 8 segments per chunk
-static CslsPlan plan_csls(int64_t n1, int64_t n2, int k, bool big = false) {
+static CslsPlan plan_csls(int64_t n1, int64_t n2, int k, int big = 0 /* candidate rows of a big tile: 0, 256 or 192 */) {
     CslsPlan p;
     if (n1 < 4096 || n2 < 4096 || k > 32) return p;
     p.sample = std::max(n1, n2) >= 32768 ? 4096 : 1024;       // keeps r n / S, the survivors per row, in the low hundreds
@@ -3201,8 +3322,8 @@ static CslsPlan plan_csls(int64_t n1, int64_t n2, int k, bool big = false) {
     p.r2 = rank_of(n1);
     const double m1 = (double)p.r1 * n2 / p.sample, m2 = (double)p.r2 * n1 / p.sample;      // survivors per row / per column
     if (m1 * (1.0 + 5.0 / std::sqrt((double)p.r1)) > kMeanRegs * 64 || m2 * (1.0 + 5.0 / std::sqrt((double)p.r2)) > kMeanRegs * 64) return p;
-    p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, big ? BIG_MT : TILE), &p.tpc);
-    p.nseg = (big ? 8 : 4) * p.chunks;
+    p.chunks = pick_chunks(oea::ceil_div(n1, TILE), oea::ceil_div(n2, big ? big : TILE), &p.tpc);
+    p.nseg = (big ? big / 32 : 4) * p.chunks;
     if (p.nseg > kMeanSeg) return p;
     // the threshold is the r-th of a sample: the survivor count of a row scales with a factor of relative spread 1 / sqrt(r)
     // COMMON to its segments, on top of each segment's own sqrt(m) noise
@@ -3473,7 +3594,13 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     static const bool big_on = [] { const char *e = getenv("OEA_BF16_BIG"); return !(e && e[0] == '0'); }();
     const bool big = big_on && p1.kp > 128;
     const int nw = big ? 8 : 4;
-    const int chunks = pick_chunks(qt, big ? oea::ceil_div(n2, BIG_MT) : ctiles, &tpc);
+    // OEA_BF16_BIG_MODE: 1 (default) = all 8 waves multiply, fragment reads one MFMA group ahead; 2 = 6 multiplying + 2 loading waves on
+    // 192-candidate tiles (measured equal: 35.3 against 34.7 ms at 70,000^2 x 1,200); 0 = the first form; the
+    // CSLS-terms-in-the-epilogue variant (rare) keeps mode 0
+    static const int big_mode_env = [] { const char *e = getenv("OEA_BF16_BIG_MODE"); return e ? atoi(e) : 1; }();
+    const int big_mode = sweep_r ? 0 : big_mode_env;
+    const int big_mt = big_mode == 2 ? SPEC_MT : BIG_MT;
+    const int chunks = pick_chunks(qt, big ? oea::ceil_div(n2, big_mt) : ctiles, &tpc);
     const int64_t n_waves = (int64_t)nw * qt * chunks;
     OEA_REQUIRE(n_waves <= bf16_max_waves(n1), "more workgroups than the workspace was sized for (OEA_RANK_WGS)");
     const unsigned slice_cap = (unsigned)(cap / n_waves);
@@ -3496,27 +3623,26 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
         else if (nch == 1) OEA_BF16_LAUNCH((rank_bf16_breg_kernel<W, C, 1>), GRID, TPC);                \
         else OEA_BF16_LAUNCH((rank_bf16_kernel<W, C>), GRID, TPC);                                      \
     } while (0)
-    static const bool big_pf = [] { const char *e = getenv("OEA_BF16_BIG_PF"); return !(e && e[0] == '0'); }();
-#define OEA_BF16_BIG_SWEEP(C, P)                                                                                                     \
+#define OEA_BF16_BIG_SWEEP(C, M)                                                                                                     \
     do {                                                                                                                            \
         static bool attr_set = false;                                                                                               \
         if (!attr_set) {                                                                                                            \
-            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C, P>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C, M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               BIG_LDS_BYTES));                                                                      \
             attr_set = true;                                                                                                        \
         }                                                                                                                           \
-        rank_bf16_big_kernel<C, P><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
+        rank_bf16_big_kernel<C, M><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
                                                                                      gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, gs);    \
     } while (0)
     if (sweep_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
-        if (big) OEA_BF16_BIG_SWEEP(true, false);      // (CSLS terms in the epilogue -- only when the two extra coordinates would cost a
-                                                       //  chunk: the prefetched form spills there, 188 B per lane)
-        else OEA_BF16_SWEEP(false, true, gs, tpc);
+        if (big) OEA_BF16_BIG_SWEEP(true, 0);          // (CSLS terms in the epilogue -- only when the two extra coordinates would cost a
+        else OEA_BF16_SWEEP(false, true, gs, tpc);     //  chunk: the prefetched forms spill there)
     } else {
         if (warm >= 2) OEA_BF16_SWEEP(true, false, gw, warm);
-        if (big && big_pf) OEA_BF16_BIG_SWEEP(false, true);
-        else if (big) OEA_BF16_BIG_SWEEP(false, false);
+        if (big && big_mode == 2) OEA_BF16_BIG_SWEEP(false, 2);
+        else if (big && big_mode == 1) OEA_BF16_BIG_SWEEP(false, 1);
+        else if (big) OEA_BF16_BIG_SWEEP(false, 0);
         else OEA_BF16_SWEEP(false, false, gs, tpc);
     }
 #undef OEA_BF16_BIG_SWEEP
@@ -3784,8 +3910,8 @@ int oea_row_topk_mean(const float *s, int64_t n1, int64_t n2, int64_t ld, int32_
 }
 
 size_t oea_csls_means_workspace_bytes(int64_t n1, int64_t n2, int32_t k) {
-    const CslsPlan p = plan_csls(n1, n2, k), pb = plan_csls(n1, n2, k, true);       // (the call picks one of the two by the row width)
-    return p.ok ? std::max(p.total, pb.ok ? pb.total : 0) : 0;
+    const CslsPlan p = plan_csls(n1, n2, k), pb = plan_csls(n1, n2, k, BIG_MT), ps = plan_csls(n1, n2, k, SPEC_MT);   // (the call picks one by the row width)
+    return p.ok ? std::max(p.total, std::max(pb.ok ? pb.total : 0, ps.ok ? ps.total : 0)) : 0;
 }
 
 int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, int64_t n2, int32_t ld2, int32_t dim, int32_t k,
@@ -3801,8 +3927,10 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
     const double bf16_min = env_min ? atof(env_min) : 3e8;
     const bool bf16 = bf16_on && (double)n1 * (double)n2 >= bf16_min;
     static const bool big_on = [] { const char *e = getenv("OEA_BF16_BIG"); return !(e && e[0] == '0'); }();
-    const bool big = bf16 && big_on && (dim + BK - 1) / BK * BK > 128 && plan_csls(n1, n2, k, true).ok;
-    const CslsPlan p = plan_csls(n1, n2, k, big);
+    static const int big_mode = [] { const char *e = getenv("OEA_BF16_BIG_MODE"); return e ? atoi(e) : 1; }();
+    const int big_mt = big_mode == 2 ? SPEC_MT : BIG_MT;
+    const bool big = bf16 && big_on && (dim + BK - 1) / BK * BK > 128 && plan_csls(n1, n2, k, big_mt).ok;
+    const CslsPlan p = plan_csls(n1, n2, k, big ? big_mt : 0);
     if (!p.ok || !use_glds()) { oea::set_error("oea_csls_means: shape not covered (n1, n2 >= 4096, k <= 32, packed tiles)"); return OEA_EUNSUPPORTED; }
     OEA_REQUIRE(ws_bytes >= p.total, "workspace smaller than oea_csls_means_workspace_bytes");
     hipStream_t st = oea::as_stream(stream);
@@ -3863,22 +3991,22 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         static const bool breg_on = [] { const char *e = getenv("OEA_BF16_BREG"); return !(e && e[0] == '0'); }();
 #define OEA_CSLS_APPEND(N) csls_append_kernel<true, true, N><<<tile_grid_blocks(grid), 256, 0, st>>>(b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, \
                                                                                                    p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid)
-        static const bool big_pf = [] { const char *e = getenv("OEA_BF16_BIG_PF"); return !(e && e[0] == '0'); }();
         if (big) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
-                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
-                attr_set = true;
-            }
-            if (big_pf)
-                csls_append_kernel<true, true, 0, 8, true><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(
-                    b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
-            else
-                csls_append_kernel<true, true, 0, 8, false><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(
-                    b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);
+#define OEA_CSLS_BIG(M)                                                                                                              \
+            do {                                                                                                                    \
+                static bool attr_set = false;                                                                                       \
+                if (!attr_set) {                                                                                                    \
+                    OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, M>),       \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));                  \
+                    attr_set = true;                                                                                                \
+                }                                                                                                                   \
+                csls_append_kernel<true, true, 0, 8, M><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(                        \
+                    b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);      \
+            } while (0)
+            if (big_mode == 2) OEA_CSLS_BIG(2);
+            else if (big_mode == 1) OEA_CSLS_BIG(1);
+            else OEA_CSLS_BIG(0);
+#undef OEA_CSLS_BIG
         } else switch ((breg_on && kp <= 128) ? kp / 32 : 0) {
             case 4: OEA_CSLS_APPEND(4); break;
             case 3: OEA_CSLS_APPEND(3); break;
