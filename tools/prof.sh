@@ -16,7 +16,7 @@ case $mode in
   trace)
     [ "$1" = "--" ] && shift
     D=$(mktemp -d /tmp/oea_trace_XXXX)
-    $ROCPROF --kernel-trace --stats --output-format csv -d $D -- "$@" > $O/trace_stdout.log 2>&1
+    timeout 900 $ROCPROF --kernel-trace --stats --output-format csv -d $D -- "$@" > $O/trace_stdout.log 2>&1
     f=$(find $D -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp $f $O/trace_stats.csv
     rm -rf $D
@@ -26,7 +26,7 @@ case $mode in
     [ "$1" = "--" ] && shift
     D=$(mktemp -d /tmp/oea_pmc_XXXX)
     n=$(ls $O/pmc_*.csv 2>/dev/null | wc -l); n=$((n + 1))
-    $ROCPROF --kernel-trace --pmc $ctrs --output-format csv -d $D -- "$@" > $O/pmc_${n}_stdout.log 2>&1
+    timeout 600 $ROCPROF --kernel-trace --pmc $ctrs --output-format csv -d $D -- "$@" > $O/pmc_${n}_stdout.log 2>&1
     python - "$D" "$O/pmc_$n.csv" <<'PY'
 import collections, csv, glob, os, sys
 acc, cnt, names = collections.defaultdict(float), collections.Counter(), set()
