@@ -3602,9 +3602,16 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     const int big_mt = big_mode == 2 ? SPEC_MT : BIG_MT;
     const int chunks = pick_chunks(qt, big ? oea::ceil_div(n2, big_mt) : ctiles, &tpc);
     const int64_t n_waves = (int64_t)nw * qt * chunks;
-    OEA_REQUIRE(n_waves <= bf16_max_waves(n1), "more workgroups than the workspace was sized for (OEA_RANK_WGS)");
-    const unsigned slice_cap = (unsigned)(cap / n_waves);
-    OEA_REQUIRE(slice_cap >= 32, "record slices too small");
+    const unsigned slice_cap = (unsigned)(cap / std::max<int64_t>(n_waves, 1));
+    if (n_waves > bf16_max_waves(n1) || slice_cap < 32) {
+        // more workgroups than the workspace was sized for (OEA_RANK_WGS raised) or record slices too small: reported like a record
+        // overflow -- the caller takes the fp32 entry point (this used to be a hard error)
+        rc = release_packed(st);
+        if (rc != OEA_OK) return rc;
+        if (status) OEA_CHECK_HIP(hipMemsetAsync(status, 1, 2 * sizeof(int32_t), st));
+        if (metrics_out) OEA_CHECK_HIP(hipMemsetAsync(metrics_out, 1, sizeof(long long) * (size_t)(nk + 4), st));
+        return OEA_OK;
+    }
     // warm-up over 1/16 of the candidate tiles (at most 16 = 2,048 candidates, 3 % of a 70,000-row sweep); a small candidate
     // set needs none: every workgroup sees most of it anyway
     const int warm = (int)std::min<int64_t>(kBf16WarmTiles, ctiles / 16);

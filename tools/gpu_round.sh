@@ -10,5 +10,6 @@ export TMPDIR=/tmp
 ( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > $O/pytest_gpu.log 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) > $O/smoke.log 2>&1
 ( S=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 2> $O/bench.err | tail -1; echo "bench wall $(( $(date +%s) - S )) s" ) > $O/bench_driver_like.log 2>&1
+cp bench_detail.json $O/bench_detail.json 2>/dev/null      # (the trace run below writes its own bench_detail.json)
 tools/prof.sh trace ${TAG}_trace -- timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu --no-traffic --no-gnn --no-extra
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log; tail -1 $O/bench_driver_like.log
