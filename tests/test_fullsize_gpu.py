@@ -52,6 +52,49 @@ def test_rank_eval_70k(ops):
     assert np.array_equal(np.concatenate([ra.cpu().numpy(), rb.cpu().numpy()]), rank_h)
 
 
+def test_rank_eval_70k_alinet_width(ops, monkeypatch):
+    """AliNet's evaluation shape (alinet.py:948-966: [init, out0, out1] = 500 + 400 + 300 columns, each block L2-normalised;
+    alinet_args_100K.json: eval_metric inner, csls 10; 70,000 test pairs).  The product path (certified bf16 prefilter, K-blocked
+    accumulation, 256 x 128 tiles on the three-stage ring) against the ORACLE on sampled query rows (each needs all 70,000
+    candidates at 1,200 columns), against the exact fp32 sweep on every row, with and without CSLS means; the prefilter must not
+    have fallen back and its record count stays small on a table whose Hits@1 is about one half."""
+    from oracle import cport
+    from openea_amd.modules.finding.similarity import csls_means_device
+    rng = np.random.RandomState(12)
+    n, dims = 70000, (500, 400, 300)
+    d = sum(dims)
+    b1s, b2s = [], []
+    for db in dims:
+        b1 = rng.standard_normal((n, db)).astype(np.float32)
+        b2 = (b1 + 8.0 * rng.standard_normal((n, db)).astype(np.float32)).astype(np.float32)
+        b1s.append(b1 / np.linalg.norm(b1, axis=1, keepdims=True))
+        b2s.append(b2 / np.linalg.norm(b2, axis=1, keepdims=True))
+    e1, e2 = np.concatenate(b1s, 1), np.concatenate(b2s, 1)
+    del b1s, b2s
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    assert ops.eval_bf16_enabled(n, n)
+    st = {}
+    rank, argmax = ops.rank_eval_bf16(t1, t2, d, stats=st)
+    assert not st["fallback"] and st["records"] < 64 * n, st
+    rank_h, am_h = rank.cpu().numpy(), argmax.cpu().numpy()
+    assert 0.3 < float((rank_h == 0).mean()) < 0.7                    # SURVEY 8d: Hits@1 between 0.3 and 0.7
+    rows = rng.choice(n, 32, replace=False)
+    s = cport.sim_matrix(e1[rows], e2, "inner")
+    g = s[np.arange(len(rows)), rows]
+    ref = ((s > g[:, None]) | ((s == g[:, None]) & (np.arange(n)[None, :] < rows[:, None]))).sum(1)
+    assert np.array_equal(rank_h[rows], ref) and np.array_equal(am_h[rows], s.argmax(1))
+    r32, a32 = ops.rank_eval(t1, t2, d, "inner", allow_bf16=False)   # the exact fp32 sweep, every row
+    assert torch.equal(rank, r32) and torch.equal(argmax, a32)
+    rr, cc = csls_means_device(t1, t2, d, "inner", 10)
+    monkeypatch.setenv("OEA_CSLS_BF16", "0")
+    rr32, cc32 = csls_means_device(t1, t2, d, "inner", 10)
+    monkeypatch.delenv("OEA_CSLS_BF16")
+    assert torch.equal(rr, rr32) and torch.equal(cc, cc32)           # the means of the bf16 sweep ARE the fp32 sweep's
+    rc, ac = ops.rank_eval_bf16(t1, t2, d, csls_r=rr, csls_c=cc)
+    rc32, ac32 = ops.rank_eval(t1, t2, d, "inner", rr, cc, allow_bf16=False)
+    assert torch.equal(rc, rc32) and torch.equal(ac, ac32)
+
+
 def test_rank_eval_manhattan_10k5(ops):
     from oracle import cport
     rng = np.random.RandomState(1)
