@@ -861,6 +861,12 @@ int oea_comm_alltoallv(oea_comm_t c, const void *send, const int64_t *send_count
  *   stats_host (may be NULL): int64 [4] = bytes pushed (gradient rows sent), bytes pulled (rows received), largest number of
  *   rows sent in a step, steps run. */
 size_t oea_halo_workspace_bytes(int64_t n_ent, int32_t world, int32_t steps, int64_t max_batch, int32_t k);
+/* the plan alone (what oea_triple_epoch_range_halo computes first): counts_host [step_end - step_begin][world][world] = distinct entity
+ * rows rank r's share of step s refers to that rank o owns; lists_host (may be NULL) [steps][world][*cap_out] = the lists (local row
+ * indices j, entity id = j * world + o; owner-major, ascending).  neg_all = the epoch's negatives [rows * k, 3] (NULL when k = 0). */
+int oea_halo_plan(const int32_t *pos_all, const int32_t *neg_all, int32_t k, const int64_t *offsets_host, const int64_t *offsets_dev,
+                  int32_t steps, int32_t step_begin, int32_t step_end, int64_t n_ent, int32_t world, void *halo_ws, size_t halo_ws_bytes,
+                  int32_t *counts_host, int32_t *lists_host, int64_t *cap_out, void *stream);
 size_t oea_halo_buffer_bytes(int64_t n_ent, int32_t world, int64_t max_batch, int32_t k, int32_t ld);
 int oea_triple_epoch_range_halo(oea_comm_t comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
                                 int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,

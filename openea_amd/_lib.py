@@ -239,6 +239,7 @@ PROTOTYPES = {
     "oea_comm_alltoallv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "oea_halo_workspace_bytes": (_sz, [_i64, _i32, _i32, _i64, _i32]),
     "oea_halo_buffer_bytes": (_sz, [_i64, _i32, _i64, _i32, _i32]),
+    "oea_halo_plan": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _sz, _vp, _vp, C.POINTER(_i64), _vp]),
     "oea_triple_epoch_range_halo": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                         C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
                                         C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),

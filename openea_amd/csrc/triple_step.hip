@@ -2190,6 +2190,40 @@ size_t oea_halo_buffer_bytes(int64_t n_ent, int32_t world, int64_t max_batch, in
     return align256((size_t)rows * (ld + 1) * sizeof(grad_t));
 }
 
+// the plan alone: counts_host [step_end - step_begin][world][world] = distinct rows rank r's share of step s refers to that rank o owns
+// (what sizes every message of oea_triple_epoch_range_halo), lists_host (may be NULL) [steps][world][cap] the row lists themselves
+// (local indices j, id = j * world + owner, owner-major, ascending); *cap_out = entries per (step, rank).  Parity: tests hold both to
+// a numpy restatement (oracle/np_oracle.py:halo_plan).
+int oea_halo_plan(const int32_t *pos_all, const int32_t *neg_all, int32_t k, const int64_t *offsets_host, const int64_t *offsets_dev,
+                  int32_t steps, int32_t step_begin, int32_t step_end, int64_t n_ent, int32_t world, void *halo_ws, size_t halo_ws_bytes,
+                  int32_t *counts_host, int32_t *lists_host, int64_t *cap_out, void *stream) {
+    OEA_REQUIRE(pos_all && offsets_host && offsets_dev && halo_ws && counts_host, "null pointer");
+    OEA_REQUIRE(steps >= 0 && k >= 0 && (k == 0 || neg_all) && 0 <= step_begin && step_begin <= step_end && step_end <= steps && world >= 1, "arguments");
+    hipStream_t st = oea::as_stream(stream);
+    const int32_t nS = step_end - step_begin;
+    int64_t max_batch = 0;
+    for (int32_t s = 0; s < steps; ++s) max_batch = std::max(max_batch, offsets_host[s + 1] - offsets_host[s]);
+    const HaloGeom g = halo_geom(n_ent, world, 0, max_batch, k);
+    if (cap_out) *cap_out = g.cap;
+    if (nS == 0) return OEA_OK;
+    HaloWs hw;
+    OEA_REQUIRE(halo_ws_bytes >= halo_ws_layout(g, nS, halo_ws, &hw), "halo workspace smaller than oea_halo_workspace_bytes");
+    OEA_CHECK_HIP(hipMemsetAsync(hw.bitmaps, 0, 4 * (size_t)nS * world * g.nwords, st));
+    OEA_CHECK_HIP(hipMemsetAsync(hw.err, 0, 4, st));
+    const int64_t rows = offsets_host[step_end] - offsets_host[step_begin];
+    if (rows > 0)
+        halo_mark_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div(rows * (k + 1), 256), 16384), 256, 0, st>>>(
+            pos_all, neg_all, k, offsets_dev, step_begin, step_end, g, hw.bitmaps);
+    halo_compact_kernel<<<(unsigned)(nS * world), 256, 0, st>>>(hw.bitmaps, g, hw.lists, hw.counts, hw.err);
+    int32_t err = 0;
+    OEA_CHECK_HIP(hipMemcpyAsync(counts_host, hw.counts, 4 * (size_t)nS * world * world, hipMemcpyDeviceToHost, st));
+    if (lists_host) OEA_CHECK_HIP(hipMemcpyAsync(lists_host, hw.lists, 4 * (size_t)nS * world * g.cap, hipMemcpyDeviceToHost, st));
+    OEA_CHECK_HIP(hipMemcpyAsync(&err, hw.err, 4, hipMemcpyDeviceToHost, st));
+    OEA_CHECK_HIP(hipStreamSynchronize(st));
+    OEA_REQUIRE(err == 0, "halo lists overflowed their capacity");
+    return OEA_OK;
+}
+
 int oea_triple_epoch_range_halo(oea_comm_t comm, float *ent, float *acc_own, int64_t n_ent, float *rel, float *rel_acc,
                                 int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
                                 const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,

@@ -402,6 +402,28 @@ def halo_buffers(n_ent, ld, world, steps, max_batch, k, dev):
     return dict(ws=torch.empty(wsb, **u8), a=torch.empty(xb, **u8), b=torch.empty(xb, **u8), key=(int(steps), int(max_batch), int(k)))
 
 
+def halo_plan(pos_all, neg_all, k, offsets, n_ent, world, step_range=None, with_lists=True):
+    """which rows every rank's share of every step refers to, per owner (oea_halo_plan) -> (counts int32 [steps, world, world],
+    lists int32 [steps, world, cap] or None): what sizes the messages of the boundary-row exchange"""
+    steps = len(offsets) - 1
+    lo, hi = (0, steps) if step_range is None else step_range
+    max_batch = int(np.diff(offsets).max()) if steps else 0
+    dev = pos_all.device
+    ws = torch.empty(lib().oea_halo_workspace_bytes(int(n_ent), int(world), hi - lo, max_batch, int(k)), dtype=torch.uint8, device=dev)
+    off_dev = torch.from_numpy(np.ascontiguousarray(offsets, np.int64)).to(dev)
+    counts = np.zeros((hi - lo, world, world), np.int32)
+    cap = C.c_int64(0)
+    check(lib().oea_halo_plan(_p(pos_all), _p(neg_all), int(k), offsets.ctypes.data_as(C.c_void_p), _p(off_dev), steps, int(lo), int(hi),
+                              int(n_ent), int(world), _p(ws), ws.numel(), counts.ctypes.data_as(C.c_void_p), None, C.byref(cap), _stream()))
+    lists = None
+    if with_lists:
+        lists = np.zeros((hi - lo, world, int(cap.value)), np.int32)
+        check(lib().oea_halo_plan(_p(pos_all), _p(neg_all), int(k), offsets.ctypes.data_as(C.c_void_p), _p(off_dev), steps, int(lo), int(hi),
+                                  int(n_ent), int(world), _p(ws), ws.numel(), counts.ctypes.data_as(C.c_void_p),
+                                  lists.ctypes.data_as(C.c_void_p), C.byref(cap), _stream()))
+    return counts, lists
+
+
 def triple_epoch_halo(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base, neg_buf,
                       err_flag, cfg, workspace, loss_accum, offsets_dev, splits_dev, bufs, halo, step_range=None):
     """triple_epoch_comm with the boundary-row exchange (oea_triple_epoch_range_halo); bufs = part_buffers(...), halo =

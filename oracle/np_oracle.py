@@ -675,3 +675,29 @@ def rotate_lookup(ent, ids, part_norm=True, sum_norm=False):
     if sum_norm:
         out = _l2n_rows(out)
     return out.astype(np.float32)
+
+
+def halo_plan(pos_all, neg_all, k, offsets, n_ent, world):
+    """Boundary-row plan of the partitioned step (no reference counterpart: the reference is single-device; restated from the
+    protocol in DESIGN.md section 6 / include/openea_hip.h:oea_halo_plan, test infrastructure only).  Rank r's share of step s =
+    rows [nb r / world, nb (r + 1) / world) of the batch; the rows it refers to = heads and tails of its positives and of their k
+    negatives; owner of entity id = id mod world, local index = id div world.
+    -> (counts int64 [steps, world, world], lists: dict (s, r, o) -> ascending local indices)"""
+    pos_all = np.asarray(pos_all)
+    neg_all = None if neg_all is None else np.asarray(neg_all)
+    steps = len(offsets) - 1
+    counts = np.zeros((steps, world, world), np.int64)
+    lists = {}
+    for s in range(steps):
+        b0, nb = int(offsets[s]), int(offsets[s + 1] - offsets[s])
+        for r in range(world):
+            lo, hi = b0 + nb * r // world, b0 + nb * (r + 1) // world
+            ids = [pos_all[lo:hi, 0], pos_all[lo:hi, 2]]
+            if k > 0 and hi > lo:
+                ids += [neg_all[lo * k:hi * k, 0], neg_all[lo * k:hi * k, 2]]
+            ids = np.unique(np.concatenate(ids)) if hi > lo else np.zeros(0, np.int64)
+            for o in range(world):
+                mine = np.sort(ids[ids % world == o] // world)
+                lists[(s, r, o)] = mine
+                counts[s, r, o] = len(mine)
+    return counts, lists

@@ -416,3 +416,47 @@ def test_boundary_row_exchange_with_2_and_4_ranks_equals_the_single_process_job(
         with capsys.disabled():
             print("halo exchange at world %d: %.0f bytes per step and rank (dense protocol: %.0f)" % (world, float(ranks[0]["xbytes"]), dense))
         assert float(ranks[0]["xbytes"]) < dense
+
+
+@pytest.mark.parametrize("world,k", [(2, 4), (4, 10), (8, 10), (3, 0)])
+def test_halo_plan_equals_the_oracle_restatement(world, k):
+    """oea_halo_plan (halo_mark_kernel + halo_compact_kernel: what sizes every message of the boundary-row exchange and names the
+    rows) against oracle/np_oracle.py:halo_plan on ragged batches (the last one short, one EMPTY), Zipf-headed positives, entries of
+    the negatives that are not corruptions of their positive, a world size that does not divide the table, k = 0: the counts
+    [steps, world, world] and every row list (ascending local indices per owner) are equal."""
+    torch = pytest.importorskip("torch")
+    from openea_amd import ops
+    from oracle import np_oracle as orc
+    ops.lib()
+    rng = np.random.RandomState(100 * world + k)
+    n_ent, n_rel = 7001, 37
+    offsets = np.array([0, 1500, 1500, 3200, 5000, 5303], np.int64)            # step 1 is empty, step 4 short
+    n = int(offsets[-1])
+    w = 1.0 / np.arange(1, n_ent + 1) ** 0.9
+    pos = np.stack([rng.choice(n_ent, n, p=w / w.sum()), rng.randint(0, n_rel, n), rng.randint(0, n_ent, n)], 1).astype(np.int32)
+    neg = None
+    if k:
+        neg = np.repeat(pos, k, 0)
+        flip = rng.rand(len(neg)) < 0.5
+        neg[flip, 0] = rng.randint(0, n_ent, int(flip.sum()))
+        neg[~flip, 2] = rng.randint(0, n_ent, int((~flip).sum()))
+        neg[7] = (n_ent - 1, 3, n_ent - 2)                                       # not a corruption of its positive; the table's last rows
+    pos_d = ops.to_ids(pos)
+    neg_d = ops.to_ids(neg) if k else None
+    counts, lists = ops.halo_plan(pos_d, neg_d, k, offsets, n_ent, world)
+    ref_counts, ref_lists = orc.halo_plan(pos, neg, k, offsets, n_ent, world)
+    assert np.array_equal(counts.astype(np.int64), ref_counts)
+    for s in range(len(offsets) - 1):
+        for r in range(world):
+            at = 0
+            for o in range(world):
+                c = int(counts[s, r, o])
+                assert np.array_equal(lists[s, r, at:at + c].astype(np.int64), ref_lists[(s, r, o)]), (s, r, o)
+                at += c
+    # a sub-range of the steps plans the same lists
+    c2, l2 = ops.halo_plan(pos_d, neg_d, k, offsets, n_ent, world, step_range=(2, 5))
+    assert np.array_equal(c2, counts[2:5])
+    for s in range(3):
+        for r in range(world):
+            m = int(c2[s, r].sum())
+            assert np.array_equal(l2[s, r, :m], lists[2 + s, r, :m])
