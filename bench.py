@@ -1147,11 +1147,22 @@ def gnn_legs(torch, ops, dev, traffic=None):
     from openea_amd.modules.finding.alignment import greedy_alignment_device
     n_e, d_e = 70000, 300
     t1, t2 = _eval_tables(torch, ops, dev, n_e, d_e, rng)
+    tk_e = [1, 5, 10, 50]
     os.environ["OEA_L1_EVAL"] = "f64"                                   # every pair in fp64 (round 2's path, kept beside the default)
-    ms_l1_f64 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 0), 1)
+    f64 = greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 0)
+    ms_l1_f64 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 0), 1)
+    f64_c = greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 10)
     os.environ["OEA_L1_EVAL"] = "grid"
-    ms_l1 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 0), 2)
-    ms_l1_csls = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "manhattan", False, 10), 1)
+    g16 = greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 0)
+    ms_l1 = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 0), 2)
+    g16_c = greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 10)
+    ms_l1_csls = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, tk_e, "manhattan", False, 10), 1)
+    # the timed grid path gives the all-pairs fp64 path's ranks and nearest candidates, plain and with CSLS (asserted like the AliNet leg)
+    l1_same = bool(torch.equal(g16[0], f64[0]) and torch.equal(g16[1], f64[1]) and torch.equal(g16_c[0], f64_c[0])
+                   and torch.equal(g16_c[1], f64_c[1]))
+    assert l1_same, "manhattan evaluation: grid path != all-pairs fp64 path at 70,000 x 300"
+    l1_hits1 = int(g16[2][0])
+    del f64, f64_c, g16, g16_c
     ms_in = _wall(torch, lambda: greedy_alignment_device(t1, t2, d_e, [1, 5, 10, 50], "inner", False, 0), 2)
     sad_ops = float(n_e) * n_e * ((d_e + 7) // 8 * 8) / 2.0                # one v_sad_u16 per pair and two columns
     out["rdgcn_eval_70000x300"] = {
@@ -1159,7 +1170,7 @@ def gnn_legs(torch, ops, dev, traffic=None):
                     "with csls = 10 -- basic_model.py:132-135; inner beside it)",
         "manhattan_ms": round(ms_l1, 2), "manhattan_pairs_per_s": round(n_e / ms_l1 * 1e3, 1),
         "manhattan_csls10_ms": round(ms_l1_csls, 2), "manhattan_csls10_pairs_per_s": round(n_e / ms_l1_csls * 1e3, 1),
-        "manhattan_all_pairs_fp64_ms": round(ms_l1_f64, 2),
+        "manhattan_all_pairs_fp64_ms": round(ms_l1_f64, 2), "identical_to_all_pairs_fp64": l1_same, "hits1": l1_hits1,
         "inner_ms": round(ms_in, 2), "inner_pairs_per_s": round(n_e / ms_in * 1e3, 1),
         "roofline": {"kernel": "l1_u16_strip_kernel (16-bit grid distances of every pair; exact fp64 similarities only where the "
                                "grid's error bound leaves the comparison with the gold one open: same ranks as the all-pairs kernel)",

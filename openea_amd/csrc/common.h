@@ -108,6 +108,19 @@ __device__ __forceinline__ float group_sum(float v) {
     }
     return v;
 }
+// Sum over the wave's 64 lanes as a SCALAR (wave-uniform) value: the four butterfly steps inside the rows of 16, then the gfx9 row
+// broadcasts -- row_bcast15 (every row adds lane 15 of the row on its left), row_bcast31 (rows 2 and 3 add lane 31) -- leave the
+// total in lane 63, read with v_readlane: 6 DPP adds instead of 4 + 2 x (copy, permlane swap, add), and the result can steer scalar
+// branches.  Fixed order -> deterministic (not the order of group_sum<64>).
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    v += dpp_f32<0x142>(v);        // row_bcast15, all rows: row i += row i-1 (old values); only row 3 = r2 + r3 and row 1 = r0 + r1 matter
+    v += dpp_f32<0x143>(v);        // row_bcast31: rows 2, 3 += lane 31 = r0 + r1
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 template <int G>
 __device__ __forceinline__ double group_sum_d(double v) {
 #pragma unroll

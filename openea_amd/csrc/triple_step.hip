@@ -651,6 +651,253 @@ __global__ __launch_bounds__(256, 3) void triple_grouped_dma(
     block_loss_partial(loss_local, ws.partials);
 }
 
+// ---- kernel 1a'', round 6: one WAVE per positive ----------------------------------------------------------------------------------------
+// triple_grouped puts two positives on a wave (one per 32-lane half).  Everything that depends on the ids -- row addresses, "is this
+// negative a tail or a head corruption", "is its hinge active" -- is then per-LANE state: 64-bit address arithmetic on the VALU for every
+// row, ids handed round by ds_bpermute, every conditional atomic under its own exec mask (of its 2,900 instructions 1,100 are scalar
+// bookkeeping, 220 of them s_nop), 168 registers = three waves per SIMD.  Here a wave owns ONE positive:
+//   * ids arrive by SCALAR loads (the wave index is uniform: s_load_dwordx16 + x8 + x4 + x2 for the 30 ids of 10 negatives);
+//   * rows move through BUFFER instructions: one resource per table, the row's byte offset in the instruction's scalar offset (one
+//     s_mul_i32 per row), lane * 4 in the vector offset, fragment * 256 in the immediate -- no address arithmetic on the VALU at all.
+//     The lanes whose column of the LAST fragment lies past the row's end carry an out-of-range vector offset for that fragment:
+//     the addressing hardware returns 0 for their loads and drops their atomics -- no exec masks, no clamps, no selects;
+//   * all control flow is wave-uniform (s_cbranch_scc / vcc): an inactive hinge skips its atomics without touching exec;
+//   * the sampler corrupts ONE side per round (batch.py:101-107), so the k negatives of a positive are almost always all tail
+//     corruptions or all head corruptions: one uniform test picks a select-free loop (tail: d = (h + r) - c with h + r computed
+//     once; head: d = (c + r) - t), and gh == gr (tail) / gt == -gr (head) bit for bit, so ONE accumulator serves both rows.
+//     Positives with mixed sides, or with entries that are not corruptions of them at all, are scored as 1 + k independent triples
+//     (score_independent: the same loss and gradient, three rows per triple);
+//   * lane-strided fragments of 64 columns: ceil(ld / 64) registers per row (2 at d = 100, packed-fp32 instructions) -> ~64 registers.
+// The scalar unit is shared by the CU's four SIMDs (one instruction per cycle): the scalar work per positive (~250 instructions)
+// matters as much as the vector work (~400).
+// Arithmetic per element as in triple_grouped (normalise, a + r - b, hinge coefficients, accumulation in slot order); the row
+// reductions run over 64 lanes instead of 32, so sums differ from it in the last bit (both are held to the oracle at 1e-4).
+// LIMITED loss, both tables normalised, k <= 10, ld <= 256; everything else stays on triple_grouped.
+#ifdef OEA_DET_SCRATCH
+constexpr int kGradShift = 3;
+#else
+constexpr int kGradShift = 2;
+#endif
+constexpr unsigned kBufFlags = 0x00020000u;                       // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+// Resources span 2 GB from the table's base; row byte offsets (scalar offset) stay below 1 GB (launch rule), so an offset of 3 GB in the
+// vector register is out of range whether or not the hardware counts the scalar offset in its range check, and the sum never wraps.
+constexpr int kBufRecords = (int)0x80000000u;
+constexpr int kBufOob = (int)0xC0000000u;
+
+__device__ __forceinline__ void buf_grad_add(__amdgpu_buffer_rsrc_t rs, float v, int voff, int soff, int imm) {
+#ifdef OEA_DET_SCRATCH
+    const long long q = oea::to_fixed(v);
+    const int vo = voff + imm;
+    asm volatile("buffer_atomic_add_x2 %0, %1, %2, %3 offen" ::"v"(q), "v"(vo), "s"(rs), "s"(soff) : "memory");
+#else
+    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, voff + imm, soff, 0);
+#endif
+}
+__device__ __forceinline__ void buf_flag_set(__amdgpu_buffer_rsrc_t rs, int row) {       // every lane stores the same word: one request
+#ifdef OEA_DET_SCRATCH
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 one = {1u, 0u};
+    __builtin_amdgcn_raw_buffer_store_b64(one, rs, 0, row * 8, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b32(0x3f800000u, rs, 0, row * 4, 0);
+#endif
+}
+// `vt` = this lane's vector offset for the LAST fragment: its column's byte offset where the column exists, kBufOob where it does not
+// (>= num_records under either reading of the range check: the access reads 0 / the atomic is dropped)
+template <int IT>
+__device__ __forceinline__ void wave_load_row(__amdgpu_buffer_rsrc_t rs, int soff, int v4, int vt, Row<64, IT> &r) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+        r.v[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, it < IT - 1 ? v4 + it * 256 : vt, soff, 0));
+}
+template <int IT>
+__device__ __forceinline__ void wave_atomic_row(__amdgpu_buffer_rsrc_t rs, int soff, int vg, int vgt, const Row<64, IT> &g, float sign) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (it < IT - 1) buf_grad_add(rs, sign * g.v[it], vg, soff, it * (64 << kGradShift));
+        else buf_grad_add(rs, sign * g.v[it], vgt, soff, 0);
+    }
+}
+__device__ __forceinline__ float uniform_f(float x) {       // a value every lane holds -> scalar register (uniform branches on it)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+// y = l2_normalize(v) with the sum of squares as a scalar (tf.nn.l2_normalize: v * rsqrt(max(sum v^2, 1e-12)))
+template <int IT>
+__device__ __forceinline__ void wave_normalize(Row<64, IT> &r) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) s += r.v[it] * r.v[it];
+    const float inv = rsqrtf(fmaxf(oea::wave_sum_uniform(s), 1e-12f));
+#pragma unroll
+    for (int it = 0; it < IT; ++it) r.v[it] *= inv;
+}
+
+template <int IT, int L1, int KT>
+__global__ __launch_bounds__(512) void triple_wave(
+    const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
+    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
+    constexpr int G = 64, KC = 10;
+    if (KT > 0) k = KT;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = blockDim.x >> 6;                                          // 8 (ld <= 128) or 4 waves: launch_step's groups per block
+    const int64_t w0 = (int64_t)blockIdx.x * wpb + wv, nw = (int64_t)gridDim.x * wpb;
+    const int row_b = ld * 4, row_g = ld << kGradShift;                       // bytes per table row / scratch row
+    const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ent), 0, kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_rel = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rel), 0, kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_eg = __builtin_amdgcn_make_buffer_rsrc(ws.ent_grad, 0, kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_et = __builtin_amdgcn_make_buffer_rsrc(ws.ent_touched, 0, kBufRecords, kBufFlags);
+    const int v4 = lane * 4, vg = lane << kGradShift;
+    const int c_last = (IT - 1) * 64 + lane;                                  // this lane's column in the last fragment
+    const int vt = c_last < ld ? c_last * 4 : kBufOob, vgt = c_last < ld ? c_last << kGradShift : kBufOob;
+    const float c_neg = L1 ? -cfg.balance : -2.f * cfg.balance;               // dL/dd of an active negative = c_neg * (d or sgn d)
+    double loss_local = 0.0;
+    for (int64_t p = w0; p < n_pos; p += nw) {
+        const int32_t *pp = pos + 3 * p;
+        const int32_t *ng = neg + p * k * 3;
+        const int h = pp[0], r = pp[1], t = pp[2];
+        Row<G, IT> yh, yr, yt;
+        wave_load_row<IT>(rs_ent, h * row_b, v4, vt, yh);
+        wave_load_row<IT>(rs_rel, r * row_b, v4, vt, yr);
+        wave_load_row<IT>(rs_ent, t * row_b, v4, vt, yt);
+        int ids[3 * KC];
+        if (KT == KC || k == KC) {                                      // constant offsets -> wide scalar loads
+#pragma unroll
+            for (int q = 0; q < 3 * KC; ++q) ids[q] = ng[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3 * KC; ++q) ids[q] = q < 3 * k ? ng[q] : 0;
+        }
+        // every entry a corruption of this positive, and all on one side?
+        unsigned bad = 0, xh = 0, xt = 0;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (KT == KC || j < k) {
+                const unsigned a = (unsigned)(ids[3 * j] ^ h), b = (unsigned)(ids[3 * j + 2] ^ t), c = (unsigned)(ids[3 * j + 1] ^ r);
+                bad |= c | min(a, b);
+                xh |= a;
+                xt |= b;
+            }
+        if (bad | min(xh, xt)) {                                        // rare: 1 + k independent triples, one copy of the code
+            double ls = score_independent<G, IT>(ent, rel, ld, lane, p, h, r, t, true, cfg, ws, OEA_LOSS_LIMITED, L1);
+#pragma unroll 1
+            for (int j = 0; j < k; ++j)
+                ls += score_independent<G, IT>(ent, rel, ld, lane, p, ng[3 * j], ng[3 * j + 1], ng[3 * j + 2], false, cfg, ws, OEA_LOSS_LIMITED, L1);
+            loss_local += ls;
+            continue;
+        }
+        const bool tails = xh == 0;                                     // (k == 0: vacuously)
+        int ce[KC];
+        Row<G, IT> yc[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (KT == KC || j < k) {
+                ce[j] = tails ? ids[3 * j + 2] : ids[3 * j];
+                wave_load_row<IT>(rs_ent, ce[j] * row_b, v4, vt, yc[j]);
+            }
+        // ---- the positive ------------------------------------------------------------------------------------------------------
+        wave_normalize<IT>(yh);
+        wave_normalize<IT>(yr);
+        wave_normalize<IT>(yt);
+        Row<G, IT> u, gacc, gpos;
+        float sp = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            u.v[it] = yh.v[it] + yr.v[it];
+            const float d = u.v[it] - yt.v[it];
+            gpos.v[it] = d;
+            sp += L1 ? fabsf(d) : d * d;
+        }
+        const float xp = oea::wave_sum_uniform(sp) - cfg.pos_margin;  // losses.py:53: relu(s+ - pos_margin)
+        const bool cpos = xp > 0.f;
+        float lsum = cpos ? xp : 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            gpos.v[it] = cpos ? (L1 ? sgn(gpos.v[it]) : 2.f * gpos.v[it]) : 0.f;
+            gacc.v[it] = gpos.v[it];
+        }
+        // ---- the negatives: scores first (k independent chains), then hinges in slot order -------------------------------------
+        float sc[KC];
+        if (tails) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j)
+                if (KT == KC || j < k) {
+                    wave_normalize<IT>(yc[j]);
+                    float s = 0.f;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const float d = u.v[it] - yc[j].v[it];          // (h + r) - t'
+                        yc[j].v[it] = d;
+                        s += L1 ? fabsf(d) : d * d;
+                    }
+                    sc[j] = oea::wave_sum_uniform(s);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KC; ++j)
+                if (KT == KC || j < k) {
+                    wave_normalize<IT>(yc[j]);
+                    float s = 0.f;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const float d = yc[j].v[it] + yr.v[it] - yt.v[it];   // (h' + r) - t
+                        yc[j].v[it] = d;
+                        s += L1 ? fabsf(d) : d * d;
+                    }
+                    sc[j] = oea::wave_sum_uniform(s);
+                }
+        }
+        bool anyneg = false;
+        const float sign_c = tails ? -1.f : 1.f;                        // d/d(corrupted row): -g (tail) / +g (head)
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (KT == KC || j < k) {
+                const float xn = cfg.neg_margin - sc[j];     // losses.py:54: balance * relu(neg_margin - s-)
+                if (xn > 0.f) {
+                    lsum += cfg.balance * xn;
+                    anyneg = true;
+                    Row<G, IT> g;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        g.v[it] = L1 ? c_neg * sgn(yc[j].v[it]) : c_neg * yc[j].v[it];
+                        gacc.v[it] += g.v[it];
+                    }
+                    wave_atomic_row<IT>(rs_eg, ce[j] * row_g, vg, vgt, g, sign_c);
+                    buf_flag_set(rs_et, ce[j]);
+                }
+            }
+        // ---- the positive's rows: tail side gh = gr = gacc, gt = -gpos; head side gr = gacc, gt = -gacc, gh = gpos -----------------
+        if (cpos | anyneg) {
+            const int copy = (int)(p % kRelCopies);
+            grad_t *rgb = copy == 0 ? ws.rel_grad : ws.rel_extra + (copy - 1) * ws.rel_copy_stride;
+            const __amdgpu_buffer_rsrc_t rs_rg = __builtin_amdgcn_make_buffer_rsrc(rgb, 0, kBufRecords, kBufFlags);
+            const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(ws.rel_touched, 0, kBufRecords, kBufFlags);
+            wave_atomic_row<IT>(rs_rg, r * row_g, vg, vgt, gacc, 1.f);
+            buf_flag_set(rs_rt, r);
+            if (tails) {
+                wave_atomic_row<IT>(rs_eg, h * row_g, vg, vgt, gacc, 1.f);
+                buf_flag_set(rs_et, h);
+                if (cpos) { wave_atomic_row<IT>(rs_eg, t * row_g, vg, vgt, gpos, -1.f); buf_flag_set(rs_et, t); }
+            } else {
+                wave_atomic_row<IT>(rs_eg, t * row_g, vg, vgt, gacc, -1.f);
+                buf_flag_set(rs_et, t);
+                if (cpos) { wave_atomic_row<IT>(rs_eg, h * row_g, vg, vgt, gpos, 1.f); buf_flag_set(rs_et, h); }
+            }
+        }
+        loss_local += (double)lsum;
+    }
+    // one partial per workgroup, fixed order
+    __shared__ double sred[8];
+    if (lane == 0) sred[wv] = loss_local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < wpb; ++w) s += sred[w];
+        ws.partials[blockIdx.x] = s;
+    }
+}
+
 // ---- TransH (approaches/bootea_transh.py:58-96) ---------------------------------------------------------------
 // h' = h - (h.n) n, t' = t - (t.n) n with n = l2n(l2n(normal[r])); s = |h' + r - t'|.  With P = I - n n^T:
 //   d/dh = P g,  d/dt = -P g,  d/dr = g,  d/dn = ((t.n) - (h.n)) g + (g.n) (t - h)        (g = dL/d delta).
@@ -1638,11 +1885,38 @@ __global__ void halo_owned_rows_kernel(const float *__restrict__ ent, int64_t n_
 
 // triple_grouped specialised on (loss kind, norm) -- the per-triple losses that reach it (margin pairs go to
 // triple_generic); OEA_STEP_RUNTIME_KIND=1 keeps the one kernel with the run-time switch (experiments).
+// OEA_STEP_WAVE = 0: triple_grouped (two positives per wave) everywhere
+static bool step_wave_enabled() {
+    static const int env = [] { const char *e = getenv("OEA_STEP_WAVE"); return e ? atoi(e) : 1; }();
+    return env != 0;
+}
+
+template <int IT64>
+void launch_wave(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
+                 int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
+    const int k = cfg.neg_group_k;
+#define OEA_WAVE(L1, KT) oea::launch_timed(triple_wave<IT64, L1, KT>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws)
+    if (k == 10) { if (cfg.l1) OEA_WAVE(1, 10); else OEA_WAVE(0, 10); }
+    else { if (cfg.l1) OEA_WAVE(1, 0); else OEA_WAVE(0, 0); }
+#undef OEA_WAVE
+}
+
 template <int G, int IT>
 void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
-                    int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
+                    int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws, bool wave_fits) {
     static const int runtime_kind = [] { const char *e = getenv("OEA_STEP_RUNTIME_KIND"); return e ? atoi(e) : 0; }();
     const int k = cfg.neg_group_k;
+    // one wave per positive (round 6): the per-triple losses with a compile-time kind, rows of at most 256 columns, tables whose
+    // byte offsets fit the instruction's 32-bit scalar offset; same grid as triple_grouped with blocks of (256 / G) waves, so the
+    // number of loss partials is launch_step's nb1 either way
+    if constexpr ((G == 32 && IT <= 4) || (G == 64 && IT == 4)) {
+        if (wave_fits && !runtime_kind && cfg.loss_kind == OEA_LOSS_LIMITED && cfg.ent_l2_norm && cfg.rel_l2_norm && k >= 0 && k <= 10 &&
+            step_wave_enabled()) {
+            constexpr int IT64 = G == 32 ? (IT + 1) / 2 : 4;
+            launch_wave<IT64>(nb, (block / G) * 64, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
+            return;
+        }
+    }
     // software-pipelined form (triple_grouped_dma): np positives per group, the smallest np whose grid is resident at once (three
     // workgroups of 8 groups per CU: 6,144 groups); OEA_STEP_PIPE = 0 / 1 overrides the size rule, OEA_STEP_PIPE_NP fixes np
     static const int pipe_env = [] { const char *e = getenv("OEA_STEP_PIPE"); return e ? atoi(e) : -1; }();
@@ -1711,7 +1985,8 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
         else if (transh)
             oea::launch_timed(triple_transh_grouped<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
         else if (grouped)
-            launch_grouped<G, IT>(nb1, block, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
+            launch_grouped<G, IT>(nb1, block, st, ent, rel, ld, pos, n_pos, neg, cfg, ws,
+                                  std::max(n_ent, n_rel) * (int64_t)ld * (int64_t)sizeof(grad_t) < ((int64_t)1 << 30));
         else
             oea::launch_timed(triple_generic<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         if (phase == OEA_PHASE_GRAD || dense_opt)
@@ -1912,6 +2187,7 @@ int oea_step_apply_normals(int64_t n_ent, int64_t n_rel, int32_t ld, const oea_s
 }
 
 int64_t oea_step_items(const oea_step_cfg *cfg, int64_t n_pos, int64_t n_neg) { return cfg ? step_items(*cfg, n_pos, n_neg) : -1; }
+
 
 int oea_part_pack(void *workspace, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t world, void *send_, void *rel_x_,
                   void *stream) {

@@ -95,6 +95,98 @@ def test_rank_eval_70k_alinet_width(ops, monkeypatch):
     assert torch.equal(rc, rc32) and torch.equal(ac, ac32)
 
 
+def _l1_rank_ref(s, rows, csls_r=None, csls_c=None):
+    """ranks / nearest candidates of the sampled query rows from their full similarity strips (alignment.py:146-168: the number of
+    candidates ranked before the gold, ties by column; with CSLS (2 s - r) - c in fp32, similarity.py:57-77)"""
+    if csls_r is not None:
+        from oracle import cport
+        s = cport.csls_apply(s, csls_r[rows], csls_c)
+    g = s[np.arange(len(rows)), rows]
+    cols = np.arange(s.shape[1])[None, :]
+    return ((s > g[:, None]) | ((s == g[:, None]) & (cols < rows[:, None]))).sum(1), s.argmax(1)
+
+
+@pytest.mark.parametrize("table", ["half", "clustered"])
+def test_rank_eval_70k_manhattan_rdgcn_width(ops, table, monkeypatch):
+    """RDGCN-100K / GCN-Align test(): eval_metric manhattan (run/args/rdgcn_args_100K.json:26, similarity.py:46-48), 70,000 test
+    pairs at 300 columns, plain and with csls = 10 (basic_model.py:132-135).  The product path -- 16-bit grid distances of every
+    pair, exact fp64 chains only where the grid's error bound leaves a comparison open, CSLS means from the k + 32 nearest on the
+    grid, the rank pass over the kept strips (19.6 GB) -- against the C ORACLE on 32 sampled query rows (all 70,000 candidates
+    each, the sequential fp64 chain of scipy's cdist) and against the all-pairs fp64 device path on EVERY row; the CSLS means are
+    compared bit for bit.  'half': Hits@1 about one half; 'clustered': 20,000 candidates in 40 tight clusters and every gold
+    inside one -- hundreds of candidates within the grid's error of the gold distance (the band / exact-pair paths at size)."""
+    from oracle import cport
+    from openea_amd.modules.finding.similarity import csls_means_device
+    rng = np.random.RandomState(21)
+    n, d, k = 70000, 300, 10
+    e1 = _unit_rows(rng, n, d)
+    if table == "half":
+        e2 = (e1 + 2.0 * rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d)).astype(np.float32)
+    else:
+        e2 = (e1 + 0.05 * rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d)).astype(np.float32)
+        for c0 in range(10000, 30000, 500):                           # 40 clusters of 500 near-duplicates
+            e2[c0:c0 + 500] = e2[c0] + 2e-4 * rng.standard_normal((500, d)).astype(np.float32)
+        e1[10000:30000] = e2[10000:30000] + 1e-4 * rng.standard_normal((20000, d)).astype(np.float32)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    rows = np.sort(np.concatenate([rng.choice(np.arange(10000, 30000), 16, replace=False),
+                                   rng.choice(np.setdiff1d(np.arange(n), np.arange(10000, 30000)), 16, replace=False)]))
+    s_rows = cport.sim_matrix(e1[rows], e2, "manhattan")              # [32, 70,000]: the oracle's strips of the sampled rows
+    # ---- plain ---------------------------------------------------------------------------------------------------------------
+    monkeypatch.setenv("OEA_L1_EVAL", "grid")
+    rank, argmax = ops.rank_eval(t1, t2, d, "manhattan")
+    monkeypatch.setenv("OEA_L1_EVAL", "f64")
+    rank64, argmax64 = ops.rank_eval(t1, t2, d, "manhattan")          # every pair in fp64 on the device
+    assert torch.equal(rank, rank64) and torch.equal(argmax, argmax64)
+    rk_ref, am_ref = _l1_rank_ref(s_rows, rows)
+    assert np.array_equal(rank.cpu().numpy()[rows], rk_ref) and np.array_equal(argmax.cpu().numpy()[rows], am_ref)
+    h1 = float((rank == 0).float().mean().item())
+    if table == "half":
+        assert 0.3 < h1 < 0.7, h1                                      # SURVEY 8d: Hits@1 between 0.3 and 0.7
+    # ---- csls = 10: means, then ranks of (2 s - r) - c -------------------------------------------------------------------------
+    r64, c64 = csls_means_device(t1, t2, d, "manhattan", k)           # strips of every pair in fp64 + row_topk_mean
+    rk64, am64 = ops.rank_eval(t1, t2, d, "manhattan", r64, c64)
+    monkeypatch.setenv("OEA_L1_EVAL", "grid")
+    r, c, grid = csls_means_device(t1, t2, d, "manhattan", k, return_grid=True)
+    assert grid is not None and len(grid.strips) > 0                   # the query strips stay for the rank pass (they fit)
+    assert torch.equal(r, r64) and torch.equal(c, c64)                 # the means, bit for bit
+    assert np.array_equal(r.cpu().numpy()[rows], cport.topk_mean(s_rows, k))
+    rk, am = ops.rank_eval_l1_grid(t1, t2, d, csls_r=r, csls_c=c, grid=grid)
+    assert not grid.strips
+    assert torch.equal(rk, rk64) and torch.equal(am, am64)
+    rk_ref, am_ref = _l1_rank_ref(s_rows, rows, r.cpu().numpy(), c.cpu().numpy())
+    assert np.array_equal(rk.cpu().numpy()[rows], rk_ref) and np.array_equal(am.cpu().numpy()[rows], am_ref)
+    # the call test() makes (greedy_alignment_device): the same numbers
+    from openea_amd.modules.finding.alignment import greedy_alignment_device
+    rk2, am2, hits, rs, rr = greedy_alignment_device(t1, t2, d, [1, 5, 10, 50], "manhattan", False, k)
+    assert torch.equal(rk2, rk) and torch.equal(am2, am) and hits[0] == int((rk == 0).sum().item())
+
+
+def test_rank_eval_70k_bf16_csls_row_blocks(ops):
+    """the row-sharded inner-product evaluation with CSLS at BootEA-100K's size (70,000^2 x 100): two blocks of
+    query rows through oea_rank_eval_bf16_csls with their gold offsets and their slices of the row means == the unsharded call
+    == the exact fp32 sweep."""
+    from openea_amd.modules.finding.similarity import csls_means_device
+    rng = np.random.RandomState(5)
+    n, d = 70000, 100
+    e1 = _unit_rows(rng, n, d)
+    e2 = e1 + 0.9 * _unit_rows(rng, n, d)
+    t1, t2 = ops.to_table(e1), ops.to_table(e2)
+    assert ops.eval_bf16_enabled(n, n)
+    rr, cc = csls_means_device(t1, t2, d, "inner", 10)
+    st = {}
+    rank, argmax = ops.rank_eval_bf16(t1, t2, d, csls_r=rr, csls_c=cc, stats=st)
+    assert not st["fallback"]
+    r32, a32 = ops.rank_eval(t1, t2, d, "inner", rr, cc, allow_bf16=False)
+    assert torch.equal(rank, r32) and torch.equal(argmax, a32)
+    assert 0.05 < float((rank == 0).float().mean().item()) < 0.95
+    lo = 33333
+    sa, sb = {}, {}
+    ra, aa = ops.rank_eval_bf16(t1[:lo], t2, d, gold_offset=0, csls_r=rr[:lo].contiguous(), csls_c=cc, stats=sa)
+    rb, ab = ops.rank_eval_bf16(t1[lo:], t2, d, gold_offset=lo, csls_r=rr[lo:].contiguous(), csls_c=cc, stats=sb)
+    assert not sa["fallback"] and not sb["fallback"]
+    assert torch.equal(torch.cat([ra, rb]), rank) and torch.equal(torch.cat([aa, ab]), argmax)
+
+
 def test_rank_eval_manhattan_10k5(ops):
     from oracle import cport
     rng = np.random.RandomState(1)
