@@ -29,10 +29,10 @@ is timed --repeats times (default 50) and the MEDIAN region is reported (a singl
 sample of it says little).
 
 OUTPUT.  The LAST line of stdout (rank 0) is ONE compact JSON object of at most 4 KB: the contract's keys, `roofline`
-(triple_grouped: HIP events on its dispatches, design bytes, counter traffic), `roofline_eval`, `cpu_baseline` and a few dozen
+(triple_wave, the scoring kernel of the step: HIP events on its dispatches, design bytes, counter traffic), `roofline_eval`, `cpu_baseline` and a few dozen
 scalars under `extra`.  Everything else -- per-kernel counter dictionaries, region times, formulas, notes, provenance -- goes
 to bench_detail.json (repo root; also gpurun_out/ when that directory exists), named by the line's `detail` key:
-  roofline      dominant kernel (triple_grouped, fwd + bwd), timed live by HIP events attached to its dispatches.
+  roofline      dominant kernel (triple_wave, fwd + bwd; triple_grouped under OEA_STEP_WAVE=0), timed live by HIP events attached to its dispatches.
                 `frac` is priced on the bytes the kernel is DESIGNED to move -- it shares the positive's three rows across
                 its k negatives: 8*d*(3+k) B per positive (read 3+k rows, accumulate 3+k gradient rows); SURVEY 8d's
                 24*d B per scored triple (which counts those rows once per triple) is kept as `frac_sec8d` in the detail.
@@ -238,6 +238,7 @@ class Workload:
         (fwd_ms, gap_ms, apply_ms), n_calls = ops.profile_end(4)
         loss = tr.pop_loss()
         ep.check()
+        touched = self.touched_rows()
         t = torch.tensor(times, dtype=torch.float64, device=self.ent.var.device)
         c = torch.tensor(pos, dtype=torch.float64, device=self.ent.var.device)
         if self.world > 1:
@@ -245,7 +246,30 @@ class Workload:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(times=t.cpu().numpy(), pos=c.cpu().numpy(), pos_local=np.asarray(pos, np.float64),
-                    fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss)
+                    fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss, touched_rows=touched)
+
+    def touched_rows(self, n_steps=4):
+        """distinct entity + relation rows the optimiser visits per step on this rank: counted from the ids of the current epoch's
+        first steps (positives + the negatives drawn ahead for them), not assumed -- apply_rows works on the rows that received
+        gradient, and 20*d B per row of THOSE is what `step_frac` prices (the whole table over-counted by a third)"""
+        torch, ep = self.torch, self.epochs
+        b, k = ep.batches, self.neg
+        neg_all = getattr(ep, "_neg_all", None)
+        if neg_all is None or not getattr(ep, "_epoch_negs_ready", False):
+            return None
+        out = []
+        for s in range(min(n_steps, len(b.splits))):
+            o0, o1 = int(b.offsets[s]), int(b.offsets[s + 1])
+            if self.world > 1:
+                n = o1 - o0
+                o0, o1 = o0 + n * self.rank // self.world, o0 + n * (self.rank + 1) // self.world
+            if o1 <= o0:
+                continue
+            p, n = b.dall[o0:o1], neg_all[o0 * k:o1 * k]
+            ents = torch.unique(torch.cat([p[:, 0], p[:, 2], n[:, 0], n[:, 2]])).numel()
+            rels = torch.unique(p[:, 1]).numel()
+            out.append(ents + rels)
+        return float(np.mean(out)) if out else None
 
     def phase_times(self, steps):
         """N > 1, one C call per epoch (oea_triple_epoch_range_comm): HIP events at the phase boundaries of `steps` further
@@ -283,11 +307,13 @@ class Workload:
         sec8d = sec8d_bytes / fwd_s / 1e9 if fwd_s > 0 else 0.0
         traffic = traffic or {}
         tb = traffic.get("hbm_bytes_per_launch")
-        # whole step: scoring + Adagrad (20*d B per touched row; touched rows <= unique ids of the batch, estimated
-        # by the table rows here: at both shapes a batch touches most of the table)
-        touched = min(self.kgs.entities_num + self.kgs.relations_num, scored_per_launch * 2)
+        # whole step: scoring + Adagrad (20*d B per touched row: value and accumulator read + written, gradient read).  Touched rows
+        # are COUNTED from the batch ids (touched_rows); every row that received gradient is one (an upper bound of what the
+        # kernels visit: a row whose hinges were all inactive is skipped)
+        counted = m.get("touched_rows")
+        touched = counted if counted else min(self.kgs.entities_num + self.kgs.relations_num, scored_per_launch * 2)
         step_design = design_bytes + 20.0 * d * touched
-        roofline = {"kernel": "triple_grouped (fwd + bwd)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"kernel": "triple_wave (fwd + bwd; triple_grouped where OEA_STEP_WAVE=0 or the shape is outside its rule)", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": tb, "traffic_source": traffic.get("source"),
                     "hbm_frac": round(tb / fwd_s / 1e9 / HBM_PEAK_GBS, 4) if (tb and fwd_s > 0) else None,
@@ -295,7 +321,8 @@ class Workload:
                     "achieved_sec8d": round(sec8d, 1), "frac_sec8d": round(min(sec8d / HBM_PEAK_GBS, 1.0), 4),
                     "sec8d_bytes_per_launch": int(sec8d_bytes),
                     "step_frac": round(step_design / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "design_bytes_per_step": int(step_design),
+                    "design_bytes_per_step": int(step_design), "touched_rows_per_step": int(touched),
+                    "touched_rows_source": "counted from the batch ids" if counted else "assumed (min(table rows, 2 * scored triples))",
                     "avg_kernel_us": round(fwd_s * 1e6, 2), "apply_rows_avg_us": round(apply_s * 1e6, 2),
                     "gap_between_kernels_us": round(m["gap_ms"] * 1e3 / launches, 2),
                     "launches_timed": int(m["n_calls"]),
@@ -364,11 +391,15 @@ def measure_traffic(shape, d, batch, neg, eps, timeout_s=240):
                 return None, 0
             k = max(ks, key=lambda kk: n[kk])
             return int((2.0 * fetch[k] + write.get(k, 0.0)) * 1024), int(n[k])
-        tb, calls = pick("triple_grouped")
+        tb, calls = pick("triple_wave")
+        kname = "triple_wave"
+        if tb is None:
+            tb, calls = pick("triple_grouped")
+            kname = "triple_grouped"
         ab, _ = pick("apply_rows")
         if tb is None:
-            raise RuntimeError("triple_grouped not in the counter output")
-        return {"hbm_bytes_per_launch": tb, "apply_rows_hbm_bytes_per_launch": ab, "launches": calls,
+            raise RuntimeError("neither triple_wave nor triple_grouped in the counter output")
+        return {"hbm_bytes_per_launch": tb, "apply_rows_hbm_bytes_per_launch": ab, "launches": calls, "kernel": kname,
                 "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over a "
                           "40-step child run of the same workload, (2*FETCH + WRITE) KB averaged over %d launches (%.0f s)"
                           % (calls, time.time() - t0)}
@@ -590,7 +621,7 @@ def compact_line(out, detail_path=None):
                    "parallelism": (cfg.get("parallelism") or "")[:60]}
     r = _pick(rl, ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac", "avg_kernel_us", "design_bytes_per_launch",
                    "step_frac", "apply_rows_avg_us", "apply_rows_hbm_frac", "launches_timed"))
-    r["kernel"] = "triple_grouped"
+    r["kernel"] = "triple_grouped" if os.environ.get("OEA_STEP_WAVE", "1") == "0" else "triple_wave"
     r.setdefault("traffic", None)
     c["roofline"] = r
     re_ = out.get("roofline_eval")

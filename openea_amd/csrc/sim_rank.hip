@@ -3632,14 +3632,12 @@ static int rank_eval_bf16_impl(const float *e1, int64_t n1, int32_t ld1, const f
     } while (0)
 #define OEA_BF16_BIG_SWEEP(C, M)                                                                                                     \
     do {                                                                                                                            \
-        static bool attr_set = false;                                                                                               \
-        if (!attr_set) {                                                                                                            \
-            OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C, M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                              BIG_LDS_BYTES));                                                                      \
-            attr_set = true;                                                                                                        \
-        }                                                                                                                           \
+        /* the attribute belongs to (function, DEVICE): set on every call (cheap), not once per process */             \
+        OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rank_bf16_big_kernel<C, M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          BIG_LDS_BYTES));                                                                          \
         rank_bf16_big_kernel<C, M><<<tile_grid_blocks(gs), 512, BIG_LDS_BYTES, st>>>(p1.p, n1, p1.kp, p2.p, n2, dim_p, gold, tol, sweep_r, sweep_c, tpc, \
                                                                                      gold_offset, rank, lbrow, rec, rec_cnt, slice_cap, gs);    \
+        OEA_CHECK_HIP(hipGetLastError());                                                                                           \
     } while (0)
     if (sweep_r) {
         if (warm >= 2) OEA_BF16_SWEEP(true, true, gw, warm);
@@ -4001,14 +3999,11 @@ int oea_csls_means(const float *e1, int64_t n1, int32_t ld1, const float *e2, in
         if (big) {
 #define OEA_CSLS_BIG(M)                                                                                                              \
             do {                                                                                                                    \
-                static bool attr_set = false;                                                                                       \
-                if (!attr_set) {                                                                                                    \
-                    OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, M>),       \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));                  \
-                    attr_set = true;                                                                                                \
-                }                                                                                                                   \
+                OEA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csls_append_kernel<true, true, 0, 8, M>),           \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));   /* per device */   \
                 csls_append_kernel<true, true, 0, 8, M><<<tile_grid_blocks(grid), 512, BIG_LDS_BYTES, st>>>(                        \
                     b1.p, n1, kp, b2.p, n2, kp, dim, thr1, thr2, p.tpc, p.cap, p.ccap, qlists, qcnt, clists, ccnt, tol, grid);      \
+                OEA_CHECK_HIP(hipGetLastError());                                                                                   \
             } while (0)
             if (big_mode == 2) OEA_CSLS_BIG(2);
             else if (big_mode == 1) OEA_CSLS_BIG(1);

@@ -105,20 +105,6 @@ __device__ __forceinline__ void load_row(const float *__restrict__ base, int ld,
         r.v[it] = ((TIGHT && G == 32 && it < IT - 1) || c < ld) ? base[c] : 0.f;
     }
 }
-// the same without a branch (the software-pipelined kernel: conditional loads put every gather in its own basic block and the
-// wait-count insertion falls back to vmcnt(0)): the last fragment's column is clamped into the row and the value zeroed by a select
-template <int G, int IT>
-__device__ __forceinline__ void load_row_nb(const float *__restrict__ base, int ld, int lane, Row<G, IT> &r) {
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int c = it * G + lane;
-        r.v[it] = base[it < IT - 1 ? c : min(c, ld - 1)];          // (the pad lanes of the last fragment hold a copy of column ld - 1:
-    }                                                              //  mask_row_tail zeroes them where the row is CONSUMED -- a select
-}                                                                  //  here would be a use of the loaded value in front of the arithmetic)
-template <int G, int IT>
-__device__ __forceinline__ void mask_row_tail(Row<G, IT> &r, int ld, int lane) {
-    if ((IT - 1) * G + lane >= ld) r.v[IT - 1] = 0.f;
-}
 // a row of the gradient scratch: raw elements (exact sums of the relation copies), then ONE conversion to fp32
 template <int G, int IT>
 __device__ __forceinline__ void load_grad_raw(const grad_t *__restrict__ base, int ld, int lane, grad_t (&q)[IT]) {
@@ -447,210 +433,6 @@ __global__ __launch_bounds__(256, (IT <= 4 ? 3 : 2)) void triple_grouped(
     block_loss_partial(loss_local, ws.partials);
 }
 
-// ---- kernel 1a', software-pipelined (round 5): the 100K shape ------------------------------------------------------------------------
-// triple_grouped gives a group ONE positive: ids -> rows -> arithmetic -> atomics, four phases in series per wave, and a resident wave
-// has row loads in flight for ~13 % of its 19 us -- 3.1 TB/s at the 100K shape, where the tables (80 MB + the scratch) no longer sit
-// in the caches and 10,000 waves take 3.3 rounds of the resident set.  triple_grouped_dma (below) lets a group walk several
-// positives with the gathers of the NEXT one in flight behind the arithmetic of the current one.  Same arithmetic per positive as
-// triple_grouped, bit for bit (the loss partials group differently: fp64 sums, last-bit differences in the printed loss only).
-// k <= KC, ld <= 128.  (Two register-held row sets were tried first: in a loop hipcc's wait-count insertion gives loop-carried
-// loads a vmcnt(0) at first use, which waits for the gathers just issued as well; fully unrolled it spills 24 ... 208 registers.)
-template <int G, int IT, int KC>
-struct PosSet {
-    int h, r, t;
-    int nid;                              // the negatives' ids, 3 per slot across the group's lanes
-    int ce[KC];
-    unsigned tailm, okm, slow;
-    Row<G, IT> yh, yr, yt, yc[KC];
-};
-
-// the arithmetic + atomics of one positive and its k negatives: triple_grouped's, statement for statement
-template <int G, int IT, int KC, int LOSS, int L1>
-__device__ __forceinline__ double pipe_compute(PosSet<G, IT, KC> &s, int64_t p, const float *__restrict__ ent, const float *__restrict__ rel,
-                                               int ld, int lane, const oea_step_cfg &cfg, const StepWs &ws, int lk, int l1) {
-    Row<G, IT> delta, g, gh, gr, gt;
-    mask_row_tail<G, IT>(s.yh, ld, lane);
-    mask_row_tail<G, IT>(s.yr, ld, lane);
-    mask_row_tail<G, IT>(s.yt, ld, lane);
-    normalize<G, IT>(s.yh, cfg.ent_l2_norm);
-    normalize<G, IT>(s.yr, cfg.rel_l2_norm);
-    normalize<G, IT>(s.yt, cfg.ent_l2_norm);
-    const float sp = score<G, IT>(s.yh, s.yr, s.yt, l1, delta);
-    float coef, l;
-    triple_coef_kind(lk, cfg, true, sp, coef, l);
-    double lsum = (double)l;
-    dscore<G, IT>(delta, coef, l1, g);
-#pragma unroll
-    for (int it = 0; it < IT; ++it) { gh.v[it] = g.v[it]; gr.v[it] = g.v[it]; gt.v[it] = -g.v[it]; }
-    bool any = coef != 0.f;
-    if (s.slow) {
-#pragma unroll 1
-        for (int j = 0; j < KC; ++j)
-            if ((s.slow >> j) & 1u)
-                lsum += score_independent<G, IT>(ent, rel, ld, lane, p, __shfl(s.nid, 3 * j, G), __shfl(s.nid, 3 * j + 1, G),
-                                                 __shfl(s.nid, 3 * j + 2, G), false, cfg, ws, lk, l1);
-    }
-    float sc[KC];
-#pragma unroll
-    for (int j = 0; j < KC; ++j) {
-        mask_row_tail<G, IT>(s.yc[j], ld, lane);
-        normalize<G, IT>(s.yc[j], cfg.ent_l2_norm);
-        float sv = 0.f;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const bool tl = (s.tailm >> j) & 1u;
-            const float a = tl ? s.yh.v[it] : s.yc[j].v[it], b = tl ? s.yc[j].v[it] : s.yt.v[it];
-            const float d = a + s.yr.v[it] - b;
-            s.yc[j].v[it] = d;
-            sv += l1 ? fabsf(d) : d * d;
-        }
-        sc[j] = group_sum<G>(sv);
-    }
-#pragma unroll
-    for (int j = 0; j < KC; ++j) {
-        if (!((s.okm >> j) & 1u)) continue;
-        const bool tl = (s.tailm >> j) & 1u;
-        triple_coef_kind(lk, cfg, false, sc[j], coef, l);
-        lsum += (double)l;
-        if (coef != 0.f) {
-            any = true;
-            dscore<G, IT>(s.yc[j], coef, l1, g);
-            if (tl) {
-#pragma unroll
-                for (int it = 0; it < IT; ++it) { gh.v[it] += g.v[it]; gr.v[it] += g.v[it]; }
-            } else {
-#pragma unroll
-                for (int it = 0; it < IT; ++it) { gr.v[it] += g.v[it]; gt.v[it] -= g.v[it]; }
-            }
-            atomic_row<G, IT>(ws.ent_grad + (int64_t)s.ce[j] * ld, ld, lane, g, tl ? -1.f : 1.f);
-            if (lane == 0) ws.ent_touched[s.ce[j]] = 1.f;
-        }
-    }
-    if (any) {
-        atomic_row<G, IT>(ws.ent_grad + (int64_t)s.h * ld, ld, lane, gh, 1.f);
-        atomic_row<G, IT>(ws.rel_copy(p % kRelCopies) + (int64_t)s.r * ld, ld, lane, gr, 1.f);
-        atomic_row<G, IT>(ws.ent_grad + (int64_t)s.t * ld, ld, lane, gt, 1.f);
-        if (lane == 0) { ws.ent_touched[s.h] = 1.f; ws.ent_touched[s.t] = 1.f; ws.rel_touched[s.r] = 1.f; }
-    }
-    return lsum;
-}
-
-// The gathers go through the LDS: `global_load_lds_dwordx4` moves a row (<= 128 floats = 32 lanes x 16 B) from the table into a
-// 512-byte slot of the wave's staging area with ONE instruction, no destination registers and no wait until the data is wanted --
-// 13 DMA instructions per wave and stage (both of the wave's groups at once: lanes 0-31 row of group 0, lanes 32-63 row of group 1)
-// instead of 104 dword loads.  A group walks `np` positives: at stage i it copies the landed rows of positive i from the LDS into
-// registers (lane-strided fragments, as triple_grouped holds them: every atomic instruction still covers one 128-byte segment),
-// starts the DMA of positive i + 1 into the same slots, requests the ids of positive i + 2 and only then does the arithmetic and the
-// atomics of positive i -- the gathers of i + 1 travel behind them.  One row set in registers: three waves per SIMD as before;
-// LDS: 13 KB per wave (52 KB per workgroup, three workgroups per CU).  Waits are explicit (vmcnt(0) at the top of a stage: the DMA
-// was issued a whole stage earlier; the atomics of the previous stage are acknowledged there too -- 1-2 us during which the SIMD's
-// other waves run), the compiler's own wait-count insertion only ever adds to them.
-template <int G, int IT, int LOSS, int L1>
-__global__ __launch_bounds__(256, 3) void triple_grouped_dma(
-    const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
-    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws, int np) {
-    constexpr int KC = 10, ROWS = 3 + KC;
-    static_assert(G == 32 && IT <= 4 && 3 * KC <= G, "rows of at most 128 columns, one chunk of negatives");
-    __shared__ __attribute__((aligned(16))) float stage[4][ROWS][256];        // [wave][row slot][2 groups x 128 floats]
-    const int lane = threadIdx.x % G, wave = threadIdx.x >> 6, half = (threadIdx.x >> 5) & 1;
-    float *wbase = &stage[wave][0][0];
-    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngrp = (int64_t)gridDim.x * blockDim.x / G;
-    const int lk = LOSS >= 0 ? LOSS : cfg.loss_kind;
-    const int l1 = L1 >= 0 ? L1 : cfg.l1;
-    const int col16 = 4 * min(lane, ld / 4 - 1);               // this lane's 16-byte piece of a row (the pad lanes repeat the last one)
-    double loss_local = 0.0;
-    auto ids = [&](int i, int &pid, int &nid) {              // round trip 1 of the group's i-th positive (a dead slot reads row 0's ids)
-        const int64_t p = grp + (int64_t)i * ngrp, q = p < n_pos ? p : 0;
-        pid = lane < 3 ? pos[3 * q + lane] : 0;
-        nid = lane < 3 * k ? neg[q * k * 3 + lane] : 0;
-    };
-    auto dma = [&](const float *row, int slot) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(row + col16),
-                                         reinterpret_cast<__attribute__((address_space(3))) void *>(reinterpret_cast<uintptr_t>(wbase + slot * 256)),
-                                         16, 0, 0);
-    };
-    // the ids of a positive -> its meta data (the PosSet's scalars) + the DMA of its 3 + k rows
-    auto start = [&](PosSet<G, IT, KC> &s, int pid, int nid) {
-        s.h = __shfl(pid, 0, G); s.r = __shfl(pid, 1, G); s.t = __shfl(pid, 2, G);
-        s.nid = nid;
-        dma(ent + (int64_t)s.h * ld, 0);
-        dma(rel + (int64_t)s.r * ld, 1);
-        dma(ent + (int64_t)s.t * ld, 2);
-        s.tailm = s.okm = s.slow = 0;
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            const int ch = __shfl(nid, 3 * j, G), cr = __shfl(nid, 3 * j + 1, G), ct = __shfl(nid, 3 * j + 2, G);
-            const bool valid = j < k;
-            const bool tl = ch == s.h;
-            const bool ok = valid && cr == s.r && (tl || ct == s.t);
-            s.tailm |= tl ? 1u << j : 0u;
-            s.okm |= ok ? 1u << j : 0u;
-            s.slow |= (valid && !ok) ? 1u << j : 0u;
-            s.ce[j] = valid ? (tl ? ct : ch) : s.h;
-            dma(ent + (int64_t)s.ce[j] * ld, 3 + j);
-        }
-    };
-    auto take = [&](Row<G, IT> &r, int slot) {               // LDS slot -> lane-strided fragments
-        const float *src = wbase + slot * 256 + half * 128;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = it * G + lane;
-            r.v[it] = ((it < IT - 1) || c < ld) ? src[c] : 0.f;
-        }
-    };
-    PosSet<G, IT, KC> cur;
-    int h2 = 0, r2 = 0, t2 = 0, nid2 = 0, ce2[KC];
-    unsigned tailm2 = 0, okm2 = 0, slow2 = 0;
-    int pidn, nidn;
-    ids(0, pidn, nidn);
-    start(cur, pidn, nidn);
-    if (np > 1) ids(1, pidn, nidn);
-    for (int i = 0; i < np; ++i) {
-        const int64_t p = grp + (int64_t)i * ngrp;
-        // ---- the rows of positive i have had a whole stage to arrive ------------------------------------------------------------
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        take(cur.yh, 0); take(cur.yr, 1); take(cur.yt, 2);
-#pragma unroll
-        for (int j = 0; j < KC; ++j) take(cur.yc[j], 3 + j);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every slot is in registers: the staging area is free again
-        // ---- positive i + 1: meta data into the spare scalars, rows by DMA; ids of positive i + 2 ------------------------------
-        const bool more = i + 1 < np;
-        if (more) {
-            h2 = __shfl(pidn, 0, G); r2 = __shfl(pidn, 1, G); t2 = __shfl(pidn, 2, G);
-            nid2 = nidn;
-            dma(ent + (int64_t)h2 * ld, 0);
-            dma(rel + (int64_t)r2 * ld, 1);
-            dma(ent + (int64_t)t2 * ld, 2);
-            tailm2 = okm2 = slow2 = 0;
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                const int ch = __shfl(nidn, 3 * j, G), cr = __shfl(nidn, 3 * j + 1, G), ct = __shfl(nidn, 3 * j + 2, G);
-                const bool valid = j < k;
-                const bool tl = ch == h2;
-                const bool ok = valid && cr == r2 && (tl || ct == t2);
-                tailm2 |= tl ? 1u << j : 0u;
-                okm2 |= ok ? 1u << j : 0u;
-                slow2 |= (valid && !ok) ? 1u << j : 0u;
-                ce2[j] = valid ? (tl ? ct : ch) : h2;
-                dma(ent + (int64_t)ce2[j] * ld, 3 + j);
-            }
-            if (i + 2 < np) ids(i + 2, pidn, nidn);
-        }
-        // ---- arithmetic + atomics of positive i ----------------------------------------------------------------------------------
-        if (p < n_pos) {
-            const double l = pipe_compute<G, IT, KC, LOSS, L1>(cur, p, ent, rel, ld, lane, cfg, ws, lk, l1);
-            if (lane == 0) loss_local += l;
-        }
-        if (more) {
-            cur.h = h2; cur.r = r2; cur.t = t2; cur.nid = nid2; cur.tailm = tailm2; cur.okm = okm2; cur.slow = slow2;
-#pragma unroll
-            for (int j = 0; j < KC; ++j) cur.ce[j] = ce2[j];
-        }
-    }
-    block_loss_partial(loss_local, ws.partials);
-}
-
 // ---- kernel 1a'', round 6: one WAVE per positive ----------------------------------------------------------------------------------------
 // triple_grouped puts two positives on a wave (one per 32-lane half).  Everything that depends on the ids -- row addresses, "is this
 // negative a tail or a head corruption", "is its hinge active" -- is then per-LANE state: 64-bit address arithmetic on the VALU for every
@@ -736,7 +518,7 @@ __device__ __forceinline__ void wave_normalize(Row<64, IT> &r) {
 template <int IT, int L1, int KT>
 __global__ __launch_bounds__(512) void triple_wave(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
-    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws) {
+    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws, int dbg) {
     constexpr int G = 64, KC = 10;
     if (KT > 0) k = KT;
     const int lane = threadIdx.x & 63;
@@ -744,10 +526,12 @@ __global__ __launch_bounds__(512) void triple_wave(
     const int wpb = blockDim.x >> 6;                                          // 8 (ld <= 128) or 4 waves: launch_step's groups per block
     const int64_t w0 = (int64_t)blockIdx.x * wpb + wv, nw = (int64_t)gridDim.x * wpb;
     const int row_b = ld * 4, row_g = ld << kGradShift;                       // bytes per table row / scratch row
-    const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ent), 0, kBufRecords, kBufFlags);
-    const __amdgpu_buffer_rsrc_t rs_rel = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rel), 0, kBufRecords, kBufFlags);
-    const __amdgpu_buffer_rsrc_t rs_eg = __builtin_amdgcn_make_buffer_rsrc(ws.ent_grad, 0, kBufRecords, kBufFlags);
-    const __amdgpu_buffer_rsrc_t rs_et = __builtin_amdgcn_make_buffer_rsrc(ws.ent_touched, 0, kBufRecords, kBufFlags);
+    // dbg (OEA_STEP_WAVE_DBG, experiments only): bit 0 = an empty resource for the scratch (every atomic is issued and dropped), bit 1 =
+    // empty resources for the tables (every row load is issued and returns 0), bit 2 = no touched flags
+    const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ent), 0, (dbg & 2) ? 0 : kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_rel = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(rel), 0, (dbg & 2) ? 0 : kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_eg = __builtin_amdgcn_make_buffer_rsrc(ws.ent_grad, 0, (dbg & 1) ? 0 : kBufRecords, kBufFlags);
+    const __amdgpu_buffer_rsrc_t rs_et = __builtin_amdgcn_make_buffer_rsrc(ws.ent_touched, 0, (dbg & 4) ? 0 : kBufRecords, kBufFlags);
     const int v4 = lane * 4, vg = lane << kGradShift;
     const int c_last = (IT - 1) * 64 + lane;                                  // this lane's column in the last fragment
     const int vt = c_last < ld ? c_last * 4 : kBufOob, vgt = c_last < ld ? c_last << kGradShift : kBufOob;
@@ -871,8 +655,8 @@ __global__ __launch_bounds__(512) void triple_wave(
         if (cpos | anyneg) {
             const int copy = (int)(p % kRelCopies);
             grad_t *rgb = copy == 0 ? ws.rel_grad : ws.rel_extra + (copy - 1) * ws.rel_copy_stride;
-            const __amdgpu_buffer_rsrc_t rs_rg = __builtin_amdgcn_make_buffer_rsrc(rgb, 0, kBufRecords, kBufFlags);
-            const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(ws.rel_touched, 0, kBufRecords, kBufFlags);
+            const __amdgpu_buffer_rsrc_t rs_rg = __builtin_amdgcn_make_buffer_rsrc(rgb, 0, (dbg & 1) ? 0 : kBufRecords, kBufFlags);
+            const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(ws.rel_touched, 0, (dbg & 4) ? 0 : kBufRecords, kBufFlags);
             wave_atomic_row<IT>(rs_rg, r * row_g, vg, vgt, gacc, 1.f);
             buf_flag_set(rs_rt, r);
             if (tails) {
@@ -1895,7 +1679,8 @@ template <int IT64>
 void launch_wave(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
                  int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
     const int k = cfg.neg_group_k;
-#define OEA_WAVE(L1, KT) oea::launch_timed(triple_wave<IT64, L1, KT>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws)
+    static const int dbg = [] { const char *e = getenv("OEA_STEP_WAVE_DBG"); return e ? atoi(e) : 0; }();
+#define OEA_WAVE(L1, KT) oea::launch_timed(triple_wave<IT64, L1, KT>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, dbg)
     if (k == 10) { if (cfg.l1) OEA_WAVE(1, 10); else OEA_WAVE(0, 10); }
     else { if (cfg.l1) OEA_WAVE(1, 0); else OEA_WAVE(0, 0); }
 #undef OEA_WAVE
@@ -1914,20 +1699,6 @@ void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const f
             step_wave_enabled()) {
             constexpr int IT64 = G == 32 ? (IT + 1) / 2 : 4;
             launch_wave<IT64>(nb, (block / G) * 64, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
-            return;
-        }
-    }
-    // software-pipelined form (triple_grouped_dma): np positives per group, the smallest np whose grid is resident at once (three
-    // workgroups of 8 groups per CU: 6,144 groups); OEA_STEP_PIPE = 0 / 1 overrides the size rule, OEA_STEP_PIPE_NP fixes np
-    static const int pipe_env = [] { const char *e = getenv("OEA_STEP_PIPE"); return e ? atoi(e) : -1; }();
-    static const int np_env = [] { const char *e = getenv("OEA_STEP_PIPE_NP"); return e ? atoi(e) : 0; }();
-    if constexpr (G == 32 && IT <= 4) {
-        const bool pipe = pipe_env >= 0 ? pipe_env != 0 : false;
-        const int np = np_env ? np_env : (int)std::max<int64_t>(2, oea::ceil_div(n_pos, 6144));
-        if (pipe && !runtime_kind && k >= 1 && k <= 10 && cfg.loss_kind == OEA_LOSS_LIMITED && n_pos >= 2048) {
-            const int nbp = (int)oea::ceil_div(oea::ceil_div(n_pos, np), block / G);
-            if (cfg.l1) oea::launch_timed(triple_grouped_dma<G, IT, OEA_LOSS_LIMITED, 1>, nbp, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, np);
-            else oea::launch_timed(triple_grouped_dma<G, IT, OEA_LOSS_LIMITED, 0>, nbp, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, np);
             return;
         }
     }

@@ -191,15 +191,34 @@ class CAbiComm:
               "through torch.distributed callbacks" % str(e)[:200], file=sys.stderr)
 
     def close(self):
-        """oea_comm_destroy (the RCCL communicator and its staging buffers); idempotent"""
+        """oea_comm_destroy (the RCCL communicator and its staging buffers) after the work enqueued on the device has drained;
+        idempotent.  The EXPLICIT way out (TripleTrainer.close()): ncclCommDestroy with work in flight, or after the runtime /
+        process group is gone, can hang or crash where no try/except reaches."""
         h, self.handle = getattr(self, "handle", None), None
         if h is not None and getattr(h, "value", None):
             try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 self.lib.oea_comm_destroy(h)
-            except Exception:            # noqa: BLE001 -- interpreter shutdown
+            except Exception:            # noqa: BLE001
                 pass
 
     def __del__(self):
+        # garbage collection is not a safe place for ncclCommDestroy: at interpreter shutdown the HIP / RCCL runtime or the process
+        # group may already be torn down.  Late collection leaks the communicator (the process is ending); close() destroys it.
+        import sys
+        if sys is None or sys.is_finalizing():
+            self.handle = None
+            return
+        try:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                self.handle = None
+                return
+        except Exception:                # noqa: BLE001
+            self.handle = None
+            return
         self.close()
 
     _NP = {0: np.float32, 1: np.float64, 2: np.int64}

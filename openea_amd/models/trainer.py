@@ -466,7 +466,11 @@ class RelationTripleEpochs:
             have = self.k and self._epoch_negs_ready
             if hasattr(trainer, "count_steps"):
                 trainer.count_steps(int((np.diff(b.offsets[lo:hi + 1]) > 0).sum()))
-            if c_part and getattr(trainer, "exchange", None) == "halo":
+            # the boundary-row exchange plans a range from negatives that EXIST (drawn ahead for the epoch); a range that starts inside
+            # an epoch whose negatives were dropped (set_neighbours between two run_steps calls) takes the dense exchange, which
+            # samples step by step
+            halo_ok = (not self.k) or have or lo == 0
+            if c_part and getattr(trainer, "exchange", None) == "halo" and halo_ok:
                 halo = trainer.halo_buffers(S, int(np.diff(b.offsets).max()), self.k)
                 if getattr(self, "_off_dev", None) is None:          # (k = 0: no negatives buffer made them)
                     self._off_dev = torch.from_numpy(b.offsets).to(self.dev)

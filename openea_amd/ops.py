@@ -382,6 +382,7 @@ def triple_epoch_comm(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, s
                       err_flag, cfg, workspace, loss_accum, offsets_dev, splits_dev, bufs, step_range=None):
     """steps [lo, hi) of a data-parallel epoch under the entity-id partition from ONE C call over the C ABI's communicator
     (oea_triple_epoch_range_comm); bufs = part_buffers(...)."""
+    offsets, splits = np.ascontiguousarray(offsets, np.int64), np.ascontiguousarray(splits, np.int64)   # what the C side reads
     steps = len(splits)
     lo, hi = (0, steps) if step_range is None else step_range
     check(lib().oea_triple_epoch_range_comm(comm, _p(ent), _p(acc_own), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
@@ -405,12 +406,13 @@ def halo_buffers(n_ent, ld, world, steps, max_batch, k, dev):
 def halo_plan(pos_all, neg_all, k, offsets, n_ent, world, step_range=None, with_lists=True):
     """which rows every rank's share of every step refers to, per owner (oea_halo_plan) -> (counts int32 [steps, world, world],
     lists int32 [steps, world, cap] or None): what sizes the messages of the boundary-row exchange"""
+    offsets = np.ascontiguousarray(offsets, np.int64)      # ONE array for the host pointer and the device copy (ADVICE r05)
     steps = len(offsets) - 1
     lo, hi = (0, steps) if step_range is None else step_range
     max_batch = int(np.diff(offsets).max()) if steps else 0
     dev = pos_all.device
     ws = torch.empty(lib().oea_halo_workspace_bytes(int(n_ent), int(world), hi - lo, max_batch, int(k)), dtype=torch.uint8, device=dev)
-    off_dev = torch.from_numpy(np.ascontiguousarray(offsets, np.int64)).to(dev)
+    off_dev = torch.from_numpy(offsets).to(dev)
     counts = np.zeros((hi - lo, world, world), np.int32)
     cap = C.c_int64(0)
     check(lib().oea_halo_plan(_p(pos_all), _p(neg_all), int(k), offsets.ctypes.data_as(C.c_void_p), _p(off_dev), steps, int(lo), int(hi),
@@ -428,6 +430,7 @@ def triple_epoch_halo(comm, ent, acc_own, rel, rel_acc, dim, pos_all, offsets, s
                       err_flag, cfg, workspace, loss_accum, offsets_dev, splits_dev, bufs, halo, step_range=None):
     """triple_epoch_comm with the boundary-row exchange (oea_triple_epoch_range_halo); bufs = part_buffers(...), halo =
     halo_buffers(...) -> (bytes pushed, bytes pulled, largest rows sent in a step, steps) of this rank"""
+    offsets, splits = np.ascontiguousarray(offsets, np.int64), np.ascontiguousarray(splits, np.int64)   # what the C side reads
     steps = len(splits)
     lo, hi = (0, steps) if step_range is None else step_range
     stats = (C.c_int64 * 4)()

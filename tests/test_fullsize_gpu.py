@@ -169,7 +169,7 @@ def test_rank_eval_70k_bf16_csls_row_blocks(ops):
     rng = np.random.RandomState(5)
     n, d = 70000, 100
     e1 = _unit_rows(rng, n, d)
-    e2 = e1 + 0.9 * _unit_rows(rng, n, d)
+    e2 = e1 + 2.0 * _unit_rows(rng, n, d)
     t1, t2 = ops.to_table(e1), ops.to_table(e2)
     assert ops.eval_bf16_enabled(n, n)
     rr, cc = csls_means_device(t1, t2, d, "inner", 10)
@@ -178,7 +178,7 @@ def test_rank_eval_70k_bf16_csls_row_blocks(ops):
     assert not st["fallback"]
     r32, a32 = ops.rank_eval(t1, t2, d, "inner", rr, cc, allow_bf16=False)
     assert torch.equal(rank, r32) and torch.equal(argmax, a32)
-    assert 0.05 < float((rank == 0).float().mean().item()) < 0.95
+    assert 0.02 < float((rank == 0).float().mean().item()) < 0.98     # neither all golds first nor none: both epilogue paths run
     lo = 33333
     sa, sb = {}, {}
     ra, aa = ops.rank_eval_bf16(t1[:lo], t2, d, gold_offset=0, csls_r=rr[:lo].contiguous(), csls_c=cc, stats=sa)
