@@ -239,6 +239,12 @@ class Workload:
         loss = tr.pop_loss()
         ep.check()
         touched = self.touched_rows()
+        plan_stats = None
+        try:
+            if getattr(ep, "_plan", None) is not None and getattr(ep, "_plan_ready", False):
+                plan_stats = ops.step_plan_stats(ep._plan, *ep._plan_dims)
+        except Exception as e:      # noqa: BLE001 -- a diagnostic, never the bench line
+            plan_stats = {"error": str(e)[:200]}
         t = torch.tensor(times, dtype=torch.float64, device=self.ent.var.device)
         c = torch.tensor(pos, dtype=torch.float64, device=self.ent.var.device)
         if self.world > 1:
@@ -246,7 +252,7 @@ class Workload:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
         return dict(times=t.cpu().numpy(), pos=c.cpu().numpy(), pos_local=np.asarray(pos, np.float64),
-                    fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss, touched_rows=touched)
+                    fwd_ms=fwd_ms, gap_ms=gap_ms, apply_ms=apply_ms, n_calls=n_calls, loss=loss, touched_rows=touched, plan_stats=plan_stats)
 
     def touched_rows(self, n_steps=4):
         """distinct entity + relation rows the optimiser visits per step on this rank: counted from the ids of the current epoch's
@@ -325,7 +331,7 @@ class Workload:
                     "touched_rows_source": "counted from the batch ids" if counted else "assumed (min(table rows, 2 * scored triples))",
                     "avg_kernel_us": round(fwd_s * 1e6, 2), "apply_rows_avg_us": round(apply_s * 1e6, 2),
                     "gap_between_kernels_us": round(m["gap_ms"] * 1e3 / launches, 2),
-                    "launches_timed": int(m["n_calls"]),
+                    "launches_timed": int(m["n_calls"]), "step_plan": m.get("plan_stats"),
                     "timing": "HIP start/stop events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on every "
                               "%d-th step of %d further K-step regions run right after the throughput regions (events on a "
                               "dispatch stop it from being pipelined behind its predecessor, so they stay out of `value`; a "

@@ -344,6 +344,47 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                            void *stream);
 
+/* ---- the gathered-sum plan of an epoch (round 6; csrc/step_plan.h) ------------------------------------------------------------
+ * Replaces, for the rows of the positives' own heads and tails, the scatter-add TF performs on the gradient of
+ * tf.nn.embedding_lookup (IndexedSlices -> unsorted_segment_sum, models/basic_model.py:89-98, modules/base/optimizers.py:4-7) --
+ * which the step kernels otherwise do with fp32 atomics that execute memory-side on gfx950 (~20 G requests/s: 24 of 54 us of the
+ * scoring kernel at the EN-FR-100K shape).  The epoch's positives and the negatives drawn ahead for them say BEFORE the epoch runs
+ * which entity row receives which positive's gradient rows: oea_step_plan_build sorts those references by (step, row) once per
+ * epoch (stable: batch order inside a row).  With a plan, the scoring kernel writes two rows per positive with plain stores and the
+ * optimiser kernel (apply_rows_plan) gathers every listed row's sum in the plan's order -- deterministic for those rows -- and
+ * visits exactly the rows that received gradient; relation rows, the corrupted rows of ACTIVE negatives and positives outside the
+ * rule (negatives on mixed sides, entries that are no corruption of their positive) keep the atomic scratch and the flag-driven
+ * optimiser pass.  Result = oea_triple_epoch_range up to the order of fp32 additions.
+ *   oea_step_plan_supported  1 when an epoch under `cfg` would use a plan (TransE score, limited loss, both tables normalised,
+ *                            1 <= k <= 10 == cfg->neg_group_k, ld <= 256, SGD / Adagrad, fp32 scratch, tables + state larger than
+ *                            128 MB -- cache-resident tables keep the flag-driven optimiser pass, which is faster there --,
+ *                            OEA_STEP_PLAN != 0; OEA_STEP_PLAN=2 drops the size condition)
+ *   oea_step_plan_bytes      workspace of a plan for n_total positives in `steps` batches of at most max_batch rows (includes the
+ *                            2 * max_batch contribution rows)
+ *   oea_step_plan_build      pos_all [n_total, 3] in batch order, neg_all [n_total * k, 3] (oea_sample_negatives_epoch), offsets_dev
+ *                            [steps + 1] int64 on the device; a few launches + three device primitives on `stream`, no allocation,
+ *                            no host read: meant for a side stream behind the previous epoch
+ *   oea_triple_epoch_range_plan  = oea_triple_epoch_range with the plan workspace; plan_built = 0: the call builds the plan itself
+ *                            (on `stream`, after drawing the negatives when it draws them); plan == NULL or an unsupported
+ *                            configuration: exactly oea_triple_epoch_range. */
+int32_t oea_step_plan_supported(const oea_step_cfg *cfg, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t k);
+size_t oea_step_plan_bytes(int64_t n_total, int32_t steps, int64_t max_batch, int64_t n_ent, int32_t ld);
+int oea_step_plan_build(const int32_t *pos_all, const int32_t *neg_all, int32_t k, const int64_t *offsets_dev, int64_t n_total,
+                        int32_t steps, int64_t max_batch, int64_t n_ent, int32_t ld, void *plan, size_t plan_bytes, void *stream);
+/* byte offsets inside a plan workspace (for tests that hold a built plan to the oracle's restatement): out[0] sorted entry values
+ * (uint32: sign << 31 | slot), [1] distinct keys (uint64: step << row_bits | row), [2] first entry of every distinct key (uint32),
+ * [3] number of distinct keys (int32), [4] first distinct key of every step (int32 [steps + 1]), [5] contribution rows, [6] row_bits,
+ * [7] total bytes, [8] per-positive hub bits (uint32 [n_total]: bit 0 / 1 = the positive's head / tail row has more than 8
+ * references in its step and takes this positive's gradient through the atomic scratch instead); out has 9 elements */
+int oea_step_plan_offsets(int64_t n_total, int32_t steps, int64_t max_batch, int64_t n_ent, int32_t ld, int64_t *out);
+int oea_triple_epoch_range_plan(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                                int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                                uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                                void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                                void *plan, size_t plan_bytes, int32_t plan_built, void *stream);
+
 /* The same for ONE RANK of a job whose ranks take contiguous shares of every batch (rows [n rank / world, n (rank + 1) / world)
  * of the batch's n rows, as models/dist.py:shard_batch) and train on LOCAL copies of the tables between two exchanges
  * (`dp_exchange = 'epoch'`: no collective inside the epoch; the caller reconciles the copies at the epoch's end).  The

@@ -78,6 +78,13 @@ static inline void launch_timed(K kernel, dim3 grid, dim3 block, hipStream_t st,
     else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
 }
 
+// the same with the events given by the caller (a phase of SEVERAL launches timed as one: start event on the first, stop on the last)
+template <class K, class... A>
+static inline void launch_events(K kernel, dim3 grid, dim3 block, hipStream_t st, hipEvent_t e0, hipEvent_t e1, A... args) {
+    if (e0 || e1) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+}
+
 // ---- wave64 helpers ---------------------------------------------------------------------
 // Sum over the G-lane group (G power of two <= 64) containing this lane; every lane of the
 // group gets the result.  Butterfly with __shfl_xor: fixed order -> deterministic.

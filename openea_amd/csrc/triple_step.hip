@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.h"
+#include "step_plan.h"
 
 namespace {
 
@@ -470,7 +471,9 @@ __device__ __forceinline__ void buf_grad_add(__amdgpu_buffer_rsrc_t rs, float v,
 #ifdef OEA_DET_SCRATCH
     const long long q = oea::to_fixed(v);
     const int vo = voff + imm;
-    asm volatile("buffer_atomic_add_x2 %0, %1, %2, %3 offen" ::"v"(q), "v"(vo), "s"(rs), "s"(soff) : "memory");
+    // s_nop 4: the hazard recogniser does not look inside inline assembly, and a VMEM instruction must not read a scalar register a
+    // VALU instruction (v_readlane of a spilled scalar, v_readfirstlane) wrote fewer than 5 wait states earlier
+    asm volatile("s_nop 4\n\tbuffer_atomic_add_x2 %0, %1, %2, %3 offen" ::"v"(q), "v"(vo), "s"(rs), "s"(soff) : "memory");
 #else
     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rs, voff + imm, soff, 0);
 #endif
@@ -515,10 +518,14 @@ __device__ __forceinline__ void wave_normalize(Row<64, IT> &r) {
     for (int it = 0; it < IT; ++it) r.v[it] *= inv;
 }
 
-template <int IT, int L1, int KT>
+// PLAN (step_plan.h): the positive's two gradient rows A = gacc, B = gpos leave as PLAIN stores into contrib[2 p + {0, 1}] (the
+// epoch's plan tells the optimiser kernel which entity rows add which of them, with which sign, in which order); only the relation
+// row and the corrupted rows of active negatives still go through the atomic scratch.
+template <int IT, int L1, int KT, bool PLAN>
 __global__ __launch_bounds__(512) void triple_wave(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
-    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws, int dbg) {
+    int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws, int dbg, float *__restrict__ contrib,
+    const uint32_t *__restrict__ pflags) {
     constexpr int G = 64, KC = 10;
     if (KT > 0) k = KT;
     const int lane = threadIdx.x & 63;
@@ -652,6 +659,16 @@ __global__ __launch_bounds__(512) void triple_wave(
                 }
             }
         // ---- the positive's rows: tail side gh = gr = gacc, gt = -gpos; head side gr = gacc, gt = -gacc, gh = gpos -----------------
+        if (PLAN) {
+            const __amdgpu_buffer_rsrc_t rs_cb = __builtin_amdgcn_make_buffer_rsrc(contrib, 0, kBufRecords, kBufFlags);
+            const int so = (int)p * 2 * row_b;                          // rows 2 p (A) and 2 p + 1 (B), always written: the plan reads them
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int vo = it < IT - 1 ? v4 + it * 256 : vt;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gacc.v[it]), rs_cb, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gpos.v[it]), rs_cb, vo, so + row_b, 0);
+            }
+        }
         if (cpos | anyneg) {
             const int copy = (int)(p % kRelCopies);
             grad_t *rgb = copy == 0 ? ws.rel_grad : ws.rel_extra + (copy - 1) * ws.rel_copy_stride;
@@ -659,14 +676,16 @@ __global__ __launch_bounds__(512) void triple_wave(
             const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc(ws.rel_touched, 0, (dbg & 4) ? 0 : kBufRecords, kBufFlags);
             wave_atomic_row<IT>(rs_rg, r * row_g, vg, vgt, gacc, 1.f);
             buf_flag_set(rs_rt, r);
-            if (tails) {
-                wave_atomic_row<IT>(rs_eg, h * row_g, vg, vgt, gacc, 1.f);
+            // without a plan both rows go through the atomic scratch; with one only the rows the plan marks as hubs of this step
+            const unsigned via_atomics = PLAN ? pflags[p] : 3u;         // bit 0: head row, bit 1: tail row
+            const bool h_full = tails, t_full = !tails;                  // the row that receives the whole sum (the other: the positive's term)
+            if ((via_atomics & 1u) && (h_full || cpos)) {
+                wave_atomic_row<IT>(rs_eg, h * row_g, vg, vgt, h_full ? gacc : gpos, 1.f);
                 buf_flag_set(rs_et, h);
-                if (cpos) { wave_atomic_row<IT>(rs_eg, t * row_g, vg, vgt, gpos, -1.f); buf_flag_set(rs_et, t); }
-            } else {
-                wave_atomic_row<IT>(rs_eg, t * row_g, vg, vgt, gacc, -1.f);
+            }
+            if ((via_atomics & 2u) && (t_full || cpos)) {
+                wave_atomic_row<IT>(rs_eg, t * row_g, vg, vgt, t_full ? gacc : gpos, -1.f);
                 buf_flag_set(rs_et, t);
-                if (cpos) { wave_atomic_row<IT>(rs_eg, h * row_g, vg, vgt, gpos, 1.f); buf_flag_set(rs_et, h); }
             }
         }
         loss_local += (double)lsum;
@@ -1077,7 +1096,8 @@ __global__ __launch_bounds__(256) void apply_normal_rows(int64_t n_rel, int ld, 
 
 // ---- kernel 2: optimiser on touched rows (relation rows first, then entity rows) -------------------
 // pull the summed gradient of one row back through the normalisation, apply Adagrad / SGD, clear the scratch row
-template <int G, int IT>
+// CLEAR = false: the gradient did not come from the scratch row (apply_rows_plan): nothing to zero
+template <int G, int IT, bool CLEAR = true>
 __device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__restrict__ acc, grad_t *__restrict__ g,
                                               flag_t *__restrict__ touched_flag, int ld, int lane, int on,
                                               const oea_step_cfg &cfg, const Row<G, IT> &rv, Row<G, IT> &rg,
@@ -1104,10 +1124,57 @@ __device__ __forceinline__ void apply_one_row(float *__restrict__ v, float *__re
             } else {
                 v[c] = rv.v[it] - cfg.lr * gv;
             }
-            g[c] = 0;
+            if (CLEAR) g[c] = 0;
         }
     }
-    if (lane == 0) *touched_flag = 0;
+    if (CLEAR && lane == 0) *touched_flag = 0;
+}
+
+// one relation row: fetched together with its flag (most relations of a batch are touched); sums (fixed order) and clears the
+// scratch copies
+template <int G, int IT>
+__device__ __forceinline__ void apply_relation_row(int64_t row, float *__restrict__ rel, float *__restrict__ rel_acc, int ld, int lane,
+                                                   const oea_step_cfg &cfg, const StepWs &ws, int copies_folded) {
+    float *v = rel + row * ld;
+    float *acc = rel_acc + row * ld;
+    grad_t *g = ws.rel_grad + row * ld;
+    const float flag = (float)ws.rel_touched[row];
+    Row<G, IT> rv, rg, ra;
+    grad_t q[IT];                       // raw scratch elements: the copies are summed exactly in the fixed-point build
+    load_row<G, IT>(v, ld, lane, rv);
+    load_grad_raw<G, IT>(g, ld, lane, q);
+    if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
+    if (flag == 0.f) return;
+    if (!copies_folded) {               // sum (fixed order) and clear the other copies
+        // copies fetched together (all loads issued before use).  The fixed-point build keeps this loop rolled: unrolled, its
+        // int64 elements (two registers each) took the kernel from 120 to 172 VGPRs = from 4 to 2 waves per SIMD, and the
+        // latency-bound 15K shape paid double (11.3 -> 23.7 us, gpurun_out r04a)
+        constexpr int CB = IT <= 4 ? 5 : 1;
+#ifdef OEA_DET_SCRATCH
+#pragma unroll 1
+#endif
+        for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
+            grad_t tmp[CB][IT];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int c = it * G + lane;
+                    tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? ws.rel_copy(cp0 + u)[row * ld + c] : (grad_t)0;
+                }
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int c = it * G + lane;
+                    q[it] += tmp[u][it];
+                    if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0) ws.rel_copy(cp0 + u)[row * ld + c] = 0;
+                }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) rg.v[it] = oea::grad_val(q[it]);
+    apply_one_row<G, IT>(v, acc, g, ws.rel_touched + row, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
 }
 
 // Work item w of the grid: w < n_rel -> relation row w (sums its 16 scratch copies); else R consecutive entity rows.
@@ -1151,48 +1218,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
             }
             continue;
         }
-        // ---- one relation row: fetched together with the flag (most rows of a batch are touched) ------------------
-        const int64_t row = w;
-        float *v = rel + row * ld;
-        float *acc = rel_acc + row * ld;
-        grad_t *g = ws.rel_grad + row * ld;
-        const float flag = (float)ws.rel_touched[row];
-        Row<G, IT> rv, rg, ra;
-        grad_t q[IT];                       // raw scratch elements: the copies are summed exactly in the fixed-point build
-        load_row<G, IT>(v, ld, lane, rv);
-        load_grad_raw<G, IT>(g, ld, lane, q);
-        if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(acc, ld, lane, ra);
-        if (flag == 0.f) continue;
-        if (!copies_folded) {               // sum (fixed order) and clear the other copies
-            // copies fetched together (all loads issued before use).  The fixed-point build keeps this loop rolled: unrolled, its
-            // int64 elements (two registers each) took the kernel from 120 to 172 VGPRs = from 4 to 2 waves per SIMD, and the
-            // latency-bound 15K shape paid double (11.3 -> 23.7 us, gpurun_out r04a)
-            constexpr int CB = IT <= 4 ? 5 : 1;
-#ifdef OEA_DET_SCRATCH
-#pragma unroll 1
-#endif
-            for (int cp0 = 1; cp0 < kRelCopies; cp0 += CB) {
-                grad_t tmp[CB][IT];
-#pragma unroll
-                for (int u = 0; u < CB; ++u)
-#pragma unroll
-                    for (int it = 0; it < IT; ++it) {
-                        const int c = it * G + lane;
-                        tmp[u][it] = (cp0 + u < kRelCopies && c < ld) ? ws.rel_copy(cp0 + u)[row * ld + c] : (grad_t)0;
-                    }
-#pragma unroll
-                for (int u = 0; u < CB; ++u)
-#pragma unroll
-                    for (int it = 0; it < IT; ++it) {
-                        const int c = it * G + lane;
-                        q[it] += tmp[u][it];
-                        if (cp0 + u < kRelCopies && c < ld && tmp[u][it] != 0) ws.rel_copy(cp0 + u)[row * ld + c] = 0;
-                    }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) rg.v[it] = oea::grad_val(q[it]);
-        apply_one_row<G, IT>(v, acc, g, ws.rel_touched + row, ld, lane, cfg.rel_l2_norm, cfg, rv, rg, ra);
+        apply_relation_row<G, IT>(w, rel, rel_acc, ld, lane, cfg, ws, copies_folded);
     }
     // fixed-order reduction of the loss partials by one wave of block 0
     if (blockIdx.x == 0 && threadIdx.x < 64) {
@@ -1200,6 +1226,124 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
         for (int i = threadIdx.x; i < n_partials; i += 64) s += ws.partials[i];
         s = oea::wave_sum_d(s);
         if (threadIdx.x == 0) *loss_accum += s;
+    }
+}
+
+// ---- kernel 2', round 6: the optimiser of a PLANNED step (step_plan.h), one launch, four kinds of blocks ----------------------------------
+//   [0, rel_blocks)        relation rows, one lane group per row as in apply_rows (16 scratch copies summed in order);
+//   [.., + plan_blocks)    one lane group per DISTINCT entity row the step's positives refer to as head or tail and that is no hub:
+//                          gradient = the sum of its plan entries (sign, slot) over contrib[slot] in the plan's order -- the batch
+//                          order, whatever the hardware does -- plus the row of the atomic scratch where its touched flag is up (an
+//                          active negative corrupted INTO this row).  Chain of dependent loads: step_first -> record -> rows;
+//   [.., + scan_blocks)    what the plan does not list: entity rows whose touched flag is up (corrupted rows of active negatives, hub
+//                          rows, rows of positives outside the rule: a few thousand of 200,000).  A wave reads 64 flags with one
+//                          load and its groups take the flagged rows of the ballot; chunk c = rows {c, c + n_chunk, ...}: entity ids
+//                          are degree-ordered (read.py:64-79), 64 CONSECUTIVE rows at the head of the table are all hubs and one
+//                          wave would work through them alone.  Rows the plan sums are left to their group (membership map);
+//   last block             the loss partials, 256 lanes + a fixed tree (one wave walking 2,500 partials took 18 us).
+// Same update everywhere: gradient back through the normalisation, Adagrad / SGD (apply_one_row).
+template <int G, int IT>
+__global__ __launch_bounds__(256) void apply_step_plan(float *__restrict__ ent, float *__restrict__ ent_acc, int64_t n_ent,
+                                                       float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel, int ld,
+                                                       oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum,
+                                                       int copies_folded, int rel_blocks, int plan_blocks,
+                                                       const uint4 *__restrict__ recs, const uint32_t *__restrict__ vals,
+                                                       const int32_t *__restrict__ step_first, int s, const uint8_t *__restrict__ inplan,
+                                                       const float *__restrict__ contrib) {
+    constexpr int GPB = 256 / G, GPW = 64 / G;
+    const int lane = threadIdx.x % G;
+    const int b = (int)blockIdx.x, nb = (int)gridDim.x;
+    if (b < rel_blocks) {
+        for (int64_t row = (int64_t)b * GPB + threadIdx.x / G; row < n_rel; row += (int64_t)rel_blocks * GPB)
+            apply_relation_row<G, IT>(row, rel, rel_acc, ld, lane, cfg, ws, copies_folded);
+    } else if (b < rel_blocks + plan_blocks) {
+        const int64_t grp = (int64_t)(b - rel_blocks) * GPB + threadIdx.x / G, ngrp = (int64_t)plan_blocks * GPB;
+        const int64_t i1 = step_first[s + 1];
+        for (int64_t i = step_first[s] + grp; i < i1; i += ngrp) {
+            const uint4 rec = recs[i];                                 // {row, first entry, entries, first entry's value}
+            if (rec.z > oea::kPlanHubEntries) continue;                // a hub of this step: its gradient went through the atomic scratch
+            const int64_t row = rec.x;
+            const uint32_t e0 = rec.y, e1 = rec.y + rec.z, v0 = rec.w;
+            const float flag = (float)ws.ent_touched[row];
+            Row<G, IT> rv, ra, rg, rc;
+            load_row<G, IT>(ent + row * ld, ld, lane, rv);
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(ent_acc + row * ld, ld, lane, ra);
+            load_row<G, IT>(contrib + (int64_t)(v0 & 0x7fffffffu) * ld, ld, lane, rc);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) rg.v[it] = (v0 >> 31) ? -rc.v[it] : rc.v[it];
+            for (uint32_t e = e0 + 1; e < e1; e += 3) {                // further references to the row, in batch order, three in flight
+                uint32_t ve[3];
+                Row<G, IT> r3[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) ve[u] = vals[min(e + u, e1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) load_row<G, IT>(contrib + (int64_t)(ve[u] & 0x7fffffffu) * ld, ld, lane, r3[u]);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (e + u < e1) {
+#pragma unroll
+                        for (int it = 0; it < IT; ++it) rg.v[it] += (ve[u] >> 31) ? -r3[u].v[it] : r3[u].v[it];
+                    }
+            }
+            if (flag != 0.f) {                                         // + what the atomic scratch holds for this row
+                grad_t *g = ws.ent_grad + row * ld;
+                Row<G, IT> rs;
+                load_grad_row<G, IT>(g, ld, lane, rs);
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    rg.v[it] += rs.v[it];
+                    const int c = it * G + lane;
+                    if (c < ld) g[c] = 0;
+                }
+                if (lane == 0) ws.ent_touched[row] = 0;
+            }
+            apply_one_row<G, IT, false>(ent + row * ld, ent_acc + row * ld, nullptr, nullptr, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
+        }
+    } else if (b < nb - 1) {
+        const int first = rel_blocks + plan_blocks;
+        const int wl = threadIdx.x & 63, gw = wl / G;
+        const int64_t wave = (int64_t)(b - first) * 4 + (threadIdx.x >> 6), nwave = (int64_t)(nb - 1 - first) * 4;
+        const int64_t n_chunk = (n_ent + 63) / 64;
+        const uint8_t *mine = inplan + (int64_t)s * n_ent;
+        for (int64_t chunk = wave; chunk < n_chunk; chunk += nwave) {
+            const int64_t r = (int64_t)wl * n_chunk + chunk;
+            const bool todo = r < n_ent && (float)ws.ent_touched[r] != 0.f && mine[r] == 0;
+            unsigned long long mask = __ballot(todo);
+            while (mask) {
+                int64_t row = -1;
+#pragma unroll
+                for (int q = 0; q < GPW; ++q)
+                    if (mask) {
+                        const int bit = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        if (gw == q) row = (int64_t)bit * n_chunk + chunk;
+                    }
+                if (row >= 0) {
+                    Row<G, IT> rv, rg, ra;
+                    load_row<G, IT>(ent + row * ld, ld, lane, rv);
+                    load_grad_row<G, IT>(ws.ent_grad + row * ld, ld, lane, rg);
+                    if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row<G, IT>(ent_acc + row * ld, ld, lane, ra);
+                    apply_one_row<G, IT>(ent + row * ld, ent_acc + row * ld, ws.ent_grad + row * ld, ws.ent_touched + row, ld, lane,
+                                         cfg.ent_l2_norm, cfg, rv, rg, ra);
+                }
+            }
+        }
+    } else {
+        // the loss partials of the scoring kernel: every lane a strided share (all loads in flight), then a fixed tree
+        __shared__ double sp[256];
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = u * 256 + (int)threadIdx.x; v[u] = i < n_partials ? ws.partials[i] : 0.0; }
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+        sp[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sp[threadIdx.x] += sp[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *loss_accum += sp[0];
     }
 }
 
@@ -1677,18 +1821,31 @@ static bool step_wave_enabled() {
 
 template <int IT64>
 void launch_wave(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
-                 int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws) {
+                 int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws, float *contrib = nullptr,
+                 const uint32_t *pflags = nullptr) {
     const int k = cfg.neg_group_k;
     static const int dbg = [] { const char *e = getenv("OEA_STEP_WAVE_DBG"); return e ? atoi(e) : 0; }();
-#define OEA_WAVE(L1, KT) oea::launch_timed(triple_wave<IT64, L1, KT>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, dbg)
+#define OEA_WAVE(L1, KT)                                                                                                               \
+    do {                                                                                                                               \
+        if (contrib) oea::launch_timed(triple_wave<IT64, L1, KT, true>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, dbg, contrib, pflags);   \
+        else oea::launch_timed(triple_wave<IT64, L1, KT, false>, nb, block, st, ent, rel, ld, pos, n_pos, neg, k, cfg, ws, dbg, contrib, pflags);          \
+    } while (0)
     if (k == 10) { if (cfg.l1) OEA_WAVE(1, 10); else OEA_WAVE(0, 10); }
     else { if (cfg.l1) OEA_WAVE(1, 0); else OEA_WAVE(0, 0); }
 #undef OEA_WAVE
 }
 
+// the rule of triple_wave (and of the epoch plan that builds on it)
+static bool wave_rule(const oea_step_cfg &cfg, int64_t n_ent, int64_t n_rel, int32_t ld) {
+    return cfg.score_kind == OEA_SCORE_TRANSE && cfg.loss_kind == OEA_LOSS_LIMITED && cfg.ent_l2_norm && cfg.rel_l2_norm &&
+           cfg.neg_group_k >= 1 && cfg.neg_group_k <= 10 && ld <= 256 &&
+           std::max(n_ent, n_rel) * (int64_t)ld * (int64_t)sizeof(grad_t) < ((int64_t)1 << 30) && step_wave_enabled();
+}
+
 template <int G, int IT>
 void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const float *rel, int ld, const int32_t *pos,
-                    int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws, bool wave_fits) {
+                    int64_t n_pos, const int32_t *neg, const oea_step_cfg &cfg, const StepWs &ws, bool wave_fits, float *contrib = nullptr,
+                    const uint32_t *pflags = nullptr) {
     static const int runtime_kind = [] { const char *e = getenv("OEA_STEP_RUNTIME_KIND"); return e ? atoi(e) : 0; }();
     const int k = cfg.neg_group_k;
     // one wave per positive (round 6): the per-triple losses with a compile-time kind, rows of at most 256 columns, tables whose
@@ -1698,7 +1855,7 @@ void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const f
         if (wave_fits && !runtime_kind && cfg.loss_kind == OEA_LOSS_LIMITED && cfg.ent_l2_norm && cfg.rel_l2_norm && k >= 0 && k <= 10 &&
             step_wave_enabled()) {
             constexpr int IT64 = G == 32 ? (IT + 1) / 2 : 4;
-            launch_wave<IT64>(nb, (block / G) * 64, st, ent, rel, ld, pos, n_pos, neg, cfg, ws);
+            launch_wave<IT64>(nb, (block / G) * 64, st, ent, rel, ld, pos, n_pos, neg, cfg, ws, contrib, pflags);
             return;
         }
     }
@@ -1733,7 +1890,8 @@ static int64_t step_items(const oea_step_cfg &cfg, int64_t n_pos, int64_t n_neg)
 template <int G, int IT>
 int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                 int32_t ld, const int32_t *pos, int64_t n_pos, const int32_t *neg, int64_t n_neg,
-                const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st) {
+                const oea_step_cfg &cfg, const StepWs &ws, double *loss_accum, int phase, hipStream_t st,
+                const oea::StepPlanView *plan = nullptr, int plan_step = 0, int64_t plan_first_pos = 0) {
     const int block = 256, gpb = block / G;
     const bool transh = cfg.score_kind == OEA_SCORE_TRANSH, transd = cfg.score_kind == OEA_SCORE_TRANSD;
     const bool dense_opt = cfg.opt_kind == OEA_OPT_ADAM || cfg.opt_kind == OEA_OPT_ADADELTA;
@@ -1757,7 +1915,8 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             oea::launch_timed(triple_transh_grouped<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg ? cfg.neg_group_k : 0, cfg, ws);
         else if (grouped)
             launch_grouped<G, IT>(nb1, block, st, ent, rel, ld, pos, n_pos, neg, cfg, ws,
-                                  std::max(n_ent, n_rel) * (int64_t)ld * (int64_t)sizeof(grad_t) < ((int64_t)1 << 30));
+                                  std::max(n_ent, n_rel) * (int64_t)ld * (int64_t)sizeof(grad_t) < ((int64_t)1 << 30),
+                                  plan ? plan->contrib : nullptr, plan ? plan->pflags + plan_first_pos : nullptr);
         else
             oea::launch_timed(triple_generic<G, IT>, nb1, block, st, ent, rel, ld, pos, n_pos, neg, n_neg, cfg, ws);
         if (phase == OEA_PHASE_GRAD || dense_opt)
@@ -1766,13 +1925,16 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
     }
     const int nb2 = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent + n_rel, gpb), 1), 16384);
     if (phase != OEA_PHASE_GRAD) {
+        // the APPLY phase's event pair: start on its first launch, stop on its last (the plan path has two)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        (void)oea::prof_pair(&ev0, &ev1);
         if (dense_opt) {
             // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (AdamOptimizer._apply_dense)
             const double t = (double)cfg.opt_t;
             const float lr_t = cfg.opt_kind == OEA_OPT_ADAM
                                    ? (float)((double)cfg.lr * std::sqrt(1.0 - std::pow((double)cfg.beta2, t)) / (1.0 - std::pow((double)cfg.beta1, t)))
                                    : cfg.lr;
-            oea::launch_timed(apply_rows_dense<G, IT>, nb2, block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
+            oea::launch_events(apply_rows_dense<G, IT>, nb2, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws,
                               items > 0 ? nb1 : 0, loss_accum, lr_t);
         } else {
             // rows per lane group: 1.  Measured at the 15K shape (gpurun_out r02a, in-epoch HIP events): R = 1 17.4 us,
@@ -1785,17 +1947,44 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
             // OEA_APPLY_FLAG_FIRST=1: look at the touched flag before fetching the three rows.  Measured (gpurun_out r02d):
             // 15K shape 11.1 -> 12.8 us, 100K shape 64.0 -> 72.5 us -- a batch touches most of the table at both shapes
             // and the dependent round trip costs more than the rows it saves; off by default.
-            static const int flag_first = [] { const char *e = getenv("OEA_APPLY_FLAG_FIRST"); return e ? atoi(e) : 0; }();
+            static const int flag_first_env = [] { const char *e = getenv("OEA_APPLY_FLAG_FIRST"); return e ? atoi(e) : 0; }();
+            const int flag_first = plan ? 1 : flag_first_env;     // behind the plan pass few entity rows are left: look at the flag first
             auto nb = [&](int r) { return (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + oea::ceil_div(n_ent, r), gpb), 1), 16384); };
             // 16-lane groups (4 rows per wave, ceil(ld / 16) fragments per lane) when the tables do not fit the caches: the
             // kernel is then bound by HBM and the narrower groups waste fewer lanes on the row's tail -- 100K shape 64.5 ->
             // 54.9 us (step 0.139 -> 0.125 ms); at the 15K shape (latency-bound, cache-resident) they LOSE, 11.0 -> 16.3 us
             // (gpurun_out r02p).  OEA_APPLY_G16 = 0 / 1 overrides the size rule.
             const bool g16 = apply_g16(n_ent, n_rel, ld);
+            if (plan) {
+                // ONE launch: relation rows | the plan's rows (gathered sums) | flagged rows the plan does not list | loss partials
+                static_assert(kMaxBlocks <= 16 * 256, "the partials block reads 16 per lane");
+                const int64_t bound = 2 * n_pos;                       // at most two distinct rows per positive
+                if (g16 && G == 32) {
+                    const int it16 = (ld + 15) / 16;
+                    const int relb = (int)std::max<int64_t>(oea::ceil_div(n_rel, 16), 1);
+                    const int planb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(bound, 16), 1), 8192);
+                    const int scanb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent, 256), 1), 4096);
+#define OEA_APPLYP16(ITX) oea::launch_events(apply_step_plan<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, planb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib)
+                    if (it16 <= 2) OEA_APPLYP16(2);
+                    else if (it16 <= 4) OEA_APPLYP16(4);
+                    else if (it16 == 5) OEA_APPLYP16(5);
+                    else if (it16 == 6) OEA_APPLYP16(6);
+                    else if (it16 == 7) OEA_APPLYP16(7);
+                    else OEA_APPLYP16(8);
+#undef OEA_APPLYP16
+                } else {
+                    const int relb = (int)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1);
+                    const int planb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(bound, gpb), 1), 8192);
+                    const int scanb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent, 256), 1), 4096);
+                    oea::launch_events(apply_step_plan<G, IT>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc,
+                                       n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, planb, plan->recs, plan->vals_b,
+                                       plan->step_first, plan_step, plan->inplan, plan->contrib);
+                }
+            } else
             if (g16 && G == 32 && R == 1) {
                 const int it16 = (ld + 15) / 16;
                 const int nbg = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_rel + n_ent, 16), 1), 16384);
-#define OEA_APPLY16(ITX) oea::launch_timed(apply_rows<16, ITX, 1>, nbg, block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first)
+#define OEA_APPLY16(ITX) oea::launch_events(apply_rows<16, ITX, 1>, nbg, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first)
                 if (it16 <= 2) OEA_APPLY16(2);
                 else if (it16 <= 4) OEA_APPLY16(4);
                 else if (it16 == 5) OEA_APPLY16(5);
@@ -1805,11 +1994,11 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
 #undef OEA_APPLY16
             } else
             if (R >= 4 && IT <= 4)
-                oea::launch_timed(apply_rows<G, IT, 4>, nb(4), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
+                oea::launch_events(apply_rows<G, IT, 4>, nb(4), block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
             else if (R >= 2 && IT <= 8)
-                oea::launch_timed(apply_rows<G, IT, 2>, nb(2), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
+                oea::launch_events(apply_rows<G, IT, 2>, nb(2), block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
             else
-                oea::launch_timed(apply_rows<G, IT, 1>, nb(1), block, st, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
+                oea::launch_events(apply_rows<G, IT, 1>, nb(1), block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, flag_first);
         }
         if (transh)
             apply_normal_rows<G, IT><<<(unsigned)std::max<int64_t>(oea::ceil_div(n_rel, gpb), 1), block, 0, st>>>(
@@ -1842,10 +2031,25 @@ int oea_triple_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float
                                  workspace, loss_accum, OEA_PHASE_BOTH, stream);
 }
 
+static int step_phase_impl(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
+                           int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
+                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
+                           double *loss_accum, int32_t phase, void *stream, const oea::StepPlanView *plan, int plan_step,
+                           int64_t plan_first_pos);
+
 int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
                           int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
                           double *loss_accum, int32_t phase, void *stream) {
+    return step_phase_impl(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n_pos, neg, n_neg, cfg, workspace, loss_accum, phase,
+                           stream, nullptr, 0, 0);
+}
+
+static int step_phase_impl(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc,
+                           int64_t n_rel, int32_t dim, int32_t ld, const int32_t *pos, int64_t n_pos,
+                           const int32_t *neg, int64_t n_neg, const oea_step_cfg *cfg, void *workspace,
+                           double *loss_accum, int32_t phase, void *stream, const oea::StepPlanView *plan, int plan_step,
+                           int64_t plan_first_pos) {
     OEA_REQUIRE(phase >= OEA_PHASE_BOTH && phase <= OEA_PHASE_APPLY, "phase");
     OEA_REQUIRE(ent && rel && (pos || n_pos == 0) && cfg && workspace && loss_accum, "null pointer");
     OEA_REQUIRE(ld % 4 == 0 && dim <= ld && dim > 0, "ld % 4 == 0 and dim <= ld");
@@ -1875,7 +2079,7 @@ int oea_triple_step_phase(float *ent, float *ent_acc, int64_t n_ent, float *rel,
     StepWs ws;
     ws_layout(n_ent, n_rel, ld, workspace, &ws);
     hipStream_t st = oea::as_stream(stream);
-#define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, phase, st)
+#define OEA_STEP(G, IT) launch_step<G, IT>(ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, pos, n_pos, neg, n_neg, *cfg, ws, loss_accum, phase, st, plan, plan_step, plan_first_pos)
     // Measured and dropped (round 4, gpurun_out r04f): 64-lane groups for 64 < ld <= 128 (one positive per wave, two fragments
     // per lane): scoring kernel 17.8 -> 20.0 us at the 15K shape, 64.2 -> 60.4 us at the 100K shape, where the 64-lane optimiser
     // kernel loses 18 us against the 16-lane one -- 3 % at best for a second instantiation of every kernel.
@@ -2050,6 +2254,14 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
                                         workspace, loss_accum, offsets_dev, splits_dev, 0, 1, stream);
 }
 
+static int epoch_range_impl(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                            int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                            const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                            const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                            uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                            int32_t rank, int32_t world, void *plan, size_t plan_bytes, int32_t plan_built, void *stream);
+
 int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
                                  int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
                                  const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
@@ -2057,6 +2269,41 @@ int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, floa
                                  uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
                                  void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                                  int32_t rank, int32_t world, void *stream) {
+    return epoch_range_impl(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos_all, offsets_host, splits_host, steps, step_begin,
+                            step_end, k, side0, side1, seed, step_base, neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev,
+                            splits_dev, rank, world, nullptr, 0, 0, stream);
+}
+
+// 1 when an epoch of this configuration would run on the gathered-sum plan (step_plan.h): triple_wave's rule, SGD / Adagrad, the
+// fp32 scratch (the fixed-point build keeps ONE summation path for one GPU and for G ranks), OEA_STEP_PLAN != 0
+int32_t oea_step_plan_supported(const oea_step_cfg *cfg, int64_t n_ent, int64_t n_rel, int32_t ld, int32_t k) {
+    static const int env = [] { const char *e = getenv("OEA_STEP_PLAN"); return e ? atoi(e) : 1; }();
+    if (!cfg || env == 0 || oea::kDetScratch) return 0;
+    // tables that fit the caches (the 15K shape: 9 MB) keep the flag-driven optimiser: its streaming pass over the whole table
+    // costs 11 us there and the plan's chains of dependent loads 20 (measured, tools/r06/d.sh); OEA_STEP_PLAN=2 forces the plan
+    if (env != 2 && !apply_g16(n_ent, n_rel, ld)) return 0;
+    return wave_rule(*cfg, n_ent, n_rel, ld) && cfg->neg_group_k == k && (cfg->opt_kind == OEA_OPT_SGD || cfg->opt_kind == OEA_OPT_ADAGRAD);
+}
+
+int oea_triple_epoch_range_plan(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                                int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                                const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                                const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                                uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                                void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                                void *plan, size_t plan_bytes, int32_t plan_built, void *stream) {
+    return epoch_range_impl(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos_all, offsets_host, splits_host, steps, step_begin,
+                            step_end, k, side0, side1, seed, step_base, neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev,
+                            splits_dev, 0, 1, plan, plan_bytes, plan_built, stream);
+}
+
+static int epoch_range_impl(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *rel_acc, int64_t n_rel,
+                            int32_t dim, int32_t ld, const int32_t *pos_all, const int64_t *offsets_host,
+                            const int64_t *splits_host, int32_t steps, int32_t step_begin, int32_t step_end, int32_t k,
+                            const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
+                            uint32_t step_base, int32_t *neg_buf, int32_t *err_flag, const oea_step_cfg *cfg,
+                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
+                            int32_t rank, int32_t world, void *plan, size_t plan_bytes, int32_t plan_built, void *stream) {
     OEA_REQUIRE(pos_all && offsets_host && splits_host && cfg, "null pointer");
     OEA_REQUIRE(steps >= 0 && k >= 0, "steps, k >= 0");
     OEA_REQUIRE(0 <= step_begin && step_begin <= step_end && step_end <= steps, "0 <= step_begin <= step_end <= steps");
@@ -2077,6 +2324,20 @@ int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, floa
                                                   side1, seed, step_base, 10, neg_buf, err_flag, stream);
         if (rc != OEA_OK) return rc;
     }
+    // the gathered-sum plan (step_plan.h): needs the whole epoch's negatives to exist before its first step
+    oea::StepPlanView pv;
+    const bool use_plan = plan && world == 1 && ahead && (presampled || sample_all) && oea_step_plan_supported(cfg, n_ent, n_rel, ld, k);
+    if (use_plan) {
+        int64_t max_batch = 0;
+        for (int32_t s = 0; s < steps; ++s) max_batch = std::max(max_batch, offsets_host[s + 1] - offsets_host[s]);
+        const size_t need = oea::step_plan_layout(offsets_host[steps], steps, max_batch, n_ent, ld, plan, &pv);
+        OEA_REQUIRE(plan_bytes >= need, "plan workspace smaller than oea_step_plan_bytes");
+        if (!plan_built) {
+            const int rc = oea_step_plan_build(pos_all, neg_buf, k, offsets_dev, offsets_host[steps], steps, max_batch, n_ent, ld, plan,
+                                               plan_bytes, stream);
+            if (rc != OEA_OK) return rc;
+        }
+    }
     oea_step_cfg step_cfg = *cfg;             // Adam: opt_t counts the steps actually run (cfg->opt_t = count of the first)
     for (int32_t s = step_begin; s < step_end; ++s) {
         const int64_t b0 = offsets_host[s], nb = offsets_host[s + 1] - b0;
@@ -2094,9 +2355,9 @@ int oea_triple_epoch_range_shard(float *ent, float *ent_acc, int64_t n_ent, floa
             if (rc != OEA_OK) return rc;
         }
         if (n > 0) {
-            const int rc = oea_triple_step_phase(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
-                                                 k > 0 ? negs : nullptr, n * (int64_t)k, &step_cfg, workspace, loss_accum,
-                                                 OEA_PHASE_BOTH, stream);
+            const int rc = step_phase_impl(ent, ent_acc, n_ent, rel, rel_acc, n_rel, dim, ld, pos, n,
+                                           k > 0 ? negs : nullptr, n * (int64_t)k, &step_cfg, workspace, loss_accum,
+                                           OEA_PHASE_BOTH, stream, use_plan ? &pv : nullptr, s, lo);
             if (rc != OEA_OK) return rc;
         }
         ++step_cfg.opt_t;

@@ -12,6 +12,8 @@ its own slice of every batch, the gradient scratch is summed with ONE all-reduce
 every rank applies the identical optimiser update (include/openea_hip.h: OEA_PHASE_*), which
 equals the single-GPU step on the concatenated batch.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -387,6 +389,9 @@ class RelationTripleEpochs:
         self.global_step = 0
         self._epoch_base = 0                  # global_step at the start of the current epoch (Philox step of its step 0)
         self._epoch_negs_ready = False        # _neg_all holds the current epoch's negatives
+        self._plan = self._plan_next = None   # gathered-sum plans of the current / the prepared epoch (ops.step_plan_build)
+        self._plan_ready = False              # _plan was built from the current epoch's positives and negatives
+        self._plan_key = None                 # (n_ent, ld) of the tables the plans were sized for
         b = self.batches
         self.neg_buf = torch.empty(((b.b1 + b.b2) * max(self.k, 1), 3), dtype=torch.int32, device=self.dev)
         self.err = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -397,6 +402,7 @@ class RelationTripleEpochs:
         self.s2.set_neighbours(nbr2)
         self._sides = None
         self._epoch_negs_ready = False        # negatives drawn ahead with the old lists are not used any further
+        self._plan_ready = False              # ... nor the plan sorted from them
 
     def batch(self, step):
         """-> (pos [n,3], neg [n*k,3]) device tensors for step `step` of the current epoch.
@@ -492,6 +498,11 @@ class RelationTripleEpochs:
                                       trainer.ws, trainer.loss, self._off_dev if self.k else None,
                                       self._spl_dev if self.k else None, trainer.part, step_range=(lo, hi))
             else:
+                plan = None
+                if self.world == 1 and not local and self.k and self._plan_wanted(trainer):
+                    # the epoch's gathered-sum plan (include/openea_hip.h): sorted on the side stream with the negatives it is
+                    # built from (_prefetch_next), or by the call itself when it draws them (first epoch, after a refresh)
+                    plan = (self._plan, self._plan_ready and bool(have))
                 ops.triple_epoch(trainer.ent.var, trainer.ent_acc, trainer.rel.var, trainer.rel_acc, trainer.ent.dim,
                                  b.dall, b.offsets, b.splits, self.k,
                                  None if (have or not self.k) else self._sides[0],
@@ -499,7 +510,9 @@ class RelationTripleEpochs:
                                  self._neg_all if self.k else None, self.err if self.k else None, trainer.cfg,
                                  trainer.ws, trainer.loss, self._off_dev if self.k else None,
                                  self._spl_dev if self.k else None, step_range=(lo, hi),
-                                 shard=(self.rank, self.world) if local else (0, 1))
+                                 shard=(self.rank, self.world) if local else (0, 1), plan=plan)
+                if plan is not None and (have or lo == 0):
+                    self._plan_ready = True               # built by the call (or already there) for the rest of this epoch
             if lo == 0 and self.k:
                 self._epoch_negs_ready = True             # a range that starts the epoch draws all its negatives
             self.global_step += hi - lo
@@ -508,7 +521,7 @@ class RelationTripleEpochs:
                 nb = np.diff(b.offsets[lo:hi + 1])
                 n = int((nb * (self.rank + 1) // self.world - nb * self.rank // self.world).sum())
             if ev_start is not None:
-                self._prefetch_next(ev_start)             # next epoch's shuffle + negatives on the side stream
+                self._prefetch_next(ev_start, trainer)    # next epoch's shuffle + negatives (+ plan) on the side stream
             if hi == S:
                 self._epoch_base = self.global_step
                 if local:
@@ -538,7 +551,22 @@ class RelationTripleEpochs:
     # sampler reads the triple set and the neighbour lists, not the tables), so they are enqueued on a second HIP
     # stream into spare buffers right after epoch e's kernels; the next run_epoch swaps the buffers in.  A change of
     # the neighbour lists in between (truncated-sampling refresh) drops the prepared negatives.
-    def _prefetch_next(self, ev_start):
+    def _plan_wanted(self, trainer):
+        """does this trainer's epoch run on the gathered-sum plan?  Allocates the two plan workspaces on first use."""
+        ent, rel = trainer.ent, trainer.rel
+        if not ops.step_plan_supported(trainer.cfg, ent.rows, rel.rows, ent.ld, self.k):
+            return False
+        key = (ent.rows, ent.ld)
+        if self._plan is None or self._plan_key != key:
+            b = self.batches
+            mb = int(np.diff(b.offsets).max()) if len(b.splits) else 0
+            self._plan_dims = (int(b.offsets[-1]), len(b.splits), mb, ent.rows, ent.ld)
+            self._plan = ops.step_plan_buffer(*self._plan_dims, dev=self.dev)
+            self._plan_next = ops.step_plan_buffer(*self._plan_dims, dev=self.dev)
+            self._plan_key, self._plan_ready = key, False
+        return True
+
+    def _prefetch_next(self, ev_start, trainer=None):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
             self._neg_next = torch.empty_like(self._neg_all) if self.k else None
@@ -550,9 +578,16 @@ class RelationTripleEpochs:
             if self.k:
                 ops.sample_negatives_epoch(self.batches.dall_next, self._off_dev, self._spl_dev, len(self.batches.splits), self.k,
                                            self._sides[0], self._sides[1], self.seed, next_base, self._neg_next, self.err)
+            planned = False
+            if (self.k and trainer is not None and self.world == 1 and not getattr(trainer, "local_epochs", False)
+                    and getattr(trainer, "part", None) is None and self._plan_wanted(trainer)):
+                n_total, steps, mb, n_ent, ld = self._plan_dims
+                ops.step_plan_build(self.batches.dall_next, self._neg_next, self.k, self._off_dev, n_total, steps, mb, n_ent, ld,
+                                    self._plan_next)
+                planned = True
             self._prefetch_ev = torch.cuda.Event()
             self._prefetch_ev.record(side)
-        self._prefetch = (self._sides, next_base)
+        self._prefetch = (self._sides, next_base, planned)
 
     def _take_prefetch(self, main):
         """make the prepared epoch current; -> True when its negatives are usable as they are."""
@@ -565,12 +600,16 @@ class RelationTripleEpochs:
         ok = self.k > 0 and pf[0] is self._sides and pf[1] == self._epoch_base
         if ok:
             self._neg_all, self._neg_next = self._neg_next, self._neg_all
+        self._plan_ready = bool(ok and len(pf) > 2 and pf[2])
+        if self._plan_ready:
+            self._plan, self._plan_next = self._plan_next, self._plan
         return ok
 
     def end_epoch(self):
         """per-step path: the epoch's last batch() has been taken"""
         self._epoch_base = self.global_step
         self._epoch_negs_ready = False
+        self._plan_ready = False
         if getattr(self, "_prefetch", None) is not None:      # already shuffled into the spare buffer: make it current
             self._take_prefetch(torch.cuda.current_stream())
             return

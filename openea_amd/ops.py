@@ -342,13 +342,25 @@ def sample_negatives_epoch(pos_all, offsets_dev, splits_dev, steps, k, side0, si
 
 
 def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, side0, side1, seed, step_base,
-                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None, step_range=None, shard=(0, 1)):
+                 neg_buf, err_flag, cfg, workspace, loss_accum, offsets_dev=None, splits_dev=None, step_range=None, shard=(0, 1),
+                 plan=None):
     """Enqueue every step of an epoch (or steps [lo, hi) of it: step_range) with one call (offsets / splits: host int64
     numpy arrays; their device copies enable sampling the whole epoch ahead in one launch -- neg_buf then covers the
     epoch).  step_base: Philox step of the epoch's step 0.  shard = (rank, world): this rank's contiguous share of every
     batch, trained on the local tables (dp_exchange = 'epoch')."""
     steps = len(splits)
     lo, hi = (0, steps) if step_range is None else step_range
+    if plan is not None and tuple(shard) == (0, 1):
+        # the gathered-sum plan of the epoch (step_plan_buffer / step_plan_build; include/openea_hip.h): plan = (buffer, built)
+        check(lib().oea_triple_epoch_range_plan(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
+                                                ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
+                                                splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
+                                                C.byref(side0) if side0 is not None else None,
+                                                C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
+                                                _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
+                                                _p(offsets_dev), _p(splits_dev), _p(plan[0]), plan[0].numel(), int(bool(plan[1])),
+                                                _stream()))
+        return
     check(lib().oea_triple_epoch_range_shard(_p(ent), _p(ent_acc), ent.shape[0], _p(rel), _p(rel_acc), rel.shape[0], dim,
                                        ent.shape[1], _p(pos_all), offsets.ctypes.data_as(C.c_void_p),
                                        splits.ctypes.data_as(C.c_void_p), steps, int(lo), int(hi), int(k),
@@ -356,6 +368,51 @@ def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, s
                                        C.byref(side1) if side1 is not None else None, int(seed), int(step_base),
                                        _p(neg_buf), _p(err_flag), C.byref(cfg), _p(workspace), _p(loss_accum),
                                        _p(offsets_dev), _p(splits_dev), int(shard[0]), int(shard[1]), _stream()))
+
+
+def step_plan_supported(cfg, n_ent, n_rel, ld, k):
+    """would an epoch under cfg run on the gathered-sum plan (oea_step_plan_supported)?"""
+    return bool(lib().oea_step_plan_supported(C.byref(cfg), int(n_ent), int(n_rel), int(ld), int(k)))
+
+
+def step_plan_buffer(n_total, steps, max_batch, n_ent, ld, dev=None):
+    """workspace of one epoch's plan (oea_step_plan_bytes)"""
+    nbytes = lib().oea_step_plan_bytes(int(n_total), int(steps), int(max_batch), int(n_ent), int(ld))
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev or device())
+
+
+def step_plan_build(pos_all, neg_all, k, offsets_dev, n_total, steps, max_batch, n_ent, ld, plan):
+    """sort the epoch's (step, row) references on the current stream (oea_step_plan_build): no allocation, no host read"""
+    check(lib().oea_step_plan_build(_p(pos_all), _p(neg_all), int(k), _p(offsets_dev), int(n_total), int(steps), int(max_batch),
+                                    int(n_ent), int(ld), _p(plan), plan.numel(), _stream()))
+
+
+def step_plan_arrays(plan, n_total, steps, max_batch, n_ent, ld):
+    """host copies of a built plan (tests): dict(vals uint32 [2 n_total], ukeys uint64 [n_unique], uoff uint32 [n_unique + 1],
+    step_first int32 [steps + 1], row_bits, pflags uint32 [n_total])"""
+    off = (C.c_int64 * 9)()
+    check(lib().oea_step_plan_offsets(int(n_total), int(steps), int(max_batch), int(n_ent), int(ld), C.cast(off, C.c_void_p)))
+    raw = plan.cpu().numpy()
+    m = 2 * int(n_total)
+    nu = int(raw[off[3]: off[3] + 4].view(np.int32)[0])
+    return dict(vals=raw[off[0]: off[0] + 4 * m].view(np.uint32).copy(), ukeys=raw[off[1]: off[1] + 8 * nu].view(np.uint64).copy(),
+                uoff=raw[off[2]: off[2] + 4 * (nu + 1)].view(np.uint32).copy(),
+                step_first=raw[off[4]: off[4] + 4 * (steps + 1)].view(np.int32).copy(), row_bits=int(off[6]), n_unique=nu,
+                pflags=raw[off[8]: off[8] + 4 * int(n_total)].view(np.uint32).copy())
+
+
+def step_plan_stats(plan, n_total, steps, max_batch, n_ent, ld):
+    """what a built plan looks like (bench detail / experiments): positives outside the rule, references to hub rows, rows and
+    entries per step"""
+    a = step_plan_arrays(plan, n_total, steps, max_batch, n_ent, ld)
+    last = int(a["step_first"][steps])                       # distinct keys of real steps
+    cnt = np.diff(a["uoff"].astype(np.int64))[:last]
+    listed = int(a["uoff"][last])                            # references of positives inside the rule
+    hub = cnt > 8
+    return dict(positives=int(n_total), outside_rule=int(n_total - listed // 2), rows_per_step=float(last) / max(steps, 1),
+                refs_per_row_mean=float(cnt.mean()) if last else 0.0, refs_per_row_max=int(cnt.max()) if last else 0,
+                hub_rows_per_step=float(hub.sum()) / max(steps, 1), refs_to_hub_rows=int(cnt[hub].sum()),
+                refs_listed=listed)
 
 
 def comm_single_or_none():

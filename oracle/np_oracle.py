@@ -701,3 +701,45 @@ def halo_plan(pos_all, neg_all, k, offsets, n_ent, world):
                 lists[(s, r, o)] = mine
                 counts[s, r, o] = len(mine)
     return counts, lists
+
+
+def step_plan(pos_all, neg_all, k, offsets, n_ent, hub_entries=8):
+    """Gathered-sum plan of a translational epoch (no reference counterpart: it is the bookkeeping of the scatter-add TF performs on
+    the gradient of tf.nn.embedding_lookup, models/basic_model.py:89-98, done once per epoch; restated from
+    include/openea_hip.h:oea_step_plan_build, test infrastructure only).  A positive whose k negatives are all corruptions of it on
+    ONE side (batch.py:101-107: one Bernoulli per sampling round) refers to its head and tail row:
+        tail side (every negative keeps the head):  head += A_p,  tail -= B_p
+        head side (every negative keeps the tail):  head += B_p,  tail -= A_p
+    with slots A_p = 2 * (index inside the batch), B_p = A_p + 1; other positives are left to the atomic path.
+    -> dict(ukeys uint64 [(step << row_bits) | row, ascending], uoff, vals uint32 [sign << 31 | slot, batch order inside a key],
+            step_first int64 [steps + 1], row_bits, pflags uint32 [n])"""
+    pos_all = np.asarray(pos_all, np.int64)
+    neg = np.asarray(neg_all, np.int64).reshape(len(pos_all), k, 3) if k > 0 else np.zeros((len(pos_all), 0, 3), np.int64)
+    steps = len(offsets) - 1
+    row_bits = max(int(max(n_ent - 1, 1)).bit_length(), 1)
+    keys, vals = [], []
+    for s in range(steps):
+        for p in range(int(offsets[s]), int(offsets[s + 1])):
+            h, r, t = pos_all[p]
+            same_h, same_t, same_r = neg[p, :, 0] == h, neg[p, :, 2] == t, neg[p, :, 1] == r
+            corruption = same_r & (same_h | same_t)
+            if not corruption.all() or not (same_h.all() or same_t.all()):
+                continue
+            tails = bool(same_h.all())                       # (a positive whose negatives all equal it counts as tail side)
+            slot = 2 * (p - int(offsets[s]))
+            keys += [(s << row_bits) | int(h), (s << row_bits) | int(t)]
+            vals += [slot + (0 if tails else 1), (1 << 31) | (slot + (1 if tails else 0))]
+    keys, vals = np.asarray(keys, np.uint64), np.asarray(vals, np.uint32)
+    order = np.argsort(keys, kind="stable")
+    keys, vals = keys[order], vals[order]
+    ukeys, first = np.unique(keys, return_index=True)
+    uoff = np.concatenate([first, [len(keys)]]).astype(np.uint32)
+    step_first = np.searchsorted(ukeys, (np.arange(steps + 1, dtype=np.uint64) << np.uint64(row_bits)))
+    # hubs: a row with more than hub_entries references in one step takes its positives' gradient through the atomic scratch;
+    # pflags[p] bit 0 / 1 = positive p's head / tail reference is to such a row
+    pflags = np.zeros(len(pos_all), np.uint32)
+    for i in np.nonzero(np.diff(uoff.astype(np.int64)) > hub_entries)[0]:
+        s = int(ukeys[i]) >> row_bits
+        for v in vals[uoff[i]:uoff[i + 1]]:
+            pflags[int(offsets[s]) + ((int(v) & 0x7fffffff) >> 1)] |= 2 if (int(v) >> 31) else 1
+    return dict(ukeys=ukeys, uoff=uoff, vals=vals, step_first=step_first.astype(np.int64), row_bits=row_bits, pflags=pflags)

@@ -399,6 +399,51 @@ def test_triple_step_vs_oracle(ops, case, grouped):
         np.testing.assert_allclose(d_eacc.cpu().numpy()[:, :d], ent_acc, rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("d,k,l1", [(100, 10, False), (128, 3, False), (128, 10, False), (100, 3, False), (75, 7, True), (200, 10, False),
+                                    (64, 1, False), (37, 10, True), (256, 5, False)])
+def test_triple_step_one_sided_negatives_vs_oracle(ops, d, k, l1):
+    """The sampler's layout -- all k negatives of a positive corrupt the SAME side (one Bernoulli per round, batch.py:101-107) --
+    is what triple_wave's select-free loops take (the mixed-side batches of test_triple_step_vs_oracle go through its
+    independent-triple path): three Adagrad steps of the limited loss against the C oracle, per-row 1e-4, at every fragment
+    count (ld <= 64 / 128 / 256), k = 10 (compile-time) and k < 10 (run-time), both norms; a self-loop, a negative equal to its
+    positive and an entity that is head of forty positives ride along."""
+    from oracle import cport
+    from _tol import assert_rows_close
+    rng = np.random.RandomState(1000 * d + k)
+    n_ent, n_rel, n_pos = 900, 19, 1100
+    ent = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32) * 1.3
+    rel = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32) * 0.7
+    ent_acc, rel_acc = np.full_like(ent, 0.1), np.full_like(rel, 0.1)
+    pos = np.stack([rng.randint(0, n_ent, n_pos), rng.randint(0, n_rel, n_pos), rng.randint(0, n_ent, n_pos)], 1).astype(np.int32)
+    pos[11, 2] = pos[11, 0]
+    pos[100:140, 0] = 7
+    neg = np.repeat(pos, k, axis=0)
+    flip = np.repeat(rng.rand(n_pos) < 0.5, k)
+    neg[flip, 0] = rng.randint(0, n_ent, int(flip.sum()))
+    neg[~flip, 2] = rng.randint(0, n_ent, int((~flip).sum()))
+    neg[3 * k] = pos[3]
+    kw = dict(loss="limited", loss_norm="L1" if l1 else "L2", pos_margin=0.01 if not l1 else 0.5, neg_margin=2.0 if not l1 else 4.0,
+              balance=0.2, optimizer="Adagrad", lr=0.01)
+    ld = ops.pad4(d)
+    d_ent, d_rel = ops.to_table(ent), ops.to_table(rel)
+    d_eacc, d_racc = ops.to_table(ent_acc), ops.to_table(rel_acc)
+    d_eacc[:, d:] = 0.1
+    d_racc[:, d:] = 0.1
+    ws = ops.step_workspace(n_ent, n_rel, ld)
+    loss_acc = torch.zeros(1, dtype=torch.float64, device=d_ent.device)
+    cfg = ops.make_step_cfg(neg_group_k=k, **kw)
+    d_pos, d_neg = ops.to_ids(pos), ops.to_ids(neg)
+    loss_ref = 0.0
+    for _ in range(3):
+        ops.triple_step(d_ent, d_eacc, d_rel, d_racc, d, d_pos, d_neg, cfg, ws, loss_acc)
+        loss_ref += cport.triple_step(ent, ent_acc, rel, rel_acc, pos, neg, **kw)
+    torch.cuda.synchronize()
+    assert_rows_close(d_ent.cpu().numpy()[:, :d], ent, "entity table after 3 steps")
+    assert_rows_close(d_rel.cpu().numpy()[:, :d], rel, "relation table after 3 steps")
+    assert abs(loss_acc.item() - loss_ref) <= 1e-4 * abs(loss_ref) + 1e-6
+    assert not bool((ws[: ws.numel() - 8 * 4096] != 0).any().item())          # scratch + flags left clean
+
+
 def _unit(x):
     return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
 
@@ -1248,12 +1293,12 @@ np.savez(os.environ["OEA_OUT"], **out)
 
 
 def test_wave_per_positive_step_kernel_equals_the_grouped_kernel(tmp_path):
-    \"\"\"triple_wave (one wave per positive: scalar ids, buffer addressing, one accumulator for the two rows that receive the same
+    """triple_wave (one wave per positive: scalar ids, buffer addressing, one accumulator for the two rows that receive the same
     sum) against triple_grouped (OEA_STEP_WAVE=0: two positives per wave) in the fixed-point build, where the scatter-add has no
     order: three Adagrad steps on Zipf-headed batches (d = 100 / 75 / 128 / 200 with every positive's negatives on one side --
     the select-free loops; d = 37 with the L1 norm and a side per negative -- the independent-triple path; an entry that is no
     corruption of its positive; a negative equal to its positive).  The two kernels reduce a row over 64 / 32 lanes, so a score
-    differs in its last bit and the tables agree to 1e-6 of their norm, not bit for bit; run to run each kernel IS bit-stable.\"\"\"
+    differs in its last bit and the tables agree to 1e-6 of their norm, not bit for bit; run to run each kernel IS bit-stable."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1264,10 +1309,144 @@ def test_wave_per_positive_step_kernel_equals_the_grouped_kernel(tmp_path):
         p = subprocess.run([sys.executable, "-c", WAVE_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
         res[tag] = dict(np.load(out))
+    # the oracle on the same batches: which kernel is off, should the two disagree
+    from oracle import cport
+    worst = {}
+    for d, n_pos, k, sides in ((100, 6500, 10, "same"), (75, 5000, 10, "same"), (37, 4100, 7, "mixed"), (128, 3000, 3, "same"), (200, 2000, 10, "same")):
+        rng = np.random.RandomState(d)
+        n_ent, n_rel = 5000, 61
+        ent = (rng.standard_normal((n_ent, d)) / np.sqrt(d)).astype(np.float32) * 1.3
+        rel = (rng.standard_normal((n_rel, d)) / np.sqrt(d)).astype(np.float32) * 0.7
+        w = 1.0 / np.arange(1, n_ent + 1) ** 0.9
+        pos = np.stack([rng.choice(n_ent, n_pos, p=w / w.sum()), rng.randint(0, n_rel, n_pos), rng.randint(0, n_ent, n_pos)], 1).astype(np.int32)
+        neg = np.repeat(pos, k, 0)
+        flip = np.repeat(rng.rand(n_pos) < 0.5, k) if sides == "same" else rng.rand(len(neg)) < 0.5
+        neg[flip, 0] = rng.randint(0, n_ent, int(flip.sum()))
+        neg[~flip, 2] = rng.randint(0, n_ent, int((~flip).sum()))
+        neg[5] = (3, 1, 4)
+        neg[3 * k] = pos[3]
+        ea, ra = np.full_like(ent, 0.1), np.full_like(rel, 0.1)
+        for _ in range(3):
+            cport.triple_step(ent, ea, rel, ra, pos, neg, loss="limited", loss_norm="L2" if d != 37 else "L1", pos_margin=0.01, neg_margin=2.0,
+                              balance=0.2, optimizer="Adagrad", lr=0.01)
+        for tag in ("g", "w"):
+            dev = np.linalg.norm(res[tag]["e%d" % d][:, :d] - ent, axis=1)
+            worst[(tag, d)] = (float(dev.max()), int(dev.argmax()), int((dev > 1e-4).sum()))
+    bad = {kk: v for kk, v in worst.items() if v[0] > 2e-4}
+    assert not bad, "rows off the oracle by more than 2e-4 (kernel g = triple_grouped, w = triple_wave; max deviation, row, rows > 1e-4): %s" % bad
     for d in (100, 75, 37, 128, 200):
         for t in ("e", "r"):
             a, b = res["g"]["%s%d" % (t, d)], res["w"]["%s%d" % (t, d)]
-            assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(a), (t, d, np.linalg.norm(a - b) / np.linalg.norm(a))
+            assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(a), (t, d, np.linalg.norm(a - b) / np.linalg.norm(a), worst)
             assert np.array_equal(b, res["w2"]["%s%d" % (t, d)]), (t, d)          # fixed-point sums: the same bits run to run
         la, lb = float(res["g"]["l%d" % d]), float(res["w"]["l%d" % d])
+        assert abs(la - lb) <= 1e-6 * abs(la), d
+
+
+@pytest.mark.parametrize("k", [10, 3, 1])
+def test_step_plan_equals_the_oracle_restatement(ops, k):
+    """oea_step_plan_build (the (step, row)-sorted references of an epoch's positives: which entity row adds which positive's
+    gradient rows, with which sign, in batch order) against oracle/np_oracle.py:step_plan on an epoch of ragged batches (one of
+    them empty) whose negatives are mostly one-sided per positive -- the sampler's output -- with positives of mixed sides, a
+    foreign entry, a negative equal to its positive and self-loops in between."""
+    from oracle import np_oracle
+    rng = np.random.RandomState(40 + k)
+    n_ent, n_rel, ld = 3000, 17, 36
+    sizes = [700, 0, 1333, 64, 901]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offsets[-1])
+    pos = np.stack([rng.randint(0, n_ent, n), rng.randint(0, n_rel, n), rng.randint(0, n_ent, n)], 1).astype(np.int32)
+    pos[7, 2] = pos[7, 0]                                            # a self-loop: both references on one row
+    pos[800:840, 0] = 42                                             # a hub of step 2: 40 heads on one row (+ 30 tails on another)
+    pos[850:880, 2] = 77
+    neg = np.repeat(pos, k, 0)
+    side = np.repeat(rng.rand(n) < 0.5, k)
+    mixed = np.repeat(rng.rand(n) < 0.05, k)                         # rounds after a collision: a side per negative
+    side = np.where(mixed, rng.rand(n * k) < 0.5, side)
+    neg[side, 0] = rng.randint(0, n_ent, int(side.sum()))
+    neg[~side, 2] = rng.randint(0, n_ent, int((~side).sum()))
+    neg[5 * k] = (3, 1, 4)                                           # not a corruption of positive 5
+    neg[9 * k: 10 * k] = pos[9]                                      # negatives equal to their positive (max_try exhausted)
+    dev = ops.device()
+    d_pos, d_neg = ops.to_ids(pos), ops.to_ids(neg)
+    off_dev = torch.from_numpy(offsets).to(dev)
+    dims = (n, len(sizes), max(sizes), n_ent, ld)
+    plan = ops.step_plan_buffer(*dims, dev=dev)
+    ops.step_plan_build(d_pos, d_neg, k, off_dev, *dims, plan)
+    torch.cuda.synchronize()
+    got = ops.step_plan_arrays(plan, *dims)
+    ref = np_oracle.step_plan(pos, neg, k, offsets, n_ent)
+    assert got["row_bits"] == ref["row_bits"]
+    nu = len(ref["ukeys"])
+    sf = got["step_first"]
+    assert np.array_equal(sf, ref["step_first"])                      # (the last entry = number of keys of real steps)
+    assert np.array_equal(got["ukeys"][:nu], ref["ukeys"])
+    assert np.array_equal(got["uoff"][:nu + 1], ref["uoff"])
+    assert np.array_equal(got["vals"][:len(ref["vals"])], ref["vals"])
+    assert 0 < nu <= 2 * n and sf[1] == sf[2]                         # the empty batch owns no keys
+    assert np.array_equal(got["pflags"], ref["pflags"])
+    assert (ref["pflags"][800:840] & 1).sum() >= 38 and (ref["pflags"][850:880] & 2).sum() >= 28      # (mixed-side positives drop out)
+
+
+PLAN_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["OEA_ROOT"])
+from openea_amd import ops
+from openea_amd.models.trainer import EmbeddingTable, RelationTripleEpochs, TripleTrainer, refresh_neighbours
+from openea_amd.modules.base.initializers import truncated_normal_host
+from openea_amd.modules.load.synth import make_kgs
+dev = torch.device("cuda", 0)
+out = {}
+for d, k, B, norm in ((32, 10, 1500, "L2"), (75, 5, 2600, "L1"), (100, 10, 900, "L2")):
+    kgs = make_kgs("small", mode="swapping", seed=1)
+    rng = np.random.RandomState(d)
+    ent_h = truncated_normal_host(rng, (kgs.entities_num, d), 1.0 / np.sqrt(d))
+    ent, ent0 = EmbeddingTable(ent_h, True, "ent_embeds", dev), EmbeddingTable(ent_h.copy(), True, "ent_embeds_0", dev)
+    rel = EmbeddingTable(truncated_normal_host(rng, (kgs.relations_num, d), 1.0 / np.sqrt(d)), True, "rel_embeds", dev)
+    cfg = ops.make_step_cfg(loss="limited", loss_norm=norm, pos_margin=0.01, neg_margin=2.0, balance=0.2, optimizer="Adagrad", lr=0.01,
+                            neg_group_k=k)
+    tr = TripleTrainer(ent, rel, cfg, "Adagrad")
+    ep = RelationTripleEpochs(kgs, B, k, seed=11, dev=dev)
+    S = len(ep.batches.splits)
+    assert ops.step_plan_supported(cfg, ent.rows, rel.rows, ent.ld, k) == (os.environ["OEA_STEP_PLAN"] == "2")
+    n = ep.run_epoch(tr)                                   # epoch 1: negatives drawn and plan sorted inside the call
+    n += ep.run_steps(tr, S + 2)                           # epoch 2 (prepared on the side stream) and two steps of epoch 3
+    # (neighbour lists from the INITIAL table: lists from the trained one would turn last-bit differences of the two runs' fp32
+    #  sums into different neighbour sets, different negatives and tables 1e-4 apart -- measured, six runs of ONE build)
+    nbr = [refresh_neighbours(ent0, kg.entities_list, max(2, int(0.1 * kg.entities_num))) for kg in (kgs.kg1, kgs.kg2)]
+    ep.set_neighbours(*nbr)                                # truncated sampling: the prepared negatives and plans are dropped
+    n += ep.run_steps(tr, S - 2)                           # the rest of epoch 3: sampled step by step, no plan
+    n += ep.run_steps(tr, 2 * S)                           # epochs 4 and 5 on new negatives
+    ep.check()
+    torch.cuda.synchronize()
+    out["e%d" % d], out["r%d" % d], out["l%d" % d], out["n%d" % d] = ent.raw(), rel.raw(), tr.pop_loss(), n
+np.savez(os.environ["OEA_OUT"], **out)
+'''
+
+
+def test_planned_epochs_equal_the_atomic_epochs(tmp_path):
+    """Five epochs through the device epoch engine with the gathered-sum plan (the default: positives' own rows by plain stores +
+    an ordered gather in the optimiser) against OEA_STEP_PLAN=0 (every gradient row through the atomic scratch): whole epochs,
+    ranges that cross epoch boundaries (the plan of the next epoch is sorted on the side stream), a neighbour refresh in the
+    middle of an epoch (prepared negatives and plan dropped, the rest of that epoch sampled step by step).  The two differ in the
+    ORDER of fp32 additions only: tables within 2e-6 of their norm, loss within 1e-6."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for plan in ("2", "0"):                                  # 2: the plan whatever the table size (the default keeps it for tables > 128 MB)
+        out = str(tmp_path / ("plan%s.npz" % plan))
+        env = dict(os.environ, OEA_ROOT=root, OEA_OUT=out, OEA_STEP_PLAN=plan)
+        env.pop("OEA_STEP_DETERMINISTIC", None)
+        p = subprocess.run([sys.executable, "-c", PLAN_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+        res[plan] = dict(np.load(out))
+    for d in (32, 75, 100):
+        assert int(res["2"]["n%d" % d]) == int(res["0"]["n%d" % d])
+        for t in ("e", "r"):
+            a, b = res["0"]["%s%d" % (t, d)], res["2"]["%s%d" % (t, d)]
+            assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a), (t, d, np.linalg.norm(a - b) / np.linalg.norm(a))
+        la, lb = float(res["0"]["l%d" % d]), float(res["2"]["l%d" % d])
         assert abs(la - lb) <= 1e-6 * abs(la), d
