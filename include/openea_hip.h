@@ -285,6 +285,16 @@ int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uin
                          uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                          int32_t *err_flag, void *stream);
 
+/* The same kernel fed from a RECORD of the reference's own draws instead of Philox (tests: pins the sampler's algorithm -- rounds,
+ * one side per round, distinct draws, true triples removed except in the last round, order of acceptance -- against
+ * generate_neg_triples_fast itself, modules/train/batch.py:89-119, which draws with python's Mersenne Twister and cannot be matched
+ * draw by draw otherwise).  replay int32 [n_pos, max_try, 1 + k]: per positive and round, np.random.binomial's value (1 = corrupt
+ * the head) followed by the POSITIONS in the candidate list of that round's random.sample (as many as were still needed; the rest
+ * -1).  err_flag 2: a recorded position does not fit the candidate list. */
+int oea_sample_negatives_replay(const int32_t *pos, int64_t n_pos, int32_t k, const uint64_t *table, uint64_t capacity,
+                                const int32_t *entity_list, int32_t n_ent_list, const int32_t *ent_pos, const int32_t *nbr,
+                                int32_t nbr_k, int32_t max_try, const int32_t *replay, int32_t *out, int32_t *err_flag, void *stream);
+
 /* One launch for a whole (pos_batch1 + pos_batch2) batch of generate_relation_triple_batch
  * (batch.py:36-45): positives [0, n_split) are sampled against side[0] (KG1's triple set,
  * entity list and neighbours), positives [n_split, n_pos) against side[1] (KG2).  Identical

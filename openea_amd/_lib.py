@@ -125,6 +125,7 @@ PROTOTYPES = {
     "oea_tripleset_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
     "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,
                                        _u32, _u32, _i32, _vp, _vp, _vp]),
+    "oea_sample_negatives_replay": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "oea_sample_negatives_pair": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(SamplerSide), C.POINTER(SamplerSide),
                                             _u64, _u32, _u32, _i32, _vp, _vp, _vp]),
     "oea_sample_negatives_epoch": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, C.POINTER(SamplerSide),

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int32_t *__restrict__ pos, int64_t n_pos, int64_t n_split, int k, oea_sampler_side side0,
     oea_sampler_side side1, uint32_t k0, uint32_t k1, uint32_t step, uint32_t pos_offset,
     int max_try, int32_t *__restrict__ out, int32_t *__restrict__ err_flag,
-    const int64_t *__restrict__ seg_off, const int64_t *__restrict__ seg_split, int n_seg) {
+    const int64_t *__restrict__ seg_off, const int64_t *__restrict__ seg_split, int n_seg, const int32_t *__restrict__ replay) {
     const int lane = threadIdx.x % G;
     const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (p >= n_pos) return;                       // whole groups exit together
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     int got = 0;
     for (int tr = 0; tr < max_try && got < k; ++tr) {
         uint4 w = oea::philox4x32_10(c0, step, (uint32_t)tr, 0u, k0, k1);
-        const bool corrupt_head = (w.x & 1u) != 0u;
+        // replay (oea_sample_negatives_replay): the round's Bernoulli and its draws come from a RECORDED run of the reference
+        // (random.sample positions, np.random.binomial) instead of Philox -- same rounds, same filter, same order of acceptance
+        const int32_t *rp = replay ? replay + ((int64_t)p * max_try + tr) * (1 + k) : nullptr;
+        const bool corrupt_head = rp ? rp[0] != 0 : (w.x & 1u) != 0u;
         const int32_t *cand = corrupt_head ? hc : tc;
         const int nc = corrupt_head ? hn : tn;
         const int need = k - got;
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
         int32_t v = -1 - lane;                       // inactive lanes never match anything
         if (active) {
             w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane, k0, k1);
-            v = (int32_t)__umulhi(w.x, (uint32_t)nc);
+            v = rp ? rp[1 + lane] : (int32_t)__umulhi(w.x, (uint32_t)nc);
+            if (rp && (v < 0 || v >= nc)) { *err_flag = 2; return; }        // the record does not fit this positive's candidate list
         }
         for (;;) {
             bool conflict = false;
@@ -185,7 +189,7 @@ static int sample_impl(const int32_t *pos, int64_t n_pos, int64_t n_split, int32
                        const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
                        uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                        int32_t *err_flag, const int64_t *seg_off_dev, const int64_t *seg_split_dev, int n_seg,
-                       void *stream) {
+                       void *stream, const int32_t *replay = nullptr) {
     OEA_REQUIRE(pos && out && err_flag, "null pointer");
     OEA_REQUIRE(k >= 1 && k <= kMaxK, "1 <= k <= 64");
     OEA_REQUIRE(max_try >= 1, "max_try >= 1");
@@ -199,11 +203,11 @@ static int sample_impl(const int32_t *pos, int64_t n_pos, int64_t n_split, int32
     if (k <= 16)
         sample_negatives_kernel<16><<<(unsigned)oea::ceil_div(n_pos, 256 / 16), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
-            out, err_flag, seg_off_dev, seg_split_dev, n_seg);
+            out, err_flag, seg_off_dev, seg_split_dev, n_seg, replay);
     else
         sample_negatives_kernel<64><<<(unsigned)oea::ceil_div(n_pos, 256 / 64), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
-            out, err_flag, seg_off_dev, seg_split_dev, n_seg);
+            out, err_flag, seg_off_dev, seg_split_dev, n_seg, replay);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
@@ -214,6 +218,16 @@ int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split
                               int32_t *err_flag, void *stream) {
     return sample_impl(pos, n_pos, n_split, k, side0, side1, seed, step, pos_offset, max_try, out, err_flag, nullptr,
                        nullptr, 0, stream);
+}
+
+int oea_sample_negatives_replay(const int32_t *pos, int64_t n_pos, int32_t k, const uint64_t *table, uint64_t capacity,
+                                const int32_t *entity_list, int32_t n_ent_list, const int32_t *ent_pos, const int32_t *nbr,
+                                int32_t nbr_k, int32_t max_try, const int32_t *replay, int32_t *out, int32_t *err_flag, void *stream) {
+    OEA_REQUIRE(replay, "replay record");
+    oea_sampler_side sd;
+    sd.table = table; sd.capacity = capacity; sd.entity_list = entity_list; sd.ent_pos = ent_pos; sd.nbr = nbr;
+    sd.n_ent_list = n_ent_list; sd.nbr_k = nbr_k;
+    return sample_impl(pos, n_pos, n_pos, k, &sd, &sd, 0, 0u, 0u, max_try, out, err_flag, nullptr, nullptr, 0, stream, replay);
 }
 
 int oea_sample_negatives_epoch(const int32_t *pos_all, int64_t n_rows, const int64_t *offsets_dev,

@@ -315,6 +315,19 @@ def sample_negatives(pos, k, table, entity_list, ent_pos=None, nbr=None, seed=0,
     return out, err_flag
 
 
+def sample_negatives_replay(pos, k, table, entity_list, replay, ent_pos=None, nbr=None, max_try=10):
+    """the sampler kernel fed from a recorded run of the reference (oea_sample_negatives_replay): replay int32
+    [n_pos, max_try, 1 + k] = per round the side bit and the candidate-list positions random.sample returned"""
+    n_pos = pos.shape[0]
+    out = torch.zeros((n_pos * k, 3), dtype=torch.int32, device=pos.device)
+    err_flag = torch.zeros(1, dtype=torch.int32, device=pos.device)
+    nbr_k = 0 if nbr is None else nbr.shape[1]
+    assert tuple(replay.shape) == (n_pos, max_try, 1 + k) and replay.dtype == torch.int32 and replay.is_contiguous()
+    check(lib().oea_sample_negatives_replay(_p(pos), n_pos, k, _p(table), table.numel(), _p(entity_list), entity_list.numel(),
+                                            _p(ent_pos), _p(nbr), nbr_k, int(max_try), _p(replay), _p(out), _p(err_flag), _stream()))
+    return out, err_flag
+
+
 def sampler_side(table, entity_list, ent_pos, nbr):
     """pack one KG's sampler state for sample_negatives_pair (keeps the tensors alive)."""
     side = _lib.SamplerSide(table.data_ptr(), table.numel(), entity_list.data_ptr(),

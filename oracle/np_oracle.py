@@ -403,6 +403,34 @@ def gcn_se_epoch(W, coords, values, ILL, gamma, k, negs, lr, features=None):
 # ----------------------------------------------------------------------------------------
 # Sparse attention pieces (alinet.py:656-677, rdgcn.py:202-215) -- which grouping tf.sparse_softmax applies is unpinned (H3)
 # ----------------------------------------------------------------------------------------
+# H3, the argument for the DEFAULT grouping 'runs' (every maximal run of CONSECUTIVE entries with the same row index is one softmax
+# group) -- written down so that it can be reviewed against the TensorFlow 1.x sources (not vendored, not installable here;
+# README.md:110 pins 1.8 / 1.12; tests/golden/make_tf1_golden.py settles it in five minutes wherever TensorFlow exists):
+#   1. ORDER OF THE FED TENSOR.  AliNet's adjacency is scipy's `(D^-1/2 A D^-1/2).tocoo()` of a CSC product (alinet.py:27-41,51):
+#      tocoo() of a CSC matrix enumerates column by column, so indices arrive COLUMN-major (checked against scipy in the survey
+#      and in tests/test_graph_golden.py).  tf.SparseTensor keeps the order it is given; nothing in alinet.py calls
+#      tf.sparse_reorder.
+#   2. `adjs[0] * con_sa` (alinet.py:667-668) is SparseDenseCwiseMul (sparse_dense_binary_op_shared.cc): it maps over the
+#      entries in place -- indices and their order unchanged.
+#   3. `tf.sparse_add(con_sa_1, con_sa_2)` (alinet.py:669; sparse_add_op.cc, SparseAddOp::Compute) is a two-pointer MERGE of the
+#      two index lists: while both have entries it compares a_indices[i] with b_indices[j] (sparse::DimComparator::cmp over the
+#      dimensions): 0 -> emit the sum and advance both, -1 -> emit a, +1 -> emit b.  The two operands carry the SAME index list
+#      (both are `adjs[0] * dense`), so every comparison is 0: the output has the operands' entries, summed, in the operands'
+#      order -- column-major again.  (The op documents that it ASSUMES lexicographic order and does not check it.)
+#   4. `tf.sparse_softmax` (alinet.py:673; sparse_softmax_op.cc, SparseSoftmaxOp::Compute) wraps indices / values in a
+#      sparse::SparseTensor with the default order {0, 1} WITHOUT sorting or validating, then iterates
+#      `st.group({0, ..., rank - 2})`.  sparse::GroupIterable (util/sparse/group_iterator.h) advances
+#      `while (next_loc < N && GroupMatches(ix, loc, next_loc)) ++next_loc`: a group is a maximal run of CONSECUTIVE entries
+#      whose group dimensions agree.  That the tensor really is sorted in that order is a DCHECK in SparseTensor::group
+#      ("Group dimension is not in the same order as the sort order") -- compiled out of release wheels.  Each group's values
+#      are replaced by exp(v - max) / sum in place, output index i = input index i.
+#   5. Hence on the column-major tensor of 1. a group = consecutive entries of one ROW inside one COLUMN's listing = a single
+#      entry wherever the pattern has no duplicate coordinates: every alpha is exp(0) / exp(0) = 1 and the layer aggregates the
+#      unweighted neighbour sum ('runs').  If TensorFlow instead canonicalised the order somewhere on this path ('reorder'), or
+#      if the reference is read as what its authors intended ('row': softmax over a node's whole neighbourhood), the other two
+#      groupings apply; kernels, oracle and bench carry all three (approaches/alinet.py: softmax_grouping).
+#   RDGCN (rdgcn.py:202-215) feeds `r_mat` in python-set order with duplicate (h, t) pairs: the same rule applies there --
+#   groups = runs of equal h in THAT order -- and is what its restatement takes as data (seg_ptr).
 
 
 def segment_softmax(logits, seg_offsets):
@@ -743,3 +771,30 @@ def step_plan(pos_all, neg_all, k, offsets, n_ent, hub_entries=8):
         for v in vals[uoff[i]:uoff[i + 1]]:
             pflags[int(offsets[s]) + ((int(v) & 0x7fffffff) >> 1)] |= 2 if (int(v) >> 31) else 1
     return dict(ukeys=ukeys, uoff=uoff, vals=vals, step_first=step_first.astype(np.int64), row_bits=row_bits, pflags=pflags)
+
+
+def sample_negatives_replay(pos, k, triples, cand_head, cand_tail, replay, max_try=10):
+    """generate_neg_triples_fast (modules/train/batch.py:89-119) with its random numbers REPLAYED from a record: per positive up to
+    max_try rounds; round i corrupts the head when replay[p, i, 0] == 1 (np.random.binomial(1, 0.5), batch.py:99), else the tail;
+    the entities drawn are the candidate list's entries at positions replay[p, i, 1 : 1 + need] (random.sample(candidates, need),
+    batch.py:101,104: distinct), need = negatives still missing; drawn triples that are true triples are dropped (set difference,
+    batch.py:110) except in the last round (batch.py:106-108); accepted negatives are appended in draw order (the reference appends
+    them in python-set order: a positive's negatives are compared as a multiset).
+    cand_head[p] / cand_tail[p]: the candidate list of positive p's head / tail (neighbor.get(entity, entities_list)).
+    -> int32 [n_pos * k, 3]"""
+    tri = set(map(tuple, np.asarray(triples).tolist()))
+    out = np.zeros((len(pos) * k, 3), np.int32)
+    for p, (h, r, t) in enumerate(np.asarray(pos).tolist()):
+        got = []
+        for i in range(max_try):
+            need = k - len(got)
+            head = int(replay[p, i, 0]) == 1
+            cands = cand_head[p] if head else cand_tail[p]
+            drawn = [int(cands[int(j)]) for j in replay[p, i, 1:1 + need]]
+            neg = [(e, r, t) if head else (h, r, e) for e in drawn]
+            got += neg if i == max_try - 1 else [x for x in neg if x not in tri]
+            if len(got) == k:
+                break
+        assert len(got) == k
+        out[p * k:(p + 1) * k] = got
+    return out

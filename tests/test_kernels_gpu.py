@@ -320,6 +320,40 @@ def test_sampler_neighbour_fallback_and_k64(ops):
         assert np.all((got[:, :, 0] == pos[:, None, 0]) | (got[:, :, 2] == pos[:, None, 2]))
 
 
+@pytest.mark.parametrize("case", ["truncated", "uniform", "dense"])
+def test_device_sampler_replays_the_reference_run(ops, golden_dir, case):
+    """sample_negatives_kernel fed the RECORDED draws of a run of the reference's generate_neg_triples_fast
+    (oea_sample_negatives_replay; tests/golden/neg_replay.npz) instead of Philox: the reference's negatives, every positive's
+    family as a multiset, and the oracle's replay slot for slot -- the sampler's algorithm (rounds, one side per round, removal of
+    true triples except in the last round) pinned against the reference itself, not only against its restatement."""
+    from oracle import np_oracle
+    g = np.load(os.path.join(golden_dir, "neg_replay.npz"))
+    nbr = None
+    if case == "dense":
+        tri, ents, pos, k, max_try = g["dense_triples"], g["dense_entities"], g["dense_pos"], 5, 3
+        ch = ct = [ents] * len(pos)
+    else:
+        s = np.load(os.path.join(golden_dir, "neg_sampling.npz"))
+        tri, ents, pos, k, max_try = s["triples"], s["entity_list"], s["pos"], 10, 10
+        row = {int(e): i for i, e in enumerate(ents)}
+        if case == "truncated":
+            nbr = s["nbr"]
+        ch = [s["nbr"][row[int(h)]] if case == "truncated" else ents for h in pos[:, 0]]
+        ct = [s["nbr"][row[int(t)]] if case == "truncated" else ents for t in pos[:, 2]]
+    replay, ref = g["replay_" + case], g["neg_" + case]
+    ent_pos = np.full(int(ents.max()) + 1, -1, np.int32)
+    ent_pos[ents] = np.arange(len(ents), dtype=np.int32)
+    table = ops.tripleset_build(ops.to_ids(tri))
+    out, err = ops.sample_negatives_replay(ops.to_ids(pos), k, table, ops.to_ids(ents), torch.from_numpy(replay).to(ops.device()),
+                                           ent_pos=ops.to_ids(ent_pos) if nbr is not None else None,
+                                           nbr=ops.to_ids(nbr) if nbr is not None else None, max_try=max_try)
+    assert int(err.item()) == 0
+    got = out.cpu().numpy()
+    fam = lambda a: [sorted(map(tuple, f.tolist())) for f in np.asarray(a).reshape(-1, k, 3)]      # noqa: E731
+    assert fam(got) == fam(ref)
+    assert np.array_equal(got, np_oracle.sample_negatives_replay(pos, k, tri, ch, ct, replay, max_try))
+
+
 # ---------------------------------------------------------------------------------------------
 # translational step
 # ---------------------------------------------------------------------------------------------

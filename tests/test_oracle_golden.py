@@ -568,3 +568,37 @@ def test_sampler_statistics_match_reference(golden_dir, mode):
     # neither histogram is flat (positions that would give a true triple are rejected and re-drawn): the two samplers
     # must show the same profile; sigma of the difference of two multinomial frequencies ~ sqrt(2 p / N)
     assert np.abs(ours_n - ref_n).max() < 6 * np.sqrt(2 * ref_n.max() / ref_hist.sum())
+
+
+def _families(neg, k):
+    """a positive's k negatives as a sorted list (the reference appends a round's negatives in python-set order)"""
+    neg = np.asarray(neg).reshape(-1, k, 3)
+    return [sorted(map(tuple, fam.tolist())) for fam in neg]
+
+
+@pytest.mark.parametrize("case", ["truncated", "uniform", "dense"])
+def test_sampler_replay_equals_the_reference_run(golden_dir, case):
+    """generate_neg_triples_fast itself (modules/train/batch.py:89-119), its python random numbers recorded
+    (tests/golden/make_neg_replay_golden.py): the oracle's restatement of the algorithm, fed the SAME draws, yields the reference's
+    negatives -- every positive's family of k, as a multiset.  Half of the positives of these fixtures need more than one round
+    (true triples drawn and removed), the dense case runs into the last round, which keeps them."""
+    from oracle import np_oracle
+    g = np.load(os.path.join(golden_dir, "neg_replay.npz"))
+    if case == "dense":
+        tri, ents, pos, k, max_try = g["dense_triples"], g["dense_entities"], g["dense_pos"], 5, 3
+        ch = ct = [ents] * len(pos)
+    else:
+        s = np.load(os.path.join(golden_dir, "neg_sampling.npz"))
+        tri, ents, pos, k, max_try = s["triples"], s["entity_list"], s["pos"], 10, 10
+        row = {int(e): i for i, e in enumerate(ents)}
+        ch = [s["nbr"][row[int(h)]] if case == "truncated" else ents for h in pos[:, 0]]
+        ct = [s["nbr"][row[int(t)]] if case == "truncated" else ents for t in pos[:, 2]]
+    replay, ref = g["replay_" + case], g["neg_" + case]
+    got = np_oracle.sample_negatives_replay(pos, k, tri, ch, ct, replay, max_try)
+    assert _families(got, k) == _families(ref, k)
+    rounds = (replay[:, :, 0] >= 0).sum(1)
+    assert (rounds > 1).sum() >= len(pos) // 3                      # the record exercises the retry rounds
+    if case == "dense":
+        assert rounds.max() == max_try                              # ... and the last round, which keeps true triples
+        tset = set(map(tuple, tri.tolist()))
+        assert any(tuple(x) in tset for x in ref.tolist())
