@@ -452,6 +452,16 @@ int oea_greedy_matching(const int32_t *left, const int32_t *right, const float *
 int oea_pair_dots(const float *e1, int32_t ld1, const float *e2, int32_t ld2, int32_t dim, const int32_t *ii,
                   const int32_t *jj, int64_t n, float *out, void *stream);
 
+/* The k best (largest != 0: largest values; else smallest) of every row of a SHORT candidate matrix vals [n_rows, ld] (first nc <= 1,024
+ * columns) by ranking, ties to the earlier column: out_sel int32 [n_rows, k] = the selected columns in ascending column order,
+ * mapped through ids [n_rows, ld_ids] when given (NULL: the columns themselves); out_kth [n_rows] = the k-th best value.  Either
+ * output may be NULL.  What np.argsort / np.partition do on the [t, k + margin] candidate lists of RDGCN's get_neg
+ * (approaches/rdgcn.py:75-87) and of calculate_nearest_k (modules/finding/similarity.py:80-83) after the grid prefilter. */
+int oea_row_rank_select_f32(const float *vals, int64_t n_rows, int32_t nc, int64_t ld, int32_t k, int32_t largest, const int32_t *ids,
+                            int64_t ld_ids, int32_t *out_sel, float *out_kth, void *stream);
+int oea_row_rank_select_f64(const double *vals, int64_t n_rows, int32_t nc, int64_t ld, int32_t k, int32_t largest, const int32_t *ids,
+                            int64_t ld_ids, int32_t *out_sel, double *out_kth, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Neighbour search -- replaces find_neighbours (modules/train/batch.py:157-165):
  * np.matmul(sub_embed, embed.T) + per-row np.argpartition(-row, k)[:k].

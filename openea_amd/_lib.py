@@ -168,6 +168,8 @@ PROTOTYPES = {
     "oea_topk_sym_workspace_bytes": (_sz, [_i64, _i32]),
     "oea_topk_workspace_bytes": (_sz, [_i64, _i64]),
     "oea_topk_inner": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "oea_row_rank_select_f32": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "oea_row_rank_select_f64": (C.c_int, [_vp, _i64, _i32, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "oea_topk_rows": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "oea_rank_rows": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "oea_rank_workspace_bytes": (_sz, [_i64]),

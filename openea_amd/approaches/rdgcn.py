@@ -343,10 +343,9 @@ def get_neg(ill_ids, output_layer, dim, k, exact_strip=False, margin=32, prefilt
         bound = worst * step - (dim * 1.02 + 4.0) * step
     del s
     d64 = ops.pair_l1_f64(q, output_layer, dim, cand)
-    order = torch.argsort(d64, dim=1, stable=True)[:, :k]                        # k smallest distances, ties -> smaller id
-    sel = torch.sort(torch.gather(cand.to(torch.int64), 1, order), dim=1).values.to(torch.int32)
+    # k smallest distances, ties -> smaller id (cand is ascending), ids ascending: ranking kernel instead of argsort + sort
+    sel, kth = ops.row_rank_select(d64.contiguous(), k, False, ids=cand.contiguous(), want_kth=bound is not None)
     if bound is not None:
-        kth = torch.gather(d64, 1, order[:, k - 1:k]).reshape(-1)
         redo = torch.nonzero(~(bound > kth)).reshape(-1)
         if stats is not None:
             stats['uncertified'] = int(redo.numel())

@@ -1662,6 +1662,70 @@ void gather_packed_rows(const float *qp, int kp, const int32_t *rows, const int3
 }
 }  // namespace oea
 
+// ---- short candidate lists: the k best of a row of at most 1,024 values by RANKING (no sort) ---------------------------------------------
+// One wave per row; every lane owns the columns lane, lane + 64, ...; rank of a value = how many values of the row beat it (better
+// value, or the same value in an earlier column); rank < k selects.  The selected columns leave in ascending column order (a wave
+// ballot prefix), optionally mapped through the row's id list; the k-th best value (rank k - 1) is written beside them.  Replaces
+// torch.argsort / sort / topk on [rows, k + margin] matrices (approaches/rdgcn.py:get_neg, ops.l1_grid_topk_means).
+template <typename T, bool LARGEST>
+__global__ __launch_bounds__(256) void row_rank_select_kernel(const T *__restrict__ vals, int64_t n_rows, int nc, int64_t ld, int k,
+                                                              const int32_t *__restrict__ ids, int64_t ld_ids,
+                                                              int32_t *__restrict__ out_sel, T *__restrict__ out_kth) {
+    constexpr int PER = 16;                                   // 64 x 16 = 1,024 columns
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    __shared__ T sh[4][1024];
+    T *mine = sh[threadIdx.x >> 6];
+    const T *v = vals + row * ld;
+    for (int c = lane; c < nc; c += 64) mine[c] = v[c];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    int rank[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) rank[u] = 0;
+    for (int j = 0; j < nc; ++j) {
+        const T o = mine[j];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nc) {
+                const T x = mine[c];
+                const bool beats = LARGEST ? (o > x) : (o < x);
+                rank[u] += (beats || (o == x && j < c)) ? 1 : 0;
+            }
+        }
+    }
+    int base = 0;                                             // selected columns before this group of 64
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int c = lane + 64 * u;
+        if (64 * u >= nc) break;                              // (uniform)
+        const bool sel = c < nc && rank[u] < k;
+        const unsigned long long m = __ballot(sel);
+        if (sel) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (out_sel) out_sel[row * k + slot] = ids ? ids[row * ld_ids + c] : c;
+            if (out_kth && rank[u] == k - 1) out_kth[row] = mine[c];
+        }
+        base += __popcll(m);
+    }
+}
+
+template <typename T>
+static int rank_select(const T *vals, int64_t n_rows, int32_t nc, int64_t ld, int32_t k, int32_t largest, const int32_t *ids, int64_t ld_ids,
+                       int32_t *out_sel, T *out_kth, void *stream) {
+    OEA_REQUIRE(vals && (out_sel || out_kth), "null pointer");
+    OEA_REQUIRE(nc >= 1 && nc <= 1024 && k >= 1 && k <= nc && ld >= nc, "1 <= k <= nc <= 1024, ld >= nc");
+    if (n_rows == 0) return OEA_OK;
+    const unsigned nb = (unsigned)oea::ceil_div(n_rows, 4);
+    hipStream_t st = oea::as_stream(stream);
+    if (largest) row_rank_select_kernel<T, true><<<nb, 256, 0, st>>>(vals, n_rows, nc, ld, k, ids, ld_ids, out_sel, out_kth);
+    else row_rank_select_kernel<T, false><<<nb, 256, 0, st>>>(vals, n_rows, nc, ld, k, ids, ld_ids, out_sel, out_kth);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
 extern "C" {
 
 size_t oea_topk_workspace_bytes(int64_t nq, int64_t nc) {
@@ -1674,6 +1738,16 @@ size_t oea_topk_sym_workspace_bytes(int64_t n, int32_t k) {
     if (q.ok) return q.total;
     const SymPlan p = plan_sym(n, k, ~(size_t)0);
     return p.ok ? p.total : 0;
+}
+
+int oea_row_rank_select_f32(const float *vals, int64_t n_rows, int32_t nc, int64_t ld, int32_t k, int32_t largest, const int32_t *ids,
+                            int64_t ld_ids, int32_t *out_sel, float *out_kth, void *stream) {
+    return rank_select<float>(vals, n_rows, nc, ld, k, largest, ids, ld_ids, out_sel, out_kth, stream);
+}
+
+int oea_row_rank_select_f64(const double *vals, int64_t n_rows, int32_t nc, int64_t ld, int32_t k, int32_t largest, const int32_t *ids,
+                            int64_t ld_ids, int32_t *out_sel, double *out_kth, void *stream) {
+    return rank_select<double>(vals, n_rows, nc, ld, k, largest, ids, ld_ids, out_sel, out_kth, stream);
 }
 
 int oea_topk_rows(const float *s, int64_t n_rows, int64_t nc, int64_t ld, int32_t k, const int32_t *id_map,

@@ -595,6 +595,21 @@ def topk_rows(s, k, id_map=None, nc=None):
     return out
 
 
+def row_rank_select(vals, k, largest, ids=None, want_sel=True, want_kth=False):
+    """the k best of every row of a short [n, c <= 1,024] fp32 / fp64 matrix by ranking (ties: earlier column) -> (selected columns
+    int32 [n, k] in ascending column order, mapped through ids [n, c] when given; k-th best value [n]) (oea_row_rank_select_*)"""
+    assert vals.dim() == 2 and vals.is_contiguous() and vals.dtype in (torch.float32, torch.float64)
+    n, c = vals.shape
+    sel = torch.empty((n, k), dtype=torch.int32, device=vals.device) if want_sel else None
+    kth = torch.empty(n, dtype=vals.dtype, device=vals.device) if want_kth else None
+    fn = lib().oea_row_rank_select_f32 if vals.dtype == torch.float32 else lib().oea_row_rank_select_f64
+    if ids is not None:
+        assert ids.dtype == torch.int32 and ids.is_contiguous() and ids.shape == vals.shape
+    check(fn(_p(vals), n, c, vals.stride(0), int(k), int(bool(largest)), _p(ids), 0 if ids is None else ids.stride(0), _p(sel), _p(kth),
+             _stream()))
+    return sel, kth
+
+
 def eval_bf16_enabled(n1, n2):
     """the certified bf16 prefilter (oea_rank_eval_bf16) takes the inner-product evaluation (with or without CSLS means) from
     3e8 pairs (~17,000^2) on: its six launches and the exact fix-up cost ~0.1 ms, which the 10,500 test pairs of the 15K
@@ -677,7 +692,7 @@ def l1_grid_topk_means(q_tab, c_tab, qq, qc, dim, k, step, err, margin=32, block
     rows_per = keep.rows_per if keep is not None else int(max(128, min(n, block_bytes // (4 * ld))))
     out = torch.empty(n, dtype=torch.float32, device=q_tab.device)
     c = min(k + margin, nc)
-    redone = 0
+    bad = torch.zeros(n, dtype=torch.bool, device=q_tab.device)
     for r0 in range(0, n, rows_per):
         rows = min(rows_per, n - r0)
         strip = keep.strip(r0, rows, keep=True) if keep is not None else l1_u16_strip(qq[r0: r0 + rows], qc)
@@ -685,20 +700,20 @@ def l1_grid_topk_means(q_tab, c_tab, qq, qc, dim, k, step, err, margin=32, block
         worst = -torch.gather(strip, 1, cand.to(torch.int64)).amin(dim=1).to(torch.float64)
         qb = q_tab[r0: r0 + rows]
         sims = pair_l1_sim(qb, c_tab, dim, cand)
-        means = row_topk_mean(sims, k)
-        kth = torch.topk(sims, k, dim=1).values[:, k - 1].to(torch.float64)
+        out[r0: r0 + rows] = row_topk_mean(sims, k)
+        _, kth = row_rank_select(sims, k, True, want_sel=False, want_kth=True)       # the k-th largest exact similarity of the list
         # a non-member's distance is at least worst * step - err (+ 4 steps: float rounding of large grid sums)
         bound = 1.0 - (worst * step - (err + 4.0 * step))
-        redo = torch.nonzero(~(bound <= kth)).reshape(-1) if c < nc else torch.zeros(0, dtype=torch.int64, device=q_tab.device)
-        if redo.numel():
-            redone += int(redo.numel())
-            for b0 in range(0, redo.numel(), 4096):
-                idx = redo[b0: b0 + 4096]
-                s = sim_matrix(qb.index_select(0, idx).contiguous(), c_tab, dim, 'manhattan')
-                means[idx] = row_topk_mean(s, k)
-                del s
-        out[r0: r0 + rows] = means
+        if c < nc:
+            bad[r0: r0 + rows] = ~(bound <= kth.to(torch.float64))
         del strip
+    redo = torch.nonzero(bad).reshape(-1)                    # ONE host read per call (was one per block of rows)
+    redone = int(redo.numel())
+    for b0 in range(0, redone, 4096):                        # uncertified rows: the all-pairs fp64 strip
+        idx = redo[b0: b0 + 4096]
+        s = sim_matrix(q_tab.index_select(0, idx).contiguous(), c_tab, dim, 'manhattan')
+        out[idx] = row_topk_mean(s, k)
+        del s
     if stats is not None:
         stats['uncertified'] = stats.get('uncertified', 0) + redone
     return out

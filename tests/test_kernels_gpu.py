@@ -1484,3 +1484,26 @@ def test_planned_epochs_equal_the_atomic_epochs(tmp_path):
             assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a), (t, d, np.linalg.norm(a - b) / np.linalg.norm(a))
         la, lb = float(res["0"]["l%d" % d]), float(res["2"]["l%d" % d])
         assert abs(la - lb) <= 1e-6 * abs(la), d
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n,c,k,largest", [(300, 42, 10, True), (257, 157, 125, False), (5, 1, 1, True), (64, 1024, 37, False), (100, 65, 65, True)])
+def test_row_rank_select_equals_a_stable_sort(ops, dtype, n, c, k, largest):
+    """oea_row_rank_select_*: the k best of every row of a short candidate matrix by ranking (ties to the earlier column), the
+    selected columns in ascending order (mapped through an id list) and the k-th best value == a stable sort (what np.argsort /
+    np.partition give on the candidate lists of get_neg, approaches/rdgcn.py:75-87, and of calculate_nearest_k,
+    similarity.py:80-83); rows full of ties included."""
+    rng = np.random.RandomState(n + c)
+    v = rng.standard_normal((n, c))
+    v[:, ::3] = np.round(v[:, ::3], 1)                                  # ties
+    v[0] = 1.0
+    v = v.astype(np.float32 if dtype == "f32" else np.float64)
+    ids = np.sort(rng.choice(100000, (n, c), replace=True), axis=1).astype(np.int32)
+    dv = torch.from_numpy(v).to(ops.device())
+    sel, kth = ops.row_rank_select(dv, k, largest, ids=torch.from_numpy(ids).to(ops.device()), want_kth=True)
+    order = np.argsort(-v if largest else v, axis=1, kind="stable")[:, :k]
+    cols = np.sort(order, axis=1)
+    assert np.array_equal(sel.cpu().numpy(), np.take_along_axis(ids, cols, 1))
+    assert np.array_equal(kth.cpu().numpy(), np.take_along_axis(v, order[:, k - 1:k], 1).reshape(-1))
+    sel2, _ = ops.row_rank_select(dv, k, largest)
+    assert np.array_equal(sel2.cpu().numpy(), cols)
