@@ -354,6 +354,15 @@ int oea_triple_epoch_range(float *ent, float *ent_acc, int64_t n_ent, float *rel
                            void *workspace, double *loss_accum, const int64_t *offsets_dev, const int64_t *splits_dev,
                            void *stream);
 
+/* An epoch's shuffle and batch layout in one call (basic_model.py:234-235: random.shuffle of both KGs' relation-triple lists;
+ * modules/train/batch.py:17-22: batch s = KG1's slice s then KG2's slice s): triples int32 [n1 + n2, 3] = list 1 then list 2 (never
+ * modified), slot int64 [n_slots] = the fixed map "position in the epoch's batch layout -> position in cat(list1, list2)"; a fresh
+ * uniform permutation of each list (Philox4x32-10 keys of (index, epoch) under `seed`, one stable radix sort) is applied under the
+ * map: dall[j] = triples[perm[slot[j]]].  No allocation, no host read (side stream). */
+size_t oea_epoch_layout_bytes(int64_t n);
+int oea_epoch_layout(const int32_t *triples, int64_t n1, int64_t n2, const int64_t *slot, int64_t n_slots, uint64_t seed, uint32_t epoch,
+                     int32_t *dall, void *workspace, size_t ws_bytes, void *stream);
+
 /* ---- the gathered-sum plan of an epoch (round 6; csrc/step_plan.h) ------------------------------------------------------------
  * Replaces, for the rows of the positives' own heads and tails, the scatter-add TF performs on the gradient of
  * tf.nn.embedding_lookup (IndexedSlices -> unsorted_segment_sum, models/basic_model.py:89-98, modules/base/optimizers.py:4-7) --

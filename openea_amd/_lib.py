@@ -139,6 +139,8 @@ PROTOTYPES = {
     "oea_triple_epoch_range_shard": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                          C.POINTER(SamplerSide), C.POINTER(SamplerSide), _u64, _u32, _vp, _vp,
                                          C.POINTER(StepCfg), _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "oea_epoch_layout_bytes": (_sz, [_i64]),
+    "oea_epoch_layout": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _u64, _u32, _vp, _vp, _sz, _vp]),
     "oea_step_plan_supported": (_i32, [C.POINTER(StepCfg), _i64, _i64, _i32, _i32]),
     "oea_step_plan_bytes": (_sz, [_i64, _i32, _i64, _i64, _i32]),
     "oea_step_plan_offsets": (C.c_int, [_i64, _i32, _i64, _i64, _i32, _vp]),

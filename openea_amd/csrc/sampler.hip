@@ -15,6 +15,8 @@
 // One 16-lane (k <= 16) or 64-lane group per positive, one lane per sampled slot: candidate
 // reads and membership probes of a try go out in parallel (the one-lane-per-positive version
 // was a 34 us dependent chain for 2,500 positives -- profiles/r01a_bench_kernel_stats.txt).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -60,8 +62,14 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     int max_try, int32_t *__restrict__ out, int32_t *__restrict__ err_flag,
     const int64_t *__restrict__ seg_off, const int64_t *__restrict__ seg_split, int n_seg, const int32_t *__restrict__ replay) {
     const int lane = threadIdx.x % G;
-    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    if (p >= n_pos) return;                       // whole groups exit together
+    const uint32_t step_in = step;
+    const int64_t n_split_in = n_split;
+    // grid-stride over the positives: the epoch launch (side stream, a whole epoch to finish in) keeps to a few workgroups per CU
+    // so that the step kernels of the epoch that is RUNNING find their wave slots -- one workgroup per 16 positives held every
+    // slot of the chip for its 350 us and the scoring kernel beside it took 420 us instead of 40 (tools/r06/e.sh)
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; p < n_pos; p += (int64_t)gridDim.x * blockDim.x / G) {
+    step = step_in;
+    n_split = n_split_in;
     // Epoch mode (seg_off != NULL): `pos` holds every batch of the epoch back to back; the batch of
     // row p is found by bisection and the Philox counter is (row within batch, step + batch), i.e.
     // exactly the stream of a per-batch call -- one launch samples the whole epoch.
@@ -105,14 +113,14 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
         const int32_t *cand = corrupt_head ? hc : tc;
         const int nc = corrupt_head ? hn : tn;
         const int need = k - got;
-        if (need > nc) { if (lane == 0) *err_flag = 1; return; }   // random.sample would raise ValueError
+        if (need > nc) { if (lane == 0) *err_flag = 1; break; }    // random.sample would raise ValueError
         const bool active = lane < need;
         uint32_t att = 0;
         int32_t v = -1 - lane;                       // inactive lanes never match anything
         if (active) {
             w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane, k0, k1);
             v = rp ? rp[1 + lane] : (int32_t)__umulhi(w.x, (uint32_t)nc);
-            if (rp && (v < 0 || v >= nc)) { *err_flag = 2; return; }        // the record does not fit this positive's candidate list
+            if (rp && (v < 0 || v >= nc)) { *err_flag = 2; v = 0; }         // the record does not fit this positive's candidate list
         }
         for (;;) {
             bool conflict = false;
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
             o[0] = nh; o[1] = r; o[2] = nt;
         }
         got += __popcll(acc_mask);
+    }
     }
 }
 
@@ -200,12 +209,14 @@ static int sample_impl(const int32_t *pos, int64_t n_pos, int64_t n_split, int32
     if (rc != OEA_OK) return rc;
     if (n_pos == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
+    // epoch mode = side stream: at most 512 workgroups (two per CU: a quarter of the wave slots) beside the running epoch's kernels
+    const int64_t cap = seg_off_dev ? 512 : ((int64_t)1 << 30);
     if (k <= 16)
-        sample_negatives_kernel<16><<<(unsigned)oea::ceil_div(n_pos, 256 / 16), 256, 0, st>>>(
+        sample_negatives_kernel<16><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_pos, 256 / 16), cap), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
             out, err_flag, seg_off_dev, seg_split_dev, n_seg, replay);
     else
-        sample_negatives_kernel<64><<<(unsigned)oea::ceil_div(n_pos, 256 / 64), 256, 0, st>>>(
+        sample_negatives_kernel<64><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_pos, 256 / 64), cap), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,
             out, err_flag, seg_off_dev, seg_split_dev, n_seg, replay);
     OEA_CHECK_HIP(hipGetLastError());

@@ -116,25 +116,45 @@ __global__ void plan_records_kernel(const uint64_t *__restrict__ ukeys, const ui
     }
 }
 
-// one wave per distinct key: a row with more than kPlanHubEntries references in its step marks the positives that refer to it
-// (bit 0: as head, bit 1: as tail) -- the scoring kernel sends those rows' gradient through the atomic scratch
-__global__ void plan_hub_kernel(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ uoff, const uint32_t *__restrict__ vals,
-                                const int32_t *__restrict__ n_unique, const int64_t *__restrict__ offsets, int steps, int row_bits,
-                                uint32_t *__restrict__ pflags) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int nu = *n_unique;
-    for (int64_t i = wave; i < nu; i += nwave) {
-        const uint32_t e0 = uoff[i], e1 = uoff[i + 1];
-        if (e1 - e0 <= kPlanHubEntries) continue;
-        const int64_t step = (int64_t)(ukeys[i] >> row_bits);
-        if (step >= steps) continue;                              // the sentinel run of the positives outside the rule
-        const int64_t b0 = offsets[step];
-        for (uint32_t e = e0 + lane; e < e1; e += 64) {
-            const uint32_t v = vals[e];
-            atomicOr(&pflags[b0 + ((v & 0x7fffffffu) >> 1)], (v >> 31) ? 2u : 1u);
-        }
-    }
+// one thread per sorted entry: is its key's run longer than kPlanHubEntries?  (Look at most kPlanHubEntries entries to the left and
+// right: a run is a hub exactly when some window of kPlanHubEntries + 1 consecutive entries around the entry carries one key.)  Hub
+// entries mark their positive (bit 0: referred to as head, bit 1: as tail) -- the scoring kernel sends those rows' gradient through
+// the atomic scratch.  (A wave per distinct key walked 1.3 M keys to find a few thousand hubs: 58 us; this: one pass over the entries.)
+__global__ void plan_hub_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, int64_t m,
+                                const int64_t *__restrict__ offsets, int steps, int row_bits, uint32_t *__restrict__ pflags) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const uint64_t key = keys[e];
+    const int64_t step = (int64_t)(key >> row_bits);
+    if (step >= steps) return;                                    // the sentinel run of the positives outside the rule
+    int left = 0, right = 0;
+    while (left < (int)kPlanHubEntries && e - left - 1 >= 0 && keys[e - left - 1] == key) ++left;
+    while (left + right < (int)kPlanHubEntries && e + right + 1 < m && keys[e + right + 1] == key) ++right;
+    if (left + right < (int)kPlanHubEntries) return;              // run length = left + right + 1 (capped) <= kPlanHubEntries
+    const uint32_t v = vals[e];
+    atomicOr(&pflags[offsets[step] + ((v & 0x7fffffffu) >> 1)], (v >> 31) ? 2u : 1u);
+}
+
+// ---- an epoch's shuffle + batch layout in one place (basic_model.py:234-235: random.shuffle of both KGs' triple lists; batch.py:17-22:
+// batch s = KG1's slice s followed by KG2's slice s) ---------------------------------------------------------------------------------------
+// keys: a KG bit above 40 random bits (Philox4x32-10 of (index, epoch) under the seed): ONE stable radix sort permutes each KG's list
+// inside its own half; then dall[j] = triples[perm[slot[j]]].  A fresh uniform permutation of the FIXED list every epoch is the
+// distribution of shuffling the previous epoch's order.  (torch.randperm x 2 + cat + two index gathers were 17 launches and 0.66 ms
+// of side-stream time per epoch at the 100K shape -- a quarter of what the epoch's own kernels take.)
+__global__ void layout_keys_kernel(int64_t n1, int64_t n, uint32_t k0, uint32_t k1, uint32_t epoch, uint64_t *__restrict__ keys,
+                                   uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 w = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), epoch, 0x5eedu, k0, k1);
+    keys[i] = ((uint64_t)(i >= n1 ? 1u : 0u) << 40) | ((uint64_t)(w.x & 0xffu) << 32) | (uint64_t)w.y;
+    idx[i] = (uint32_t)i;
+}
+__global__ void layout_gather_kernel(const int32_t *__restrict__ triples, const uint32_t *__restrict__ perm, const int64_t *__restrict__ slot,
+                                     int64_t n_slots, int32_t *__restrict__ dall) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_slots) return;
+    const int64_t src = perm[slot[j]];
+    dall[3 * j] = triples[3 * src]; dall[3 * j + 1] = triples[3 * src + 1]; dall[3 * j + 2] = triples[3 * src + 2];
 }
 
 }  // namespace
@@ -159,6 +179,36 @@ int oea_step_plan_offsets(int64_t n_total, int32_t steps, int64_t max_batch, int
     out[0] = (char *)v.vals_b - base; out[1] = (char *)v.ukeys - base; out[2] = (char *)v.uoff - base;
     out[3] = (char *)v.n_unique - base; out[4] = (char *)v.step_first - base; out[5] = (char *)v.contrib - base;
     out[6] = v.row_bits; out[7] = (int64_t)total; out[8] = (char *)v.pflags - base;
+    return OEA_OK;
+}
+
+size_t oea_epoch_layout_bytes(int64_t n) {
+    if (n < 0) return 0;
+    const size_t m = (size_t)std::max<int64_t>(n, 1);
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    m, 0, 41, (hipStream_t)0);
+    return 2 * oea::al256(8 * m) + 2 * oea::al256(4 * m) + oea::al256(t + 256);
+}
+
+int oea_epoch_layout(const int32_t *triples, int64_t n1, int64_t n2, const int64_t *slot, int64_t n_slots, uint64_t seed, uint32_t epoch,
+                     int32_t *dall, void *workspace, size_t ws_bytes, void *stream) {
+    OEA_REQUIRE(triples && (slot || n_slots == 0) && (dall || n_slots == 0) && workspace, "null pointer");
+    OEA_REQUIRE(n1 >= 0 && n2 >= 0 && n_slots >= 0 && n1 + n2 < ((int64_t)1 << 32), "sizes");
+    const int64_t n = n1 + n2;
+    OEA_REQUIRE(ws_bytes >= oea_epoch_layout_bytes(n), "workspace smaller than oea_epoch_layout_bytes");
+    if (n == 0 || n_slots == 0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    char *w = static_cast<char *>(workspace);
+    const size_t m = (size_t)n;
+    uint64_t *ka = (uint64_t *)w, *kb = (uint64_t *)(w + oea::al256(8 * m));
+    uint32_t *ia = (uint32_t *)(w + 2 * oea::al256(8 * m)), *ib = (uint32_t *)(w + 2 * oea::al256(8 * m) + oea::al256(4 * m));
+    void *temp = w + 2 * oea::al256(8 * m) + 2 * oea::al256(4 * m);
+    size_t tb = ws_bytes - (2 * oea::al256(8 * m) + 2 * oea::al256(4 * m));
+    oea::layout_keys_kernel<<<(unsigned)oea::ceil_div(n, 256), 256, 0, st>>>(n1, n, (uint32_t)seed, (uint32_t)(seed >> 32), epoch, ka, ia);
+    OEA_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint64_t *)ka, kb, (const uint32_t *)ia, ib, m, 0, 41, st));
+    oea::layout_gather_kernel<<<(unsigned)oea::ceil_div(n_slots, 256), 256, 0, st>>>(triples, ib, slot, n_slots, dall);
+    OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
 
@@ -193,8 +243,8 @@ int oea_step_plan_build(const int32_t *pos_all, const int32_t *neg_all, int32_t 
     OEA_CHECK_HIP(hipMemsetAsync(v.inplan, 0, (size_t)steps * (size_t)n_ent, st));
     oea::plan_records_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div((int64_t)m, 256), 4096), 256, 0, st>>>(
         v.ukeys, v.uoff, v.vals_b, v.n_unique, steps, v.row_bits, n_ent, v.recs, v.inplan);
-    oea::plan_hub_kernel<<<(unsigned)std::min<int64_t>(oea::ceil_div((int64_t)m, 4 * 16), 4096), 256, 0, st>>>(
-        v.ukeys, v.uoff, v.vals_b, v.n_unique, offsets_dev, steps, v.row_bits, v.pflags);
+    oea::plan_hub_kernel<<<(unsigned)oea::ceil_div((int64_t)m, 256), 256, 0, st>>>(v.keys_b, v.vals_b, (int64_t)m, offsets_dev, steps, v.row_bits,
+                                                                                   v.pflags);
     OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }

@@ -383,6 +383,16 @@ def triple_epoch(ent, ent_acc, rel, rel_acc, dim, pos_all, offsets, splits, k, s
                                        _p(offsets_dev), _p(splits_dev), int(shard[0]), int(shard[1]), _stream()))
 
 
+def epoch_layout(triples, n1, n2, slot, seed, epoch, dall, workspace=None):
+    """an epoch's shuffle of both triple lists + the batch layout gather (oea_epoch_layout) on the current stream -> workspace"""
+    n = int(n1) + int(n2)
+    if workspace is None:
+        workspace = torch.empty(lib().oea_epoch_layout_bytes(n), dtype=torch.uint8, device=triples.device)
+    check(lib().oea_epoch_layout(_p(triples), int(n1), int(n2), _p(slot), slot.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(epoch) & 0xFFFFFFFF,
+                                 _p(dall), _p(workspace), workspace.numel(), _stream()))
+    return workspace
+
+
 def step_plan_supported(cfg, n_ent, n_rel, ld, k):
     """would an epoch under cfg run on the gathered-sum plan (oea_step_plan_supported)?"""
     return bool(lib().oea_step_plan_supported(C.byref(cfg), int(n_ent), int(n_rel), int(ld), int(k)))

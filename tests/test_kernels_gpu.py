@@ -1507,3 +1507,39 @@ def test_row_rank_select_equals_a_stable_sort(ops, dtype, n, c, k, largest):
     assert np.array_equal(kth.cpu().numpy(), np.take_along_axis(v, order[:, k - 1:k], 1).reshape(-1))
     sel2, _ = ops.row_rank_select(dv, k, largest)
     assert np.array_equal(sel2.cpu().numpy(), cols)
+
+
+def test_epoch_layout_is_a_fresh_permutation_of_each_list(ops):
+    """oea_epoch_layout (basic_model.py:234-235 random.shuffle of both KGs' lists + batch.py:17-22 batch layout): every epoch's
+    layout visits each list's triples at most once and exactly as many as the layout has slots for that list, KG1's slice in front
+    of KG2's in every batch; the same (seed, epoch) gives the same layout, another epoch another one; positions are uniform
+    (a triple's mean slot over 64 epochs is near the middle)."""
+    from openea_amd.modules.train.batch import EpochBatches
+    rng = np.random.RandomState(3)
+    t1 = np.stack([rng.randint(0, 500, 4000), rng.randint(0, 9, 4000), np.arange(4000)], 1).astype(np.int32)       # unique by column 2
+    t2 = np.stack([rng.randint(500, 900, 2500), rng.randint(0, 9, 2500), np.arange(4000, 6500)], 1).astype(np.int32)
+    b = EpochBatches(t1, t2, 1000)
+    gen = torch.Generator(device=ops.device())
+    gen.manual_seed(17)
+    first = b.dall.cpu().numpy().copy()
+    assert np.array_equal(first, np.concatenate([t1, t2])[b.slot.cpu().numpy()])          # before any shuffle: the lists as loaded
+    layouts, pos_sum = [], np.zeros(6500)
+    for e in range(64):
+        b.shuffle(gen)
+        d = b.dall.cpu().numpy()
+        layouts.append(d.copy())
+        ids = d[:, 2]
+        assert len(np.unique(ids)) == len(ids)                                              # nothing visited twice
+        for s in range(len(b.splits)):
+            o0, o1, sp = int(b.offsets[s]), int(b.offsets[s + 1]), int(b.splits[s])
+            assert (ids[o0:o0 + sp] < 4000).all() and (ids[o0 + sp:o1] >= 4000).all()      # KG1's slice, then KG2's
+        pos_sum[ids] += np.arange(len(ids))
+        full = np.concatenate([t1, t2])
+        assert np.array_equal(d, full[ids])                                                 # rows travel whole
+    assert not np.array_equal(layouts[0], layouts[1])
+    b2 = EpochBatches(t1, t2, 1000)
+    b2.shuffle(gen)
+    assert np.array_equal(b2.dall.cpu().numpy(), layouts[0])                                # same seed, same epoch counter
+    visited = pos_sum > 0
+    mean_pos = pos_sum[visited] / 64
+    assert abs(mean_pos[:100].mean() / len(first) - 0.5) < 0.12                              # no triple keeps to one end of the epoch
