@@ -1855,7 +1855,12 @@ void launch_grouped(int nb, int block, hipStream_t st, const float *ent, const f
         if (wave_fits && !runtime_kind && cfg.loss_kind == OEA_LOSS_LIMITED && cfg.ent_l2_norm && cfg.rel_l2_norm && k >= 0 && k <= 10 &&
             step_wave_enabled()) {
             constexpr int IT64 = G == 32 ? (IT + 1) / 2 : 4;
-            launch_wave<IT64>(nb, (block / G) * 64, st, ent, rel, ld, pos, n_pos, neg, cfg, ws, contrib, pflags);
+            // G == 32 (ld <= 128): the grid has one workgroup per 8 positives (launch_step's rule for the loss partials).  512 threads =
+            // one positive per wave; 256 threads = two per wave (grid stride): half the waves, nearly all resident at once, and
+            // 4-wave workgroups find their slots beside side-stream kernels where 8-wave workgroups starve (OEA_STEP_WAVE_BLOCK)
+            static const int blk_env = [] { const char *e = getenv("OEA_STEP_WAVE_BLOCK"); return e ? atoi(e) : 0; }();
+            const int wblock = G == 32 ? (blk_env == 256 || blk_env == 512 ? blk_env : 512) : (block / G) * 64;
+            launch_wave<IT64>(nb, wblock, st, ent, rel, ld, pos, n_pos, neg, cfg, ws, contrib, pflags);
             return;
         }
     }

@@ -255,6 +255,16 @@ def step_exchange_view(workspace, n_ent, n_rel, ld):
     return workspace[: dt.itemsize * n].view(dt)
 
 
+def step_entity_flags(workspace, n_ent, n_rel, ld):
+    """the entity rows' touched flags inside the step workspace (a view; scratch element type): nonzero = the row received gradient
+    through the atomic scratch in the GRAD phase that just ran"""
+    eg, et = C.c_void_p(), C.c_void_p()
+    check(lib().oea_step_entity_scratch(_p(workspace), int(n_ent), int(n_rel), int(ld), C.byref(eg), C.byref(et)))
+    dt = scratch_dtype()
+    off = et.value - workspace.data_ptr()
+    return workspace[off: off + dt.itemsize * int(n_ent)].view(dt)
+
+
 def step_normal_views(workspace, n_ent, n_rel, ld):
     """TransH under the entity-id partition: fp32 views of the normal-vector gradient scratch [n_rel * ld] and its touched
     flags [n_rel] inside the step workspace (summed over the ranks after the GRAD phase, include/openea_hip.h)."""

@@ -55,6 +55,16 @@ for rr in runs:
     big = sorted(((b[0] - a[1]) / 1e3, a[2], b[2]) for a, b in zip(rr, rr[1:]) if b[0] - a[1] > 3000)[-6:]
     print("run of %d kernels: span %.2f ms, busy %.2f ms, idle %.1f us per step; largest gaps (us, after, before): %s" %
           (len(rr), span / 1e6, busy / 1e6, (span - busy) / 1e3 / (len(rr) / 2), [(round(g, 1), x, y) for g, x, y in big]))
+    # the run in slices of 10 steps: mean kernel time per step, and the side-stream kernels active in the slice
+    for i in range(0, len(rr), 20):
+        sl = rr[i:i + 20]
+        t0, t1 = sl[0][0], sl[-1][1]
+        act = collections.Counter()
+        for s_, e_, k_, n_ in side:
+            if s_ < t1 and e_ > t0: act[k_] += (min(e_, t1) - max(s_, t0)) / 1e3
+        print("    steps %3d-%3d: %.1f us per step (wave %.1f, apply %.1f)   side stream active (us): %s" %
+              (i // 2, i // 2 + len(sl) // 2, (t1 - t0) / 1e3 / (len(sl) / 2), sum(e - s for s, e, k, _ in sl if k == "wave") / 1e3 / (len(sl) / 2),
+               sum(e - s for s, e, k, _ in sl if k == "apply") / 1e3 / (len(sl) / 2), {k: round(v) for k, v in act.items()}))
 tot = collections.Counter()
 for s, e, k, n in ev: tot[k] += e - s
 print("total kernel time by kind (ms):", {k: round(v / 1e6, 2) for k, v in tot.items()})
