@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256) void apply_rows(float *__restrict__ ent, float
 
 // ---- kernel 2', round 6: the optimiser of a PLANNED step (step_plan.h), one launch, four kinds of blocks ----------------------------------
 //   [0, rel_blocks)        relation rows, one lane group per row as in apply_rows (16 scratch copies summed in order);
-//   [.., + plan_blocks)    one lane group per DISTINCT entity row the step's positives refer to as head or tail and that is no hub:
+//   (plan blocks, listed third in the grid)    one lane group per DISTINCT entity row the step's positives refer to as head or tail and that is no hub:
 //                          gradient = the sum of its plan entries (sign, slot) over contrib[slot] in the plan's order -- the batch
 //                          order, whatever the hardware does -- plus the row of the atomic scratch where its touched flag is up (an
 //                          active negative corrupted INTO this row).  Chain of dependent loads: step_first -> record -> rows;
@@ -1246,7 +1246,7 @@ template <int G, int IT>
 __global__ __launch_bounds__(256) void apply_step_plan(float *__restrict__ ent, float *__restrict__ ent_acc, int64_t n_ent,
                                                        float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel, int ld,
                                                        oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum,
-                                                       int copies_folded, int rel_blocks, int plan_blocks,
+                                                       int copies_folded, int rel_blocks, int scan_blocks,
                                                        const uint4 *__restrict__ recs, const uint32_t *__restrict__ vals,
                                                        const int32_t *__restrict__ step_first, int s, const uint8_t *__restrict__ inplan,
                                                        const float *__restrict__ contrib) {
@@ -1256,8 +1256,9 @@ __global__ __launch_bounds__(256) void apply_step_plan(float *__restrict__ ent, 
     if (b < rel_blocks) {
         for (int64_t row = (int64_t)b * GPB + threadIdx.x / G; row < n_rel; row += (int64_t)rel_blocks * GPB)
             apply_relation_row<G, IT>(row, rel, rel_acc, ld, lane, cfg, ws, copies_folded);
-    } else if (b < rel_blocks + plan_blocks) {
-        const int64_t grp = (int64_t)(b - rel_blocks) * GPB + threadIdx.x / G, ngrp = (int64_t)plan_blocks * GPB;
+    } else if (b >= rel_blocks + scan_blocks && b < nb - 1) {
+        const int plan_blocks = nb - 1 - rel_blocks - scan_blocks;
+        const int64_t grp = (int64_t)(b - rel_blocks - scan_blocks) * GPB + threadIdx.x / G, ngrp = (int64_t)plan_blocks * GPB;
         const int64_t i1 = step_first[s + 1];
         for (int64_t i = step_first[s] + grp; i < i1; i += ngrp) {
             const uint4 rec = recs[i];                                 // {row, first entry, entries, first entry's value}
@@ -1300,9 +1301,11 @@ __global__ __launch_bounds__(256) void apply_step_plan(float *__restrict__ ent, 
             apply_one_row<G, IT, false>(ent + row * ld, ent_acc + row * ld, nullptr, nullptr, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
         }
     } else if (b < nb - 1) {
-        const int first = rel_blocks + plan_blocks;
+        // (the scan's blocks come BEFORE the plan's in the grid: its waves work through their flagged rows one group-load at a time --
+        //  the long pole late in training, when many negatives are active -- and should not wait for the plan's blocks to retire)
+        const int first = rel_blocks;
         const int wl = threadIdx.x & 63, gw = wl / G;
-        const int64_t wave = (int64_t)(b - first) * 4 + (threadIdx.x >> 6), nwave = (int64_t)(nb - 1 - first) * 4;
+        const int64_t wave = (int64_t)(b - first) * 4 + (threadIdx.x >> 6), nwave = (int64_t)scan_blocks * 4;
         const int64_t n_chunk = (n_ent + 63) / 64;
         const uint8_t *mine = inplan + (int64_t)s * n_ent;
         for (int64_t chunk = wave; chunk < n_chunk; chunk += nwave) {
@@ -1969,7 +1972,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                     const int relb = (int)std::max<int64_t>(oea::ceil_div(n_rel, 16), 1);
                     const int planb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(bound, 16), 1), 8192);
                     const int scanb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent, 256), 1), 4096);
-#define OEA_APPLYP16(ITX) oea::launch_events(apply_step_plan<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, planb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib)
+#define OEA_APPLYP16(ITX) oea::launch_events(apply_step_plan<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, scanb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib)
                     if (it16 <= 2) OEA_APPLYP16(2);
                     else if (it16 <= 4) OEA_APPLYP16(4);
                     else if (it16 == 5) OEA_APPLYP16(5);
@@ -1982,7 +1985,7 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                     const int planb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(bound, gpb), 1), 8192);
                     const int scanb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent, 256), 1), 4096);
                     oea::launch_events(apply_step_plan<G, IT>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc,
-                                       n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, planb, plan->recs, plan->vals_b,
+                                       n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, scanb, plan->recs, plan->vals_b,
                                        plan->step_first, plan_step, plan->inplan, plan->contrib);
                 }
             } else
