@@ -15,6 +15,8 @@
 // One 16-lane (k <= 16) or 64-lane group per positive, one lane per sampled slot: candidate
 // reads and membership probes of a try go out in parallel (the one-lane-per-positive version
 // was a 34 us dependent chain for 2,500 positives -- profiles/r01a_bench_kernel_stats.txt).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -64,9 +66,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int lane = threadIdx.x % G;
     const uint32_t step_in = step;
     const int64_t n_split_in = n_split;
-    // grid-stride over the positives: the epoch launch (side stream, a whole epoch to finish in) keeps to a few workgroups per CU
-    // so that the step kernels of the epoch that is RUNNING find their wave slots -- one workgroup per 16 positives held every
-    // slot of the chip for its 350 us and the scoring kernel beside it took 420 us instead of 40 (tools/r06/e.sh)
+    // grid-stride over the positives (the launch may be capped: OEA_SAMPLER_CAP, experiments)
     for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G; p < n_pos; p += (int64_t)gridDim.x * blockDim.x / G) {
     step = step_in;
     n_split = n_split_in;
@@ -75,14 +75,28 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     // exactly the stream of a per-batch call -- one launch samples the whole epoch.
     int64_t pl = p;                               // row index inside its batch
     if (seg_off) {
-        int lo = 0, hi = n_seg;                   // invariant: seg_off[lo] <= p < seg_off[hi]
+        // the wave's first row is looked up on the scalar unit (uniform addresses: s_load, no vector-memory round trips in front of
+        // everything else this thread does); a lane whose row lies past that batch's end -- a wave straddling a boundary -- bisects alone
+        const int64_t p0 = ((int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+        int lo = 0, hi = n_seg;                   // invariant: seg_off[lo] <= p0 < seg_off[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (seg_off[mid] <= p) lo = mid; else hi = mid;
+            if (seg_off[mid] <= p0) lo = mid; else hi = mid;
         }
-        pl = p - seg_off[lo];
-        n_split = seg_split[lo];
-        step += (uint32_t)lo;
+        int64_t first = seg_off[lo], split = seg_split[lo];           // scalar loads
+        int seg = lo;
+        if (p >= seg_off[lo + 1]) {
+            int l2 = lo;
+            hi = n_seg;
+            while (hi - l2 > 1) {
+                const int mid = (l2 + hi) >> 1;
+                if (seg_off[mid] <= p) l2 = mid; else hi = mid;
+            }
+            seg = l2; first = seg_off[l2]; split = seg_split[l2];
+        }
+        pl = p - first;
+        n_split = split;
+        step += (uint32_t)seg;
     }
     // positives [0, n_split) belong to KG1, the rest to KG2 (pos_batch1 + pos_batch2, batch.py:45)
     const oea_sampler_side &sd = pl < n_split ? side0 : side1;
@@ -209,8 +223,12 @@ static int sample_impl(const int32_t *pos, int64_t n_pos, int64_t n_split, int32
     if (rc != OEA_OK) return rc;
     if (n_pos == 0) return OEA_OK;
     hipStream_t st = oea::as_stream(stream);
-    // epoch mode = side stream: at most 512 workgroups (two per CU: a quarter of the wave slots) beside the running epoch's kernels
-    const int64_t cap = seg_off_dev ? 512 : ((int64_t)1 << 30);
+    // OEA_SAMPLER_CAP > 0: at most that many workgroups for the epoch launch (side stream).  Measured under the bench's protocol
+    // (20-step regions, device synchronised at both ends): no cap 0.095 ms per step, 512 workgroups 0.113-0.125, 128 0.20 -- what the
+    // side stream has not finished is waited for at the next synchronisation, so the shortest sampler wins although the step kernels
+    // that run beside it take 420 instead of 40 us (tools/r06/e.sh)
+    static const int64_t cap_env = [] { const char *e = getenv("OEA_SAMPLER_CAP"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t cap = (seg_off_dev && cap_env > 0) ? cap_env : ((int64_t)1 << 30);
     if (k <= 16)
         sample_negatives_kernel<16><<<(unsigned)std::min<int64_t>(oea::ceil_div(n_pos, 256 / 16), cap), 256, 0, st>>>(
             pos, n_pos, n_split, k, *side0, *side1, (uint32_t)seed, (uint32_t)(seed >> 32), step, pos_offset, max_try,

@@ -561,6 +561,53 @@ def perm_index(i, n, key):
             return x
 
 
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    return x
+
+
+def epoch_layout_perm(n, seed, epoch, second):
+    """The epoch's permutation of one KG's triple list (basic_model.py:234-235 random.shuffle(kgs.kg1/kg2.relation_triples_list)
+    draws it from Python's Mersenne Twister; here it is a keyed bijection so that it can be evaluated per element): 6 alternating
+    Feistel rounds on the ceil(log2 n)-bit index keyed by Philox4x32-10 of (epoch, list, 0x5eed, {0, 1}) under the seed,
+    cycle-walked into [0, n).  -> int64 [n], perm[i] = the list position read for shuffled position i."""
+    from . import cport
+    key2 = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    wa = cport.philox(np.array([epoch, 1 if second else 0, 0x5eed, 0], np.uint32), key2)
+    wb = cport.philox(np.array([epoch, 1 if second else 0, 0x5eed, 1], np.uint32), key2)
+    key = [wa[0], wa[1], wa[2], wa[3], wb[0], wb[1]]
+    bits = 1
+    while bits < 32 and (1 << bits) < n:
+        bits += 1
+    bits = max(bits, 2)
+    rbits = bits // 2
+    lbits = bits - rbits
+    lmask, rmask = np.uint32((1 << lbits) - 1), np.uint32((1 << rbits) - 1)
+    x = np.arange(n, dtype=np.uint32)
+    todo = np.ones(n, bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            v = x[todo]
+            l, r = v >> np.uint32(rbits), v & rmask
+            for q in range(0, 6, 2):
+                l = (l ^ _mix32(r ^ key[q])) & lmask
+                r = (r ^ _mix32(l ^ key[q + 1])) & rmask
+            v = (l << np.uint32(rbits)) | r
+            x[todo] = v
+            todo[todo] = v >= n
+    return x.astype(np.int64)
+
+
+def epoch_layout(t1, t2, slot, seed, epoch):
+    """batch.py:17-22 over the shuffled lists: layout row j = (KG1 list ++ KG2 list)[perm(slot[j])], each list permuted on its own."""
+    n1 = len(t1)
+    full = np.concatenate([t1, t2])
+    p = np.concatenate([epoch_layout_perm(n1, seed, epoch, False), n1 + epoch_layout_perm(len(t2), seed, epoch, True)]) if len(t2) else \
+        epoch_layout_perm(n1, seed, epoch, False)
+    return full[p[np.asarray(slot)]]
+
+
 def link_negatives(n_pos, k, seed, step, pos_links=None, ents1=None, ents2=None, nbr1=None, row1=None, nbr2=None,
                    row2=None, exclude=()):
     """alinet.py:988-1006: uniform -> k rounds of zip(sample(ents1, n_pos), sample(ents2, n_pos)); truncated -> per link

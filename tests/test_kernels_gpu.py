@@ -1515,6 +1515,7 @@ def test_epoch_layout_is_a_fresh_permutation_of_each_list(ops):
     of KG2's in every batch; the same (seed, epoch) gives the same layout, another epoch another one; positions are uniform
     (a triple's mean slot over 64 epochs is near the middle)."""
     from openea_amd.modules.train.batch import EpochBatches
+    from oracle import np_oracle as orc
     rng = np.random.RandomState(3)
     t1 = np.stack([rng.randint(0, 500, 4000), rng.randint(0, 9, 4000), np.arange(4000)], 1).astype(np.int32)       # unique by column 2
     t2 = np.stack([rng.randint(500, 900, 2500), rng.randint(0, 9, 2500), np.arange(4000, 6500)], 1).astype(np.int32)
@@ -1536,6 +1537,8 @@ def test_epoch_layout_is_a_fresh_permutation_of_each_list(ops):
         pos_sum[ids] += np.arange(len(ids))
         full = np.concatenate([t1, t2])
         assert np.array_equal(d, full[ids])                                                 # rows travel whole
+        if e < 4:                                                                           # the keyed permutation, restated in numpy
+            assert np.array_equal(d, orc.epoch_layout(t1, t2, b.slot.cpu().numpy(), 17, e + 1))
     assert not np.array_equal(layouts[0], layouts[1])
     b2 = EpochBatches(t1, t2, 1000)
     b2.shuffle(gen)

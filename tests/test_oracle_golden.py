@@ -602,3 +602,20 @@ def test_sampler_replay_equals_the_reference_run(golden_dir, case):
         assert rounds.max() == max_try                              # ... and the last round, which keeps true triples
         tset = set(map(tuple, tri.tolist()))
         assert any(tuple(x) in tset for x in ref.tolist())
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 4096, 4097, 100003])
+def test_epoch_layout_permutation_is_a_bijection(n):
+    """oracle.epoch_layout_perm (the restatement the device layout is held to; basic_model.py:234-235 shuffles with Python's MT,
+    any uniform permutation is the same algorithm): every index exactly once for any n, another epoch / list / seed another
+    permutation, and no trace of the identity (a position's image is uncorrelated with it)."""
+    from oracle import np_oracle as orc
+    p = orc.epoch_layout_perm(n, 17, 3, False)
+    assert np.array_equal(np.sort(p), np.arange(n))
+    if n >= 4096:
+        q, r, t = orc.epoch_layout_perm(n, 17, 4, False), orc.epoch_layout_perm(n, 17, 3, True), orc.epoch_layout_perm(n, 18, 3, False)
+        for other in (q, r, t):
+            assert (p == other).mean() < 0.01
+            assert abs(np.corrcoef(p, other)[0, 1]) < 0.05
+        assert abs(np.corrcoef(np.arange(n), p)[0, 1]) < 0.05
+        assert abs(np.abs(np.diff(p)).mean() / n - 1 / 3) < 0.02          # neighbours land a third of the list apart, as for uniform draws
