@@ -709,6 +709,13 @@ int oea_sparse_attn_fwd(const oea_attn_graph *g, const float *z, const float *v,
 int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v, const float *alpha,
                         const float *dout, int32_t dim, int32_t ld, float lrelu_slope, float *dz, float *dv,
                         float *workspace, int32_t phases, void *stream);
+/* The softmax half of the backward alone, for groups whose values are attached to ANOTHER pattern than the one they were
+ * normalised over (the third reading of alinet.py:670-676's tf.sparse_softmax on a non-canonical tensor, SURVEY H3: row softmax
+ * of the canonically sorted values, p-th value re-attached to the p-th index as fed): dz holds d alpha per edge on entry (the
+ * caller's oea_pair_dots over the as-fed pattern) and d z = alpha (d alpha - sum_group alpha d alpha) lrelu'(z) on exit, for
+ * the sub-segments [sub0, sub1).  Same kernels and summation order as oea_sparse_attn_bwd's OEA_ATTN_DZ phase. */
+int oea_sparse_attn_dz(const oea_attn_graph *g, const float *z, const float *alpha, float *dz, float lrelu_slope,
+                       float *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row-wise glue of the GNN approaches, fused (csrc/gnn_fused.hip): one pass forward, one pass backward, one wave per

@@ -200,6 +200,7 @@ PROTOTYPES = {
     "oea_sparse_attn_workspace_floats": (_sz, [C.POINTER(AttnGraph)]),
     "oea_sparse_attn_fwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "oea_sparse_attn_bwd": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "oea_sparse_attn_dz": (C.c_int, [C.POINTER(AttnGraph), _vp, _vp, _vp, _f32, _vp, _vp]),
     "oea_concat_l2n_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
     "oea_concat_l2n_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "oea_pair_loss_l2_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _vp, _vp]),

@@ -216,6 +216,79 @@ __global__ __launch_bounds__(256) void attn_bwd_dalpha_kernel(const int32_t *__r
     if (lane == 0) sub_c[s] = csum;
 }
 
+// B1, rows as float4: SIXTEEN lanes per edge (four edges of the sub-segment in flight per wave), every lane 16 B of the gathered
+// V row per load and IT4 loads in flight, the dot product finished by a 16-lane reduction.  The wave-per-edge form above issues
+// ld / 64 four-byte loads and a six-step wave reduction for EVERY edge: at d = 400 (AliNet's middle layer, 4.1 M two-hop edges)
+// it was 2.4 ms of the 3.6 ms backward beside a forward aggregate that gathers the same rows in 1.07 ms.
+// MASKED: dim % 4 != 0 -- the float4 that straddles dim is cut per element on both operands.
+template <int IT4, bool MASKED>
+__global__ __launch_bounds__(256) void attn_bwd_dalpha_rows_kernel(const int32_t *__restrict__ sub_ptr,
+                                                                   const int32_t *__restrict__ sub_seg,
+                                                                   const int32_t *__restrict__ seg_sub_ptr,
+                                                                   const int32_t *__restrict__ seg_row, int64_t sub0,
+                                                                   int64_t sub1, const int32_t *__restrict__ colidx,
+                                                                   const float *__restrict__ v, const float *__restrict__ alpha,
+                                                                   const float *__restrict__ dout, int dim, int ld,
+                                                                   float *__restrict__ dz, float *__restrict__ sub_c) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+    const int64_t s = sub0 + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= sub1) return;
+    const int e0 = sub_ptr[s], e1 = sub_ptr[s + 1];
+    const int g = sub_seg[s];
+    if (e1 - e0 == 1 && seg_sub_ptr[g + 1] - seg_sub_ptr[g] == 1) {     // a one-edge segment: d z = 0 exactly (see above)
+        if (lane == 0) { dz[e0] = 0.f; sub_c[s] = 0.f; }
+        return;
+    }
+    auto cut = [&](float4 x, int col) {
+        if (MASKED) {
+            if (col + 1 >= dim) x.y = 0.f;
+            if (col + 2 >= dim) x.z = 0.f;
+            if (col + 3 >= dim) x.w = 0.f;
+        }
+        return x;
+    };
+    const float *dor = dout + (int64_t)seg_row[g] * ld;
+    float4 d[IT4];
+#pragma unroll
+    for (int it = 0; it < IT4; ++it) {
+        const int col = (it * 16 + l16) * 4;
+        d[it] = col < dim ? cut(oea::ld4(dor + col), col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float csum = 0.f;
+    for (int chunk = e0; chunk < e1; chunk += W) {
+        const int cc = chunk + lane < e1 ? colidx[chunk + lane] : 0;           // the chunk's columns: one coalesced read
+        const int cnt = min(W, e1 - chunk);
+        for (int base = 0; base < cnt; base += 4) {
+            const int j = base + grp;
+            const bool on = j < cnt;
+            const int c = __shfl(cc, on ? j : 0, 64);
+            float p = 0.f;
+            if (on) {
+                const float *vr = v + (int64_t)c * ld;
+                float4 x[IT4];
+#pragma unroll
+                for (int it = 0; it < IT4; ++it) {
+                    const int col = (it * 16 + l16) * 4;
+                    x[it] = col < dim ? oea::ld4(vr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int it = 0; it < IT4; ++it) {
+                    const float4 y = cut(x[it], (it * 16 + l16) * 4);
+                    p = fmaf(d[it].x, y.x, p); p = fmaf(d[it].y, y.y, p); p = fmaf(d[it].z, y.z, p); p = fmaf(d[it].w, y.w, p);
+                }
+            }
+            p = grp_sum<16>(p);
+            if (on && l16 == 0) {
+                const int e = chunk + j;
+                dz[e] = p;
+                csum += alpha[e] * p;
+            }
+        }
+    }
+    csum = wave_sum(csum);                                                       // (only the groups' first lanes hold terms)
+    if (lane == 0) sub_c[s] = csum;
+}
+
 // B2 + B3: segment c (fixed order over its sub-segments), then d z of this sub-segment
 template <int G>
 __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_seg,
@@ -239,6 +312,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dz_kernel(const int32_t *__restr
         const float de = alpha[e] * (dz[e] - c);
         dz[e] = de * (z[e] > 0.f ? 1.f : slope);
     }
+}
+
+// B1': the sub-segment's partial c = sum alpha_e d alpha_e from d alpha GIVEN per edge (in dz) -- oea_sparse_attn_dz: the softmax
+// groups' edges do not share an output row there (values re-attached to another pattern), so the dots come from oea_pair_dots
+template <int G>
+__global__ __launch_bounds__(256) void attn_sub_c_kernel(const int32_t *__restrict__ sub_ptr, int64_t sub0, int64_t sub1,
+                                                         const float *__restrict__ alpha, const float *__restrict__ dalpha,
+                                                         float *__restrict__ sub_c) {
+    const int lane = threadIdx.x % G;
+    const int64_t s = sub0 + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    if (s >= sub1) return;
+    float c = 0.f;
+    for (int e = sub_ptr[s] + lane; e < sub_ptr[s + 1]; e += G) c += alpha[e] * dalpha[e];
+    c = grp_sum<G>(c);
+    if (lane == 0) sub_c[s] = c;
 }
 
 #define OEA_ATTN_DISPATCH(ld, CALL)                                      \
@@ -350,11 +438,25 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
     } else if ((phases & OEA_ATTN_DZ) && g->sub1 > g->sub0) {
         OEA_REQUIRE(z && v && dz, "null pointer");
         const unsigned grid = (unsigned)oea::ceil_div(g->sub1 - g->sub0, 4);
+        static const bool rows16 = [] { const char *e = getenv("OEA_ATTN_BWD_ROWS"); return !(e && e[0] == '0'); }();
+        const int it4 = (int)oea::ceil_div((int64_t)oea::ceil_div((int64_t)dim, 4), 16);
+        if (rows16 && it4 <= 20 && (((uintptr_t)v | (uintptr_t)dout) & 15) == 0) {
+#define ROWS(N, M)                                                                                                                  \
+    attn_bwd_dalpha_rows_kernel<N, M><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->seg_row, g->sub0, g->sub1, g->colidx, \
+                                                            v, alpha, dout, dim, ld, dz, sub_c)
+#define ROWS_IT(N) do { if (dim & 3) ROWS(N, true); else ROWS(N, false); } while (0)
+            if (it4 <= 1) ROWS_IT(1); else if (it4 <= 2) ROWS_IT(2); else if (it4 <= 4) ROWS_IT(4); else if (it4 <= 5) ROWS_IT(5);
+            else if (it4 <= 7) ROWS_IT(7); else if (it4 <= 8) ROWS_IT(8); else if (it4 <= 10) ROWS_IT(10); else if (it4 <= 13) ROWS_IT(13);
+            else if (it4 <= 16) ROWS_IT(16); else ROWS_IT(20);
+#undef ROWS_IT
+#undef ROWS
+        } else {
 #define CALL(IT)                                                                                                      \
     attn_bwd_dalpha_kernel<IT><<<grid, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->seg_row, g->sub0, g->sub1, g->colidx, v, alpha, \
                                                      dout, dim, ld, dz, sub_c)
-        OEA_ATTN_DISPATCH(ld, CALL);
+            OEA_ATTN_DISPATCH(ld, CALL);
 #undef CALL
+        }
         const int G = group_width(g);
         const unsigned gz = (unsigned)oea::ceil_div((g->sub1 - g->sub0) * G, 256);
         if (G == 1) attn_bwd_dz_kernel<1><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c, lrelu_slope, dz);
@@ -371,6 +473,27 @@ int oea_sparse_attn_bwd(const oea_attn_graph *g, const float *z, const float *v,
         return oea_spmm_csr(g->t_rowptr + g->t_row0, g->t_row, slot_vals, g->t_row1 - g->t_row0, dout, dim, ld, 0, nullptr,
                             dv + g->t_row0 * (int64_t)ld, ld, g->t_split, stream);
     }
+    return OEA_OK;
+}
+
+int oea_sparse_attn_dz(const oea_attn_graph *g, const float *z, const float *alpha, float *dz, float lrelu_slope, float *workspace,
+                       void *stream) {
+    const int rc = check_graph(g);
+    if (rc != OEA_OK) return rc;
+    OEA_REQUIRE(z && alpha && dz && workspace, "null pointer");
+    if (g->sub1 <= g->sub0) return OEA_OK;
+    hipStream_t st = oea::as_stream(stream);
+    float *sub_c = workspace;
+    const int G = group_width(g);
+    const unsigned gz = (unsigned)oea::ceil_div((g->sub1 - g->sub0) * G, 256);
+#define CALL(GW)                                                                                                                          \
+    do {                                                                                                                                  \
+        attn_sub_c_kernel<GW><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub0, g->sub1, alpha, dz, sub_c);                                        \
+        attn_bwd_dz_kernel<GW><<<gz, 256, 0, st>>>(g->sub_ptr, g->sub_seg, g->seg_sub_ptr, g->sub0, g->sub1, z, alpha, sub_c, lrelu_slope, dz); \
+    } while (0)
+    if (G == 1) CALL(1); else if (G == 8) CALL(8); else CALL(64);
+#undef CALL
+    OEA_CHECK_HIP(hipGetLastError());
     return OEA_OK;
 }
 

@@ -177,7 +177,9 @@ def _init_reorder(self, rows, cols, dev):
     the CANONICALLY sorted tensor and its p-th output value is attached to the p-th index of the tensor as fed."""
     perm = np.lexsort((cols, rows))                                            # sorted position -> edge as fed
     self.r_perm = torch.from_numpy(perm.astype(np.int64)).to(dev)
-    self.r_seg = torch.from_numpy(rows[perm]).to(dev)                           # softmax group of every sorted position
+    # the softmax groups: the rows of the sorted tensor, as the segment structures of csrc/sparse_attn.hip (statistics, alpha
+    # and d z only -- the aggregate, its transpose and the dots run over the AS-FED pattern below)
+    self.r_sorted = EdgeGraph(rows[perm], cols[perm], np.ones(len(rows), np.float32), self.shape, dev, grouping='row')
     self.r_fwd = _pattern_csr(rows, cols, self.shape[0], dev)                   # out = P . v,  P[rows[p], cols[p]] = alpha_sorted[p]
     self.r_bwd = _pattern_csr(cols, rows, self.shape[1], dev)                   # dv = P^T . dout
     self.r_rows32, self.r_cols32 = ops.to_ids(rows, dev), ops.to_ids(cols, dev)
@@ -188,35 +190,40 @@ EdgeGraph._init_reorder = _init_reorder
 
 
 class ReorderAttnFn(torch.autograd.Function):
-    """sparse attention under grouping='reorder': a per-row softmax of the sorted logits (1-D torch segment ops: plumbing
-    on [nnz] vectors) whose values are re-attached to the as-fed pattern; the aggregate, its transpose and the per-edge
-    dots dout[row] . v[col] are the HIP kernels (oea_spmm_csr, oea_pair_dots)."""
+    """sparse attention under grouping='reorder': the per-row softmax of the SORTED logits is csrc/sparse_attn.hip's segment
+    softmax over the sorted pattern's rows (oea_sparse_attn_fwd, OEA_ATTN_ALPHA) and its backward oea_sparse_attn_dz; the values
+    are attached position by position to the as-fed pattern, over which the aggregate, its transpose (oea_spmm_csr) and the
+    per-edge dots dout[row] . v[col] (oea_pair_dots) run.  torch only permutes the [nnz] logit / gradient vectors."""
 
     @staticmethod
     def forward(ctx, z, v, g, slope):
         v = v.contiguous()
-        zs = torch.nn.functional.leaky_relu(z[g.r_perm], slope)
-        mx = torch.full((g.shape[0],), -torch.inf, device=z.device).scatter_reduce(0, g.r_seg, zs, 'amax')
-        e = torch.exp(zs - mx[g.r_seg])
-        alpha = e / torch.zeros(g.shape[0], device=z.device).index_add_(0, g.r_seg, e)[g.r_seg]
+        zs = z[g.r_perm].contiguous()
+        gs = g.r_sorted.attn
+        _, alpha = ops.sparse_attn_fwd(gs, zs, v, v.shape[1], slope, g.shape[0], out=zs, phases=ops.ATTN_ALPHA)   # (out unused)
+        sh = g.r_sorted.shard
+        if sh is not None:                         # row-sharded job: this rank normalised its block of groups
+            from . import dist as mdist
+            mdist.allgather_blocks(alpha, sh['edge_bounds'])
         rowptr, colidx, slot_edge, _ = g.r_fwd
         out = ops.spmm_csr(rowptr, colidx, alpha[slot_edge].contiguous(), v, v.shape[1], split=g.r_split[0])
         ctx.g, ctx.slope = g, slope
-        ctx.save_for_backward(z, v, alpha)
+        ctx.save_for_backward(zs, v, alpha)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        z, v, alpha = ctx.saved_tensors
+        zs, v, alpha = ctx.saved_tensors
         g, dout = ctx.g, dout.contiguous()
         rowptr, colidx, slot_edge, _ = g.r_bwd
         dv = ops.spmm_csr(rowptr, colidx, alpha[slot_edge].contiguous(), dout, dout.shape[1], split=g.r_split[1])
         dalpha = ops.pair_dots(dout, v, v.shape[1], g.r_rows32, g.r_cols32)         # position p: the edge as fed
-        s = torch.zeros(g.shape[0], device=z.device).index_add_(0, g.r_seg, alpha * dalpha)
-        dzs = alpha * (dalpha - s[g.r_seg])
-        zs = z[g.r_perm]
-        dzs = torch.where(zs > 0, dzs, dzs * ctx.slope)
-        dz = torch.empty_like(z)
+        dzs = ops.sparse_attn_dz_(g.r_sorted.attn, zs, alpha, dalpha, ctx.slope, v.shape[1])
+        sh = g.r_sorted.shard
+        if sh is not None:
+            from . import dist as mdist
+            mdist.allgather_blocks(dzs, sh['edge_bounds'])
+        dz = torch.empty_like(dzs)
         dz[g.r_perm] = dzs
         return dz, dv, None, None
 

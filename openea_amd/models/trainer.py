@@ -642,13 +642,31 @@ def _entity_ids_on_device(entity_list, device):
     return ids
 
 
+def refresh_is_sharded(n, k, world_size):
+    """Does a refresh of n entities' k nearest neighbours on world_size ranks shard its query rows?  A rank's row block against the
+    whole table is a queries != candidates search: the fp32 list path (46 ms per 100,000^2 pairs, bench r04), followed by the
+    all-gather of the [n, k] int32 table (priced at 300 GB/s of all-link xGMI).  The symmetric search of the whole table (upper
+    triangle only, bf16 split, 13 ms at 100,000^2) run by EVERY rank needs no exchange and returns the same sets on all of them:
+    it wins while world_size is small (2-3 ranks at the 100K shape).  OEA_REFRESH_MODE = shard | replicate overrides."""
+    if world_size <= 1:
+        return False
+    mode = os.environ.get("OEA_REFRESH_MODE", "")
+    if mode in ("shard", "replicate"):
+        return mode == "shard"
+    if n < 12288:                 # below the symmetric stream path's range (csrc/topk.hip plan_stream): nothing to replicate cheaply
+        return True
+    scale = (n / 1.0e5) ** 2
+    sharded_ms = 46.0 * scale / world_size + 4.0 * n * k * (world_size - 1) / world_size / 300.0e6
+    return sharded_ms < 13.0 * scale
+
+
 def refresh_neighbours(ent, entity_list, k):
     """Truncated-sampling refresh (basic_model.py:267-289): embeddings of the KG's entities
     (normalised lookup) -> k nearest entity ids per entity, all on the device."""
     ids = _entity_ids_on_device(entity_list, ent.var.device)
     emb = ent.lookup(ids)
     from . import dist as mdist
-    if mdist.world()[1] > 1:      # query rows sharded over the ranks, table all-gathered
+    if refresh_is_sharded(emb.shape[0], k, mdist.world()[1]):      # query rows sharded over the ranks, table all-gathered
         return mdist.sharded_neighbours(emb, ent.dim, ids, k,
                                         lambda q, cand, d, kk, id_map: ops.topk_inner(q.contiguous(), cand, d, kk, id_map=id_map))
     return neighbours_device(emb, ent.dim, ids, k)

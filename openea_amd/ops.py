@@ -1168,6 +1168,13 @@ def sparse_attn_bwd(g, z, v, alpha, dout, dim, slope, dz=None, dv=None, phases=A
     return dz, dv
 
 
+def sparse_attn_dz_(g, z, alpha, dalpha, slope, ld):
+    """d alpha per edge (overwritten) -> d z per edge, over the graph's softmax groups (oea_sparse_attn_dz)"""
+    ws = _attn_ws(g, ld, z.device)
+    check(lib().oea_sparse_attn_dz(C.byref(g), _p(z), _p(alpha), _p(dalpha), float(slope), _p(ws), _stream()))
+    return dalpha
+
+
 def adam_dense_(param, grad, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     check(lib().oea_adam_dense(_p(param), _p(grad), _p(m), _p(v), param.numel(), float(lr), float(beta1), float(beta2),
                                float(eps), int(t), _stream()))

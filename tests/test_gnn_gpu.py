@@ -24,7 +24,7 @@ def _graph(rng, n, avg_deg, with_dups=True):
 
 
 @pytest.mark.parametrize("grouping", ["row", "runs"])
-@pytest.mark.parametrize("d", [32, 100, 400])
+@pytest.mark.parametrize("d", [32, 100, 400, 1200])
 def test_sparse_attention_matches_oracle(ops, grouping, d):
     from openea_amd.models.graph_ops import EdgeGraph, sparse_attention
     from oracle import np_oracle as orc
@@ -64,6 +64,70 @@ def test_sparse_attention_matches_oracle(ops, grouping, d):
     # rows sum to one per segment
     a = orc.segment_softmax(np.where(z_h > 0, z_h, 0.2 * z_h), seg_ptr)
     assert np.allclose(np.add.reduceat(a, seg_ptr[:-1][np.diff(seg_ptr) > 0]), 1.0)
+
+
+def test_sparse_attention_backward_ignores_padding_columns(ops):
+    """the C entry takes dim < ld (rows padded to a multiple of 4): d z must not see the padding, whatever it holds -- here NaN in
+    both gathered operands, dim = 75 in rows of 76 (the float4 that straddles dim is cut per element) and dim = 72 in rows of 76
+    (a whole float4 of padding)."""
+    from openea_amd.models.graph_ops import EdgeGraph
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(11)
+    n = 300
+    rows, cols, vals = _graph(rng, n, 5)
+    g = EdgeGraph(rows, cols, vals, (n, n), ops.device(), grouping="row")
+    z_h = rng.standard_normal(g.nnz).astype(np.float32)
+    seg_ptr, seg_row, col = g.seg_ptr_host, g.seg_row_host, g.e_colidx.cpu().numpy()
+    for dim in (75, 72):
+        v_h = rng.standard_normal((n, 76)).astype(np.float32)
+        w_h = rng.standard_normal((n, 76)).astype(np.float32)
+        v_h[:, dim:] = np.nan
+        w_h[:, dim:] = np.nan
+        z, v, w = (torch.tensor(a, device=g.dev) for a in (z_h, v_h, w_h))
+        _, alpha = orc.sparse_attn_forward(z_h, v_h[:, :dim], seg_ptr, seg_row, col, n)
+        dz_ref, _ = orc.sparse_attn_backward(z_h, v_h[:, :dim], alpha, w_h[:, :dim], seg_ptr, seg_row, col)
+        dz, _ = ops.sparse_attn_bwd(g.attn, z, v, torch.tensor(alpha.astype(np.float32), device=g.dev), w, dim, 0.2, phases=ops.ATTN_DZ)
+        np.testing.assert_allclose(dz.cpu().numpy(), dz_ref, rtol=0, atol=3e-5 * max(1.0, np.abs(dz_ref).max()))
+
+
+@pytest.mark.parametrize("d", [48, 400])
+def test_sparse_attention_reorder_equals_fp64_composition(ops, d):
+    """grouping='reorder' (third reading of alinet.py:670-676): row softmax of the canonically SORTED logits, the p-th
+    value attached to the p-th index AS FED.  The device path (segment softmax kernels over the sorted pattern, oea_sparse_attn_dz,
+    aggregate / transpose / pair dots over the as-fed pattern) against the same composition written with torch fp64 autograd on
+    the host; column-major feed order with a hub column and rows cut into several sub-segments."""
+    from openea_amd.models.graph_ops import EdgeGraph, sparse_attention
+    rng = np.random.RandomState(d)
+    n = 400
+    rows, cols, vals = _graph(rng, n, 6)
+    cols[50:350] = 3
+    order = np.lexsort((rows, cols))                               # as fed: column-major (alinet.py's adjacency)
+    rows, cols = rows[order], cols[order]
+    EdgeGraph.SUB = 64
+    g = EdgeGraph(rows, cols, np.ones(len(rows), np.float32), (n, n), ops.device(), grouping="reorder")
+    EdgeGraph.SUB = 256
+    z_h = rng.standard_normal(g.nnz) * 2
+    v_h = rng.standard_normal((n, d))
+    w_h = rng.standard_normal((n, d))
+    z = torch.tensor(z_h, dtype=torch.float32, device=g.dev, requires_grad=True)
+    v = torch.tensor(v_h, dtype=torch.float32, device=g.dev, requires_grad=True)
+    out = sparse_attention(g, z, v, slope=0.2)
+    (out * torch.tensor(w_h, dtype=torch.float32, device=g.dev)).sum().backward()
+    # fp64 composition
+    perm = torch.from_numpy(np.lexsort((cols, rows)))
+    seg = torch.from_numpy(rows)[perm]
+    z64 = torch.tensor(z_h.astype(np.float32).astype(np.float64), requires_grad=True)
+    v64 = torch.tensor(v_h.astype(np.float32).astype(np.float64), requires_grad=True)
+    zs = torch.nn.functional.leaky_relu(z64[perm], 0.2)
+    mx = torch.full((n,), -np.inf, dtype=torch.float64).scatter_reduce(0, seg, zs.detach(), "amax")
+    e = torch.exp(zs - mx[seg])
+    alpha = e / torch.zeros(n, dtype=torch.float64).index_add(0, seg, e)[seg]
+    ref = torch.zeros(n, d, dtype=torch.float64).index_add(0, torch.from_numpy(rows), alpha[:, None] * v64[torch.from_numpy(cols)])
+    (ref * torch.tensor(w_h.astype(np.float32).astype(np.float64))).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    dz_ref, dv_ref = z64.grad.numpy(), v64.grad.numpy()
+    np.testing.assert_allclose(z.grad.cpu().numpy(), dz_ref, rtol=0, atol=3e-5 * max(1.0, np.abs(dz_ref).max()))
+    np.testing.assert_allclose(v.grad.cpu().numpy(), dv_ref, rtol=0, atol=2e-5 * max(1.0, np.abs(dv_ref).max()))
 
 
 def test_sparse_attention_single_edge_runs(ops):
