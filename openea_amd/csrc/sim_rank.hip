@@ -1394,13 +1394,70 @@ __device__ __forceinline__ void stream_tile(const f32x16 (&acc)[2][2], int c0, i
     }
 }
 
+// ---- the same records without a branch per accumulator (round 6) --------------------------------------------------------------------
+// stream_tile's `if (pr)` is taken for 4 of 5 accumulators (k / n = 2 %: some lane of the 64 passes), each time through
+// s_and_saveexec / s_cbranch / 64-bit address arithmetic / a second compare against the capacity: ~190 cycles per accumulator and
+// side when nothing overlaps it (measured with one wave per SIMD: 24 K cycles of epilogue beside 3 K of MFMA per tile).  Here one
+// accumulator and side is ONE straight block: v_cmpx puts the predicate into EXEC, the slot is mbcnt(EXEC), the record leaves through
+// a raw buffer whose num_records IS the stream's capacity (the hardware drops what does not fit: positions, and so the redo pass,
+// are unchanged), the position advances on the scalar unit, EXEC is restored.  5 VALU + 2 stores + 3 SALU, no branch.
+template <uint32_t TAG_ADD>
+__device__ __forceinline__ void stream_append(float v, float cut, uint32_t tag_base, __amdgpu_buffer_rsrc_t srd, uint32_t &pos,
+                                              unsigned long long full) {
+    // (the record as ONE 8-byte store from a register pair was slower: 12.4 against 11.6 ms per 100,000^2 search -- the pair costs a
+    //  copy of the accumulator for all lanes and registers the kernel does not have)
+    uint32_t c, t, cnt;
+    asm volatile(
+        "v_cmpx_ge_f32 vcc, %[v], %[cut]\n\t"
+        "s_nop 1\n\t"                                      // a VALU result in a scalar register (EXEC) read as DATA by the next VALU: 2 wait states
+        "v_mbcnt_lo_u32_b32 %[c], exec_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[c], exec_hi, %[c]\n\t"
+        "v_lshl_add_u32 %[c], %[c], 3, %[pos]\n\t"
+        "v_add_u32 %[t], %[ta], %[tb]\n\t"
+        "buffer_store_dword %[v], %[c], %[srd], 0 offen\n\t"
+        "buffer_store_dword %[t], %[c], %[srd], 0 offen offset:4\n\t"
+        "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+        "s_lshl3_add_u32 %[pos], %[cnt], %[pos]\n\t"
+        "s_mov_b64 exec, %[full]\n\t"
+        : [c] "=&v"(c), [t] "=&v"(t), [cnt] "=&s"(cnt), [pos] "+s"(pos)
+        : [v] "v"(v), [cut] "v"(cut), [tb] "v"(tag_base), [ta] "n"(TAG_ADD), [srd] "s"(srd), [full] "s"(full)
+        : "vcc", "scc", "memory");
+}
+
+// interior tiles (every candidate row exists); rj[tn] = rtag[tn] + c0 + jl0 and cq[tn] = (jl0 << 24) | qidx[tn] carry the lane's part of
+// the second record word, the (tm, r) part is a constant of the step I = 16 tm + r
+template <int I>
+__device__ __forceinline__ void stream_fast_steps(const f32x16 (&acc)[2][2], const float (&th)[2], const uint32_t (&rj)[2], const uint32_t (&cq)[2],
+                                                  float my_tc, bool upper, __amdgpu_buffer_rsrc_t srd_r, __amdgpu_buffer_rsrc_t srd_c,
+                                                  uint32_t &rpos, uint32_t &cpos, unsigned long long full) {
+    if constexpr (I < 32) {
+        constexpr int tm = I >> 4, r = I & 15;
+        constexpr uint32_t jc = (uint32_t)(tm * 32 + (r & 3) + 8 * (r >> 2));
+        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_tc), tm * 16 + r));
+        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_tc), 32 + tm * 16 + r));
+        const float tc = upper ? t1 : t0;
+        stream_append<jc>(acc[tm][0][r], th[0], rj[0], srd_r, rpos, full);
+        stream_append<(jc << 24)>(acc[tm][0][r], tc, cq[0], srd_c, cpos, full);
+        stream_append<jc>(acc[tm][1][r], th[1], rj[1], srd_r, rpos, full);
+        stream_append<(jc << 24)>(acc[tm][1][r], tc, cq[1], srd_c, cpos, full);
+        stream_fast_steps<I + 1>(acc, th, rj, cq, my_tc, upper, srd_r, srd_c, rpos, cpos, full);
+    }
+}
+
+__device__ __forceinline__ void stream_tile_fast(const f32x16 (&acc)[2][2], const float (&th)[2], const uint32_t (&rj)[2], const uint32_t (&cq)[2],
+                                                 float my_tc, int lane, __amdgpu_buffer_rsrc_t srd_r, __amdgpu_buffer_rsrc_t srd_c,
+                                                 uint32_t &rpos, uint32_t &cpos) {
+    const unsigned long long full = __builtin_amdgcn_ballot_w64(true);
+    stream_fast_steps<0>(acc, th, rj, cq, my_tc, lane >= 32, srd_r, srd_c, rpos, cpos, full);
+}
+
 // NCH = Kp / 32 in {1..4}: the query tile's operand in registers (tile_pipeline_bf16_breg); 0: both operands through LDS
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     uint2 *__restrict__ row_streams, int rcap, uint2 *__restrict__ col_streams, int ccap, int32_t *__restrict__ row_cnt,
     int32_t *__restrict__ col_off, int lp1, uint8_t *__restrict__ row_fail, const float *__restrict__ tol_ptr,
-    int32_t *__restrict__ redo_cnt, int4 *__restrict__ redo, int redo_cap) {
+    int32_t *__restrict__ redo_cnt, int4 *__restrict__ redo, int redo_cap, int fast) {
     __shared__ __attribute__((aligned(16))) float lds[NCH > 0 ? 4 * TILE * PLD : 4 * TILE * LDS_LD];
     float *As = lds, *Bs = lds + 2 * TILE * LDS_LD;
     const int4 item = items[blockIdx.x];                           // (qt, ct_begin, ct_end, segment group)
@@ -1432,6 +1489,15 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const int jl0 = wm * 64 + 4 * half;
     const int my_jl = jl0 + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
     uint32_t rpos = 0, cpos = 0;                                   // wave-uniform, bytes
+    auto uniform_ptr = [](char *p) {                              // the wave's stream base, on the scalar unit
+        const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+        return reinterpret_cast<char *>(((uintptr_t)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(rs), 0, (int)rbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(cs), 0, (int)cbytes, 0x00020000);
+    const uint32_t cq[2] = {((uint32_t)jl0 << 24) | qidx[0], ((uint32_t)jl0 << 24) | qidx[1]};
+    const bool fast_on = fast != 0;
     auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
         const int ct = item.y + (int)t;
         const int64_t c0 = (int64_t)ct * TILE;
@@ -1451,7 +1517,10 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
                         if (qi[tn] >= n) acc[tm][tn][r] = -INFINITY;
         }
         const uint32_t r0 = rpos, p0 = cpos;
-        if (c0 + TILE <= n) stream_tile<true>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
+        if (c0 + TILE <= n && fast_on) {
+            const uint32_t rj[2] = {rtag[0] + (uint32_t)((int)c0 + jl0), rtag[1] + (uint32_t)((int)c0 + jl0)};
+            stream_tile_fast(acc, th, rj, cq, my_tc, lane, srd_r, srd_c, rpos, cpos);
+        } else if (c0 + TILE <= n) stream_tile<true>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
         else stream_tile<false>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
         if (rpos > rbytes || cpos > cbytes) {                        // wave-uniform, rare: records of this tile did not fit
             int slot = 0;
@@ -3405,11 +3474,13 @@ int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     // (the B-in-registers pipeline, NCH = Kp / 32, spills in this kernel -- its epilogue already takes the register file: 13.3 -> 20.8 ms
     //  at 100,000 rows; it stays on the LDS pipeline.  OEA_TOPK_STREAM_NCH = 1..4 selects the register form for experiments.)
     static const int nch_env = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return e ? atoi(e) : 0; }();
+    // OEA_TOPK_STREAM_FAST=0: the branching epilogue (stream_tile) on every tile -- the ablation of stream_tile_fast
+    static const int fast_env = [] { const char *e = getenv("OEA_TOPK_STREAM_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
 #define OEA_STREAM_LAUNCH(N)                                                                                                          \
     topk_stream_sym_kernel<N><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),            \
                                                                  static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), \
                                                                  ccap, row_cnt, col_off, lp1, row_fail, tol_dev, redo_cnt,              \
-                                                                 static_cast<int4 *>(redo), redo_cap)
+                                                                 static_cast<int4 *>(redo), redo_cap, fast_env)
     if (nch_env == 4 && op.kp == 128) OEA_STREAM_LAUNCH(4);
     else OEA_STREAM_LAUNCH(0);
 #undef OEA_STREAM_LAUNCH
