@@ -56,6 +56,11 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
                             int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
                             uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st);
 
+int topk_append_bf16_prepare(const float *q, int64_t nq, int ldq, const float *c, int64_t nc, int ldc, int dim, float *tol_dev,
+                             hipStream_t st, const float **qs, const float **cs, int *kp);
+void topk_append_bf16_launch(const float *qs, int64_t nq, const float *cs, int64_t nc, int kp, int dim, const float *thr, int cap,
+                             int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill,
+                             int sp_cap, const float *tol_dev, hipStream_t st);
 int topk_append_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, int nseg,
                          int cap, float *list_vals, int32_t *list_cols, int32_t *counts, int T, int ccap, void *clists,
                          uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, float *tol_dev, hipStream_t st);

@@ -1117,11 +1117,15 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
 // N x N strip in HBM.  Values and columns go to two arrays (one dword store each from the register that holds them) at a
 // 32-bit byte offset from a wave-uniform base.  counts[q * nseg + seg] may exceed cap: the entries past cap went to the
 // query's spill list (one global atomic each; rare unless the neighbours of a row crowd into one candidate range).
-template <bool PACKED>
+// BF16 (round 6): q / c are the hi / lo split packed rows (ldq = ldc = Kp), the sweep runs on the bf16 matrix pipe and the lists hold
+// every pair with v~ >= thr - tol (tol = *tol_ptr bounds |v~ - v|): list_select_kernel decides the neighbourhood of the k-th value
+// with exact chains -- the same sets as the fp32 sweep
+template <bool PACKED, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr, int tiles_per_chunk, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols,
-    int32_t *__restrict__ counts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap) {
+    int32_t *__restrict__ counts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap,
+    const float *__restrict__ tol_ptr = nullptr) {
     __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     for (int tn = 0; tn < 2; ++tn) {
         const int ql = wn * 64 + tn * 32 + (lane & 31);
         qi[tn] = q0 + ql;
-        th[tn] = qi[tn] < nq ? thr[qi[tn]] : INFINITY;            // padding rows never append
+        th[tn] = qi[tn] < nq ? thr[qi[tn]] - (BF16 ? *tol_ptr : 0.f) : INFINITY;            // padding rows never append
         bbeg[tn] = boff[tn] = 4u * (uint32_t)((ql * nseg + sidx) * cap);
         blast[tn] = boff[tn] + 4u * (uint32_t)(cap - 1);          // survivors past cap overwrite the last slot; boff keeps counting
     }
@@ -1171,15 +1175,16 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
             }
         }
     };
-    run_tiles<PACKED>(
-        c, nc, ldc, q, nq, ldq, dim, q0, ct_end > ct_begin ? ct_end - ct_begin : 0,
-        [=](int64_t t) { return (ct_begin + t) * TILE; }, As, Bs,
-        [&](int64_t t, f32x16 (&acc)[2][2]) {
-            const int64_t c0 = (ct_begin + t) * TILE;
-            const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
-            if (c0 + TILE <= nc) sweep(acc, jb, 0x7fffffff);      // interior tile: the bound folds away
-            else sweep(acc, jb, (int)nc);
-        });
+    auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
+        const int64_t c0 = (ct_begin + t) * TILE;
+        const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
+        if (c0 + TILE <= nc) sweep(acc, jb, 0x7fffffff);          // interior tile: the bound folds away
+        else sweep(acc, jb, (int)nc);
+    };
+    const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
+    auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
+    if constexpr (BF16) tile_pipeline_bf16<false>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
         if (qi[tn] < nq) counts[qi[tn] * nseg + sidx] = (int32_t)((boff[tn] - bbeg[tn]) >> 2);
@@ -3512,6 +3517,28 @@ void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc
     const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);       // chunks planned by topk_append_chunks
     topk_append_kernel<true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
         qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, static_cast<uint2 *>(spill), sp_cap);
+}
+// the same on the bf16 hi / lo split of both tables (queries != candidates): _prepare packs them (slots 3 / 4) and leaves the bound on
+// |v~ - v| in tol_dev[0] (max row norms of the two tables in tol_dev[1], [2]); _launch sweeps a block of query rows
+int topk_append_bf16_prepare(const float *q, int64_t nq, int ldq, const float *c, int64_t nc, int ldc, int dim, float *tol_dev,
+                             hipStream_t st, const float **qs, const float **cs, int *kp) {
+    PackedOp pq, pc;
+    int rc = pack_operand_bf16(3, q, nq, ldq, dim, st, &pq);
+    if (rc == OEA_OK) rc = pack_operand_bf16(4, c, nc, ldc, dim, st, &pc);
+    if (rc != OEA_OK) return rc;
+    OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 16, st));
+    row_norm_max_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(q, nq, ldq, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
+    row_norm_max_kernel<<<(unsigned)ceil_div(nc, 256), 256, 0, st>>>(c, nc, ldc, dim, reinterpret_cast<unsigned *>(tol_dev) + 2);
+    csls_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim, false));
+    *qs = pq.p; *cs = pc.p; *kp = pq.kp;
+    return OEA_OK;
+}
+void topk_append_bf16_launch(const float *qs, int64_t nq, const float *cs, int64_t nc, int kp, int dim, const float *thr, int cap,
+                             int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill,
+                             int sp_cap, const float *tol_dev, hipStream_t st) {
+    const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);
+    topk_append_kernel<true, true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
+        qs, nq, kp, cs, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, static_cast<uint2 *>(spill), sp_cap, tol_dev);
 }
 }  // namespace oea
 

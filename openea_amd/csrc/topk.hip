@@ -843,7 +843,8 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                                                                    const float *__restrict__ exact_src, int ld_src, int dim,
                                                                    const float *__restrict__ tol_ptr,
                                                                    const uint2 *__restrict__ compact, const int32_t *__restrict__ compact_cnt,
-                                                                   int compact_cap, const uint8_t *__restrict__ row_fail) {
+                                                                   int compact_cap, const uint8_t *__restrict__ row_fail,
+                                                                   const float *__restrict__ exact_q = nullptr, int ld_q = 0) {
     // compact != NULL: the row's survivors are ONE list of compact_cnt[row] (value, column) pairs (topk_bucket_kernel); rows a
     // full stream or a full list may have lost entries of (row_fail) go to the strip fallback
     // tol_ptr != NULL: the list values are APPROXIMATE (v~ of the bf16 sweep, |v~ - v| <= tol = *tol_ptr) and the lists hold every
@@ -851,6 +852,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     // of t~, so  v~ > t~ + 2 tol  =>  v > t: selected;   v~ < t~ - 2 tol  =>  v < t: not selected;  the band in between (a dozen
     // entries) is decided by the EXACT k-ordered chains against rows of exact_src, (value desc, column asc) as everywhere.
     // The band must lie inside the lists (t~ - 2 tol >= thr - tol), else the row goes to the strip fallback.
+    // exact_q != NULL: the query rows of this launch come from another table than the candidates (row r of the launch = exact_q + r ld_q)
     // stop_after (experiments, OEA_TOPK_SELECT_STOP): leave after phase 1 (lengths + scan), 2 (gather), 3 (histogram + bucket),
     // 4 (threshold bucket ranked), 5 (bitmap set); 0 = run to the end.  Results are garbage when it is set.
     // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
                 const int nband = s_nband, need2 = k - n_above;
                 fail = lo2 < lo || nband > kCandCap || need2 < 0 || need2 > nband;      // block-uniform
                 if (!fail) {
-                    const float *__restrict__ a = exact_src + row * (int64_t)ld_src;
+                    const float *__restrict__ a = exact_q ? exact_q + row * (int64_t)ld_q : exact_src + row * (int64_t)ld_src;
                     for (int i = tid; i < nband; i += SEL_THREADS) {
                         const float *__restrict__ b = exact_src + (int64_t)c_col[i] * ld_src;
                         float acc = 0.f;
@@ -1921,6 +1923,15 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         int kps = 0;
         int rc = oea::pack_rows(2, c, kSample, ldc * (int)lp.stride, dim, st, &sp, &kps);   // every stride-th candidate row
         if (rc != OEA_OK) return rc;
+        // the sweep on the bf16 hi / lo split of both tables (3 / 16 of the fp32 matrix time; OEA_TOPK_BF16=0: the exact fp32 sweep):
+        // approximate list values, the select decides the neighbourhood of the k-th value with exact chains -- same sets
+        float *tol_dev = reinterpret_cast<float *>(w + lp.off_nfail + 64);
+        const float *qs = nullptr, *cs = nullptr;
+        int kps2 = 0;
+        if (bf16_sweep) {
+            rc = oea::topk_append_bf16_prepare(q, nq, ldq, c, nc, ldc, dim, tol_dev, st, &qs, &cs, &kps2);
+            if (rc != OEA_OK) return rc;
+        }
         for (int64_t r0 = 0; r0 < nq; r0 += lp.rows_per) {
             const int64_t rows = std::min<int64_t>(lp.rows_per, nq - r0);
             oea::sim_inner_store_packed(qp + r0 * kp, rows, sp, kSample, kp, dim, sstrip, kSample, st);
@@ -1928,13 +1939,18 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
             OEA_CHECK_HIP(hipMemsetAsync(spill_cnt, 0, sizeof(int32_t) * (size_t)rows, st));
-            oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, spill_cnt,
-                                    spill, kSpillCap, st);
+            if (bf16_sweep)
+                oea::topk_append_bf16_launch(qs + r0 * kps2, rows, cs, nc, kps2, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts,
+                                             spill_cnt, spill, kSpillCap, tol_dev, st);
+            else
+                oea::topk_append_packed(qp + r0 * kp, rows, cp, nc, kp, dim, thr, lp.cap, lp.chunks, list_vals, list_cols, counts, spill_cnt,
+                                        spill, kSpillCap, st);
             list_select_kernel<<<(unsigned)rows, SEL_THREADS, select_lds_bytes(nc), st>>>(
                 list_vals, list_cols, counts, thr, lp.nseg, lp.cap, nc,
                                                                       k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, nullptr, nullptr, 0, 0,
                                                                       spill_cnt, static_cast<const uint2 *>(spill), select_stop(),
-                                                                      nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr);
+                                                                      bf16_sweep ? c : nullptr, ldc, dim, bf16_sweep ? tol_dev : nullptr,
+                                                                      nullptr, nullptr, 0, nullptr, bf16_sweep ? q + r0 * (int64_t)ldq : nullptr, ldq);
             // rows the select gave up on: through the strip path, in batches, inside the (now dead) list storage
             rc = redo_failed_rows(qp + r0 * kp, kp, cp, nc, dim, k, id_map, out_idx + r0 * (int64_t)k, fail_rows, n_fail, list_vals,
                                   2 * lp.cols_off, lp.ld, st);

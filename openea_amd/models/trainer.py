@@ -644,10 +644,11 @@ def _entity_ids_on_device(entity_list, device):
 
 def refresh_is_sharded(n, k, world_size):
     """Does a refresh of n entities' k nearest neighbours on world_size ranks shard its query rows?  A rank's row block against the
-    whole table is a queries != candidates search: the fp32 list path (46 ms per 100,000^2 pairs, bench r04), followed by the
-    all-gather of the [n, k] int32 table (priced at 300 GB/s of all-link xGMI).  The symmetric search of the whole table (upper
-    triangle only, bf16 split, 13 ms at 100,000^2) run by EVERY rank needs no exchange and returns the same sets on all of them:
-    it wins while world_size is small (2-3 ranks at the 100K shape).  OEA_REFRESH_MODE = shard | replicate overrides."""
+    whole table is a queries != candidates search (the general list path on the bf16 split: 9.9 ms per 50,000 x 100,000 rows,
+    tools/r06/m.sh), followed by the all-gather of the [n, k] int32 table (priced at 300 GB/s of all-link xGMI).  The symmetric
+    search of the whole table (upper triangle only, 11.6 ms at 100,000^2) run by EVERY rank needs no exchange and returns the same
+    sets on all of them.  Sharding pays from two ranks on at the 100K shape (9.9 + 1.3 against 11.6 ms), not below the symmetric
+    stream path's range.  OEA_REFRESH_MODE = shard | replicate overrides."""
     if world_size <= 1:
         return False
     mode = os.environ.get("OEA_REFRESH_MODE", "")
@@ -656,8 +657,8 @@ def refresh_is_sharded(n, k, world_size):
     if n < 12288:                 # below the symmetric stream path's range (csrc/topk.hip plan_stream): nothing to replicate cheaply
         return True
     scale = (n / 1.0e5) ** 2
-    sharded_ms = 46.0 * scale / world_size + 4.0 * n * k * (world_size - 1) / world_size / 300.0e6
-    return sharded_ms < 13.0 * scale
+    sharded_ms = 19.8 * scale / world_size + 4.0 * n * k * (world_size - 1) / world_size / 300.0e6
+    return sharded_ms < 11.6 * scale
 
 
 def refresh_neighbours(ent, entity_list, k):

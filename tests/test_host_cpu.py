@@ -426,12 +426,13 @@ def test_bench_line_is_compact_strict_json():
 
 def test_refresh_shards_only_where_it_pays(monkeypatch):
     """refresh_neighbours on several ranks (basic_model.py:267-289 runs on one device): a rank's row block against the whole table
-    cannot use the symmetric search, so sharding pays only from the world size on at which (general search / N + all-gather of the
-    [n, k] table) undercuts every rank running the symmetric search itself; both modes return the same sets."""
+    cannot use the symmetric search, so sharding pays only where (general search / N + all-gather of the [n, k] table) undercuts
+    every rank running the symmetric search itself; both modes return the same sets."""
     from openea_amd.models.trainer import refresh_is_sharded
     monkeypatch.delenv("OEA_REFRESH_MODE", raising=False)
     assert not refresh_is_sharded(100000, 2000, 1)
-    assert not refresh_is_sharded(100000, 2000, 2) and refresh_is_sharded(100000, 2000, 8)
+    assert refresh_is_sharded(100000, 2000, 2) and refresh_is_sharded(100000, 2000, 8)
+    assert not refresh_is_sharded(100000, 20000, 2)               # a table whose all-gather costs more than the search it saves
     assert refresh_is_sharded(9000, 100, 2)                       # below the symmetric path's range
     monkeypatch.setenv("OEA_REFRESH_MODE", "shard")
     assert refresh_is_sharded(100000, 2000, 2)

@@ -1155,6 +1155,45 @@ def test_topk_strip_free_path_bit_exact(ops, case, monkeypatch):
     assert np.array_equal(out[rows], ref * 3 + 1)
 
 
+@pytest.mark.parametrize("case", ["random", "clusters", "ties", "unnormalised", "d300_k10", "row_block"])
+def test_topk_general_path_on_the_bf16_split_bit_exact(ops, case):
+    """queries != candidates (batch.py:122-165 with a sub-list of entities; the bootstrapping candidates of alignment_finder.py:12-60;
+    a rank's row block of a sharded refresh) at nc >= 32,768, nq >= 4,096: the threshold-append sweep runs on the bf16 hi / lo split
+    of BOTH tables (round 6), the lists hold approximate values >= thr - tol, and the select decides the neighbourhood of the k-th
+    value with exact k-ordered chains of the query row against the candidate rows.  The sets must be the oracle's (value desc,
+    column asc), bit for bit: tight clusters (whole tiles survive), thousands of exact ties at the k-th value, rows of very
+    different norms (the bound is on the largest), d = 300 with k = 10."""
+    from oracle import cport
+    rng = np.random.RandomState(11)
+    nq, nc, d, k = (4300, 33000, 300, 10) if case == "d300_k10" else (4300, 33000, 40, 700)
+    c = rng.standard_normal((nc, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    if case == "clusters":
+        cen = rng.standard_normal((30, d)).astype(np.float32)
+        c = cen[np.arange(nc) * 30 // nc] + 0.05 * c
+        q = cen[np.arange(nq) * 30 // nq] + 0.05 * q
+    if case == "ties":
+        c[5000:8000] = c[5000]
+        q[100:200] = c[5000]
+    if case != "unnormalised":
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    else:
+        c *= rng.uniform(0.1, 6.0, (nc, 1)).astype(np.float32)
+        q *= rng.uniform(0.1, 6.0, (nq, 1)).astype(np.float32)
+    if case == "row_block":                      # a rank's block of the table itself (models/dist.py:sharded_neighbours): every row finds itself
+        q = c[5000:5000 + nq].copy()
+    tq, tc = ops.to_table(q), ops.to_table(c)
+    if case == "row_block":
+        tq = tc[5000:5000 + nq]
+    ids = ops.to_ids((np.arange(nc, dtype=np.int32) * 3 + 1))
+    out = ops.topk_inner(tq, tc, d, k, id_map=ids).cpu().numpy()
+    assert out.shape == (nq, k) and np.all(np.diff(out, axis=1) > 0)
+    rows = np.concatenate([rng.choice(nq, 40, replace=False), np.array([100, 150, 199, 200, 0, nq - 1])])
+    ref = cport.topk_inner(q[rows], c, k)
+    assert np.array_equal(out[rows], ref * 3 + 1)
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("case", ["random", "duplicates", "constant", "unnormalised", "alinet1200", "d500"])
 def test_csls_means_one_sweep_bit_exact(ops, case, bf16, monkeypatch):
