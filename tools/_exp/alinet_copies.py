@@ -1,5 +1,5 @@
-"""where do AliNet's device-to-device copies come from?  torch profiler with stacks over two epochs at the EN-DE-100K shape:
-the `Memcpy DtoD` events grouped by the python frame that issued them"""
+"""where do AliNet's __amd_rocclr_copyBuffer launches come from?  torch profiler over one epoch at the EN-DE-100K shape: every runtime
+memcpy call (hipMemcpy*), grouped by the chain of torch ops above it and the python frame that issued it"""
 import collections, contextlib, io, os, sys
 import torch
 from torch.profiler import profile, ProfilerActivity
@@ -15,20 +15,24 @@ m.set_args(get_args(name, scale="100K", output="/tmp/oea_prof/", training_data="
 m.set_kgs(kgs)
 with contextlib.redirect_stdout(io.StringIO()):
     m.init(); m.run(); torch.cuda.synchronize()
-    m.args.max_epoch = 2
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         m.run(); torch.cuda.synchronize()
-ops_ = collections.Counter(); shapes = collections.defaultdict(collections.Counter); stacks = collections.defaultdict(collections.Counter)
+groups, dev = collections.Counter(), collections.Counter()
 for e in prof.events():
-    if e.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::to"):
-        # does it have a DtoD memcpy child?
-        kids = [k for k in e.cpu_children] if hasattr(e, "cpu_children") else []
-        has = any("Memcpy" in (k.name or "") or "copy" in (k.name or "").lower() for k in kids) or e.name == "aten::copy_"
-        if e.name == "aten::copy_":
-            ops_[e.name] += 1
-            shapes[e.name][str(e.input_shapes)[:80]] += 1
-            st = [s for s in (e.stack or []) if "openea_amd" in s or "torch/autograd" in s or "optim" in s][:3]
-            stacks[e.name][" <- ".join(x.split("/")[-1][:70] for x in st)] += 1
-print("aten::copy_ calls in 2 epochs:", ops_["aten::copy_"])
-for s, c in shapes["aten::copy_"].most_common(12): print("  %4d  %s" % (c, s))
-for s, c in stacks["aten::copy_"].most_common(14): print("  %4d  %s" % (c, s))
+    nm = e.name or ""
+    if "emcpy" in nm and e.device_type.name == "CPU":
+        chain, p = [], e.cpu_parent
+        stack = None
+        while p is not None and len(chain) < 4:
+            chain.append(p.name)
+            if stack is None and p.stack:
+                st = [s for s in p.stack if "openea_amd" in s]
+                stack = st[0].split("/")[-1][:80] if st else None
+            p = p.cpu_parent
+        groups[(nm, " <- ".join(chain), stack)] += 1
+    if e.device_type.name != "CPU" and ("emcpy" in nm or "copyBuffer" in nm):
+        dev[nm] += 1
+print("device-side copy events:", dict(dev))
+print("runtime memcpy calls in one epoch: %d" % sum(groups.values()))
+for (nm, chain, stack), c in groups.most_common(25):
+    print("  %4d  %s | %s | %s" % (c, nm, chain, stack))
