@@ -119,11 +119,16 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
     int got = 0;
     for (int tr = 0; tr < max_try && got < k; ++tr) {
-        uint4 w = oea::philox4x32_10(c0, step, (uint32_t)tr, 0u, k0, k1);
+        // Philox block 0 of the round decides the side, block 1 + s is slot s's draw.  With a spare lane in the group (k < G) ONE call
+        // per lane serves both: the group's last lane computes block 0 and hands its first word round, the others their own block --
+        // the same numbers as two calls per lane at half the integer multiplies (the kernel's main VALU cost)
+        const bool spare = k < G;
+        uint4 w = oea::philox4x32_10(c0, step, (uint32_t)tr, (spare && lane != G - 1) ? 1u + (uint32_t)lane : 0u, k0, k1);
+        const uint32_t side_word = spare ? (uint32_t)__shfl((int)w.x, (int)((threadIdx.x & 63) / G * G) + G - 1, 64) : w.x;
         // replay (oea_sample_negatives_replay): the round's Bernoulli and its draws come from a RECORDED run of the reference
         // (random.sample positions, np.random.binomial) instead of Philox -- same rounds, same filter, same order of acceptance
         const int32_t *rp = replay ? replay + ((int64_t)p * max_try + tr) * (1 + k) : nullptr;
-        const bool corrupt_head = rp ? rp[0] != 0 : (w.x & 1u) != 0u;
+        const bool corrupt_head = rp ? rp[0] != 0 : (side_word & 1u) != 0u;
         const int32_t *cand = corrupt_head ? hc : tc;
         const int nc = corrupt_head ? hn : tn;
         const int need = k - got;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
         uint32_t att = 0;
         int32_t v = -1 - lane;                       // inactive lanes never match anything
         if (active) {
-            w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane, k0, k1);
+            if (!spare) w = oea::philox4x32_10(c0, step, (uint32_t)tr, 1u + (uint32_t)lane, k0, k1);
             v = rp ? rp[1 + lane] : (int32_t)__umulhi(w.x, (uint32_t)nc);
             if (rp && (v < 0 || v >= nc)) { *err_flag = 2; v = 0; }         // the record does not fit this positive's candidate list
         }

@@ -1350,6 +1350,177 @@ __global__ __launch_bounds__(256) void apply_step_plan(float *__restrict__ ent, 
     }
 }
 
+#ifndef OEA_DET_SCRATCH
+// ---- apply_step_plan with rows as float4 (round 6) ------------------------------------------------------------------------------------------
+// The same launch and the same four kinds of blocks; the entity rows (plan rows and flag-scan rows) travel as 16 B per lane: a lane
+// group of G lanes holds IT4 = ceil(ld / (4 G)) float4 per row (ld = 100, G = 16: two loads per row instead of seven dwords), a quarter
+// of the memory instructions and of the registers per row stream -- the kernel is ONE residency of latency-bound chains
+// (record -> rows -> stores), so what it issues per row is what it costs.  Relation rows and loss partials as in apply_step_plan.
+template <int IT4>
+struct Row4 {
+    float4 v[IT4];
+};
+template <int G, int IT4>
+__device__ __forceinline__ void load_row4(const float *__restrict__ base, int ld, int lane, Row4<IT4> &r) {
+#pragma unroll
+    for (int it = 0; it < IT4; ++it) {
+        const int c = (it * G + lane) * 4;                          // ld % 4 == 0: a float4 is inside the row or past it
+        r.v[it] = c < ld ? oea::ld4(base + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) { return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w)); }
+__device__ __forceinline__ float4 f4_add(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+__device__ __forceinline__ float f4_dot(float4 x, float4 y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+
+// apply_one_row on float4 fragments (fp32 scratch): back through the normalisation, Adagrad / SGD, optional clear of the scratch row
+template <int G, int IT4, bool CLEAR>
+__device__ __forceinline__ void apply_one_row4(float *__restrict__ v, float *__restrict__ acc, float *__restrict__ g, flag_t *__restrict__ touched_flag,
+                                               int ld, int lane, int on, const oea_step_cfg &cfg, const Row4<IT4> &rv, const Row4<IT4> &rg,
+                                               const Row4<IT4> &ra) {
+    float inv = 1.f, ydg = 0.f;
+    if (on) {
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT4; ++it) { ss += f4_dot(rv.v[it], rv.v[it]); dot += f4_dot(rv.v[it], rg.v[it]); }
+        ss = group_sum<G>(ss);
+        inv = rsqrtf(fmaxf(ss, 1e-12f));
+        dot = group_sum<G>(dot) * inv;
+        ydg = ss > 1e-12f ? dot : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < IT4; ++it) {
+        const int c = (it * G + lane) * 4;
+        if (c < ld) {
+            float4 gv = rg.v[it];
+            const float4 y = rv.v[it];
+            if (on)                                                  // (g - y (y . g)) / |v|, y = v / |v|: apply_one_row's expression
+                gv = make_float4((gv.x - y.x * inv * ydg) * inv, (gv.y - y.y * inv * ydg) * inv, (gv.z - y.z * inv * ydg) * inv,
+                                 (gv.w - y.w * inv * ydg) * inv);
+            float4 nv;
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) {
+                const float4 a = make_float4(ra.v[it].x + gv.x * gv.x, ra.v[it].y + gv.y * gv.y, ra.v[it].z + gv.z * gv.z,
+                                             ra.v[it].w + gv.w * gv.w);
+                oea::st4(acc + c, a);
+                nv = make_float4(rv.v[it].x - cfg.lr * gv.x / sqrtf(a.x), rv.v[it].y - cfg.lr * gv.y / sqrtf(a.y),
+                                 rv.v[it].z - cfg.lr * gv.z / sqrtf(a.z), rv.v[it].w - cfg.lr * gv.w / sqrtf(a.w));
+            } else {
+                nv = make_float4(y.x - cfg.lr * gv.x, y.y - cfg.lr * gv.y, y.z - cfg.lr * gv.z, y.w - cfg.lr * gv.w);
+            }
+            oea::st4(v + c, nv);
+            if (CLEAR) oea::st4(g + c, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    if (CLEAR && lane == 0) *touched_flag = 0;
+}
+
+template <int G, int IT>
+__global__ __launch_bounds__(256) void apply_step_plan_v4(float *__restrict__ ent, float *__restrict__ ent_acc, int64_t n_ent,
+                                                          float *__restrict__ rel, float *__restrict__ rel_acc, int64_t n_rel, int ld,
+                                                          oea_step_cfg cfg, StepWs ws, int n_partials, double *__restrict__ loss_accum,
+                                                          int copies_folded, int rel_blocks, int scan_blocks,
+                                                          const uint4 *__restrict__ recs, const uint32_t *__restrict__ vals,
+                                                          const int32_t *__restrict__ step_first, int s, const uint8_t *__restrict__ inplan,
+                                                          const float *__restrict__ contrib) {
+    constexpr int GPB = 256 / G, GPW = 64 / G, IT4 = (IT + 3) / 4;
+    const int lane = threadIdx.x % G;
+    const int b = (int)blockIdx.x, nb = (int)gridDim.x;
+    if (b < rel_blocks) {
+        for (int64_t row = (int64_t)b * GPB + threadIdx.x / G; row < n_rel; row += (int64_t)rel_blocks * GPB)
+            apply_relation_row<G, IT>(row, rel, rel_acc, ld, lane, cfg, ws, copies_folded);
+    } else if (b >= rel_blocks + scan_blocks && b < nb - 1) {
+        const int plan_blocks = nb - 1 - rel_blocks - scan_blocks;
+        const int64_t grp = (int64_t)(b - rel_blocks - scan_blocks) * GPB + threadIdx.x / G, ngrp = (int64_t)plan_blocks * GPB;
+        const int64_t i1 = step_first[s + 1];
+        for (int64_t i = step_first[s] + grp; i < i1; i += ngrp) {
+            const uint4 rec = recs[i];                                 // {row, first entry, entries, first entry's value}
+            if (rec.z > oea::kPlanHubEntries) continue;
+            const int64_t row = rec.x;
+            const uint32_t e0 = rec.y, e1 = rec.y + rec.z, v0 = rec.w;
+            const float flag = (float)ws.ent_touched[row];
+            Row4<IT4> rv, ra, rg, rc;
+            load_row4<G, IT4>(ent + row * ld, ld, lane, rv);
+            if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row4<G, IT4>(ent_acc + row * ld, ld, lane, ra);
+            load_row4<G, IT4>(contrib + (int64_t)(v0 & 0x7fffffffu) * ld, ld, lane, rc);
+            const float s0 = (v0 >> 31) ? -1.f : 1.f;
+#pragma unroll
+            for (int it = 0; it < IT4; ++it) rg.v[it] = make_float4(s0 * rc.v[it].x, s0 * rc.v[it].y, s0 * rc.v[it].z, s0 * rc.v[it].w);
+            for (uint32_t e = e0 + 1; e < e1; e += 3) {                // further references to the row, in batch order, three in flight
+                uint32_t ve[3];
+                Row4<IT4> r3[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) ve[u] = vals[min(e + u, e1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) load_row4<G, IT4>(contrib + (int64_t)(ve[u] & 0x7fffffffu) * ld, ld, lane, r3[u]);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (e + u < e1) {
+                        const float su = (ve[u] >> 31) ? -1.f : 1.f;
+#pragma unroll
+                        for (int it = 0; it < IT4; ++it) rg.v[it] = f4_axpy(su, r3[u].v[it], rg.v[it]);
+                    }
+            }
+            if (flag != 0.f) {                                         // + what the atomic scratch holds for this row
+                float *g = ws.ent_grad + row * ld;
+                Row4<IT4> rs;
+                load_row4<G, IT4>(g, ld, lane, rs);
+#pragma unroll
+                for (int it = 0; it < IT4; ++it) {
+                    rg.v[it] = f4_add(rg.v[it], rs.v[it]);
+                    const int c = (it * G + lane) * 4;
+                    if (c < ld) oea::st4(g + c, make_float4(0.f, 0.f, 0.f, 0.f));
+                }
+                if (lane == 0) ws.ent_touched[row] = 0;
+            }
+            apply_one_row4<G, IT4, false>(ent + row * ld, ent_acc + row * ld, nullptr, nullptr, ld, lane, cfg.ent_l2_norm, cfg, rv, rg, ra);
+        }
+    } else if (b < nb - 1) {
+        const int first = rel_blocks;
+        const int wl = threadIdx.x & 63, gw = wl / G;
+        const int64_t wave = (int64_t)(b - first) * 4 + (threadIdx.x >> 6), nwave = (int64_t)scan_blocks * 4;
+        const int64_t n_chunk = (n_ent + 63) / 64;
+        const uint8_t *mine = inplan + (int64_t)s * n_ent;
+        for (int64_t chunk = wave; chunk < n_chunk; chunk += nwave) {
+            const int64_t r = (int64_t)wl * n_chunk + chunk;
+            const bool todo = r < n_ent && (float)ws.ent_touched[r] != 0.f && mine[r] == 0;
+            unsigned long long mask = __ballot(todo);
+            while (mask) {
+                int64_t row = -1;
+#pragma unroll
+                for (int q = 0; q < GPW; ++q)
+                    if (mask) {
+                        const int bit = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        if (gw == q) row = (int64_t)bit * n_chunk + chunk;
+                    }
+                if (row >= 0) {
+                    Row4<IT4> rv, rg, ra;
+                    load_row4<G, IT4>(ent + row * ld, ld, lane, rv);
+                    load_row4<G, IT4>(ws.ent_grad + row * ld, ld, lane, rg);
+                    if (cfg.opt_kind == OEA_OPT_ADAGRAD) load_row4<G, IT4>(ent_acc + row * ld, ld, lane, ra);
+                    apply_one_row4<G, IT4, true>(ent + row * ld, ent_acc + row * ld, ws.ent_grad + row * ld, ws.ent_touched + row, ld, lane,
+                                                 cfg.ent_l2_norm, cfg, rv, rg, ra);
+                }
+            }
+        }
+    } else {
+        __shared__ double sp[256];
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = u * 256 + (int)threadIdx.x; v[u] = i < n_partials ? ws.partials[i] : 0.0; }
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+        sp[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) sp[threadIdx.x] += sp[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *loss_accum += sp[0];
+    }
+}
+#endif  // !OEA_DET_SCRATCH
+
 // ---- kernel 2b: optimisers whose update is DENSE (tf.train.AdamOptimizer / AdadeltaOptimizer, optimizers.py:13-16) -------
 // The tables are l2_normalize(variable): the gradient of a gather comes back through the normalisation as a dense
 // tensor, so TF's dense kernels run -- Adam moves every row every step (m and v decay where the gradient is zero),
@@ -1972,7 +2143,14 @@ int launch_step(float *ent, float *ent_acc, int64_t n_ent, float *rel, float *re
                     const int relb = (int)std::max<int64_t>(oea::ceil_div(n_rel, 16), 1);
                     const int planb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(bound, 16), 1), 8192);
                     const int scanb = (int)std::min<int64_t>(std::max<int64_t>(oea::ceil_div(n_ent, 256), 1), 4096);
+#ifndef OEA_DET_SCRATCH
+                    // rows as float4 (apply_step_plan_v4); OEA_APPLY_V4=0: dword fragments
+                    static const bool v4 = [] { const char *e = getenv("OEA_APPLY_V4"); return !(e && e[0] == '0'); }();
+#define OEA_APPLYP16(ITX) do { if (v4) oea::launch_events(apply_step_plan_v4<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, scanb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib); \
+    else oea::launch_events(apply_step_plan<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, scanb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib); } while (0)
+#else
 #define OEA_APPLYP16(ITX) oea::launch_events(apply_step_plan<16, ITX>, relb + planb + scanb + 1, block, st, ev0, ev1, ent, ent_acc, n_ent, rel, rel_acc, n_rel, ld, cfg, ws, n_part, loss_accum, folded, relb, scanb, plan->recs, plan->vals_b, plan->step_first, plan_step, plan->inplan, plan->contrib)
+#endif
                     if (it16 <= 2) OEA_APPLYP16(2);
                     else if (it16 <= 4) OEA_APPLYP16(4);
                     else if (it16 == 5) OEA_APPLYP16(5);
