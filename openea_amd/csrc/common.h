@@ -57,7 +57,10 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
                             uint8_t *ccounts, int32_t *spill_cnt, void *spill, int sp_cap, hipStream_t st);
 
 int topk_append_bf16_prepare(const float *q, int64_t nq, int ldq, const float *c, int64_t nc, int ldc, int dim, float *tol_dev,
-                             hipStream_t st, const float **qs, const float **cs, int *kp);
+                             hipStream_t st, const float **qs, const float **cs, int *kp, bool q_packed);
+int sample_strip_bf16_pack(const float *q, int64_t nq, int ldq, const float *c, int64_t n_sample, int ld_sample, int dim, hipStream_t st,
+                           const float **qs, const float **ss, int *kp);
+void sample_strip_bf16_launch(const float *qs, int64_t rows, const float *ss, int64_t n_sample, int kp, int dim, float *strip, hipStream_t st);
 void topk_append_bf16_launch(const float *qs, int64_t nq, const float *cs, int64_t nc, int kp, int dim, const float *thr, int cap,
                              int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill,
                              int sp_cap, const float *tol_dev, hipStream_t st);
@@ -68,7 +71,7 @@ int topk_append_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
 int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, void *row_streams,
                          int rcap, void *col_streams, int ccap, int32_t *row_cnt, int32_t *col_off, int lp1, uint8_t *row_fail,
                          float *tol_dev, void *ovf_pool, int32_t *ovf_alloc, int32_t *ovf_len, int ovf_chunks, int32_t *redo_cnt,
-                         void *redo, int redo_cap, hipStream_t st);
+                         void *redo, int redo_cap, hipStream_t st, bool packed);
 int comm_phase_mark(struct ::oea_comm *c, hipStream_t st);      // comm.hip: phase boundary of the one-call partitioned epoch
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -3469,9 +3469,10 @@ void topk_append_sym_packed(const float *ep, int64_t n, int kp, int dim, const f
 int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const float *thr, const void *items, int n_items, void *row_streams,
                          int rcap, void *col_streams, int ccap, int32_t *row_cnt, int32_t *col_off, int lp1, uint8_t *row_fail,
                          float *tol_dev, void *ovf_pool, int32_t *ovf_alloc, int32_t *ovf_len, int ovf_chunks, int32_t *redo_cnt,
-                         void *redo, int redo_cap, hipStream_t st) {
+                         void *redo, int redo_cap, hipStream_t st, bool packed) {
     PackedOp op;
-    const int rc = pack_operand_bf16(3, src, n, ld, dim, st, &op);
+    int64_t n_pad_unused = 0;
+    const int rc = packed ? reserve_operand(3, n, dim, st, &op, &n_pad_unused) : pack_operand_bf16(3, src, n, ld, dim, st, &op);   // packed: by sample_strip_bf16
     if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
     row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
@@ -3518,12 +3519,29 @@ void topk_append_packed(const float *qp, int64_t nq, const float *cp, int64_t nc
     topk_append_kernel<true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
         qp, nq, kp, cp, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, static_cast<uint2 *>(spill), sp_cap);
 }
+// the neighbour search's sample strip on the bf16 split (round 6; the CSLS means' strips since round 5): a threshold is an ESTIMATE of where
+// the k-th value lies -- the lists are cut below it by the bound and a row whose list comes out short or long takes the exact fallback
+// either way.  Packs the query rows (slot 3: the sweep that follows finds them there) and every stride-th candidate row (slot 2).
+int sample_strip_bf16_pack(const float *q, int64_t nq, int ldq, const float *c, int64_t n_sample, int ld_sample, int dim, hipStream_t st,
+                           const float **qs, const float **ss, int *kp) {
+    PackedOp pq, ps;
+    int rc = pack_operand_bf16(3, q, nq, ldq, dim, st, &pq);
+    if (rc == OEA_OK) rc = pack_operand_bf16(2, c, n_sample, ld_sample, dim, st, &ps);
+    if (rc != OEA_OK) return rc;
+    *qs = pq.p; *ss = ps.p; *kp = pq.kp;
+    return OEA_OK;
+}
+void sample_strip_bf16_launch(const float *qs, int64_t rows, const float *ss, int64_t n_sample, int kp, int dim, float *strip, hipStream_t st) {
+    sim_bf16_store_kernel<<<dim3((unsigned)ceil_div(n_sample, TILE), (unsigned)ceil_div(rows, TILE)), 256, 0, st>>>(qs, rows, kp, ss, n_sample, dim,
+                                                                                                                   strip, n_sample);
+}
 // the same on the bf16 hi / lo split of both tables (queries != candidates): _prepare packs them (slots 3 / 4) and leaves the bound on
 // |v~ - v| in tol_dev[0] (max row norms of the two tables in tol_dev[1], [2]); _launch sweeps a block of query rows
 int topk_append_bf16_prepare(const float *q, int64_t nq, int ldq, const float *c, int64_t nc, int ldc, int dim, float *tol_dev,
-                             hipStream_t st, const float **qs, const float **cs, int *kp) {
+                             hipStream_t st, const float **qs, const float **cs, int *kp, bool q_packed) {
     PackedOp pq, pc;
-    int rc = pack_operand_bf16(3, q, nq, ldq, dim, st, &pq);
+    int64_t n_pad_unused = 0;
+    int rc = q_packed ? reserve_operand(3, nq, dim, st, &pq, &n_pad_unused) : pack_operand_bf16(3, q, nq, ldq, dim, st, &pq);
     if (rc == OEA_OK) rc = pack_operand_bf16(4, c, nc, ldc, dim, st, &pc);
     if (rc != OEA_OK) return rc;
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 16, st));

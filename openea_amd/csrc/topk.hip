@@ -1807,11 +1807,22 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
         sym_items_kernel<<<(unsigned)oea::ceil_div((int64_t)sp.groups * sp.T, 256), 256, 0, st>>>(sp.T, sp.L, sp.groups,
                                                                                               reinterpret_cast<int4 *>(items_dev));
-        float *smp = nullptr;
-        int kps = 0;
-        int rc = oea::pack_rows(2, c, kSample, ldc * (int)sp.stride, dim, st, &smp, &kps);
-        if (rc != OEA_OK) return rc;
-        oea::sim_inner_store_packed(qp, nq, smp, kSample, kp, dim, sstrip, kSample, st);
+        // the sample strip on the bf16 split as well (OEA_TOPK_BF16_STRIP=0: fp32): thresholds are estimates, see sample_strip_bf16_pack
+        static const bool bf16_strip = [] { const char *e = getenv("OEA_TOPK_BF16_STRIP"); return !(e && e[0] == '0'); }();
+        int rc = OEA_OK;
+        if (bf16_strip) {
+            const float *qs = nullptr, *ss = nullptr;
+            int kps2 = 0;
+            rc = oea::sample_strip_bf16_pack(c, nc, ldc, c, kSample, ldc * (int)sp.stride, dim, st, &qs, &ss, &kps2);
+            if (rc != OEA_OK) return rc;
+            oea::sample_strip_bf16_launch(qs, nq, ss, kSample, kps2, dim, sstrip, st);
+        } else {
+            float *smp = nullptr;
+            int kps = 0;
+            rc = oea::pack_rows(2, c, kSample, ldc * (int)sp.stride, dim, st, &smp, &kps);
+            if (rc != OEA_OK) return rc;
+            oea::sim_inner_store_packed(qp, nq, smp, kSample, kp, dim, sstrip, kSample, st);
+        }
         kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(nq, 4), 256, 0, st>>>(sstrip, nq, kSample, sp.r, thr);
         int32_t *ovf_alloc = reinterpret_cast<int32_t *>(w + sp.off_nfail + 128);
         int32_t *ovf_len = reinterpret_cast<int32_t *>(w + sp.off_ovflen);
@@ -1819,7 +1830,7 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         OEA_CHECK_HIP(hipMemsetAsync(row_fail, 0, (size_t)nq, st));
         rc = oea::topk_stream_sym_bf16(c, nc, ldc, dim, thr, items_dev, sp.n_items, w + sp.off_rstream, sp.rcap, w + sp.off_cstream, sp.ccap,
                                        row_cnt, col_off, sp.L + 1, row_fail, tol_dev, w + sp.off_ovf, ovf_alloc, ovf_len, sp.ovf_chunks,
-                                       ovf_alloc + 1, w + sp.off_redo, sp.redo_cap, st);
+                                       ovf_alloc + 1, w + sp.off_redo, sp.redo_cap, st, bf16_strip);
         if (rc != OEA_OK) return rc;
         const size_t bucket_lds = sizeof(uint32_t) * (2 * (64 + 4 * (size_t)sp.T) + 2) + 8 * (size_t)kBucketFlight * kBucketThreads;
         static const hipError_t bucket_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_bucket_kernel),
@@ -1919,22 +1930,27 @@ int oea_topk_inner(const float *q, int64_t nq, int32_t ldq, const float *c, int6
         int32_t *spill_cnt = reinterpret_cast<int32_t *>(w + lp.off_spcnt);
         void *spill = w + lp.off_spill;
         OEA_REQUIRE(kp <= 4096, "dim <= 4096 on the list path");
+        // the sweep on the bf16 hi / lo split of both tables (3 / 16 of the fp32 matrix time; OEA_TOPK_BF16=0: the exact fp32 sweep):
+        // approximate list values, the select decides the neighbourhood of the k-th value with exact chains -- same sets; the sample
+        // strip of the thresholds on the split as well (estimates)
+        static const bool bf16_strip = [] { const char *e = getenv("OEA_TOPK_BF16_STRIP"); return !(e && e[0] == '0'); }();
+        const bool strip16 = bf16_sweep && bf16_strip;
+        float *tol_dev = reinterpret_cast<float *>(w + lp.off_nfail + 64);
+        const float *qs = nullptr, *cs = nullptr, *ss = nullptr;
+        int kps2 = 0, rc = OEA_OK;
         float *sp = nullptr;
         int kps = 0;
-        int rc = oea::pack_rows(2, c, kSample, ldc * (int)lp.stride, dim, st, &sp, &kps);   // every stride-th candidate row
+        if (strip16) rc = oea::sample_strip_bf16_pack(q, nq, ldq, c, kSample, ldc * (int)lp.stride, dim, st, &qs, &ss, &kps2);
+        else rc = oea::pack_rows(2, c, kSample, ldc * (int)lp.stride, dim, st, &sp, &kps);   // every stride-th candidate row
         if (rc != OEA_OK) return rc;
-        // the sweep on the bf16 hi / lo split of both tables (3 / 16 of the fp32 matrix time; OEA_TOPK_BF16=0: the exact fp32 sweep):
-        // approximate list values, the select decides the neighbourhood of the k-th value with exact chains -- same sets
-        float *tol_dev = reinterpret_cast<float *>(w + lp.off_nfail + 64);
-        const float *qs = nullptr, *cs = nullptr;
-        int kps2 = 0;
         if (bf16_sweep) {
-            rc = oea::topk_append_bf16_prepare(q, nq, ldq, c, nc, ldc, dim, tol_dev, st, &qs, &cs, &kps2);
+            rc = oea::topk_append_bf16_prepare(q, nq, ldq, c, nc, ldc, dim, tol_dev, st, &qs, &cs, &kps2, strip16);
             if (rc != OEA_OK) return rc;
         }
         for (int64_t r0 = 0; r0 < nq; r0 += lp.rows_per) {
             const int64_t rows = std::min<int64_t>(lp.rows_per, nq - r0);
-            oea::sim_inner_store_packed(qp + r0 * kp, rows, sp, kSample, kp, dim, sstrip, kSample, st);
+            if (strip16) oea::sample_strip_bf16_launch(qs + r0 * kps2, rows, ss, kSample, kps2, dim, sstrip, st);
+            else oea::sim_inner_store_packed(qp + r0 * kp, rows, sp, kSample, kp, dim, sstrip, kSample, st);
             kth_value_kernel<kSample / 64><<<(unsigned)oea::ceil_div(rows, 4), 256, 0, st>>>(sstrip, rows, kSample, lp.r, thr);
             OEA_CHECK_HIP(hipMemsetAsync(n_fail, 0, sizeof(int32_t), st));
             // the chunk count (hence the segment layout) is the one planned for a full pass: a short last pass reuses it
