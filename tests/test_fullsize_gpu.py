@@ -368,3 +368,34 @@ def test_neighbour_search_on_clustered_rows_spills_and_stays_exact(ops):
     assert np.array_equal(sym[rows], cport.topk_inner(emb[rows], emb, k))
     own = (sym // 600 == (np.arange(n) // 600)[:, None]).sum(1)           # the own cluster's ~600 rows lead every list
     assert own.min() >= 500
+
+
+def test_epoch_layout_100k_shape_is_a_permutation_of_each_list(ops):
+    """oea_epoch_layout at the EN-FR-100K shape (basic_model.py:234-235 shuffles both KGs' triple lists, batch.py:17-22 lays the
+    batches out: 40 batches of 20,000 over ~800,000 triples): every slot of the layout holds a distinct triple of the right list,
+    KG1's slice in front of KG2's in every batch, the layout equals the numpy restatement of the keyed permutation, and two epochs
+    share no more positions than chance allows."""
+    from openea_amd.modules.train.batch import EpochBatches
+    from oracle import np_oracle as orc
+    rng = np.random.RandomState(5)
+    n1, n2 = 410000, 390000
+    t1 = np.stack([rng.randint(0, 100000, n1), rng.randint(0, 300, n1), np.arange(n1)], 1).astype(np.int32)          # unique by column 2
+    t2 = np.stack([rng.randint(100000, 200000, n2), rng.randint(0, 300, n2), np.arange(n1, n1 + n2)], 1).astype(np.int32)
+    b = EpochBatches(t1, t2, 20000)
+    gen = torch.Generator(device=ops.device())
+    gen.manual_seed(23)
+    slot = b.slot.cpu().numpy()
+    layouts = []
+    for e in range(2):
+        b.shuffle(gen)
+        d = b.dall.cpu().numpy()
+        layouts.append(d.copy())
+        ids = d[:, 2].astype(np.int64)
+        assert len(np.unique(ids)) == len(ids)                                               # nothing twice
+        assert np.array_equal((ids >= n1), (slot >= n1))                                     # every slot draws from its own list
+        assert np.array_equal(d, np.concatenate([t1, t2])[ids])                              # rows travel whole
+        for s in (0, len(b.splits) // 2, len(b.splits) - 1):
+            o0, o1, sp = int(b.offsets[s]), int(b.offsets[s + 1]), int(b.splits[s])
+            assert (ids[o0:o0 + sp] < n1).all() and (ids[o0 + sp:o1] >= n1).all()
+        assert np.array_equal(d, orc.epoch_layout(t1, t2, slot, 23, e + 1))
+    assert (layouts[0][:, 2] == layouts[1][:, 2]).mean() < 1e-3
