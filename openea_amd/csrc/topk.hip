@@ -832,7 +832,7 @@ constexpr int kBitWords = 8192;           // bitmap of selected columns in (dyna
 // registers; the exact k-th by (value desc, column asc) comes from a 2048-bucket histogram over [thr, row max] plus a
 // pairwise ranking inside the threshold bucket (as in the strip select); the selected columns are set in an LDS bitmap
 // and enumerated in ascending order -- no sort.
-__global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *__restrict__ list_vals, const int32_t *__restrict__ list_cols,
+__global__ __launch_bounds__(SEL_THREADS, 5) void list_select_kernel(const float *__restrict__ list_vals, const int32_t *__restrict__ list_cols,
                                                                    const int32_t *__restrict__ counts,
                                                                    const float *__restrict__ thr, int nseg, int cap, int64_t nc,
                                                                    int k, const int32_t *__restrict__ id_map, int32_t *__restrict__ out,
@@ -857,10 +857,13 @@ __global__ __launch_bounds__(SEL_THREADS) void list_select_kernel(const float *_
     // 4 (threshold bucket ranked), 5 (bitmap set); 0 = run to the end.  Results are garbage when it is set.
     // symmetric search (T > 0): T more segments per row, one per query tile, of (value, column) pairs (topk_append_sym_kernel)
     __shared__ int hist[kBins];
-    __shared__ uint32_t c_key[kCandCap];
-    __shared__ int c_col[kCandCap];
-    __shared__ int s_off[kMaxSegAll + 1];
-    extern __shared__ uint32_t bitmap[];      // ceil(nc / 32) words (dynamic: 12.5 KB at nc = 100,000 keeps 5 workgroups per CU)
+    // the segment offsets (lengths + scan, gather: phases 1-2) and the candidate tables (threshold bucket, band: phases 4-5) never live
+    // at the same time (barriers in between): one array -- 8 KB less static LDS = FIVE workgroups per CU instead of four at nc = 100,000
+    __shared__ uint32_t s_raw[(kMaxSegAll + 1 > 2 * kCandCap) ? kMaxSegAll + 1 : 2 * kCandCap];
+    uint32_t *c_key = s_raw;
+    int *c_col = reinterpret_cast<int *>(s_raw + kCandCap);
+    int *s_off = reinterpret_cast<int *>(s_raw);
+    extern __shared__ uint32_t bitmap[];      // ceil(nc / 32) words (dynamic: 12.5 KB at nc = 100,000)
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
     __shared__ int s_bad, s_bstar, s_need, s_ncand, s_tcol, s_nband;
