@@ -1120,14 +1120,15 @@ __global__ __launch_bounds__(256, 2) void rank_inner_kernel(
 // BF16 (round 6): q / c are the hi / lo split packed rows (ldq = ldc = Kp), the sweep runs on the bf16 matrix pipe and the lists hold
 // every pair with v~ >= thr - tol (tol = *tol_ptr bounds |v~ - v|): list_select_kernel decides the neighbourhood of the k-th value
 // with exact chains -- the same sets as the fp32 sweep
-template <bool PACKED, bool BF16 = false>
+// NCH > 0 (BF16 only): the query operand in registers (tile_pipeline_bf16_breg, Kp = 32 NCH)
+template <bool PACKED, bool BF16 = false, int NCH = 0>
 __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     const float *__restrict__ q, int64_t nq, int ldq, const float *__restrict__ c, int64_t nc, int ldc, int dim,
     const float *__restrict__ thr, int tiles_per_chunk, int cap, float *__restrict__ list_vals, int32_t *__restrict__ list_cols,
     int32_t *__restrict__ counts, int32_t *__restrict__ spill_cnt, uint2 *__restrict__ spill, int sp_cap,
     const float *__restrict__ tol_ptr = nullptr) {
-    __shared__ __attribute__((aligned(16))) float As[2 * TILE * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * TILE * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE * LDS_LD];          // one array: the register form uses it as 2 x 2 chunks of A
+    float *As = lds, *Bs = lds + 2 * TILE * LDS_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t q0 = (int64_t)blockIdx.x * TILE;
@@ -1183,7 +1184,8 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
-    if constexpr (BF16) tile_pipeline_bf16<false>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
+    if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (BF16) tile_pipeline_bf16<false>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -1457,7 +1459,8 @@ __device__ __forceinline__ void stream_tile_fast(const f32x16 (&acc)[2][2], cons
 }
 
 // NCH = Kp / 32 in {1..4}: the query tile's operand in registers (tile_pipeline_bf16_breg); 0: both operands through LDS
-template <int NCH>
+// FAST: every tile through stream_tile_fast (compile-time: the branching epilogue and its registers are not in the kernel)
+template <int NCH, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const float *__restrict__ e, int64_t n, int kp, int dim, const float *__restrict__ thr, const int4 *__restrict__ items,
     uint2 *__restrict__ row_streams, int rcap, uint2 *__restrict__ col_streams, int ccap, int32_t *__restrict__ row_cnt,
@@ -1522,7 +1525,14 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
                         if (qi[tn] >= n) acc[tm][tn][r] = -INFINITY;
         }
         const uint32_t r0 = rpos, p0 = cpos;
-        if (c0 + TILE <= n && fast_on) {
+        if (FAST || (c0 + TILE <= n && fast_on)) {
+            if (FAST && c0 + TILE > n) {                             // ragged last candidate tile: rows past n never pass a cut
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((int)c0 + jl0 + tm * 32 + (r & 3) + 8 * (r >> 2) >= (int)n) { acc[tm][0][r] = -INFINITY; acc[tm][1][r] = -INFINITY; }
+            }
             const uint32_t rj[2] = {rtag[0] + (uint32_t)((int)c0 + jl0), rtag[1] + (uint32_t)((int)c0 + jl0)};
             stream_tile_fast(acc, th, rj, cq, my_tc, lane, srd_r, srd_c, rpos, cpos);
         } else if (c0 + TILE <= n) stream_tile<true>(acc, (int)c0, jl0, (int)n, th, rtag, qidx, my_tc, lane, rs, rbytes, cs, cbytes, rpos, cpos);
@@ -3477,18 +3487,22 @@ int topk_stream_sym_bf16(const float *src, int64_t n, int ld, int dim, const flo
     OEA_CHECK_HIP(hipMemsetAsync(tol_dev, 0, 8, st));
     row_norm_max_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(src, n, ld, dim, reinterpret_cast<unsigned *>(tol_dev) + 1);
     knn_tol_kernel<<<1, 1, 0, st>>>(tol_dev, bf16_eps_rel(dim, false));
-    // (the B-in-registers pipeline, NCH = Kp / 32, spills in this kernel -- its epilogue already takes the register file: 13.3 -> 20.8 ms
-    //  at 100,000 rows; it stays on the LDS pipeline.  OEA_TOPK_STREAM_NCH = 1..4 selects the register form for experiments.)
-    static const int nch_env = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return e ? atoi(e) : 0; }();
+    static const int nch_env = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return e ? atoi(e) : 1; }();
     // OEA_TOPK_STREAM_FAST=0: the branching epilogue (stream_tile) on every tile -- the ablation of stream_tile_fast
     static const int fast_env = [] { const char *e = getenv("OEA_TOPK_STREAM_FAST"); return (e && e[0] == '0') ? 0 : 1; }();
-#define OEA_STREAM_LAUNCH(N)                                                                                                          \
-    topk_stream_sym_kernel<N><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),            \
+#define OEA_STREAM_LAUNCH(N, F)                                                                                                       \
+    topk_stream_sym_kernel<N, F><<<(unsigned)n_items, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items),         \
                                                                  static_cast<uint2 *>(row_streams), rcap, static_cast<uint2 *>(col_streams), \
                                                                  ccap, row_cnt, col_off, lp1, row_fail, tol_dev, redo_cnt,              \
                                                                  static_cast<int4 *>(redo), redo_cap, fast_env)
-    if (nch_env == 4 && op.kp == 128) OEA_STREAM_LAUNCH(4);
-    else OEA_STREAM_LAUNCH(0);
+    // the query operand in registers (tile_pipeline_bf16_breg: the candidate stages alone travel through LDS, nothing is re-sent per chunk)
+    // for 64 < dim <= 128 when the branch-free epilogue is compiled in alone: with the branching one the kernel spilled (13.3 -> 20.8 ms),
+    // without it it fits (20 B of scratch) -- 11.3 -> 10.5 ms at 100,000^2 x 100.  OEA_TOPK_STREAM_NCH=0: both operands through LDS
+    const bool breg = nch_env != 0 && fast_env;
+    if (breg && op.kp == 128) OEA_STREAM_LAUNCH(4, true);
+    else if (breg && op.kp == 96) OEA_STREAM_LAUNCH(3, true);
+    else if (fast_env) OEA_STREAM_LAUNCH(0, true);
+    else OEA_STREAM_LAUNCH(0, false);
 #undef OEA_STREAM_LAUNCH
     topk_stream_redo_kernel<<<2048, 256, 0, st>>>(op.p, n, op.kp, dim, thr, static_cast<const int4 *>(items), rcap, ccap, row_fail, tol_dev,
                                                   redo_cnt, static_cast<const int4 *>(redo), redo_cap, static_cast<uint4 *>(ovf_pool), ovf_alloc,
@@ -3555,8 +3569,15 @@ void topk_append_bf16_launch(const float *qs, int64_t nq, const float *cs, int64
                              int chunks, float *list_vals, int32_t *list_cols, int32_t *counts, int32_t *spill_cnt, void *spill,
                              int sp_cap, const float *tol_dev, hipStream_t st) {
     const int tpc = (int)ceil_div(ceil_div(nc, TILE), chunks);
-    topk_append_kernel<true, true><<<dim3((unsigned)ceil_div(nq, TILE), (unsigned)chunks), 256, 0, st>>>(
-        qs, nq, kp, cs, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, static_cast<uint2 *>(spill), sp_cap, tol_dev);
+    static const bool breg = [] { const char *e = getenv("OEA_TOPK_STREAM_NCH"); return !(e && e[0] == '0'); }();
+    const dim3 grid((unsigned)ceil_div(nq, TILE), (unsigned)chunks);
+#define OEA_APPEND_LAUNCH(N)                                                                                                             \
+    topk_append_kernel<true, true, N><<<grid, 256, 0, st>>>(qs, nq, kp, cs, nc, kp, dim, thr, tpc, cap, list_vals, list_cols, counts, spill_cnt, \
+                                                            static_cast<uint2 *>(spill), sp_cap, tol_dev)
+    if (breg && kp == 128) OEA_APPEND_LAUNCH(4);
+    else if (breg && kp == 96) OEA_APPEND_LAUNCH(3);
+    else OEA_APPEND_LAUNCH(0);
+#undef OEA_APPEND_LAUNCH
 }
 }  // namespace oea
 

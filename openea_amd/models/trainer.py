@@ -644,10 +644,10 @@ def _entity_ids_on_device(entity_list, device):
 
 def refresh_is_sharded(n, k, world_size):
     """Does a refresh of n entities' k nearest neighbours on world_size ranks shard its query rows?  A rank's row block against the
-    whole table is a queries != candidates search (the general list path on the bf16 split: 9.9 ms per 50,000 x 100,000 rows,
-    tools/r06/m.sh), followed by the all-gather of the [n, k] int32 table (priced at 300 GB/s of all-link xGMI).  The symmetric
-    search of the whole table (upper triangle only, 11.6 ms at 100,000^2) run by EVERY rank needs no exchange and returns the same
-    sets on all of them.  Sharding pays from two ranks on at the 100K shape (9.9 + 1.3 against 11.6 ms), not below the symmetric
+    whole table is a queries != candidates search (the general list path on the bf16 split: 8.0 ms per 50,000 x 100,000 rows,
+    tools/r06/u.sh), followed by the all-gather of the [n, k] int32 table (priced at 300 GB/s of all-link xGMI).  The symmetric
+    search of the whole table (upper triangle only, 10.3 ms at 100,000^2) run by EVERY rank needs no exchange and returns the same
+    sets on all of them.  Sharding pays from two ranks on at the 100K shape (8.0 + 1.3 against 10.3 ms), not below the symmetric
     stream path's range.  OEA_REFRESH_MODE = shard | replicate overrides."""
     if world_size <= 1:
         return False
@@ -657,8 +657,8 @@ def refresh_is_sharded(n, k, world_size):
     if n < 12288:                 # below the symmetric stream path's range (csrc/topk.hip plan_stream): nothing to replicate cheaply
         return True
     scale = (n / 1.0e5) ** 2
-    sharded_ms = 19.8 * scale / world_size + 4.0 * n * k * (world_size - 1) / world_size / 300.0e6
-    return sharded_ms < 11.6 * scale
+    sharded_ms = 16.0 * scale / world_size + 4.0 * n * k * (world_size - 1) / world_size / 300.0e6
+    return sharded_ms < 10.3 * scale
 
 
 def refresh_neighbours(ent, entity_list, k):
