@@ -1506,13 +1506,22 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     const __amdgpu_buffer_rsrc_t srd_c = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(cs), 0, (int)cbytes, 0x00020000);
     const uint32_t cq[2] = {((uint32_t)jl0 << 24) | qidx[0], ((uint32_t)jl0 << 24) | qidx[1]};
     const bool fast_on = fast != 0;
+    float thr_pre = INFINITY;                                        // thr of this lane's candidate row in the tile about to be finished
+    {
+        const int64_t j0 = (int64_t)item.y * TILE + my_jl;
+        if (item.y < item.z && j0 < n) thr_pre = thr[j0];
+    }
     auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
         const int ct = item.y + (int)t;
         const int64_t c0 = (int64_t)ct * TILE;
         const bool offdiag = ct != qt;                               // workgroup-uniform
         const int64_t my_j = c0 + my_jl;
         // the candidate-side cut is +inf where nothing may be recorded: on the diagonal and past the last candidate row
-        const float my_tc = (offdiag && my_j < n) ? thr[my_j] - tol : INFINITY;
+        const float my_tc = (offdiag && my_j < n) ? thr_pre - tol : INFINITY;
+        {                                                            // the next tile's threshold, one tile ahead (an exposed L2 round trip
+            const int64_t nj = c0 + TILE + my_jl;                    // per tile and wave when asked for here)
+            thr_pre = (ct + 1 < item.z && nj < n) ? thr[nj] : INFINITY;
+        }
         if (lane == 0) coff[t] = (int32_t)(cpos >> 3);
         if (!q_all) {                                                // ragged last query tile: the (zero) rows past n must not reach
                                                                      // the candidate lists: their accumulators become -inf
@@ -3070,21 +3079,34 @@ __device__ __forceinline__ void rank_bf16_body(
         if (pred && at < slice_cap) my_rec[at] = make_uint2((uint32_t)qi[tn], (uint32_t)j | kind);
         nrec += (unsigned)__popcll(m);
     };
+    // what a tile's epilogue reads from memory -- the row's shared bound (other lanes / workgroups may have raised it) and, with CSLS,
+    // the column mean this lane looks after -- is requested ONE TILE AHEAD (round 6): asked for at the top of the epilogue it was an
+    // exposed L2 round trip per tile and wave.  A bound that is one tile old is still a lower bound (it only grows).
+    const int l32c = lane & 31;
+    const int my_off = wm * 64 + 4 * (lane >> 5) + (l32c >> 4) * 32 + (l32c & 3) + 8 * ((l32c & 15) >> 2);
+    unsigned lb_pre[2] = {0u, 0u};
+    float c_pre = 0.f;
+    auto prefetch = [&](int64_t t) {                         // for tile t of this work item
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+            if (qi[tn] < n1) lb_pre[tn] = __hip_atomic_load(lbrow + qi[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CSLS) {
+            const int64_t my_j = (ct_begin + t) * MT + my_off;
+            c_pre = (my_j < n2 && ct_begin + t < ct_end) ? csls_c[my_j] : 0.f;
+        }
+    };
+    prefetch(0);
     auto epilogue = [&](int64_t t, f32x16 (&acc)[2][2]) {
             const int64_t c0 = (ct_begin + t) * MT;
             const int jb = (int)c0 + wm * 64 + 4 * (lane >> 5);
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)                 // the other lanes / workgroups of the row may have raised the bound
+            for (int tn = 0; tn < 2; ++tn)
                 if (qi[tn] < n1) {
-                    const float o = ord2f(__hip_atomic_load(lbrow + qi[tn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const float o = ord2f(lb_pre[tn]);
                     if (o > lb[tn]) { lb[tn] = o; lbm[tn] = o - tol[tn]; }
                 }
-            float my_c = 0.f;
-            if (CSLS) {
-                const int l32 = lane & 31;
-                const int64_t my_j = (int64_t)jb + (l32 >> 4) * 32 + (l32 & 3) + 8 * ((l32 & 15) >> 2);
-                my_c = my_j < n2 ? csls_c[my_j] : 0.f;
-            }
+            const float my_c = CSLS ? c_pre : 0.f;
+            prefetch(t + 1);
             if (c0 + MT <= n2) rank_bf16_tile<WARM, true, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
             else rank_bf16_tile<WARM, false, CSLS>(acc, jb, (int)n2, glo, ghi, lb, lbm, cnt, dirty, qi, gold_off, tol, rq, my_c, record);
 #pragma unroll
