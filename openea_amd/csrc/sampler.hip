@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
         const unsigned long long acc_mask = (__ballot(accept) & gmask) >> gbase;
         if (accept) {
             const int slot = got + __popcll(acc_mask & ((1ull << lane) - 1ull));
-            int32_t *o = out + ((int64_t)p * k + slot) * 3;
-            o[0] = nh; o[1] = r; o[2] = nt;
+            struct __attribute__((packed, aligned(4))) Triple { int32_t h, r, t; };          // one 12-byte store per lane
+            *reinterpret_cast<Triple *>(out + ((int64_t)p * k + slot) * 3) = Triple{nh, r, nt};
         }
         got += __popcll(acc_mask);
     }
