@@ -307,7 +307,15 @@ typedef struct oea_sampler_side {
     const int32_t *nbr;      /* NULL: uniform sampling over entity_list */
     int32_t n_ent_list;
     int32_t nbr_k;
+    const uint32_t *filter;  /* NULL, or oea_tripleset_filter_build's bit array over the same triples (round 6) */
+    uint64_t filter_bits;
 } oea_sampler_side;
+/* A "certainly absent" pre-test for the membership probes of the sampler (batch.py:108-110: `set(neg_triples) - pos_triples`): one bit per
+ * hash bucket, oea_tripleset_filter_bits(capacity) = 8 x capacity bits (1 MB for the 400,000 triples of a 100K KG: resident in every XCD's
+ * L2, where the 8 MB key table is not).  A clear bit answers the probe; a set bit (all present triples, ~5 % of the absent ones) goes on to
+ * the key table: the sampler's output is unchanged. */
+uint64_t oea_tripleset_filter_bits(uint64_t capacity);
+int oea_tripleset_filter_build(const int32_t *triples, int64_t n, uint32_t *filter, uint64_t filter_bits, void *stream);
 int oea_sample_negatives_pair(const int32_t *pos, int64_t n_pos, int64_t n_split, int32_t k,
                               const oea_sampler_side *side0, const oea_sampler_side *side1, uint64_t seed,
                               uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,

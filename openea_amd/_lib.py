@@ -33,7 +33,8 @@ class StepCfg(C.Structure):
 class SamplerSide(C.Structure):
     """mirror of `oea_sampler_side` (include/openea_hip.h)."""
     _fields_ = [("table", C.c_void_p), ("capacity", C.c_uint64), ("entity_list", C.c_void_p),
-                ("ent_pos", C.c_void_p), ("nbr", C.c_void_p), ("n_ent_list", C.c_int32), ("nbr_k", C.c_int32)]
+                ("ent_pos", C.c_void_p), ("nbr", C.c_void_p), ("n_ent_list", C.c_int32), ("nbr_k", C.c_int32),
+                ("filter", C.c_void_p), ("filter_bits", C.c_uint64)]
 
 
 class CsrSplit(C.Structure):
@@ -126,6 +127,8 @@ PROTOTYPES = {
     "oea_sample_negatives": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _u64,
                                        _u32, _u32, _i32, _vp, _vp, _vp]),
     "oea_sample_negatives_replay": (C.c_int, [_vp, _i64, _i32, _vp, _u64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "oea_tripleset_filter_bits": (C.c_uint64, [_u64]),
+    "oea_tripleset_filter_build": (C.c_int, [_vp, _i64, _vp, _u64, _vp]),
     "oea_sample_negatives_pair": (C.c_int, [_vp, _i64, _i64, _i32, C.POINTER(SamplerSide), C.POINTER(SamplerSide),
                                             _u64, _u32, _u32, _i32, _vp, _vp, _vp]),
     "oea_sample_negatives_epoch": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, C.POINTER(SamplerSide),

@@ -40,8 +40,23 @@ __global__ void tripleset_insert(const int32_t *__restrict__ triples, int64_t n,
     }
 }
 
-__device__ __forceinline__ bool contains(const uint64_t *__restrict__ table, uint64_t capacity, uint32_t h, uint32_t r, uint32_t t) {
+__device__ __forceinline__ uint64_t filter_bit(uint64_t key, uint64_t bits) { return oea::mix64(key ^ 0x9E3779B97F4A7C15ull) & (bits - 1); }
+
+__global__ void tripleset_filter_insert(const int32_t *__restrict__ triples, int64_t n, uint32_t *__restrict__ filter, uint64_t bits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = filter_bit(oea::pack_triple((uint32_t)triples[3 * i], (uint32_t)triples[3 * i + 1], (uint32_t)triples[3 * i + 2]), bits);
+        atomicOr(&filter[b >> 5], 1u << (b & 31));
+    }
+}
+
+// filter (may be NULL): a clear bit = certainly absent, no probe of the key table (include/openea_hip.h)
+__device__ __forceinline__ bool contains(const uint64_t *__restrict__ table, uint64_t capacity, const uint32_t *__restrict__ filter,
+                                         uint64_t filter_bits, uint32_t h, uint32_t r, uint32_t t) {
     const uint64_t key = oea::pack_triple(h, r, t);
+    if (filter) {
+        const uint64_t b = filter_bit(key, filter_bits);
+        if (!((filter[b >> 5] >> (b & 31)) & 1u)) return false;
+    }
     uint64_t s = oea::mix64(key) & (capacity - 1);
     for (;;) {
         const uint64_t cur = table[s];
@@ -105,6 +120,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
     const int32_t *__restrict__ entity_list = sd.entity_list;
     const int32_t *__restrict__ ent_pos = sd.ent_pos;
     const int32_t *__restrict__ nbr = sd.nbr;
+    const uint32_t *__restrict__ filter = sd.filter;
+    const uint64_t filter_bits = sd.filter_bits;
     const int n_ent_list = sd.n_ent_list, nbr_k = sd.nbr_k;
     const int32_t h = pos[3 * p], r = pos[3 * p + 1], t = pos[3 * p + 2];
     // neighbor.get(e, entities_list): entities without a neighbour row (e.g. the other KG's
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(
             const int32_t e = cand[v];
             nh = corrupt_head ? e : h;
             nt = corrupt_head ? t : e;
-            accept = (tr == max_try - 1) || !contains(table, capacity, (uint32_t)nh, (uint32_t)r, (uint32_t)nt);
+            accept = (tr == max_try - 1) || !contains(table, capacity, filter, filter_bits, (uint32_t)nh, (uint32_t)r, (uint32_t)nt);
         }
         const unsigned long long acc_mask = (__ballot(accept) & gmask) >> gbase;
         if (accept) {
@@ -194,12 +211,24 @@ int oea_tripleset_build(const int32_t *triples, int64_t n, uint64_t *table, uint
     return OEA_OK;
 }
 
+uint64_t oea_tripleset_filter_bits(uint64_t capacity) { return 8ull * capacity; }
+
+int oea_tripleset_filter_build(const int32_t *triples, int64_t n, uint32_t *filter, uint64_t filter_bits, void *stream) {
+    OEA_REQUIRE(filter && (triples || n == 0), "null pointer");
+    OEA_REQUIRE(filter_bits >= 32 && (filter_bits & (filter_bits - 1)) == 0, "filter_bits: a power of two >= 32");
+    hipStream_t st = oea::as_stream(stream);
+    OEA_CHECK_HIP(hipMemsetAsync(filter, 0, (size_t)(filter_bits / 8), st));
+    if (n > 0) tripleset_filter_insert<<<(unsigned)std::min<int64_t>(oea::ceil_div(n, 256), 4096), 256, 0, st>>>(triples, n, filter, filter_bits);
+    OEA_CHECK_HIP(hipGetLastError());
+    return OEA_OK;
+}
+
 int oea_sample_negatives(const int32_t *pos, int64_t n_pos, int32_t k, const uint64_t *table,
                          uint64_t capacity, const int32_t *entity_list, int32_t n_ent_list,
                          const int32_t *ent_pos, const int32_t *nbr, int32_t nbr_k, uint64_t seed,
                          uint32_t step, uint32_t pos_offset, int32_t max_try, int32_t *out,
                          int32_t *err_flag, void *stream) {
-    oea_sampler_side sd;
+    oea_sampler_side sd{};
     sd.table = table; sd.capacity = capacity; sd.entity_list = entity_list; sd.ent_pos = ent_pos; sd.nbr = nbr;
     sd.n_ent_list = n_ent_list; sd.nbr_k = nbr_k;
     return oea_sample_negatives_pair(pos, n_pos, n_pos, k, &sd, &sd, seed, step, pos_offset, max_try, out, err_flag,
@@ -258,7 +287,7 @@ int oea_sample_negatives_replay(const int32_t *pos, int64_t n_pos, int32_t k, co
                                 const int32_t *entity_list, int32_t n_ent_list, const int32_t *ent_pos, const int32_t *nbr,
                                 int32_t nbr_k, int32_t max_try, const int32_t *replay, int32_t *out, int32_t *err_flag, void *stream) {
     OEA_REQUIRE(replay, "replay record");
-    oea_sampler_side sd;
+    oea_sampler_side sd{};
     sd.table = table; sd.capacity = capacity; sd.entity_list = entity_list; sd.ent_pos = ent_pos; sd.nbr = nbr;
     sd.n_ent_list = n_ent_list; sd.nbr_k = nbr_k;
     return sample_impl(pos, n_pos, n_pos, k, &sd, &sd, 0, 0u, 0u, max_try, out, err_flag, nullptr, nullptr, 0, stream, replay);

@@ -10,6 +10,8 @@ Two layers:
 There is no CPU implementation here: without libopenea_hip.so / a GPU every sampling or search
 call raises ``OpenEAHipError``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -68,7 +70,10 @@ class TripleSampler:
         ent_pos = np.full(n_total, -1, np.int32)
         ent_pos[np.asarray(entities_list, np.int64)] = np.arange(len(entities_list), dtype=np.int32)
         self.ent_pos = ops.to_ids(ent_pos, dev)
-        self.table = ops.tripleset_build(ops.to_ids(tri, dev))
+        tri_dev = ops.to_ids(tri, dev)
+        self.table = ops.tripleset_build(tri_dev)
+        # the "certainly absent" bit array in front of the key table (csrc/sampler.hip; OEA_SAMPLER_FILTER=0: probes only)
+        self.filter = ops.tripleset_filter(tri_dev, self.table.numel()) if os.environ.get("OEA_SAMPLER_FILTER", "1")[:1] != "0" else None
         self.nbr = None                       # int32 [N, k] entity ids; row = position in entity_list
         self.nbr_pos = None
         # the membership keys pack (head 24 bits | relation 16 bits | tail 24 bits): larger ids would alias silently
@@ -86,7 +91,7 @@ class TripleSampler:
     def side(self):
         """this KG's state packed for ops.sample_negatives_pair."""
         pos = self.nbr_pos if (self.nbr is not None and getattr(self, "nbr_pos", None) is not None) else self.ent_pos
-        return ops.sampler_side(self.table, self.entity_list, pos, self.nbr)
+        return ops.sampler_side(self.table, self.entity_list, pos, self.nbr, getattr(self, "filter", None))
 
     def sample(self, pos, k, seed, step, pos_offset=0, out=None, max_try=10):
         """pos: device int32 [n,3] -> device int32 [n*k, 3]."""

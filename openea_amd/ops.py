@@ -338,13 +338,23 @@ def sample_negatives_replay(pos, k, table, entity_list, replay, ent_pos=None, nb
     return out, err_flag
 
 
-def sampler_side(table, entity_list, ent_pos, nbr):
+def tripleset_filter(triples, capacity):
+    """the "certainly absent" bit array over the triples of a membership table of `capacity` slots (oea_tripleset_filter_build)
+    -> device int32 [capacity / 4] (8 x capacity bits)"""
+    bits = int(lib().oea_tripleset_filter_bits(int(capacity)))
+    filt = torch.empty(bits // 32, dtype=torch.int32, device=triples.device)
+    check(lib().oea_tripleset_filter_build(_p(triples), triples.shape[0], _p(filt), bits, _stream()))
+    return filt
+
+
+def sampler_side(table, entity_list, ent_pos, nbr, filt=None):
     """pack one KG's sampler state for sample_negatives_pair (keeps the tensors alive)."""
     side = _lib.SamplerSide(table.data_ptr(), table.numel(), entity_list.data_ptr(),
                             ent_pos.data_ptr() if ent_pos is not None else None,
                             nbr.data_ptr() if nbr is not None else None, entity_list.numel(),
-                            0 if nbr is None else nbr.shape[1])
-    side._keep = (table, entity_list, ent_pos, nbr)
+                            0 if nbr is None else nbr.shape[1],
+                            filt.data_ptr() if filt is not None else None, 0 if filt is None else 32 * filt.numel())
+    side._keep = (table, entity_list, ent_pos, nbr, filt)
     return side
 
 

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from openea_amd import _lib
     assert C.sizeof(_lib.StepCfg) == 88            # 12 x 4-byte fields + 2 pointers (8-byte aligned) + 2 x int32 + 3 floats + int32 of oea_step_cfg
-    assert C.sizeof(_lib.SamplerSide) == 48        # 5 pointers/u64 + 2 int32
+    assert C.sizeof(_lib.SamplerSide) == 64        # 5 pointers/u64 + 2 int32 + filter pointer + u64
     assert C.sizeof(_lib.RotateCfg) == 72          # 6 doubles + int64 + 4 x int32 of oea_rotate_cfg
     assert C.sizeof(_lib.CsrSplit) == 80           # 4 pointers + 3 int32 (+ pad) + 2 pointers + int64 + pointer of oea_csr_split
     assert C.sizeof(_lib.AttnGraph) == 30 * 8      # 13 pointers + 17 int64 of oea_attn_graph
