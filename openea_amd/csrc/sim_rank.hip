@@ -764,14 +764,17 @@ __device__ __forceinline__ void load_bregs(const float *__restrict__ bn, int kp,
 }
 
 // acc += the three split products of chunk c (two k-steps): A fragments from the staged chunk, B fragments from registers
+// one_step: only the chunk's first k-step (the second one is the zero padding of a row whose 16-k steps are odd in number: dim = 100 is
+// seven steps -- an eighth of the tile's MFMAs and fragment reads)
 template <int NCH>
-__device__ __forceinline__ void mma_chunk_breg(const float *__restrict__ As, const BRegs<NCH> &b, int c, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mma_chunk_breg(const float *__restrict__ As, const BRegs<NCH> &b, int c, f32x16 (&acc)[2][2], bool one_step = false) {
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     const int wm = wave >> 1;
     const int x = (lane >> 1) & 7, half = lane >> 5;
     const float *ap = As + (wm * 64 + (lane & 31)) * PLD;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1 && one_step) break;                               // wave-uniform
         const int g = 4 * s2 + 2 * half;
         const int oh = 4 * (g ^ x), ol = 4 * ((g + 1) ^ x);
         const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(ap + oh), a0l = *reinterpret_cast<const bf16x8 *>(ap + ol);
@@ -794,11 +797,12 @@ __device__ __forceinline__ void mma_chunk_breg(const float *__restrict__ As, con
 
 template <int NCH, class MTile, class Epilogue>
 __device__ __forceinline__ void tile_pipeline_bf16_breg(const float *__restrict__ am, int kp, const float *__restrict__ bn, int64_t n0,
-                                                        int64_t n_tiles, MTile m_tile, float *As, Epilogue epilogue) {
+                                                        int64_t n_tiles, MTile m_tile, float *As, Epilogue epilogue, int dim = 0) {
     constexpr int BUF = TILE * PLD;                                   // one chunk
     constexpr int NS = (NCH + 1) / 2;                                 // stages per tile: chunks [2 s, min(2 s + 2, NCH))
     const int64_t total = n_tiles * NS;
     if (total == 0) return;
+    const bool odd_steps = dim > 0 && (dim + 15) / 16 == 2 * NCH - 1; // the last chunk's second k-step is padding
     BRegs<NCH> b;
     load_bregs<NCH>(bn, kp, n0, b);
     auto stage = [&](int64_t t, int s, float *slot) {
@@ -822,8 +826,8 @@ __device__ __forceinline__ void tile_pipeline_bf16_breg(const float *__restrict_
 #pragma unroll
         for (int s = 0; s < NS; ++s)                                 // (compile-time chunk indices for the register file)
             if (s == sidx) {
-                mma_chunk_breg<NCH>(cur, b, 2 * s, acc);
-                if (2 * s + 1 < NCH) mma_chunk_breg<NCH>(cur + BUF, b, 2 * s + 1, acc);
+                mma_chunk_breg<NCH>(cur, b, 2 * s, acc, odd_steps && 2 * s == NCH - 1);
+                if (2 * s + 1 < NCH) mma_chunk_breg<NCH>(cur + BUF, b, 2 * s + 1, acc, odd_steps && 2 * s + 1 == NCH - 1);
             }
         if (++sidx == NS) {                                          // before the barrier: see tile_pipeline_bf16
             epilogue(t, acc);
@@ -1184,7 +1188,7 @@ __global__ __launch_bounds__(256, 2) void topk_append_kernel(
     };
     const int64_t n_tiles = ct_end > ct_begin ? ct_end - ct_begin : 0;
     auto m_tile = [=](int64_t t) { return (ct_begin + t) * TILE; };
-    if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
+    if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue, dim);
     else if constexpr (BF16) tile_pipeline_bf16<false>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
@@ -1566,7 +1570,7 @@ __global__ __launch_bounds__(256, 2) void topk_stream_sym_kernel(
     };
     const int64_t n_tiles = (int64_t)(item.z - item.y);
     auto m_tile = [=](int64_t t) { return (int64_t)(item.y + t) * TILE; };
-    if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(e, kp, e, q0, n_tiles, m_tile, As, epilogue);
+    if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(e, kp, e, q0, n_tiles, m_tile, As, epilogue, dim);
     else tile_pipeline_bf16<false>(e, kp, e, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     if (lane == 0) {
         coff[n_tiles] = (int32_t)(cpos >> 3);
@@ -2614,7 +2618,7 @@ __global__ __launch_bounds__(NW * 64, 2) void csls_append_kernel(
         tile_pipeline_bf16_spec(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
         if (wave >= NC) return;                                // a loader
     } else if constexpr (BF16 && NW == 8) tile_pipeline_bf16_big<MODE == 1>(c, ldc, q, dim, q0, n_tiles, m_tile, lds, epilogue);
-    else if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (BF16 && NCH > 0) tile_pipeline_bf16_breg<NCH>(c, ldc, q, q0, n_tiles, m_tile, As, epilogue, dim);
     else if constexpr (BF16) tile_pipeline_bf16<true>(c, ldc, q, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
     else run_tiles<PACKED>(c, nc, ldc, q, nq, ldq, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
@@ -3122,7 +3126,7 @@ __device__ __forceinline__ void rank_bf16_body(
             return;
         }
     } else if constexpr (NW == 8) tile_pipeline_bf16_big<MODE == 1>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, epilogue);
-    else if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue);
+    else if constexpr (NCH > 0) tile_pipeline_bf16_breg<NCH>(cp, kp, qp, q0, n_tiles, m_tile, As, epilogue, dim);
     else tile_pipeline_bf16<true>(cp, kp, qp, dim, q0, n_tiles, m_tile, As, Bs, epilogue);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
