@@ -522,7 +522,7 @@ __device__ __forceinline__ void wave_normalize(Row<64, IT> &r) {
 // epoch's plan tells the optimiser kernel which entity rows add which of them, with which sign, in which order); only the relation
 // row and the corrupted rows of active negatives still go through the atomic scratch.
 template <int IT, int L1, int KT, bool PLAN>
-__global__ __launch_bounds__(512) void triple_wave(
+__global__ __launch_bounds__(512, (IT <= 2 ? (KT == 10 ? 8 : 7) : 4)) void triple_wave(
     const float *__restrict__ ent, const float *__restrict__ rel, int ld, const int32_t *__restrict__ pos,
     int64_t n_pos, const int32_t *__restrict__ neg, int k, oea_step_cfg cfg, StepWs ws, int dbg, float *__restrict__ contrib,
     const uint32_t *__restrict__ pflags) {
